@@ -1,0 +1,352 @@
+"""ctypes bindings for the parity checkers.  TEST INFRASTRUCTURE -- not the product.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+
+* ``OracleScanner``  -- oracle/liboracle.so, the plain-C restatement (pire_oracle.c)
+* ``RefScanner``     -- oracle/_ref/libpire_ref.so, the UNMODIFIED reference library
+                        (present wherever `make -C oracle ref` ran; built in the dev
+                        container, shipped to the GPU box as a prebuilt .so)
+* ``corpus_*``       -- host mirror of the on-device synthetic corpus generator
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liboracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libpire_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+FLAG_BEGIN = 1
+FLAG_END = 2
+BEGIN_MARK = 258
+END_MARK = 259
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+i64p = C.POINTER(C.c_int64)
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (always) and oracle/_ref (only where the reference tree exists)."""
+    targets = ["oracle"]
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "pire", "run.h")):
+        targets += ["ref"]
+    cmd = ["make", "-C", HERE, "-j8"] + (["-B"] if force else []) + targets
+    subprocess.run(cmd, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def _ptr(a: Optional[np.ndarray], typ):
+    if a is None:
+        return None
+    return a.ctypes.data_as(typ)
+
+
+def _as_text(text) -> np.ndarray:
+    if isinstance(text, (bytes, bytearray)):
+        return np.frombuffer(bytes(text), dtype=np.uint8)
+    a = np.ascontiguousarray(text, dtype=np.uint8)
+    return a
+
+
+def pack_strings(strings: Sequence[bytes]):
+    """Concatenate byte strings -> (text u8[], offsets u64[n+1])."""
+    offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+    if strings:
+        offs[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64)
+    text = np.frombuffer(b"".join(strings), dtype=np.uint8) if strings else np.zeros(0, np.uint8)
+    return text, offs
+
+
+# --------------------------------------------------------------------------- oracle (C port)
+
+_oracle_lib = None
+
+
+def oracle_lib():
+    global _oracle_lib
+    if _oracle_lib is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        L = C.CDLL(ORACLE_SO)
+        L.oracle_scanner_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.oracle_scanner_load.restype = C.c_int
+        L.oracle_scanner_free.argtypes = [C.c_void_p]
+        for name in ("oracle_size", "oracle_letters_count", "oracle_regexps_count", "oracle_initial_index",
+                     "oracle_row_stride", "oracle_header_size"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint32
+        L.oracle_empty.argtypes = [C.c_void_p]
+        L.oracle_empty.restype = C.c_int
+        L.oracle_letter_class.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_letter_class.restype = C.c_uint32
+        L.oracle_next_index.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.oracle_next_index.restype = C.c_uint32
+        L.oracle_final.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_final.restype = C.c_int
+        L.oracle_dead.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_dead.restype = C.c_int
+        L.oracle_accepted_regexps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_size_t]
+        L.oracle_accepted_regexps.restype = C.c_size_t
+        L.oracle_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p, u8p, C.c_int]
+        L.oracle_run.restype = None
+        L.oracle_run_shortcut.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p, u8p]
+        L.oracle_run_shortcut.restype = None
+        L.oracle_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
+        L.oracle_prefix.restype = None
+        L.corpus_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
+                                  C.c_void_p, C.c_int]
+        L.corpus_fill.restype = None
+        _oracle_lib = L
+    return _oracle_lib
+
+
+class OracleScanner:
+    """The C restatement, loaded from a Scanner::Save() blob."""
+
+    def __init__(self, blob: bytes):
+        L = oracle_lib()
+        self._L = L
+        self.blob = bytes(blob)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        if L.oracle_scanner_load(self.blob, len(self.blob), C.byref(h), err, 256) != 0:
+            raise ValueError(err.value.decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.oracle_scanner_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.oracle_size(s._h))
+    letters = property(lambda s: s._L.oracle_letters_count(s._h))
+    regexps = property(lambda s: s._L.oracle_regexps_count(s._h))
+    initial = property(lambda s: s._L.oracle_initial_index(s._h))
+    empty = property(lambda s: bool(s._L.oracle_empty(s._h)))
+    row_stride = property(lambda s: s._L.oracle_row_stride(s._h))
+    header_size = property(lambda s: s._L.oracle_header_size(s._h))
+
+    def letter_class(self, ch: int) -> int:
+        return self._L.oracle_letter_class(self._h, ch)
+
+    def next(self, idx: int, ch: int) -> int:
+        return self._L.oracle_next_index(self._h, idx, ch)
+
+    def final(self, idx: int) -> bool:
+        return bool(self._L.oracle_final(self._h, idx))
+
+    def dead(self, idx: int) -> bool:
+        return bool(self._L.oracle_dead(self._h, idx))
+
+    def accepted(self, idx: int):
+        buf = (C.c_uint64 * 256)()
+        n = self._L.oracle_accepted_regexps(self._h, idx, buf, 256)
+        return [int(buf[i]) for i in range(min(n, 256))]
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None, threads=1, shortcut=False):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        tp = text.ctypes.data if text.size else None
+        if shortcut:
+            self._L.oracle_run_shortcut(self._h, tp, _ptr(offsets, u64p), n, flags, _ptr(init, u32p),
+                                        _ptr(idx, u32p), _ptr(fin, u8p))
+        else:
+            self._L.oracle_run(self._h, tp, _ptr(offsets, u64p), n, flags, _ptr(init, u32p),
+                               _ptr(idx, u32p), _ptr(fin, u8p), threads)
+        return idx, fin
+
+    def run_strings(self, strings: Sequence[bytes], **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+    def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.empty(n, dtype=np.int64)
+        self._L.oracle_prefix(self._h, int(longest), text.ctypes.data if text.size else None,
+                              _ptr(offsets, u64p), n, int(through_begin), int(through_end), _ptr(out, i64p))
+        return out
+
+
+# --------------------------------------------------------------------------- reference library
+
+_ref_lib = None
+
+
+def ref_available() -> bool:
+    return os.path.exists(REF_SO)
+
+
+def ref_lib():
+    global _ref_lib
+    if _ref_lib is None:
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO + " (run `make -C oracle ref` where /root/reference exists)")
+        L = C.CDLL(REF_SO)
+        L.pire_ref_last_error.restype = C.c_char_p
+        L.pire_ref_compile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_size_t]
+        L.pire_ref_compile.restype = C.c_void_p
+        L.pire_ref_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.pire_ref_load.restype = C.c_void_p
+        L.pire_ref_free.argtypes = [C.c_void_p]
+        L.pire_ref_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_save.restype = C.c_size_t
+        for name in ("pire_ref_size", "pire_ref_letters", "pire_ref_regexps", "pire_ref_bufsize"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_size_t
+        L.pire_ref_empty.argtypes = [C.c_void_p]
+        L.pire_ref_empty.restype = C.c_int
+        L.pire_ref_initial_index.argtypes = [C.c_void_p]
+        L.pire_ref_initial_index.restype = C.c_uint32
+        L.pire_ref_next.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pire_ref_next.restype = C.c_uint32
+        L.pire_ref_final.argtypes = [C.c_void_p, C.c_uint32]
+        L.pire_ref_final.restype = C.c_int
+        L.pire_ref_dead.argtypes = [C.c_void_p, C.c_uint32]
+        L.pire_ref_dead.restype = C.c_int
+        L.pire_ref_accepted.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_size_t]
+        L.pire_ref_accepted.restype = C.c_size_t
+        L.pire_ref_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p,
+                                   u8p, C.c_int]
+        L.pire_ref_run.restype = C.c_int
+        L.pire_ref_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
+        L.pire_ref_prefix.restype = C.c_int
+        _ref_lib = L
+    return _ref_lib
+
+
+class RefScanner:
+    """The real Pire::Scanner (+ NonrelocScanner twin) behind a C ABI."""
+
+    SCANNER = 0
+    NONRELOC = 1
+
+    def __init__(self, handle):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def compile(cls, patterns: Sequence[str], options: Optional[Sequence[str]] = None, glue_max: int = 0):
+        L = ref_lib()
+        n = len(patterns)
+        pats = (C.c_char_p * n)(*[p.encode("latin-1") if isinstance(p, str) else p for p in patterns])
+        opts = (C.c_char_p * n)(*[(o or "").encode() for o in (options or [""] * n)])
+        return cls(L.pire_ref_compile(pats, opts, n, glue_max))
+
+    @classmethod
+    def load(cls, blob: bytes):
+        L = ref_lib()
+        return cls(L.pire_ref_load(bytes(blob), len(blob)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_size(s._h))
+    letters = property(lambda s: s._L.pire_ref_letters(s._h))
+    regexps = property(lambda s: s._L.pire_ref_regexps(s._h))
+    bufsize = property(lambda s: s._L.pire_ref_bufsize(s._h))
+    initial = property(lambda s: s._L.pire_ref_initial_index(s._h))
+    empty = property(lambda s: bool(s._L.pire_ref_empty(s._h)))
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_save(self._h, buf, n)
+        return buf.raw
+
+    def next(self, idx: int, ch: int) -> int:
+        return self._L.pire_ref_next(self._h, idx, ch)
+
+    def final(self, idx: int) -> bool:
+        return bool(self._L.pire_ref_final(self._h, idx))
+
+    def dead(self, idx: int) -> bool:
+        return bool(self._L.pire_ref_dead(self._h, idx))
+
+    def accepted(self, idx: int):
+        buf = (C.c_uint64 * 256)()
+        n = self._L.pire_ref_accepted(self._h, idx, buf, 256)
+        return [int(buf[i]) for i in range(min(n, 256))]
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None, kind=0, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        rc = self._L.pire_ref_run(self._h, kind, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n,
+                                  flags, _ptr(init, u32p), _ptr(idx, u32p), _ptr(fin, u8p), threads)
+        if rc != 0:
+            raise RuntimeError(self._L.pire_ref_last_error().decode())
+        return idx, fin
+
+    def run_strings(self, strings: Sequence[bytes], **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+    def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.empty(n, dtype=np.int64)
+        rc = self._L.pire_ref_prefix(self._h, int(longest), text.ctypes.data if text.size else None,
+                                     _ptr(offsets, u64p), n, int(through_begin), int(through_end), _ptr(out, i64p))
+        if rc != 0:
+            raise RuntimeError(self._L.pire_ref_last_error().decode())
+        return out
+
+
+# --------------------------------------------------------------------------- corpus (host mirror)
+
+CORPUS_MAX_PLANTS = 16
+CORPUS_PLANT_BYTES = 64
+
+
+class CorpusPlants(C.Structure):
+    _fields_ = [
+        ("nplants", C.c_uint32),
+        ("len", C.c_uint32 * CORPUS_MAX_PLANTS),
+        ("at_tail", C.c_uint32 * CORPUS_MAX_PLANTS),
+        ("bytes", (C.c_uint8 * CORPUS_PLANT_BYTES) * CORPUS_MAX_PLANTS),
+    ]
+
+
+def make_plants(plants: Sequence[tuple]) -> CorpusPlants:
+    """plants: sequence of (witness_bytes, at_tail_bool)."""
+    p = CorpusPlants()
+    assert len(plants) <= CORPUS_MAX_PLANTS
+    p.nplants = len(plants)
+    for i, (w, tail) in enumerate(plants):
+        assert len(w) <= CORPUS_PLANT_BYTES
+        p.len[i] = len(w)
+        p.at_tail[i] = 1 if tail else 0
+        for k, b in enumerate(w):
+            p.bytes[i][k] = b
+    return p
+
+
+def corpus_fill(seed: int, first: int, count: int, length: int, plants: Optional[CorpusPlants] = None,
+                threads: int = 1) -> np.ndarray:
+    """Strings [first, first+count) of the synthetic corpus as a (count, length) u8 array."""
+    out = np.empty((count, length), dtype=np.uint8)
+    L = oracle_lib()
+    L.corpus_fill(seed, first, count, length, length, C.byref(plants) if plants is not None else None,
+                  out.ctypes.data, threads)
+    return out

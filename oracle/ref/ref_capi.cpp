@@ -1,0 +1,286 @@
+/*
+ * TEST INFRASTRUCTURE (oracle/_ref build only) -- not part of the product path.
+ *
+ * A plain C ABI over the UNMODIFIED reference library, compiled from the sources
+ * where they lie under /root/reference/pire (see oracle/Makefile).  It exists so
+ * that python tests, the golden-vector generator and bench.py's cpu_baseline leg
+ * can (a) compile patterns into Pire::Scanner tables exactly as the reference's
+ * own benchmark does, (b) obtain the public Scanner::Save() blob the GPU table is
+ * ingested from, and (c) run the reference's own
+ * Runner(sc).Begin().Run(ptr,len).End() on the same bytes the GPU scans.
+ *
+ * Nothing here is algorithm code of ours: every function is a thin call into the
+ * reference's public API (file:line cited per function).
+ */
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <pire/pire.h>
+#include <pire/stub/memstreams.h>
+
+namespace {
+
+using Pire::Scanner;
+using Pire::NonrelocScanner;
+
+struct RefScanner {
+	Scanner         reloc;
+	NonrelocScanner nonreloc;     // deep copy, multi.h:213-220
+	Pire::SlowScanner slow;       // only for kind == 2 handles
+	bool            hasSlow = false;
+};
+
+thread_local std::string g_err;
+
+void SetErr(const char* what) { g_err = what ? what : "unknown error"; }
+
+/* tests/common.h:40-69 (ParseRegexp): option letters i,u,n,a. */
+Pire::Fsm ParseOne(const char* pattern, const char* options)
+{
+	Pire::Lexer lexer;
+	Pire::TVector<Pire::wchar32> ucs4;
+	bool surround = true;
+	for (const char* o = options ? options : ""; *o; ++o) {
+		switch (*o) {
+		case 'i': lexer.AddFeature(Pire::Features::CaseInsensitive()); break;
+		case 'u': lexer.SetEncoding(Pire::Encodings::Utf8()); break;
+		case 'n': surround = false; break;
+		case 'a': lexer.AddFeature(Pire::Features::AndNotSupport()); break;
+		default: throw Pire::Error(std::string("Unknown option: ") + *o);
+		}
+	}
+	lexer.Encoding().FromLocal(pattern, pattern + strlen(pattern), std::back_inserter(ucs4));
+	lexer.Assign(ucs4.begin(), ucs4.end());
+	Pire::Fsm fsm = lexer.Parse();
+	if (surround)
+		fsm.Surround();           // fsm.cpp:1198-1203; bench.cpp:101-102,116-117
+	return fsm;
+}
+
+/* State <-> index using public API only (multi.h:161, 281-284, 99, 119, 347). */
+template<class Sc>
+struct Geometry {
+	size_t base;
+	size_t stride;
+	explicit Geometry(const Sc& sc)
+	{
+		typedef typename Sc::Transition Tr;
+		const size_t header = sizeof(typename Sc::ScannerRowHeader) / sizeof(Tr);
+		const size_t align = sizeof(Pire::Impl::MaxSizeWord) / sizeof(Tr);
+		const size_t row = (sc.LettersCount() + header + align - 1) / align * align;
+		stride = row * sizeof(Tr);
+		typename Sc::State init;
+		sc.Initialize(init);
+		base = init - sc.StateIndex(init) * stride;
+	}
+	size_t ToState(uint32_t idx) const { return base + size_t(idx) * stride; }
+};
+
+enum { FLAG_BEGIN = 1, FLAG_END = 2 };
+
+template<class Sc>
+void RunRange(const Sc& sc, const char* text, const uint64_t* offsets, uint64_t lo, uint64_t hi,
+              uint32_t flags, const uint32_t* initIdx, uint32_t* outIdx, uint8_t* outFinal)
+{
+	Geometry<Sc> geo(sc);
+	for (uint64_t i = lo; i < hi; ++i) {
+		typename Sc::State st;
+		if (initIdx)
+			st = geo.ToState(initIdx[i]);
+		else
+			sc.Initialize(st);
+		// run.h:365-392 (RunHelper) spelled out so that Begin/End are optional
+		if (flags & FLAG_BEGIN)
+			Pire::Step(sc, st, Pire::BeginMark);
+		Pire::Run(sc, st, text + offsets[i], text + offsets[i + 1]);
+		if (flags & FLAG_END)
+			Pire::Step(sc, st, Pire::EndMark);
+		if (outIdx)
+			outIdx[i] = static_cast<uint32_t>(sc.StateIndex(st));
+		if (outFinal)
+			outFinal[i] = sc.Final(st) ? 1 : 0;
+	}
+}
+
+template<class Sc>
+void RunThreads(const Sc& sc, const char* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                const uint32_t* initIdx, uint32_t* outIdx, uint8_t* outFinal, int threads)
+{
+	if (threads <= 1) {
+		RunRange(sc, text, offsets, 0, n, flags, initIdx, outIdx, outFinal);
+		return;
+	}
+	// The reference has no threading; this index-range sharding driver is ours.
+	std::vector<std::thread> pool;
+	for (int t = 0; t < threads; ++t) {
+		uint64_t lo = n * t / threads, hi = n * (t + 1) / threads;
+		pool.emplace_back([&, lo, hi] { RunRange(sc, text, offsets, lo, hi, flags, initIdx, outIdx, outFinal); });
+	}
+	for (auto& th : pool)
+		th.join();
+}
+
+} // namespace
+
+extern "C" {
+
+const char* pire_ref_last_error(void) { return g_err.c_str(); }
+
+/* Compile n patterns and glue them left to right -- tools/bench/bench.cpp:108-132. */
+void* pire_ref_compile(const char* const* patterns, const char* const* options, int n, size_t glueMaxSize)
+{
+	try {
+		std::unique_ptr<RefScanner> h(new RefScanner);
+		for (int i = 0; i < n; ++i) {
+			Pire::Fsm fsm = ParseOne(patterns[i], options ? options[i] : "");
+			Scanner one = fsm.Compile<Scanner>();            // fsm.h:273-277
+			if (i == 0) {
+				one.Swap(h->reloc);
+			} else {
+				h->reloc = Scanner::Glue(h->reloc, one, glueMaxSize);   // multi.h:1092-1103
+				if (h->reloc.Empty()) {
+					SetErr("Scanner gluing failed - pattern too complicated");
+					return nullptr;
+				}
+			}
+		}
+		h->nonreloc = NonrelocScanner(h->reloc);
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+/* Load a Scanner::Save() blob -- multi.h:575-599. */
+void* pire_ref_load(const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefScanner> h(new RefScanner);
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		h->reloc.Load(&in);
+		h->nonreloc = NonrelocScanner(h->reloc);
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_free(void* h) { delete static_cast<RefScanner*>(h); }
+
+/* Scanner::Save -- multi.h:620-624, 557-573.  Returns the blob size; copies if it fits. */
+size_t pire_ref_save(void* h, void* buf, size_t cap)
+{
+	std::ostringstream out;
+	static_cast<RefScanner*>(h)->reloc.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_size(void* h)          { return static_cast<RefScanner*>(h)->reloc.Size(); }          // multi.h:134
+size_t pire_ref_letters(void* h)       { return static_cast<RefScanner*>(h)->reloc.LettersCount(); }  // multi.h:140
+size_t pire_ref_regexps(void* h)       { return static_cast<RefScanner*>(h)->reloc.RegexpsCount(); }  // multi.h:139
+size_t pire_ref_bufsize(void* h)       { return static_cast<RefScanner*>(h)->reloc.BufSize(); }       // multi.h:297-305
+int    pire_ref_empty(void* h)         { return static_cast<RefScanner*>(h)->reloc.Empty() ? 1 : 0; } // multi.h:135
+
+uint32_t pire_ref_initial_index(void* h)
+{
+	const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+	Scanner::State st;
+	sc.Initialize(st);
+	return static_cast<uint32_t>(sc.StateIndex(st));
+}
+
+/* One Step() from a state index -- run.h:50-57, multi.h:189-192. */
+uint32_t pire_ref_next(void* h, uint32_t idx, uint32_t ch)
+{
+	const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+	Scanner::State st = Geometry<Scanner>(sc).ToState(idx);
+	Pire::Step(sc, st, static_cast<Pire::Char>(ch));
+	return static_cast<uint32_t>(sc.StateIndex(st));
+}
+
+int pire_ref_final(void* h, uint32_t idx)   // multi.h:143
+{
+	const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+	return sc.Final(Geometry<Scanner>(sc).ToState(idx)) ? 1 : 0;
+}
+
+int pire_ref_dead(void* h, uint32_t idx)    // multi.h:147
+{
+	const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+	return sc.Dead(Geometry<Scanner>(sc).ToState(idx)) ? 1 : 0;
+}
+
+/* AcceptedRegexps -- multi.h:149-158.  Returns the count; writes up to cap ids. */
+size_t pire_ref_accepted(void* h, uint32_t idx, uint64_t* out, size_t cap)
+{
+	const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+	auto range = sc.AcceptedRegexps(Geometry<Scanner>(sc).ToState(idx));
+	size_t n = 0;
+	for (const size_t* p = range.first; p != range.second; ++p, ++n)
+		if (out && n < cap)
+			out[n] = *p;
+	return n;
+}
+
+/*
+ * Runner(sc).Begin().Run(ptr,len).End() per string -- run.h:365-392, 271-275; call shape of
+ * tools/bench/bench.cpp:244.  kind: 0 = Pire::Scanner, 1 = Pire::NonrelocScanner.
+ * flags: bit0 = Begin(), bit1 = End().  threads > 1 shards strings by index (our driver).
+ */
+int pire_ref_run(void* h, int kind, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                 const uint32_t* initIdx, uint32_t* outIdx, uint8_t* outFinal, int threads)
+{
+	try {
+		RefScanner* r = static_cast<RefScanner*>(h);
+		const char* t = static_cast<const char*>(text);
+		if (kind == 0)
+			RunThreads(r->reloc, t, offsets, n, flags, initIdx, outIdx, outFinal, threads);
+		else if (kind == 1)
+			RunThreads(r->nonreloc, t, offsets, n, flags, initIdx, outIdx, outFinal, threads);
+		else {
+			SetErr("unknown scanner kind");
+			return -1;
+		}
+		return 0;
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return -1;
+	}
+}
+
+/*
+ * LongestPrefix / ShortestPrefix -- run.h:277-311.  Writes the prefix length, or -1 for "no prefix"
+ * (null return in the reference).
+ */
+int pire_ref_prefix(void* h, int longest, const void* text, const uint64_t* offsets, uint64_t n,
+                    int throughBegin, int throughEnd, int64_t* outLen)
+{
+	try {
+		const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+		const char* t = static_cast<const char*>(text);
+		for (uint64_t i = 0; i < n; ++i) {
+			const char* b = t + offsets[i];
+			const char* e = t + offsets[i + 1];
+			const char* p = longest ? Pire::LongestPrefix(sc, b, e, throughBegin != 0, throughEnd != 0)
+			                        : Pire::ShortestPrefix(sc, b, e, throughBegin != 0, throughEnd != 0);
+			outLen[i] = p ? static_cast<int64_t>(p - b) : -1;
+		}
+		return 0;
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return -1;
+	}
+}
+
+} // extern "C"
