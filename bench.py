@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- scanned GB/s of the MI355X scan path on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 8 regexps glued with
+Scanner::Glue ("set_a", patterns of the reference's own tools/bench/run-bench), 2^20 strings x 4 KiB per GPU,
+synthetic corpus generated on the device (oracle/corpus.h definition, planted witnesses), Begin().Run().End()
+per string.  One "step" = one pass of the hot path over the whole per-GPU batch + the match-count reduce.
+Inputs are resident in HBM when the timed region starts.  Multi-GPU: one process per GPU, the corpus is sharded
+by string index (rank r owns global strings [r*n, (r+1)*n)), no data-path collective; the only exchange is the
+all-reduce (RCCL) of the uint64[regexps+2] match counters per step.  Weak scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+SEED = 0x5EED5EED
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2-strings", type=int, default=20, help="strings per GPU = 2^this (headline: 20)")
+    ap.add_argument("--len", type=int, default=4096, help="bytes per string (headline: 4096)")
+    ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")
+    ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin):
+    """The reference's own Runner(sc).Begin().Run().End() (oracle/_ref, kind 'reference') -- or the C port
+    (kind 'port') if the prebuilt reference library is not on this box -- timed on this host's cores over the
+    first `sample` strings of rank 0's corpus; also the parity check of the GPU results on that sample."""
+    from oracle import binding as ob
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 256)
+    t0 = time.time()
+    host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=threads)
+    gen_s = time.time() - t0
+    text = host.reshape(-1)
+    offs = np.arange(sample + 1, dtype=np.uint64) * length
+    nbytes = sample * length
+    out = {"cores": threads, "host_cores": cores, "sample": f"first {sample} strings x {length} B of rank 0's corpus "
+           f"({nbytes / 2**20:.0f} MiB), Begin().Run().End() per string", "corpus_gen_s": round(gen_s, 3)}
+    runs = {}
+    if ob.ref_available():
+        try:
+            ref = ob.RefScanner.load(blob)
+            out["kind"] = "reference"
+            for label, kind, thr in (("scanner_1t", 0, 1), ("nonreloc_1t", 1, 1), ("scanner_all", 0, threads),
+                                     ("nonreloc_all", 1, threads)):
+                sub = sample if thr > 1 else max(sample // 16, 1)
+                t0 = time.time()
+                idx, fin = ref.run(text[:sub * length], offs[:sub + 1], kind=kind, threads=thr)
+                dt = time.time() - t0
+                runs[label] = {"GBps": round(sub * length / dt / 1e9, 4), "seconds": round(dt, 3), "threads": thr,
+                               "strings": sub}
+                if label == "scanner_all":
+                    cpu_idx, cpu_fin = idx, fin
+            out["value"] = runs["scanner_all"]["GBps"]
+            out["impl"] = "Pire::Scanner (unmodified reference, g++ -O2), std::thread sharding by string index is ours"
+        except Exception as e:   # prebuilt .so not loadable here: fall back to the port, say so
+            out["ref_error"] = str(e)
+            runs = {}
+    if not runs:
+        o = ob.OracleScanner(blob)
+        out["kind"] = "port"
+        for label, thr in (("port_1t", 1), ("port_all", threads)):
+            sub = sample if thr > 1 else max(sample // 16, 1)
+            t0 = time.time()
+            idx, fin = o.run(text[:sub * length], offs[:sub + 1], threads=thr)
+            dt = time.time() - t0
+            runs[label] = {"GBps": round(sub * length / dt / 1e9, 4), "seconds": round(dt, 3), "threads": thr,
+                           "strings": sub}
+            if label == "port_all":
+                cpu_idx, cpu_fin = idx, fin
+        out["value"] = runs["port_all"]["GBps"]
+        out["impl"] = "oracle/pire_oracle.c byte-wise port, pthread sharding"
+    out["unit"] = "GB/s"
+    out["runs"] = runs
+    out["parity_vs_gpu"] = bool((cpu_idx == gpu_idx[:sample]).all() and (cpu_fin == gpu_fin[:sample]).all())
+    out["distinct_end_states_in_sample"] = int(len(np.unique(cpu_idx)))
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import pire_amd
+    from pire_amd import binding as pb
+    from tests import helpers as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    big = [b for b in H.big_sets() if b["name"] == args.set][0]
+    blob = H.load_blob(big["blob"])
+    table = pire_amd.Table(blob)
+    table.upload()
+    plants = H.plants_for(big)
+    n = 1 << args.log2_strings
+    length = args.len
+    stream = torch.cuda.current_stream().cuda_stream
+
+    # rank r owns global strings [r*n, (r+1)*n): generated in place, never crosses PCIe or xGMI
+    text = torch.empty((n, length), dtype=torch.uint8, device=dev)
+    pire_amd.corpus_fill_device(text.data_ptr(), SEED, rank * n, n, length, length, plants, stream)
+    out_idx = torch.empty(n, dtype=torch.int32, device=dev)
+    out_fin = torch.empty(n, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(table.RegexpsCount + 2, dtype=torch.int64, device=dev)
+    flags = pb.FLAG_BEGIN | pb.FLAG_END
+
+    def step(ev=None):
+        counts.zero_()
+        if ev:
+            ev[0].record()
+        table.run_strided_device(text.data_ptr(), n, length, length, flags, out_idx.data_ptr(), out_fin.data_ptr(),
+                                 counts.data_ptr(), 0, stream)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)   # the path's only exchange: 80 B of match counters
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    kernel_name = pb.last_kernel()
+
+    total_counts = counts.cpu().numpy().astype(np.uint64)
+    gpu_idx = out_idx.cpu().numpy().astype(np.uint32)
+    gpu_fin = out_fin.cpu().numpy()
+
+    if rank == 0:
+        scanned = float(n) * length * args.steps * world
+        value = scanned / elapsed / 1e9
+        algo_bytes = n * (length + 5)                     # input read once + u32 state idx + u8 final per string
+        avg_ms = float(np.mean(kernel_ms))
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        info = table.refresh_info()
+        res = {
+            "metric": "scanned GB/s (whole node) + ns/byte, 8-regex glued Scanner, 4KiB strings",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "ns_per_byte": round(1.0 / value, 6),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C3: 8 regexps glued via Scanner::Glue ({args.set}), 2^{args.log2_strings} x {length} B "
+                            f"strings per GPU, Begin().Run().End() per string, match-count reduce",
+                "patterns": big["patterns"],
+                "table": {"states": info.states, "letters": info.letters, "regexps": info.regexps,
+                          "ref_buf_bytes": int(info.ref_buf_size), "lds_dense_rows": info.hot_states,
+                          "lds_table_bytes": info.lds_table_bytes},
+                "strings_per_gpu": n, "string_bytes": length, "corpus_seed": SEED,
+                "parallelism": f"shard-by-string x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": f"pirehip::ScanTiledKernel ({kernel_name})", "kernel_avg_ms": round(avg_ms, 4),
+                "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
+                "algorithmic_bytes_per_launch": algo_bytes,
+                "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
+            },
+            "match_counts": {"final": int(total_counts[0]), "strings": int(total_counts[1]),
+                             "per_regexp": [int(c) for c in total_counts[2:]]},
+        }
+        assert int(total_counts[1]) == n * world, "match-count reduce lost strings"
+        if not args.no_cpu:
+            sample = min(n, 1 << args.cpu_sample_log2)
+            res["cpu_baseline"] = cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin)
+        print(json.dumps(res))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

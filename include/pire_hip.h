@@ -1,0 +1,174 @@
+/*
+ * pire_hip.h -- C ABI of libpire_hip.so: the MI355X (gfx950) implementation of Pire's scan path.
+ *
+ * Scope: exactly one reference path --
+ *     Pire::Runner(scanner).Begin().Run(ptr, len).End()            (pire/run.h:365-392)
+ * i.e. the DFA walk  Step(BeginMark); Run(begin,end); Step(EndMark)  (run.h:50-57, 271-275) over a
+ * compiled Pire::Scanner / Pire::NonrelocScanner table (pire/scanners/multi.h:87-554), batched over
+ * N independent strings, one string per GPU lane.  Regex parsing, FSM construction, determinisation,
+ * minimisation and Scanner::Glue stay in the reference library on the host; the hand-off between the
+ * two is the reference's PUBLIC serialised form, Scanner::Save() (multi.h:557-573, 620-624).
+ *
+ * The reference has no FFI for this path: it is a header-only C++ template concept.  The binding a
+ * Pire maintainer would add is therefore a C++ shim over this C ABI (include/pire_hip/batch_runner.hpp,
+ * INTEGRATION.md).  All entry points take plain pointers and sizes; no C++ / torch types.
+ *
+ * Results are bit-exact with the reference: for every string, the StateIndex (multi.h:281-284) of the
+ * state the reference would end in, and its Final flag (multi.h:143).
+ *
+ * Error model (the reference throws Pire::Error, pire/stub/stl.h:213-217): every call returns
+ * PIRE_HIP_OK (0) or a negative code; pire_hip_last_error() returns the thread-local message.
+ * There is NO CPU fallback: without a usable HIP device every run call fails with PIRE_HIP_ENODEVICE.
+ */
+#ifndef PIRE_HIP_H
+#define PIRE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIRE_HIP_ABI_VERSION 1
+
+enum {
+	PIRE_HIP_OK        =  0,
+	PIRE_HIP_EINVAL    = -1,   /* bad argument                                                        */
+	PIRE_HIP_EFORMAT   = -2,   /* blob rejected: same checks as Header::Validate, common.h:65-77,     */
+	                           /* and Scanner::Load, multi.h:575-599                                  */
+	PIRE_HIP_ENODEVICE = -3,   /* no HIP device / HIP runtime error (message has the hipError string) */
+	PIRE_HIP_ENOMEM    = -4,
+	PIRE_HIP_EUNSUPPORTED = -5
+};
+
+/* run flags */
+enum {
+	PIRE_HIP_RUN_BEGIN     = 1u << 0,   /* Step(BeginMark) before the text  -- RunHelper::Begin(), run.h:375 */
+	PIRE_HIP_RUN_END       = 1u << 1,   /* Step(EndMark) after the text     -- RunHelper::End(),   run.h:376 */
+	PIRE_HIP_RUN_ON_DEVICE = 1u << 2,   /* text/offsets/init/out pointers are DEVICE pointers; the call only */
+	                                    /* enqueues work on `stream`. Without it they are HOST pointers and  */
+	                                    /* the call copies in, runs, copies out and synchronises.            */
+	PIRE_HIP_RUN_GENERIC   = 1u << 3    /* force the generic (offset-driven) kernel; testing/diagnostics     */
+};
+
+typedef struct pire_hip_table pire_hip_table;
+
+/* Geometry of an ingested scanner; mirrors the public getters of Pire::Scanner. */
+typedef struct pire_hip_table_info {
+	uint32_t abi_version;
+	uint32_t states;          /* Scanner::Size()          multi.h:134 */
+	uint32_t letters;         /* Scanner::LettersCount()  multi.h:140 */
+	uint32_t regexps;         /* Scanner::RegexpsCount()  multi.h:139 */
+	uint32_t initial;         /* StateIndex(Initialize()) multi.h:161, 281-284 */
+	uint32_t empty;           /* Scanner::Empty()         multi.h:135 */
+	uint32_t header_size;     /* HEADER_SIZE in transitions, multi.h:349 (18 for Scanner, 2 for ScannerNoMask) */
+	uint32_t row_stride;      /* RowSize()*sizeof(Transition) of the RELOCATABLE form, multi.h:347 */
+	uint32_t hot_states;      /* states resident in LDS as dense 256-column rows (device layout) */
+	uint32_t lds_table_bytes; /* LDS bytes the table occupies per workgroup */
+	uint64_t device_bytes;    /* HBM bytes of the device-side table */
+	uint64_t ref_buf_size;    /* Scanner::BufSize()       multi.h:297-305 */
+} pire_hip_table_info;
+
+/* ---- table life cycle -------------------------------------------------------------------------- */
+
+/*
+ * Ingest a scanner from the bytes written by Pire::Scanner::Save() / NonrelocScanner::Save()
+ * (multi.h:557-573; a Nonreloc scanner serialises as Relocatable, multi.h:604-608).  Replaces
+ * Scanner::Load (multi.h:575-599) / Scanner::Mmap (multi.h:244-279) for the GPU side.  Validates the
+ * header like Header::Validate.  The blob is copied; the handle is immutable and may be shared between
+ * host threads.  Works without a GPU (host-side parse only); the device image is uploaded on first run
+ * or by pire_hip_table_upload().
+ */
+int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** out);
+
+/* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
+int pire_hip_table_upload(pire_hip_table* t);
+
+void pire_hip_table_destroy(pire_hip_table* t);
+
+int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out);
+
+/* ---- per-state queries on the host (no GPU involved) ------------------------------------------- */
+
+/* Scanner::Final(state)  multi.h:143.   idx = StateIndex. Returns 0/1, or <0 on bad idx. */
+int pire_hip_table_final(const pire_hip_table* t, uint32_t state_idx);
+/* Scanner::Dead(state)   multi.h:147 */
+int pire_hip_table_dead(const pire_hip_table* t, uint32_t state_idx);
+/* Scanner::AcceptedRegexps(state) multi.h:149-158: (begin, count) describe an array owned by the table. */
+int pire_hip_table_accepted_regexps(const pire_hip_table* t, uint32_t state_idx,
+                                    const uint64_t** begin, size_t* count);
+/* The letter class of ch (Translate(ch) - HEADER_SIZE, multi.h:163-166); ch < 264. */
+int pire_hip_table_letter_class(const pire_hip_table* t, uint32_t ch);
+/*
+ * Scanner::Next (multi.h:189-192) as a TABLE ACCESSOR on state indices: the index reached from state_idx on
+ * ch (ch < 260, ch != 257), or <0.  For inspecting an ingested table and for single Step()s on one host-side
+ * state (RunHelper::Step, run.h:371); it is not, and must not be used as, a scan loop -- Run() is GPU only.
+ */
+int64_t pire_hip_table_next(const pire_hip_table* t, uint32_t state_idx, uint32_t ch);
+/*
+ * Device-layout introspection (tests): orig_of_perm[states] = reference state index of
+ * each device ("perm") id; hot_rows[(hot_states+1)*256] = the dense LDS rows, entries are perm ids < hot_states
+ * or hot_states (= trap: the lane leaves the LDS-resident set).  Either pointer may be NULL.
+ */
+int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8_t* hot_rows);
+
+/* ---- the hot path -------------------------------------------------------------------------------- */
+
+/*
+ * For each i in [0,n):   st = Initialize() or state #init_state_idx[i]       (RunHelper ctors, run.h:368-369)
+ *                        if (flags & BEGIN) Step(st, BeginMark)
+ *                        Run(st, text + offsets[i], text + offsets[i+1])    (Pire::Run, run.h:271-275)
+ *                        if (flags & END)   Step(st, EndMark)
+ *                        out_state_idx[i] = StateIndex(st);  out_final[i] = Final(st)
+ * out_counts (nullable), uint64[regexps + 2], is ACCUMULATED into (caller zeroes it):
+ *     [0] += number of strings whose end state is Final,  [1] += n,
+ *     [2 + r] += number of strings whose end state lists regexp r in AcceptedRegexps().
+ * init_state_idx, out_state_idx, out_final may each be NULL.  n == 0, zero-length strings and the empty
+ * scanner are valid (tests/pire_ut.cpp:760-837).  Offsets are byte offsets into text, non-decreasing.
+ * `stream` is a hipStream_t (NULL = default stream).
+ */
+int pire_hip_run(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n,
+                 uint32_t flags, const uint32_t* init_state_idx,
+                 uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts, void* stream);
+
+/*
+ * Same walk over fixed-length records: string i = text[i*stride, i*stride + len).  This is the layout the
+ * tiled LDS-resident kernel is specialised for (len a multiple of 16, stride a multiple of 16, text
+ * 16-byte aligned, device pointers); anything else is routed to the generic kernel with the same results.
+ */
+int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
+                         uint32_t flags, const uint32_t* init_state_idx,
+                         uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts, void* stream);
+
+/*
+ * Pire::Step (run.h:50-57) on a device-resident array of state indices: state_idx[i] = Next(state_idx[i], ch),
+ * ch < 260 (bytes, BeginMark 258, EndMark 259).  Device pointers only.
+ */
+int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream);
+
+/* Name of the kernel the last run on this thread dispatched to ("tiled", "generic"); diagnostics. */
+const char* pire_hip_last_kernel(void);
+
+/* Milliseconds the most recent kernel launched by this thread took, measured with hipEvents on the
+ * launch stream when timing was enabled with pire_hip_set_timing(1).  Synchronises the stream. */
+int   pire_hip_set_timing(int enabled);
+float pire_hip_last_kernel_ms(void);
+
+/* ---- errors ---------------------------------------------------------------------------------------- */
+const char* pire_hip_last_error(void);
+int pire_hip_device_count(void);
+
+/* ---- benchmark utility (not part of the reference surface) ------------------------------------------ */
+/*
+ * Fill device memory with the synthetic corpus of SURVEY.md section 8d: string s occupies
+ * out[(s-first)*stride, +len).  `plants` is a host pointer to a corpus_plants struct (oracle/corpus.h layout)
+ * or NULL.  Bit-identical with oracle/corpus.c for the same (seed, s).
+ */
+int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,
+                         uint64_t stride, const void* plants, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIRE_HIP_H */

@@ -1,0 +1,293 @@
+"""ctypes binding of libpire_hip.so (include/pire_hip.h).  No scan logic lives here."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(HERE, "libpire_hip.so")
+
+FLAG_BEGIN = 1
+FLAG_END = 2
+FLAG_ON_DEVICE = 4
+FLAG_GENERIC = 8
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class PireHipError(RuntimeError):
+    """Counterpart of Pire::Error (pire/stub/stl.h:213-217) for the C ABI's negative return codes."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"pire_hip error {code}: {msg}")
+        self.code = code
+
+
+class TableInfo(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32),
+        ("states", C.c_uint32),
+        ("letters", C.c_uint32),
+        ("regexps", C.c_uint32),
+        ("initial", C.c_uint32),
+        ("empty", C.c_uint32),
+        ("header_size", C.c_uint32),
+        ("row_stride", C.c_uint32),
+        ("hot_states", C.c_uint32),
+        ("lds_table_bytes", C.c_uint32),
+        ("device_bytes", C.c_uint64),
+        ("ref_buf_size", C.c_uint64),
+    ]
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def build(force: bool = False) -> str:
+    """Compile libpire_hip.so in-tree for gfx950 with hipcc (works without a GPU)."""
+    cmd = ["make", "-C", os.path.join(HERE, "csrc")] + (["-B"] if force else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libpire_hip.so failed:\n" + r.stdout)
+    return _LIB_PATH
+
+
+_lib = None
+
+# every symbol include/pire_hip.h declares: (name, restype, argtypes)
+ABI = [
+    ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_table_upload", C.c_int, [C.c_void_p]),
+    ("pire_hip_table_destroy", None, [C.c_void_p]),
+    ("pire_hip_table_get_info", C.c_int, [C.c_void_p, C.POINTER(TableInfo)]),
+    ("pire_hip_table_final", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("pire_hip_table_dead", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("pire_hip_table_accepted_regexps", C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(u64p), C.POINTER(C.c_size_t)]),
+    ("pire_hip_table_letter_class", C.c_int, [C.c_void_p, C.c_uint32]),
+    ("pire_hip_table_next", C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    ("pire_hip_table_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    ("pire_hip_last_kernel", C.c_char_p, []),
+    ("pire_hip_set_timing", C.c_int, [C.c_int]),
+    ("pire_hip_last_kernel_ms", C.c_float, []),
+    ("pire_hip_last_error", C.c_char_p, []),
+    ("pire_hip_device_count", C.c_int, []),
+    ("pire_hip_corpus_fill", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                       C.c_void_p, C.c_void_p]),
+]
+
+
+def lib():
+    """Load the native library.  Fails loudly if it has not been built: there is no Python/CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pire_amd/csrc` (hipcc, gfx950). pire_amd has no CPU fallback.")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; a process must hold exactly ONE HIP runtime or the second
+        # one finds no devices.  Let torch's copy load first so that our NEEDED libamdhip64.so.7 binds to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(_LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def device_count() -> int:
+    return lib().pire_hip_device_count()
+
+
+def _check(rc: int):
+    if rc < 0:
+        raise PireHipError(rc, lib().pire_hip_last_error().decode(errors="replace"))
+    return rc
+
+
+def _np_ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data
+
+
+class Table:
+    """An ingested Pire::Scanner (from Scanner::Save() bytes).  Mirrors the scanner's public getters."""
+
+    def __init__(self, blob: bytes):
+        L = lib()
+        h = C.c_void_p()
+        blob = bytes(blob)
+        _check(L.pire_hip_table_create(blob, len(blob), C.byref(h)))
+        self._h = h
+        info = TableInfo()
+        _check(L.pire_hip_table_get_info(h, C.byref(info)))
+        self.info = info
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pire_hip_table_destroy(h)
+            self._h = None
+
+    # --- Scanner getters (multi.h:134-161)
+    Size = property(lambda s: s.info.states)
+    LettersCount = property(lambda s: s.info.letters)
+    RegexpsCount = property(lambda s: s.info.regexps)
+    Empty = property(lambda s: bool(s.info.empty))
+    initial = property(lambda s: s.info.initial)
+
+    def refresh_info(self):
+        _check(lib().pire_hip_table_get_info(self._h, C.byref(self.info)))
+        return self.info
+
+    def Final(self, idx: int) -> bool:
+        return bool(_check(lib().pire_hip_table_final(self._h, idx)))
+
+    def Dead(self, idx: int) -> bool:
+        return bool(_check(lib().pire_hip_table_dead(self._h, idx)))
+
+    def AcceptedRegexps(self, idx: int):
+        b = u64p()
+        n = C.c_size_t()
+        _check(lib().pire_hip_table_accepted_regexps(self._h, idx, C.byref(b), C.byref(n)))
+        return [int(b[i]) for i in range(n.value)]
+
+    def letter_class(self, ch: int) -> int:
+        return _check(lib().pire_hip_table_letter_class(self._h, ch))
+
+    def Next(self, idx: int, ch: int) -> int:
+        """Table accessor (Scanner::Next on indices); not a scan loop."""
+        return _check(lib().pire_hip_table_next(self._h, idx, ch))
+
+    def layout(self):
+        """(orig_of_perm u32[states], hot_rows u8[hot+1, 256]) -- the device numbering and dense LDS rows."""
+        o = np.empty(self.info.states, dtype=np.uint32)
+        h = np.empty((self.info.hot_states + 1, 256), dtype=np.uint8)
+        _check(lib().pire_hip_table_layout(self._h, o.ctypes.data, h.ctypes.data))
+        return o, h
+
+    def upload(self):
+        _check(lib().pire_hip_table_upload(self._h))
+
+    # --- host-pointer runs (numpy in, numpy out): the PCIe-inclusive convenience mode
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None, counts=False):
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        cnt = np.zeros(self.RegexpsCount + 2, dtype=np.uint64) if counts else None
+        _check(lib().pire_hip_run(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                  flags & ~FLAG_ON_DEVICE, _np_ptr(init), idx.ctypes.data, fin.ctypes.data,
+                                  _np_ptr(cnt), None))
+        return (idx, fin, cnt) if counts else (idx, fin)
+
+    def run_strings(self, strings, **kw):
+        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+        if strings:
+            offs[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64)
+        text = np.frombuffer(b"".join(strings), dtype=np.uint8)
+        return self.run(text, offs, **kw)
+
+    def run_strided_host(self, text2d: np.ndarray, flags=FLAG_BEGIN | FLAG_END, init_idx=None, counts=False):
+        text2d = np.ascontiguousarray(text2d, dtype=np.uint8)
+        n, length = text2d.shape
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        cnt = np.zeros(self.RegexpsCount + 2, dtype=np.uint64) if counts else None
+        _check(lib().pire_hip_run_strided(self._h, text2d.ctypes.data if text2d.size else None, n, length, length,
+                                          flags & ~FLAG_ON_DEVICE, _np_ptr(init), idx.ctypes.data, fin.ctypes.data,
+                                          _np_ptr(cnt), None))
+        return (idx, fin, cnt) if counts else (idx, fin)
+
+    # --- device-pointer runs (raw addresses; torch tensors' data_ptr()): only enqueue on `stream`
+    def run_strided_device(self, text_ptr: int, n: int, length: int, stride: int, flags, out_idx_ptr=0,
+                           out_final_ptr=0, out_counts_ptr=0, init_ptr=0, stream: int = 0):
+        _check(lib().pire_hip_run_strided(self._h, text_ptr or None, n, length, stride, flags | FLAG_ON_DEVICE,
+                                          init_ptr or None, out_idx_ptr or None, out_final_ptr or None,
+                                          out_counts_ptr or None, stream or None))
+
+    def run_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_final_ptr=0,
+                   out_counts_ptr=0, init_ptr=0, stream: int = 0):
+        _check(lib().pire_hip_run(self._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
+                                  init_ptr or None, out_idx_ptr or None, out_final_ptr or None,
+                                  out_counts_ptr or None, stream or None))
+
+    def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
+        _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))
+
+
+class BatchRunner:
+    """Batched twin of Pire::Runner / RunHelper (run.h:365-392):  BatchRunner(t).Begin().Run(text, offs).End()."""
+
+    def __init__(self, table: Table, init_idx=None):
+        self.table = table
+        self._flags = 0
+        self._init = init_idx
+        self._text = None
+        self._offsets = None
+        self._result = None
+
+    def Begin(self):
+        self._flags |= FLAG_BEGIN
+        return self
+
+    def Run(self, text, offsets):
+        self._text, self._offsets = text, offsets
+        return self
+
+    def End(self):
+        self._flags |= FLAG_END
+        return self
+
+    def _go(self):
+        if self._result is None:
+            if self._text is None:
+                raise ValueError("Run() was not called")
+            self._result = self.table.run(self._text, self._offsets, flags=self._flags, init_idx=self._init)
+        return self._result
+
+    def State(self):
+        """StateIndex of every string's end state (run.h:378)."""
+        return self._go()[0]
+
+    def Final(self):
+        """operator bool of RunHelper, per string (run.h:380)."""
+        return self._go()[1].astype(bool)
+
+
+def last_kernel() -> str:
+    return lib().pire_hip_last_kernel().decode()
+
+
+def set_timing(enabled: bool):
+    lib().pire_hip_set_timing(1 if enabled else 0)
+
+
+def last_kernel_ms() -> float:
+    return float(lib().pire_hip_last_kernel_ms())
+
+
+def corpus_fill_device(out_ptr: int, seed: int, first: int, count: int, length: int, stride: int, plants=None,
+                       stream: int = 0):
+    """Generate the synthetic corpus in device memory (plants: oracle.binding.CorpusPlants or None)."""
+    p = C.byref(plants) if plants is not None else None
+    _check(lib().pire_hip_corpus_fill(out_ptr, seed, first, count, length, stride, p, stream or None))

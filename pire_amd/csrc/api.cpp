@@ -1,0 +1,438 @@
+// C ABI of libpire_hip.so (include/pire_hip.h).  Thin: argument checks, host<->device staging for the
+// host-pointer convenience mode, kernel selection.  There is deliberately no CPU implementation of the walk
+// here: without a HIP device the run entry points fail with PIRE_HIP_ENODEVICE.
+
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace pirehip {
+
+namespace {
+thread_local std::string g_error;
+thread_local const char* g_lastKernel = "none";
+thread_local bool g_timing = false;
+thread_local float g_lastMs = -1.0f;
+}  // namespace
+
+void SetError(const std::string& msg) { g_error = msg; }
+
+int HipFail(hipError_t e, const char* what)
+{
+	g_error = std::string(what) + ": " + hipGetErrorString(e);
+	(void)hipGetLastError();   // clear the sticky error
+	return e == hipErrorOutOfMemory ? PIRE_HIP_ENOMEM : PIRE_HIP_ENODEVICE;
+}
+
+namespace {
+
+// Owns temporary device buffers of the host-pointer mode.
+struct Staging {
+	std::vector<void*> ptrs;
+	~Staging()
+	{
+		for (void* p : ptrs)
+			(void)hipFree(p);
+	}
+	int Alloc(void** out, size_t bytes)
+	{
+		*out = nullptr;
+		hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMalloc(staging)");
+		ptrs.push_back(*out);
+		return PIRE_HIP_OK;
+	}
+	template <class T>
+	int In(const T* host, size_t count, const T** dev, hipStream_t s)
+	{
+		void* d;
+		if (int rc = Alloc(&d, count * sizeof(T)))
+			return rc;
+		if (count) {
+			hipError_t e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, s);
+			if (e != hipSuccess)
+				return HipFail(e, "hipMemcpy(H2D)");
+		}
+		*dev = static_cast<const T*>(d);
+		return PIRE_HIP_OK;
+	}
+};
+
+int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
+{
+	if (int rc = UploadTable(t))
+		return rc;
+	const HostTable& h = t->host;
+	const DeviceTable& d = t->dev;
+	memset(p, 0, sizeof(*p));
+	p->hotRows = d.hotRows;
+	p->hotFlags = d.hotFlags;
+	p->cls = d.cls;
+	p->nextPerm = d.nextPerm;
+	p->flagsPerm = d.flagsPerm;
+	p->origOfPerm = d.origOfPerm;
+	p->permOfOrig = d.permOfOrig;
+	p->acceptMaskPerm = d.acceptMaskPerm;
+	p->acceptOffPerm = d.acceptOffPerm;
+	p->acceptIds = d.acceptIds;
+	p->states = h.states;
+	p->letters = h.letters;
+	p->regexps = h.regexps;
+	p->hot = h.hot;
+	p->beginCls = h.cls[kBeginMark];
+	p->endCls = h.cls[kEndMark];
+	p->flags = flags;
+	uint32_t start = h.initial;                                     // Initialize(), multi.h:161
+	if (flags & PIRE_HIP_RUN_BEGIN)
+		start = h.next[size_t(start) * h.letters + h.cls[kBeginMark]];  // Begin(), run.h:375
+	p->startPerm = h.permOfOrig[start];
+	return PIRE_HIP_OK;
+}
+
+int Dispatch(const ScanParams& p, hipStream_t stream)
+{
+	if (p.n == 0)
+		return PIRE_HIP_OK;
+	const bool tiled = !(p.flags & PIRE_HIP_RUN_GENERIC) && TiledEligible(p);
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	if (g_timing) {
+		if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)
+			return HipFail(hipGetLastError(), "hipEventCreate");
+		(void)hipEventRecord(ev0, stream);
+	}
+	g_lastKernel = tiled ? "tiled" : "generic";
+	int rc = tiled ? LaunchTiled(p, stream) : LaunchGeneric(p, stream);
+	if (g_timing) {
+		(void)hipEventRecord(ev1, stream);
+		if (rc == PIRE_HIP_OK) {
+			hipError_t e = hipEventSynchronize(ev1);
+			if (e != hipSuccess)
+				rc = HipFail(e, "hipEventSynchronize");
+			else
+				(void)hipEventElapsedTime(&g_lastMs, ev0, ev1);
+		}
+		(void)hipEventDestroy(ev0);
+		(void)hipEventDestroy(ev1);
+	}
+	return rc;
+}
+
+// Shared body of pire_hip_run / pire_hip_run_strided.
+int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint64_t len, uint64_t stride,
+            uint32_t flags, const uint32_t* init, uint32_t* outIdx, uint8_t* outFinal, uint64_t* outCounts,
+            void* streamPtr)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	ScanParams p;
+	if (int rc = FillParams(t, &p, flags))
+		return rc;
+	p.n = n;
+	p.len = len;
+	p.stride = stride;
+
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		p.initIdx = init;
+		p.outIdx = outIdx;
+		p.outFinal = outFinal;
+		p.outCounts = reinterpret_cast<unsigned long long*>(outCounts);
+		return Dispatch(p, stream);
+	}
+
+	// Host-pointer mode: stage through HBM.  (PCIe-inclusive; the benchmark never times this mode.)
+	if (n == 0)
+		return PIRE_HIP_OK;
+	Staging st;
+	uint64_t textBytes;
+	if (offsets) {
+		for (uint64_t i = 0; i < n; ++i)
+			if (offsets[i] > offsets[i + 1]) {
+				SetError("offsets must be non-decreasing");
+				return PIRE_HIP_EINVAL;
+			}
+		textBytes = offsets[n];
+	} else {
+		textBytes = (n - 1) * stride + len;
+	}
+	if (!text && textBytes) {
+		// a null text pointer is fine only when every string is empty (tests/pire_ut.cpp:832-837)
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	const uint8_t* dText = nullptr;
+	if (int rc = st.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream))
+		return rc;
+	p.text = dText;
+	if (offsets)
+		if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
+			return rc;
+	if (init)
+		if (int rc = st.In(init, size_t(n), &p.initIdx, stream))
+			return rc;
+	void* dIdx = nullptr;
+	void* dFin = nullptr;
+	void* dCnt = nullptr;
+	if (outIdx) {
+		if (int rc = st.Alloc(&dIdx, size_t(n) * 4))
+			return rc;
+		p.outIdx = static_cast<uint32_t*>(dIdx);
+	}
+	if (outFinal) {
+		if (int rc = st.Alloc(&dFin, size_t(n)))
+			return rc;
+		p.outFinal = static_cast<uint8_t*>(dFin);
+	}
+	const size_t cntBytes = (size_t(t->host.regexps) + 2) * 8;
+	if (outCounts) {
+		if (int rc = st.Alloc(&dCnt, cntBytes))
+			return rc;
+		hipError_t e = hipMemcpyAsync(dCnt, outCounts, cntBytes, hipMemcpyHostToDevice, stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(counts)");
+		p.outCounts = static_cast<unsigned long long*>(dCnt);
+	}
+	if (int rc = Dispatch(p, stream))
+		return rc;
+	hipError_t e = hipSuccess;
+	if (outIdx)
+		e = hipMemcpyAsync(outIdx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && outFinal)
+		e = hipMemcpyAsync(outFinal, dFin, size_t(n), hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && outCounts)
+		e = hipMemcpyAsync(outCounts, dCnt, cntBytes, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+		return HipFail(e, "copy back / synchronize");
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+}  // namespace pirehip
+
+using namespace pirehip;
+
+extern "C" {
+
+const char* pire_hip_last_error(void) { return g_error.c_str(); }
+const char* pire_hip_last_kernel(void) { return g_lastKernel; }
+
+int pire_hip_set_timing(int enabled)
+{
+	g_timing = enabled != 0;
+	return PIRE_HIP_OK;
+}
+
+float pire_hip_last_kernel_ms(void) { return g_lastMs; }
+
+int pire_hip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n;
+}
+
+int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** out)
+{
+	if (!out) {
+		SetError("null out pointer");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	std::unique_ptr<pire_hip_table> t(new (std::nothrow) pire_hip_table);
+	if (!t) {
+		SetError("out of memory");
+		return PIRE_HIP_ENOMEM;
+	}
+	if (int rc = BuildHostTable(save_blob, len, &t->host))
+		return rc;
+	*out = t.release();
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_table_upload(pire_hip_table* t)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	return UploadTable(t);
+}
+
+void pire_hip_table_destroy(pire_hip_table* t)
+{
+	if (!t)
+		return;
+	FreeDeviceTable(&t->dev);
+	delete t;
+}
+
+int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
+{
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	const HostTable& h = t->host;
+	memset(out, 0, sizeof(*out));
+	out->abi_version = PIRE_HIP_ABI_VERSION;
+	out->states = h.states;
+	out->letters = h.letters;
+	out->regexps = h.regexps;
+	out->initial = h.initial;
+	out->empty = h.empty ? 1 : 0;
+	out->header_size = h.headerSize;
+	out->row_stride = h.rowStride;
+	out->hot_states = h.hot;
+	out->lds_table_bytes = (h.hot + 1) * 256 + 256 + 528;
+	out->device_bytes = t->dev.bytes;
+	out->ref_buf_size = h.refBufSize;
+	return PIRE_HIP_OK;
+}
+
+static int CheckIdx(const pire_hip_table* t, uint32_t idx)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	if (idx >= t->host.states) {
+		SetError("state index out of range");
+		return PIRE_HIP_EINVAL;
+	}
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_table_final(const pire_hip_table* t, uint32_t idx)
+{
+	if (int rc = CheckIdx(t, idx))
+		return rc;
+	return (t->host.flags[idx] & kFinal) ? 1 : 0;
+}
+
+int pire_hip_table_dead(const pire_hip_table* t, uint32_t idx)
+{
+	if (int rc = CheckIdx(t, idx))
+		return rc;
+	return (t->host.flags[idx] & kDead) ? 1 : 0;
+}
+
+int pire_hip_table_accepted_regexps(const pire_hip_table* t, uint32_t idx, const uint64_t** begin, size_t* count)
+{
+	if (int rc = CheckIdx(t, idx))
+		return rc;
+	if (!begin || !count) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	const HostTable& h = t->host;
+	*begin = h.acceptIds.data() + h.acceptOff[idx];
+	*count = size_t(h.acceptOff[idx + 1] - h.acceptOff[idx]);
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_table_letter_class(const pire_hip_table* t, uint32_t ch)
+{
+	if (!t || ch >= kMaxChar) {
+		SetError("bad argument");
+		return PIRE_HIP_EINVAL;
+	}
+	return t->host.cls[ch];
+}
+
+int64_t pire_hip_table_next(const pire_hip_table* t, uint32_t idx, uint32_t ch)
+{
+	if (int rc = CheckIdx(t, idx))
+		return rc;
+	if (ch >= kMaxCharUnaligned || ch == kEpsilon) {
+		SetError("character out of range");
+		return PIRE_HIP_EINVAL;
+	}
+	const HostTable& h = t->host;
+	return h.next[size_t(idx) * h.letters + h.cls[ch]];
+}
+
+int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8_t* hot_rows)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	const HostTable& h = t->host;
+	if (orig_of_perm)
+		memcpy(orig_of_perm, h.origOfPerm.data(), h.origOfPerm.size() * sizeof(uint32_t));
+	if (hot_rows)
+		memcpy(hot_rows, h.hotRows.data(), h.hotRows.size());
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_run(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                 const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts,
+                 void* stream)
+{
+	if (n && !offsets) {
+		SetError("null offsets");
+		return PIRE_HIP_EINVAL;
+	}
+	if (offsets && !(flags & PIRE_HIP_RUN_ON_DEVICE) && n) {
+		// fixed-length, 16-byte-friendly batches handed over as offsets still get the tiled kernel
+		const uint64_t len = offsets[1] - offsets[0];
+		bool uniform = offsets[0] == 0 && len >= 128 && len % 16 == 0;
+		for (uint64_t i = 1; uniform && i < n; ++i)
+			uniform = offsets[i + 1] - offsets[i] == len;
+		if (uniform)
+			return RunImpl(t, text, nullptr, n, len, len, flags, init_state_idx, out_state_idx, out_final,
+			               out_counts, stream);
+	}
+	return RunImpl(t, text, offsets, n, 0, 0, flags, init_state_idx, out_state_idx, out_final, out_counts, stream);
+}
+
+int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
+                         uint32_t flags, const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final,
+                         uint64_t* out_counts, void* stream)
+{
+	if (stride < len) {
+		SetError("stride smaller than len");
+		return PIRE_HIP_EINVAL;
+	}
+	return RunImpl(t, text, nullptr, n, len, stride, flags, init_state_idx, out_state_idx, out_final, out_counts,
+	               stream);
+}
+
+int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream)
+{
+	if (!t || (n && !state_idx) || ch >= kMaxCharUnaligned || ch == kEpsilon) {
+		SetError("bad argument");
+		return PIRE_HIP_EINVAL;
+	}
+	ScanParams p;
+	if (int rc = FillParams(t, &p, 0))
+		return rc;
+	return LaunchStep(p, state_idx, n, t->host.cls[ch], static_cast<hipStream_t>(stream));
+}
+
+int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,
+                         uint64_t stride, const void* plants, void* stream)
+{
+	if (!device_out && count && len) {
+		SetError("null output");
+		return PIRE_HIP_EINVAL;
+	}
+	return LaunchCorpusFill(static_cast<uint8_t*>(device_out), seed, first, count, len, stride, plants,
+	                        static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+// Internal structures of libpire_hip.so (not installed).  See DESIGN.md for the data layout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/pire_hip.h"
+
+namespace pirehip {
+
+// pire/defs.h:59-73
+enum : uint32_t {
+	kEpsilon = 257,
+	kBeginMark = 258,
+	kEndMark = 259,
+	kMaxCharUnaligned = 260,
+	kMaxChar = 264,
+};
+
+enum : uint8_t {
+	kFinal = 1,      // FinalFlag, multi.h:91
+	kDead = 2,       // DeadFlag,  multi.h:92
+	kAbsorbing = 4,  // ours: every transition of the row (all letter classes, marks included) is a self loop
+};
+
+constexpr uint32_t kMaxHotRows = 256;   // dense rows addressable by a u8 state id (255 hot + 1 trap)
+
+// Host-side, fully decoded scanner.  States are in the REFERENCE's numbering ("orig") unless a name says perm.
+struct HostTable {
+	// geometry (mirrors Scanner::Locals, multi.h:315-323)
+	uint32_t states = 0, letters = 0, regexps = 0, initial = 0;
+	bool empty = false;
+	uint32_t headerSize = 0, rowStride = 0;
+	uint64_t refBufSize = 0;
+
+	std::vector<uint16_t> cls;        // [264] letter class of each Char (Translate() - HEADER_SIZE)
+	std::vector<uint32_t> next;       // [states * letters] next state index, orig numbering
+	std::vector<uint8_t> flags;       // [states] kFinal|kDead|kAbsorbing
+	std::vector<uint64_t> acceptOff;  // [states + 1] CSR into acceptIds
+	std::vector<uint64_t> acceptIds;  // AcceptedRegexps lists (multi.h:149-158)
+
+	// device numbering: hot states first ("perm" ids).  permOfOrig / origOfPerm are inverse permutations.
+	std::vector<uint32_t> permOfOrig, origOfPerm;
+	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
+	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
+	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
+};
+
+// Device image (one HIP device).
+struct DeviceTable {
+	int device = -1;
+	uint8_t* hotRows = nullptr;       // [(hot+1)*256]
+	uint8_t* hotFlags = nullptr;      // [256]
+	uint16_t* cls = nullptr;          // [264]
+	uint32_t* nextPerm = nullptr;     // [states*letters], perm ids in, perm ids out
+	uint8_t* flagsPerm = nullptr;     // [states]
+	uint32_t* origOfPerm = nullptr;   // [states]
+	uint32_t* permOfOrig = nullptr;   // [states]
+	uint64_t* acceptMaskPerm = nullptr;  // [states] bit r = regexp r accepted (regexps <= 64), else null
+	uint64_t* acceptOffPerm = nullptr;   // [states+1] CSR (regexps > 64)
+	uint64_t* acceptIds = nullptr;
+	uint64_t bytes = 0;
+};
+
+}  // namespace pirehip
+
+struct pire_hip_table {
+	pirehip::HostTable host;
+	pirehip::DeviceTable dev;
+	std::mutex uploadMutex;
+};
+
+namespace pirehip {
+
+// Kernel parameter block (passed by value).
+struct ScanParams {
+	// table
+	const uint8_t* hotRows;
+	const uint8_t* hotFlags;
+	const uint16_t* cls;
+	const uint32_t* nextPerm;
+	const uint8_t* flagsPerm;
+	const uint32_t* origOfPerm;
+	const uint32_t* permOfOrig;
+	const uint64_t* acceptMaskPerm;
+	const uint64_t* acceptOffPerm;
+	const uint64_t* acceptIds;
+	uint32_t states, letters, regexps, hot;
+	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
+	uint32_t beginCls, endCls;
+	uint32_t flags;          // PIRE_HIP_RUN_*
+	// batch
+	const uint8_t* text;
+	const uint64_t* offsets; // nullable: then string i = [i*stride, i*stride+len)
+	uint64_t n, len, stride;
+	const uint32_t* initIdx; // nullable
+	uint32_t* outIdx;        // nullable
+	uint8_t* outFinal;       // nullable
+	unsigned long long* outCounts;  // nullable
+};
+
+void SetError(const std::string& msg);
+int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_HIP_ENODEVICE / ENOMEM
+
+// table.cpp
+int BuildHostTable(const void* blob, size_t len, HostTable* out);
+int UploadTable(pire_hip_table* t);
+void FreeDeviceTable(DeviceTable* d);
+
+// kernels.hip
+int LaunchGeneric(const ScanParams& p, hipStream_t stream);
+int LaunchTiled(const ScanParams& p, hipStream_t stream);
+bool TiledEligible(const ScanParams& p);
+int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
+int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
+                     const void* plantsHost, hipStream_t stream);
+
+}  // namespace pirehip

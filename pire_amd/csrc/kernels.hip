@@ -1,0 +1,690 @@
+// HIP kernels of the scan path for gfx950 (MI355X / CDNA4).  No MFMA: the path is a byte-gather DFA walk.
+//
+// What is computed (per input string, one string per lane):
+//     st = start;  for each byte b:  st = Next(st, b);   [Begin/End marks around it]
+// which is Pire::Run / Pire::Step of /root/reference/pire/run.h:50-57, 271-275 over the table of
+// /root/reference/pire/scanners/multi.h:163-192 (Next = row[letters[ch]]).
+//
+// Device table layout (built in table.cpp, described in DESIGN.md section 3):
+//   * states are renumbered "hot first" (perm ids); the reference's ids come back through origOfPerm[]
+//   * hot rows: up to 255 states have a DENSE row of 256 u8 entries in LDS, indexed directly by the input
+//     byte (the byte->letter-class translation of multi.h:163-166 is folded in).  One LDS gather per byte:
+//         addr = v_perm_b32(st, word, sel)   = (st << 8) | byte_k(word)
+//         st   = ds_read_u8(addr)
+//     An entry is the next hot id, or the trap id H ("left the hot set"); row H maps every byte to H.
+//   * everything else: nextPerm[perm * letters + cls[byte]] (u32) in HBM/L2 -- the exact, slow step.
+// A lane that leaves the hot set is re-walked exactly through the slow step for the 16-byte chunk in which it
+// trapped, so results never depend on which rows are hot.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "internal.h"
+
+namespace pirehip {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// LDS carve-up shared by both scan kernels (single dynamic region, 16-byte aligned pieces).
+struct LdsLayout {
+	uint32_t hotBytes;     // (hot+1)*256
+	uint32_t flagsOff;     // 256 B of hot flags
+	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
+	uint32_t countsOff;    // (regexps+2) u32 block-local counters
+	uint32_t total;
+};
+
+__host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps)
+{
+	LdsLayout l;
+	l.hotBytes = (hot + 1) * 256;
+	l.flagsOff = l.hotBytes;
+	l.clsOff = l.flagsOff + 256;
+	l.countsOff = l.clsOff + 528;
+	l.total = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
+	return l;
+}
+
+constexpr uint32_t kMaxLdsCountRegexps = 1024;
+constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
+
+// Cooperative load of the LDS-resident part of the table.
+__device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+{
+	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+	const u32x4* src = reinterpret_cast<const u32x4*>(p.hotRows);
+	u32x4* dst = reinterpret_cast<u32x4*>(lds);
+	for (uint32_t i = tid; i < L.hotBytes / 16; i += nthr)
+		dst[i] = src[i];
+	for (uint32_t i = tid; i < 256 / 4; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.flagsOff)[i] = reinterpret_cast<const uint32_t*>(p.hotFlags)[i];
+	for (uint32_t i = tid; i < 264 / 2; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.clsOff)[i] = reinterpret_cast<const uint32_t*>(p.cls)[i];
+	if (p.outCounts)
+		for (uint32_t i = tid; i < p.regexps + 2; i += nthr)
+			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
+	__syncthreads();
+}
+
+// The exact step for any state: multi.h:169-192 on the perm-numbered table.
+__device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                             uint32_t st, uint32_t byte)
+{
+	if (st < p.hot) {
+		const uint32_t e = lds[(st << 8) | byte];
+		if (e != p.hot)
+			return e;
+	}
+	const uint32_t c = reinterpret_cast<const uint16_t*>(lds + L.clsOff)[byte];
+	return p.nextPerm[size_t(st) * p.letters + c];
+}
+
+__device__ __forceinline__ uint32_t SlowStepWord(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                                 uint32_t st, uint32_t w)
+{
+	st = SlowStep(p, lds, L, st, w & 0xFF);
+	st = SlowStep(p, lds, L, st, (w >> 8) & 0xFF);
+	st = SlowStep(p, lds, L, st, (w >> 16) & 0xFF);
+	st = SlowStep(p, lds, L, st, w >> 24);
+	return st;
+}
+
+// Start state of string s (perm id): Initialize() or the caller's resume state, then Begin() if asked.
+__device__ __forceinline__ uint32_t StartState(const ScanParams& p, uint64_t s)
+{
+	if (!p.initIdx)
+		return p.startPerm;   // host folded Initialize()+Begin() into one id
+	uint32_t st = p.permOfOrig[p.initIdx[s]];
+	if (p.flags & PIRE_HIP_RUN_BEGIN)
+		st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+	return st;
+}
+
+// End(), outputs and block-local match counters for one finished string.
+__device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint64_t s,
+                                       bool active, uint32_t st)
+{
+	if (p.flags & PIRE_HIP_RUN_END)
+		st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+	const uint8_t fl = p.flagsPerm[st];
+	if (active) {
+		if (p.outIdx)
+			p.outIdx[s] = p.origOfPerm[st];
+		if (p.outFinal)
+			p.outFinal[s] = fl & kFinal;
+	}
+	if (p.outCounts) {
+		uint32_t* cnt = reinterpret_cast<uint32_t*>(lds + L.countsOff);
+		const int lane = threadIdx.x & 63;
+		const unsigned long long finals = __ballot(active && (fl & kFinal));
+		const unsigned long long actives = __ballot(active);
+		if (lane == 0) {
+			atomicAdd(&cnt[0], (uint32_t)__popcll(finals));
+			atomicAdd(&cnt[1], (uint32_t)__popcll(actives));
+		}
+		if (p.acceptMaskPerm) {
+			const uint64_t m = active ? p.acceptMaskPerm[st] : 0;
+			for (uint32_t r = 0; r < p.regexps; ++r) {
+				const unsigned long long b = __ballot((m >> r) & 1);
+				if (lane == 0 && b)
+					atomicAdd(&cnt[2 + r], (uint32_t)__popcll(b));
+			}
+		} else if (active) {
+			for (uint64_t k = p.acceptOffPerm[st]; k < p.acceptOffPerm[st + 1]; ++k)
+				atomicAdd(&cnt[2 + p.acceptIds[k]], 1u);
+		}
+	}
+}
+
+__device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+{
+	if (!p.outCounts)
+		return;
+	__syncthreads();
+	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + L.countsOff);
+	for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
+		if (cnt[i])
+			atomicAdd(&p.outCounts[i], (unsigned long long)cnt[i]);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ generic kernel
+// Any offsets, any alignment, any length (including 0).  One string per lane, exact step per byte.
+
+__global__ __launch_bounds__(256) void ScanGenericKernel(ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	LoadTableToLds(p, lds, L);
+
+	const uint64_t nrounds = (p.n + 63) / 64;
+	const uint32_t wavesPerBlock = blockDim.x >> 6;
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint64_t task = uint64_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6); task < nrounds;
+	     task += uint64_t(gridDim.x) * wavesPerBlock) {
+		const uint64_t s = task * 64 + lane;
+		const bool active = s < p.n;
+		uint32_t st = 0;
+		if (active) {
+			st = StartState(p, s);
+			uint64_t b, e;
+			if (p.offsets) {
+				b = p.offsets[s];
+				e = p.offsets[s + 1];
+			} else {
+				b = s * p.stride;
+				e = b + p.len;
+			}
+			const uint8_t* ptr = p.text + b;
+			const uint8_t* end = p.text + e;
+			while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+				st = SlowStep(p, lds, L, st, *ptr);
+				++ptr;
+			}
+			for (; ptr + 16 <= end; ptr += 16) {
+				const u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
+				st = SlowStepWord(p, lds, L, st, v.x);
+				st = SlowStepWord(p, lds, L, st, v.y);
+				st = SlowStepWord(p, lds, L, st, v.z);
+				st = SlowStepWord(p, lds, L, st, v.w);
+			}
+			for (; ptr < end; ++ptr)
+				st = SlowStep(p, lds, L, st, *ptr);
+		}
+		Finish(p, lds, L, s, active, st);
+	}
+	FlushCounts(p, lds, L);
+}
+
+// ------------------------------------------------------------------------------------------ tiled kernel
+// Fixed-length records, 16-byte aligned.  Each lane streams ITS OWN string straight from HBM in 128-byte
+// tiles (8 x global_load_dwordx4 = exactly one cache line per lane per tile), double-buffered in VGPRs, and
+// walks the tile out of registers with one LDS gather per byte.  No LDS staging: measured on MI355X
+// (profiles/micro_loadpath_r01.log) the per-lane line-sized access streams at the same ~6.2 TB/s as a fully
+// coalesced read, so all of the LDS is left for the table.
+
+// One 128-byte tile = exactly one cache line per lane, as 8 x global_load_dwordx4 into 32 VGPRs.
+//
+// The loads are issued from inline asm and waited for with hand-counted s_waitcnt vmcnt(N).  Reason (measured,
+// DESIGN.md section 6): hipcc's own wait insertion turns every loop-carried prefetch into `s_waitcnt vmcnt(0)` at
+// the tile boundary, which collapses an N-deep register pipeline to depth 1.  Counting is safe with foreign VMEM
+// ops in the queue: loads return in order among themselves, so "at most 8*k outstanding" implies every load issued
+// before the last k tiles has landed; extra compiler-issued ops only make the wait stricter.
+__device__ __forceinline__ void IssueTile(u32x4 (&r)[8], const void* src)
+{
+	// "+v": the tile registers are updated IN PLACE, so a ring slot is one fixed set of 32 VGPRs for the whole
+	// kernel and the compiler has no reason to copy a slot whose loads are still in flight.
+	asm volatile(
+		"global_load_dwordx4 %0, %8, off\n\t"
+		"global_load_dwordx4 %1, %8, off offset:16\n\t"
+		"global_load_dwordx4 %2, %8, off offset:32\n\t"
+		"global_load_dwordx4 %3, %8, off offset:48\n\t"
+		"global_load_dwordx4 %4, %8, off offset:64\n\t"
+		"global_load_dwordx4 %5, %8, off offset:80\n\t"
+		"global_load_dwordx4 %6, %8, off offset:96\n\t"
+		"global_load_dwordx4 %7, %8, off offset:112"
+		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+		: "v"(src));
+}
+
+// Wait until at most TILES_BEHIND tiles issued after `r` are still in flight; names r so nothing reads it earlier.
+template <int TILES_BEHIND>
+__device__ __forceinline__ void WaitTile(u32x4 (&r)[8])
+{
+	asm volatile("s_waitcnt vmcnt(%8)"
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+	             : "n"(TILES_BEHIND * 8));
+}
+
+// The hot rows sit at LDS byte address 0 (the kernels declare no static __shared__, so the dynamic region
+// starts at 0): the v_perm result IS the ds_read address, with no base add in the dependent chain.
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
+__device__ __forceinline__ uint32_t HotLookup(uint32_t addr)
+{
+	return *reinterpret_cast<LdsBytePtr>(static_cast<uintptr_t>(addr));
+}
+
+// Exact re-walk of one 16-byte chunk for the lanes that trapped.  Deliberately a rolled loop (the chunk is shifted
+// through as a 128-bit value): this is the cold path, and keeping it small keeps the hot loop dense in the I-cache.
+__device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
+                                           uint32_t st)
+{
+#pragma unroll 1
+	for (int i = 0; i < 16; ++i) {
+		st = SlowStep(p, lds, L, st, v.x & 0xFF);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return st;
+}
+
+// 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
+__device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                          const u32x4 v, uint32_t& hs, uint32_t& cold)
+{
+	const uint32_t hs0 = hs;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
+		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
+		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
+		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
+	}
+	if (hs == p.hot) {
+		const uint32_t f = SlowChunk(p, lds, L, v, hs0 != p.hot ? hs0 : cold);
+		if (f < p.hot) {
+			hs = f;
+		} else {
+			hs = p.hot;
+			cold = f;
+		}
+	}
+}
+
+__device__ __forceinline__ void StepTile(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                         const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold)
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		StepChunk(p, lds, L, r[k], hs, cold);
+}
+
+// Wave-wide early out (north_star: "wavefront ballot/any for early-out on dead states"): once every lane sits
+// in a row whose every transition is a self loop, the rest of the text cannot change any state.  This is the
+// GPU counterpart of the NO_EXIT_MASK return of multi.h:955-958, 979-982.
+__device__ __forceinline__ bool AllAbsorbing(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t hs)
+{
+	const bool a = hs != p.hot && (lds[L.flagsOff + hs] & kAbsorbing);
+	return __all(a);
+}
+
+__device__ __forceinline__ void ZeroTile(u32x4 (&r)[8])
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		r[k] = u32x4{0, 0, 0, 0};
+}
+
+// One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1
+// ahead (index clamped to the last tile, so the steady-state loop has no conditional loads), wait until the
+// current slot has landed, walk it.
+template <int NBUF>
+__device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t* base,
+                                      uint32_t t, uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8],
+                                      uint32_t& hs, uint32_t& cold)
+{
+	const uint32_t ahead = t + (NBUF - 1) < lastTile ? t + (NBUF - 1) : lastTile;
+	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
+		IssueTile(refill, base + size_t(ahead) * 128);
+	WaitTile<NBUF - 1>(cur);
+	StepTile(p, lds, L, cur, hs, cold);
+}
+
+template <int WAVES, int NBUF, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
+{
+	static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	LoadTableToLds(p, lds, L);
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t ntasks = (p.n + 63) / 64;
+	const uint32_t ntiles = uint32_t(p.len / 128);   // >= 1 (TiledEligible)
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t groups = ntiles / NBUF;
+	const uint32_t rem = ntiles % NBUF;
+
+	// Ring slots: tile t lives in slot t % NBUF.  Fixed registers for the whole kernel (see IssueTile).
+	u32x4 a[8], b[8], c[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	if (NBUF == 3)
+		ZeroTile(c);
+
+	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += uint64_t(gridDim.x) * WAVES) {
+		const uint64_t s = task * 64 + lane;
+		const bool active = s < p.n;
+		const uint64_t sc = active ? s : p.n - 1;
+		const uint8_t* base = p.text + sc * p.stride;
+
+		uint32_t cold = StartState(p, sc);
+		uint32_t hs = cold < p.hot ? cold : p.hot;
+
+		bool done = false;
+		if (NBUF == 3) {
+			IssueTile(a, base);
+			IssueTile(b, base + size_t(lastTile < 1 ? lastTile : 1) * 128);
+			for (uint32_t g = 0; g < groups && !done; ++g) {
+				const uint32_t t = g * 3;
+				Phase<3>(p, lds, L, base, t, lastTile, a, c, hs, cold);
+				Phase<3>(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
+				Phase<3>(p, lds, L, base, t + 2, lastTile, c, b, hs, cold);
+				done = AllAbsorbing(p, lds, L, hs);
+			}
+			if (!done && rem >= 1) {
+				WaitTile<1>(a);      // only slot b's refill was issued after it
+				StepTile(p, lds, L, a, hs, cold);
+			}
+			if (!done && rem == 2) {
+				WaitTile<0>(b);
+				StepTile(p, lds, L, b, hs, cold);
+			}
+		} else {
+			IssueTile(a, base);
+			for (uint32_t g = 0; g < groups && !done; ++g) {
+				const uint32_t t = g * 2;
+				Phase<2>(p, lds, L, base, t, lastTile, a, b, hs, cold);
+				Phase<2>(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
+				done = AllAbsorbing(p, lds, L, hs);
+			}
+			if (!done && rem == 1) {
+				WaitTile<0>(a);
+				StepTile(p, lds, L, a, hs, cold);
+			}
+		}
+
+		uint32_t st = hs != p.hot ? hs : cold;
+		// tail shorter than a tile: exact steps straight from memory (len % 16 == 0 is not required here)
+		for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
+			st = SlowStep(p, lds, L, st, base[i]);
+		Finish(p, lds, L, s, active, st);
+	}
+	FlushCounts(p, lds, L);
+}
+
+// ------------------------------------------------------------------------------------------ tiled kernel, interleaved refill
+// Same walk, but the refill of the tile two ahead is spread over the current tile: one global_load_dwordx4 after
+// each 16-byte chunk instead of a burst of eight.  (A/B candidate)
+
+template <int OFF>
+__device__ __forceinline__ void IssueOne(u32x4& r, const void* src)
+{
+	asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(r) : "v"(src), "n"(OFF));
+}
+
+__device__ __forceinline__ void PhaseIL(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                        const uint8_t* base, uint32_t t, uint32_t lastTile, u32x4 (&cur)[8],
+                                        u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
+{
+	const uint32_t ahead = t + 2 < lastTile ? t + 2 : lastTile;
+	const uint8_t* src = base + size_t(ahead) * 128;
+	WaitTile<1>(cur);
+	StepChunk(p, lds, L, cur[0], hs, cold); IssueOne<0>(refill[0], src);
+	StepChunk(p, lds, L, cur[1], hs, cold); IssueOne<16>(refill[1], src);
+	StepChunk(p, lds, L, cur[2], hs, cold); IssueOne<32>(refill[2], src);
+	StepChunk(p, lds, L, cur[3], hs, cold); IssueOne<48>(refill[3], src);
+	StepChunk(p, lds, L, cur[4], hs, cold); IssueOne<64>(refill[4], src);
+	StepChunk(p, lds, L, cur[5], hs, cold); IssueOne<80>(refill[5], src);
+	StepChunk(p, lds, L, cur[6], hs, cold); IssueOne<96>(refill[6], src);
+	StepChunk(p, lds, L, cur[7], hs, cold); IssueOne<112>(refill[7], src);
+}
+
+template <int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernelIL(ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	LoadTableToLds(p, lds, L);
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t ntasks = (p.n + 63) / 64;
+	const uint32_t ntiles = uint32_t(p.len / 128);
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t groups = ntiles / 3;
+	const uint32_t rem = ntiles % 3;
+
+	u32x4 a[8], b[8], c[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	ZeroTile(c);
+
+	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += uint64_t(gridDim.x) * WAVES) {
+		const uint64_t s = task * 64 + lane;
+		const bool active = s < p.n;
+		const uint64_t sc = active ? s : p.n - 1;
+		const uint8_t* base = p.text + sc * p.stride;
+
+		uint32_t cold = StartState(p, sc);
+		uint32_t hs = cold < p.hot ? cold : p.hot;
+
+		bool done = false;
+		IssueTile(a, base);
+		IssueTile(b, base + size_t(lastTile < 1 ? lastTile : 1) * 128);
+		for (uint32_t g = 0; g < groups && !done; ++g) {
+			const uint32_t t = g * 3;
+			PhaseIL(p, lds, L, base, t, lastTile, a, c, hs, cold);
+			PhaseIL(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
+			PhaseIL(p, lds, L, base, t + 2, lastTile, c, b, hs, cold);
+			done = AllAbsorbing(p, lds, L, hs);
+		}
+		if (!done && rem >= 1) {
+			WaitTile<1>(a);
+			StepTile(p, lds, L, a, hs, cold);
+		}
+		if (!done && rem == 2) {
+			WaitTile<0>(b);
+			StepTile(p, lds, L, b, hs, cold);
+		}
+
+		uint32_t st = hs != p.hot ? hs : cold;
+		for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
+			st = SlowStep(p, lds, L, st, base[i]);
+		Finish(p, lds, L, s, active, st);
+	}
+	FlushCounts(p, lds, L);
+}
+
+// ------------------------------------------------------------------------------------------ single Step()
+
+__global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateIdx, uint64_t n, uint32_t cls)
+{
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) {
+		const uint32_t st = p.permOfOrig[stateIdx[i]];
+		stateIdx[i] = p.origOfPerm[p.nextPerm[size_t(st) * p.letters + cls]];
+	}
+}
+
+// ------------------------------------------------------------------------------------------ corpus generator
+// Device twin of oracle/corpus.c (same integer arithmetic; tests/test_corpus.py pins equality).
+
+struct DevPlants {
+	uint32_t nplants;
+	uint32_t len[16];
+	uint32_t atTail[16];
+	uint8_t bytes[16][64];
+};
+
+__device__ __forceinline__ uint64_t Mix64(uint64_t z)
+{
+	z ^= z >> 30;
+	z *= 0xBF58476D1CE4E5B9ull;
+	z ^= z >> 27;
+	z *= 0x94D049BB133111EBull;
+	z ^= z >> 31;
+	return z;
+}
+
+__global__ __launch_bounds__(256) void CorpusFillKernel(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count,
+                                                        uint64_t len, uint64_t stride, DevPlants plants)
+{
+	const uint64_t wordsPerString = (len + 7) / 8;
+	const uint64_t total = count * wordsPerString;
+	for (uint64_t g = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; g < total; g += uint64_t(gridDim.x) * blockDim.x) {
+		const uint64_t i = g / wordsPerString, w = g % wordsPerString;
+		const uint64_t s = first + i;
+		const uint64_t x = Mix64(seed + s * 0x9E3779B97F4A7C15ull + (w + 1) * 0xD1B54A32D192ED03ull);
+		uint64_t poff = ~0ull, plen = 0;
+		uint32_t pid = 0;
+		if (plants.nplants) {
+			const uint64_t slot = s % (plants.nplants + 1);
+			if (slot != 0) {
+				pid = uint32_t(slot - 1);
+				const uint64_t wl = plants.len[pid];
+				if (wl <= len) {
+					plen = wl;
+					poff = plants.atTail[pid] ? len - wl : Mix64(seed ^ s ^ 0xA5A5A5A5ull) % (len - wl + 1);
+				}
+			}
+		}
+		uint8_t* dst = out + i * stride + w * 8;
+		for (uint32_t k = 0; k < 8 && w * 8 + k < len; ++k) {
+			const uint64_t pos = w * 8 + k;
+			uint8_t v = uint8_t(0x20 + ((((x >> (8 * k)) & 0xFF) * 95) >> 8));
+			if (plen && pos >= poff && pos < poff + plen)
+				v = plants.bytes[pid][pos - poff];
+			dst[k] = v;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+
+namespace {
+
+int DeviceCUs(int* cus)
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	hipDeviceProp_t prop;
+	e = hipGetDeviceProperties(&prop, dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDeviceProperties");
+	*cus = prop.multiProcessorCount;
+	return PIRE_HIP_OK;
+}
+
+template <class K>
+int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hipStream_t stream)
+{
+	int cus = 0;
+	int rc = DeviceCUs(&cus);
+	if (rc)
+		return rc;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	int perCu = 0;
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, ldsBytes);
+	if (e != hipSuccess)
+		return HipFail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+	if (perCu < 1)
+		perCu = 1;
+	const uint64_t ntasks = (p.n + 63) / 64;
+	const uint64_t wavesPerBlock = uint64_t(threads) / 64;
+	uint64_t blocks = (ntasks + wavesPerBlock - 1) / wavesPerBlock;
+	blocks = std::min<uint64_t>(blocks, uint64_t(cus) * perCu);
+	if (blocks == 0)
+		blocks = 1;
+	hipLaunchKernelGGL(kernel, dim3(unsigned(blocks)), dim3(threads), ldsBytes, stream, p);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "kernel launch");
+	return PIRE_HIP_OK;
+}
+
+int CheckCounts(const ScanParams& p)
+{
+	if (p.outCounts && p.regexps > kMaxLdsCountRegexps) {
+		SetError("out_counts is supported for scanners with at most 1024 regexps");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
+int LaunchGeneric(const ScanParams& p, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	return LaunchScan(ScanGenericKernel, p, 256, L.total, stream);
+}
+
+bool TiledEligible(const ScanParams& p)
+{
+	return p.offsets == nullptr && p.n > 0 && p.len >= 128 && (p.stride % 16) == 0 &&
+	       (reinterpret_cast<uintptr_t>(p.text) % 16) == 0;
+}
+
+int LaunchTiled(const ScanParams& p, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	// Variant knob for A/B measurements; the default is the measured best.
+	static const int variant = [] {
+		const char* v = getenv("PIRE_HIP_TILED_VARIANT");
+		return v ? atoi(v) : 0;
+	}();
+	static const bool noload = getenv("PIRE_HIP_DEBUG_NOLOAD") != nullptr;
+	ScanParams q = p;
+	if (noload)
+		q.flags |= kDebugNoRefill;
+	const ScanParams& p2 = q;
+	switch (variant) {
+	case 1:  return LaunchScan(ScanTiledKernel<16, 2, 1>, p2, 1024, L.total, stream);
+	case 2:  return LaunchScan(ScanTiledKernel<12, 2, 6>, p2, 768, L.total, stream);
+	case 3:  return LaunchScan(ScanTiledKernel<10, 2, 5>, p2, 640, L.total, stream);
+	case 4:  return LaunchScan(ScanTiledKernel<12, 3, 1>, p2, 768, L.total, stream);
+	case 5:  return LaunchScan(ScanTiledKernel<8, 3, 1>, p2, 512, L.total, stream);
+	case 6:  return LaunchScan(ScanTiledKernelIL<16, 1>, p2, 1024, L.total, stream);
+	case 7:  return LaunchScan(ScanTiledKernelIL<12, 1>, p2, 768, L.total, stream);
+	default: return LaunchScan(ScanTiledKernel<16, 3, 1>, p2, 1024, L.total, stream);
+	}
+}
+
+int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream)
+{
+	if (n == 0)
+		return PIRE_HIP_OK;
+	const unsigned blocks = unsigned((n + 255) / 256);
+	hipLaunchKernelGGL(StepKernel, dim3(blocks), dim3(256), 0, stream, p, stateIdx, n, cls);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "step kernel launch");
+	return PIRE_HIP_OK;
+}
+
+int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
+                     const void* plantsHost, hipStream_t stream)
+{
+	DevPlants pl;
+	memset(&pl, 0, sizeof(pl));
+	if (plantsHost)
+		memcpy(&pl, plantsHost, sizeof(pl));   // same layout as corpus_plants (oracle/corpus.h)
+	if (pl.nplants > 16) {
+		SetError("corpus: too many plants");
+		return PIRE_HIP_EINVAL;
+	}
+	if (count == 0 || len == 0)
+		return PIRE_HIP_OK;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const uint64_t total = count * ((len + 7) / 8);
+	const unsigned blocks = unsigned(std::min<uint64_t>((total + 255) / 256, uint64_t(cus) * 32));
+	hipLaunchKernelGGL(CorpusFillKernel, dim3(blocks), dim3(256), 0, stream, out, seed, first, count, len, stride, pl);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "corpus kernel launch");
+	return PIRE_HIP_OK;
+}
+
+}  // namespace pirehip

@@ -1,0 +1,369 @@
+// Scanner::Save() blob  ->  compact host table  ->  device image.
+//
+// Reference layout facts used here (all under /root/reference/pire):
+//   blob        = Header(24 B) | Locals(48 B) | bool empty (padded to 8) | BufSize() bytes   scanners/multi.h:557-573
+//   Header      = {Magic "PIRE", Version 7, PtrSize 8, MaxWordSize 16, Type 1, HdrSize 48}     scanners/common.h:44-63
+//   buffer      = m_letters[264] u16 | m_final[finalTableSize] u64 | m_finalIndex[states] u64
+//                 | m_transitions[states * RowSize] u32                                         multi.h:381-388
+//   row         = ScannerRowHeader (ExitMasks<N>: N*4 u64 masks + u64 Flags; NoShortcuts: u64 Flags)
+//                 then one u32 per letter class = signed byte distance to the target row        multi.h:55-67, 704-767
+//   m_letters[] = class + HEADER_SIZE                                                           multi.h:375
+// The ExitMasks themselves are a CPU (SSE2) skipping device and are not carried over: they never change a
+// result (multi.h:925-934 asserts it); the GPU analogue is the absorbing-row early-out.
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "internal.h"
+
+namespace pirehip {
+
+namespace {
+
+struct RefHeader {
+	uint32_t magic, version, ptrSize, maxWordSize, type, hdrSize;
+};
+
+struct RefLocals {
+	uint32_t statesCount, lettersCount, regexpsCount, pad0;
+	uint64_t initial;
+	uint32_t finalTableSize, pad1;
+	uint64_t relocationSignature, shortcuttingSignature;
+};
+static_assert(sizeof(RefHeader) == 24, "Header layout");
+static_assert(sizeof(RefLocals) == 48, "Locals layout");
+
+constexpr uint32_t kMagic = 0x45524950u;
+
+size_t AlignUp(size_t v, size_t b) { return (v + b - 1) & ~(b - 1); }
+
+int Bad(const char* msg)
+{
+	SetError(msg);
+	return PIRE_HIP_EFORMAT;
+}
+
+// Expected visits per state for text drawn from a simple byte model, used only to decide WHICH rows get the
+// fast dense LDS representation.  Any choice is correct; a better choice is faster.
+std::vector<double> VisitMass(const HostTable& t, uint32_t start)
+{
+	const uint32_t N = t.states, C = t.letters;
+	std::vector<double> classProb(C, 0.0);
+	for (uint32_t b = 0; b < 256; ++b) {
+		double q = 0.1 / 256.0;
+		if (b >= 0x20 && b <= 0x7E)
+			q += 0.9 / 95.0;
+		classProb[t.cls[b]] += q;
+	}
+	std::vector<double> p(N, 0.0), np(N, 0.0), mass(N, 0.0);
+	std::vector<uint32_t> live{start}, nlive;
+	p[start] = 1.0;
+	for (int step = 0; step < 512; ++step) {
+		nlive.clear();
+		for (uint32_t s : live) {
+			const double ps = p[s];
+			mass[s] += ps;
+			if (ps < 1e-13)
+				continue;
+			const uint32_t* row = &t.next[size_t(s) * C];
+			for (uint32_t c = 0; c < C; ++c) {
+				if (classProb[c] == 0.0)
+					continue;
+				const uint32_t d = row[c];
+				if (np[d] == 0.0)
+					nlive.push_back(d);
+				np[d] += ps * classProb[c];
+			}
+		}
+		for (uint32_t s : live)
+			p[s] = 0.0;
+		for (uint32_t s : nlive) {
+			p[s] = np[s];
+			np[s] = 0.0;
+		}
+		live.swap(nlive);
+		if (live.size() > 65536)
+			break;   // mass has spread too thin to matter for a <=255-row choice
+	}
+	return mass;
+}
+
+void ChooseHotAndPermute(HostTable& t)
+{
+	const uint32_t N = t.states, C = t.letters;
+	// every string starts at Initialize() and (normally) takes BeginMark first; rank from both
+	std::vector<double> mass = VisitMass(t, t.initial);
+	{
+		const uint32_t afterBegin = t.next[size_t(t.initial) * C + t.cls[kBeginMark]];
+		std::vector<double> m2 = VisitMass(t, afterBegin);
+		for (uint32_t s = 0; s < N; ++s)
+			mass[s] += m2[s];
+		mass[afterBegin] += 1.0;
+		mass[t.initial] += 1.0;
+	}
+	std::vector<uint32_t> order(N);
+	std::iota(order.begin(), order.end(), 0u);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return mass[a] > mass[b]; });
+
+	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
+	t.origOfPerm = order;
+	t.permOfOrig.assign(N, 0);
+	for (uint32_t pid = 0; pid < N; ++pid)
+		t.permOfOrig[order[pid]] = pid;
+
+	// dense rows: entry = perm id of next state if that is hot, else the trap id (== hot)
+	const uint32_t H = t.hot;
+	t.hotRows.assign(size_t(H + 1) * 256, uint8_t(H));
+	for (uint32_t pid = 0; pid < H; ++pid) {
+		const uint32_t* row = &t.next[size_t(order[pid]) * C];
+		uint8_t* out = &t.hotRows[size_t(pid) * 256];
+		for (uint32_t b = 0; b < 256; ++b) {
+			const uint32_t d = t.permOfOrig[row[t.cls[b]]];
+			out[b] = d < H ? uint8_t(d) : uint8_t(H);
+		}
+	}
+	t.hotFlags.assign(256, 0);
+	for (uint32_t pid = 0; pid < H; ++pid)
+		t.hotFlags[pid] = t.flags[order[pid]];
+}
+
+}  // namespace
+
+int BuildHostTable(const void* blob, size_t len, HostTable* out)
+{
+	const uint8_t* p = static_cast<const uint8_t*>(blob);
+	if (!p || len < sizeof(RefHeader))
+		return Bad("EOF reached while reading the scanner header");
+	RefHeader h;
+	memcpy(&h, p, sizeof(h));
+	// Header::Validate, common.h:65-77
+	if (h.magic != kMagic || h.ptrSize != 8 || h.maxWordSize != 16)
+		return Bad("Serialized regexp incompatible with your system");
+	if (h.version != 7 && h.version != 6)
+		return Bad("You are trying to used an incompatible version of a serialized regexp");
+	if (h.type != 1 /* ScannerIOTypes::Scanner */ || h.hdrSize != sizeof(RefLocals))
+		return Bad("Serialized regexp incompatible with your system");
+	size_t pos = AlignUp(sizeof(RefHeader), 8);
+
+	if (len < pos + sizeof(RefLocals))
+		return Bad("EOF reached while reading the scanner locals");
+	RefLocals m;
+	memcpy(&m, p + pos, sizeof(m));
+	pos += AlignUp(sizeof(RefLocals), 8);
+	if (m.relocationSignature != 1)
+		return Bad("Type mismatch while mmapping Pire::Scanner");
+	uint32_t maskCount;
+	if (m.shortcuttingSignature == 0x1000)
+		maskCount = 0;
+	else if ((m.shortcuttingSignature >> 8) == 0x20 && (m.shortcuttingSignature & 0xFF) != 0)
+		maskCount = uint32_t(m.shortcuttingSignature & 0xFF);
+	else
+		return Bad("This scanner has different shortcutting type");
+
+	if (len < pos + 1)
+		return Bad("EOF reached while reading the scanner");
+	const bool empty = p[pos] != 0;
+	pos += 8;
+
+	HostTable& t = *out;
+	t = HostTable();
+	const uint32_t flagsOff = maskCount * 4 * 8;
+	t.headerSize = (flagsOff + 8) / 4;
+	t.empty = empty;
+
+	if (empty) {
+		// Scanner::Null() = Fsm::MakeFalse() compiled (multi.h:339-344): it never matches.  Model it as one
+		// non-final state with a single letter class that loops (tests/pire_ut.cpp:760-830 pins the behaviour).
+		t.states = 1;
+		t.letters = 1;
+		t.regexps = 0;
+		t.initial = 0;
+		t.rowStride = uint32_t(AlignUp(1 + t.headerSize, 4) * 4);
+		t.cls.assign(kMaxChar, 0);
+		t.next.assign(1, 0);
+		t.flags.assign(1, uint8_t(kDead | kAbsorbing));
+		t.acceptOff.assign(2, 0);
+		ChooseHotAndPermute(t);
+		return PIRE_HIP_OK;
+	}
+
+	if (m.statesCount == 0 || m.lettersCount == 0 || m.lettersCount > kMaxChar)
+		return Bad("Corrupt scanner: bad state or letter count");
+	const size_t rowSize = AlignUp(size_t(m.lettersCount) + t.headerSize, 16 / 4);
+	const size_t bufSize = AlignUp(size_t(kMaxChar) * 2 + size_t(m.finalTableSize) * 8 + size_t(m.statesCount) * 8 +
+	                                   rowSize * m.statesCount * 4,
+	                               8);
+	if (len < pos + bufSize)
+		return Bad("EOF reached while reading the scanner buffer");
+
+	t.states = m.statesCount;
+	t.letters = m.lettersCount;
+	t.regexps = m.regexpsCount;
+	t.rowStride = uint32_t(rowSize * 4);
+	t.refBufSize = bufSize;
+
+	const uint8_t* buf = p + pos;
+	const uint8_t* letters = buf;
+	const uint8_t* finalTab = letters + size_t(kMaxChar) * 2;
+	const uint8_t* finalIndex = finalTab + size_t(m.finalTableSize) * 8;
+	const uint8_t* trans = finalIndex + size_t(m.statesCount) * 8;
+	const uint64_t stride = t.rowStride;
+	const uint64_t tableBytes = stride * t.states;
+
+	if (m.initial % stride != 0 || m.initial >= tableBytes)
+		return Bad("Corrupt scanner: initial state out of range");
+	t.initial = uint32_t(m.initial / stride);
+
+	t.cls.assign(kMaxChar, 0);
+	for (uint32_t c = 0; c < kMaxChar; ++c) {
+		uint16_t v;
+		memcpy(&v, letters + size_t(c) * 2, 2);
+		if (c == kEpsilon || c >= kMaxCharUnaligned) {
+			t.cls[c] = 0;   // never fed to Next(); the reference leaves these slots unset (multi.h:420)
+			continue;
+		}
+		if (v < t.headerSize || v >= t.headerSize + t.letters)
+			return Bad("Corrupt scanner: letter class out of range");
+		t.cls[c] = uint16_t(v - t.headerSize);
+	}
+
+	t.next.resize(size_t(t.states) * t.letters);
+	t.flags.resize(t.states);
+	for (uint32_t s = 0; s < t.states; ++s) {
+		const uint8_t* row = trans + size_t(s) * stride;
+		uint64_t fl;
+		memcpy(&fl, row + flagsOff, 8);
+		bool absorbing = true;
+		for (uint32_t c = 0; c < t.letters; ++c) {
+			int32_t shift;
+			memcpy(&shift, row + size_t(t.headerSize + c) * 4, 4);
+			const int64_t dest = int64_t(s) * int64_t(stride) + shift;   // Relocatable::Go, multi.h:65
+			if (dest < 0 || uint64_t(dest) >= tableBytes || uint64_t(dest) % stride != 0)
+				return Bad("Corrupt scanner: transition out of range");
+			const uint32_t d = uint32_t(uint64_t(dest) / stride);
+			t.next[size_t(s) * t.letters + c] = d;
+			absorbing = absorbing && d == s;
+		}
+		t.flags[s] = uint8_t((fl & 1 ? kFinal : 0) | (fl & 2 ? kDead : 0) | (absorbing ? kAbsorbing : 0));
+	}
+
+	t.acceptOff.assign(size_t(t.states) + 1, 0);
+	for (uint32_t s = 0; s < t.states; ++s) {
+		uint64_t fi;
+		memcpy(&fi, finalIndex + size_t(s) * 8, 8);
+		t.acceptOff[s] = t.acceptIds.size();
+		for (;; ++fi) {
+			if (fi >= m.finalTableSize)
+				return Bad("Corrupt scanner: final table is not terminated");
+			uint64_t id;
+			memcpy(&id, finalTab + fi * 8, 8);
+			if (id == ~uint64_t(0))
+				break;   // End sentinel, multi.h:96, 155
+			t.acceptIds.push_back(id);
+		}
+	}
+	t.acceptOff[t.states] = t.acceptIds.size();
+
+	ChooseHotAndPermute(t);
+	return PIRE_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ device image
+
+namespace {
+
+template <class T>
+int Put(T** dst, const std::vector<T>& src, uint64_t* total)
+{
+	*dst = nullptr;
+	const size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
+	hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), bytes);
+	if (e != hipSuccess)
+		return HipFail(e, "hipMalloc(table)");
+	if (!src.empty()) {
+		e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(table)");
+	}
+	*total += bytes;
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
+void FreeDeviceTable(DeviceTable* d)
+{
+	if (d->device < 0)
+		return;
+	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
+	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds};
+	for (void* q : ptrs)
+		if (q)
+			(void)hipFree(q);
+	*d = DeviceTable();
+}
+
+int UploadTable(pire_hip_table* t)
+{
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	if (t->dev.device == dev)
+		return PIRE_HIP_OK;
+	FreeDeviceTable(&t->dev);
+
+	const HostTable& h = t->host;
+	const uint32_t N = h.states, C = h.letters;
+	std::vector<uint32_t> nextPerm(size_t(N) * C);
+	std::vector<uint8_t> flagsPerm(N);
+	for (uint32_t pid = 0; pid < N; ++pid) {
+		const uint32_t o = h.origOfPerm[pid];
+		for (uint32_t c = 0; c < C; ++c)
+			nextPerm[size_t(pid) * C + c] = h.permOfOrig[h.next[size_t(o) * C + c]];
+		flagsPerm[pid] = h.flags[o];
+	}
+	DeviceTable d;
+	int rc;
+	if ((rc = Put(&d.hotRows, h.hotRows, &d.bytes)) || (rc = Put(&d.hotFlags, h.hotFlags, &d.bytes)) ||
+	    (rc = Put(&d.cls, h.cls, &d.bytes)) || (rc = Put(&d.nextPerm, nextPerm, &d.bytes)) ||
+	    (rc = Put(&d.flagsPerm, flagsPerm, &d.bytes)) || (rc = Put(&d.origOfPerm, h.origOfPerm, &d.bytes)) ||
+	    (rc = Put(&d.permOfOrig, h.permOfOrig, &d.bytes))) {
+		d.device = dev;
+		FreeDeviceTable(&d);
+		return rc;
+	}
+	if (h.regexps <= 64) {
+		std::vector<uint64_t> mask(N, 0);
+		for (uint32_t pid = 0; pid < N; ++pid) {
+			const uint32_t o = h.origOfPerm[pid];
+			for (uint64_t k = h.acceptOff[o]; k < h.acceptOff[o + 1]; ++k)
+				if (h.acceptIds[k] < 64)
+					mask[pid] |= uint64_t(1) << h.acceptIds[k];
+		}
+		rc = Put(&d.acceptMaskPerm, mask, &d.bytes);
+	} else {
+		std::vector<uint64_t> off(size_t(N) + 1, 0), ids;
+		for (uint32_t pid = 0; pid < N; ++pid) {
+			const uint32_t o = h.origOfPerm[pid];
+			off[pid] = ids.size();
+			ids.insert(ids.end(), h.acceptIds.begin() + h.acceptOff[o], h.acceptIds.begin() + h.acceptOff[o + 1]);
+		}
+		off[N] = ids.size();
+		if (!(rc = Put(&d.acceptOffPerm, off, &d.bytes)))
+			rc = Put(&d.acceptIds, ids, &d.bytes);
+	}
+	if (rc) {
+		d.device = dev;
+		FreeDeviceTable(&d);
+		return rc;
+	}
+	d.device = dev;
+	t->dev = d;
+	return PIRE_HIP_OK;
+}
+
+}  // namespace pirehip

@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the UNMODIFIED reference library (oracle/_ref/libpire_ref.so).
+
+Run in the dev container (where /root/reference exists):   python tests/golden/make_golden.py
+The fixtures travel with the repo; the reference does not exist on the GPU box.
+
+Two kinds of knowledge are recorded per case:
+  * ``ref_expect``  -- the accept/deny verdict WRITTEN IN the reference's own unit tests
+                       (/root/reference/tests/pire_ut.cpp, line cited per case): the known answers;
+  * ``idx`` / ``final`` / ``accepted`` -- what the compiled reference itself returned for
+    Runner(sc).Begin().Run(s).End() on each string (StateIndex, Final, AcceptedRegexps): these pin
+    bit-exact state ids, which the reference's tests do not.
+The generator asserts that the two agree (ACCEPTS <=> AcceptedRegexps non-empty, tests/common.h:171-177).
+"""
+import base64
+import gzip
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.binding import RefScanner, corpus_fill, make_plants  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+A, D = True, False   # ACCEPTS / DENIES
+
+# (name, source, patterns, options, [(string, verdict-or-None)])
+CASES = [
+    ("string", "pire_ut.cpp:38-45", ["abc"], [""], [(b"def abc ghi", A), (b"abc", A), (b"def abd ghi", D)]),
+    ("boundaries_begin", "pire_ut.cpp:49-52", ["^abc"], [""], [(b"abc ghi", A), (b"def abc", D)]),
+    ("boundaries_end", "pire_ut.cpp:54-57", ["abc$"], [""], [(b"abc ghi", D), (b"def abc", A)]),
+    ("prim_alt", "pire_ut.cpp:62-66", ["abc|def"], [""], [(b"def", A), (b"abc", A), (b"deb", D)]),
+    ("prim_star", "pire_ut.cpp:68-74", ["ad*e"], [""],
+     [(b"xaez", A), (b"xadez", A), (b"xaddez", A), (b"xadddddddddddddddddddddddez", A), (b"xafez", D)]),
+    ("prim_plus", "pire_ut.cpp:76-82", ["ad+e"], [""],
+     [(b"xaez", D), (b"xadez", A), (b"xaddez", A), (b"xadddddddddddddddddddddddez", A), (b"xafez", D)]),
+    ("prim_opt", "pire_ut.cpp:84-89", ["ad?e"], [""], [(b"xaez", A), (b"xadez", A), (b"xaddez", D), (b"xafez", D)]),
+    ("prim_count", "pire_ut.cpp:91-95", ["a.{1}e"], [""], [(b"axe", A), (b"ae", D), (b"axye", D)]),
+] + [
+    ("mass_alt_%d" % i, "pire_ut.cpp:98-118", [p], [""],
+     [(b"abc", A), (b"def", A), (b"ghi", A), (b"klm", A), (b"aei", D), (b"klc", D)])
+    for i, p in enumerate(["((abc|def)|ghi)|klm", "(abc|def)|(ghi|klm)", "abc|(def|(ghi|klm))", "abc|(def|ghi)|klm"])
+] + [
+    ("composition_slashes", "pire_ut.cpp:122-132", ["^/([^\\\\/]|\\\\.)*/[a-z]*$"], [""],
+     [(b"/regexp/i", A), (b"/regexp2/", A), (b"regexp", D), (b"/dir\\/file/", A), (b"/dir/file/", D),
+      (b"/dir\\\\/", A), (b"/dir\\\\/file/", D)]),
+    ("composition_head_tail", "pire_ut.cpp:134-139", ["Head(Inner)*Tail"], [""],
+     [(b"HeadInnerTail", A), (b"HeadInnerInnerTail", A), (b"HeadInneInnerTail", D), (b"HeadTail", A)]),
+    ("rep_3_6", "pire_ut.cpp:144-151", ["^x{3,6}$"], [""],
+     [(b"xx", D), (b"xxx", A), (b"xxxx", A), (b"xxxxx", A), (b"xxxxxx", A), (b"xxxxxxx", D)]),
+    ("rep_3_inf", "pire_ut.cpp:153-159", ["^x{3,}$"], [""],
+     [(b"xx", D), (b"xxx", A), (b"xxxx", A), (b"x" * 11, A), (b"x" * 47, A)]),
+    ("rep_3", "pire_ut.cpp:161-168", ["^x{3}$"], [""],
+     [(b"x", D), (b"xx", D), (b"xxx", A), (b"xxxx", D), (b"xxxxx", D), (b"x" * 47, D)]),
+    ("rep_dot_3_10", "pire_ut.cpp:170-178", ["x.{3,10}$"], [""],
+     [(b"b" * (2 * n) + b"x" + b"e" * n, A if 3 <= n <= 10 else D) for n in range(20)]),
+    ("utf8_dot", "pire_ut.cpp:183-206", ["^.$"], ["u"],
+     [(b"\x41", A), (b"\x81", D), (b"\xC1\x81", A), (b"\xC1", D), (b"\xC1\x41", D), (b"\xC1\xC2", D),
+      (b"\xC1\x81\x82", D), (b"\xE1\x81\x82", A), (b"\xE1", D), (b"\xE1\x42", D), (b"\xE1\x42\x43", D),
+      (b"\xE1\xC2\xC3", D), (b"\xE1\x82", D), (b"\xE1\x82\x83\x84", D), (b"\xF1\x81\x82\x83", A)]),
+    ("utf8_literal", "pire_ut.cpp:208", ["x\xD0\xA4y"], ["u"], [(b"x\xD0\xA4y", A)]),
+    ("andnot_1", "pire_ut.cpp:213-219", ["<([0-9]+&~123&~456)>"], ["a"],
+     [(b"<111>", A), (b"<124>", A), (b"<123>", D), (b"<456>", D), (b"<abc>", D)]),
+    ("andnot_2", "pire_ut.cpp:221-224", ["[0-9]+\\&1+"], ["a"], [(b"111", D), (b"123&111", A)]),
+    ("misc_1", "pire_ut.cpp:240", ["^[^\\s=/>]*$"], ["n"], [(b"a", A)]),
+    ("misc_tab", "pire_ut.cpp:241", ["\\t"], [""], [(b"\t", A)]),
+    ("ranges", "pire_ut.cpp:253-256", ["a\\W"], [""], [(b"a,", A), (b"ab", D)]),
+    ("shortcuts_aaa", "pire_ut.cpp:630-634", ["aaa"], [""],
+     [(b"." * 38 + b"aaa" + b"." * 13, A), (b"." * 38 + b"aab" + b"." * 13, D), (b"." * 54, D)]),
+    ("shortcuts_ab3", "pire_ut.cpp:635-640", ["[ab]{3}"], [""],
+     [(b"." * 38 + b"aaa" + b"." * 13, A), (b"." * 38 + b"aab" + b"." * 13, A), (b"." * 38 + b"bbb" + b"." * 13, A),
+      (b"." * 54, D)]),
+    ("shortcuts_utf8", "pire_ut.cpp:641-645", ["\xD0\xB0"], ["u"],
+     [(b"." * 38 + b"\xD0\xB0" + b"." * 15, A), (b"." * 35 + b"\xD0\xB0" + b"." * 18, A),
+      (b"." * 32 + b"\xD0\xB0" + b"." * 21, A)]),
+    ("aligned_xy", "pire_ut.cpp:733-743", ["xy"], [""],
+     [(b"xy", A), (b"yz", D), (b"......xy", A), (b"......yz", D)]),
+    ("aligned_abcde", "pire_ut.cpp:745-755", ["abcde"], [""],
+     [(b"ZZZZZabcdeZZZZZZ", A), (b"ZZZZZabcdfZZZZZZ", D), (b"ZabcdeZZZ", A), (b"ZxbcdeZZZ", D),
+      (b"ZZZZZZZZZZZZZabcde", A), (b"ZZZZZZZZZZZZZabcdf", D)]),
+    ("serialization_pattern", "pire_ut.cpp:534-538, 555", ["^regexp$"], [""],
+     [(b"regexp", A), (b"regxp", D), (b"regexp t", D)]),
+    ("copying_pattern", "pire_ut.cpp:503-517", ["^r$"], [""], [(b"r", A), (b"p", D)]),
+    ("empty_scanner", "pire_ut.cpp:760-830", [], [], [(b"a strin", D), (b"", D)]),
+    ("null_fsm", "pire_ut.cpp:832-837 (Fsm() is not exposed; the empty pattern, unsurrounded, is the same automaton)",
+     [""], ["n"], [(b"", None)]),
+    ("survey_known_answer", "SURVEY.md 8c / README:60", ["hello\\s+w.+d$"], [""],
+     [(b"hello world", A), (b"Hello world", D), (b"say hello   wod", A), (b"hello world!", D), (b"hello wd", D),
+      (b"", D), (b"xxhello\tw--d", A)]),
+]
+
+# Glue (pire_ut.cpp:648-705): expected AcceptedRegexps lists are written in the test itself.
+GLUE_CASES = [
+    ("glue_aaa_bbb", "pire_ut.cpp:651-674", ["aaa", "bbb"], ["", ""],
+     [(b"aaa", [0]), (b"bbb", [1]), (b"aaabbb", [0, 1]), (b"ccc", [])]),
+    # the test glues (ccc, (aaa,bbb)); a left fold gives the same regexp numbering ccc=0, aaa=1, bbb=2
+    ("glue_ccc_aaa_bbb", "pire_ut.cpp:676-683", ["ccc", "aaa", "bbb"], ["", "", ""],
+     [(b"ccc", [0]), (b"aaa", [1]), (b"aaabbb", [1, 2]), (b"xyz", [])]),
+    ("glue_nonfinal", "pire_ut.cpp:684-692", ["a", "c"], ["n", "n"], [(b"ac", [])]),
+    ("inline_glue3", "inline_ut.cpp:60-91 (patterns)", ["foo", "bar", "http://([a-z0-9]+\\.)+[a-z]{2,4}/?"], ["", "", ""],
+     [(b"foo", [0]), (b"bar", [1]), (b"foobar", [0, 1]), (b"see http://aba.caba.ru/ ok", [2]), (b"none", [])]),
+]
+
+# The 8-regexp sets of SURVEY.md section 8d (patterns from tools/bench/run-bench:42-80, README:60, pire_ut.cpp).
+SET_A = ["hello\\s+w.+d$", "ABCDEFGHIJKLMNOPQRSTUVWXYZ$", "[XYZ]ABCDEFGHIJKLMNOPQRSTUVWXYZ$",
+         "[ -~]*ABCDEFGHIJKLMNOPQRSTUVWXYZ$", "(\\d{3}-|\\(\\d{3}\\)\\s+)(\\d{3}-\\d{4})$", "[@QZ]$", "[ABC]$", "[net]$"]
+SET_A_WITNESS = [(b"hello  world", True), (b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", True),
+                 (b"XABCDEFGHIJKLMNOPQRSTUVWXYZ", True), (b"abc ABCDEFGHIJKLMNOPQRSTUVWXYZ", True),
+                 (b"(123)  456-7890", True), (b"Q", True), (b"B", True), (b"t", True)]
+SET_D = ["hello\\s+w.+d$", "abc", "abc|def", "ad*e", "ad+e", "Head(Inner)*Tail", "^x{3,6}$", "aaa"]
+SET_D_WITNESS = [(b"hello  world", True), (b"abc", False), (b"def", False), (b"addde", False), (b"ade", False),
+                 (b"HeadInnerInnerTail", False), (b"xxxx", False), (b"aaa", False)]
+CORPUS_SEED = 0x5EED5EED
+
+
+def write_blob(name, blob):
+    if len(blob) > 65536:
+        path = name + ".blob.gz"
+        with open(os.path.join(OUT, path), "wb") as f:
+            f.write(gzip.compress(blob, 9, mtime=0))
+    else:
+        path = name + ".blob"
+        with open(os.path.join(OUT, path), "wb") as f:
+            f.write(blob)
+    return path
+
+
+def record(sc, strings):
+    idx, fin = sc.run_strings(strings)
+    idx_n, fin_n = sc.run_strings(strings, kind=RefScanner.NONRELOC)
+    assert (idx == idx_n).all() and (fin == fin_n).all(), "Scanner vs NonrelocScanner disagree"
+    acc = [sc.accepted(int(i)) for i in idx]
+    return [int(i) for i in idx], [int(f) for f in fin], acc
+
+
+def geometry(sc):
+    return {"states": sc.size, "letters": sc.letters, "regexps": sc.regexps, "initial": sc.initial,
+            "bufsize": sc.bufsize, "empty": sc.empty}
+
+
+def main():
+    cases = []
+    for name, source, pats, opts, items in CASES:
+        sc = RefScanner.compile(pats, opts)
+        strings = [s for s, _ in items]
+        idx, fin, acc = record(sc, strings)
+        for (s, verdict), a in zip(items, acc):
+            if verdict is not None:
+                assert (len(a) > 0) == verdict, (name, s, a, verdict)
+        blob = sc.save()
+        cases.append({"name": name, "source": source, "patterns": pats, "options": opts, "geometry": geometry(sc),
+                      "blob": write_blob(name, blob), "blob_sha256": hashlib.sha256(blob).hexdigest(),
+                      "strings_hex": [s.hex() for s in strings],
+                      "ref_expect": [v for _, v in items], "idx": idx, "final": fin, "accepted": acc})
+    for name, source, pats, opts, items in GLUE_CASES:
+        sc = RefScanner.compile(pats, opts)
+        strings = [s for s, _ in items]
+        idx, fin, acc = record(sc, strings)
+        for (s, want), a in zip(items, acc):
+            assert a == want, (name, s, a, want)
+        blob = sc.save()
+        cases.append({"name": name, "source": source, "patterns": pats, "options": opts, "geometry": geometry(sc),
+                      "blob": write_blob(name, blob), "blob_sha256": hashlib.sha256(blob).hexdigest(),
+                      "strings_hex": [s.hex() for s in strings],
+                      "ref_expect_accepted": [w for _, w in items], "idx": idx, "final": fin, "accepted": acc})
+
+    # big glued sets: geometry + results on seeded corpus strings and on raw random bytes (all 256 values)
+    big = []
+    for name, pats, wit in (("set_a", SET_A, SET_A_WITNESS), ("set_d", SET_D, SET_D_WITNESS)):
+        sc = RefScanner.compile(pats, [""] * len(pats))
+        blob = sc.save()
+        plants = make_plants(wit)
+        n, length = 96, 1024
+        data = corpus_fill(CORPUS_SEED, 0, n, length, plants)
+        offs = np.arange(n + 1, dtype=np.uint64) * length
+        idx, fin = sc.run(data.reshape(-1), offs)
+        rng = np.random.RandomState(1234)
+        lens = rng.randint(0, 300, size=64)
+        raw = [bytes(rng.randint(0, 256, size=int(k), dtype=np.uint8)) for k in lens]
+        ridx, rfin, racc = record(sc, raw)
+        big.append({"name": name, "patterns": pats, "witnesses_hex": [w.hex() for w, _ in wit],
+                    "witness_at_tail": [bool(t) for _, t in wit], "geometry": geometry(sc),
+                    "blob": write_blob(name, blob), "blob_sha256": hashlib.sha256(blob).hexdigest(),
+                    "corpus": {"seed": CORPUS_SEED, "n": n, "len": length,
+                               "sha256": hashlib.sha256(data.tobytes()).hexdigest(),
+                               "idx": [int(i) for i in idx], "final": [int(f) for f in fin],
+                               "accepted": [sc.accepted(int(i)) for i in idx]},
+                    "raw": {"numpy_randomstate_seed": 1234, "strings_hex": [r.hex() for r in raw], "idx": ridx,
+                            "final": rfin, "accepted": racc}})
+
+    # corpus generator pin: bytes of a few strings, with and without plants
+    plants = make_plants(SET_A_WITNESS)
+    c0 = corpus_fill(CORPUS_SEED, 0, 4, 100, None)
+    c1 = corpus_fill(CORPUS_SEED, 5, 12, 77, plants)
+    corpus = {"seed": CORPUS_SEED, "noplant_first4_len100_b64": base64.b64encode(c0.tobytes()).decode(),
+              "planted_from5_count12_len77_b64": base64.b64encode(c1.tobytes()).decode()}
+
+    with open(os.path.join(OUT, "cases.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
+                   "cases": cases, "big": big, "corpus": corpus}, f, indent=1)
+    print("wrote", len(cases), "cases,", len(big), "big sets")
+
+
+if __name__ == "__main__":
+    main()

