@@ -1,0 +1,195 @@
+/*
+ * batch_runner.hpp -- header-only C++ shim that keeps the Pire::Scanner / Pire::Runner vocabulary on top of the
+ * C ABI of libpire_hip.so (include/pire_hip.h).  This is the binding a Pire maintainer would add:
+ * the reference has no FFI on this path, it is a compile-time template concept (pire/run.h:50-57, 271-275,
+ * 365-392), so the drop-in is a class with the same fluent surface, batched over N strings:
+ *
+ *     Pire::Scanner sc = ...;                                  // built by the reference, on the host, unchanged
+ *     Pire::Hip::BatchRunner<Pire::Scanner> run(sc);           // Save() -> pire_hip_table_create()
+ *     run.Begin().Run(text, offsets, n).End();                 // == for each i: Runner(sc).Begin().Run(..).End()
+ *     const auto& states = run.States();                       // std::vector<Pire::Scanner::State>
+ *     bool ok = sc.Final(states[i]);                           // every Scanner accessor keeps working
+ *     auto ids = sc.AcceptedRegexps(states[i]);
+ *
+ * It compiles against the unmodified reference headers (<pire/pire.h>); nothing in it re-implements the walk: the
+ * states come back from the GPU as StateIndex values and are turned into Scanner::State (a row address inside the
+ * host scanner) with public API only -- Initialize(), StateIndex(), LettersCount(), sizeof(ScannerRowHeader),
+ * Transition (pire/scanners/multi.h:161, 281-284, 140, 119, 99, 347).
+ *
+ * Errors: the C ABI's negative codes are re-thrown as Pire::Error (pire/stub/stl.h:213-217), the reference's own
+ * exception type for this library.
+ */
+#ifndef PIRE_HIP_BATCH_RUNNER_HPP
+#define PIRE_HIP_BATCH_RUNNER_HPP
+
+#include <cstdint>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <pire/pire.h>
+
+#include "../pire_hip.h"
+
+namespace Pire {
+namespace Hip {
+
+inline void Check(int rc)
+{
+	if (rc < 0)
+		throw Pire::Error(std::string("pire_hip: ") + pire_hip_last_error());
+}
+
+/* A device-side copy of a compiled scanner.  Immutable, shareable between threads, like the scanner itself. */
+template <class Scanner>
+class Table {
+public:
+	explicit Table(const Scanner& sc)
+	    : m_table(nullptr)
+	{
+		// the PUBLIC hand-off: Scanner::Save (multi.h:307, 557-573); NonrelocScanner saves as Relocatable (604-608)
+		std::ostringstream out;
+		sc.Save(&out);
+		const std::string blob = out.str();
+		Check(pire_hip_table_create(blob.data(), blob.size(), &m_table));
+
+		// State <-> StateIndex geometry of THIS host scanner, public API only
+		typedef typename Scanner::Transition Tr;
+		const size_t header = sizeof(typename Scanner::ScannerRowHeader) / sizeof(Tr);           // HEADER_SIZE, 349
+		const size_t align = sizeof(Pire::Impl::MaxSizeWord) / sizeof(Tr);
+		const size_t row = (sc.LettersCount() + header + align - 1) / align * align;             // RowSize(), 347
+		m_stride = row * sizeof(Tr);
+		typename Scanner::State init;
+		sc.Initialize(init);
+		m_base = init - sc.StateIndex(init) * m_stride;
+	}
+	~Table() { pire_hip_table_destroy(m_table); }
+
+	pire_hip_table* Handle() const { return m_table; }
+	typename Scanner::State ToState(uint32_t idx) const { return m_base + size_t(idx) * m_stride; }
+	uint32_t ToIndex(typename Scanner::State st) const { return uint32_t((st - m_base) / m_stride); }
+
+private:
+	Table(const Table&);
+	Table& operator=(const Table&);
+	pire_hip_table* m_table;
+	size_t m_base, m_stride;
+};
+
+/* Batched twin of Pire::RunHelper (run.h:365-386). */
+template <class Scanner>
+class BatchRunner {
+public:
+	typedef typename Scanner::State State;
+
+	explicit BatchRunner(const Scanner& sc)
+	    : m_own(new Table<Scanner>(sc)), m_table(m_own), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false) {}
+	/* Re-use one device table for many batches. */
+	explicit BatchRunner(const Table<Scanner>& table)
+	    : m_own(nullptr), m_table(&table), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false) {}
+	~BatchRunner() { delete m_own; }
+
+	/* RunHelper(sc, st): resume every string from a previously returned state (run.h:368, 391-392). */
+	BatchRunner& From(const std::vector<State>& states)
+	{
+		m_init.resize(states.size());
+		for (size_t i = 0; i < states.size(); ++i)
+			m_init[i] = m_table->ToIndex(states[i]);
+		return *this;
+	}
+
+	BatchRunner& Begin() { m_flags |= PIRE_HIP_RUN_BEGIN; return *this; }     // run.h:375
+	BatchRunner& End() { m_flags |= PIRE_HIP_RUN_END; return *this; }         // run.h:376
+
+	/* Run(begin,end) for n strings: string i = text[offsets[i], offsets[i+1]).  Host pointers. */
+	BatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_text = text;
+		m_offsets = offsets;
+		m_n = n;
+		m_ran = false;
+		return *this;
+	}
+
+	/* Convenience: a vector of strings (copied into one buffer). */
+	BatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_ownText.clear();
+		m_ownOffsets.assign(1, 0);
+		for (size_t i = 0; i < strings.size(); ++i) {
+			m_ownText.append(strings[i]);
+			m_ownOffsets.push_back(m_ownText.size());
+		}
+		return Run(m_ownText.data(), m_ownOffsets.data(), strings.size());
+	}
+
+	/* RunHelper::State() per string (run.h:378). */
+	const std::vector<State>& States()
+	{
+		Execute();
+		return m_states;
+	}
+
+	/* operator bool of RunHelper per string (run.h:380): Final(State()). */
+	const std::vector<char>& Finals()
+	{
+		Execute();
+		return m_final;
+	}
+
+	/* [0] strings ending in a final state, [1] strings scanned, [2+r] strings accepting regexp r. */
+	const std::vector<uint64_t>& MatchCounts()
+	{
+		Execute();
+		return m_counts;
+	}
+
+private:
+	void Execute()
+	{
+		if (m_ran)
+			return;
+		if (!m_init.empty() && m_init.size() != m_n)
+			throw Pire::Error("pire_hip: From() and Run() disagree on the number of strings");
+		std::vector<uint32_t> idx(m_n);
+		std::vector<uint8_t> fin(m_n);
+		pire_hip_table_info info;
+		Check(pire_hip_table_get_info(m_table->Handle(), &info));
+		m_counts.assign(size_t(info.regexps) + 2, 0);
+		static const uint64_t kNoOffsets[1] = {0};
+		Check(pire_hip_run(m_table->Handle(), m_text, m_n ? m_offsets : kNoOffsets, m_n, m_flags,
+		                   m_init.empty() ? nullptr : m_init.data(), idx.data(), fin.data(), m_counts.data(), nullptr));
+		m_states.resize(m_n);
+		m_final.resize(m_n);
+		for (size_t i = 0; i < m_n; ++i) {
+			m_states[i] = m_table->ToState(idx[i]);
+			m_final[i] = char(fin[i]);
+		}
+		m_ran = true;
+	}
+
+	BatchRunner(const BatchRunner&);
+	BatchRunner& operator=(const BatchRunner&);
+
+	Table<Scanner>* m_own;
+	const Table<Scanner>* m_table;
+	uint32_t m_flags;
+	const char* m_text;
+	const uint64_t* m_offsets;
+	size_t m_n;
+	bool m_ran;
+	std::vector<uint32_t> m_init;
+	std::vector<State> m_states;
+	std::vector<char> m_final;
+	std::vector<uint64_t> m_counts;
+	ystring m_ownText;
+	std::vector<uint64_t> m_ownOffsets;
+};
+
+template <class Scanner>
+BatchRunner<Scanner>* NewBatchRunner(const Scanner& sc) { return new BatchRunner<Scanner>(sc); }
+
+}  // namespace Hip
+}  // namespace Pire
+
+#endif

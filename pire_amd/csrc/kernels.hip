@@ -52,6 +52,7 @@ __host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps)
 
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
 constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
+constexpr uint32_t kDebugNoStep = 1u << 29;     // internal, never set through the C ABI
 
 // Cooperative load of the LDS-resident part of the table.
 __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
@@ -209,28 +210,53 @@ __global__ __launch_bounds__(256) void ScanGenericKernel(ScanParams p)
 // (profiles/micro_loadpath_r01.log) the per-lane line-sized access streams at the same ~6.2 TB/s as a fully
 // coalesced read, so all of the LDS is left for the table.
 
-// One 128-byte tile = exactly one cache line per lane, as 8 x global_load_dwordx4 into 32 VGPRs.
+// ---- tile loads -------------------------------------------------------------------------------------------
+// A tile is 128 bytes (one cache line) of each of the wave's 64 strings.  It is fetched with 8 x
+// global_load_dwordx4 in which EIGHT ADJACENT LANES COVER ONE WHOLE LINE: instruction j, lane l reads
+//     chunk (l & 7) of string  s0 + (l & ~7) + j        (16 bytes)
+// so every instruction touches 8 full lines instead of 64 partial ones.  Measured on MI355X
+// (profiles/r01_pmc_summary_strided_16w_nbuf3.txt): with one-line-per-lane loads the L1 (TCP) tag pipeline was the
+// binding unit -- TA busy 75 %, TA stalled by TC 56 %, 0.63 lane-accesses/clk/CU -- and `nt` could not be used
+// because each line was touched by 8 separate instructions.  With whole-line instructions the same bytes cost
+// 1/8 of the L1 accesses and stream with `nt`.
+// After the loads, lane 8g+k holds in register j chunk k of string 8g+j; an 8x8 transpose across each group of 8
+// lanes (TransposeTile, DPP only, no LDS) leaves lane 8g+j with chunks 0..7 of its own string in registers 0..7.
 //
 // The loads are issued from inline asm and waited for with hand-counted s_waitcnt vmcnt(N).  Reason (measured,
 // DESIGN.md section 6): hipcc's own wait insertion turns every loop-carried prefetch into `s_waitcnt vmcnt(0)` at
 // the tile boundary, which collapses an N-deep register pipeline to depth 1.  Counting is safe with foreign VMEM
 // ops in the queue: loads return in order among themselves, so "at most 8*k outstanding" implies every load issued
 // before the last k tiles has landed; extra compiler-issued ops only make the wait stricter.
-__device__ __forceinline__ void IssueTile(u32x4 (&r)[8], const void* src)
+// "+v": the tile registers are updated IN PLACE, so the compiler has no reason to copy a slot that is in flight.
+template <bool NT>
+__device__ __forceinline__ void IssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride)
 {
-	// "+v": the tile registers are updated IN PLACE, so a ring slot is one fixed set of 32 VGPRs for the whole
-	// kernel and the compiler has no reason to copy a slot whose loads are still in flight.
-	asm volatile(
-		"global_load_dwordx4 %0, %8, off\n\t"
-		"global_load_dwordx4 %1, %8, off offset:16\n\t"
-		"global_load_dwordx4 %2, %8, off offset:32\n\t"
-		"global_load_dwordx4 %3, %8, off offset:48\n\t"
-		"global_load_dwordx4 %4, %8, off offset:64\n\t"
-		"global_load_dwordx4 %5, %8, off offset:80\n\t"
-		"global_load_dwordx4 %6, %8, off offset:96\n\t"
-		"global_load_dwordx4 %7, %8, off offset:112"
-		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-		: "v"(src));
+	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
+	if (NT)
+		asm volatile(
+			"global_load_dwordx4 %0, %8, %9 nt\n\t"
+			"global_load_dwordx4 %1, %8, %10 nt\n\t"
+			"global_load_dwordx4 %2, %8, %11 nt\n\t"
+			"global_load_dwordx4 %3, %8, %12 nt\n\t"
+			"global_load_dwordx4 %4, %8, %13 nt\n\t"
+			"global_load_dwordx4 %5, %8, %14 nt\n\t"
+			"global_load_dwordx4 %6, %8, %15 nt\n\t"
+			"global_load_dwordx4 %7, %8, %16 nt"
+			: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+			: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+	else
+		asm volatile(
+			"global_load_dwordx4 %0, %8, %9\n\t"
+			"global_load_dwordx4 %1, %8, %10\n\t"
+			"global_load_dwordx4 %2, %8, %11\n\t"
+			"global_load_dwordx4 %3, %8, %12\n\t"
+			"global_load_dwordx4 %4, %8, %13\n\t"
+			"global_load_dwordx4 %5, %8, %14\n\t"
+			"global_load_dwordx4 %6, %8, %15\n\t"
+			"global_load_dwordx4 %7, %8, %16"
+			: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+			: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
 }
 
 // Wait until at most TILES_BEHIND tiles issued after `r` are still in flight; names r so nothing reads it earlier.
@@ -240,6 +266,45 @@ __device__ __forceinline__ void WaitTile(u32x4 (&r)[8])
 	asm volatile("s_waitcnt vmcnt(%8)"
 	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
 	             : "n"(TILES_BEHIND * 8));
+}
+
+// One butterfly stage of the 8x8 transpose: exchange (register bit D) with (lane bit D) for the pair x = reg k,
+// y = reg k|D:   x'[l] = (l & D) ? y[l ^ D] : x[l],    y'[l] = (l & D) ? y[l] : x[l ^ D].
+template <int D>
+__device__ __forceinline__ void Butterfly(uint32_t& x, uint32_t& y, bool laneBit)
+{
+	if (D == 4) {
+		// row_shr:4 into banks 1,3 (lanes with bit 2 set read lane l-4); row_shl:4 into banks 0,2
+		const uint32_t nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
+		const uint32_t ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
+		x = nx;
+		y = ny;
+	} else {
+		constexpr int ctrl = D == 1 ? 0xB1 /* quad_perm:[1,0,3,2] */ : 0x4E /* quad_perm:[2,3,0,1] */;
+		const uint32_t xp = __builtin_amdgcn_mov_dpp(x, ctrl, 0xF, 0xF, true);
+		const uint32_t yp = __builtin_amdgcn_mov_dpp(y, ctrl, 0xF, 0xF, true);
+		x = laneBit ? yp : x;
+		y = laneBit ? y : xp;
+	}
+}
+
+__device__ __forceinline__ void TransposeTile(u32x4 (&r)[8], uint32_t lane)
+{
+	const bool b0 = lane & 1, b1 = lane & 2;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		uint32_t d[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			d[k] = r[k][w];
+		Butterfly<1>(d[0], d[1], b0); Butterfly<1>(d[2], d[3], b0); Butterfly<1>(d[4], d[5], b0); Butterfly<1>(d[6], d[7], b0);
+		Butterfly<2>(d[0], d[2], b1); Butterfly<2>(d[1], d[3], b1); Butterfly<2>(d[4], d[6], b1); Butterfly<2>(d[5], d[7], b1);
+		Butterfly<4>(d[0], d[4], false); Butterfly<4>(d[1], d[5], false); Butterfly<4>(d[2], d[6], false); Butterfly<4>(d[3], d[7], false);
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			r[k][w] = d[k];
+		__builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the transpose's temporaries to ~10 VGPRs
+	}
 }
 
 // The hot rows sit at LDS byte address 0 (the kernels declare no static __shared__, so the dynamic region
@@ -314,174 +379,91 @@ __device__ __forceinline__ void ZeroTile(u32x4 (&r)[8])
 		r[k] = u32x4{0, 0, 0, 0};
 }
 
+__device__ __forceinline__ uint64_t Uniform64(uint64_t v)
+{
+	const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
+	const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+	return (uint64_t(hi) << 32) | lo;
+}
+
 // One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1
 // ahead (index clamped to the last tile, so the steady-state loop has no conditional loads), wait until the
-// current slot has landed, walk it.
-template <int NBUF>
-__device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t* base,
-                                      uint32_t t, uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8],
-                                      uint32_t& hs, uint32_t& cold)
+// current slot has landed, transpose it into lane-owns-string order, walk it.
+template <int NBUF, bool NT>
+__device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
+                                      uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile, u32x4 (&cur)[8],
+                                      u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
 {
 	const uint32_t ahead = t + (NBUF - 1) < lastTile ? t + (NBUF - 1) : lastTile;
 	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
-		IssueTile(refill, base + size_t(ahead) * 128);
+		IssueTile<NT>(refill, voff, rowBase + uint64_t(ahead) * 128, p.stride);
 	WaitTile<NBUF - 1>(cur);
+	TransposeTile(cur, lane);
+	if (p.flags & kDebugNoStep) {      // measurement knob only (PIRE_HIP_DEBUG_NOSTEP): stream + transpose, no walk
+		hs ^= (cur[0].x ^ cur[7].w) & 1;
+		return;
+	}
 	StepTile(p, lds, L, cur, hs, cold);
 }
 
-template <int WAVES, int NBUF, int MINW>
+// Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
+// the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
+// gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
+template <int WAVES, int NBUF, bool NT, int MINW>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
-	static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
+	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
+	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
 	LoadTableToLds(p, lds, L);
 
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t ntasks = (p.n + 63) / 64;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = p.n / 64;                // whole tasks only
 	const uint32_t ntiles = uint32_t(p.len / 128);   // >= 1 (TiledEligible)
 	const uint32_t lastTile = ntiles - 1;
 	const uint32_t groups = ntiles / NBUF;
 	const uint32_t rem = ntiles % NBUF;
+	// per-lane byte offset inside a task's tile: string (lane & ~7) [+ j per instruction], chunk (lane & 7)
+	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
 
-	// Ring slots: tile t lives in slot t % NBUF.  Fixed registers for the whole kernel (see IssueTile).
-	u32x4 a[8], b[8], c[8];
+	// Ring slots: tile t lives in slot t % 2.
+	u32x4 a[8], b[8];
 	ZeroTile(a);
 	ZeroTile(b);
-	if (NBUF == 3)
-		ZeroTile(c);
 
 	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += uint64_t(gridDim.x) * WAVES) {
-		const uint64_t s = task * 64 + lane;
-		const bool active = s < p.n;
-		const uint64_t sc = active ? s : p.n - 1;
-		const uint8_t* base = p.text + sc * p.stride;
+		const uint64_t s0 = task * 64;
+		const uint64_t s = s0 + lane;
+		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
 
-		uint32_t cold = StartState(p, sc);
+		uint32_t cold = StartState(p, s);
 		uint32_t hs = cold < p.hot ? cold : p.hot;
 
 		bool done = false;
-		if (NBUF == 3) {
-			IssueTile(a, base);
-			IssueTile(b, base + size_t(lastTile < 1 ? lastTile : 1) * 128);
-			for (uint32_t g = 0; g < groups && !done; ++g) {
-				const uint32_t t = g * 3;
-				Phase<3>(p, lds, L, base, t, lastTile, a, c, hs, cold);
-				Phase<3>(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
-				Phase<3>(p, lds, L, base, t + 2, lastTile, c, b, hs, cold);
-				done = AllAbsorbing(p, lds, L, hs);
-			}
-			if (!done && rem >= 1) {
-				WaitTile<1>(a);      // only slot b's refill was issued after it
-				StepTile(p, lds, L, a, hs, cold);
-			}
-			if (!done && rem == 2) {
-				WaitTile<0>(b);
-				StepTile(p, lds, L, b, hs, cold);
-			}
-		} else {
-			IssueTile(a, base);
-			for (uint32_t g = 0; g < groups && !done; ++g) {
-				const uint32_t t = g * 2;
-				Phase<2>(p, lds, L, base, t, lastTile, a, b, hs, cold);
-				Phase<2>(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
-				done = AllAbsorbing(p, lds, L, hs);
-			}
-			if (!done && rem == 1) {
-				WaitTile<0>(a);
-				StepTile(p, lds, L, a, hs, cold);
-			}
-		}
-
-		uint32_t st = hs != p.hot ? hs : cold;
-		// tail shorter than a tile: exact steps straight from memory (len % 16 == 0 is not required here)
-		for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
-			st = SlowStep(p, lds, L, st, base[i]);
-		Finish(p, lds, L, s, active, st);
-	}
-	FlushCounts(p, lds, L);
-}
-
-// ------------------------------------------------------------------------------------------ tiled kernel, interleaved refill
-// Same walk, but the refill of the tile two ahead is spread over the current tile: one global_load_dwordx4 after
-// each 16-byte chunk instead of a burst of eight.  (A/B candidate)
-
-template <int OFF>
-__device__ __forceinline__ void IssueOne(u32x4& r, const void* src)
-{
-	asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(r) : "v"(src), "n"(OFF));
-}
-
-__device__ __forceinline__ void PhaseIL(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
-                                        const uint8_t* base, uint32_t t, uint32_t lastTile, u32x4 (&cur)[8],
-                                        u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
-{
-	const uint32_t ahead = t + 2 < lastTile ? t + 2 : lastTile;
-	const uint8_t* src = base + size_t(ahead) * 128;
-	WaitTile<1>(cur);
-	StepChunk(p, lds, L, cur[0], hs, cold); IssueOne<0>(refill[0], src);
-	StepChunk(p, lds, L, cur[1], hs, cold); IssueOne<16>(refill[1], src);
-	StepChunk(p, lds, L, cur[2], hs, cold); IssueOne<32>(refill[2], src);
-	StepChunk(p, lds, L, cur[3], hs, cold); IssueOne<48>(refill[3], src);
-	StepChunk(p, lds, L, cur[4], hs, cold); IssueOne<64>(refill[4], src);
-	StepChunk(p, lds, L, cur[5], hs, cold); IssueOne<80>(refill[5], src);
-	StepChunk(p, lds, L, cur[6], hs, cold); IssueOne<96>(refill[6], src);
-	StepChunk(p, lds, L, cur[7], hs, cold); IssueOne<112>(refill[7], src);
-}
-
-template <int WAVES, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernelIL(ScanParams p)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
-	LoadTableToLds(p, lds, L);
-
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint64_t ntasks = (p.n + 63) / 64;
-	const uint32_t ntiles = uint32_t(p.len / 128);
-	const uint32_t lastTile = ntiles - 1;
-	const uint32_t groups = ntiles / 3;
-	const uint32_t rem = ntiles % 3;
-
-	u32x4 a[8], b[8], c[8];
-	ZeroTile(a);
-	ZeroTile(b);
-	ZeroTile(c);
-
-	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += uint64_t(gridDim.x) * WAVES) {
-		const uint64_t s = task * 64 + lane;
-		const bool active = s < p.n;
-		const uint64_t sc = active ? s : p.n - 1;
-		const uint8_t* base = p.text + sc * p.stride;
-
-		uint32_t cold = StartState(p, sc);
-		uint32_t hs = cold < p.hot ? cold : p.hot;
-
-		bool done = false;
-		IssueTile(a, base);
-		IssueTile(b, base + size_t(lastTile < 1 ? lastTile : 1) * 128);
+		IssueTile<NT>(a, voff, rowBase, p.stride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
-			const uint32_t t = g * 3;
-			PhaseIL(p, lds, L, base, t, lastTile, a, c, hs, cold);
-			PhaseIL(p, lds, L, base, t + 1, lastTile, b, a, hs, cold);
-			PhaseIL(p, lds, L, base, t + 2, lastTile, c, b, hs, cold);
+			const uint32_t t = g * 2;
+			Phase<2, NT>(p, lds, L, rowBase, voff, lane, t, lastTile, a, b, hs, cold);
+			Phase<2, NT>(p, lds, L, rowBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
 			done = AllAbsorbing(p, lds, L, hs);
 		}
-		if (!done && rem >= 1) {
-			WaitTile<1>(a);
+		if (!done && rem == 1) {
+			WaitTile<0>(a);
+			TransposeTile(a, lane);
 			StepTile(p, lds, L, a, hs, cold);
-		}
-		if (!done && rem == 2) {
-			WaitTile<0>(b);
-			StepTile(p, lds, L, b, hs, cold);
 		}
 
 		uint32_t st = hs != p.hot ? hs : cold;
-		for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
-			st = SlowStep(p, lds, L, st, base[i]);
-		Finish(p, lds, L, s, active, st);
+		// tail shorter than a tile: exact steps straight from memory
+		if (!done) {
+			const uint8_t* base = p.text + s * p.stride;
+			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
+				st = SlowStep(p, lds, L, st, base[i]);
+		}
+		Finish(p, lds, L, s, true, st);
 	}
 	FlushCounts(p, lds, L);
 }
@@ -619,7 +601,7 @@ int LaunchGeneric(const ScanParams& p, hipStream_t stream)
 
 bool TiledEligible(const ScanParams& p)
 {
-	return p.offsets == nullptr && p.n > 0 && p.len >= 128 && (p.stride % 16) == 0 &&
+	return p.offsets == nullptr && p.n >= 64 && p.len >= 128 && (p.stride % 16) == 0 && p.stride * 64 < (1ull << 31) &&
 	       (reinterpret_cast<uintptr_t>(p.text) % 16) == 0;
 }
 
@@ -635,19 +617,31 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	}();
 	static const bool noload = getenv("PIRE_HIP_DEBUG_NOLOAD") != nullptr;
 	ScanParams q = p;
+	static const bool nostep = getenv("PIRE_HIP_DEBUG_NOSTEP") != nullptr;
 	if (noload)
 		q.flags |= kDebugNoRefill;
-	const ScanParams& p2 = q;
+	if (nostep)
+		q.flags |= kDebugNoStep;
+	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
+	int rc;
 	switch (variant) {
-	case 1:  return LaunchScan(ScanTiledKernel<16, 2, 1>, p2, 1024, L.total, stream);
-	case 2:  return LaunchScan(ScanTiledKernel<12, 2, 6>, p2, 768, L.total, stream);
-	case 3:  return LaunchScan(ScanTiledKernel<10, 2, 5>, p2, 640, L.total, stream);
-	case 4:  return LaunchScan(ScanTiledKernel<12, 3, 1>, p2, 768, L.total, stream);
-	case 5:  return LaunchScan(ScanTiledKernel<8, 3, 1>, p2, 512, L.total, stream);
-	case 6:  return LaunchScan(ScanTiledKernelIL<16, 1>, p2, 1024, L.total, stream);
-	case 7:  return LaunchScan(ScanTiledKernelIL<12, 1>, p2, 768, L.total, stream);
-	default: return LaunchScan(ScanTiledKernel<16, 3, 1>, p2, 1024, L.total, stream);
+	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5>, q, 1024, L.total, stream); break;
+	case 2:  rc = LaunchScan(ScanTiledKernel<10, 2, true, 5>, q, 640, L.total, stream); break;
+	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5>, q, 1024, L.total, stream); break;
 	}
+	if (rc != PIRE_HIP_OK || q.n == p.n)
+		return rc;
+	ScanParams tail = p;
+	tail.flags &= ~(kDebugNoRefill | kDebugNoStep);
+	tail.n = p.n - q.n;
+	tail.text = p.text + q.n * p.stride;
+	if (p.initIdx)
+		tail.initIdx = p.initIdx + q.n;
+	if (p.outIdx)
+		tail.outIdx = p.outIdx + q.n;
+	if (p.outFinal)
+		tail.outFinal = p.outFinal + q.n;
+	return LaunchGeneric(tail, stream);
 }
 
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream)

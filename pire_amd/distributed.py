@@ -1,0 +1,66 @@
+"""Multi-GPU plumbing of the scan path: one process per GPU, strings sharded by index, one tiny collective.
+
+The path shards naturally (each string's walk is independent, pire/run.h:271-275), so there is NO data-path
+collective: rank r owns the contiguous global string range shard_range(n_total, r, world) and scans it locally.
+The only exchange is the sum of the uint64[regexps+2] match counters (80 B for 8 regexps) -- an all-reduce over
+RCCL (torch.distributed backend "nccl" on ROCm) -- and, for timing, a MAX over ranks."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) of global string indices owned by `rank` (sizes differ by at most 1)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def world_info() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str, device=None):
+    """Initialise torch.distributed (rendezvous on 127.0.0.1 unless MASTER_ADDR says otherwise)."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if dist.is_initialized():
+        return
+    if device is not None and backend == "nccl":
+        dist.init_process_group(backend=backend, device_id=device)
+    else:
+        dist.init_process_group(backend=backend)
+
+
+def allreduce_counts(counts):
+    """Sum the match counters over all ranks in place (no-op for a single process)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    return counts
+
+
+def max_over_ranks(seconds: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

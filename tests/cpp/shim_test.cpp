@@ -1,0 +1,128 @@
+// Drop-in check of include/pire_hip/batch_runner.hpp against the UNMODIFIED reference, in the reference's own
+// vocabulary: for every (pattern set, string) the GPU BatchRunner must return exactly the Scanner::State that
+//     Pire::Runner(sc).Begin().Run(str).End().State()            (run.h:365-392; call shape of tests/common.h:158-169)
+// returns, so sc.Final(st) and sc.AcceptedRegexps(st) agree as well.  Patterns/strings are those of the reference's
+// tests (tests/pire_ut.cpp: String, Boundaries, Primitives, Repetition, TestShortcuts, Glue, Aligned, EmptyScanner).
+// Built only where /root/reference exists (tests/cpp/Makefile); the binary ships to the GPU box.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <pire/pire.h>
+#include <pire_hip/batch_runner.hpp>
+
+static int g_checks = 0, g_fail = 0;
+#define CHECK(cond) do { ++g_checks; if (!(cond)) { ++g_fail; fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); } } while (0)
+
+static Pire::Fsm Parse(const char* re, bool surround = true)
+{
+	Pire::Fsm fsm = Pire::Lexer(re, re + strlen(re)).Parse();
+	if (surround)
+		fsm.Surround();
+	return fsm;
+}
+
+template <class Scanner>
+static void CompareAll(const Scanner& sc, const std::vector<Pire::ystring>& strings)
+{
+	Pire::Hip::BatchRunner<Scanner> gpu(sc);
+	const std::vector<typename Scanner::State>& st = gpu.Begin().Run(strings).End().States();
+	const std::vector<char>& fin = gpu.Finals();
+	CHECK(st.size() == strings.size());
+	uint64_t finals = 0;
+	for (size_t i = 0; i < strings.size(); ++i) {
+		typename Scanner::State want = Pire::Runner(sc).Begin().Run(strings[i]).End().State();
+		CHECK(st[i] == want);                                  // the very same row address inside the host scanner
+		CHECK((fin[i] != 0) == sc.Final(want));
+		auto a = sc.AcceptedRegexps(st[i]);
+		auto b = sc.AcceptedRegexps(want);
+		CHECK((a.second - a.first) == (b.second - b.first));
+		finals += sc.Final(want) ? 1 : 0;
+	}
+	CHECK(gpu.MatchCounts()[0] == finals);
+	CHECK(gpu.MatchCounts()[1] == strings.size());
+}
+
+template <class Scanner>
+static void TestSuite()
+{
+	std::vector<Pire::ystring> text = {
+		"def abc ghi", "abc", "def abd ghi", "abc ghi", "def abc", "xaez", "xadddddddddddddddddddddddez", "xafez",
+		"xx", "xxx", "xxxxxx", "xxxxxxx", "", "hello world", "say hello   wod", "hello world!",
+		"......................................aaa.............", "......................................aab.............",
+		"ZZZZZabcdeZZZZZZ", "ZZZZZZZZZZZZZabcdf", "aaabbb", "ccc", "HeadInnerInnerTail",
+		Pire::ystring(5000, 'x') + "abc" + Pire::ystring(777, 'y'),
+	};
+	const char* patterns[] = {"abc", "^abc", "abc$", "ad*e", "^x{3,6}$", "hello\\s+w.+d$", "aaa", "[ab]{3}", "abcde",
+	                          "Head(Inner)*Tail"};
+	for (const char* re : patterns) {
+		Scanner sc = Parse(re).template Compile<Scanner>();
+		CompareAll(sc, text);
+	}
+	// Scanner::Glue -- pire_ut.cpp:648-705
+	Scanner sc1 = Parse("aaa").template Compile<Scanner>();
+	Scanner sc2 = Parse("bbb").template Compile<Scanner>();
+	Scanner glued = Scanner::Glue(sc1, sc2);
+	CHECK(glued.RegexpsCount() == 2);
+	CompareAll(glued, text);
+	{
+		Pire::Hip::BatchRunner<Scanner> gpu(glued);
+		std::vector<Pire::ystring> s = {"aaa", "bbb", "aaabbb", "ccc"};
+		const auto& st = gpu.Begin().Run(s).End().States();
+		auto r0 = glued.AcceptedRegexps(st[0]);
+		CHECK(r0.second - r0.first == 1 && *r0.first == 0);
+		auto r1 = glued.AcceptedRegexps(st[1]);
+		CHECK(r1.second - r1.first == 1 && *r1.first == 1);
+		auto r2 = glued.AcceptedRegexps(st[2]);
+		CHECK(r2.second - r2.first == 2 && r2.first[0] == 0 && r2.first[1] == 1);
+		auto r3 = glued.AcceptedRegexps(st[3]);
+		CHECK(r3.second == r3.first);
+		CHECK(gpu.MatchCounts()[2] == 2 && gpu.MatchCounts()[3] == 2);
+	}
+	Scanner sc3 = Parse("ccc").template Compile<Scanner>();
+	Scanner glued3 = Scanner::Glue(sc3, glued);
+	CHECK(glued3.RegexpsCount() == 3);
+	CompareAll(glued3, text);
+	// resume from saved states: Runner(sc, st) -- run.h:391-392
+	{
+		Scanner sc = Parse("hello\\s+w.+d$").template Compile<Scanner>();
+		std::vector<Pire::ystring> head = {"say hel", "hello", "", "hello w"}, tail = {"lo   wod", " world!", "hello world", "orld"};
+		Pire::Hip::Table<Scanner> table(sc);
+		Pire::Hip::BatchRunner<Scanner> first(table);
+		std::vector<typename Scanner::State> mid = first.Begin().Run(head).States();
+		Pire::Hip::BatchRunner<Scanner> second(table);
+		const auto& end = second.From(mid).Run(tail).End().States();
+		for (size_t i = 0; i < head.size(); ++i) {
+			typename Scanner::State want = Pire::Runner(sc).Begin().Run(head[i] + tail[i]).End().State();
+			CHECK(end[i] == want);
+		}
+	}
+	// empty scanner never matches and must not crash -- pire_ut.cpp:760-830
+	{
+		Scanner empty;
+		CHECK(empty.Empty());
+		Pire::Hip::BatchRunner<Scanner> gpu(empty);
+		std::vector<Pire::ystring> s = {"a strin", ""};
+		const auto& fin = gpu.Begin().Run(s).End().Finals();
+		CHECK(!fin[0] && !fin[1]);
+	}
+}
+
+int main()
+{
+	try {
+		TestSuite<Pire::Scanner>();
+		TestSuite<Pire::NonrelocScanner>();
+		TestSuite<Pire::ScannerNoMask>();
+	} catch (const std::exception& e) {
+		fprintf(stderr, "exception: %s\n", e.what());
+		return 2;
+	}
+	if (g_fail) {
+		fprintf(stderr, "FAILED %d of %d checks\n", g_fail, g_checks);
+		return 1;
+	}
+	printf("OK(shim %d checks)\n", g_checks);
+	return 0;
+}

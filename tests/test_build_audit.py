@@ -1,0 +1,40 @@
+"""Static audit of the compiled gfx950 kernels (no GPU needed; hipcc cross-compiles).
+
+The tiled kernel issues its HBM loads from inline asm and waits for them with hand-counted s_waitcnt, so the
+compiler does not know those registers are in flight.  If it ever spills (or otherwise copies) a tile register
+between the load and the wait, the scan reads garbage silently.  This was observed with a three-slot ring
+(DESIGN.md section 6).  Pin: every instantiated scan kernel has NO scratch and NO spills."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_scan_kernels_have_no_scratch_and_no_spills():
+    src = os.path.join(ROOT, "pire_amd", "csrc", "kernels.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-c", src, "-o", "/dev/null",
+                        "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    kernels = {}
+    cur = None
+    for line in r.stdout.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    tiled = {k: v for k, v in kernels.items() if "ScanTiledKernel" in k}
+    assert tiled, "no tiled kernel instantiation found"
+    for name, res in list(tiled.items()) + [(k, v) for k, v in kernels.items() if "ScanGenericKernel" in k]:
+        assert res.get("ScratchSize", -1) == 0, (name, res)
+        assert res.get("VGPRs Spill", -1) == 0, (name, res)   # SGPR spills go to VGPR lanes, harmless
+    for name, res in tiled.items():
+        assert res["VGPRs"] <= 96, (name, res)   # 5 waves/SIMD: room for 16 waves/CU plus the ring
