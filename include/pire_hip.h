@@ -68,6 +68,9 @@ typedef struct pire_hip_table_info {
 	uint32_t lds_table_bytes; /* LDS bytes the table occupies per workgroup */
 	uint64_t device_bytes;    /* HBM bytes of the device-side table */
 	uint64_t ref_buf_size;    /* Scanner::BufSize()       multi.h:297-305 */
+	uint64_t last_trap_samples; /* cold-state samples seen by the most recent pire_hip_table_adapt() */
+	uint32_t adaptations;     /* how many times pire_hip_table_adapt() changed the LDS rows */
+	uint32_t reserved;
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */
@@ -84,6 +87,16 @@ int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** ou
 
 /* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
 int pire_hip_table_upload(pire_hip_table* t);
+
+/*
+ * Re-rank the LDS-resident dense rows from what the scans on this table actually visited (the kernels keep
+ * sampled visit counters on the device).  A table is created with rows ranked by a byte model of "typical"
+ * text; after a representative batch, adapt() promotes the states the data really spends its time in, so that
+ * later batches stay on the one-LDS-gather-per-byte path.  Purely a performance call: results are bit-exact
+ * with or without it.  Synchronises the device; must not run concurrently with scans on the same table.
+ * *changed_rows (nullable) receives the number of rows that entered the dense set.
+ */
+int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows);
 
 void pire_hip_table_destroy(pire_hip_table* t);
 

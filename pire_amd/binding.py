@@ -43,6 +43,9 @@ class TableInfo(C.Structure):
         ("lds_table_bytes", C.c_uint32),
         ("device_bytes", C.c_uint64),
         ("ref_buf_size", C.c_uint64),
+        ("last_trap_samples", C.c_uint64),
+        ("adaptations", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -65,6 +68,7 @@ _lib = None
 ABI = [
     ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_upload", C.c_int, [C.c_void_p]),
+    ("pire_hip_table_adapt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("pire_hip_table_destroy", None, [C.c_void_p]),
     ("pire_hip_table_get_info", C.c_int, [C.c_void_p, C.POINTER(TableInfo)]),
     ("pire_hip_table_final", C.c_int, [C.c_void_p, C.c_uint32]),
@@ -180,6 +184,13 @@ class Table:
         h = np.empty((self.info.hot_states + 1, 256), dtype=np.uint8)
         _check(lib().pire_hip_table_layout(self._h, o.ctypes.data, h.ctypes.data))
         return o, h
+
+    def adapt(self) -> int:
+        """Re-rank the LDS rows from the visit counters of earlier scans; returns the number of rows promoted."""
+        n = C.c_uint32(0)
+        _check(lib().pire_hip_table_adapt(self._h, C.byref(n)))
+        self.refresh_info()
+        return n.value
 
     def upload(self):
         _check(lib().pire_hip_table_upload(self._h))

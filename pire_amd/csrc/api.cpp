@@ -80,6 +80,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->acceptMaskPerm = d.acceptMaskPerm;
 	p->acceptOffPerm = d.acceptOffPerm;
 	p->acceptIds = d.acceptIds;
+	p->visitHot = d.visitHot;
+	p->visitCold = d.visitCold;
 	p->states = h.states;
 	p->letters = h.letters;
 	p->regexps = h.regexps;
@@ -272,6 +274,15 @@ int pire_hip_table_upload(pire_hip_table* t)
 	return UploadTable(t);
 }
 
+int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	return AdaptTable(t, changed_rows);
+}
+
 void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)
@@ -297,8 +308,10 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 	out->header_size = h.headerSize;
 	out->row_stride = h.rowStride;
 	out->hot_states = h.hot;
-	out->lds_table_bytes = (h.hot + 1) * 256 + 256 + 528;
+	out->lds_table_bytes = (h.hot + 1) * 256 + 256 + 528 + 1024;
 	out->device_bytes = t->dev.bytes;
+	out->adaptations = h.adaptations;
+	out->last_trap_samples = h.lastTrapSamples;
 	out->ref_buf_size = h.refBufSize;
 	return PIRE_HIP_OK;
 }

@@ -49,6 +49,9 @@ struct HostTable {
 	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
+	std::vector<double> priorMass;    // [states] expected visits under the byte model, max-normalised (orig numbering)
+	uint64_t lastTrapSamples = 0;     // cold-state samples seen by the most recent pire_hip_table_adapt()
+	uint32_t adaptations = 0;
 };
 
 // Device image (one HIP device).
@@ -64,6 +67,8 @@ struct DeviceTable {
 	uint64_t* acceptMaskPerm = nullptr;  // [states] bit r = regexp r accepted (regexps <= 64), else null
 	uint64_t* acceptOffPerm = nullptr;   // [states+1] CSR (regexps > 64)
 	uint64_t* acceptIds = nullptr;
+	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
+	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
 	uint64_t bytes = 0;
 };
 
@@ -90,6 +95,8 @@ struct ScanParams {
 	const uint64_t* acceptMaskPerm;
 	const uint64_t* acceptOffPerm;
 	const uint64_t* acceptIds;
+	uint32_t* visitHot;
+	uint32_t* visitCold;
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;
@@ -110,6 +117,7 @@ int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_H
 // table.cpp
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t);
+int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
 void FreeDeviceTable(DeviceTable* d);
 
 // kernels.hip

@@ -36,6 +36,7 @@ struct LdsLayout {
 	uint32_t flagsOff;     // 256 B of hot flags
 	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
 	uint32_t countsOff;    // (regexps+2) u32 block-local counters
+	uint32_t histOff;      // 256 u32: sampled visits of hot ids (feeds pire_hip_table_adapt)
 	uint32_t total;
 };
 
@@ -46,13 +47,16 @@ __host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps)
 	l.flagsOff = l.hotBytes;
 	l.clsOff = l.flagsOff + 256;
 	l.countsOff = l.clsOff + 528;
-	l.total = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
+	l.histOff = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
+	l.total = l.histOff + 1024;
 	return l;
 }
 
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
 constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
 constexpr uint32_t kDebugNoStep = 1u << 29;     // internal, never set through the C ABI
+constexpr uint32_t kDebugNoColdCount = 1u << 28;
+constexpr uint32_t kDebugNoHist = 1u << 27;
 
 // Cooperative load of the LDS-resident part of the table.
 __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
@@ -69,6 +73,8 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 	if (p.outCounts)
 		for (uint32_t i = tid; i < p.regexps + 2; i += nthr)
 			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
+	for (uint32_t i = tid; i < 256; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.histOff)[i] = 0;
 	__syncthreads();
 }
 
@@ -144,9 +150,13 @@ __device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const 
 
 __device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
 {
+	__syncthreads();
+	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + L.histOff);
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+		if (hist[i])
+			atomicAdd(&p.visitHot[i], hist[i]);
 	if (!p.outCounts)
 		return;
-	__syncthreads();
 	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + L.countsOff);
 	for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
 		if (cnt[i])
@@ -333,7 +343,7 @@ __device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t
 
 // 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
 __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
-                                          const u32x4 v, uint32_t& hs, uint32_t& cold)
+                                          const u32x4 v, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
 {
 	const uint32_t hs0 = hs;
 #pragma unroll
@@ -351,16 +361,21 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 		} else {
 			hs = p.hot;
 			cold = f;
+			// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
+			// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
+			// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
+			if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
+				atomicAdd(&p.visitCold[f], 1u);
 		}
 	}
 }
 
 __device__ __forceinline__ void StepTile(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
-                                         const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold)
+                                         const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold, uint32_t tile)
 {
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
-		StepChunk(p, lds, L, r[k], hs, cold);
+		StepChunk(p, lds, L, r[k], hs, cold, (tile * 8 + k) & 63);
 }
 
 // Wave-wide early out (north_star: "wavefront ballot/any for early-out on dead states"): once every lane sits
@@ -399,11 +414,13 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 		IssueTile<NT>(refill, voff, rowBase + uint64_t(ahead) * 128, p.stride);
 	WaitTile<NBUF - 1>(cur);
 	TransposeTile(cur, lane);
+	if (lane == (t & 63) && !(p.flags & kDebugNoHist))   // visit sample: one lane per wave per tile, rotating
+		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs, 1u);
 	if (p.flags & kDebugNoStep) {      // measurement knob only (PIRE_HIP_DEBUG_NOSTEP): stream + transpose, no walk
 		hs ^= (cur[0].x ^ cur[7].w) & 1;
 		return;
 	}
-	StepTile(p, lds, L, cur, hs, cold);
+	StepTile(p, lds, L, cur, hs, cold, t);
 }
 
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
@@ -453,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 		if (!done && rem == 1) {
 			WaitTile<0>(a);
 			TransposeTile(a, lane);
-			StepTile(p, lds, L, a, hs, cold);
+			StepTile(p, lds, L, a, hs, cold, lastTile);
 		}
 
 		uint32_t st = hs != p.hot ? hs : cold;
@@ -622,6 +639,10 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoRefill;
 	if (nostep)
 		q.flags |= kDebugNoStep;
+	if (getenv("PIRE_HIP_DEBUG_NOCOLDCOUNT"))
+		q.flags |= kDebugNoColdCount;
+	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
+		q.flags |= kDebugNoHist;
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
 	switch (variant) {
@@ -632,7 +653,7 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;
 	ScanParams tail = p;
-	tail.flags &= ~(kDebugNoRefill | kDebugNoStep);
+	tail.flags &= ~(kDebugNoRefill | kDebugNoStep | kDebugNoColdCount | kDebugNoHist);
 	tail.n = p.n - q.n;
 	tail.text = p.text + q.n * p.stride;
 	if (p.initIdx)

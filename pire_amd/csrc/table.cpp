@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <iterator>
 #include <cstring>
 #include <numeric>
 
@@ -90,22 +91,13 @@ std::vector<double> VisitMass(const HostTable& t, uint32_t start)
 	return mass;
 }
 
-void ChooseHotAndPermute(HostTable& t)
+// Renumber "hot first" by `score` (higher = hotter) and build the dense LDS rows.
+void PermuteByScore(HostTable& t, const std::vector<double>& score)
 {
 	const uint32_t N = t.states, C = t.letters;
-	// every string starts at Initialize() and (normally) takes BeginMark first; rank from both
-	std::vector<double> mass = VisitMass(t, t.initial);
-	{
-		const uint32_t afterBegin = t.next[size_t(t.initial) * C + t.cls[kBeginMark]];
-		std::vector<double> m2 = VisitMass(t, afterBegin);
-		for (uint32_t s = 0; s < N; ++s)
-			mass[s] += m2[s];
-		mass[afterBegin] += 1.0;
-		mass[t.initial] += 1.0;
-	}
 	std::vector<uint32_t> order(N);
 	std::iota(order.begin(), order.end(), 0u);
-	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return mass[a] > mass[b]; });
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
 	t.origOfPerm = order;
@@ -127,6 +119,26 @@ void ChooseHotAndPermute(HostTable& t)
 	t.hotFlags.assign(256, 0);
 	for (uint32_t pid = 0; pid < H; ++pid)
 		t.hotFlags[pid] = t.flags[order[pid]];
+}
+
+void ChooseHotAndPermute(HostTable& t)
+{
+	const uint32_t N = t.states, C = t.letters;
+	// every string starts at Initialize() and (normally) takes BeginMark first; rank from both
+	std::vector<double> mass = VisitMass(t, t.initial);
+	{
+		const uint32_t afterBegin = t.next[size_t(t.initial) * C + t.cls[kBeginMark]];
+		std::vector<double> m2 = VisitMass(t, afterBegin);
+		for (uint32_t s = 0; s < N; ++s)
+			mass[s] += m2[s];
+		mass[afterBegin] += 1.0;
+		mass[t.initial] += 1.0;
+	}
+	const double top = *std::max_element(mass.begin(), mass.end());
+	t.priorMass.resize(N);
+	for (uint32_t s = 0; s < N; ++s)
+		t.priorMass[s] = top > 0 ? mass[s] / top : 0.0;
+	PermuteByScore(t, t.priorMass);
 }
 
 }  // namespace
@@ -298,7 +310,7 @@ void FreeDeviceTable(DeviceTable* d)
 	if (d->device < 0)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
-	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds};
+	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -356,6 +368,10 @@ int UploadTable(pire_hip_table* t)
 		if (!(rc = Put(&d.acceptOffPerm, off, &d.bytes)))
 			rc = Put(&d.acceptIds, ids, &d.bytes);
 	}
+	if (!rc)
+		rc = Put(&d.visitHot, std::vector<uint32_t>(256, 0), &d.bytes);
+	if (!rc)
+		rc = Put(&d.visitCold, std::vector<uint32_t>(N, 0), &d.bytes);
 	if (rc) {
 		d.device = dev;
 		FreeDeviceTable(&d);
@@ -364,6 +380,56 @@ int UploadTable(pire_hip_table* t)
 	d.device = dev;
 	t->dev = d;
 	return PIRE_HIP_OK;
+}
+
+// Re-rank the dense LDS rows from what the kernels actually visited (see pire_hip_table_adapt in pire_hip.h).
+int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
+{
+	if (changedRows)
+		*changedRows = 0;
+	if (t->dev.device < 0)
+		return PIRE_HIP_OK;   // never ran: nothing observed
+	hipError_t e = hipDeviceSynchronize();
+	if (e != hipSuccess)
+		return HipFail(e, "hipDeviceSynchronize");
+	HostTable& h = t->host;
+	const uint32_t N = h.states, H = h.hot;
+	std::vector<uint32_t> hot(256), cold(N);
+	e = hipMemcpy(hot.data(), t->dev.visitHot, 256 * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess)
+		e = hipMemcpy(cold.data(), t->dev.visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
+	if (e != hipSuccess)
+		return HipFail(e, "hipMemcpy(visit counters)");
+	// hot ids are sampled once per wave per 128-byte tile (1 of 64*128 lane-steps), cold ids once per trapped
+	// 16-byte chunk for one rotating lane of 64 (1 of 64*16 lane-steps): bring both to "lane-steps".
+	std::vector<double> score(N);
+	uint64_t coldSamples = 0;
+	for (uint32_t pid = 0; pid < N; ++pid) {
+		const uint32_t o = h.origOfPerm[pid];
+		double est = double(cold[pid]) * 1024.0;
+		if (pid < H)
+			est += double(hot[pid]) * 8192.0;
+		if (pid >= H)
+			coldSamples += cold[pid];
+		score[o] = est + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
+	}
+	h.lastTrapSamples = coldSamples;
+	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
+	std::sort(before.begin(), before.end());
+	if (coldSamples == 0) {
+		(void)hipMemset(t->dev.visitHot, 0, 256 * 4);
+		return PIRE_HIP_OK;   // nothing trapped: the current rows already cover the traffic
+	}
+	PermuteByScore(h, score);
+	std::vector<uint32_t> after(h.origOfPerm.begin(), h.origOfPerm.begin() + h.hot);
+	std::sort(after.begin(), after.end());
+	std::vector<uint32_t> diff;
+	std::set_difference(after.begin(), after.end(), before.begin(), before.end(), std::back_inserter(diff));
+	if (changedRows)
+		*changedRows = uint32_t(diff.size());
+	h.adaptations++;
+	FreeDeviceTable(&t->dev);
+	return UploadTable(t);
 }
 
 }  // namespace pirehip

@@ -115,6 +115,14 @@ SET_A_WITNESS = [(b"hello  world", True), (b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", True),
 SET_D = ["hello\\s+w.+d$", "abc", "abc|def", "ad*e", "ad+e", "Head(Inner)*Tail", "^x{3,6}$", "aaa"]
 SET_D_WITNESS = [(b"hello  world", True), (b"abc", False), (b"def", False), (b"addde", False), (b"ade", False),
                  (b"HeadInnerInnerTail", False), (b"xxxx", False), (b"aaa", False)]
+# BASELINE config 5a: a glued table far too big for LDS (8 952 states x 60 letters, 3.2 MB reference buffer; SURVEY 8d "Set B")
+SET_B = ["hello\\s+w.+d$", "ABCDEFGHIJKLMNOPQRSTUVWXYZ$", "[XYZ]ABCDEFGHIJKLMNOPQRSTUVWXYZ$",
+         "[ -~]*ABCDEFGHIJKLMNOPQRSTUVWXYZ$", "(\\d{3}-|\\(\\d{3}\\)\\s+)(\\d{3}-\\d{4})$",
+         "http://([a-z0-9]+\\.)+[a-z]{2,4}/?", "^[a-z]+@[a-z]+\\.com", "foo(bar|baz)+qux"]
+SET_B_WITNESS = [(b"hello  world", True), (b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", True),
+                 (b"XABCDEFGHIJKLMNOPQRSTUVWXYZ", True), (b"abc ABCDEFGHIJKLMNOPQRSTUVWXYZ", True),
+                 (b"(123)  456-7890", True), (b" http://aba.caba.ru/ ", False), (b"foobarbazbarqux", False),
+                 (b"http://x.yz/foobazqux", False)]
 CORPUS_SEED = 0x5EED5EED
 
 
@@ -171,7 +179,8 @@ def main():
 
     # big glued sets: geometry + results on seeded corpus strings and on raw random bytes (all 256 values)
     big = []
-    for name, pats, wit in (("set_a", SET_A, SET_A_WITNESS), ("set_d", SET_D, SET_D_WITNESS)):
+    for name, pats, wit in (("set_a", SET_A, SET_A_WITNESS), ("set_d", SET_D, SET_D_WITNESS),
+                            ("set_b", SET_B, SET_B_WITNESS)):
         sc = RefScanner.compile(pats, [""] * len(pats))
         blob = sc.save()
         plants = make_plants(wit)
@@ -192,6 +201,23 @@ def main():
                                "accepted": [sc.accepted(int(i)) for i in idx]},
                     "raw": {"numpy_randomstate_seed": 1234, "strings_hex": [r.hex() for r in raw], "idx": ridx,
                             "final": rfin, "accepted": racc}})
+
+    # BASELINE config C2: the single pattern, with a planted witness so that full-size runs are not vacuous
+    sc = RefScanner.compile(["hello\\s+w.+d$"], [""])
+    blob = sc.save()
+    wit = [(b"hello  world", True), (b"hello w-d", True), (b"hello\tworld", False)]
+    plants2 = make_plants(wit)
+    n, length = 96, 1024
+    data = corpus_fill(CORPUS_SEED, 0, n, length, plants2)
+    idx, fin = sc.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length)
+    big.append({"name": "c2_single", "patterns": ["hello\\s+w.+d$"], "witnesses_hex": [w.hex() for w, _ in wit],
+                "witness_at_tail": [bool(t) for _, t in wit], "geometry": geometry(sc),
+                "blob": write_blob("c2_single", blob), "blob_sha256": hashlib.sha256(blob).hexdigest(),
+                "corpus": {"seed": CORPUS_SEED, "n": n, "len": length,
+                           "sha256": hashlib.sha256(data.tobytes()).hexdigest(),
+                           "idx": [int(i) for i in idx], "final": [int(f) for f in fin],
+                           "accepted": [sc.accepted(int(i)) for i in idx]},
+                "raw": {"numpy_randomstate_seed": 1234, "strings_hex": [], "idx": [], "final": [], "accepted": []}})
 
     # corpus generator pin: bytes of a few strings, with and without plants
     plants = make_plants(SET_A_WITNESS)

@@ -98,7 +98,7 @@ def test_big_sets_golden_tiled_and_generic(pa, torch_cuda, big):
     assert idx.tolist() == big["raw"]["idx"] and fin.tolist() == big["raw"]["final"]
 
 
-@pytest.mark.parametrize("name", ["set_a", "set_d", "survey_known_answer", "inline_glue3", "utf8_dot"])
+@pytest.mark.parametrize("name", ["set_a", "set_d", "set_b", "survey_known_answer", "inline_glue3", "utf8_dot"])
 def test_random_ragged_batches_vs_oracle(pa, name):
     """Ragged, unaligned, empty strings; bytes 0..255; every flag combination."""
     case = [c for c in H.all_cases() + H.big_sets() if c["name"] == name][0]
@@ -113,9 +113,9 @@ def test_random_ragged_batches_vs_oracle(pa, name):
         assert (gi == oi).all() and (gf == of).all()
 
 
-@pytest.mark.parametrize("name", ["set_a", "set_d"])
+@pytest.mark.parametrize("name", ["set_a", "set_d", "set_b", "c2_single"])
 @pytest.mark.parametrize("n,length", [(1, 128), (63, 256), (64, 4096), (65, 384), (1000, 1024), (4097, 128 * 3 + 16),
-                                      (300, 100), (129, 4096 + 48)])
+                                      (300, 100), (129, 4096 + 48), (128, 128), (192, 256 + 16)])
 def test_tiled_kernel_shapes_vs_oracle(pa, torch_cuda, name, n, length):
     """Tile-count / lane-count edge cases of the tiled kernel: partial waves, odd tile counts, tails shorter than
     a tile, lengths below one tile (routed to the generic kernel)."""
@@ -206,22 +206,27 @@ def test_empty_inputs_and_empty_scanner(pa):
     assert idx.tolist() == o.run_strings([b"", b"", b""])[0].tolist()
 
 
-def test_full_size_config_properties(pa, torch_cuda):
-    """BASELINE config sizes (2^20 x 4 KiB, 8 glued regexps) on the device-generated corpus: sampled strings are
-    re-generated on the host and checked bit-exactly against the oracle, and whole-batch counters must be
-    consistent with the per-string outputs (a checksum of checksums)."""
+@pytest.mark.parametrize("name,length", [("c2_single", 4096), ("set_a", 4096), ("set_b", 16384)],
+                         ids=["C2_single_1Mx4K", "C3_glued8_1Mx4K", "C5a_bigtable_1Mx16K"])
+def test_full_size_config_properties(pa, torch_cuda, name, length):
+    """BASELINE.json configs at FULL size (C2: single Scanner, C3: 8 glued regexps, C5a: a glued table that spills
+    LDS -- HBM-resident transitions -- with 16 KiB strings; 2^20 strings each) on the device-generated corpus:
+    sampled strings are re-generated on the host and checked bit-exactly against the oracle, and whole-batch
+    counters must be consistent with the per-string outputs (a checksum of checksums)."""
     torch = torch_cuda
-    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    big = [b for b in H.big_sets() if b["name"] == name][0]
     blob = H.load_blob(big["blob"])
     t, o = pa.Table(blob), ob.OracleScanner(blob)
     plants = H.plants_for(big)
-    n, length, seed = 1 << 20, 4096, 0x5EED5EED
+    n, seed = 1 << 20, 0x5EED5EED
     buf = torch.empty((n, length), dtype=torch.uint8, device="cuda")
     pa.corpus_fill_device(buf.data_ptr(), seed, 0, n, length, length, plants, torch.cuda.current_stream().cuda_stream)
     idx, fin, cnt = dev_run_strided(torch, t, buf)
     # sampled bit-exact check
     rng = np.random.RandomState(0)
-    sample = np.unique(np.concatenate([rng.randint(0, n, 3000), np.arange(0, 600), np.arange(n - 300, n)]))
+    k = 3000 if length <= 4096 else 700
+    sample = np.unique(np.concatenate([rng.randint(0, n, k), np.arange(0, 600 if length <= 4096 else 150),
+                                       np.arange(n - 300, n)]))
     for lo in range(0, len(sample), 512):
         sel = sample[lo:lo + 512]
         host = np.stack([ob.corpus_fill(seed, int(s), 1, length, plants)[0] for s in sel])
@@ -236,7 +241,38 @@ def test_full_size_config_properties(pa, torch_cuda):
         for r in t.AcceptedRegexps(s):
             per[r] += h
     assert (per == cnt[2:]).all()
-    # plants: string s carries witness (s % 9) - 1, so every regexp is matched by about n/9 strings at least
-    for r in range(t.RegexpsCount):
-        assert cnt[2 + r] >= n // 9 - 1
-    assert len(states) >= 8
+    # plants: string s carries witness (s % (P+1)) - 1, so every regexp is matched by about n/(P+1) strings at least
+    nplants = len(big["witnesses_hex"])
+    if name == "set_a":          # witness r is a witness of regexp r
+        for r in range(t.RegexpsCount):
+            assert cnt[2 + r] >= n // (nplants + 1) - 1
+    tails = sum(1 for x in big["witness_at_tail"] if x)
+    assert cnt[0] >= (n // (nplants + 1)) * tails - nplants   # every tail-anchored witness is a match
+    assert len(states) >= (8 if t.RegexpsCount >= 8 else 2)
+
+
+@pytest.mark.parametrize("name", ["set_d", "set_b", "set_a"])
+def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name):
+    """pire_hip_table_adapt(): after one representative batch the rows the data really visits move into LDS.
+    Results must be bit-identical before and after; the trap counter must collapse."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    n, length = 8192, 2048
+    data = ob.corpus_fill(77, 0, n, length, H.plants_for(big), threads=4)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    gi, gf, cnt = dev_run_strided(torch, t, d)
+    assert (gi == oi).all() and (gf == of).all()
+    changed = t.adapt()
+    first_traps = t.info.last_trap_samples
+    assert first_traps > 0 and changed > 0
+    gi2, gf2, cnt2 = dev_run_strided(torch, t, d)
+    assert (gi2 == oi).all() and (gf2 == of).all() and (cnt2 == cnt).all()
+    t.adapt()
+    assert t.info.last_trap_samples * 20 < first_traps, "adapted table must trap at least 20x less on the same data"
+    gi3, gf3, _ = dev_run_strided(torch, t, d)
+    assert (gi3 == oi).all() and (gf3 == of).all()
+    # the host-side view stays in the reference's numbering
+    assert t.Final(int(oi[0])) == bool(of[0])

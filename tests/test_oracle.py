@@ -52,7 +52,7 @@ def test_oracle_big_sets(big):
         idx, fin = o.run(data.reshape(-1), offs, shortcut=shortcut)
         assert idx.tolist() == c["idx"] and fin.tolist() == c["final"]
     assert [o.accepted(int(i)) for i in idx] == c["accepted"]
-    assert len(set(c["idx"])) >= 8, "planted corpus must exercise several distinct end states"
+    assert len(set(c["idx"])) >= (8 if o.regexps >= 8 else 2), "planted corpus must exercise several distinct end states"
     raw = [bytes.fromhex(h) for h in big["raw"]["strings_hex"]]
     idx, fin = o.run_strings(raw)
     assert idx.tolist() == big["raw"]["idx"] and fin.tolist() == big["raw"]["final"]
