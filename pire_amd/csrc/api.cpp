@@ -80,6 +80,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->acceptMaskPerm = d.acceptMaskPerm;
 	p->acceptOffPerm = d.acceptOffPerm;
 	p->acceptIds = d.acceptIds;
+	p->finSelf = d.finSelf;
+	p->finEnd = d.finEnd;
 	p->visitHot = d.visitHot;
 	p->visitCold = d.visitCold;
 	p->states = h.states;

@@ -54,6 +54,13 @@ struct HostTable {
 	uint32_t adaptations = 0;
 };
 
+// Everything the end of a string needs, in ONE 16-byte load: reference StateIndex, device id + flags, regexp mask.
+struct FinRec {
+	uint32_t orig;        // StateIndex (multi.h:281-284) of the end state
+	uint32_t permFlags;   // device id of the end state | flags << 28
+	uint64_t acceptMask;  // bit r = regexp r in AcceptedRegexps() (regexps <= 64)
+};
+
 // Device image (one HIP device).
 struct DeviceTable {
 	int device = -1;
@@ -67,6 +74,8 @@ struct DeviceTable {
 	uint64_t* acceptMaskPerm = nullptr;  // [states] bit r = regexp r accepted (regexps <= 64), else null
 	uint64_t* acceptOffPerm = nullptr;   // [states+1] CSR (regexps > 64)
 	uint64_t* acceptIds = nullptr;
+	struct FinRec* finSelf = nullptr; // [states] end-of-string record when End() is not requested
+	struct FinRec* finEnd = nullptr;  // [states] end-of-string record after Step(EndMark)
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
 	uint64_t bytes = 0;
@@ -95,6 +104,8 @@ struct ScanParams {
 	const uint64_t* acceptMaskPerm;
 	const uint64_t* acceptOffPerm;
 	const uint64_t* acceptIds;
+	const FinRec* finSelf;
+	const FinRec* finEnd;
 	uint32_t* visitHot;
 	uint32_t* visitCold;
 	uint32_t states, letters, regexps, hot;

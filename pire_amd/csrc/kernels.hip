@@ -112,16 +112,18 @@ __device__ __forceinline__ uint32_t StartState(const ScanParams& p, uint64_t s)
 	return st;
 }
 
-// End(), outputs and block-local match counters for one finished string.
+// End(), outputs and block-local match counters for one finished string.  One 16-byte record load replaces the
+// chain  nextPerm[EndMark] -> flags -> origOfPerm -> acceptMask  of dependent lookups.
 __device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint64_t s,
                                        bool active, uint32_t st)
 {
-	if (p.flags & PIRE_HIP_RUN_END)
-		st = p.nextPerm[size_t(st) * p.letters + p.endCls];
-	const uint8_t fl = p.flagsPerm[st];
+	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+	const u32x4 raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
+	const uint64_t mask = (uint64_t(raw.w) << 32) | raw.z;
 	if (active) {
 		if (p.outIdx)
-			p.outIdx[s] = p.origOfPerm[st];
+			p.outIdx[s] = orig;
 		if (p.outFinal)
 			p.outFinal[s] = fl & kFinal;
 	}
@@ -135,14 +137,14 @@ __device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const 
 			atomicAdd(&cnt[1], (uint32_t)__popcll(actives));
 		}
 		if (p.acceptMaskPerm) {
-			const uint64_t m = active ? p.acceptMaskPerm[st] : 0;
+			const uint64_t m = active ? mask : 0;
 			for (uint32_t r = 0; r < p.regexps; ++r) {
 				const unsigned long long b = __ballot((m >> r) & 1);
 				if (lane == 0 && b)
 					atomicAdd(&cnt[2 + r], (uint32_t)__popcll(b));
 			}
 		} else if (active) {
-			for (uint64_t k = p.acceptOffPerm[st]; k < p.acceptOffPerm[st + 1]; ++k)
+			for (uint64_t k = p.acceptOffPerm[endPerm]; k < p.acceptOffPerm[endPerm + 1]; ++k)
 				atomicAdd(&cnt[2 + p.acceptIds[k]], 1u);
 		}
 	}
@@ -406,12 +408,15 @@ __device__ __forceinline__ uint64_t Uniform64(uint64_t v)
 // current slot has landed, transpose it into lane-owns-string order, walk it.
 template <int NBUF, bool NT>
 __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
-                                      uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile, u32x4 (&cur)[8],
-                                      u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
+                                      uint64_t chainBase, uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile,
+                                      u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
 {
-	const uint32_t ahead = t + (NBUF - 1) < lastTile ? t + (NBUF - 1) : lastTile;
+	// Refill target: the next tile of this task, or -- on the task's last tile -- tile 0 of the wave's NEXT task
+	// (chainBase; equals this task's last tile when there is nothing to chain to), so that neither the HBM
+	// latency of a task's first tile nor a duplicate load of its last tile is ever paid.
+	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
 	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
-		IssueTile<NT>(refill, voff, rowBase + uint64_t(ahead) * 128, p.stride);
+		IssueTile<NT>(refill, voff, ahead, p.stride);
 	WaitTile<NBUF - 1>(cur);
 	TransposeTile(cur, lane);
 	if (lane == (t & 63) && !(p.flags & kDebugNoHist))   // visit sample: one lane per wave per tile, rotating
@@ -451,22 +456,31 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	ZeroTile(a);
 	ZeroTile(b);
 
-	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += uint64_t(gridDim.x) * WAVES) {
+	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
+	const bool chain = rem == 0;
+	bool primed = false;   // slot a already holds (or is receiving) tile 0 of the task about to start
+	const uint64_t taskStep = uint64_t(gridDim.x) * WAVES;
+	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += taskStep) {
 		const uint64_t s0 = task * 64;
 		const uint64_t s = s0 + lane;
 		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
+		const bool hasNext = chain && task + taskStep < ntasks;
+		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
+		                                   : rowBase + uint64_t(lastTile) * 128;
 
 		uint32_t cold = StartState(p, s);
 		uint32_t hs = cold < p.hot ? cold : p.hot;
 
 		bool done = false;
-		IssueTile<NT>(a, voff, rowBase, p.stride);
+		if (!primed)
+			IssueTile<NT>(a, voff, rowBase, p.stride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
 			const uint32_t t = g * 2;
-			Phase<2, NT>(p, lds, L, rowBase, voff, lane, t, lastTile, a, b, hs, cold);
-			Phase<2, NT>(p, lds, L, rowBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
+			Phase<2, NT>(p, lds, L, rowBase, chainBase, voff, lane, t, lastTile, a, b, hs, cold);
+			Phase<2, NT>(p, lds, L, rowBase, chainBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
 			done = AllAbsorbing(p, lds, L, hs);
 		}
+		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (!done && rem == 1) {
 			WaitTile<0>(a);
 			TransposeTile(a, lane);

@@ -310,7 +310,8 @@ void FreeDeviceTable(DeviceTable* d)
 	if (d->device < 0)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
-	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold};
+	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
+	                d->finSelf,    d->finEnd};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -367,6 +368,28 @@ int UploadTable(pire_hip_table* t)
 		off[N] = ids.size();
 		if (!(rc = Put(&d.acceptOffPerm, off, &d.bytes)))
 			rc = Put(&d.acceptIds, ids, &d.bytes);
+	}
+	if (!rc) {
+		// end-of-string records (one 16-byte load per string instead of a chain of dependent lookups)
+		std::vector<FinRec> self(N), end(N);
+		const uint32_t endCls = h.cls[kEndMark];
+		auto fill = [&](FinRec& r, uint32_t pid) {
+			const uint32_t o = h.origOfPerm[pid];
+			r.orig = o;
+			r.permFlags = pid | (uint32_t(h.flags[o]) << 28);
+			r.acceptMask = 0;
+			if (h.regexps <= 64)
+				for (uint64_t k = h.acceptOff[o]; k < h.acceptOff[o + 1]; ++k)
+					if (h.acceptIds[k] < 64)
+						r.acceptMask |= uint64_t(1) << h.acceptIds[k];
+		};
+		for (uint32_t pid = 0; pid < N; ++pid) {
+			fill(self[pid], pid);
+			fill(end[pid], nextPerm[size_t(pid) * C + endCls]);
+		}
+		rc = Put(&d.finSelf, self, &d.bytes);
+		if (!rc)
+			rc = Put(&d.finEnd, end, &d.bytes);
 	}
 	if (!rc)
 		rc = Put(&d.visitHot, std::vector<uint32_t>(256, 0), &d.bytes);

@@ -1,10 +1,10 @@
 #!/bin/bash
 set -u
 export PYTHONUNBUFFERED=1
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-for cfg in "set_a 4096 --no-adapt" "set_a 4096" "c2_single 4096" "set_b 16384" "set_d 4096"; do
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+for cfg in "set_a 4096" "set_a 4096" "c2_single 4096" "set_b 16384" "set_d 4096"; do
   set -- $cfg
-  timeout 600 python bench.py --set $1 --len $2 --steps 10 --warmup 2 --no-cpu ${3:-} 2>&1 | tail -1 | python -c "
+  timeout 600 python bench.py --set $1 --len $2 --steps 20 --warmup 3 --no-cpu ${3:-} 2>&1 | tail -1 | python -c "
 import sys, json
 l = sys.stdin.read().strip()
 try:
