@@ -11,7 +11,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | 
 echo "== bench (default)"
 timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/final/bench_n1.json
 echo "== bench C2 single pattern (parity config, informational)"
-timeout 600 python bench.py --set survey_known_answer --steps 10 --warmup 2 --cpu-sample-log2 18 2>&1 | tail -1 | cut -c1-700 | tee gpurun_out/final/bench_c2.json
+timeout 600 python bench.py --set c2_single --steps 10 --warmup 2 --cpu-sample-log2 18 2>&1 | tail -1 | cut -c1-700 | tee gpurun_out/final/bench_c2.json
 echo "== rocprofv3 kernel stats of the bench command"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -o stats -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/final/stats.log 2>&1
 cat gpurun_out/final/stats/stats_kernel_stats.csv | head -5
