@@ -168,6 +168,41 @@ const char* pire_hip_last_kernel(void);
 int   pire_hip_set_timing(int enabled);
 float pire_hip_last_kernel_ms(void);
 
+/* ---- SlowScanner (BASELINE config 5b) --------------------------------------------------------------- */
+/*
+ * Pire::SlowScanner (pire/scanners/slow.h:51-420): NFA simulation for patterns whose DFA would not fit anywhere
+ * (e.g. /x.{40}$/).  Its state is the SET of active NFA states (slow.h:63-74), so results are the Final flag
+ * (slow.h:152-158) and, optionally, the set itself as a bitset.  Ingests SlowScanner::Save() bytes
+ * (pire/scanner_io.cpp:71-111).  GPU limit: 256 NFA states (8-word sets in registers).
+ */
+typedef struct pire_hip_slow_table pire_hip_slow_table;
+
+typedef struct pire_hip_slow_info {
+	uint32_t states;      /* SlowScanner::Size()            slow.h:83-84 */
+	uint32_t letters;     /* SlowScanner::GetLettersCount() slow.h:81    */
+	uint32_t start;       /* m.start                        slow.h:343   */
+	uint32_t words;       /* (states + 31) / 32: uint32 words of one state set */
+	uint32_t empty;       /* SlowScanner::Empty()           slow.h:85    */
+	uint32_t reserved;
+	uint64_t mask_bytes;  /* size of the (state, letter) -> target-set matrix */
+} pire_hip_slow_info;
+
+int pire_hip_slow_table_create(const void* save_blob, size_t len, pire_hip_slow_table** out);
+void pire_hip_slow_table_destroy(pire_hip_slow_table* t);
+int pire_hip_slow_table_get_info(const pire_hip_slow_table* t, pire_hip_slow_info* out);
+
+/*
+ * For each string: Initialize (slow.h:89-95); Begin() if flags&BEGIN; Run (the SlowScanner specialisation,
+ * slow.h:436-451); End() if flags&END.  out_final[i] = Final(state).  out_state_bits (nullable): `words` uint32 per
+ * string, bit s set <=> NFA state s is in the final state set.  out_counts (nullable) uint64[2] accumulated:
+ * [0] += strings ending Final, [1] += n.  Pointer/flag conventions as pire_hip_run.
+ */
+int pire_hip_slow_run(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                      uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts, void* stream);
+int pire_hip_slow_run_strided(pire_hip_slow_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
+                              uint32_t flags, uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts,
+                              void* stream);
+
 /* ---- errors ---------------------------------------------------------------------------------------- */
 const char* pire_hip_last_error(void);
 int pire_hip_device_count(void);

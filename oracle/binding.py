@@ -103,6 +103,16 @@ def oracle_lib():
         L.corpus_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                   C.c_void_p, C.c_int]
         L.corpus_fill.restype = None
+        L.oracle_slow_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.oracle_slow_load.restype = C.c_int
+        L.oracle_slow_free.argtypes = [C.c_void_p]
+        for name in ("oracle_slow_size", "oracle_slow_letters"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint32
+        L.oracle_slow_empty.argtypes = [C.c_void_p]
+        L.oracle_slow_empty.restype = C.c_int
+        L.oracle_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p]
+        L.oracle_slow_run.restype = None
         _oracle_lib = L
     return _oracle_lib
 
@@ -180,6 +190,44 @@ class OracleScanner:
         return out
 
 
+class OracleSlowScanner:
+    """C restatement of Pire::SlowScanner, loaded from SlowScanner::Save() bytes."""
+
+    def __init__(self, blob: bytes):
+        L = oracle_lib()
+        self._L = L
+        self.blob = bytes(blob)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        if L.oracle_slow_load(self.blob, len(self.blob), C.byref(h), err, 256) != 0:
+            raise ValueError(err.value.decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.oracle_slow_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.oracle_slow_size(s._h))
+    letters = property(lambda s: s._L.oracle_slow_letters(s._h))
+    empty = property(lambda s: bool(s._L.oracle_slow_empty(s._h)))
+    words = property(lambda s: (s.size + 31) // 32)
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        fin = np.empty(n, dtype=np.uint8)
+        bits = np.empty((n, self.words), dtype=np.uint32)
+        self._L.oracle_slow_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                _ptr(fin, u8p), _ptr(bits, u32p))
+        return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
 # --------------------------------------------------------------------------- reference library
 
 _ref_lib = None
@@ -223,8 +271,75 @@ def ref_lib():
         L.pire_ref_run.restype = C.c_int
         L.pire_ref_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
         L.pire_ref_prefix.restype = C.c_int
+        L.pire_ref_slow_compile.argtypes = [C.c_char_p, C.c_char_p]
+        L.pire_ref_slow_compile.restype = C.c_void_p
+        L.pire_ref_slow_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.pire_ref_slow_load.restype = C.c_void_p
+        L.pire_ref_slow_free.argtypes = [C.c_void_p]
+        L.pire_ref_slow_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_slow_save.restype = C.c_size_t
+        for name in ("pire_ref_slow_size", "pire_ref_slow_letters"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_size_t
+        L.pire_ref_slow_empty.argtypes = [C.c_void_p]
+        L.pire_ref_slow_empty.restype = C.c_int
+        L.pire_ref_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p, C.c_int]
+        L.pire_ref_slow_run.restype = C.c_int
         _ref_lib = L
     return _ref_lib
+
+
+class RefSlowScanner:
+    """The real Pire::SlowScanner behind a C ABI."""
+
+    def __init__(self, handle):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def compile(cls, pattern, options=""):
+        L = ref_lib()
+        p = pattern.encode("latin-1") if isinstance(pattern, str) else pattern
+        return cls(L.pire_ref_slow_compile(p, options.encode()))
+
+    @classmethod
+    def load(cls, blob: bytes):
+        L = ref_lib()
+        return cls(L.pire_ref_slow_load(bytes(blob), len(blob)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_slow_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_slow_size(s._h))
+    letters = property(lambda s: s._L.pire_ref_slow_letters(s._h))
+    empty = property(lambda s: bool(s._L.pire_ref_slow_empty(s._h)))
+    words = property(lambda s: (s.size + 31) // 32)
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_slow_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_slow_save(self._h, buf, n)
+        return buf.raw
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        fin = np.empty(n, dtype=np.uint8)
+        bits = np.empty((n, self.words), dtype=np.uint32)
+        rc = self._L.pire_ref_slow_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                       _ptr(fin, u8p), _ptr(bits, u32p), threads)
+        if rc != 0:
+            raise RuntimeError(self._L.pire_ref_last_error().decode())
+        return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
 
 
 class RefScanner:

@@ -283,4 +283,100 @@ int pire_ref_prefix(void* h, int longest, const void* text, const uint64_t* offs
 	}
 }
 
+/* ------------------------------------------------------------------ SlowScanner (scanners/slow.h) */
+
+struct RefSlow {
+	Pire::SlowScanner sc;
+};
+
+/* Fsm::Compile<SlowScanner>() -- slow.h:420-423; one pattern, options as ParseOne. */
+void* pire_ref_slow_compile(const char* pattern, const char* options)
+{
+	try {
+		std::unique_ptr<RefSlow> h(new RefSlow);
+		Pire::Fsm fsm = ParseOne(pattern, options);
+		h->sc = fsm.Compile<Pire::SlowScanner>();
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void* pire_ref_slow_load(const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefSlow> h(new RefSlow);
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		h->sc.Load(&in);                                     // scanner_io.cpp:113-170
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_slow_free(void* h) { delete static_cast<RefSlow*>(h); }
+
+size_t pire_ref_slow_save(void* h, void* buf, size_t cap)      // scanner_io.cpp:71-111
+{
+	std::ostringstream out;
+	static_cast<RefSlow*>(h)->sc.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_slow_size(void* h) { return static_cast<RefSlow*>(h)->sc.Size(); }
+size_t pire_ref_slow_letters(void* h) { return static_cast<RefSlow*>(h)->sc.GetLettersCount(); }
+int pire_ref_slow_empty(void* h) { return static_cast<RefSlow*>(h)->sc.Empty() ? 1 : 0; }
+
+/*
+ * Runner(sc).Begin().Run(ptr,len).End() with the SlowScanner specialisation of Run (slow.h:436-451).
+ * outFinal[i] = Final(state) (slow.h:152-158).  outBits (nullable): the state SET as a bitset,
+ * words = (Size()+31)/32 uint32 per string (the reference keeps a vector + bitset; the set is what is defined).
+ */
+int pire_ref_slow_run(void* h, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                      uint8_t* outFinal, uint32_t* outBits, int threads)
+{
+	try {
+		const Pire::SlowScanner& sc = static_cast<RefSlow*>(h)->sc;
+		const char* t = static_cast<const char*>(text);
+		const size_t words = (sc.Size() + 31) / 32;
+		auto range = [&](uint64_t lo, uint64_t hi) {
+			for (uint64_t i = lo; i < hi; ++i) {
+				Pire::SlowScanner::State st;
+				sc.Initialize(st);
+				if (flags & FLAG_BEGIN)
+					Pire::Step(sc, st, Pire::BeginMark);
+				Pire::Run(sc, st, t + offsets[i], t + offsets[i + 1]);
+				if (flags & FLAG_END)
+					Pire::Step(sc, st, Pire::EndMark);
+				if (outFinal)
+					outFinal[i] = sc.Final(st) ? 1 : 0;
+				if (outBits) {
+					uint32_t* w = outBits + i * words;
+					memset(w, 0, words * 4);
+					for (unsigned s : st.states)
+						w[s / 32] |= 1u << (s % 32);
+				}
+			}
+		};
+		if (threads <= 1) {
+			range(0, n);
+		} else {
+			std::vector<std::thread> pool;
+			for (int k = 0; k < threads; ++k)
+				pool.emplace_back(range, n * k / threads, n * (k + 1) / threads);
+			for (auto& th : pool)
+				th.join();
+		}
+		return 0;
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return -1;
+	}
+}
+
 } // extern "C"

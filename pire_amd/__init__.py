@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     FLAG_GENERIC,
     PireHipError,
     Table,
+    SlowTable,
     BatchRunner,
     build,
     corpus_fill_device,

@@ -49,6 +49,11 @@ class TableInfo(C.Structure):
     ]
 
 
+class SlowInfo(C.Structure):
+    _fields_ = [("states", C.c_uint32), ("letters", C.c_uint32), ("start", C.c_uint32), ("words", C.c_uint32),
+                ("empty", C.c_uint32), ("reserved", C.c_uint32), ("mask_bytes", C.c_uint64)]
+
+
 def lib_path() -> str:
     return _LIB_PATH
 
@@ -82,6 +87,13 @@ ABI = [
     ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    ("pire_hip_slow_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_slow_table_destroy", None, [C.c_void_p]),
+    ("pire_hip_slow_table_get_info", C.c_int, [C.c_void_p, C.POINTER(SlowInfo)]),
+    ("pire_hip_slow_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
+    ("pire_hip_slow_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
     ("pire_hip_set_timing", C.c_int, [C.c_int]),
     ("pire_hip_last_kernel_ms", C.c_float, []),
@@ -244,6 +256,54 @@ class Table:
 
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))
+
+
+class SlowTable:
+    """An ingested Pire::SlowScanner (from SlowScanner::Save() bytes)."""
+
+    def __init__(self, blob: bytes):
+        L = lib()
+        h = C.c_void_p()
+        blob = bytes(blob)
+        _check(L.pire_hip_slow_table_create(blob, len(blob), C.byref(h)))
+        self._h = h
+        self.info = SlowInfo()
+        _check(L.pire_hip_slow_table_get_info(h, C.byref(self.info)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib().pire_hip_slow_table_destroy(h)
+            self._h = None
+
+    Size = property(lambda s: s.info.states)
+    LettersCount = property(lambda s: s.info.letters)
+    Empty = property(lambda s: bool(s.info.empty))
+    words = property(lambda s: s.info.words)
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, counts=False):
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        fin = np.empty(n, dtype=np.uint8)
+        bits = np.empty((n, self.words), dtype=np.uint32)
+        cnt = np.zeros(2, dtype=np.uint64) if counts else None
+        _check(lib().pire_hip_slow_run(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                       flags & ~FLAG_ON_DEVICE, fin.ctypes.data, bits.ctypes.data, _np_ptr(cnt), None))
+        return (fin, bits, cnt) if counts else (fin, bits)
+
+    def run_strings(self, strings, **kw):
+        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+        if strings:
+            offs[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64)
+        return self.run(np.frombuffer(b"".join(strings), dtype=np.uint8), offs, **kw)
+
+    def run_strided_device(self, text_ptr, n, length, stride, flags, out_final_ptr=0, out_bits_ptr=0, out_counts_ptr=0,
+                           stream=0):
+        _check(lib().pire_hip_slow_run_strided(self._h, text_ptr or None, n, length, stride, flags | FLAG_ON_DEVICE,
+                                               out_final_ptr or None, out_bits_ptr or None, out_counts_ptr or None,
+                                               stream or None))
 
 
 class BatchRunner:

@@ -1,0 +1,498 @@
+// Pire::SlowScanner on the GPU (BASELINE config 5b): NFA simulation, one string per lane, the state is the SET of
+// active NFA states held as a bitset in registers.
+//
+// Reference: /root/reference/pire/scanners/slow.h
+//   State{vector<unsigned> states; BitSet flags}   63-74     (the set is what Next/Final are defined on)
+//   NextTranslated(cur, next, l)                    103-130   next = union of jump lists of every active state
+//   Final(s) = any active state is final            152-158
+//   Run<SlowScanner>                                436-451   Step per byte, double-buffered
+//   serialised form (Save)                          scanner_io.cpp:71-111
+// Device form: for every (state, letter) a K-word bitmask of the jump list (the CSR lists of the reference turned
+// into rows), kept in LDS when it fits; a step is  next = OR over active s of mask[s][letter].  Work per byte is
+// O(active states * K), as in the reference -- this is the scanner for automata whose DFA would not fit anywhere.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "internal.h"
+
+namespace pirehip {
+
+struct SlowHost {
+	uint32_t states = 0, letters = 0, start = 0, words = 0;
+	bool empty = false;
+	std::vector<uint8_t> letterOf;     // [264] letter of each Char (m_letters, slow.h:349)
+	std::vector<uint32_t> masks;       // [states*letters][words]
+	std::vector<uint32_t> finals;      // [words] bitset of final states
+};
+
+struct SlowDevice {
+	int device = -1;
+	uint8_t* letterOf = nullptr;
+	uint32_t* masks = nullptr;
+	uint32_t* finals = nullptr;
+};
+
+}  // namespace pirehip
+
+struct pire_hip_slow_table {
+	pirehip::SlowHost host;
+	pirehip::SlowDevice dev;
+};
+
+namespace pirehip {
+
+struct SlowParams {
+	const uint8_t* letterOf;
+	const uint32_t* masks;
+	const uint32_t* finals;
+	uint32_t states, letters, start, words, flags, masksInLds;
+	const uint8_t* text;
+	const uint64_t* offsets;   // nullable: strided
+	uint64_t n, len, stride;
+	uint8_t* outFinal;
+	uint32_t* outBits;
+	unsigned long long* outCounts;
+};
+
+template <int K>
+__device__ __forceinline__ void SlowStep(const uint32_t* masks, uint32_t letters, uint32_t (&cur)[K], uint32_t letter)
+{
+	uint32_t next[K];
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+		next[k] = 0;
+#pragma unroll
+	for (int w = 0; w < K; ++w) {
+		uint32_t bits = cur[w];
+		while (bits) {
+			const uint32_t s = w * 32 + __builtin_ctz(bits);
+			bits &= bits - 1;
+			const uint32_t* row = masks + (size_t(s) * letters + letter) * K;
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				next[k] |= row[k];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+		cur[k] = next[k];
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void SlowScanKernel(SlowParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* ldsLetter = lds;                                        // 264 bytes
+	uint32_t* ldsMasks = reinterpret_cast<uint32_t*>(lds + 272);
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		ldsLetter[i] = p.letterOf[i];
+	const uint32_t maskWords = p.states * p.letters * K;
+	if (p.masksInLds)
+		for (uint32_t i = threadIdx.x; i < maskWords; i += blockDim.x)
+			ldsMasks[i] = p.masks[i];
+	__syncthreads();
+	const uint32_t* masks = p.masksInLds ? ldsMasks : p.masks;
+
+	const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+	unsigned long long finals = 0, strings = 0;
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += stride) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		uint32_t cur[K];
+#pragma unroll
+		for (int k = 0; k < K; ++k)   // Initialize, slow.h:89-95 (selects, so that cur[] stays in registers)
+			cur[k] = (uint32_t(k) == (p.start >> 5)) ? (1u << (p.start & 31)) : 0u;
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			SlowStep<K>(masks, p.letters, cur, ldsLetter[kBeginMark]);   // Begin(), run.h:375
+		const uint8_t* ptr = p.text + b;
+		const uint8_t* end = p.text + e;
+		for (; ptr < end; ++ptr)
+			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);         // Run<SlowScanner>, slow.h:436-451
+		if (p.flags & PIRE_HIP_RUN_END)
+			SlowStep<K>(masks, p.letters, cur, ldsLetter[kEndMark]);     // End(), run.h:376
+		bool fin = false;
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			fin = fin || (cur[k] & p.finals[k]) != 0;                    // Final, slow.h:152-158
+		if (p.outFinal)
+			p.outFinal[s] = fin ? 1 : 0;
+		if (p.outBits) {
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				if (uint32_t(k) < p.words)
+					p.outBits[s * p.words + k] = cur[k];
+		}
+		finals += fin ? 1 : 0;
+		strings += 1;
+	}
+	if (p.outCounts) {
+		// wave reduce, one atomic pair per wave
+		for (int off = 32; off > 0; off >>= 1) {
+			finals += __shfl_down(finals, off);
+			strings += __shfl_down(strings, off);
+		}
+		if ((threadIdx.x & 63) == 0 && strings) {
+			atomicAdd(&p.outCounts[0], finals);
+			atomicAdd(&p.outCounts[1], strings);
+		}
+	}
+}
+
+namespace {
+
+size_t Up8(size_t v) { return (v + 7) & ~size_t(7); }
+
+int BadSlow(const char* msg)
+{
+	SetError(msg);
+	return PIRE_HIP_EFORMAT;
+}
+
+// SlowScanner::Load, scanner_io.cpp:113-170 (layout written by Save, 71-111).
+int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
+{
+	const uint8_t* p = static_cast<const uint8_t*>(blob);
+	if (!p || len < 24 + 24 + 8)
+		return BadSlow("EOF reached while reading the SlowScanner header");
+	uint32_t hdr[6];
+	memcpy(hdr, p, 24);
+	if (hdr[0] != 0x45524950u || hdr[2] != 8 || hdr[3] != 16)
+		return BadSlow("Serialized regexp incompatible with your system");
+	if (hdr[1] != 7 && hdr[1] != 6)
+		return BadSlow("You are trying to used an incompatible version of a serialized regexp");
+	if (hdr[4] != 3 /* ScannerIOTypes::SlowScanner */ || hdr[5] != 24)
+		return BadSlow("Serialized regexp incompatible with your system");
+	uint64_t states, letters, start;
+	memcpy(&states, p + 24, 8);
+	memcpy(&letters, p + 32, 8);
+	memcpy(&start, p + 40, 8);
+	size_t pos = 48;
+	const bool empty = p[pos] != 0;
+	pos += 8;
+	SlowHost& h = *out;
+	h = SlowHost();
+	h.empty = empty;
+	if (empty) {
+		// Null() = Fsm::MakeFalse() compiled (slow.h:425-429): one non-final state, nowhere to go
+		h.states = 1;
+		h.letters = 1;
+		h.start = 0;
+		h.words = 1;
+		h.letterOf.assign(kMaxChar, 0);
+		h.masks.assign(1, 0);
+		h.finals.assign(1, 0);
+		return PIRE_HIP_OK;
+	}
+	if (states == 0 || letters == 0 || letters > 256 || states > (1u << 20) || start >= states)
+		return BadSlow("Corrupt SlowScanner: bad geometry");
+	h.states = uint32_t(states);
+	h.letters = uint32_t(letters);
+	h.start = uint32_t(start);
+	h.words = (h.states + 31) / 32;
+	if (len < pos + size_t(kMaxChar) * 8)
+		return BadSlow("EOF reached while reading SlowScanner letters");
+	h.letterOf.assign(kMaxChar, 0);
+	for (uint32_t c = 0; c < kMaxChar; ++c) {
+		uint64_t v;
+		memcpy(&v, p + pos + size_t(c) * 8, 8);
+		if (v >= letters)
+			return BadSlow("Corrupt SlowScanner: letter out of range");
+		h.letterOf[c] = uint8_t(v);
+	}
+	pos += size_t(kMaxChar) * 8;
+	if (len < pos + Up8(states))
+		return BadSlow("EOF reached while reading SlowScanner finals");
+	h.finals.assign(h.words, 0);
+	for (uint32_t s = 0; s < h.states; ++s)
+		if (p[pos + s])
+			h.finals[s >> 5] |= 1u << (s & 31);
+	pos += Up8(states);
+	const size_t npos = size_t(states) * letters + 1;
+	if (len < pos + npos * 8)
+		return BadSlow("EOF reached while reading SlowScanner jump positions");
+	std::vector<uint64_t> jumpPos(npos);
+	memcpy(jumpPos.data(), p + pos, npos * 8);
+	pos += npos * 8;
+	const uint64_t njumps = jumpPos[npos - 1];
+	if (len < pos + Up8(size_t(njumps) * 4))
+		return BadSlow("EOF reached while reading SlowScanner jumps");
+	h.masks.assign(size_t(states) * letters * h.words, 0);
+	for (size_t i = 0; i + 1 < npos; ++i) {
+		if (jumpPos[i] > jumpPos[i + 1] || jumpPos[i + 1] > njumps)
+			return BadSlow("Corrupt SlowScanner: jump positions not monotone");
+		for (uint64_t k = jumpPos[i]; k < jumpPos[i + 1]; ++k) {
+			uint32_t tgt;
+			memcpy(&tgt, p + pos + size_t(k) * 4, 4);
+			if (tgt >= states)
+				return BadSlow("Corrupt SlowScanner: jump target out of range");
+			h.masks[i * h.words + (tgt >> 5)] |= 1u << (tgt & 31);
+		}
+	}
+	return PIRE_HIP_OK;
+}
+
+template <class T>
+int PutSlow(T** dst, const std::vector<T>& src)
+{
+	*dst = nullptr;
+	hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), std::max<size_t>(src.size() * sizeof(T), 16));
+	if (e != hipSuccess)
+		return HipFail(e, "hipMalloc(slow table)");
+	if (!src.empty()) {
+		e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(slow table)");
+	}
+	return PIRE_HIP_OK;
+}
+
+void FreeSlowDevice(SlowDevice* d)
+{
+	if (d->device < 0)
+		return;
+	if (d->letterOf) (void)hipFree(d->letterOf);
+	if (d->masks) (void)hipFree(d->masks);
+	if (d->finals) (void)hipFree(d->finals);
+	*d = SlowDevice();
+}
+
+// The kernel is compiled for K in {1,2,4,8} words; the device rows are padded to that K.
+int DeviceK(uint32_t words)
+{
+	return words <= 1 ? 1 : words <= 2 ? 2 : words <= 4 ? 4 : words <= 8 ? 8 : 0;
+}
+
+int UploadSlow(pire_hip_slow_table* t)
+{
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	if (t->dev.device == dev)
+		return PIRE_HIP_OK;
+	FreeSlowDevice(&t->dev);
+	const SlowHost& h = t->host;
+	const int K = DeviceK(h.words);
+	if (K == 0) {
+		SetError("SlowScanner with more than 256 NFA states is not supported on the GPU yet");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	std::vector<uint32_t> masks(size_t(h.states) * h.letters * K, 0), finals(K, 0);
+	for (size_t i = 0; i < size_t(h.states) * h.letters; ++i)
+		for (uint32_t w = 0; w < h.words; ++w)
+			masks[i * K + w] = h.masks[i * h.words + w];
+	for (uint32_t w = 0; w < h.words; ++w)
+		finals[w] = h.finals[w];
+	SlowDevice d;
+	int rc;
+	if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.masks, masks)) || (rc = PutSlow(&d.finals, finals))) {
+		d.device = dev;
+		FreeSlowDevice(&d);
+		return rc;
+	}
+	d.device = dev;
+	t->dev = d;
+	return PIRE_HIP_OK;
+}
+
+template <int K>
+int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
+{
+	SlowParams p = p0;
+	const size_t maskBytes = size_t(p.states) * p.letters * K * 4;
+	p.masksInLds = maskBytes <= 150 * 1024 ? 1 : 0;
+	const uint32_t ldsBytes = uint32_t(272 + (p.masksInLds ? maskBytes : 0));
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SlowScanKernel<K>),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	int dev = 0;
+	hipDeviceProp_t prop;
+	if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess)
+		return HipFail(e, "hipGetDeviceProperties");
+	const uint64_t want = (p.n + 255) / 256;
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(prop.multiProcessorCount) * 4)));
+	hipLaunchKernelGGL(SlowScanKernel<K>, dim3(blocks), dim3(256), ldsBytes, stream, p);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "slow kernel launch");
+	return PIRE_HIP_OK;
+}
+
+int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint64_t len, uint64_t stride,
+            uint32_t flags, uint8_t* outFinal, uint32_t* outBits, uint64_t* outCounts, void* streamPtr)
+{
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	if (int rc = UploadSlow(t))
+		return rc;
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	const SlowHost& h = t->host;
+	SlowParams p;
+	memset(&p, 0, sizeof(p));
+	p.letterOf = t->dev.letterOf;
+	p.masks = t->dev.masks;
+	p.finals = t->dev.finals;
+	p.states = h.states;
+	p.letters = h.letters;
+	p.start = h.start;
+	p.words = h.words;
+	p.flags = flags;
+	p.n = n;
+	p.len = len;
+	p.stride = stride;
+	if (n == 0)
+		return PIRE_HIP_OK;
+	const int K = DeviceK(h.words);
+	auto launch = [&](const SlowParams& q) {
+		switch (K) {
+		case 1: return LaunchSlowK<1>(q, stream);
+		case 2: return LaunchSlowK<2>(q, stream);
+		case 4: return LaunchSlowK<4>(q, stream);
+		default: return LaunchSlowK<8>(q, stream);
+		}
+	};
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		p.outFinal = outFinal;
+		p.outBits = outBits;
+		p.outCounts = reinterpret_cast<unsigned long long*>(outCounts);
+		return launch(p);
+	}
+	// host-pointer mode: stage through HBM
+	std::vector<void*> tmp;
+	auto alloc = [&](void** d, size_t bytes) {
+		hipError_t e = hipMalloc(d, bytes ? bytes : 16);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMalloc(staging)");
+		tmp.push_back(*d);
+		return int(PIRE_HIP_OK);
+	};
+	auto cleanup = [&] { for (void* q : tmp) (void)hipFree(q); };
+	uint64_t textBytes = offsets ? offsets[n] : (n - 1) * stride + len;
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	void *dText = nullptr, *dOff = nullptr, *dFin = nullptr, *dBits = nullptr, *dCnt = nullptr;
+	int rc = alloc(&dText, textBytes);
+	if (!rc && textBytes)
+		if (hipMemcpyAsync(dText, text, textBytes, hipMemcpyHostToDevice, stream) != hipSuccess)
+			rc = HipFail(hipGetLastError(), "hipMemcpy(H2D)");
+	if (!rc && offsets) {
+		rc = alloc(&dOff, (n + 1) * 8);
+		if (!rc && hipMemcpyAsync(dOff, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream) != hipSuccess)
+			rc = HipFail(hipGetLastError(), "hipMemcpy(H2D)");
+	}
+	if (!rc && outFinal) rc = alloc(&dFin, n);
+	if (!rc && outBits) rc = alloc(&dBits, n * h.words * 4);
+	if (!rc && outCounts) {
+		rc = alloc(&dCnt, 16);
+		if (!rc && hipMemcpyAsync(dCnt, outCounts, 16, hipMemcpyHostToDevice, stream) != hipSuccess)
+			rc = HipFail(hipGetLastError(), "hipMemcpy(H2D)");
+	}
+	if (!rc) {
+		p.text = static_cast<const uint8_t*>(dText);
+		p.offsets = static_cast<const uint64_t*>(dOff);
+		p.outFinal = static_cast<uint8_t*>(dFin);
+		p.outBits = static_cast<uint32_t*>(dBits);
+		p.outCounts = static_cast<unsigned long long*>(dCnt);
+		rc = launch(p);
+	}
+	hipError_t e = hipSuccess;
+	if (!rc && outFinal) e = hipMemcpyAsync(outFinal, dFin, n, hipMemcpyDeviceToHost, stream);
+	if (!rc && e == hipSuccess && outBits) e = hipMemcpyAsync(outBits, dBits, n * h.words * 4, hipMemcpyDeviceToHost, stream);
+	if (!rc && e == hipSuccess && outCounts) e = hipMemcpyAsync(outCounts, dCnt, 16, hipMemcpyDeviceToHost, stream);
+	if (!rc && e == hipSuccess) e = hipStreamSynchronize(stream);
+	if (!rc && e != hipSuccess)
+		rc = HipFail(e, "copy back / synchronize");
+	cleanup();
+	return rc;
+}
+
+}  // namespace
+}  // namespace pirehip
+
+using namespace pirehip;
+
+extern "C" {
+
+int pire_hip_slow_table_create(const void* save_blob, size_t len, pire_hip_slow_table** out)
+{
+	if (!out) {
+		SetError("null out pointer");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	std::unique_ptr<pire_hip_slow_table> t(new (std::nothrow) pire_hip_slow_table);
+	if (!t) {
+		SetError("out of memory");
+		return PIRE_HIP_ENOMEM;
+	}
+	if (int rc = BuildSlowHost(save_blob, len, &t->host))
+		return rc;
+	*out = t.release();
+	return PIRE_HIP_OK;
+}
+
+void pire_hip_slow_table_destroy(pire_hip_slow_table* t)
+{
+	if (!t)
+		return;
+	FreeSlowDevice(&t->dev);
+	delete t;
+}
+
+int pire_hip_slow_table_get_info(const pire_hip_slow_table* t, pire_hip_slow_info* out)
+{
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	memset(out, 0, sizeof(*out));
+	out->states = t->host.states;
+	out->letters = t->host.letters;
+	out->start = t->host.start;
+	out->words = t->host.words;
+	out->empty = t->host.empty ? 1 : 0;
+	out->mask_bytes = uint64_t(t->host.masks.size()) * 4;
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_slow_run(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                      uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts, void* stream)
+{
+	if (n && !offsets) {
+		SetError("null offsets");
+		return PIRE_HIP_EINVAL;
+	}
+	return RunSlow(t, text, offsets, n, 0, 0, flags, out_final, out_state_bits, out_counts, stream);
+}
+
+int pire_hip_slow_run_strided(pire_hip_slow_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
+                              uint32_t flags, uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts,
+                              void* stream)
+{
+	if (stride < len) {
+		SetError("stride smaller than len");
+		return PIRE_HIP_EINVAL;
+	}
+	return RunSlow(t, text, nullptr, n, len, stride, flags, out_final, out_state_bits, out_counts, stream);
+}
+
+}  // extern "C"

@@ -23,7 +23,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.binding import RefScanner, corpus_fill, make_plants  # noqa: E402
+from oracle.binding import RefScanner, RefSlowScanner, corpus_fill, make_plants  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -226,10 +226,37 @@ def main():
     corpus = {"seed": CORPUS_SEED, "noplant_first4_len100_b64": base64.b64encode(c0.tobytes()).decode(),
               "planted_from5_count12_len77_b64": base64.b64encode(c1.tobytes()).decode()}
 
+    # SlowScanner (scanners/slow.h): the Slow test of pire_ut.cpp:707-714 + the config-5b style patterns
+    slow = []
+    SLOW = [
+        ("slow_a30", "pire_ut.cpp:707-714", "a.{30}$", "",
+         [(b"....a" + b"." * 30, A), (b"....a" + b"." * 31, D), (b"....a" + b"." * 29, D)]),
+        ("slow_x40_utf8", "BASELINE config 5 / SURVEY 8a a12", "x.{40}$", "u",
+         [(b"zzx" + b"y" * 40, A), (b"zzx" + b"y" * 39, D), (b"x" + "\u0436".encode("utf-8") * 40, A),
+          (b"x" + "\u0436".encode("utf-8") * 41, D)]),
+        ("slow_alt", "pire_ut.cpp:62-74 patterns through SlowScanner", "abc|ad*e", "",
+         [(b"def", D), (b"abc", A), (b"xadddez", A), (b"xafez", D)]),
+    ]
+    rng = np.random.RandomState(77)
+    for name, source, pat, opt, items in SLOW:
+        sc = RefSlowScanner.compile(pat, opt)
+        strings = [s_ for s_, _ in items]
+        strings += [bytes(rng.choice(np.frombuffer(b"ax.yd e\xd0\xb6bc", dtype=np.uint8), size=int(k)))
+                    for k in rng.randint(0, 120, size=40)]
+        fin, bits = sc.run_strings(strings)
+        for (s_, verdict), f_ in zip(items, fin):
+            assert bool(f_) == verdict, (name, s_, f_, verdict)
+        blob = sc.save()
+        slow.append({"name": name, "source": source, "pattern": pat, "options": opt,
+                     "geometry": {"states": sc.size, "letters": sc.letters, "words": sc.words},
+                     "blob": write_blob(name, blob), "blob_sha256": hashlib.sha256(blob).hexdigest(),
+                     "strings_hex": [x.hex() for x in strings], "ref_expect": [v for _, v in items],
+                     "final": [int(x) for x in fin], "bits_hex": [bytes(np.ascontiguousarray(b)).hex() for b in bits]})
+
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "corpus": corpus}, f, indent=1)
-    print("wrote", len(cases), "cases,", len(big), "big sets")
+                   "cases": cases, "big": big, "slow": slow, "corpus": corpus}, f, indent=1)
+    print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners")
 
 
 if __name__ == "__main__":
