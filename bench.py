@@ -109,8 +109,84 @@ def cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin):
     return out
 
 
+def bench_slow(args):
+    """BASELINE config 5b (informational, `--set slow_x40_utf8`): Pire::SlowScanner, NFA simulation.  Same JSON
+    shape as the headline; the kernel is pirehip::SlowScanKernel (VALU/LDS bound, not HBM bound)."""
+    import torch
+
+    import pire_amd
+    from pire_amd import binding as pb
+    from oracle import binding as ob
+    from tests import helpers as H
+
+    case = [c for c in H.golden()["slow"] if c["name"] == args.set][0]
+    blob = H.load_blob(case["blob"])
+    table = pire_amd.SlowTable(blob)
+    torch.cuda.set_device(0)
+    n, length = 1 << args.log2_strings, args.len
+    plants = ob.make_plants([(b"x" + b"y" * 40, True), (b"zx" + b"w" * 39, True)])   # one witness, one near miss
+    text = torch.empty((n, length), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    pire_amd.corpus_fill_device(text.data_ptr(), SEED, 0, n, length, length, plants, stream)
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
+    flags = pb.FLAG_BEGIN | pb.FLAG_END
+
+    def step():
+        cnt.zero_()
+        table.run_strided_device(text.data_ptr(), n, length, length, flags, fin.data_ptr(), 0, cnt.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms = [a.elapsed_time(b) for a, b in ev]
+    value = float(n) * length * args.steps / elapsed / 1e9
+    res = {"metric": "scanned GB/s, SlowScanner (config 5b)", "value": round(value, 2), "unit": "GB/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"C5b: SlowScanner {case['pattern']!r} ({case['options'] or 'latin1'}), "
+                                  f"{case['geometry']['states']} NFA states, 2^{args.log2_strings} x {length} B strings",
+                      "strings_per_gpu": n, "string_bytes": length},
+           "roofline": {"bound": "hbm", "achieved": round(n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "pirehip::SlowScanKernel", "kernel_avg_ms": round(float(np.mean(ms)), 4)},
+           "match_counts": {"final": int(cnt[0].item()), "strings": int(cnt[1].item())}}
+    if not args.no_cpu:
+        sample = min(n, 1 << min(args.cpu_sample_log2, 12))
+        host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=8)
+        offs = np.arange(sample + 1, dtype=np.uint64) * length
+        threads = min(os.cpu_count() or 1, 64)
+        if ob.ref_available():
+            ref = ob.RefSlowScanner.load(blob)
+            t0 = time.time()
+            rf, _ = ref.run(host.reshape(-1), offs, threads=threads)
+            dt = time.time() - t0
+            kind = "reference"
+        else:
+            o = ob.OracleSlowScanner(blob)
+            t0 = time.time()
+            rf, _ = o.run(host.reshape(-1), offs)
+            dt = time.time() - t0
+            kind, threads = "port", 1
+        res["cpu_baseline"] = {"value": round(sample * length / dt / 1e9, 4), "unit": "GB/s", "cores": threads,
+                               "kind": kind, "sample": f"first {sample} strings x {length} B",
+                               "parity_vs_gpu": bool((rf == fin[:sample].cpu().numpy()).all())}
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
+    if args.set.startswith("slow_"):
+        return bench_slow(args)
     import torch
     import torch.distributed as dist
 

@@ -118,8 +118,20 @@ __global__ __launch_bounds__(256) void SlowScanKernel(SlowParams p)
 			SlowStep<K>(masks, p.letters, cur, ldsLetter[kBeginMark]);   // Begin(), run.h:375
 		const uint8_t* ptr = p.text + b;
 		const uint8_t* end = p.text + e;
+		// Run<SlowScanner>, slow.h:436-451 -- byte by byte; 16-byte vector loads where the pointer allows
+		for (; ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15); ++ptr)
+			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);
+		for (; ptr + 16 <= end; ptr += 16) {
+			const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					SlowStep<K>(masks, p.letters, cur, ldsLetter[(w[i] >> (8 * j)) & 0xFF]);
+		}
 		for (; ptr < end; ++ptr)
-			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);         // Run<SlowScanner>, slow.h:436-451
+			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);
 		if (p.flags & PIRE_HIP_RUN_END)
 			SlowStep<K>(masks, p.letters, cur, ldsLetter[kEndMark]);     // End(), run.h:376
 		bool fin = false;
