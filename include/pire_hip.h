@@ -160,6 +160,15 @@ int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64
  */
 int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream);
 
+/*
+ * Pire::LongestPrefix / Pire::ShortestPrefix (run.h:277-311) for n strings: out_len[i] = length of the longest
+ * (shortest) prefix of string i the scanner accepts, or -1 where the reference returns a null pointer.
+ * through_begin / through_end as the reference's throughBeginMark / throughEndMark.  Scanning stops at the first
+ * dead state (pire_ut.cpp:475-483).  flags: only PIRE_HIP_RUN_ON_DEVICE is looked at.
+ */
+int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
+                    int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
+
 /* Name of the kernel the last run on this thread dispatched to ("tiled", "generic"); diagnostics. */
 const char* pire_hip_last_kernel(void);
 

@@ -435,7 +435,10 @@ void oracle_run_shortcut(const oracle_scanner* sc, const void* text, const uint6
 void oracle_prefix(const oracle_scanner* sc, int longest, const void* text, const uint64_t* offsets,
                    uint64_t n, int through_begin, int through_end, int64_t* out_len)
 {
-	const uint8_t* t = (const uint8_t*)text;
+	static const uint8_t k_empty[1] = {0};
+	/* the reference reports "no prefix" as a null pointer; with a null base an empty match at position 0 would be
+	 * indistinguishable from a miss, so empty batches get a real address */
+	const uint8_t* t = text ? (const uint8_t*)text : k_empty;
 	uint64_t i;
 	for (i = 0; i < n; ++i) {
 		const uint8_t* begin = t + offsets[i];

@@ -268,7 +268,10 @@ int pire_ref_prefix(void* h, int longest, const void* text, const uint64_t* offs
 {
 	try {
 		const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
-		const char* t = static_cast<const char*>(text);
+		// the reference reports "no prefix" as a null pointer, so a null base would make an empty match at
+		// position 0 look like a miss: give empty batches a real address
+		static const char kEmpty[1] = {0};
+		const char* t = text ? static_cast<const char*>(text) : kEmpty;
 		for (uint64_t i = 0; i < n; ++i) {
 			const char* b = t + offsets[i];
 			const char* e = t + offsets[i + 1];

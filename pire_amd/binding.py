@@ -87,6 +87,8 @@ ABI = [
     ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    ("pire_hip_prefix", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                  C.c_void_p, C.c_void_p]),
     ("pire_hip_slow_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_slow_table_destroy", None, [C.c_void_p]),
     ("pire_hip_slow_table_get_info", C.c_int, [C.c_void_p, C.POINTER(SlowInfo)]),
@@ -253,6 +255,17 @@ class Table:
         _check(lib().pire_hip_run(self._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
                                   init_ptr or None, out_idx_ptr or None, out_final_ptr or None,
                                   out_counts_ptr or None, stream or None))
+
+    def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
+        """LongestPrefix / ShortestPrefix lengths (-1 = no prefix) for host strings."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.empty(n, dtype=np.int64)
+        _check(lib().pire_hip_prefix(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                     int(longest), int(through_begin), int(through_end), 0, out.ctypes.data, None))
+        return out
 
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))

@@ -427,6 +427,55 @@ int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64
 	               stream);
 }
 
+int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
+                    int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* streamPtr)
+{
+	if (!t || (n && (!offsets || !out_len))) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	ScanParams p;
+	if (int rc = FillParams(t, &p, through_begin ? PIRE_HIP_RUN_BEGIN : 0))   // startPerm = Initialize [+ BeginMark]
+		return rc;
+	p.n = n;
+	if (n == 0)
+		return PIRE_HIP_OK;
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		return LaunchPrefix(p, longest != 0, through_end != 0, reinterpret_cast<long long*>(out_len), stream);
+	}
+	Staging st;
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i] > offsets[i + 1]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
+		}
+	const uint64_t textBytes = offsets[n];
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	const uint8_t* dText = nullptr;
+	if (int rc = st.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream))
+		return rc;
+	p.text = dText;
+	if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
+		return rc;
+	void* dOut = nullptr;
+	if (int rc = st.Alloc(&dOut, size_t(n) * 8))
+		return rc;
+	if (int rc = LaunchPrefix(p, longest != 0, through_end != 0, static_cast<long long*>(dOut), stream))
+		return rc;
+	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+		return HipFail(e, "copy back / synchronize");
+	return PIRE_HIP_OK;
+}
+
 int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream)
 {
 	if (!t || (n && !state_idx) || ch >= kMaxCharUnaligned || ch == kEpsilon) {

@@ -136,6 +136,7 @@ int LaunchGeneric(const ScanParams& p, hipStream_t stream);
 int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
+int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);
 

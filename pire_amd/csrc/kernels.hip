@@ -499,6 +499,70 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	FlushCounts(p, lds, L);
 }
 
+// ------------------------------------------------------------------------------------------ prefix searches
+// Pire::LongestPrefix / ShortestPrefix (run.h:277-311) with LongestPrefixPred / ShortestPrefixPred (run.h:69-100):
+// the same walk, but after every byte Final(state) records the position and Dead(state) (or, for the shortest
+// prefix, the first Final) ends it.  One string per lane, exact step (dense row first); the early exit is per lane.
+
+struct PrefixParams {
+	ScanParams scan;
+	uint32_t longest, throughEnd;
+	long long* outLen;
+};
+
+__device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t st)
+{
+	return st < p.hot ? lds[L.flagsOff + st] : p.flagsPerm[st];
+}
+
+__global__ __launch_bounds__(256) void PrefixKernel(PrefixParams q)
+{
+	const ScanParams& p = q.scan;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0);
+	LoadTableToLds(p, lds, L);
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		const uint8_t* text = p.text + b;
+		const uint64_t len = e - b;
+		uint32_t st = p.startPerm;                       // Initialize (+ BeginMark if throughBeginMark), run.h:280-283
+		long long pos = -1;
+		bool stop = false;
+		uint32_t f = StateFlags(p, lds, L, st);
+		if (f & kFinal) {
+			pos = 0;                                     // run.h:284 / 301-302
+			stop = !q.longest;
+		}
+		const bool foundAtStart = stop;
+		for (uint64_t i = 0; i < len && !stop; ++i) {
+			st = SlowStep(p, lds, L, st, text[i]);
+			f = StateFlags(p, lds, L, st);
+			if (f & kFinal) {
+				pos = (long long)(i + 1);
+				if (!q.longest)
+					stop = true;                         // ShortestPrefixPred: Stop on the first Final
+			}
+			if (f & kDead)
+				stop = true;                             // both predicates stop on a dead state
+		}
+		if (q.throughEnd && !foundAtStart) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			if (StateFlags(p, lds, L, st) & kFinal) {
+				if (q.longest || pos < 0)
+					pos = (long long)len;                // run.h:286-290 / 305-309
+			}
+		}
+		q.outLen[s] = pos;
+	}
+}
+
 // ------------------------------------------------------------------------------------------ single Step()
 
 __global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateIdx, uint64_t n, uint32_t cls)
@@ -677,6 +741,31 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	if (p.outFinal)
 		tail.outFinal = p.outFinal + q.n;
 	return LaunchGeneric(tail, stream);
+}
+
+int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream)
+{
+	if (p.n == 0)
+		return PIRE_HIP_OK;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, 0);
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(PrefixKernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	PrefixParams q;
+	q.scan = p;
+	q.longest = longest ? 1 : 0;
+	q.throughEnd = throughEnd ? 1 : 0;
+	q.outLen = outLen;
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 2)));
+	hipLaunchKernelGGL(PrefixKernel, dim3(blocks), dim3(256), L.total, stream, q);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "prefix kernel launch");
+	return PIRE_HIP_OK;
 }
 
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream)
