@@ -189,6 +189,70 @@ private:
 template <class Scanner>
 BatchRunner<Scanner>* NewBatchRunner(const Scanner& sc) { return new BatchRunner<Scanner>(sc); }
 
+/*
+ * Batched Pire::LongestPrefix / Pire::ShortestPrefix (run.h:277-311).  Returns, per string, the END pointer of the
+ * prefix exactly as the reference does (null = no prefix), computed from the lengths the GPU returns.
+ */
+template <class Scanner>
+std::vector<const char*> BatchPrefix(const Table<Scanner>& table, bool longest, const char* text, const uint64_t* offsets,
+                                     size_t n, bool throughBeginMark = false, bool throughEndMark = false)
+{
+	std::vector<int64_t> len(n);
+	static const uint64_t kNoOffsets[1] = {0};
+	Check(pire_hip_prefix(table.Handle(), text, n ? offsets : kNoOffsets, n, longest ? 1 : 0, throughBeginMark ? 1 : 0,
+	                      throughEndMark ? 1 : 0, 0, len.data(), nullptr));
+	std::vector<const char*> out(n);
+	for (size_t i = 0; i < n; ++i)
+		out[i] = len[i] < 0 ? nullptr : text + offsets[i] + len[i];
+	return out;
+}
+
+template <class Scanner>
+std::vector<const char*> BatchLongestPrefix(const Table<Scanner>& t, const char* text, const uint64_t* offsets, size_t n,
+                                            bool throughBeginMark = false, bool throughEndMark = false)
+{
+	return BatchPrefix(t, true, text, offsets, n, throughBeginMark, throughEndMark);
+}
+
+template <class Scanner>
+std::vector<const char*> BatchShortestPrefix(const Table<Scanner>& t, const char* text, const uint64_t* offsets, size_t n,
+                                             bool throughBeginMark = false, bool throughEndMark = false)
+{
+	return BatchPrefix(t, false, text, offsets, n, throughBeginMark, throughEndMark);
+}
+
+/*
+ * Batched Runner over a Pire::SlowScanner (scanners/slow.h): Matches(sc, str) per string, i.e.
+ * Final(Runner(sc).Begin().Run(str).End().State()).
+ */
+class SlowBatchRunner {
+public:
+	explicit SlowBatchRunner(const Pire::SlowScanner& sc)
+	    : m_table(nullptr)
+	{
+		std::ostringstream out;
+		sc.Save(&out);                                    // scanner_io.cpp:71-111
+		const std::string blob = out.str();
+		Check(pire_hip_slow_table_create(blob.data(), blob.size(), &m_table));
+	}
+	~SlowBatchRunner() { pire_hip_slow_table_destroy(m_table); }
+
+	/* Begin().Run().End() for n strings; returns operator bool of the reference's RunHelper per string. */
+	std::vector<char> Matches(const char* text, const uint64_t* offsets, size_t n)
+	{
+		std::vector<uint8_t> fin(n);
+		static const uint64_t kNoOffsets[1] = {0};
+		Check(pire_hip_slow_run(m_table, text, n ? offsets : kNoOffsets, n, PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END,
+		                        fin.data(), nullptr, nullptr, nullptr));
+		return std::vector<char>(fin.begin(), fin.end());
+	}
+
+private:
+	SlowBatchRunner(const SlowBatchRunner&);
+	SlowBatchRunner& operator=(const SlowBatchRunner&);
+	pire_hip_slow_table* m_table;
+};
+
 }  // namespace Hip
 }  // namespace Pire
 

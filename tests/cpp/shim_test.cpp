@@ -109,9 +109,46 @@ static void TestSuite()
 	}
 }
 
+// LongestPrefix / ShortestPrefix (run.h:277-311) and SlowScanner (pire_ut.cpp:707-714) through the shim.
+static void TestPrefixAndSlow()
+{
+	std::vector<Pire::ystring> text = {"aaab", "", "fixed prefix", "a fixed nonexistent prefix", "aaabbb", "bbbbbb", "xaaay"};
+	Pire::ystring flat;
+	std::vector<uint64_t> offs(1, 0);
+	for (auto& s : text) { flat += s; offs.push_back(flat.size()); }
+	const char* patterns[] = {"a*", "a", "fixed", "aa*", "a+b", "aaa"};
+	for (const char* re : patterns) {
+		Pire::Scanner sc = Parse(re, false).Compile<Pire::Scanner>();
+		Pire::Hip::Table<Pire::Scanner> table(sc);
+		for (int tb = 0; tb < 2; ++tb)
+			for (int te = 0; te < 2; ++te) {
+				auto lp = Pire::Hip::BatchLongestPrefix(table, flat.data(), offs.data(), text.size(), tb, te);
+				auto sp = Pire::Hip::BatchShortestPrefix(table, flat.data(), offs.data(), text.size(), tb, te);
+				for (size_t i = 0; i < text.size(); ++i) {
+					const char* b = flat.data() + offs[i];
+					const char* e = flat.data() + offs[i + 1];
+					CHECK(lp[i] == Pire::LongestPrefix(sc, b, e, tb, te));
+					CHECK(sp[i] == Pire::ShortestPrefix(sc, b, e, tb, te));
+				}
+			}
+	}
+	Pire::SlowScanner slow = Parse("a.{30}$").Compile<Pire::SlowScanner>();
+	Pire::Hip::SlowBatchRunner run(slow);
+	std::vector<Pire::ystring> s = {"....a..............................", "....a...............................",
+	                                "....a.............................", ""};
+	Pire::ystring f2;
+	std::vector<uint64_t> o2(1, 0);
+	for (auto& x : s) { f2 += x; o2.push_back(f2.size()); }
+	std::vector<char> m = run.Matches(f2.data(), o2.data(), s.size());
+	for (size_t i = 0; i < s.size(); ++i)
+		CHECK((m[i] != 0) == bool(Pire::Runner(slow).Begin().Run(s[i]).End()));
+	CHECK(m[0] && !m[1] && !m[2]);
+}
+
 int main()
 {
 	try {
+		TestPrefixAndSlow();
 		TestSuite<Pire::Scanner>();
 		TestSuite<Pire::NonrelocScanner>();
 		TestSuite<Pire::ScannerNoMask>();
