@@ -32,7 +32,8 @@ namespace {
 
 // LDS carve-up shared by both scan kernels (single dynamic region, 16-byte aligned pieces).
 struct LdsLayout {
-	uint32_t hotBytes;     // (hot+1)*256
+	uint32_t pitch;        // bytes between dense rows: 260 = 65 dwords rotates row r by r banks, or 256
+	uint32_t hotBytes;     // (hot+1)*pitch, rounded up to 16
 	uint32_t flagsOff;     // 256 B of hot flags
 	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
 	uint32_t countsOff;    // (regexps+2) u32 block-local counters
@@ -40,10 +41,13 @@ struct LdsLayout {
 	uint32_t total;
 };
 
-__host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps)
+constexpr uint32_t kRotPitch = 260;
+
+__host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps, uint32_t pitch = kRotPitch)
 {
 	LdsLayout l;
-	l.hotBytes = (hot + 1) * 256;
+	l.pitch = pitch;
+	l.hotBytes = ((hot + 1) * pitch + 15) / 16 * 16;
 	l.flagsOff = l.hotBytes;
 	l.clsOff = l.flagsOff + 256;
 	l.countsOff = l.clsOff + 528;
@@ -62,10 +66,12 @@ constexpr uint32_t kDebugNoHist = 1u << 27;
 __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
 {
 	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-	const u32x4* src = reinterpret_cast<const u32x4*>(p.hotRows);
-	u32x4* dst = reinterpret_cast<u32x4*>(lds);
-	for (uint32_t i = tid; i < L.hotBytes / 16; i += nthr)
-		dst[i] = src[i];
+	// dense rows: 256-byte rows in HBM, `pitch`-byte rows in LDS (dword copies: 260 is only 4-byte aligned)
+	const uint32_t* src = reinterpret_cast<const uint32_t*>(p.hotRows);
+	uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+	const uint32_t pitchDw = L.pitch / 4;
+	for (uint32_t i = tid; i < (p.hot + 1) * 64; i += nthr)
+		dst[(i >> 6) * pitchDw + (i & 63)] = src[i];
 	for (uint32_t i = tid; i < 256 / 4; i += nthr)
 		reinterpret_cast<uint32_t*>(lds + L.flagsOff)[i] = reinterpret_cast<const uint32_t*>(p.hotFlags)[i];
 	for (uint32_t i = tid; i < 264 / 2; i += nthr)
@@ -83,7 +89,7 @@ __device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t*
                                              uint32_t st, uint32_t byte)
 {
 	if (st < p.hot) {
-		const uint32_t e = lds[(st << 8) | byte];
+		const uint32_t e = lds[st * L.pitch + byte];
 		if (e != p.hot)
 			return e;
 	}
@@ -282,36 +288,62 @@ __device__ __forceinline__ void WaitTile(u32x4 (&r)[8])
 
 // One butterfly stage of the 8x8 transpose: exchange (register bit D) with (lane bit D) for the pair x = reg k,
 // y = reg k|D:   x'[l] = (l & D) ? y[l ^ D] : x[l],    y'[l] = (l & D) ? y[l] : x[l ^ D].
-template <int D>
-__device__ __forceinline__ void Butterfly(uint32_t& x, uint32_t& y, bool laneBit)
+// D = 4: two bank-masked DPP moves (row_shr:4 into banks 1,3; row_shl:4 into banks 0,2).
+__device__ __forceinline__ void Butterfly4(uint32_t& x, uint32_t& y)
 {
-	if (D == 4) {
-		// row_shr:4 into banks 1,3 (lanes with bit 2 set read lane l-4); row_shl:4 into banks 0,2
-		const uint32_t nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
-		const uint32_t ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
-		x = nx;
-		y = ny;
-	} else {
-		constexpr int ctrl = D == 1 ? 0xB1 /* quad_perm:[1,0,3,2] */ : 0x4E /* quad_perm:[2,3,0,1] */;
-		const uint32_t xp = __builtin_amdgcn_mov_dpp(x, ctrl, 0xF, 0xF, true);
-		const uint32_t yp = __builtin_amdgcn_mov_dpp(y, ctrl, 0xF, 0xF, true);
-		x = laneBit ? yp : x;
-		y = laneBit ? y : xp;
-	}
+	const uint32_t nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
+	const uint32_t ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
+	x = nx;
+	y = ny;
+}
+
+// D = 1 or 2: the partner lane sits in the same quad; one FUSED v_cndmask_b32_dpp per output (hipcc does not form
+// it from v_mov_dpp + v_cndmask: the select mask would have to be inverted for half of them).  `lo` = lanes whose
+// bit D is clear, `hi` = lanes whose bit D is set (64-bit wave masks).  Four pairs per statement, one column.
+#define PIRE_BFLY_QUAD(PERM)                                                                                           \
+	asm volatile("s_nop 1\n\t"                                                                                     \
+	             "s_mov_b64 vcc, %16\n\t"                                                                           \
+	             "v_cndmask_b32_dpp %0, %9, %8, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
+	             "v_cndmask_b32_dpp %2, %11, %10, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %4, %13, %12, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %6, %15, %14, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "s_mov_b64 vcc, %17\n\t"                                                                           \
+	             "v_cndmask_b32_dpp %1, %8, %9, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
+	             "v_cndmask_b32_dpp %3, %10, %11, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %5, %12, %13, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %7, %14, %15, vcc " PERM " row_mask:0xf bank_mask:0xf"                          \
+	             : "=&v"(nx0), "=&v"(ny0), "=&v"(nx1), "=&v"(ny1), "=&v"(nx2), "=&v"(ny2), "=&v"(nx3), "=&v"(ny3)    \
+	             : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "s"(lo), "s"(hi)          \
+	             : "vcc")
+
+// v_cndmask: D = vcc ? src1 : src0, DPP permutes src0.  With vcc = lo:  x' = lo ? x : perm(y);  with vcc = hi:
+// y' = hi ? y : perm(x).
+template <int D>
+__device__ __forceinline__ void ButterflyQuad4(uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1, uint32_t& x2,
+                                               uint32_t& y2, uint32_t& x3, uint32_t& y3, uint64_t lo, uint64_t hi)
+{
+	uint32_t nx0, ny0, nx1, ny1, nx2, ny2, nx3, ny3;
+	if (D == 1)
+		PIRE_BFLY_QUAD("quad_perm:[1,0,3,2]");
+	else
+		PIRE_BFLY_QUAD("quad_perm:[2,3,0,1]");
+	x0 = nx0; y0 = ny0; x1 = nx1; y1 = ny1; x2 = nx2; y2 = ny2; x3 = nx3; y3 = ny3;
 }
 
 __device__ __forceinline__ void TransposeTile(u32x4 (&r)[8], uint32_t lane)
 {
-	const bool b0 = lane & 1, b1 = lane & 2;
+	(void)lane;
+	const uint64_t lo1 = 0x5555555555555555ull, hi1 = 0xAAAAAAAAAAAAAAAAull;   // lane bit 0 clear / set
+	const uint64_t lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;   // lane bit 1 clear / set
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		uint32_t d[8];
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
 			d[k] = r[k][w];
-		Butterfly<1>(d[0], d[1], b0); Butterfly<1>(d[2], d[3], b0); Butterfly<1>(d[4], d[5], b0); Butterfly<1>(d[6], d[7], b0);
-		Butterfly<2>(d[0], d[2], b1); Butterfly<2>(d[1], d[3], b1); Butterfly<2>(d[4], d[6], b1); Butterfly<2>(d[5], d[7], b1);
-		Butterfly<4>(d[0], d[4], false); Butterfly<4>(d[1], d[5], false); Butterfly<4>(d[2], d[6], false); Butterfly<4>(d[3], d[7], false);
+		ButterflyQuad4<1>(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], lo1, hi1);
+		ButterflyQuad4<2>(d[0], d[2], d[1], d[3], d[4], d[6], d[5], d[7], lo2, hi2);
+		Butterfly4(d[0], d[4]); Butterfly4(d[1], d[5]); Butterfly4(d[2], d[6]); Butterfly4(d[3], d[7]);
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
 			r[k][w] = d[k];
@@ -344,6 +376,7 @@ __device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t
 }
 
 // 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
+template <bool ROT>
 __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                           const u32x4 v, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
 {
@@ -351,10 +384,21 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t x = v[w];
-		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
-		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
-		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
-		hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
+		if (ROT) {
+			// rows are 65 dwords apart, so row r is rotated by r banks: lanes in different states reading the same
+			// byte>>2 no longer hit the same bank.  The byte is extracted off the dependent chain; the chain
+			// itself stays one VALU (v_mad_u32_u24) + one ds_read_u8.
+			const uint32_t b0 = x & 0xFF, b1 = (x >> 8) & 0xFF, b2 = (x >> 16) & 0xFF, b3 = x >> 24;
+			hs = HotLookup(__umul24(hs, kRotPitch) + b0);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b1);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b2);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b3);
+		} else {
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
+		}
 	}
 	if (hs == p.hot) {
 		const uint32_t f = SlowChunk(p, lds, L, v, hs0 != p.hot ? hs0 : cold);
@@ -372,12 +416,13 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 	}
 }
 
+template <bool ROT>
 __device__ __forceinline__ void StepTile(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                          const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold, uint32_t tile)
 {
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
-		StepChunk(p, lds, L, r[k], hs, cold, (tile * 8 + k) & 63);
+		StepChunk<ROT>(p, lds, L, r[k], hs, cold, (tile * 8 + k) & 63);
 }
 
 // Wave-wide early out (north_star: "wavefront ballot/any for early-out on dead states"): once every lane sits
@@ -406,7 +451,7 @@ __device__ __forceinline__ uint64_t Uniform64(uint64_t v)
 // One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1
 // ahead (index clamped to the last tile, so the steady-state loop has no conditional loads), wait until the
 // current slot has landed, transpose it into lane-owns-string order, walk it.
-template <int NBUF, bool NT>
+template <int NBUF, bool NT, bool ROT>
 __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
                                       uint64_t chainBase, uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile,
                                       u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
@@ -425,20 +470,20 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 		hs ^= (cur[0].x ^ cur[7].w) & 1;
 		return;
 	}
-	StepTile(p, lds, L, cur, hs, cold, t);
+	StepTile<ROT>(p, lds, L, cur, hs, cold, t);
 }
 
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
 // the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
 // gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
-template <int WAVES, int NBUF, bool NT, int MINW>
+template <int WAVES, int NBUF, bool NT, int MINW, bool ROT>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
 	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
 	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT ? kRotPitch : 256u);
 	LoadTableToLds(p, lds, L);
 
 	const uint32_t lane = threadIdx.x & 63;
@@ -476,15 +521,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 			IssueTile<NT>(a, voff, rowBase, p.stride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
 			const uint32_t t = g * 2;
-			Phase<2, NT>(p, lds, L, rowBase, chainBase, voff, lane, t, lastTile, a, b, hs, cold);
-			Phase<2, NT>(p, lds, L, rowBase, chainBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t, lastTile, a, b, hs, cold);
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
 			done = AllAbsorbing(p, lds, L, hs);
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (!done && rem == 1) {
 			WaitTile<0>(a);
 			TransposeTile(a, lane);
-			StepTile(p, lds, L, a, hs, cold, lastTile);
+			StepTile<ROT>(p, lds, L, a, hs, cold, lastTile);
 		}
 
 		uint32_t st = hs != p.hot ? hs : cold;
@@ -723,10 +768,11 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoHist;
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
+	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u);
 	switch (variant) {
-	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5>, q, 1024, L.total, stream); break;
-	case 2:  rc = LaunchScan(ScanTiledKernel<10, 2, true, 5>, q, 640, L.total, stream); break;
-	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5>, q, 1024, L.total, stream); break;
+	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, true>, q, 1024, L.total, stream); break;   // bank-rotated rows
+	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, false>, q, 1024, L256.total, stream); break; // no nt
+	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, false>, q, 1024, L256.total, stream); break;
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;
