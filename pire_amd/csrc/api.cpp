@@ -98,19 +98,21 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	return PIRE_HIP_OK;
 }
 
-int Dispatch(const ScanParams& p, hipStream_t stream)
+int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,
+             uint64_t totalBytesHint = 0)
 {
 	if (p.n == 0)
 		return PIRE_HIP_OK;
 	const bool tiled = !(p.flags & PIRE_HIP_RUN_GENERIC) && TiledEligible(p);
+	const bool ragged = !tiled && !(p.flags & PIRE_HIP_RUN_GENERIC) && workCounter && RaggedEligible(p, totalBytesHint);
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	if (g_timing) {
 		if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess)
 			return HipFail(hipGetLastError(), "hipEventCreate");
 		(void)hipEventRecord(ev0, stream);
 	}
-	g_lastKernel = tiled ? "tiled" : "generic";
-	int rc = tiled ? LaunchTiled(p, stream) : LaunchGeneric(p, stream);
+	g_lastKernel = tiled ? "tiled" : ragged ? "ragged" : "generic";
+	int rc = tiled ? LaunchTiled(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
 		if (rc == PIRE_HIP_OK) {
@@ -150,7 +152,11 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		p.outIdx = outIdx;
 		p.outFinal = outFinal;
 		p.outCounts = reinterpret_cast<unsigned long long*>(outCounts);
-		return Dispatch(p, stream);
+		// device offsets: the total text size is not known on the host; n >= 256 strings of unknown length still
+		// need 128 readable bytes at `text` for the ragged kernel, which the caller guarantees by passing a batch
+		// (a batch with less than 4 KiB of text is not worth a GPU launch; use PIRE_HIP_RUN_GENERIC to force the
+		// offset-exact kernel)
+		return Dispatch(p, stream, t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots, offsets ? ~0ull : 0);
 	}
 
 	// Host-pointer mode: stage through HBM.  (PCIe-inclusive; the benchmark never times this mode.)
@@ -205,7 +211,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return HipFail(e, "hipMemcpy(counts)");
 		p.outCounts = static_cast<unsigned long long*>(dCnt);
 	}
-	if (int rc = Dispatch(p, stream))
+	if (int rc = Dispatch(p, stream, t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots, textBytes))
 		return rc;
 	hipError_t e = hipSuccess;
 	if (outIdx)

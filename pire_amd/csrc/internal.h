@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,15 +79,21 @@ struct DeviceTable {
 	struct FinRec* finEnd = nullptr;  // [states] end-of-string record after Step(EndMark)
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
+	unsigned long long* workCounter = nullptr;   // [kWorkSlots] ragged kernel: next string range to hand out;
+	                                             // one slot per launch so that launches on different streams
+	                                             // never share a counter
 	uint64_t bytes = 0;
 };
 
 }  // namespace pirehip
 
+namespace pirehip { constexpr uint32_t kWorkSlots = 1024; }
+
 struct pire_hip_table {
 	pirehip::HostTable host;
 	pirehip::DeviceTable dev;
 	std::mutex uploadMutex;
+	std::atomic<uint32_t> workSlot{0};   // round-robin over dev.workCounter[kWorkSlots]
 };
 
 namespace pirehip {
@@ -135,6 +142,8 @@ void FreeDeviceTable(DeviceTable* d);
 int LaunchGeneric(const ScanParams& p, hipStream_t stream);
 int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
+bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
+int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,

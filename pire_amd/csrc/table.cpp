@@ -311,7 +311,7 @@ void FreeDeviceTable(DeviceTable* d)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
-	                d->finSelf,    d->finEnd};
+	                d->finSelf,    d->finEnd,  d->workCounter};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -395,6 +395,8 @@ int UploadTable(pire_hip_table* t)
 		rc = Put(&d.visitHot, std::vector<uint32_t>(256, 0), &d.bytes);
 	if (!rc)
 		rc = Put(&d.visitCold, std::vector<uint32_t>(N, 0), &d.bytes);
+	if (!rc)
+		rc = Put(&d.workCounter, std::vector<unsigned long long>(kWorkSlots, 0), &d.bytes);
 	if (rc) {
 		d.device = dev;
 		FreeDeviceTable(&d);

@@ -113,6 +113,102 @@ def test_random_ragged_batches_vs_oracle(pa, name):
         assert (gi == oi).all() and (gf == of).all()
 
 
+def dev_run_ragged(torch, t, text, offs, flags=BE, init=None, generic=False):
+    """text/offs: numpy; staged by torch, run with device pointers.  Returns numpy idx, final, counts."""
+    from pire_amd import binding as pb
+
+    n = len(offs) - 1
+    d = torch.as_tensor(np.ascontiguousarray(text), device="cuda") if len(text) else torch.zeros(16, dtype=torch.uint8, device="cuda")
+    do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+    init_t = None if init is None else torch.as_tensor(np.asarray(init, dtype=np.int32), device="cuda")
+    t.run_device(d.data_ptr(), do.data_ptr(), n, flags | (pb.FLAG_GENERIC if generic else 0), idx.data_ptr(),
+                 fin.data_ptr(), cnt.data_ptr(), init_t.data_ptr() if init_t is not None else 0,
+                 torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy().astype(np.uint32), fin.cpu().numpy(), cnt.cpu().numpy().astype(np.uint64)
+
+
+def ragged_lengths(rng, kind, n):
+    if kind == "uniform":
+        return rng.randint(0, 700, size=n)
+    if kind == "edges":      # every tile / chunk boundary and its neighbours
+        base = np.array([0, 1, 15, 16, 17, 31, 32, 112, 113, 127, 128, 129, 143, 144, 145, 255, 256, 257, 383, 384, 400])
+        return base[rng.randint(0, len(base), size=n)]
+    if kind == "skewed":     # a few very long strings among many short ones: lanes must be re-used
+        ln = rng.randint(0, 40, size=n)
+        ln[rng.randint(0, n, size=6)] = rng.randint(20000, 60000, size=6)
+        return ln
+    if kind == "empty":
+        return np.zeros(n, dtype=np.int64)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("name", ["set_a", "set_d", "c2_single"])
+@pytest.mark.parametrize("kind,n", [("uniform", 5000), ("edges", 3000), ("skewed", 2500), ("empty", 300),
+                                    ("uniform", 256), ("edges", 70001)])
+def test_ragged_kernel_vs_oracle(pa, torch_cuda, name, kind, n):
+    """The dynamically scheduled ragged kernel (offset batches of >= 256 strings): every length class, lane re-use,
+    strings that end exactly at the end of the buffer, all flag combinations, match counts, resumed states."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(n + len(kind))
+    ln = ragged_lengths(rng, kind, n).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(ln)
+    total = int(offs[-1])
+    alphabet = np.frombuffer(b"abcdeaxHedInrTailhello w0123456789/.-_?=&%:@\n", dtype=np.uint8)
+    text = alphabet[rng.randint(0, len(alphabet), size=total)].astype(np.uint8)
+    for w in [bytes.fromhex(h) for h in big["witnesses_hex"]]:
+        for _ in range(50):
+            if total > len(w) + 1:
+                q = rng.randint(0, total - len(w))
+                text[q:q + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    for flags in (BE, 0):
+        oi, of = o.run(text, offs, flags=flags, threads=4)
+        gi, gf, cnt = dev_run_ragged(torch, t, text, offs, flags=flags)
+        assert pb.last_kernel() == "ragged"    # device offsets: size unknown to the host, always ragged for n >= 256
+        assert (gi == oi).all() and (gf == of).all()
+        assert (cnt == expected_counts(o, oi, of)).all()
+    # resume: every string continues from an arbitrary reachable state
+    init = rng.randint(0, t.Size, size=n).astype(np.uint32)
+    oi, of = o.run(text, offs, flags=ob.FLAG_END, init_idx=init, threads=4)
+    gi, gf, _ = dev_run_ragged(torch, t, text, offs, flags=ob.FLAG_END, init=init)
+    assert (gi == oi).all() and (gf == of).all()
+    # host-pointer entry point takes the same kernel
+    if total >= 4096:
+        gi, gf = t.run(text, offs, flags=ob.FLAG_END, init_idx=init)
+        assert pb.last_kernel() == "ragged"
+        assert (gi == oi).all() and (gf == of).all()
+    gi, gf, _ = dev_run_ragged(torch, t, text, offs, flags=ob.FLAG_END, init=init, generic=True)
+    assert pb.last_kernel() == "generic"
+    assert (gi == oi).all() and (gf == of).all()
+
+
+def test_ragged_kernel_offsets_not_from_zero(pa, torch_cuda):
+    """offsets[0] > 0 and a buffer that ends exactly with the last string (no readable slack behind it)."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(3)
+    n = 1000
+    ln = rng.randint(0, 300, size=n).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[0] = 777
+    offs[1:] = 777 + np.cumsum(ln)
+    text = rng.randint(0, 256, size=int(offs[-1]), dtype=np.uint8)
+    oi, of = o.run(text, offs, threads=4)
+    gi, gf, _ = dev_run_ragged(torch, t, text, offs)
+    assert (gi == oi).all() and (gf == of).all()
+
+
 @pytest.mark.parametrize("name", ["set_a", "set_d", "set_b", "c2_single"])
 @pytest.mark.parametrize("n,length", [(1, 128), (63, 256), (64, 4096), (65, 384), (1000, 1024), (4097, 128 * 3 + 16),
                                       (300, 100), (129, 4096 + 48), (128, 128), (192, 256 + 16)])

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One ragged batch through pire_hip_run (device pointers), for rocprofv3: tools/ragged_case.py <case> [reps]."""
+import sys
+import numpy as np
+import torch
+import pire_amd
+from pire_amd import binding as pb
+from tests import helpers as H
+
+CASES = {  # name: (lo, hi, log2 strings, multiplier)
+    "uniform8k": (0, 8192, 17, 1), "uniform8k_al128": (0, 64, 17, 128), "urls": (20, 200, 22, 1),
+    "loglines": (64, 1024, 20, 1), "fixed4096": (32, 33, 18, 128), "uniform2k": (0, 2048, 20, 1),
+}
+case = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+flags = 3 | (pb.FLAG_GENERIC if len(sys.argv) > 3 and sys.argv[3] == "generic" else 0)
+lo, hi, lg, mul = CASES[case]
+big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+t = pire_amd.Table(H.load_blob(big["blob"]))
+t.upload()
+stream = torch.cuda.current_stream().cuda_stream
+n, L = 1 << 18, 4096
+buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
+pire_amd.corpus_fill_device(buf.data_ptr(), 0x5EED5EED, 0, n, L, L, H.plants_for(big), stream)
+m = 1 << lg
+lens = (np.random.RandomState(1).randint(lo, hi, size=m) * mul).astype(np.uint64)
+offs = np.zeros(m + 1, dtype=np.uint64)
+offs[1:] = np.cumsum(lens)
+total = int(offs[-1])
+assert total <= n * L
+doffs = torch.as_tensor(offs.astype(np.int64), device="cuda")
+idx = torch.empty(m, dtype=torch.int32, device="cuda")
+fin = torch.empty(m, dtype=torch.uint8, device="cuda")
+ts = []
+for r in range(reps + 2):
+    if r in (1, 2):
+        torch.cuda.synchronize()
+        print("adapt: rows changed", t.adapt(), "hot", t.info.hot_states)
+    a = torch.cuda.Event(enable_timing=True)
+    b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    t.run_device(buf.data_ptr(), doffs.data_ptr(), m, flags, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+    b.record()
+    torch.cuda.synchronize()
+    if r >= 2:
+        ts.append(a.elapsed_time(b))
+print("%s %s: %d strings, %.3f GiB, min %.3f ms -> %.1f GB/s" % (pb.last_kernel(), case, m, total / 2**30, min(ts), total / min(ts) / 1e6))
