@@ -70,7 +70,8 @@ typedef struct pire_hip_table_info {
 	uint64_t ref_buf_size;    /* Scanner::BufSize()       multi.h:297-305 */
 	uint64_t last_trap_samples; /* cold-state samples seen by the most recent pire_hip_table_adapt() */
 	uint32_t adaptations;     /* how many times pire_hip_table_adapt() changed the LDS rows */
-	uint32_t reserved;
+	uint32_t compact_states;  /* states (hot ones included) that also have a class-indexed u16 row in LDS: the
+	                             exact re-walk of a chunk that left the dense rows stays in LDS for them */
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */

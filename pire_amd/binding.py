@@ -45,7 +45,7 @@ class TableInfo(C.Structure):
         ("ref_buf_size", C.c_uint64),
         ("last_trap_samples", C.c_uint64),
         ("adaptations", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("compact_states", C.c_uint32),
     ]
 
 

@@ -84,6 +84,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->finEnd = d.finEnd;
 	p->visitHot = d.visitHot;
 	p->visitCold = d.visitCold;
+	p->compactRows = d.compactRows;
+	p->compact = h.compact;
 	p->states = h.states;
 	p->letters = h.letters;
 	p->regexps = h.regexps;
@@ -316,7 +318,8 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 	out->header_size = h.headerSize;
 	out->row_stride = h.rowStride;
 	out->hot_states = h.hot;
-	out->lds_table_bytes = (h.hot + 1) * 256 + 256 + 528 + 1024;
+	out->lds_table_bytes = MakeLayout(h.hot, 0, 256u, h.compact ? (h.compact + 1) * CompactPitch(h.letters) : 0).total;
+	out->compact_states = h.compact;
 	out->device_bytes = t->dev.bytes;
 	out->adaptations = h.adaptations;
 	out->last_trap_samples = h.lastTrapSamples;

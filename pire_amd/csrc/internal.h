@@ -31,6 +31,62 @@ enum : uint8_t {
 
 constexpr uint32_t kMaxHotRows = 256;   // dense rows addressable by a u8 state id (255 hot + 1 trap)
 
+// LDS carve-up shared by the scan kernels (single dynamic region, 16-byte aligned pieces).
+struct LdsLayout {
+	uint32_t pitch;        // bytes between dense rows: 260 = 65 dwords rotates row r by r banks, or 256
+	uint32_t hotBytes;     // (hot+1)*pitch, rounded up to 16
+	uint32_t flagsOff;     // 256 B of hot flags
+	uint32_t cls8Off;      // 256 B: 2 * letter class of every byte (compact tier; 256-byte aligned when pitch == 256)
+	uint32_t compactOff;   // compact tier: class-indexed u16 rows of the first `compact` states + the escape row
+	uint32_t compactBytes;
+	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
+	uint32_t countsOff;    // (regexps+2) u32 block-local counters
+	uint32_t histOff;      // 256 u32: sampled visits of hot ids (feeds pire_hip_table_adapt)
+	uint32_t total;
+};
+
+constexpr uint32_t kRotPitch = 260;
+constexpr uint32_t kMaxLdsCountRegexps = 1024;
+constexpr uint32_t kLdsPerBlock = 160 * 1024;            // gfx950: 160 KiB per CU, one block per CU may have it all
+constexpr uint32_t kRaggedFinBytes = 256 * 16;           // ragged kernel: end-of-string records of the hot states
+constexpr uint32_t kRaggedLdsExtra = kRaggedFinBytes + 32;
+
+// The compact region sits right behind the dense rows so that its LDS addresses do not depend on the per-launch
+// pieces (counters): the rows hold LDS addresses.
+__host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps, uint32_t pitch = kRotPitch,
+                                                uint32_t compactBytes = 0)
+{
+	LdsLayout l;
+	l.pitch = pitch;
+	l.hotBytes = ((hot + 1) * pitch + 15) / 16 * 16;
+	l.flagsOff = l.hotBytes;
+	l.cls8Off = l.flagsOff + 256;
+	l.compactOff = l.cls8Off + 256;
+	l.compactBytes = (compactBytes + 15) / 16 * 16;
+	l.clsOff = l.compactOff + l.compactBytes;
+	l.countsOff = l.clsOff + 528;
+	l.histOff = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
+	l.total = l.histOff + 1024;
+	return l;
+}
+
+// Compact tier geometry: row = `letters` u16 entries + 1 u16 holding the row's own state id, padded to 4 bytes.
+__host__ __device__ inline uint32_t CompactPitch(uint32_t letters) { return ((letters + 1) * 2 + 3) / 4 * 4; }
+
+// How many states get a compact row next to everything else any kernel keeps in LDS (0 = tier off).
+inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps, uint32_t states)
+{
+	if (letters > 127)
+		return 0;   // the per-byte class table holds 2*class in a u8
+	const uint32_t base = MakeLayout(hot, regexps <= kMaxLdsCountRegexps ? regexps : 0, 256u).total + kRaggedLdsExtra;
+	if (base >= kLdsPerBlock)
+		return 0;
+	const uint32_t rows = (kLdsPerBlock - base) / CompactPitch(letters);
+	if (rows < hot + 2 || states <= hot)
+		return 0;   // no room beyond the hot states, or nothing beyond them
+	return rows - 1 < states ? rows - 1 : states;
+}
+
 // Host-side, fully decoded scanner.  States are in the REFERENCE's numbering ("orig") unless a name says perm.
 struct HostTable {
 	// geometry (mirrors Scanner::Locals, multi.h:315-323)
@@ -48,6 +104,7 @@ struct HostTable {
 	// device numbering: hot states first ("perm" ids).  permOfOrig / origOfPerm are inverse permutations.
 	std::vector<uint32_t> permOfOrig, origOfPerm;
 	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
+	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
 	std::vector<double> priorMass;    // [states] expected visits under the byte model, max-normalised (orig numbering)
@@ -77,6 +134,7 @@ struct DeviceTable {
 	uint64_t* acceptIds = nullptr;
 	struct FinRec* finSelf = nullptr; // [states] end-of-string record when End() is not requested
 	struct FinRec* finEnd = nullptr;  // [states] end-of-string record after Step(EndMark)
+	uint16_t* compactRows = nullptr;  // [(compact+1) rows] LDS address / 4 of the next state's row (last row = escape), padded
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
 	unsigned long long* workCounter = nullptr;   // [kWorkSlots] ragged kernel: next string range to hand out;
@@ -115,6 +173,8 @@ struct ScanParams {
 	const FinRec* finEnd;
 	uint32_t* visitHot;
 	uint32_t* visitCold;
+	const uint16_t* compactRows;
+	uint32_t compact;        // 0 = tier off
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;
@@ -128,6 +188,11 @@ struct ScanParams {
 	uint8_t* outFinal;       // nullable
 	unsigned long long* outCounts;  // nullable
 };
+
+__host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)
+{
+	return p.compact ? (p.compact + 1) * CompactPitch(p.letters) : 0;
+}
 
 void SetError(const std::string& msg);
 int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_HIP_ENODEVICE / ENOMEM

@@ -30,37 +30,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// LDS carve-up shared by both scan kernels (single dynamic region, 16-byte aligned pieces).
-struct LdsLayout {
-	uint32_t pitch;        // bytes between dense rows: 260 = 65 dwords rotates row r by r banks, or 256
-	uint32_t hotBytes;     // (hot+1)*pitch, rounded up to 16
-	uint32_t flagsOff;     // 256 B of hot flags
-	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
-	uint32_t countsOff;    // (regexps+2) u32 block-local counters
-	uint32_t histOff;      // 256 u32: sampled visits of hot ids (feeds pire_hip_table_adapt)
-	uint32_t total;
-};
-
-constexpr uint32_t kRotPitch = 260;
-
-__host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps, uint32_t pitch = kRotPitch)
-{
-	LdsLayout l;
-	l.pitch = pitch;
-	l.hotBytes = ((hot + 1) * pitch + 15) / 16 * 16;
-	l.flagsOff = l.hotBytes;
-	l.clsOff = l.flagsOff + 256;
-	l.countsOff = l.clsOff + 528;
-	l.histOff = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
-	l.total = l.histOff + 1024;
-	return l;
-}
-
-constexpr uint32_t kMaxLdsCountRegexps = 1024;
 constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
 constexpr uint32_t kDebugNoStep = 1u << 29;     // internal, never set through the C ABI
 constexpr uint32_t kDebugNoColdCount = 1u << 28;
 constexpr uint32_t kDebugNoHist = 1u << 27;
+constexpr uint32_t kDebugNoPartial = 1u << 26;   // ragged kernel timing experiments only (results are wrong)
+constexpr uint32_t kDebugNoFinish = 1u << 25;
+constexpr uint32_t kDebugNoTrap = 1u << 24;
 
 // Cooperative load of the LDS-resident part of the table.
 __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
@@ -81,6 +57,12 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
 	for (uint32_t i = tid; i < 256; i += nthr)
 		reinterpret_cast<uint32_t*>(lds + L.histOff)[i] = 0;
+	if (p.compact) {
+		for (uint32_t i = tid; i < L.compactBytes / 16; i += nthr)
+			reinterpret_cast<u32x4*>(lds + L.compactOff)[i] = reinterpret_cast<const u32x4*>(p.compactRows)[i];
+		for (uint32_t i = tid; i < 256; i += nthr)
+			lds[L.cls8Off + i] = uint8_t(2 * p.cls[i]);
+	}
 	__syncthreads();
 }
 
@@ -179,7 +161,7 @@ __device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsL
 __global__ __launch_bounds__(256) void ScanGenericKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
 	LoadTableToLds(p, lds, L);
 
 	const uint64_t nrounds = (p.n + 63) / 64;
@@ -358,6 +340,63 @@ __device__ __forceinline__ uint32_t HotLookup(uint32_t addr)
 {
 	return *reinterpret_cast<LdsBytePtr>(static_cast<uintptr_t>(addr));
 }
+typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
+__device__ __forceinline__ uint32_t LdsU16(uint32_t addr)
+{
+	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(addr));
+}
+
+// Compact tier: the exact walk of one 16-byte chunk for a lane whose state has a compact row, LDS
+// only and branch free.  Row entries are the LDS address / 4 of the next state's row, so a step is
+//   class2 = cls8[byte]            (off the dependent chain: 16 independent ds_read_u8)
+//   row    = u16[row * 4 + class2] (the chain: v_lshl_add_u32 + ds_read_u16)
+// Targets without a row lead to the absorbing escape row (id == p.compact): the caller then re-walks the chunk
+// through the full table in HBM.  Returns the state id after the chunk (<= p.compact).
+__device__ __forceinline__ uint32_t CompactChunk(const ScanParams& p, const LdsLayout& L, const u32x4 v, uint32_t st)
+{
+	const uint32_t pitch = CompactPitch(p.letters);
+	uint32_t row = (L.compactOff >> 2) + st * (pitch >> 2);
+	const uint32_t clsBase = L.cls8Off;   // multiple of 256: v_perm_b32 glues the byte under it
+	// rolled on purpose: this code is instantiated once per unrolled chunk of the callers, and the kernels have to
+	// stay well inside the 64 KiB instruction cache (measured: the unrolled form cost the tiled kernel 5%)
+	u32x4 w = v;
+#pragma unroll 1
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t x = w.x;
+		const uint32_t c0 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060500u));
+		const uint32_t c1 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060501u));
+		const uint32_t c2 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060502u));
+		const uint32_t c3 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060503u));
+		row = LdsU16((row << 2) + c0);
+		row = LdsU16((row << 2) + c1);
+		row = LdsU16((row << 2) + c2);
+		row = LdsU16((row << 2) + c3);
+		w.x = w.y;
+		w.y = w.z;
+		w.z = w.w;
+	}
+	return LdsU16((row << 2) + p.letters * 2);
+}
+
+// Same for the first `count` (1..15) bytes of v, rolled.
+__device__ __forceinline__ uint32_t CompactPartial(const ScanParams& p, const LdsLayout& L, u32x4 v, uint32_t st,
+                                                   uint32_t count)
+{
+	const uint32_t pitch = CompactPitch(p.letters);
+	uint32_t row = (L.compactOff >> 2) + st * (pitch >> 2);
+	const uint32_t clsBase = L.cls8Off;
+#pragma unroll 1
+	for (uint32_t i = 0; __any(i < count); ++i) {
+		const uint32_t c = HotLookup(__builtin_amdgcn_perm(clsBase, v.x, 0x0c060500u));
+		const uint32_t nr = LdsU16((row << 2) + c);
+		row = i < count ? nr : row;
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return LdsU16((row << 2) + p.letters * 2);
+}
 
 // Exact re-walk of one 16-byte chunk for the lanes that trapped.  Deliberately a rolled loop (the chunk is shifted
 // through as a 128-bit value): this is the cold path, and keeping it small keeps the hot loop dense in the I-cache.
@@ -400,8 +439,15 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
 		}
 	}
-	if (hs == p.hot) {
-		const uint32_t f = SlowChunk(p, lds, L, v, hs0 != p.hot ? hs0 : cold);
+	if (hs == p.hot && !(p.flags & kDebugNoTrap)) {
+		// left the dense rows somewhere in this chunk: exact re-walk from the chunk's start state, through the
+		// compact rows in LDS when the state has one, through the full table in HBM when that escapes too
+		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+		uint32_t f = p.compact;
+		if (st0 < p.compact)
+			f = CompactChunk(p, L, v, st0);
+		if (f == p.compact)
+			f = SlowChunk(p, lds, L, v, st0);
 		if (f < p.hot) {
 			hs = f;
 		} else {
@@ -483,7 +529,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
 	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT ? kRotPitch : 256u);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT ? kRotPitch : 256u, CompactBytes(p));
 	LoadTableToLds(p, lds, L);
 
 	const uint32_t lane = threadIdx.x & 63;
@@ -569,9 +615,7 @@ struct RaggedWork {
 	uint32_t lock, exhausted;
 	uint32_t pad[2];
 };
-
-constexpr uint32_t kRaggedFinBytes = 256 * sizeof(FinRec);
-constexpr uint32_t kRaggedLdsExtra = kRaggedFinBytes + sizeof(RaggedWork);
+static_assert(kRaggedFinBytes + sizeof(RaggedWork) == kRaggedLdsExtra, "LDS budget of the warm rows (internal.h)");
 
 __device__ __forceinline__ void IssueTileLane(u32x4 (&r)[8], uint64_t src)
 {
@@ -651,7 +695,12 @@ __device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* 
 		w.w >>= 8;
 	}
 	if (count != 0 && hs == p.hot) {
-		const uint32_t f = SlowPartial(p, lds, L, v, hs0 != p.hot ? hs0 : cold, count);
+		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+		uint32_t f = p.compact;
+		if (st0 < p.compact)
+			f = CompactPartial(p, L, v, st0, count);
+		if (f == p.compact)
+			f = SlowPartial(p, lds, L, v, st0, count);
 		if (f < p.hot) {
 			hs = f;
 		} else {
@@ -813,7 +862,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	const bool nLoad = nBusy && nEnd > nPos && nBase + 128 <= safeEnd;
 	// unconditional (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
 	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives
-	IssueTileLane(nxt, nLoad ? nBase : reinterpret_cast<uint64_t>(p.hotRows));
+	if (!(p.flags & kDebugNoRefill))
+		IssueTileLane(nxt, nLoad ? nBase : reinterpret_cast<uint64_t>(p.hotRows));
 	if (takeNew)
 		S.pend = false;
 	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
@@ -829,24 +879,21 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	// ---- walk the current window
 	if ((threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
-	if (__all(S.loaded && nb == 128u)) {
-		// every lane has a whole window (long strings): no per-chunk conditions
-#pragma unroll
-		for (int k = 0; k < 8; ++k)
-			StepChunk<false>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+	if (p.flags & kDebugNoStep) {
+		// timing experiments: no walk at all
 	} else if (__any(nb != 0)) {
 		if (__any(nb != 0 && S.loaded)) {
 			const uint32_t nbl = S.loaded ? nb : 0u;
 			const uint32_t head = skip ? (nbl < 16u - skip ? nbl : 16u - skip) : 0u;
 			const uint32_t rest = nbl - head;
 			const uint32_t kStart = skip ? 1u : 0u, full = rest >> 4, tail = rest & 15u;
-			if (__any(head != 0))
+			if (__any(head != 0) && !(p.flags & kDebugNoPartial))
 				StepPartial(p, lds, L, ShiftBytes(cur[0], skip), head, S.hs, S.cold, iter & 63);
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) >= kStart && uint32_t(k) < kStart + full)
 					StepChunk<false>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
-			if (__any(tail != 0)) {
+			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
 				const uint32_t kt = kStart + full;
 				u32x4 v = cur[0];
 #pragma unroll
@@ -866,7 +913,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			S.cold = st;
 		}
 	}
-	if (__any(ends))
+	if (__any(ends) && !(p.flags & kDebugNoFinish))
 		FinishRagged(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
 
 	// ---- move on
@@ -891,7 +938,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
                                                          uint32_t blockGrab)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
 	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + L.total + kRaggedFinBytes);
 	{
@@ -955,7 +1002,7 @@ __global__ __launch_bounds__(256) void PrefixKernel(PrefixParams q)
 {
 	const ScanParams& p = q.scan;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, 0);
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
 	LoadTableToLds(p, lds, L);
 	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
 		uint64_t b, e;
@@ -1122,11 +1169,13 @@ int CheckCounts(const ScanParams& p)
 
 }  // namespace
 
-int LaunchGeneric(const ScanParams& p, hipStream_t stream)
+int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 {
-	if (int rc = CheckCounts(p))
+	if (int rc = CheckCounts(p0))
 		return rc;
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
+	ScanParams p = p0;
+	p.compact = 0;   // small blocks, several per CU: no room (and no need) for the warm rows
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
 	return LaunchScan(ScanGenericKernel, p, 256, L.total, stream);
 }
 
@@ -1143,7 +1192,7 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 	hipError_t e = hipMemsetAsync(workCounter, 0, sizeof(unsigned long long), stream);
 	if (e != hipSuccess)
 		return HipFail(e, "hipMemsetAsync(work counter)");
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	const uint32_t ldsBytes = L.total + kRaggedLdsExtra;
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
@@ -1161,7 +1210,13 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 	const uint64_t perBlock = (p.n + blocks - 1) / blocks, lanes = wavesPerBlock * 64;
 	uint64_t grab = std::min<uint64_t>(16384, std::max<uint64_t>(perBlock / 8, std::min(perBlock, lanes)));
 	grab = (grab + 63) / 64 * 64;
-	hipLaunchKernelGGL(ScanRaggedKernel, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream, p,
+	ScanParams q = p;
+	if (const char* dbg = getenv("PIRE_HIP_DEBUG_RAGGED")) {   // timing experiments: 1 no partial passes, 2 no finish, 4 no traps
+		const int m = atoi(dbg);
+		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
+		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
+	}
+	hipLaunchKernelGGL(ScanRaggedKernel, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream, q,
 	                   workCounter, uint32_t(grab));
 	e = hipGetLastError();
 	if (e != hipSuccess)
@@ -1179,7 +1234,6 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 {
 	if (int rc = CheckCounts(p))
 		return rc;
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0);
 	// Variant knob for A/B measurements; the default is the measured best.
 	static const int variant = [] {
 		const char* v = getenv("PIRE_HIP_TILED_VARIANT");
@@ -1196,9 +1250,12 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoColdCount;
 	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
 		q.flags |= kDebugNoHist;
+	if (variant == 1)
+		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
-	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u);
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(q));
+	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(q));
 	switch (variant) {
 	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, true>, q, 1024, L.total, stream); break;   // bank-rotated rows
 	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, false>, q, 1024, L256.total, stream); break; // no nt
@@ -1219,14 +1276,16 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	return LaunchGeneric(tail, stream);
 }
 
-int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream)
+int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long* outLen, hipStream_t stream)
 {
-	if (p.n == 0)
+	if (p0.n == 0)
 		return PIRE_HIP_OK;
+	ScanParams p = p0;
+	p.compact = 0;
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	const LdsLayout L = MakeLayout(p.hot, 0);
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(PrefixKernel),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
 	if (e != hipSuccess)

@@ -12,6 +12,7 @@
 // result (multi.h:925-934 asserts it); the GPU analogue is the absorbing-row early-out.
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <iterator>
 #include <cstring>
@@ -100,6 +101,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
+	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
 	t.permOfOrig.assign(N, 0);
 	for (uint32_t pid = 0; pid < N; ++pid)
@@ -311,7 +313,7 @@ void FreeDeviceTable(DeviceTable* d)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
-	                d->finSelf,    d->finEnd,  d->workCounter};
+	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -390,6 +392,22 @@ int UploadTable(pire_hip_table* t)
 		rc = Put(&d.finSelf, self, &d.bytes);
 		if (!rc)
 			rc = Put(&d.finEnd, end, &d.bytes);
+	}
+	if (!rc) {
+		// compact tier: entry = LDS address / 4 of the next state's row; targets without a row go to the escape row
+		const uint32_t W = h.compact, pitch = CompactPitch(C);
+		const uint32_t base = MakeLayout(h.hot, 0, 256u).compactOff;
+		std::vector<uint16_t> rows(W ? (size_t(W + 1) * pitch / 2 + 15) / 8 * 8 : 8, 0);
+		if (W) {
+			auto addr4 = [&](uint32_t pid) { return uint16_t((base + std::min(pid, W) * pitch) / 4); };
+			for (uint32_t pid = 0; pid <= W; ++pid) {
+				uint16_t* row = &rows[size_t(pid) * pitch / 2];
+				for (uint32_t c = 0; c < C; ++c)
+					row[c] = pid < W ? addr4(nextPerm[size_t(pid) * C + c]) : addr4(W);
+				row[C] = uint16_t(pid);
+			}
+		}
+		rc = Put(&d.compactRows, rows, &d.bytes);
 	}
 	if (!rc)
 		rc = Put(&d.visitHot, std::vector<uint32_t>(256, 0), &d.bytes);
