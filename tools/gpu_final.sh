@@ -39,3 +39,5 @@ for _ in range(3):
     t0=time.perf_counter(); idx,fin=t.run_strided_host(data); dt=time.perf_counter()-t0; best=min(best,dt)
 print("PCIe-inclusive host-pointer mode: %d x %d B (%.0f MiB pageable host memory): %.1f ms -> %.2f GB/s" % (n,L,n*L/2**20,best*1e3,n*L/best/1e9))
 PY
+echo "== ragged batches through pire_hip_run (offsets), set_a table, after two adapt() passes"
+for c in urls loglines uniform2k uniform8k fixed4096; do PYTHONPATH=. timeout 120 python tools/ragged_case.py $c 3 2>&1 | grep "^ragged"; PYTHONPATH=. timeout 120 python tools/ragged_case.py $c 3 generic 2>&1 | grep "^generic"; done | tee gpurun_out/final/ragged_cases.log
