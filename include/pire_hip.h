@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PIRE_HIP_ABI_VERSION 1
+#define PIRE_HIP_ABI_VERSION 2
 
 enum {
 	PIRE_HIP_OK        =  0,
@@ -72,19 +72,35 @@ typedef struct pire_hip_table_info {
 	uint32_t adaptations;     /* how many times pire_hip_table_adapt() changed the LDS rows */
 	uint32_t compact_states;  /* states (hot ones included) that also have a class-indexed u16 row in LDS: the
 	                             exact re-walk of a chunk that left the dense rows stays in LDS for them */
+	uint32_t scanner_type;    /* ScannerIOTypes of the ingested blob (scanners/common.h:34-40): 1 Scanner, 2 SimpleScanner */
+	uint32_t reserved;
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */
 
 /*
  * Ingest a scanner from the bytes written by Pire::Scanner::Save() / NonrelocScanner::Save()
- * (multi.h:557-573; a Nonreloc scanner serialises as Relocatable, multi.h:604-608).  Replaces
+ * (multi.h:557-573; a Nonreloc scanner serialises as Relocatable, multi.h:604-608) or by
+ * Pire::SimpleScanner::Save() (scanner_io.cpp:35-49; dense rows without letter classes, one regexp, never Dead --
+ * its columns are folded into letter classes here, results are identical).  Replaces
  * Scanner::Load (multi.h:575-599) / Scanner::Mmap (multi.h:244-279) for the GPU side.  Validates the
  * header like Header::Validate.  The blob is copied; the handle is immutable and may be shared between
  * host threads.  Works without a GPU (host-side parse only); the device image is uploaded on first run
  * or by pire_hip_table_upload().
  */
 int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** out);
+
+/*
+ * Scanner::Mmap / SimpleScanner::Mmap twin (multi.h:244-279, simple.h:120-151): ingest the scanner at the start
+ * of a mapped image and report in *consumed (nullable) how many bytes it occupied -- the offset of the pointer
+ * Mmap() returns -- so that images holding several scanners back to back can be walked.  The image is decoded,
+ * not aliased: it may be unmapped as soon as the call returns.
+ */
+int pire_hip_table_mmap(const void* image, size_t size, pire_hip_table** out, size_t* consumed);
+
+/* Map `path` read-only and ingest its first scanner: the deployment flow of samples/blacklist/blacklist.cpp:64-93
+ * (compile once with Scanner::Save, mmap everywhere). */
+int pire_hip_table_create_from_file(const char* path, pire_hip_table** out);
 
 /* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
 int pire_hip_table_upload(pire_hip_table* t);

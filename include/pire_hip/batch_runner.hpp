@@ -40,6 +40,26 @@ inline void Check(int rc)
 		throw Pire::Error(std::string("pire_hip: ") + pire_hip_last_error());
 }
 
+/* Bytes between the State values of consecutive StateIndex numbers, from public API only. */
+template <class Scanner>
+struct RowGeometry {
+	static size_t Stride(const Scanner& sc)
+	{
+		typedef typename Scanner::Transition Tr;
+		const size_t header = sizeof(typename Scanner::ScannerRowHeader) / sizeof(Tr);           // HEADER_SIZE, multi.h:349
+		const size_t align = sizeof(Pire::Impl::MaxSizeWord) / sizeof(Tr);
+		const size_t row = (sc.LettersCount() + header + align - 1) / align * align;             // RowSize(), multi.h:347
+		return row * sizeof(Tr);
+	}
+};
+template <>
+struct RowGeometry<Pire::SimpleScanner> {
+	static size_t Stride(const Pire::SimpleScanner&)
+	{
+		return (Pire::MaxChar + 1) * sizeof(Pire::SimpleScanner::Transition);                    // STATE_ROW_SIZE, simple.h:43
+	}
+};
+
 /* A device-side copy of a compiled scanner.  Immutable, shareable between threads, like the scanner itself. */
 template <class Scanner>
 class Table {
@@ -47,18 +67,15 @@ public:
 	explicit Table(const Scanner& sc)
 	    : m_table(nullptr)
 	{
-		// the PUBLIC hand-off: Scanner::Save (multi.h:307, 557-573); NonrelocScanner saves as Relocatable (604-608)
+		// the PUBLIC hand-off: Scanner::Save (multi.h:307, 557-573); NonrelocScanner saves as Relocatable (604-608);
+		// SimpleScanner::Save (scanner_io.cpp:35-49)
 		std::ostringstream out;
 		sc.Save(&out);
 		const std::string blob = out.str();
 		Check(pire_hip_table_create(blob.data(), blob.size(), &m_table));
 
 		// State <-> StateIndex geometry of THIS host scanner, public API only
-		typedef typename Scanner::Transition Tr;
-		const size_t header = sizeof(typename Scanner::ScannerRowHeader) / sizeof(Tr);           // HEADER_SIZE, 349
-		const size_t align = sizeof(Pire::Impl::MaxSizeWord) / sizeof(Tr);
-		const size_t row = (sc.LettersCount() + header + align - 1) / align * align;             // RowSize(), 347
-		m_stride = row * sizeof(Tr);
+		m_stride = RowGeometry<Scanner>::Stride(sc);
 		typename Scanner::State init;
 		sc.Initialize(init);
 		m_base = init - sc.StateIndex(init) * m_stride;

@@ -113,6 +113,20 @@ def oracle_lib():
         L.oracle_slow_empty.restype = C.c_int
         L.oracle_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p]
         L.oracle_slow_run.restype = None
+        L.oracle_simple_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.oracle_simple_load.restype = C.c_int
+        L.oracle_simple_free.argtypes = [C.c_void_p]
+        for name in ("oracle_simple_size", "oracle_simple_initial_index"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint32
+        L.oracle_simple_empty.argtypes = [C.c_void_p]
+        L.oracle_simple_empty.restype = C.c_int
+        L.oracle_simple_next_index.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.oracle_simple_next_index.restype = C.c_uint32
+        L.oracle_simple_final.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_simple_final.restype = C.c_int
+        L.oracle_simple_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p, u8p]
+        L.oracle_simple_run.restype = None
         _oracle_lib = L
     return _oracle_lib
 
@@ -228,6 +242,54 @@ class OracleSlowScanner:
         return self.run(text, offs, **kw)
 
 
+class OracleSimpleScanner:
+    """C restatement of Pire::SimpleScanner, loaded from SimpleScanner::Save() bytes."""
+
+    def __init__(self, blob: bytes):
+        L = oracle_lib()
+        self._L = L
+        self.blob = bytes(blob)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        if L.oracle_simple_load(self.blob, len(self.blob), C.byref(h), err, 256) != 0:
+            raise ValueError(err.value.decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.oracle_simple_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.oracle_simple_size(s._h))
+    empty = property(lambda s: bool(s._L.oracle_simple_empty(s._h)))
+    initial = property(lambda s: s._L.oracle_simple_initial_index(s._h))
+    regexps = property(lambda s: 0 if s.empty else 1)
+
+    def next(self, idx: int, ch: int) -> int:
+        return self._L.oracle_simple_next_index(self._h, idx, ch)
+
+    def final(self, idx: int) -> bool:
+        return bool(self._L.oracle_simple_final(self._h, idx))
+
+    def accepted(self, idx: int):
+        return [0] if self.final(idx) else []          # simple.h:66-68
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        self._L.oracle_simple_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                  _ptr(init, u32p), _ptr(idx, u32p), _ptr(fin, u8p))
+        return idx, fin
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
 # --------------------------------------------------------------------------- reference library
 
 _ref_lib = None
@@ -285,6 +347,28 @@ def ref_lib():
         L.pire_ref_slow_empty.restype = C.c_int
         L.pire_ref_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p, C.c_int]
         L.pire_ref_slow_run.restype = C.c_int
+        L.pire_ref_simple_compile.argtypes = [C.c_char_p, C.c_char_p]
+        L.pire_ref_simple_compile.restype = C.c_void_p
+        L.pire_ref_simple_empty.argtypes = []
+        L.pire_ref_simple_empty.restype = C.c_void_p
+        L.pire_ref_simple_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.pire_ref_simple_load.restype = C.c_void_p
+        L.pire_ref_simple_free.argtypes = [C.c_void_p]
+        L.pire_ref_simple_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_simple_save.restype = C.c_size_t
+        for name in ("pire_ref_simple_size", "pire_ref_simple_regexps"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_size_t
+        L.pire_ref_simple_empty_flag.argtypes = [C.c_void_p]
+        L.pire_ref_simple_empty_flag.restype = C.c_int
+        L.pire_ref_simple_initial.argtypes = [C.c_void_p]
+        L.pire_ref_simple_initial.restype = C.c_uint32
+        L.pire_ref_simple_next.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.pire_ref_simple_next.restype = C.c_uint32
+        L.pire_ref_simple_final.argtypes = [C.c_void_p, C.c_uint32]
+        L.pire_ref_simple_final.restype = C.c_int
+        L.pire_ref_simple_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p, u8p, C.c_int]
+        L.pire_ref_simple_run.restype = C.c_int
         _ref_lib = L
     return _ref_lib
 
@@ -336,6 +420,68 @@ class RefSlowScanner:
         if rc != 0:
             raise RuntimeError(self._L.pire_ref_last_error().decode())
         return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
+class RefSimpleScanner:
+    """The real Pire::SimpleScanner behind a C ABI."""
+
+    def __init__(self, handle):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def compile(cls, pattern, options=""):
+        L = ref_lib()
+        p = pattern.encode("latin-1") if isinstance(pattern, str) else pattern
+        return cls(L.pire_ref_simple_compile(p, options.encode()))
+
+    @classmethod
+    def empty_scanner(cls):
+        return cls(ref_lib().pire_ref_simple_empty())
+
+    @classmethod
+    def load(cls, blob: bytes):
+        L = ref_lib()
+        return cls(L.pire_ref_simple_load(bytes(blob), len(blob)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_simple_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_simple_size(s._h))
+    regexps = property(lambda s: s._L.pire_ref_simple_regexps(s._h))
+    empty = property(lambda s: bool(s._L.pire_ref_simple_empty_flag(s._h)))
+    initial = property(lambda s: s._L.pire_ref_simple_initial(s._h))
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_simple_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_simple_save(self._h, buf, n)
+        return buf.raw
+
+    def next(self, idx: int, ch: int) -> int:
+        return self._L.pire_ref_simple_next(self._h, idx, ch)
+
+    def final(self, idx: int) -> bool:
+        return bool(self._L.pire_ref_simple_final(self._h, idx))
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        self._L.pire_ref_simple_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                    _ptr(init, u32p), _ptr(idx, u32p), _ptr(fin, u8p), threads)
+        return idx, fin
 
     def run_strings(self, strings, **kw):
         text, offs = pack_strings(strings)

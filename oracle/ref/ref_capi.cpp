@@ -382,4 +382,128 @@ int pire_ref_slow_run(void* h, const void* text, const uint64_t* offsets, uint64
 	}
 }
 
+/* ---- Pire::SimpleScanner (scanners/simple.h): the dense-row, single-regexp scanner ------------------------- */
+
+struct RefSimple {
+	Pire::SimpleScanner sc;
+	size_t base = 0, stride = 0;   // State <-> StateIndex through public API only (simple.h:73, 154-157)
+	void Geometry()
+	{
+		stride = (Pire::MaxChar + 1) * sizeof(Pire::SimpleScanner::Transition);   // STATE_ROW_SIZE, simple.h:43
+		Pire::SimpleScanner::State init;
+		sc.Initialize(init);
+		base = init - sc.StateIndex(init) * stride;   // == m_transitions + 1 slot (the tag precedes the row)
+	}
+};
+
+void* pire_ref_simple_compile(const char* pattern, const char* options)
+{
+	try {
+		std::unique_ptr<RefSimple> h(new RefSimple);
+		Pire::Fsm fsm = ParseOne(pattern, options);
+		h->sc = fsm.Compile<Pire::SimpleScanner>();     // simple.h:226-252
+		h->Geometry();
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void* pire_ref_simple_empty()
+{
+	std::unique_ptr<RefSimple> h(new RefSimple);        // SimpleScanner() aliases Null(), simple.h:50
+	h->Geometry();
+	return h.release();
+}
+
+void* pire_ref_simple_load(const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefSimple> h(new RefSimple);
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		h->sc.Load(&in);                                 // scanner_io.cpp:51-69
+		h->Geometry();
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_simple_free(void* h) { delete static_cast<RefSimple*>(h); }
+
+size_t pire_ref_simple_save(void* h, void* buf, size_t cap)       // scanner_io.cpp:35-49
+{
+	std::ostringstream out;
+	static_cast<RefSimple*>(h)->sc.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_simple_size(void* h) { return static_cast<RefSimple*>(h)->sc.Size(); }
+int pire_ref_simple_empty_flag(void* h) { return static_cast<RefSimple*>(h)->sc.Empty() ? 1 : 0; }
+size_t pire_ref_simple_regexps(void* h) { return static_cast<RefSimple*>(h)->sc.RegexpsCount(); }
+
+uint32_t pire_ref_simple_initial(void* hh)
+{
+	RefSimple* h = static_cast<RefSimple*>(hh);
+	Pire::SimpleScanner::State st;
+	h->sc.Initialize(st);
+	return uint32_t(h->sc.StateIndex(st));
+}
+
+uint32_t pire_ref_simple_next(void* hh, uint32_t idx, uint32_t ch)      // simple.h:76-81
+{
+	RefSimple* h = static_cast<RefSimple*>(hh);
+	Pire::SimpleScanner::State st = h->base + size_t(idx) * h->stride;
+	h->sc.Next(st, Pire::Char(ch));
+	return uint32_t(h->sc.StateIndex(st));
+}
+
+int pire_ref_simple_final(void* hh, uint32_t idx)                        // simple.h:62
+{
+	RefSimple* h = static_cast<RefSimple*>(hh);
+	return h->sc.Final(h->base + size_t(idx) * h->stride) ? 1 : 0;
+}
+
+/* Runner(sc).Begin().Run().End() per string (run.h:365-392); kind is ignored (one table form). */
+int pire_ref_simple_run(void* hh, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                        const uint32_t* initIdx, uint32_t* outIdx, uint8_t* outFinal, int threads)
+{
+	RefSimple* h = static_cast<RefSimple*>(hh);
+	const Pire::SimpleScanner& sc = h->sc;
+	const char* t = static_cast<const char*>(text);
+	auto range = [&](uint64_t lo, uint64_t hi) {
+		for (uint64_t i = lo; i < hi; ++i) {
+			Pire::SimpleScanner::State st;
+			if (initIdx)
+				st = h->base + size_t(initIdx[i]) * h->stride;
+			else
+				sc.Initialize(st);
+			if (flags & FLAG_BEGIN)
+				Pire::Step(sc, st, Pire::BeginMark);
+			Pire::Run(sc, st, t + offsets[i], t + offsets[i + 1]);
+			if (flags & FLAG_END)
+				Pire::Step(sc, st, Pire::EndMark);
+			if (outIdx)
+				outIdx[i] = uint32_t(sc.StateIndex(st));
+			if (outFinal)
+				outFinal[i] = sc.Final(st) ? 1 : 0;
+		}
+	};
+	if (threads <= 1) {
+		range(0, n);
+		return 0;
+	}
+	std::vector<std::thread> pool;     // sharding by string index is ours, the reference is single-threaded
+	for (int k = 0; k < threads; ++k)
+		pool.emplace_back(range, n * k / threads, n * (k + 1) / threads);
+	for (auto& th : pool)
+		th.join();
+	return 0;
+}
+
 } // extern "C"

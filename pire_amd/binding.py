@@ -46,6 +46,8 @@ class TableInfo(C.Structure):
         ("last_trap_samples", C.c_uint64),
         ("adaptations", C.c_uint32),
         ("compact_states", C.c_uint32),
+        ("scanner_type", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -72,6 +74,8 @@ _lib = None
 # every symbol include/pire_hip.h declares: (name, restype, argtypes)
 ABI = [
     ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_table_mmap", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("pire_hip_table_create_from_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_upload", C.c_int, [C.c_void_p]),
     ("pire_hip_table_adapt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("pire_hip_table_destroy", None, [C.c_void_p]),
@@ -144,17 +148,35 @@ def _np_ptr(a: Optional[np.ndarray]):
 
 
 class Table:
-    """An ingested Pire::Scanner (from Scanner::Save() bytes).  Mirrors the scanner's public getters."""
+    """An ingested Pire::Scanner / NonrelocScanner / SimpleScanner (from Save() bytes).  Mirrors the public getters."""
 
-    def __init__(self, blob: bytes):
+    def __init__(self, blob: bytes = None, _handle=None):
         L = lib()
-        h = C.c_void_p()
-        blob = bytes(blob)
-        _check(L.pire_hip_table_create(blob, len(blob), C.byref(h)))
+        h = _handle
+        if h is None:
+            h = C.c_void_p()
+            blob = bytes(blob)
+            _check(L.pire_hip_table_create(blob, len(blob), C.byref(h)))
         self._h = h
         info = TableInfo()
         _check(L.pire_hip_table_get_info(h, C.byref(info)))
         self.info = info
+
+    @classmethod
+    def from_file(cls, path: str):
+        """Scanner::Mmap deployment flow (samples/blacklist/blacklist.cpp:86-93): ingest a file written by Save()."""
+        h = C.c_void_p()
+        _check(lib().pire_hip_table_create_from_file(os.fsencode(path), C.byref(h)))
+        return cls(_handle=h)
+
+    @classmethod
+    def mmap(cls, image: bytes):
+        """Ingest the scanner at the start of `image`; returns (table, bytes consumed) like Scanner::Mmap's pointer."""
+        h = C.c_void_p()
+        used = C.c_size_t()
+        image = bytes(image)
+        _check(lib().pire_hip_table_mmap(image, len(image), C.byref(h), C.byref(used)))
+        return cls(_handle=h), used.value
 
     def __del__(self):
         h = getattr(self, "_h", None)

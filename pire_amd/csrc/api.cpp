@@ -8,6 +8,12 @@
 #include <string>
 #include <vector>
 
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "internal.h"
 
 namespace pirehip {
@@ -86,6 +92,7 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->visitCold = d.visitCold;
 	p->compactRows = d.compactRows;
 	p->compact = h.compact;
+	p->byteRot = h.byteRot;
 	p->states = h.states;
 	p->letters = h.letters;
 	p->regexps = h.regexps;
@@ -275,6 +282,45 @@ int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** ou
 	return PIRE_HIP_OK;
 }
 
+int pire_hip_table_mmap(const void* image, size_t size, pire_hip_table** out, size_t* consumed)
+{
+	if (consumed)
+		*consumed = 0;
+	const int rc = pire_hip_table_create(image, size, out);
+	if (rc == PIRE_HIP_OK && consumed)
+		*consumed = size_t((*out)->host.blobBytes);
+	return rc;
+}
+
+int pire_hip_table_create_from_file(const char* path, pire_hip_table** out)
+{
+	if (!path || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	const int fd = open(path, O_RDONLY);
+	if (fd < 0) {
+		SetError(std::string("cannot open ") + path + ": " + strerror(errno));
+		return PIRE_HIP_EINVAL;
+	}
+	struct stat st;
+	if (fstat(fd, &st) != 0 || st.st_size <= 0) {
+		SetError(std::string("cannot stat (or empty file) ") + path);
+		close(fd);
+		return PIRE_HIP_EFORMAT;
+	}
+	void* map = mmap(nullptr, size_t(st.st_size), PROT_READ, MAP_PRIVATE, fd, 0);
+	close(fd);
+	if (map == MAP_FAILED) {
+		SetError(std::string("cannot mmap ") + path + ": " + strerror(errno));
+		return PIRE_HIP_ENOMEM;
+	}
+	const int rc = pire_hip_table_create(map, size_t(st.st_size), out);   // the image is decoded, nothing aliases it
+	munmap(map, size_t(st.st_size));
+	return rc;
+}
+
 int pire_hip_table_upload(pire_hip_table* t)
 {
 	if (!t) {
@@ -320,6 +366,8 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 	out->hot_states = h.hot;
 	out->lds_table_bytes = MakeLayout(h.hot, 0, 256u, h.compact ? (h.compact + 1) * CompactPitch(h.letters) : 0).total;
 	out->compact_states = h.compact;
+	out->scanner_type = h.scannerType;
+	out->reserved = 0;
 	out->device_bytes = t->dev.bytes;
 	out->adaptations = h.adaptations;
 	out->last_trap_samples = h.lastTrapSamples;

@@ -92,8 +92,10 @@ struct HostTable {
 	// geometry (mirrors Scanner::Locals, multi.h:315-323)
 	uint32_t states = 0, letters = 0, regexps = 0, initial = 0;
 	bool empty = false;
+	uint32_t scannerType = 1;         // ScannerIOTypes (common.h:34-40): 1 Scanner, 2 SimpleScanner
 	uint32_t headerSize = 0, rowStride = 0;
 	uint64_t refBufSize = 0;
+	uint64_t blobBytes = 0;           // bytes of the serialised image this scanner occupied (what Mmap() would consume)
 
 	std::vector<uint16_t> cls;        // [264] letter class of each Char (Translate() - HEADER_SIZE)
 	std::vector<uint32_t> next;       // [states * letters] next state index, orig numbering
@@ -104,6 +106,7 @@ struct HostTable {
 	// device numbering: hot states first ("perm" ids).  permOfOrig / origOfPerm are inverse permutations.
 	std::vector<uint32_t> permOfOrig, origOfPerm;
 	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
+	uint32_t byteRot = 0;             // experiment: dense rows indexed by rotl8(byte, 2) (PIRE_HIP_BYTE_ROT=1)
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
@@ -175,6 +178,7 @@ struct ScanParams {
 	uint32_t* visitCold;
 	const uint16_t* compactRows;
 	uint32_t compact;        // 0 = tier off
+	uint32_t byteRot;
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;

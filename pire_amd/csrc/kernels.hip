@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cstdio>
+
 #include "internal.h"
 
 namespace pirehip {
@@ -67,11 +69,21 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 }
 
 // The exact step for any state: multi.h:169-192 on the perm-numbered table.
+// rotl8(b, 2) on four packed bytes / on one byte
+__device__ __forceinline__ uint32_t RotBytes(uint32_t x)
+{
+	return ((x << 2) & 0xFCFCFCFCu) | ((x >> 6) & 0x03030303u);   // v_lshlrev, v_lshrrev, v_bfi
+}
+__device__ __forceinline__ uint32_t DenseColumn(const ScanParams& p, uint32_t byte)
+{
+	return p.byteRot ? ((byte << 2) | (byte >> 6)) & 0xFFu : byte;
+}
+
 __device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                              uint32_t st, uint32_t byte)
 {
 	if (st < p.hot) {
-		const uint32_t e = lds[st * L.pitch + byte];
+		const uint32_t e = lds[st * L.pitch + DenseColumn(p, byte)];
 		if (e != p.hot)
 			return e;
 	}
@@ -415,7 +427,7 @@ __device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t
 }
 
 // 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
-template <bool ROT>
+template <int ROT>
 __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                           const u32x4 v, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
 {
@@ -423,7 +435,7 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t x = v[w];
-		if (ROT) {
+		if (ROT == 1) {
 			// rows are 65 dwords apart, so row r is rotated by r banks: lanes in different states reading the same
 			// byte>>2 no longer hit the same bank.  The byte is extracted off the dependent chain; the chain
 			// itself stays one VALU (v_mad_u32_u24) + one ds_read_u8.
@@ -433,10 +445,13 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 			hs = HotLookup(__umul24(hs, kRotPitch) + b2);
 			hs = HotLookup(__umul24(hs, kRotPitch) + b3);
 		} else {
-			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
+			// ROT == 2: the dense rows are indexed by rotl8(byte, 2), so the LDS bank is byte & 63 instead of byte >> 2
+			// (printable text then spreads over all 64 banks instead of 24); 3 VALU per 4 bytes
+			const uint32_t y = ROT == 2 ? RotBytes(x) : x;
+			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0400u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0401u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0402u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0403u));
 		}
 	}
 	if (hs == p.hot && !(p.flags & kDebugNoTrap)) {
@@ -462,7 +477,7 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 	}
 }
 
-template <bool ROT>
+template <int ROT>
 __device__ __forceinline__ void StepTile(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                          const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold, uint32_t tile)
 {
@@ -497,7 +512,7 @@ __device__ __forceinline__ uint64_t Uniform64(uint64_t v)
 // One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1
 // ahead (index clamped to the last tile, so the steady-state loop has no conditional loads), wait until the
 // current slot has landed, transpose it into lane-owns-string order, walk it.
-template <int NBUF, bool NT, bool ROT>
+template <int NBUF, bool NT, int ROT>
 __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
                                       uint64_t chainBase, uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile,
                                       u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
@@ -522,14 +537,14 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
 // the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
 // gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
-template <int WAVES, int NBUF, bool NT, int MINW, bool ROT>
+template <int WAVES, int NBUF, bool NT, int MINW, int ROT>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
 	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
 	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT ? kRotPitch : 256u, CompactBytes(p));
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT == 1 ? kRotPitch : 256u, CompactBytes(p));
 	LoadTableToLds(p, lds, L);
 
 	const uint32_t lane = threadIdx.x & 63;
@@ -892,7 +907,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) >= kStart && uint32_t(k) < kStart + full)
-					StepChunk<false>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+					StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
 				const uint32_t kt = kStart + full;
 				u32x4 v = cur[0];
@@ -1143,6 +1158,8 @@ int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hi
 	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, ldsBytes);
 	if (e != hipSuccess)
 		return HipFail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+	if (getenv("PIRE_HIP_DEBUG_LAUNCH"))
+		fprintf(stderr, "pire_hip: threads %d lds %u -> %d blocks/CU\n", threads, ldsBytes, perCu);
 	if (perCu < 1)
 		perCu = 1;
 	const uint64_t ntasks = (p.n + 63) / 64;
@@ -1182,7 +1199,7 @@ int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 {
 	// one string per lane with dynamic re-assignment: worth it from a few waves' worth of strings
-	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096;
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096 && !p.byteRot;
 }
 
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
@@ -1250,16 +1267,20 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoColdCount;
 	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
 		q.flags |= kDebugNoHist;
-	if (variant == 1)
+	if (variant == 1 || variant == 4)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(q));
 	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(q));
 	switch (variant) {
-	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, true>, q, 1024, L.total, stream); break;   // bank-rotated rows
-	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, false>, q, 1024, L256.total, stream); break; // no nt
-	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, false>, q, 1024, L256.total, stream); break;
+	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 1>, q, 1024, L.total, stream); break;   // bank-rotated rows
+	case 4:  rc = LaunchScan(ScanTiledKernel<10, 2, true, 5, 0>, q, 640, L256.total, stream); break;   // 2 blocks x 10 waves per CU
+	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream); break; // no nt
+	default:
+		rc = q.byteRot ? LaunchScan(ScanTiledKernel<16, 2, true, 5, 2>, q, 1024, L256.total, stream)
+		               : LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
+		break;
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

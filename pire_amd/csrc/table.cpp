@@ -12,6 +12,7 @@
 // result (multi.h:925-934 asserts it); the GPU analogue is the absorbing-row early-out.
 
 #include <algorithm>
+#include <map>
 #include <cstdlib>
 #include <cmath>
 #include <iterator>
@@ -101,6 +102,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
+	t.byteRot = getenv("PIRE_HIP_BYTE_ROT") ? 1 : 0;   // knob: A/B measurements
 	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
 	t.permOfOrig.assign(N, 0);
@@ -115,7 +117,8 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 		uint8_t* out = &t.hotRows[size_t(pid) * 256];
 		for (uint32_t b = 0; b < 256; ++b) {
 			const uint32_t d = t.permOfOrig[row[t.cls[b]]];
-			out[b] = d < H ? uint8_t(d) : uint8_t(H);
+			const uint32_t col = t.byteRot ? ((b << 2) | (b >> 6)) & 0xFFu : b;
+			out[col] = d < H ? uint8_t(d) : uint8_t(H);
 		}
 	}
 	t.hotFlags.assign(256, 0);
@@ -145,6 +148,112 @@ void ChooseHotAndPermute(HostTable& t)
 
 }  // namespace
 
+namespace {
+
+// Pire::SimpleScanner (scanners/simple.h): one regexp, rows of MaxChar + 1 size_t slots = [tag, byte shift per Char],
+// no letter classes, never Dead.  Save format: scanner_io.cpp:35-49.  The dense 264-column rows are folded into the
+// same HostTable as a Scanner: columns with identical transitions become one letter class, so every kernel, the
+// compact tier and the accessors work unchanged; StateIndex (simple.h:154-157) is the row number.
+int BuildSimpleHostTable(const uint8_t* p, size_t len, size_t pos, HostTable* out)
+{
+	struct SimpleLocals {
+		uint64_t statesCount, initial;   // simple.h:171-174; initial on disk = byte offset from m_transitions
+	} m;
+	if (len < pos + sizeof(m) + 8)
+		return Bad("EOF reached while reading the scanner locals");
+	memcpy(&m, p + pos, sizeof(m));
+	pos += sizeof(m);
+	const bool empty = p[pos] != 0;
+	pos += 8;
+	constexpr uint64_t kRowSlots = kMaxChar + 1;   // STATE_ROW_SIZE, simple.h:43
+	constexpr uint64_t kStride = kRowSlots * 8;
+
+	HostTable& t = *out;
+	t = HostTable();
+	t.scannerType = 2;
+	t.headerSize = 1;   // the tag slot in front of the transitions
+	t.rowStride = uint32_t(kStride);
+	t.empty = empty;
+	if (m.statesCount == 0 || m.statesCount > (1u << 24))
+		return Bad("Corrupt scanner: bad state count");
+	if (m.initial % kStride != 8 || m.initial / kStride >= m.statesCount)
+		return Bad("Corrupt scanner: initial state out of range");
+	t.states = uint32_t(m.statesCount);
+	t.initial = uint32_t(m.initial / kStride);
+	t.regexps = empty ? 0 : 1;       // RegexpsCount(), simple.h:59
+	t.cls.assign(kMaxChar, 0);
+
+	if (empty) {
+		// aliases Null() = Fsm::MakeFalse() compiled: zeroed rows (every shift 0), no final state (simple.h:187-191, 234)
+		t.letters = 1;
+		t.next.resize(t.states);
+		for (uint32_t s = 0; s < t.states; ++s)
+			t.next[s] = s;
+		t.flags.assign(t.states, uint8_t(kAbsorbing));
+		t.acceptOff.assign(size_t(t.states) + 1, 0);
+		t.blobBytes = pos;
+		ChooseHotAndPermute(t);
+		return PIRE_HIP_OK;
+	}
+
+	const uint64_t bufSize = kStride * m.statesCount;   // BufSize(), simple.h:160-163
+	if (len < pos + bufSize)
+		return Bad("EOF reached while reading the scanner buffer");
+	t.refBufSize = bufSize;
+	t.blobBytes = pos + bufSize;
+	const uint8_t* buf = p + pos;
+
+	// decode every (state, Char) -> next state
+	std::vector<uint32_t> dense(size_t(t.states) * kMaxChar);
+	for (uint32_t s = 0; s < t.states; ++s)
+		for (uint32_t c = 0; c < kMaxChar; ++c) {
+			uint64_t shift;
+			memcpy(&shift, buf + (uint64_t(s) * kRowSlots + 1 + c) * 8, 8);
+			const uint64_t dest = uint64_t(s) * kStride + shift;   // state += shift (mod 2^64), simple.h:78-79
+			if (dest % kStride != 0 || dest / kStride >= m.statesCount)
+				return Bad("Corrupt scanner: transition out of range");
+			dense[size_t(s) * kMaxChar + c] = uint32_t(dest / kStride);
+		}
+	// letter classes = distinct columns, numbered in order of first appearance
+	std::map<std::vector<uint32_t>, uint16_t> classOf;
+	std::vector<uint32_t> col(t.states);
+	std::vector<uint32_t> repr;   // representative Char of each class
+	for (uint32_t c = 0; c < kMaxChar; ++c) {
+		for (uint32_t s = 0; s < t.states; ++s)
+			col[s] = dense[size_t(s) * kMaxChar + c];
+		auto it = classOf.find(col);
+		if (it == classOf.end()) {
+			it = classOf.emplace(col, uint16_t(repr.size())).first;
+			repr.push_back(c);
+		}
+		t.cls[c] = it->second;
+	}
+	t.letters = uint32_t(repr.size());
+	t.next.resize(size_t(t.states) * t.letters);
+	t.flags.resize(t.states);
+	t.acceptOff.assign(size_t(t.states) + 1, 0);
+	for (uint32_t s = 0; s < t.states; ++s) {
+		bool absorbing = true;
+		for (uint32_t l = 0; l < t.letters; ++l) {
+			const uint32_t d = dense[size_t(s) * kMaxChar + repr[l]];
+			t.next[size_t(s) * t.letters + l] = d;
+			absorbing = absorbing && d == s;
+		}
+		uint64_t tag;
+		memcpy(&tag, buf + uint64_t(s) * kStride, 8);
+		const bool fin = tag != 0;                       // Final(), simple.h:62; Dead() is always false (64)
+		t.flags[s] = uint8_t((fin ? kFinal : 0) | (absorbing ? kAbsorbing : 0));
+		t.acceptOff[s] = t.acceptIds.size();
+		if (fin)
+			t.acceptIds.push_back(0);                    // AcceptedRegexps() = {0} when Final, simple.h:66-68, 193-203
+	}
+	t.acceptOff[t.states] = t.acceptIds.size();
+	ChooseHotAndPermute(t);
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
 int BuildHostTable(const void* blob, size_t len, HostTable* out)
 {
 	const uint8_t* p = static_cast<const uint8_t*>(blob);
@@ -157,6 +266,8 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 		return Bad("Serialized regexp incompatible with your system");
 	if (h.version != 7 && h.version != 6)
 		return Bad("You are trying to used an incompatible version of a serialized regexp");
+	if (h.type == 2 /* ScannerIOTypes::SimpleScanner, common.h:37 */ && h.hdrSize == 16)
+		return BuildSimpleHostTable(p, len, AlignUp(sizeof(RefHeader), 8), out);
 	if (h.type != 1 /* ScannerIOTypes::Scanner */ || h.hdrSize != sizeof(RefLocals))
 		return Bad("Serialized regexp incompatible with your system");
 	size_t pos = AlignUp(sizeof(RefHeader), 8);
@@ -183,6 +294,7 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 
 	HostTable& t = *out;
 	t = HostTable();
+	t.scannerType = 1;
 	const uint32_t flagsOff = maskCount * 4 * 8;
 	t.headerSize = (flagsOff + 8) / 4;
 	t.empty = empty;
@@ -199,6 +311,7 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 		t.next.assign(1, 0);
 		t.flags.assign(1, uint8_t(kDead | kAbsorbing));
 		t.acceptOff.assign(2, 0);
+		t.blobBytes = pos;
 		ChooseHotAndPermute(t);
 		return PIRE_HIP_OK;
 	}
@@ -217,6 +330,7 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 	t.regexps = m.regexpsCount;
 	t.rowStride = uint32_t(rowSize * 4);
 	t.refBufSize = bufSize;
+	t.blobBytes = AlignUp(pos + bufSize, 8);
 
 	const uint8_t* buf = p + pos;
 	const uint8_t* letters = buf;

@@ -145,10 +145,40 @@ static void TestPrefixAndSlow()
 	CHECK(m[0] && !m[1] && !m[2]);
 }
 
+// Pire::SimpleScanner through the same shim: identical State values, Final, AcceptedRegexps (simple.h:62-68).
+static void TestSimpleScanner()
+{
+	const char* patterns[] = {"hello\\s+w.+d$", "abc|def", "ad*e", "Head(Inner)*Tail"};
+	std::vector<Pire::ystring> strings;
+	const char* fixed[] = {"hello world", "Hello world", "say hello   wod", "", "abc", "xxdefyy", "addde", "HeadInnerInnerTail",
+	                       "HeadInneTail", "hello wd"};
+	for (size_t i = 0; i < sizeof(fixed) / sizeof(fixed[0]); ++i)
+		strings.push_back(fixed[i]);
+	unsigned seed = 12345;
+	for (int i = 0; i < 600; ++i) {
+		Pire::ystring s;
+		seed = seed * 1103515245u + 12345u;
+		const size_t len = (seed >> 16) % 90;
+		for (size_t k = 0; k < len; ++k) {
+			seed = seed * 1103515245u + 12345u;
+			s.push_back("abcdefHeadInrTl w\thello"[(seed >> 16) % 23]);
+		}
+		strings.push_back(s);
+	}
+	for (size_t p = 0; p < sizeof(patterns) / sizeof(patterns[0]); ++p) {
+		Pire::SimpleScanner sc = Parse(patterns[p]).Compile<Pire::SimpleScanner>();
+		CompareAll(sc, strings);
+	}
+	Pire::SimpleScanner empty;
+	CHECK(empty.Empty());
+	CompareAll(empty, strings);
+}
+
 int main()
 {
 	try {
 		TestPrefixAndSlow();
+		TestSimpleScanner();
 		TestSuite<Pire::Scanner>();
 		TestSuite<Pire::NonrelocScanner>();
 		TestSuite<Pire::ScannerNoMask>();

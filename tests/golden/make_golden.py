@@ -253,10 +253,55 @@ def main():
                      "strings_hex": [x.hex() for x in strings], "ref_expect": [v for _, v in items],
                      "final": [int(x) for x in fin], "bits_hex": [bytes(np.ascontiguousarray(b)).hex() for b in bits]})
 
+    # SimpleScanner (scanners/simple.h): tests/common.h:80-119 runs every SCANNER() block through it as well, so the
+    # verdicts of tests/pire_ut.cpp apply unchanged
+    from oracle.binding import RefSimpleScanner
+    simple = []
+    SIMPLE = [
+        ("simple_hello", "README:60 / SURVEY 8c known answer", r"hello\s+w.+d$", "",
+         [(b"hello world", A), (b"Hello world", D), (b"say hello   wod", A), (b"hello world!", D), (b"hello wd", D),
+          (b"", D), (b"xxhello\tw--d", A)]),
+        ("simple_alt", "pire_ut.cpp:62-74", "abc|def", "", [(b"abc", A), (b"def", A), (b"xxabcyy", A), (b"ab", D), (b"", D)]),
+        ("simple_count", "pire_ut.cpp:117-131 (Repetition)", "^x{3,6}$", "", [(b"xxx", A), (b"xxxxxx", A), (b"xx", D),
+                                                                               (b"xxxxxxx", D), (b"axxx", D)]),
+        ("simple_head_tail", "pire_ut.cpp:76-91 (Composition)", "Head(Inner)*Tail", "",
+         [(b"HeadTail", A), (b"HeadInnerInnerTail", A), (b"HeadInneTail", D)]),
+        ("simple_utf8_dot", "pire_ut.cpp:181-209 (UTF8)", "^.$", "u", [("\u0436".encode("utf-8"), A), (b"a", A), (b"ab", D),
+                                                                        (b"\xd0", D)]),
+    ]
+    rng = np.random.RandomState(78)
+    for name, source, pat, opt, items in SIMPLE:
+        sc = RefSimpleScanner.compile(pat, opt)
+        strings = [s_ for s_, _ in items]
+        strings += [bytes(rng.choice(np.frombuffer(b"abcdefxHeadInrTl w\t\xd0\xb6", dtype=np.uint8), size=int(k)))
+                    for k in rng.randint(0, 90, size=40)]
+        bi, bf = sc.run_strings(strings)
+        ni, nf = sc.run_strings(strings, flags=0)
+        for (s_, verdict), f_ in zip(items, bf):
+            assert bool(f_) == verdict, (name, s_, f_, verdict)
+        blob = sc.save()
+        simple.append({"name": name, "source": source, "pattern": pat, "options": opt, "states": sc.size,
+                       "initial": sc.initial, "empty": sc.empty, "blob": write_blob(name, blob),
+                       "blob_sha256": hashlib.sha256(blob).hexdigest(), "strings_hex": [x.hex() for x in strings],
+                       "accepts_hex": [x.hex() for x, v in items if v], "denies_hex": [x.hex() for x, v in items if not v],
+                       "be": {"idx": [int(x) for x in bi], "final": [int(x) for x in bf]},
+                       "none": {"idx": [int(x) for x in ni], "final": [int(x) for x in nf]}})
+    sc = RefSimpleScanner.empty_scanner()
+    strings = [b"", b"abc", b"\x00\xff"]
+    bi, bf = sc.run_strings(strings)
+    ni, nf = sc.run_strings(strings, flags=0)
+    blob = sc.save()
+    simple.append({"name": "simple_empty", "source": "pire_ut.cpp:760-830 (EmptyScanner) for SimpleScanner()", "pattern": None,
+                   "options": "", "states": sc.size, "initial": sc.initial, "empty": True, "blob": write_blob("simple_empty", blob),
+                   "blob_sha256": hashlib.sha256(blob).hexdigest(), "strings_hex": [x.hex() for x in strings],
+                   "accepts_hex": [], "denies_hex": [x.hex() for x in strings],
+                   "be": {"idx": [int(x) for x in bi], "final": [int(x) for x in bf]},
+                   "none": {"idx": [int(x) for x in ni], "final": [int(x) for x in nf]}})
+
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "slow": slow, "corpus": corpus}, f, indent=1)
-    print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners")
+                   "cases": cases, "big": big, "slow": slow, "simple": simple, "corpus": corpus}, f, indent=1)
+    print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners,", len(simple), "simple scanners")
 
 
 if __name__ == "__main__":
