@@ -178,6 +178,18 @@ int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64
 int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream);
 
 /*
+ * Batched Runner over the table walked as a Pire::HalfFinalScanner (scanners/half_final.h:32-227).  A
+ * HalfFinalScanner IS a Scanner (same Save() bytes, ingest it with pire_hip_table_create), but its Initialize and
+ * every Step end with TakeAction, which counts, per regexp, the steps that end in a state final for it
+ * (half_final.h:137-164): the number of -- possibly intersecting -- matches.  Per string i:
+ *   out_results[i * RegexpsCount() + r] = State::Result(r)   (half_final.h:90-92; u32: a count is <= length + 3)
+ *   out_state_idx / out_final (nullable)  = StateIndex / Final of the end state, as pire_hip_run.
+ * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE.  Pinned by tests/count_ut.cpp:541-550, 575.
+ */
+int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                            uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* stream);
+
+/*
  * Pire::LongestPrefix / Pire::ShortestPrefix (run.h:277-311) for n strings: out_len[i] = length of the longest
  * (shortest) prefix of string i the scanner accepts, or -1 where the reference returns a null pointer.
  * through_begin / through_end as the reference's throughBeginMark / throughEndMark.  Scanning stops at the first

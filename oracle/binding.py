@@ -113,6 +113,8 @@ def oracle_lib():
         L.oracle_slow_empty.restype = C.c_int
         L.oracle_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p]
         L.oracle_slow_run.restype = None
+        L.oracle_run_half_final.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u64p]
+        L.oracle_run_half_final.restype = None
         L.oracle_simple_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
         L.oracle_simple_load.restype = C.c_int
         L.oracle_simple_free.argtypes = [C.c_void_p]
@@ -193,6 +195,18 @@ class OracleScanner:
     def run_strings(self, strings: Sequence[bytes], **kw):
         text, offs = pack_strings(strings)
         return self.run(text, offs, **kw)
+
+    def run_half_final(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        """The table walked as a Pire::HalfFinalScanner: (idx, final, results[n, regexps])."""
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        res = np.zeros((n, max(self.regexps, 1)), dtype=np.uint64)
+        self._L.oracle_run_half_final(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                      _ptr(idx, u32p), _ptr(fin, u8p), _ptr(res, u64p))
+        return idx, fin, res[:, :self.regexps]
 
     def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
         text = _as_text(text)
@@ -347,6 +361,18 @@ def ref_lib():
         L.pire_ref_slow_empty.restype = C.c_int
         L.pire_ref_slow_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u8p, u32p, C.c_int]
         L.pire_ref_slow_run.restype = C.c_int
+        L.pire_ref_half_compile.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int, C.c_char_p]
+        L.pire_ref_half_compile.restype = C.c_void_p
+        L.pire_ref_half_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.pire_ref_half_load.restype = C.c_void_p
+        L.pire_ref_half_free.argtypes = [C.c_void_p]
+        L.pire_ref_half_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_half_save.restype = C.c_size_t
+        for name in ("pire_ref_half_size", "pire_ref_half_regexps"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_size_t
+        L.pire_ref_half_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u64p, C.c_int]
+        L.pire_ref_half_run.restype = C.c_int
         L.pire_ref_simple_compile.argtypes = [C.c_char_p, C.c_char_p]
         L.pire_ref_simple_compile.restype = C.c_void_p
         L.pire_ref_simple_empty.argtypes = []
@@ -420,6 +446,58 @@ class RefSlowScanner:
         if rc != 0:
             raise RuntimeError(self._L.pire_ref_last_error().decode())
         return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
+class RefHalfFinalScanner:
+    """The real Pire::HalfFinalScanner behind a C ABI (built like tests/count_ut.cpp:503-527)."""
+
+    GREEDY_SIMPLE, GREEDY, NONGREEDY_SIMPLE, NONGREEDY, NONGREEDY_NOINTERSECT, PLAIN = range(6)
+
+    def __init__(self, handle):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def compile(cls, patterns, modes, options="u"):
+        L = ref_lib()
+        pats = (C.c_char_p * len(patterns))(*[p.encode("utf-8") if isinstance(p, str) else p for p in patterns])
+        md = (C.c_int * len(modes))(*modes)
+        return cls(L.pire_ref_half_compile(pats, md, len(patterns), options.encode()))
+
+    @classmethod
+    def load(cls, blob: bytes):
+        return cls(ref_lib().pire_ref_half_load(bytes(blob), len(blob)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_half_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_half_size(s._h))
+    regexps = property(lambda s: s._L.pire_ref_half_regexps(s._h))
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_half_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_half_save(self._h, buf, n)
+        return buf.raw
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        res = np.zeros((n, max(self.regexps, 1)), dtype=np.uint64)
+        self._L.pire_ref_half_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                  _ptr(idx, u32p), _ptr(fin, u8p), _ptr(res, u64p), threads)
+        return idx, fin, res[:, :self.regexps]
 
     def run_strings(self, strings, **kw):
         text, offs = pack_strings(strings)

@@ -313,6 +313,64 @@ void oracle_run(const oracle_scanner* sc, const void* text, const uint64_t* offs
 	}
 }
 
+/* ------------------------------------------- HalfFinalScanner: the same table, counting TakeAction */
+
+/* HalfFinalScanner::TakeAction, half_final.h:156-164: if the state is Final, every entry of its final list
+ * (multiplicities included, BuildFinals 202-213) bumps MatchedRegexps[id]. */
+static inline void half_take_action(const oracle_scanner* sc, uint64_t st, uint64_t* matched)
+{
+	if (row_flags(sc, st) & 1) {
+		const uint64_t* it = sc->final_tab + sc->final_index[state_index(sc, st)];
+		for (; *it != (uint64_t)-1; ++it)
+			matched[*it]++;
+	}
+}
+
+void oracle_run_half_final(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
+                           uint32_t flags, uint32_t* out_idx, uint8_t* out_final, uint64_t* results)
+{
+	const uint8_t* t = (const uint8_t*)text;
+	const uint32_t R = oracle_regexps_count(sc);
+	uint64_t i, k;
+	for (i = 0; i < n; ++i) {
+		uint64_t* matched = results ? results + i * R : NULL;
+		uint64_t scratch[1];
+		uint64_t st;
+		if (sc->empty) {
+			if (out_idx) out_idx[i] = 0;
+			if (out_final) out_final[i] = 0;
+			continue;
+		}
+		if (!matched) {
+			/* counts not wanted: still walk with a throw-away array of the right size */
+			matched = (uint64_t*)calloc(R ? R : 1, sizeof(uint64_t));
+		} else {
+			memset(matched, 0, sizeof(uint64_t) * R);     /* Initialize, half_final.h:138-143 */
+		}
+		(void)scratch;
+		st = sc->m.initial;
+		half_take_action(sc, st, matched);                /* Initialize ends with TakeAction(state, 0) */
+		if (flags & ORACLE_FLAG_BEGIN) {                  /* Step = Next + TakeAction, run.h:50-57 */
+			st = next_state(sc, st, ORACLE_BEGIN_MARK);
+			half_take_action(sc, st, matched);
+		}
+		/* Run: the generic AlignedRunner (run.h:153-184) -- Step() per byte in order; the Scanner-only
+		 * shortcutting runner (multi.h:911) does not apply to the derived class */
+		for (k = offsets[i]; k < offsets[i + 1]; ++k) {
+			st = next_state(sc, st, t[k]);
+			half_take_action(sc, st, matched);
+		}
+		if (flags & ORACLE_FLAG_END) {
+			st = next_state(sc, st, ORACLE_END_MARK);
+			half_take_action(sc, st, matched);
+		}
+		if (out_idx) out_idx[i] = state_index(sc, st);
+		if (out_final) out_final[i] = (row_flags(sc, st) & 1) != 0;
+		if (!results)
+			free(matched);
+	}
+}
+
 /* ------------------------------------------- the walk with the production control flow */
 
 #define NO_SHORTCUT_MASK 1u   /* multi.h:640 */

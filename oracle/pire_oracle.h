@@ -86,6 +86,15 @@ void oracle_run(const oracle_scanner* sc, const void* text, const uint64_t* offs
 void oracle_run_shortcut(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
                          uint32_t flags, const uint32_t* init_idx, uint32_t* out_idx, uint8_t* out_final);
 
+/*
+ * Pire::HalfFinalScanner (scanners/half_final.h): the same serialised table (it IS a Scanner, Save/Load are
+ * inherited), but Initialize and every Step end with TakeAction, which counts, per regexp, the steps that end in a
+ * state final for it (half_final.h:137-164).  results (nullable): n * RegexpsCount() values = State::Result(r).
+ * Pinned by the reference's own vectors, tests/count_ut.cpp:541-550, 575.
+ */
+void oracle_run_half_final(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
+                           uint32_t flags, uint32_t* out_idx, uint8_t* out_final, uint64_t* results);
+
 /* LongestPrefix / ShortestPrefix (run.h:277-311): prefix length or -1. */
 void oracle_prefix(const oracle_scanner* sc, int longest, const void* text, const uint64_t* offsets,
                    uint64_t n, int through_begin, int through_end, int64_t* out_len);

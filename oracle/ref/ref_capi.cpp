@@ -506,4 +506,131 @@ int pire_ref_simple_run(void* hh, const void* text, const uint64_t* offsets, uin
 	return 0;
 }
 
+/* ---- Pire::HalfFinalScanner (scanners/half_final.h): a Scanner whose TakeAction counts, per regexp, the steps that
+ * end in a state final for it.  Built as tests/count_ut.cpp:503-527 does. ------------------------------------- */
+
+struct RefHalf {
+	Pire::HalfFinalScanner sc;
+};
+
+/* tests/count_ut.cpp:36-44 (MkFsm): no Surround(); option 'u' = UTF-8 (the tests' default), else Latin1; 'i'. */
+static Pire::Fsm MkCountFsm(const char* regexp, const char* options)
+{
+	Pire::Lexer lex;
+	bool utf8 = false;
+	for (const char* o = options ? options : ""; *o; ++o) {
+		if (*o == 'u')
+			utf8 = true;
+		else if (*o == 'i')
+			lex.AddFeature(Pire::Features::CaseInsensitive());
+	}
+	const Pire::Encoding& enc = utf8 ? Pire::Encodings::Utf8() : Pire::Encodings::Latin1();
+	lex.SetEncoding(enc);
+	Pire::TVector<Pire::wchar32> ucs4;
+	enc.FromLocal(regexp, regexp + strlen(regexp), std::back_inserter(ucs4));
+	lex.Assign(ucs4.begin(), ucs4.end());
+	return lex.Parse();
+}
+
+/* mode: 0 MakeGreedyCounter(true), 1 MakeGreedyCounter(false), 2 MakeNonGreedyCounter(true,true),
+ * 3 MakeNonGreedyCounter(true,false), 4 MakeNonGreedyCounter(false)   (count_ut.cpp:506-519),
+ * 5 HalfFinalScanner(Fsm) = MakeScanner (half_final.h:38-46).  count > 1: glued left to right (count_ut.cpp:520-523). */
+void* pire_ref_half_compile(const char* const* patterns, const int* modes, int count, const char* options)
+{
+	try {
+		std::unique_ptr<RefHalf> h(new RefHalf);
+		for (int i = 0; i < count; ++i) {
+			const Pire::Fsm re = MkCountFsm(patterns[i], options);
+			Pire::HalfFinalScanner one;
+			if (modes[i] == 5) {
+				one = Pire::HalfFinalScanner(re);
+			} else {
+				Pire::HalfFinalFsm fsm(re);
+				switch (modes[i]) {
+				case 0: fsm.MakeGreedyCounter(true); break;
+				case 1: fsm.MakeGreedyCounter(false); break;
+				case 2: fsm.MakeNonGreedyCounter(true, true); break;
+				case 3: fsm.MakeNonGreedyCounter(true, false); break;
+				case 4: fsm.MakeNonGreedyCounter(false); break;
+				default: throw Pire::Error("unknown half-final mode");
+				}
+				one = Pire::HalfFinalScanner(fsm);
+			}
+			h->sc = i == 0 ? one : Pire::HalfFinalScanner::Glue(h->sc, one);      // half_final.h:196-198
+			if (i && h->sc.Empty())
+				throw Pire::Error("HalfFinalScanner::Glue failed (too many states)");
+		}
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void* pire_ref_half_load(const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefHalf> h(new RefHalf);
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		h->sc.Load(&in);                                  // Scanner::Load, multi.h:575-599 (inherited)
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_half_free(void* h) { delete static_cast<RefHalf*>(h); }
+
+size_t pire_ref_half_save(void* h, void* buf, size_t cap)          // Scanner::Save, multi.h:557-573 (inherited)
+{
+	std::ostringstream out;
+	static_cast<RefHalf*>(h)->sc.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_half_size(void* h) { return static_cast<RefHalf*>(h)->sc.Size(); }
+size_t pire_ref_half_regexps(void* h) { return static_cast<RefHalf*>(h)->sc.RegexpsCount(); }
+
+/* tests/count_ut.cpp:54-63 (Run): Initialize, Step(BeginMark), Run, Step(EndMark); then Result(r) per regexp
+ * (half_final.h:90-92), Final and StateIndex.  results: n * RegexpsCount() values. */
+int pire_ref_half_run(void* hh, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                      uint32_t* outIdx, uint8_t* outFinal, uint64_t* results, int threads)
+{
+	const Pire::HalfFinalScanner& sc = static_cast<RefHalf*>(hh)->sc;
+	const size_t R = sc.RegexpsCount();
+	const char* t = static_cast<const char*>(text);
+	auto range = [&](uint64_t lo, uint64_t hi) {
+		for (uint64_t i = lo; i < hi; ++i) {
+			Pire::HalfFinalScanner::State st;
+			sc.Initialize(st);
+			if (flags & FLAG_BEGIN)
+				Pire::Step(sc, st, Pire::BeginMark);
+			Pire::Run(sc, st, t + offsets[i], t + offsets[i + 1]);
+			if (flags & FLAG_END)
+				Pire::Step(sc, st, Pire::EndMark);
+			if (outIdx)
+				outIdx[i] = uint32_t(sc.StateIndex(st));
+			if (outFinal)
+				outFinal[i] = sc.Final(st) ? 1 : 0;
+			if (results)
+				for (size_t r = 0; r < R; ++r)
+					results[i * R + r] = st.Result(r);
+		}
+	};
+	if (threads <= 1) {
+		range(0, n);
+		return 0;
+	}
+	std::vector<std::thread> pool;     // sharding by string index is ours
+	for (int k = 0; k < threads; ++k)
+		pool.emplace_back(range, n * k / threads, n * (k + 1) / threads);
+	for (auto& th : pool)
+		th.join();
+	return 0;
+}
+
 } // extern "C"

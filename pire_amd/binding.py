@@ -91,6 +91,8 @@ ABI = [
     ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_step", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    ("pire_hip_run_half_final", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_prefix", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                   C.c_void_p, C.c_void_p]),
     ("pire_hip_slow_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -277,6 +279,26 @@ class Table:
         _check(lib().pire_hip_run(self._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
                                   init_ptr or None, out_idx_ptr or None, out_final_ptr or None,
                                   out_counts_ptr or None, stream or None))
+
+    def run_half_final(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        """The table walked as a Pire::HalfFinalScanner: (StateIndex, Final, Result[n, regexps]) for host strings."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        res = np.zeros((n, max(self.RegexpsCount, 1)), dtype=np.uint32)
+        _check(lib().pire_hip_run_half_final(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                             flags & ~FLAG_ON_DEVICE, idx.ctypes.data, fin.ctypes.data,
+                                             res.ctypes.data, None))
+        return idx, fin, res[:, :self.RegexpsCount]
+
+    def run_half_final_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_final_ptr=0,
+                              out_results_ptr=0, stream: int = 0):
+        _check(lib().pire_hip_run_half_final(self._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
+                                             out_idx_ptr or None, out_final_ptr or None, out_results_ptr or None,
+                                             stream or None))
 
     def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
         """LongestPrefix / ShortestPrefix lengths (-1 = no prefix) for host strings."""

@@ -93,6 +93,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->compactRows = d.compactRows;
 	p->compact = h.compact;
 	p->byteRot = h.byteRot;
+	p->incPerm = d.incPerm;
+	p->hotFinalLo = h.hotFinalLo;
 	p->states = h.states;
 	p->letters = h.letters;
 	p->regexps = h.regexps;
@@ -482,6 +484,72 @@ int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64
 	}
 	return RunImpl(t, text, nullptr, n, len, stride, flags, init_state_idx, out_state_idx, out_final, out_counts,
 	               stream);
+}
+
+int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                            uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* streamPtr)
+{
+	if (!t || (n && (!offsets || !out_results))) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	ScanParams p;
+	if (int rc = FillParams(t, &p, 0))   // startPerm = Initialize(); Begin() is a counted step in the kernel
+		return rc;
+	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+	p.n = n;
+	if (n == 0)
+		return PIRE_HIP_OK;
+	const uint32_t R = t->host.regexps;
+	g_lastKernel = "half_final";
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		p.outIdx = out_state_idx;
+		p.outFinal = out_final;
+		return LaunchHalfFinal(p, out_results, stream);
+	}
+	Staging st;
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i] > offsets[i + 1]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
+		}
+	const uint64_t textBytes = offsets[n];
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	const uint8_t* dText = nullptr;
+	if (int rc = st.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream))
+		return rc;
+	p.text = dText;
+	if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
+		return rc;
+	void *dIdx = nullptr, *dFin = nullptr, *dRes = nullptr;
+	if (int rc = st.Alloc(&dIdx, size_t(n) * 4))
+		return rc;
+	if (int rc = st.Alloc(&dFin, size_t(n)))
+		return rc;
+	if (int rc = st.Alloc(&dRes, size_t(n) * std::max<uint32_t>(R, 1) * 4))
+		return rc;
+	p.outIdx = static_cast<uint32_t*>(dIdx);
+	p.outFinal = static_cast<uint8_t*>(dFin);
+	if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream))
+		return rc;
+	hipError_t e = hipSuccess;
+	if (out_state_idx)
+		e = hipMemcpyAsync(out_state_idx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && out_final)
+		e = hipMemcpyAsync(out_final, dFin, size_t(n), hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && R)
+		e = hipMemcpyAsync(out_results, dRes, size_t(n) * R * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+		return HipFail(e, "copy back / synchronize");
+	return PIRE_HIP_OK;
 }
 
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,

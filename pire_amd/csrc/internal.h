@@ -106,6 +106,9 @@ struct HostTable {
 	// device numbering: hot states first ("perm" ids).  permOfOrig / origOfPerm are inverse permutations.
 	std::vector<uint32_t> permOfOrig, origOfPerm;
 	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
+	uint32_t hotFinalLo = 0;          // hot perm ids >= this are Final (the hot set is ordered non-final first)
+	bool incPacked = false;           // regexps <= 8 and every final-list multiplicity <= 255: inc64 is usable
+	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
 	uint32_t byteRot = 0;             // experiment: dense rows indexed by rotl8(byte, 2) (PIRE_HIP_BYTE_ROT=1)
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
@@ -137,6 +140,7 @@ struct DeviceTable {
 	uint64_t* acceptIds = nullptr;
 	struct FinRec* finSelf = nullptr; // [states] end-of-string record when End() is not requested
 	struct FinRec* finEnd = nullptr;  // [states] end-of-string record after Step(EndMark)
+	uint64_t* incPerm = nullptr;      // [states] packed per-regexp increments of HalfFinalScanner::TakeAction, or null
 	uint16_t* compactRows = nullptr;  // [(compact+1) rows] LDS address / 4 of the next state's row (last row = escape), padded
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
@@ -179,6 +183,8 @@ struct ScanParams {
 	const uint16_t* compactRows;
 	uint32_t compact;        // 0 = tier off
 	uint32_t byteRot;
+	const uint64_t* incPerm; // nullable
+	uint32_t hotFinalLo;
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;
@@ -214,6 +220,7 @@ bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
+int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream);
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);

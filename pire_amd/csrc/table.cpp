@@ -102,6 +102,12 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
+	// inside the hot set the order is free: non-final states first, so that "hot and Final" is one compare
+	// (HalfFinalScanner's per-step TakeAction, kernels.hip HalfFinalKernel)
+	std::stable_partition(order.begin(), order.begin() + t.hot, [&](uint32_t s) { return !(t.flags[s] & kFinal); });
+	t.hotFinalLo = 0;
+	while (t.hotFinalLo < t.hot && !(t.flags[order[t.hotFinalLo]] & kFinal))
+		++t.hotFinalLo;
 	t.byteRot = getenv("PIRE_HIP_BYTE_ROT") ? 1 : 0;   // knob: A/B measurements
 	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
@@ -129,6 +135,18 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 void ChooseHotAndPermute(HostTable& t)
 {
 	const uint32_t N = t.states, C = t.letters;
+	// packed per-regexp increments of HalfFinalScanner::TakeAction (half_final.h:156-164): the final list of a
+	// state may name a regexp several times (BuildFinals, half_final.h:202-213)
+	t.inc64.assign(N, 0);
+	t.incPacked = t.regexps <= 8;
+	for (uint32_t s = 0; s < N && t.incPacked; ++s) {
+		uint32_t mult[8] = {0};
+		for (uint64_t k = t.acceptOff[s]; k < t.acceptOff[s + 1]; ++k)
+			if (t.acceptIds[k] >= 8 || ++mult[t.acceptIds[k]] > 255)
+				t.incPacked = false;
+		for (uint32_t r = 0; r < 8; ++r)
+			t.inc64[s] |= uint64_t(mult[r]) << (8 * r);
+	}
 	// every string starts at Initialize() and (normally) takes BeginMark first; rank from both
 	std::vector<double> mass = VisitMass(t, t.initial);
 	{
@@ -427,7 +445,7 @@ void FreeDeviceTable(DeviceTable* d)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
-	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows};
+	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -465,6 +483,30 @@ int UploadTable(pire_hip_table* t)
 		FreeDeviceTable(&d);
 		return rc;
 	}
+	{
+		// CSR final lists in device numbering (always: HalfFinalScanner needs the multiplicities)
+		std::vector<uint64_t> off(size_t(N) + 1, 0), ids;
+		for (uint32_t pid = 0; pid < N; ++pid) {
+			const uint32_t o = h.origOfPerm[pid];
+			off[pid] = ids.size();
+			ids.insert(ids.end(), h.acceptIds.begin() + h.acceptOff[o], h.acceptIds.begin() + h.acceptOff[o + 1]);
+		}
+		off[N] = ids.size();
+		ids.push_back(0);   // never empty
+		if (!(rc = Put(&d.acceptOffPerm, off, &d.bytes)))
+			rc = Put(&d.acceptIds, ids, &d.bytes);
+		if (!rc && h.incPacked) {
+			std::vector<uint64_t> inc(N);
+			for (uint32_t pid = 0; pid < N; ++pid)
+				inc[pid] = h.inc64[h.origOfPerm[pid]];
+			rc = Put(&d.incPerm, inc, &d.bytes);
+		}
+		if (rc) {
+			d.device = dev;
+			FreeDeviceTable(&d);
+			return rc;
+		}
+	}
 	if (h.regexps <= 64) {
 		std::vector<uint64_t> mask(N, 0);
 		for (uint32_t pid = 0; pid < N; ++pid) {
@@ -474,16 +516,6 @@ int UploadTable(pire_hip_table* t)
 					mask[pid] |= uint64_t(1) << h.acceptIds[k];
 		}
 		rc = Put(&d.acceptMaskPerm, mask, &d.bytes);
-	} else {
-		std::vector<uint64_t> off(size_t(N) + 1, 0), ids;
-		for (uint32_t pid = 0; pid < N; ++pid) {
-			const uint32_t o = h.origOfPerm[pid];
-			off[pid] = ids.size();
-			ids.insert(ids.end(), h.acceptIds.begin() + h.acceptOff[o], h.acceptIds.begin() + h.acceptOff[o + 1]);
-		}
-		off[N] = ids.size();
-		if (!(rc = Put(&d.acceptOffPerm, off, &d.bytes)))
-			rc = Put(&d.acceptIds, ids, &d.bytes);
 	}
 	if (!rc) {
 		// end-of-string records (one 16-byte load per string instead of a chain of dependent lookups)

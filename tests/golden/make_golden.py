@@ -298,9 +298,53 @@ def main():
                    "be": {"idx": [int(x) for x in bi], "final": [int(x) for x in bf]},
                    "none": {"idx": [int(x) for x in ni], "final": [int(x) for x in nf]}})
 
+    # HalfFinalScanner (scanners/half_final.h): the reference's own vectors, tests/count_ut.cpp:541-550 and 575.
+    # Five counter flavours per regexp (count_ut.cpp:503-519) plus all five glued (520-523).
+    from oracle.binding import RefHalfFinalScanner
+    HALF = [
+        ("ab+", b"abbabbbabbbbbb", [3, 3, 3, 11, 3]),
+        ("(ab)+", b"ababbababbab", [3, 3, 5, 5, 5]),
+        ("(abab)+", b"ababababab", [1, 1, 4, 4, 2]),
+        ("ab+c|b", b"abbbbbbbbbb", [1, 10, 10, 10, 10]),
+        ("ab+c|b", b"abbbbbbbbbbb", [1, 10, 11, 11, 11]),
+        ("ab+c|b", b"abbbbbbbbbbc", [1, 1, 10, 11, 10]),
+        ("ab+c|b", b"abbbbbbbbbbbc", [1, 1, 11, 12, 11]),
+        ("a\\w+c|b", b"abbbdbbbdbbc", [1, 1, 8, 9, 8]),
+        ("a\\w+c|b", b"abbbdbbbdbb", [1, 8, 8, 8, 8]),
+        ("a[a-z]+c|b", b"abeeeebeeeeeeeeeceeaeebeeeaeecceebeeaeebeeb", [2, 4, 7, 9, 7]),
+        ("(\\w\\w)+", b"ab abbb ababa a", [3, 3, 8, 8, 5]),
+    ]
+    half = []
+    seen = {}
+    rng = np.random.RandomState(79)
+    for pat, text, expect in HALF:
+        if pat not in seen:
+            glued = RefHalfFinalScanner.compile([pat] * 5, list(range(5)))
+            name = "half_%d" % len(seen)
+            blob = glued.save()
+            extra = [bytes(rng.choice(np.frombuffer(b"abcde w", dtype=np.uint8), size=int(k))) for k in rng.randint(0, 60, size=25)]
+            seen[pat] = {"name": name, "source": "tests/count_ut.cpp:503-550, 575", "pattern": pat, "states": glued.size,
+                         "regexps": glued.regexps, "blob": write_blob(name, blob),
+                         "blob_sha256": hashlib.sha256(blob).hexdigest(), "vectors": [], "_sc": glued, "_extra": extra}
+            half.append(seen[pat])
+        entry = seen[pat]
+        idx, fin, res = entry["_sc"].run_strings([text])
+        assert res[0].tolist() == expect, (pat, text, res[0].tolist(), expect)
+        for m in range(5):     # the single (unglued) scanners state the same numbers, count_ut.cpp:530-532
+            one = RefHalfFinalScanner.compile([pat], [m])
+            assert int(one.run_strings([text])[2][0, 0]) == expect[m]
+        entry["vectors"].append({"text_hex": text.hex(), "expect": expect})
+    for entry in half:
+        sc, extra = entry.pop("_sc"), entry.pop("_extra")
+        strings = [bytes.fromhex(v["text_hex"]) for v in entry["vectors"]] + extra
+        for key, flags in (("be", 3), ("none", 0)):
+            idx, fin, res = sc.run_strings(strings, flags=flags)
+            entry[key] = {"idx": [int(x) for x in idx], "final": [int(x) for x in fin], "results": res.tolist()}
+        entry["strings_hex"] = [x.hex() for x in strings]
+
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "slow": slow, "simple": simple, "corpus": corpus}, f, indent=1)
+                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "corpus": corpus}, f, indent=1)
     print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners,", len(simple), "simple scanners")
 
 
