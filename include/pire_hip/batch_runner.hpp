@@ -239,6 +239,82 @@ std::vector<const char*> BatchShortestPrefix(const Table<Scanner>& t, const char
 }
 
 /*
+ * Batched Runner over a Pire::HalfFinalScanner (scanners/half_final.h): per string the per-regexp match counts
+ * State::Result(r) (half_final.h:90-92) that Initialize + Begin() + Run() + End() accumulate through TakeAction
+ * (half_final.h:137-164), plus Final and StateIndex of the end state.  The scanner's State is an opaque class with
+ * private members, so the results come back as plain numbers.
+ */
+template <class HalfScanner = Pire::HalfFinalScanner>
+class HalfFinalBatchRunner {
+public:
+	explicit HalfFinalBatchRunner(const HalfScanner& sc)
+	    : m_table(nullptr), m_regexps(sc.RegexpsCount()), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false)
+	{
+		std::ostringstream out;
+		sc.Save(&out);                                    // Scanner::Save, multi.h:557-573 (inherited)
+		const std::string blob = out.str();
+		Check(pire_hip_table_create(blob.data(), blob.size(), &m_table));
+	}
+	~HalfFinalBatchRunner() { pire_hip_table_destroy(m_table); }
+
+	HalfFinalBatchRunner& Begin() { m_flags |= PIRE_HIP_RUN_BEGIN; return *this; }
+	HalfFinalBatchRunner& End() { m_flags |= PIRE_HIP_RUN_END; return *this; }
+	HalfFinalBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_text = text;
+		m_offsets = offsets;
+		m_n = n;
+		m_ran = false;
+		return *this;
+	}
+	HalfFinalBatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_ownText.clear();
+		m_ownOffsets.assign(1, 0);
+		for (size_t i = 0; i < strings.size(); ++i) {
+			m_ownText.append(strings[i]);
+			m_ownOffsets.push_back(m_ownText.size());
+		}
+		return Run(m_ownText.data(), m_ownOffsets.data(), strings.size());
+	}
+
+	/* State::Result(r) of string i. */
+	size_t Result(size_t i, size_t r) { Execute(); return m_results[i * m_regexps + r]; }
+	const std::vector<uint32_t>& Results() { Execute(); return m_results; }       // [n][RegexpsCount()]
+	const std::vector<char>& Finals() { Execute(); return m_final; }              // Final(State()) per string
+	const std::vector<uint32_t>& StateIndices() { Execute(); return m_idx; }      // StateIndex(State()) per string
+
+private:
+	void Execute()
+	{
+		if (m_ran)
+			return;
+		m_idx.assign(m_n, 0);
+		std::vector<uint8_t> fin(m_n);
+		m_results.assign(m_n * (m_regexps ? m_regexps : 1), 0);
+		static const uint64_t kNoOffsets[1] = {0};
+		Check(pire_hip_run_half_final(m_table, m_text, m_n ? m_offsets : kNoOffsets, m_n, m_flags, m_idx.data(), fin.data(),
+		                              m_results.data(), nullptr));
+		m_final.assign(fin.begin(), fin.end());
+		m_ran = true;
+	}
+
+	HalfFinalBatchRunner(const HalfFinalBatchRunner&);
+	HalfFinalBatchRunner& operator=(const HalfFinalBatchRunner&);
+	pire_hip_table* m_table;
+	size_t m_regexps;
+	uint32_t m_flags;
+	const char* m_text;
+	const uint64_t* m_offsets;
+	size_t m_n;
+	bool m_ran;
+	std::vector<uint32_t> m_idx, m_results;
+	std::vector<char> m_final;
+	ystring m_ownText;
+	std::vector<uint64_t> m_ownOffsets;
+};
+
+/*
  * Batched Runner over a Pire::SlowScanner (scanners/slow.h): Matches(sc, str) per string, i.e.
  * Final(Runner(sc).Begin().Run(str).End().State()).
  */

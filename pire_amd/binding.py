@@ -182,8 +182,11 @@ class Table:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            lib().pire_hip_table_destroy(h)
+        if h and _lib is not None:      # at interpreter shutdown the module globals may already be gone
+            try:
+                _lib.pire_hip_table_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     # --- Scanner getters (multi.h:134-161)
@@ -329,8 +332,11 @@ class SlowTable:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
-            lib().pire_hip_slow_table_destroy(h)
+        if h and _lib is not None:
+            try:
+                _lib.pire_hip_slow_table_destroy(h)
+            except Exception:
+                pass
             self._h = None
 
     Size = property(lambda s: s.info.states)

@@ -174,10 +174,62 @@ static void TestSimpleScanner()
 	CompareAll(empty, strings);
 }
 
+// Pire::HalfFinalScanner: State::Result(r) per string, built as tests/count_ut.cpp:503-527 builds its scanners.
+static void TestHalfFinal()
+{
+	const char* regexps[] = {"ab+", "(ab)+", "ab+c|b", "a[a-z]+c|b"};
+	std::vector<Pire::ystring> strings;
+	const char* fixed[] = {"abbabbbabbbbbb", "ababbababbab", "abbbbbbbbbbc", "abeeeebeeeeeeeeeceeaeebeeeaeecceebeeaeebeeb", "", "b"};
+	for (size_t i = 0; i < sizeof(fixed) / sizeof(fixed[0]); ++i)
+		strings.push_back(fixed[i]);
+	unsigned seed = 777;
+	for (int i = 0; i < 500; ++i) {
+		Pire::ystring s;
+		seed = seed * 1103515245u + 12345u;
+		const size_t len = (seed >> 16) % 70;
+		for (size_t k = 0; k < len; ++k) {
+			seed = seed * 1103515245u + 12345u;
+			s.push_back("abcde "[(seed >> 16) % 6]);
+		}
+		strings.push_back(s);
+	}
+	for (size_t p = 0; p < sizeof(regexps) / sizeof(regexps[0]); ++p) {
+		const Pire::Fsm re = Parse(regexps[p], false);
+		Pire::HalfFinalScanner glued;
+		for (int mode = 0; mode < 5; ++mode) {
+			Pire::HalfFinalFsm fsm(re);
+			switch (mode) {
+			case 0: fsm.MakeGreedyCounter(true); break;
+			case 1: fsm.MakeGreedyCounter(false); break;
+			case 2: fsm.MakeNonGreedyCounter(true, true); break;
+			case 3: fsm.MakeNonGreedyCounter(true, false); break;
+			default: fsm.MakeNonGreedyCounter(false); break;
+			}
+			Pire::HalfFinalScanner one(fsm);
+			glued = mode == 0 ? one : Pire::HalfFinalScanner::Glue(glued, one);
+		}
+		CHECK(glued.RegexpsCount() == 5);
+		Pire::Hip::HalfFinalBatchRunner<> gpu(glued);
+		gpu.Begin().Run(strings).End();
+		for (size_t i = 0; i < strings.size(); ++i) {
+			Pire::HalfFinalScanner::State st;
+			glued.Initialize(st);
+			Pire::Step(glued, st, Pire::BeginMark);
+			Pire::Run(glued, st, strings[i].data(), strings[i].data() + strings[i].size());
+			Pire::Step(glued, st, Pire::EndMark);
+			for (size_t r = 0; r < 5; ++r)
+				CHECK(gpu.Result(i, r) == st.Result(r));
+			CHECK((gpu.Finals()[i] != 0) == glued.Final(st));
+			CHECK(gpu.StateIndices()[i] == glued.StateIndex(st));
+		}
+	}
+}
+
 int main()
 {
 	try {
 		TestPrefixAndSlow();
+		TestHalfFinal();
 		TestSimpleScanner();
 		TestSuite<Pire::Scanner>();
 		TestSuite<Pire::NonrelocScanner>();
