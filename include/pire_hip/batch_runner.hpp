@@ -239,6 +239,61 @@ std::vector<const char*> BatchShortestPrefix(const Table<Scanner>& t, const char
 }
 
 /*
+ * Batched twin of Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94): both scanners over the same strings,
+ * State = pair of the two states (pair.h:35), Final = either (pair.h:69-72).  The two walks are independent
+ * (pair.h:52-66), so this is two device passes over the resident text, one per table.
+ */
+template <class Scanner1, class Scanner2>
+class PairBatchRunner {
+public:
+	typedef ypair<typename Scanner1::State, typename Scanner2::State> State;
+
+	PairBatchRunner(const Scanner1& s1, const Scanner2& s2) : m_first(s1), m_second(s2) {}
+
+	PairBatchRunner& Begin() { m_first.Begin(); m_second.Begin(); return *this; }
+	PairBatchRunner& End() { m_first.End(); m_second.End(); return *this; }
+	PairBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_first.Run(text, offsets, n);
+		m_second.Run(text, offsets, n);
+		return *this;
+	}
+	PairBatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_first.Run(strings);
+		m_second.Run(strings);
+		return *this;
+	}
+
+	/* RunHelper<ScannerPair>::State() per string. */
+	std::vector<State> States()
+	{
+		const std::vector<typename Scanner1::State>& a = m_first.States();
+		const std::vector<typename Scanner2::State>& b = m_second.States();
+		std::vector<State> out(a.size());
+		for (size_t i = 0; i < a.size(); ++i)
+			out[i] = ymake_pair(a[i], b[i]);
+		return out;
+	}
+	/* ScannerPair::Final per string (pair.h:69-72). */
+	std::vector<char> Finals()
+	{
+		const std::vector<char>& a = m_first.Finals();
+		const std::vector<char>& b = m_second.Finals();
+		std::vector<char> out(a.size());
+		for (size_t i = 0; i < a.size(); ++i)
+			out[i] = char(a[i] || b[i]);
+		return out;
+	}
+	BatchRunner<Scanner1>& First() { return m_first; }
+	BatchRunner<Scanner2>& Second() { return m_second; }
+
+private:
+	BatchRunner<Scanner1> m_first;
+	BatchRunner<Scanner2> m_second;
+};
+
+/*
  * Batched Runner over a Pire::HalfFinalScanner (scanners/half_final.h): per string the per-regexp match counts
  * State::Result(r) (half_final.h:90-92) that Initialize + Begin() + Run() + End() accumulate through TakeAction
  * (half_final.h:137-164), plus Final and StateIndex of the end state.  The scanner's State is an opaque class with

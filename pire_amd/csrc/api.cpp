@@ -92,7 +92,6 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->visitCold = d.visitCold;
 	p->compactRows = d.compactRows;
 	p->compact = h.compact;
-	p->byteRot = h.byteRot;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
 	p->states = h.states;

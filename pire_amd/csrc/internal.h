@@ -109,7 +109,6 @@ struct HostTable {
 	uint32_t hotFinalLo = 0;          // hot perm ids >= this are Final (the hot set is ordered non-final first)
 	bool incPacked = false;           // regexps <= 8 and every final-list multiplicity <= 255: inc64 is usable
 	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
-	uint32_t byteRot = 0;             // experiment: dense rows indexed by rotl8(byte, 2) (PIRE_HIP_BYTE_ROT=1)
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
@@ -182,7 +181,6 @@ struct ScanParams {
 	uint32_t* visitCold;
 	const uint16_t* compactRows;
 	uint32_t compact;        // 0 = tier off
-	uint32_t byteRot;
 	const uint64_t* incPerm; // nullable
 	uint32_t hotFinalLo;
 	uint32_t states, letters, regexps, hot;

@@ -69,21 +69,11 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 }
 
 // The exact step for any state: multi.h:169-192 on the perm-numbered table.
-// rotl8(b, 2) on four packed bytes / on one byte
-__device__ __forceinline__ uint32_t RotBytes(uint32_t x)
-{
-	return ((x << 2) & 0xFCFCFCFCu) | ((x >> 6) & 0x03030303u);   // v_lshlrev, v_lshrrev, v_bfi
-}
-__device__ __forceinline__ uint32_t DenseColumn(const ScanParams& p, uint32_t byte)
-{
-	return p.byteRot ? ((byte << 2) | (byte >> 6)) & 0xFFu : byte;
-}
-
 __device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
                                              uint32_t st, uint32_t byte)
 {
 	if (st < p.hot) {
-		const uint32_t e = lds[st * L.pitch + DenseColumn(p, byte)];
+		const uint32_t e = lds[st * L.pitch + byte];
 		if (e != p.hot)
 			return e;
 	}
@@ -445,13 +435,10 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 			hs = HotLookup(__umul24(hs, kRotPitch) + b2);
 			hs = HotLookup(__umul24(hs, kRotPitch) + b3);
 		} else {
-			// ROT == 2: the dense rows are indexed by rotl8(byte, 2), so the LDS bank is byte & 63 instead of byte >> 2
-			// (printable text then spreads over all 64 banks instead of 24); 3 VALU per 4 bytes
-			const uint32_t y = ROT == 2 ? RotBytes(x) : x;
-			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0400u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0401u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0402u));
-			hs = HotLookup(__builtin_amdgcn_perm(hs, y, 0x0c0c0403u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
 		}
 	}
 	if (hs == p.hot && !(p.flags & kDebugNoTrap)) {
@@ -1322,7 +1309,7 @@ int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 {
 	// one string per lane with dynamic re-assignment: worth it from a few waves' worth of strings
-	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096 && !p.byteRot;
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096;
 }
 
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
@@ -1390,7 +1377,7 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoColdCount;
 	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
 		q.flags |= kDebugNoHist;
-	if (variant == 1 || variant == 4)
+	if (variant == 1)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
@@ -1398,12 +1385,8 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(q));
 	switch (variant) {
 	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 1>, q, 1024, L.total, stream); break;   // bank-rotated rows
-	case 4:  rc = LaunchScan(ScanTiledKernel<10, 2, true, 5, 0>, q, 640, L256.total, stream); break;   // 2 blocks x 10 waves per CU
 	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream); break; // no nt
-	default:
-		rc = q.byteRot ? LaunchScan(ScanTiledKernel<16, 2, true, 5, 2>, q, 1024, L256.total, stream)
-		               : LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
-		break;
+	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream); break;
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

@@ -108,7 +108,6 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	t.hotFinalLo = 0;
 	while (t.hotFinalLo < t.hot && !(t.flags[order[t.hotFinalLo]] & kFinal))
 		++t.hotFinalLo;
-	t.byteRot = getenv("PIRE_HIP_BYTE_ROT") ? 1 : 0;   // knob: A/B measurements
 	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
 	t.permOfOrig.assign(N, 0);
@@ -123,8 +122,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 		uint8_t* out = &t.hotRows[size_t(pid) * 256];
 		for (uint32_t b = 0; b < 256; ++b) {
 			const uint32_t d = t.permOfOrig[row[t.cls[b]]];
-			const uint32_t col = t.byteRot ? ((b << 2) | (b >> 6)) & 0xFFu : b;
-			out[col] = d < H ? uint8_t(d) : uint8_t(H);
+			out[b] = d < H ? uint8_t(d) : uint8_t(H);
 		}
 	}
 	t.hotFlags.assign(256, 0);

@@ -225,10 +225,36 @@ static void TestHalfFinal()
 	}
 }
 
+// Pire::ScannerPair (scanners/pair.h): the pair of states and Final = either.
+static void TestScannerPair()
+{
+	Pire::Scanner s1 = Parse("hello\\s+w.+d$").Compile<Pire::Scanner>();
+	Pire::SimpleScanner s2 = Parse("abc|def").Compile<Pire::SimpleScanner>();
+	typedef Pire::ScannerPair<Pire::Scanner, Pire::SimpleScanner> Pair;
+	Pair pair(s1, s2);
+	std::vector<Pire::ystring> strings;
+	const char* fixed[] = {"hello world", "abc", "say hello   wod def", "", "nothing", "xxdef", "hello wd"};
+	for (size_t i = 0; i < sizeof(fixed) / sizeof(fixed[0]); ++i)
+		strings.push_back(fixed[i]);
+	Pire::Hip::PairBatchRunner<Pire::Scanner, Pire::SimpleScanner> gpu(s1, s2);
+	gpu.Begin().Run(strings).End();
+	const std::vector<Pair::State> st = gpu.States();
+	const std::vector<char> fin = gpu.Finals();
+	CHECK(st.size() == strings.size());
+	for (size_t i = 0; i < strings.size(); ++i) {
+		Pair::State want = Pire::Runner(pair).Begin().Run(strings[i]).End().State();
+		CHECK(st[i].first == want.first && st[i].second == want.second);
+		CHECK((fin[i] != 0) == pair.Final(want));
+		CHECK(pair.StateIndex(st[i]) == pair.StateIndex(want));
+	}
+	CHECK(fin[0] && fin[1] && fin[2] && !fin[3] && !fin[4] && fin[5] && !fin[6]);
+}
+
 int main()
 {
 	try {
 		TestPrefixAndSlow();
+		TestScannerPair();
 		TestHalfFinal();
 		TestSimpleScanner();
 		TestSuite<Pire::Scanner>();
