@@ -601,15 +601,16 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 //     per launch, not one per wave: same-address device atomics run at well under 100 per microsecond); waves take
 //     64 strings at a time from their block's range in LDS; lanes take single strings from their wave's range by
 //     ballot + mbcnt.
-//   * every lane walks its string in 128-byte windows that start at 16-byte boundaries (8 x global_load_dwordx4 from
-//     its own address).  The window of the NEXT iteration -- the same string's next 128 bytes, or the first window of
+//   * every lane walks its string in windows of up to 128 bytes (8 x global_load_dwordx4 from its own address).  A
+//     window starts at the string's current byte whatever its alignment, so a string of <= 128 bytes is ONE window; a
+//     longer string cuts its first window at a 16-byte boundary and is aligned from then on.  The window of the NEXT iteration -- the same string's next 128 bytes, or the first window of
 //     the lane's pending next string, whose offsets were fetched an iteration earlier -- is in flight while the
 //     current one is walked; nothing on the common path makes the compiler wait for memory during the walk (the
 //     end-of-string records of the hot states are in LDS for that reason).
-//   * a window is walked as: the <=15 bytes up to the first 16-byte boundary (only in the first window of a string),
-//     whole 16-byte chunks with the LDS fast path of the tiled kernel, the <=15 bytes after the last whole chunk
-//     (only in the last window).  The two partial passes are rolled loops over exact steps.
-//   * nothing is read outside the 16-byte blocks that hold the text: a window that would reach past the last block
+//   * a window is walked as whole 16-byte chunks with the LDS fast path of the tiled kernel, then ONE pass for the
+//     <= 15 bytes behind the last whole chunk of every lane that has some: each lane picks its chunk, walks all 16
+//     bytes unrolled and keeps the state after its last real byte (no loop, no branches).
+//   * nothing is read past the 16-byte block that holds the last byte of the text: a window that would reach further
 //     is walked byte by byte from memory instead.
 
 struct RaggedWork {
@@ -640,29 +641,6 @@ __device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
 	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
 }
 
-// v >> (8 * bytes), bytes in 0..15
-__device__ __forceinline__ u32x4 ShiftBytes(u32x4 v, uint32_t bytes)
-{
-	if (bytes & 8) {
-		v.x = v.z;
-		v.y = v.w;
-		v.z = 0;
-		v.w = 0;
-	}
-	if (bytes & 4) {
-		v.x = v.y;
-		v.y = v.z;
-		v.z = v.w;
-		v.w = 0;
-	}
-	const uint32_t sh = (bytes & 3) * 8;
-	v.x = __builtin_amdgcn_alignbit(v.y, v.x, sh);
-	v.y = __builtin_amdgcn_alignbit(v.z, v.y, sh);
-	v.z = __builtin_amdgcn_alignbit(v.w, v.z, sh);
-	v.w >>= sh;
-	return v;
-}
-
 // Exact walk of the first `count` (0..15) bytes of v; lanes with a smaller count idle (one rolled loop per wave).
 __device__ __forceinline__ uint32_t SlowPartial(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
                                                 uint32_t st, uint32_t count)
@@ -679,24 +657,30 @@ __device__ __forceinline__ uint32_t SlowPartial(const ScanParams& p, const uint8
 	return st;
 }
 
-// The first `count` (0..15) bytes of v through the LDS fast path, exact re-walk on a trap like StepChunk.  Keeps the
-// common path free of global loads: a global load in this loop would make the compiler wait for ALL outstanding
-// loads, the prefetched next window included, in every iteration.
+// The first `count` (0..15) bytes of v through the LDS fast path: the whole chunk is walked, unrolled like StepChunk,
+// and the state after byte `count` is kept (v_cmp + v_cndmask per byte, no loop, no branches); lanes with count == 0
+// keep their state.  What the walk reads past `count` is ignored.  Exact re-walk on a trap like StepChunk.
 __device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
                                             uint32_t count, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
 {
 	const uint32_t hs0 = hs;
-	u32x4 w = v;
-#pragma unroll 1
-	for (uint32_t i = 0; __any(i < count); ++i) {
-		const uint32_t nh = HotLookup(__builtin_amdgcn_perm(hs, w.x, 0x0c0c0400u));
-		hs = i < count ? nh : hs;
-		w.x = __builtin_amdgcn_alignbit(w.y, w.x, 8);
-		w.y = __builtin_amdgcn_alignbit(w.z, w.y, 8);
-		w.z = __builtin_amdgcn_alignbit(w.w, w.z, 8);
-		w.w >>= 8;
+	uint32_t h = hs, snap = hs;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
+		snap = count == uint32_t(4 * w + 1) ? h : snap;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
+		snap = count == uint32_t(4 * w + 2) ? h : snap;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
+		snap = count == uint32_t(4 * w + 3) ? h : snap;
+		if (w < 3) {
+			h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
+			snap = count == uint32_t(4 * w + 4) ? h : snap;
+		}
 	}
-	if (count != 0 && hs == p.hot) {
+	hs = snap;
+	if (count != 0 && hs == p.hot && !(p.flags & kDebugNoTrap)) {
 		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
 		uint32_t f = p.compact;
 		if (st0 < p.compact)
@@ -847,25 +831,24 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 {
 	WaitAllLoads(cur);
 
-	// ---- this window
-	const uint32_t skip = uint32_t(S.pos) & 15u;
+	// ---- this window: starts at the string's current byte, whatever its alignment.  A string that fits takes one
+	// window; a longer one cuts its first window at a 16-byte boundary so that all the following ones are aligned.
 	const uint64_t left = S.end - S.pos;
-	const uint32_t nb = !S.busy ? 0u : left < uint64_t(128u - skip) ? uint32_t(left) : 128u - skip;
-	const bool ends = S.busy && S.pos + nb == S.end;
+	const uint32_t nb = !S.busy ? 0u : left <= 128u ? uint32_t(left) : 128u - (uint32_t(S.pos) & 15u);
+	const bool ends = S.busy && nb == left;
 
-	// ---- the next window: the same string's next 128 bytes, or the pending string's first window
+	// ---- the next window: the same string's next bytes, or the pending string's first window
 	const bool cont = S.busy && !ends;
 	const bool takeNew = !cont && S.pend;
 	const uint64_t nPos = cont ? S.pos + nb : S.pendPos;
 	const uint64_t nEnd = cont ? S.end : S.pendEnd;
 	const uint32_t nIdx = cont ? S.sIdx : S.sIdxN;
 	const bool nBusy = cont || takeNew;
-	const uint64_t nBase = nPos & ~uint64_t(15);
-	const bool nLoad = nBusy && nEnd > nPos && nBase + 128 <= safeEnd;
+	const bool nLoad = nBusy && nEnd > nPos && nPos + 128 <= safeEnd;
 	// unconditional (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
 	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives
 	if (!(p.flags & kDebugNoRefill))
-		IssueTileLane(nxt, nLoad ? nBase : reinterpret_cast<uint64_t>(p.hotRows));
+		IssueTileLane(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows));
 	if (takeNew)
 		S.pend = false;
 	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
@@ -886,21 +869,17 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	} else if (__any(nb != 0)) {
 		if (__any(nb != 0 && S.loaded)) {
 			const uint32_t nbl = S.loaded ? nb : 0u;
-			const uint32_t head = skip ? (nbl < 16u - skip ? nbl : 16u - skip) : 0u;
-			const uint32_t rest = nbl - head;
-			const uint32_t kStart = skip ? 1u : 0u, full = rest >> 4, tail = rest & 15u;
-			if (__any(head != 0) && !(p.flags & kDebugNoPartial))
-				StepPartial(p, lds, L, ShiftBytes(cur[0], skip), head, S.hs, S.cold, iter & 63);
+			const uint32_t full = nbl >> 4, tail = nbl & 15u;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				if (uint32_t(k) >= kStart && uint32_t(k) < kStart + full)
+				if (uint32_t(k) < full)
 					StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
-				const uint32_t kt = kStart + full;
+				// all the partial last chunks of the wave in ONE pass: pick each lane's chunk, walk it with a snapshot
 				u32x4 v = cur[0];
 #pragma unroll
 				for (int k = 1; k < 8; ++k)
-					if (kt == uint32_t(k))
+					if (full == uint32_t(k))
 						v = cur[k];
 				StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
 			}
