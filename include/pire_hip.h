@@ -102,6 +102,17 @@ int pire_hip_table_mmap(const void* image, size_t size, pire_hip_table** out, si
  * (compile once with Scanner::Save, mmap everywhere). */
 int pire_hip_table_create_from_file(const char* path, pire_hip_table** out);
 
+/*
+ * Scanner::Glue(lhs, rhs, maxSize) (multi.h:1092-1103) on two ingested Pire::Scanner tables, host side, without the
+ * reference library: the product automaton with the reference's own letter classes (glue.h:35-46, 123-127), the
+ * reference's own breadth-first state numbering (determine.h:91-137) -- so StateIndex values are identical to those
+ * of the scanner the reference would glue -- and its flags / AcceptedRegexps lists (rhs ids shifted by
+ * lhs.RegexpsCount(), multi.h:1024-1043).  max_size 0 = the reference's default 80 000.  As in the reference an
+ * empty lhs (rhs) returns a copy of rhs (lhs), and exceeding max_size yields an EMPTY scanner (info.empty = 1), not
+ * an error.  The result is a table like any other: run it, adapt it, glue it further.
+ */
+int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out);
+
 /* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
 int pire_hip_table_upload(pire_hip_table* t);
 

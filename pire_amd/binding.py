@@ -76,6 +76,7 @@ ABI = [
     ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_mmap", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("pire_hip_table_create_from_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    ("pire_hip_table_glue", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_upload", C.c_int, [C.c_void_p]),
     ("pire_hip_table_adapt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("pire_hip_table_destroy", None, [C.c_void_p]),
@@ -160,9 +161,16 @@ class Table:
             blob = bytes(blob)
             _check(L.pire_hip_table_create(blob, len(blob), C.byref(h)))
         self._h = h
-        info = TableInfo()
-        _check(L.pire_hip_table_get_info(h, C.byref(info)))
-        self.info = info
+        self._info = None
+
+    @property
+    def info(self):
+        """pire_hip_table_info (fetched on first use: for a glued table it triggers the dense-row ranking)."""
+        if self._info is None:
+            info = TableInfo()
+            _check(lib().pire_hip_table_get_info(self._h, C.byref(info)))
+            self._info = info
+        return self._info
 
     @classmethod
     def from_file(cls, path: str):
@@ -179,6 +187,13 @@ class Table:
         image = bytes(image)
         _check(lib().pire_hip_table_mmap(image, len(image), C.byref(h), C.byref(used)))
         return cls(_handle=h), used.value
+
+    @classmethod
+    def glue(cls, lhs: "Table", rhs: "Table", max_size: int = 0):
+        """Scanner::Glue(lhs, rhs, maxSize) on two ingested tables (host side, reference numbering)."""
+        h = C.c_void_p()
+        _check(lib().pire_hip_table_glue(lhs._h, rhs._h, max_size, C.byref(h)))
+        return cls(_handle=h)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -197,7 +212,7 @@ class Table:
     initial = property(lambda s: s.info.initial)
 
     def refresh_info(self):
-        _check(lib().pire_hip_table_get_info(self._h, C.byref(self.info)))
+        self._info = None
         return self.info
 
     def Final(self, idx: int) -> bool:

@@ -322,6 +322,24 @@ int pire_hip_table_create_from_file(const char* path, pire_hip_table** out)
 	return rc;
 }
 
+int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
+{
+	if (!lhs || !rhs || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	std::unique_ptr<pire_hip_table> t(new (std::nothrow) pire_hip_table);
+	if (!t) {
+		SetError("out of memory");
+		return PIRE_HIP_ENOMEM;
+	}
+	if (int rc = GlueHostTables(lhs->host, rhs->host, max_size, &t->host))
+		return rc;
+	*out = t.release();
+	return PIRE_HIP_OK;
+}
+
 int pire_hip_table_upload(pire_hip_table* t)
 {
 	if (!t) {
@@ -354,6 +372,7 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
 	}
+	EnsureRanked(const_cast<pire_hip_table*>(t));   // hot_states / lds_table_bytes describe the ranked device layout
 	const HostTable& h = t->host;
 	memset(out, 0, sizeof(*out));
 	out->abi_version = PIRE_HIP_ABI_VERSION;
@@ -444,6 +463,7 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
 	}
+	EnsureRanked(const_cast<pire_hip_table*>(t));
 	const HostTable& h = t->host;
 	if (orig_of_perm)
 		memcpy(orig_of_perm, h.origOfPerm.data(), h.origOfPerm.size() * sizeof(uint32_t));

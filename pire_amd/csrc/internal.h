@@ -92,6 +92,7 @@ struct HostTable {
 	// geometry (mirrors Scanner::Locals, multi.h:315-323)
 	uint32_t states = 0, letters = 0, regexps = 0, initial = 0;
 	bool empty = false;
+	bool ranked = true;               // false: hot / permutation / dense rows not computed yet (EnsureRanked)
 	uint32_t scannerType = 1;         // ScannerIOTypes (common.h:34-40): 1 Scanner, 2 SimpleScanner
 	uint32_t headerSize = 0, rowStride = 0;
 	uint64_t refBufSize = 0;
@@ -208,6 +209,8 @@ int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_H
 // table.cpp
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t);
+void EnsureRanked(pire_hip_table* t);
+int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out);
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
 void FreeDeviceTable(DeviceTable* d);
 

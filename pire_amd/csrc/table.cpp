@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <map>
+#include <unordered_map>
 #include <cstdlib>
 #include <cmath>
 #include <iterator>
@@ -364,8 +365,8 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 	for (uint32_t c = 0; c < kMaxChar; ++c) {
 		uint16_t v;
 		memcpy(&v, letters + size_t(c) * 2, 2);
-		if (c == kEpsilon || c >= kMaxCharUnaligned) {
-			t.cls[c] = 0;   // never fed to Next(); the reference leaves these slots unset (multi.h:420)
+		if (c == kEpsilon) {
+			t.cls[c] = 0;   // never fed to Next(); the reference leaves this slot zero (Init, multi.h:364-365, 374-376)
 			continue;
 		}
 		if (v < t.headerSize || v >= t.headerSize + t.letters)
@@ -452,6 +453,7 @@ void FreeDeviceTable(DeviceTable* d)
 
 int UploadTable(pire_hip_table* t)
 {
+	EnsureRanked(t);
 	std::lock_guard<std::mutex> lock(t->uploadMutex);
 	int dev = -1;
 	hipError_t e = hipGetDevice(&dev);
@@ -570,6 +572,142 @@ int UploadTable(pire_hip_table* t)
 }
 
 // Re-rank the dense LDS rows from what the kernels actually visited (see pire_hip_table_adapt in pire_hip.h).
+// Scanner::Glue (multi.h:1092-1103) on two ingested tables: the product automaton, numbered exactly as the reference
+// numbers it -- ScannerGlueCommon/LettersEquality (glue.h:35-159) for the letter classes, Impl::Determine
+// (determine.h:91-137) for the breadth-first state numbering, ScannerGlueTask::AcceptStates (multi.h:1024-1043) for
+// flags and final lists.  `out` is an empty scanner when more than maxSize new states are needed (Failure()).
+int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out)
+{
+	if (a.scannerType != 1 || b.scannerType != 1)
+		return Bad("Glue is defined for Pire::Scanner tables");
+	if (a.empty) {   // multi.h:1094-1097
+		*out = b;
+		return PIRE_HIP_OK;
+	}
+	if (b.empty) {
+		*out = a;
+		return PIRE_HIP_OK;
+	}
+	if (a.headerSize != b.headerSize)
+		return Bad("Glue: the scanners have different shortcutting types");
+	if (maxSize == 0)
+		maxSize = 80000;   // DefMaxSize, multi.h:1099
+
+	HostTable t;
+	t.scannerType = 1;
+	t.headerSize = a.headerSize;
+	t.regexps = a.regexps + b.regexps;
+	t.initial = 0;   // Init(..., size_t(0), ...), multi.h:1031
+
+	// letter classes: Partition<Char, LettersEquality> filled with 0..MaxChar-1 except Epsilon, in that order
+	// (glue.h:123-127): a class is numbered when its first (= smallest, = representative) Char arrives, and the
+	// partition iterates in representative order (partition.h:40, 186-204), which is the same order
+	std::map<std::pair<uint16_t, uint16_t>, uint16_t> classOf;
+	std::vector<uint32_t> rep;
+	t.cls.assign(kMaxChar, 0);
+	for (uint32_t c = 0; c < kMaxChar; ++c) {
+		if (c == kEpsilon)
+			continue;
+		const std::pair<uint16_t, uint16_t> key(a.cls[c], b.cls[c]);
+		auto it = classOf.find(key);
+		if (it == classOf.end()) {
+			it = classOf.emplace(key, uint16_t(rep.size())).first;
+			rep.push_back(c);
+		}
+		t.cls[c] = it->second;
+	}
+	const uint32_t LC = uint32_t(rep.size());
+	t.letters = LC;
+
+	// breadth-first product construction (determine.h:100-122)
+	std::vector<std::pair<uint32_t, uint32_t>> states;
+	std::unordered_map<uint64_t, uint32_t> index;
+	auto keyOf = [](uint32_t x, uint32_t y) { return (uint64_t(x) << 32) | y; };
+	states.emplace_back(a.initial, b.initial);
+	index.emplace(keyOf(a.initial, b.initial), 0u);
+	std::vector<uint32_t> la(LC), lb(LC);
+	for (uint32_t l = 0; l < LC; ++l) {
+		la[l] = a.cls[rep[l]];
+		lb[l] = b.cls[rep[l]];
+	}
+	std::vector<uint32_t>& next = t.next;
+	bool failed = false;
+	for (size_t i = 0; i < states.size() && !failed; ++i) {
+		const uint32_t sa = states[i].first, sb = states[i].second;
+		next.resize((i + 1) * size_t(LC));
+		for (uint32_t l = 0; l < LC; ++l) {
+			const uint32_t na = a.next[size_t(sa) * a.letters + la[l]], nb = b.next[size_t(sb) * b.letters + lb[l]];
+			auto ins = index.emplace(keyOf(na, nb), uint32_t(states.size()));
+			if (ins.second) {
+				if (!maxSize--) {   // determine.h:112-113
+					failed = true;
+					break;
+				}
+				states.emplace_back(na, nb);
+			}
+			next[i * size_t(LC) + l] = ins.first->second;
+		}
+	}
+	if (failed) {
+		// task.Failure() = Scanner(): the empty scanner (glue.h:146, multi.h:121)
+		HostTable e;
+		e.scannerType = 1;
+		e.headerSize = a.headerSize;
+		e.empty = true;
+		e.states = 1;
+		e.letters = 1;
+		e.regexps = 0;
+		e.initial = 0;
+		e.rowStride = uint32_t(AlignUp(1 + e.headerSize, 4) * 4);
+		e.cls.assign(kMaxChar, 0);
+		e.next.assign(1, 0);
+		e.flags.assign(1, uint8_t(kDead | kAbsorbing));
+		e.acceptOff.assign(2, 0);
+		ChooseHotAndPermute(e);
+		*out = e;
+		return PIRE_HIP_OK;
+	}
+	const uint32_t N = uint32_t(states.size());
+	t.states = N;
+	const size_t rowSize = AlignUp(size_t(LC) + t.headerSize, 16 / 4);   // RowSize(), multi.h:347
+	t.rowStride = uint32_t(rowSize * 4);
+
+	// AcceptStates, multi.h:1024-1043: lhs ids, then rhs ids shifted by lhs.RegexpsCount(); Final = either, Dead = both
+	t.flags.resize(N);
+	t.acceptOff.assign(size_t(N) + 1, 0);
+	for (uint32_t i = 0; i < N; ++i) {
+		const uint32_t sa = states[i].first, sb = states[i].second;
+		t.acceptOff[i] = t.acceptIds.size();
+		for (uint64_t k = a.acceptOff[sa]; k < a.acceptOff[sa + 1]; ++k)
+			t.acceptIds.push_back(a.acceptIds[k]);
+		for (uint64_t k = b.acceptOff[sb]; k < b.acceptOff[sb + 1]; ++k)
+			t.acceptIds.push_back(b.acceptIds[k] + a.regexps);
+		bool absorbing = true;
+		for (uint32_t l = 0; l < LC; ++l)
+			absorbing = absorbing && next[size_t(i) * LC + l] == i;
+		const bool fin = (a.flags[sa] & kFinal) || (b.flags[sb] & kFinal);
+		const bool dead = (a.flags[sa] & kDead) && (b.flags[sb] & kDead);
+		t.flags[i] = uint8_t((fin ? kFinal : 0) | (dead ? kDead : 0) | (absorbing ? kAbsorbing : 0));
+	}
+	t.acceptOff[N] = t.acceptIds.size();
+	// BufSize(), multi.h:297-305, with finalTableSize = ids + one sentinel per state (multi.h:362)
+	t.refBufSize = AlignUp(size_t(kMaxChar) * 2 + (t.acceptIds.size() + N) * 8 + size_t(N) * 8 + rowSize * N * 4, 8);
+	t.blobBytes = 0;
+	t.ranked = false;   // the dense-row ranking (a Markov walk over the table) is only needed once the table is run
+	                    // or inspected, not for the intermediates of a left-to-right glue
+	*out = std::move(t);
+	return PIRE_HIP_OK;
+}
+
+void EnsureRanked(pire_hip_table* t)
+{
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
+	if (!t->host.ranked) {
+		ChooseHotAndPermute(t->host);
+		t->host.ranked = true;
+	}
+}
+
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 {
 	if (changedRows)

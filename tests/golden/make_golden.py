@@ -342,9 +342,21 @@ def main():
             entry[key] = {"idx": [int(x) for x in idx], "final": [int(x) for x in fin], "results": res.tolist()}
         entry["strings_hex"] = [x.hex() for x in strings]
 
+    # Scanner::Glue parts: every pattern of set_a / set_d compiled on its own (bench.cpp:114-129 glues such scanners
+    # left to right); gluing these blobs must reproduce the big sets' tables, state for state.
+    glue_parts = []
+    for name, pats in (("set_a", SET_A), ("set_d", SET_D)):
+        parts = []
+        for k, pat in enumerate(pats):
+            one = RefScanner.compile([pat], [""])
+            blob = one.save()
+            parts.append({"pattern": pat, "states": one.size, "letters": one.letters,
+                          "blob": write_blob("%s_part%d" % (name, k), blob)})
+        glue_parts.append({"name": name, "parts": parts})
+
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "corpus": corpus}, f, indent=1)
+                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "glue_parts": glue_parts, "corpus": corpus}, f, indent=1)
     print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners,", len(simple), "simple scanners")
 
 
