@@ -329,6 +329,11 @@ class Table:
                                      int(longest), int(through_begin), int(through_end), 0, out.ctypes.data, None))
         return out
 
+    def prefix_device(self, text_ptr: int, offsets_ptr: int, n: int, longest: bool, out_len_ptr: int,
+                      through_begin=False, through_end=False, stream: int = 0):
+        _check(lib().pire_hip_prefix(self._h, text_ptr or None, offsets_ptr or None, n, int(longest), int(through_begin),
+                                     int(through_end), FLAG_ON_DEVICE, out_len_ptr or None, stream or None))
+
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))
 

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""LongestPrefix / ShortestPrefix throughput: pire_hip_prefix with device pointers vs the reference on the host.  set_a table, 2^18 strings of 64..1023 B."""
+import os
+import time
+
+import numpy as np
+import torch
+
+import pire_amd
+from oracle import binding as ob
+from pire_amd import binding as pb
+from tests import helpers as H
+
+big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+blob = H.load_blob(big["blob"])
+t = pire_amd.Table(blob)
+t.upload()
+m = 1 << 18
+rng = np.random.RandomState(4)
+lens = rng.randint(64, 1024, size=m).astype(np.uint64)
+offs = np.zeros(m + 1, dtype=np.uint64)
+offs[1:] = np.cumsum(lens)
+total = int(offs[-1])
+text = ob.corpus_fill(0x5EED5EED, 0, (total + 4095) // 4096, 4096, H.plants_for(big), threads=8).reshape(-1)[:total]
+d = torch.as_tensor(text, device="cuda")
+do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+dout = torch.empty(m, dtype=torch.int64, device="cuda")
+stream = torch.cuda.current_stream().cuda_stream
+for longest in (True, False):
+    best = 1e9
+    for _ in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        t.prefix_device(d.data_ptr(), do.data_ptr(), m, longest, dout.data_ptr(), stream=stream)
+        b.record()
+        torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b))
+    out = dout.cpu().numpy()
+    name = "LongestPrefix" if longest else "ShortestPrefix"
+    scanned = int(np.where(out >= 0, out, lens.astype(np.int64)).sum()) if not longest else total
+    print("%s: %d strings, %.3f GiB: kernel %.3f ms -> %.1f GB/s of text (%.1f GB/s of bytes actually walked)"
+          % (name, m, total / 2**30, best, total / best / 1e6, scanned / best / 1e6))
+    if ob.ref_available():
+        r = ob.RefScanner.load(blob)
+        k = 1 << 15
+        t0 = time.perf_counter()
+        ref = r.prefix(text, offs[:k + 1], longest)
+        dt = time.perf_counter() - t0
+        print("  reference %s, 1 thread, first %d strings (%.1f MiB): %.3f s -> %.3f GB/s; parity on the sample: %s"
+              % (name, k, int(offs[k]) / 2**20, dt, int(offs[k]) / dt / 1e9, bool((ref == out[:k]).all())))
