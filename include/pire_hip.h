@@ -265,6 +265,42 @@ int pire_hip_device_count(void);
 int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,
                          uint64_t stride, const void* plants, void* stream);
 
+/* ---- Pire::CountingScanner / Pire::AdvancedCountingScanner (extra/count.h) ------------------------- */
+
+/*
+ * The counting scanners of pire/extra/count.h: "count the occurrences of `re` separated by `sep`", up to 16 regexps
+ * glued into one scanner.  They are LoadedScanner tables (scanners/loaded.h: transitions carry an Action) whose
+ * TakeAction keeps a current and a total counter per regexp in the state (count.h:119-234).  Both classes serialise
+ * through LoadedScanner::Save (scanner_io.cpp:172-189) with the same header, so the caller says which TakeAction
+ * the table was built for: PIRE_HIP_COUNTING_BASIC = CountingScanner (increment, then reset; count.h:251-257),
+ * PIRE_HIP_COUNTING_ADVANCED = AdvancedCountingScanner (reset, then increment; count.h:287-295).
+ * Pinned by tests/count_ut.cpp:95-200.
+ */
+typedef struct pire_hip_counting_table pire_hip_counting_table;
+
+#define PIRE_HIP_COUNTING_BASIC 0
+#define PIRE_HIP_COUNTING_ADVANCED 1
+
+typedef struct pire_hip_counting_info {
+	uint32_t states;    /* Size(), loaded.h:112 */
+	uint32_t letters;   /* LettersCount(), loaded.h:118 */
+	uint32_t regexps;   /* RegexpsCount(), loaded.h:116 */
+	uint32_t initial;   /* StateIndex(Initialize()), count.h:127-133, 171 */
+} pire_hip_counting_info;
+
+int pire_hip_counting_table_create(const void* save_blob, size_t len, pire_hip_counting_table** out);
+void pire_hip_counting_table_destroy(pire_hip_counting_table* t);
+int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_counting_info* out);
+
+/*
+ * Per string i: Initialize; Begin() if flags & BEGIN; Run; End() if flags & END (tests/count_ut.cpp:54-63), then
+ *   out_results[i * regexps + r] = State::Result(r) = max(current[r], total[r])   (count.h:206)
+ *   out_state_idx[i] (nullable)  = StateIndex of the end state                     (count.h:171)
+ * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE.
+ */
+int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
+                          uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,18 @@ def oracle_lib():
         L.oracle_slow_run.restype = None
         L.oracle_run_half_final.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u64p]
         L.oracle_run_half_final.restype = None
+        L.oracle_count_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+        L.oracle_count_load.restype = C.c_int
+        L.oracle_count_free.argtypes = [C.c_void_p]
+        for name in ("oracle_count_size", "oracle_count_letters", "oracle_count_regexps", "oracle_count_initial_index"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_uint32
+        L.oracle_count_letter.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_count_letter.restype = C.c_uint32
+        L.oracle_count_next.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, u32p]
+        L.oracle_count_next.restype = C.c_uint32
+        L.oracle_count_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u64p]
+        L.oracle_count_run.restype = None
         L.oracle_simple_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
         L.oracle_simple_load.restype = C.c_int
         L.oracle_simple_free.argtypes = [C.c_void_p]
@@ -304,6 +316,55 @@ class OracleSimpleScanner:
         return self.run(text, offs, **kw)
 
 
+class OracleCountingScanner:
+    """C restatement of Pire::CountingScanner (kind 0) / AdvancedCountingScanner (kind 1), from Save() bytes."""
+
+    BASIC, ADVANCED = 0, 1
+
+    def __init__(self, blob: bytes, kind: int):
+        L = oracle_lib()
+        self._L = L
+        self.kind = kind
+        self.blob = bytes(blob)
+        h = C.c_void_p()
+        err = C.create_string_buffer(256)
+        if L.oracle_count_load(self.blob, len(self.blob), C.byref(h), err, 256) != 0:
+            raise ValueError(err.value.decode())
+        self._h = h
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.oracle_count_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.oracle_count_size(s._h))
+    letters = property(lambda s: s._L.oracle_count_letters(s._h))
+    regexps = property(lambda s: s._L.oracle_count_regexps(s._h))
+    initial = property(lambda s: s._L.oracle_count_initial_index(s._h))
+
+    def letter(self, ch: int) -> int:
+        return self._L.oracle_count_letter(self._h, ch)
+
+    def next(self, idx: int, letter: int):
+        a = C.c_uint32()
+        n = self._L.oracle_count_next(self._h, idx, letter, C.byref(a))
+        return n, a.value
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        res = np.zeros((n, max(self.regexps, 1)), dtype=np.uint64)
+        self._L.oracle_count_run(self._h, self.kind, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n,
+                                 flags, _ptr(idx, u32p), _ptr(res, u64p))
+        return idx, res[:, :self.regexps]
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
 # --------------------------------------------------------------------------- reference library
 
 _ref_lib = None
@@ -373,6 +434,18 @@ def ref_lib():
             getattr(L, name).restype = C.c_size_t
         L.pire_ref_half_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u64p, C.c_int]
         L.pire_ref_half_run.restype = C.c_int
+        L.pire_ref_count_compile.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, C.c_char_p]
+        L.pire_ref_count_compile.restype = C.c_void_p
+        L.pire_ref_count_load.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+        L.pire_ref_count_load.restype = C.c_void_p
+        L.pire_ref_count_free.argtypes = [C.c_void_p]
+        L.pire_ref_count_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_count_save.restype = C.c_size_t
+        for name in ("pire_ref_count_size", "pire_ref_count_regexps", "pire_ref_count_letters"):
+            getattr(L, name).argtypes = [C.c_void_p]
+            getattr(L, name).restype = C.c_size_t
+        L.pire_ref_count_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u64p, C.c_int]
+        L.pire_ref_count_run.restype = C.c_int
         L.pire_ref_simple_compile.argtypes = [C.c_char_p, C.c_char_p]
         L.pire_ref_simple_compile.restype = C.c_void_p
         L.pire_ref_simple_empty.argtypes = []
@@ -446,6 +519,60 @@ class RefSlowScanner:
         if rc != 0:
             raise RuntimeError(self._L.pire_ref_last_error().decode())
         return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
+class RefCountingScanner:
+    """The real Pire::CountingScanner (kind 0) / AdvancedCountingScanner (kind 1) behind a C ABI."""
+
+    BASIC, ADVANCED = 0, 1
+
+    def __init__(self, handle, kind):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+        self.kind = kind
+
+    @classmethod
+    def compile(cls, kind, res, seps, options="u"):
+        L = ref_lib()
+        enc = lambda p: p.encode("utf-8") if isinstance(p, str) else p
+        a = (C.c_char_p * len(res))(*[enc(p) for p in res])
+        b = (C.c_char_p * len(seps))(*[enc(p) for p in seps])
+        return cls(L.pire_ref_count_compile(kind, a, b, len(res), options.encode()), kind)
+
+    @classmethod
+    def load(cls, kind, blob: bytes):
+        return cls(ref_lib().pire_ref_count_load(kind, bytes(blob), len(blob)), kind)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_count_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_count_size(s._h))
+    regexps = property(lambda s: s._L.pire_ref_count_regexps(s._h))
+    letters = property(lambda s: s._L.pire_ref_count_letters(s._h))
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_count_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_count_save(self._h, buf, n)
+        return buf.raw
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END, threads=1):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        res = np.zeros((n, max(self.regexps, 1)), dtype=np.uint64)
+        self._L.pire_ref_count_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                   _ptr(idx, u32p), _ptr(res, u64p), threads)
+        return idx, res[:, :self.regexps]
 
     def run_strings(self, strings, **kw):
         text, offs = pack_strings(strings)

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <pire/pire.h>
+#include <pire/extra.h>
 #include <pire/stub/memstreams.h>
 
 namespace {
@@ -620,6 +621,139 @@ int pire_ref_half_run(void* hh, const void* text, const uint64_t* offsets, uint6
 				for (size_t r = 0; r < R; ++r)
 					results[i * R + r] = st.Result(r);
 		}
+	};
+	if (threads <= 1) {
+		range(0, n);
+		return 0;
+	}
+	std::vector<std::thread> pool;     // sharding by string index is ours
+	for (int k = 0; k < threads; ++k)
+		pool.emplace_back(range, n * k / threads, n * (k + 1) / threads);
+	for (auto& th : pool)
+		th.join();
+	return 0;
+}
+
+/* ---- Pire::CountingScanner / AdvancedCountingScanner (extra/count.h): count occurrences of `re` separated by `sep`.
+ * LoadedScanner tables (scanners/loaded.h) whose transitions carry an action; TakeAction keeps per-regexp counters in
+ * the state.  Built as tests/count_ut.cpp:64-93 builds them. ---------------------------------------------------- */
+
+extern "C++" {
+struct RefCount {
+	int kind;                               // 0 CountingScanner, 1 AdvancedCountingScanner
+	Pire::CountingScanner cs;
+	Pire::AdvancedCountingScanner as;
+};
+
+template <class Sc>
+static void CountRun(const Sc& sc, const char* t, const uint64_t* offsets, uint64_t lo, uint64_t hi, uint32_t flags,
+                     uint32_t* outIdx, uint64_t* results)
+{
+	const size_t R = sc.RegexpsCount();
+	for (uint64_t i = lo; i < hi; ++i) {
+		typename Sc::State st;
+		sc.Initialize(st);                                           // count.h:127-133
+		if (flags & FLAG_BEGIN)
+			Pire::Step(sc, st, Pire::BeginMark);                     // tests/count_ut.cpp:54-63
+		Pire::Run(sc, st, t + offsets[i], t + offsets[i + 1]);
+		if (flags & FLAG_END)
+			Pire::Step(sc, st, Pire::EndMark);
+		if (outIdx)
+			outIdx[i] = uint32_t(sc.StateIndex(st));
+		if (results)
+			for (size_t r = 0; r < R; ++r)
+				results[i * R + r] = st.Result(int(r));              // count.h:206
+	}
+}
+}  // extern "C++"
+
+void* pire_ref_count_compile(int kind, const char* const* res, const char* const* seps, int count, const char* options)
+{
+	try {
+		std::unique_ptr<RefCount> h(new RefCount);
+		h->kind = kind;
+		for (int i = 0; i < count; ++i) {
+			const Pire::Fsm re = MkCountFsm(res[i], options), sep = MkCountFsm(seps[i], options);
+			if (kind == 0) {
+				Pire::CountingScanner one(re, sep);
+				h->cs = i == 0 ? one : Pire::CountingScanner::Glue(h->cs, one);
+				if (i && h->cs.Empty())
+					throw Pire::Error("CountingScanner::Glue failed");
+			} else if (kind == 1) {
+				Pire::AdvancedCountingScanner one(re, sep);
+				h->as = i == 0 ? one : Pire::AdvancedCountingScanner::Glue(h->as, one);
+				if (i && h->as.Empty())
+					throw Pire::Error("AdvancedCountingScanner::Glue failed");
+			} else {
+				throw Pire::Error("unknown counting scanner kind");
+			}
+		}
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void* pire_ref_count_load(int kind, const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefCount> h(new RefCount);
+		h->kind = kind;
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		if (kind == 0)
+			h->cs.Load(&in);                                         // LoadedScanner::Load, scanner_io.cpp:191-215
+		else
+			h->as.Load(&in);
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_count_free(void* h) { delete static_cast<RefCount*>(h); }
+
+size_t pire_ref_count_save(void* hh, void* buf, size_t cap)         // LoadedScanner::Save, scanner_io.cpp:172-189
+{
+	RefCount* h = static_cast<RefCount*>(hh);
+	std::ostringstream out;
+	if (h->kind == 0)
+		h->cs.Save(&out);
+	else
+		h->as.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_count_size(void* hh)
+{
+	RefCount* h = static_cast<RefCount*>(hh);
+	return h->kind == 0 ? h->cs.Size() : h->as.Size();
+}
+size_t pire_ref_count_regexps(void* hh)
+{
+	RefCount* h = static_cast<RefCount*>(hh);
+	return h->kind == 0 ? h->cs.RegexpsCount() : h->as.RegexpsCount();
+}
+size_t pire_ref_count_letters(void* hh)
+{
+	RefCount* h = static_cast<RefCount*>(hh);
+	return h->kind == 0 ? h->cs.LettersCount() : h->as.LettersCount();
+}
+
+int pire_ref_count_run(void* hh, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                       uint32_t* outIdx, uint64_t* results, int threads)
+{
+	RefCount* h = static_cast<RefCount*>(hh);
+	const char* t = static_cast<const char*>(text);
+	auto range = [&](uint64_t lo, uint64_t hi) {
+		if (h->kind == 0)
+			CountRun(h->cs, t, offsets, lo, hi, flags, outIdx, results);
+		else
+			CountRun(h->as, t, offsets, lo, hi, flags, outIdx, results);
 	};
 	if (threads <= 1) {
 		range(0, n);

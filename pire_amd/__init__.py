@@ -13,6 +13,7 @@ from .binding import (  # noqa: F401
     PireHipError,
     Table,
     SlowTable,
+    CountingTable,
     BatchRunner,
     build,
     corpus_fill_device,

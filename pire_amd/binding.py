@@ -51,6 +51,10 @@ class TableInfo(C.Structure):
     ]
 
 
+class CountingInfo(C.Structure):
+    _fields_ = [("states", C.c_uint32), ("letters", C.c_uint32), ("regexps", C.c_uint32), ("initial", C.c_uint32)]
+
+
 class SlowInfo(C.Structure):
     _fields_ = [("states", C.c_uint32), ("letters", C.c_uint32), ("start", C.c_uint32), ("words", C.c_uint32),
                 ("empty", C.c_uint32), ("reserved", C.c_uint32), ("mask_bytes", C.c_uint64)]
@@ -103,6 +107,11 @@ ABI = [
                                     C.c_void_p, C.c_void_p]),
     ("pire_hip_slow_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_counting_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_counting_table_destroy", None, [C.c_void_p]),
+    ("pire_hip_counting_table_get_info", C.c_int, [C.c_void_p, C.POINTER(CountingInfo)]),
+    ("pire_hip_counting_run", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
     ("pire_hip_set_timing", C.c_int, [C.c_int]),
     ("pire_hip_last_kernel_ms", C.c_float, []),
@@ -387,6 +396,60 @@ class SlowTable:
         _check(lib().pire_hip_slow_run_strided(self._h, text_ptr or None, n, length, stride, flags | FLAG_ON_DEVICE,
                                                out_final_ptr or None, out_bits_ptr or None, out_counts_ptr or None,
                                                stream or None))
+
+
+class CountingTable:
+    """An ingested Pire::CountingScanner / AdvancedCountingScanner (LoadedScanner::Save() bytes)."""
+
+    BASIC, ADVANCED = 0, 1
+
+    def __init__(self, blob: bytes, kind: int):
+        L = lib()
+        h = C.c_void_p()
+        blob = bytes(blob)
+        _check(L.pire_hip_counting_table_create(blob, len(blob), C.byref(h)))
+        self._h = h
+        self.kind = kind
+        self.info = CountingInfo()
+        _check(L.pire_hip_counting_table_get_info(h, C.byref(self.info)))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and _lib is not None:
+            try:
+                _lib.pire_hip_counting_table_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    Size = property(lambda s: s.info.states)
+    LettersCount = property(lambda s: s.info.letters)
+    RegexpsCount = property(lambda s: s.info.regexps)
+    initial = property(lambda s: s.info.initial)
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        """(StateIndex[n], Result[n, regexps]) for host strings."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        res = np.zeros((n, max(self.RegexpsCount, 1)), dtype=np.uint32)
+        _check(lib().pire_hip_counting_run(self._h, self.kind, text.ctypes.data if text.size else None,
+                                           offsets.ctypes.data, n, flags & ~FLAG_ON_DEVICE, idx.ctypes.data,
+                                           res.ctypes.data, None))
+        return idx, res[:, :self.RegexpsCount]
+
+    def run_strings(self, strings, **kw):
+        offs = np.zeros(len(strings) + 1, dtype=np.uint64)
+        if strings:
+            offs[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64)
+        return self.run(np.frombuffer(b"".join(strings), dtype=np.uint8), offs, **kw)
+
+    def run_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_results_ptr=0, stream: int = 0):
+        _check(lib().pire_hip_counting_run(self._h, self.kind, text_ptr or None, offsets_ptr or None, n,
+                                           flags | FLAG_ON_DEVICE, out_idx_ptr or None, out_results_ptr or None,
+                                           stream or None))
 
 
 class BatchRunner:

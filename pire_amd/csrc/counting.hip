@@ -1,0 +1,449 @@
+// Pire::CountingScanner / Pire::AdvancedCountingScanner on the GPU: count, per regexp, the
+// occurrences of `re` separated by `sep` -- the first scanners on this path whose Action is not a no-op.
+//
+// Reference: /root/reference/pire/extra/count.h, /root/reference/pire/scanners/loaded.h
+//   LoadedScanner table: u8 letters[264], Transition{u32 shift, u32 action}[states*letters], u8 tags   loaded.h:57-66, 235-243
+//   serialised form (Save)                                                                            scanner_io.cpp:172-189
+//   Next: state += SignExtend(x.shift); return x.action                                               count.h:148-153
+//   CountingScanner::TakeActionImpl: increment, then reset                                            count.h:251-257
+//   AdvancedCountingScanner::TakeActionImpl: reset, then increment                                    count.h:287-295
+//   PerformIncrement / PerformReset, IncrementPerformer / ResetPerformer                              count.h:48-101, 175-192
+//   State::Result(i) = max(current[i], total[i])                                                      count.h:206
+// Device form: transitions repacked as {next state index, action} (8 bytes), kept in LDS when the table fits
+// (counting scanners are small: tens of states); one string per lane, exact step per byte; the per-regexp counters
+// live in registers (8 or 16 pairs); an action word is applied only when it is non-zero.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "internal.h"
+
+namespace pirehip {
+
+constexpr uint32_t kMaxReCount = 16;   // LoadedScanner::MAX_RE_COUNT, loaded.h:74
+
+struct CountingHost {
+	uint32_t states = 0, letters = 0, regexps = 0, initial = 0;
+	std::vector<uint8_t> letterOf;     // [264] m_letters
+	std::vector<uint64_t> trans;       // [states*letters] next state index | action << 32
+};
+
+struct CountingDevice {
+	int device = -1;
+	uint8_t* letterOf = nullptr;
+	uint64_t* trans = nullptr;
+};
+
+}  // namespace pirehip
+
+struct pire_hip_counting_table {
+	pirehip::CountingHost host;
+	pirehip::CountingDevice dev;
+};
+
+namespace pirehip {
+
+struct CountingParams {
+	const uint8_t* letterOf;
+	const uint64_t* trans;
+	uint32_t states, letters, regexps, initial, flags, transInLds;
+	const uint8_t* text;
+	const uint64_t* offsets;
+	uint64_t n;
+	uint32_t* outIdx;
+	uint32_t* outResults;
+};
+
+// CountingState minus the state pointer (count.h:204-234).  Only bits 16..31 of m_updatedMask are ever read
+// (PerformReset masks a 32-bit action with it, count.h:187) and the reset clears everything above (count.h:190), so
+// a 32-bit mask is exact.
+template <int RMAX>
+struct Counters {
+	uint32_t current[RMAX], total[RMAX];
+	uint32_t updated;
+
+	__device__ __forceinline__ void Init()
+	{
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r)
+			current[r] = total[r] = 0;
+		updated = 0;
+	}
+	__device__ __forceinline__ void Increment(uint32_t a)   // PerformIncrement, count.h:175-182
+	{
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r)
+			current[r] += (a >> r) & 1u;
+		updated |= a << kMaxReCount;
+	}
+	__device__ __forceinline__ void Reset(uint32_t a)       // PerformReset, count.h:184-192
+	{
+		const uint32_t m = a & updated;
+		if (m) {
+#pragma unroll
+			for (int r = 0; r < RMAX; ++r)
+				if (((m >> (kMaxReCount + r)) & 1u) && current[r]) {
+					total[r] = total[r] > current[r] ? total[r] : current[r];
+					current[r] = 0;
+				}
+			updated &= ~m;
+		}
+	}
+	template <bool ADVANCED>
+	__device__ __forceinline__ void Take(uint32_t a)
+	{
+		constexpr uint32_t kInc = (1u << kMaxReCount) - 1u, kReset = kInc << kMaxReCount;   // loaded.h:223-224
+		if (ADVANCED) {
+			if (a & kReset)
+				Reset(a);
+			if (a & kInc)
+				Increment(a);
+		} else {
+			if (a & kInc)
+				Increment(a);
+			if (a & kReset)
+				Reset(a);
+		}
+	}
+};
+
+template <int RMAX, bool ADVANCED>
+__global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* letterOf = lds;                                            // 264 bytes
+	uint64_t* transLds = reinterpret_cast<uint64_t*>(lds + 272);
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		letterOf[i] = p.letterOf[i];
+	if (p.transInLds)
+		for (uint32_t i = threadIdx.x; i < p.states * p.letters; i += blockDim.x)
+			transLds[i] = p.trans[i];
+	__syncthreads();
+	const uint64_t* trans = p.transInLds ? transLds : p.trans;
+
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		Counters<RMAX> c;
+		c.Init();                                                       // Initialize, count.h:127-133
+		uint32_t st = p.initial;
+		auto step = [&](uint32_t ch) {                                  // Step = Next + TakeAction, run.h:50-57
+			const uint64_t x = trans[st * p.letters + letterOf[ch]];
+			st = uint32_t(x);
+			const uint32_t a = uint32_t(x >> 32);
+			if (a)
+				c.template Take<ADVANCED>(a);
+		};
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			step(kBeginMark);
+		const uint8_t* ptr = p.text + p.offsets[s];
+		const uint8_t* end = p.text + p.offsets[s + 1];
+		while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+			step(*ptr);
+			++ptr;
+		}
+		for (; ptr + 16 <= end; ptr += 16) {
+			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				step(v.x & 0xFF);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
+		}
+		for (; ptr < end; ++ptr)
+			step(*ptr);
+		if (p.flags & PIRE_HIP_RUN_END)
+			step(kEndMark);
+		if (p.outIdx)
+			p.outIdx[s] = st;
+		for (uint32_t r = 0; r < p.regexps; ++r) {
+			uint32_t cur = 0, tot = 0;
+#pragma unroll
+			for (int k = 0; k < RMAX; ++k)
+				if (uint32_t(k) == r) {
+					cur = c.current[k];
+					tot = c.total[k];
+				}
+			p.outResults[s * p.regexps + r] = cur > tot ? cur : tot;   // Result(r), count.h:206
+		}
+	}
+}
+
+namespace {
+
+struct RefHeader {
+	uint32_t magic, version, ptrSize, maxWordSize, type, hdrSize;
+};
+struct LoadedLocals {
+	uint32_t statesCount, lettersCount, regexpsCount, pad;
+	uint64_t initial;
+};
+
+int Bad(const char* msg)
+{
+	SetError(msg);
+	return PIRE_HIP_EFORMAT;
+}
+
+int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
+{
+	const uint8_t* p = static_cast<const uint8_t*>(blob);
+	if (!p || len < sizeof(RefHeader))
+		return Bad("EOF reached while reading the scanner header");
+	RefHeader h;
+	memcpy(&h, p, sizeof(h));
+	// Header::Validate, common.h:65-77; type LoadedScanner = 4, common.h:39
+	if (h.magic != 0x45524950u || h.ptrSize != 8 || h.maxWordSize != 16 || h.type != 4 || h.hdrSize != sizeof(LoadedLocals))
+		return Bad("Serialized regexp incompatible with your system");
+	if (h.version != 7 && h.version != 6)
+		return Bad("You are trying to used an incompatible version of a serialized regexp");
+	size_t pos = 24;
+	LoadedLocals m;
+	if (len < pos + sizeof(m))
+		return Bad("EOF reached while reading the scanner locals");
+	memcpy(&m, p + pos, sizeof(m));
+	pos += sizeof(m);
+	if (m.statesCount == 0 || m.lettersCount == 0 || m.lettersCount > 256 || m.regexpsCount > kMaxReCount)
+		return Bad("Corrupt scanner: bad state, letter or regexp count");
+	const size_t njumps = size_t(m.statesCount) * m.lettersCount;
+	if (len < pos + 264 + njumps * 8 + m.statesCount)
+		return Bad("EOF reached while reading the scanner buffer");
+	CountingHost& t = *out;
+	t = CountingHost();
+	t.states = m.statesCount;
+	t.letters = m.lettersCount;
+	t.regexps = m.regexpsCount;
+	const uint64_t stateSize = uint64_t(m.lettersCount) * 8;   // StateSize(), loaded.h:171-174
+	if (m.initial % stateSize != 0 || m.initial / stateSize >= m.statesCount)
+		return Bad("Corrupt scanner: initial state out of range");
+	t.initial = uint32_t(m.initial / stateSize);
+	t.letterOf.assign(p + pos, p + pos + 264);
+	for (uint32_t c = 0; c < 264; ++c)
+		if (t.letterOf[c] >= m.lettersCount)
+			return Bad("Corrupt scanner: letter out of range");
+	pos += 264;   // already a multiple of 8 (AlignedSaveArray)
+	t.trans.resize(njumps);
+	for (uint32_t s = 0; s < m.statesCount; ++s)
+		for (uint32_t l = 0; l < m.lettersCount; ++l) {
+			uint32_t shift, action;
+			memcpy(&shift, p + pos + (size_t(s) * m.lettersCount + l) * 8, 4);
+			memcpy(&action, p + pos + (size_t(s) * m.lettersCount + l) * 8 + 4, 4);
+			const int64_t dest = int64_t(s) * int64_t(stateSize) + int64_t(int32_t(shift));   // SignExtend, loaded.h:210
+			if (dest < 0 || uint64_t(dest) % stateSize != 0 || uint64_t(dest) / stateSize >= m.statesCount)
+				return Bad("Corrupt scanner: transition out of range");
+			t.trans[size_t(s) * m.lettersCount + l] = uint64_t(dest) / stateSize | (uint64_t(action) << 32);
+		}
+	return PIRE_HIP_OK;
+}
+
+void FreeCountingDevice(CountingDevice* d)
+{
+	if (d->device < 0)
+		return;
+	if (d->letterOf)
+		(void)hipFree(d->letterOf);
+	if (d->trans)
+		(void)hipFree(d->trans);
+	*d = CountingDevice();
+}
+
+int UploadCounting(pire_hip_counting_table* t)
+{
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	if (t->dev.device == dev)
+		return PIRE_HIP_OK;
+	FreeCountingDevice(&t->dev);
+	CountingDevice d;
+	e = hipMalloc(reinterpret_cast<void**>(&d.letterOf), 272);
+	if (e == hipSuccess)
+		e = hipMalloc(reinterpret_cast<void**>(&d.trans), t->host.trans.size() * 8);
+	if (e == hipSuccess)
+		e = hipMemcpy(d.letterOf, t->host.letterOf.data(), 264, hipMemcpyHostToDevice);
+	if (e == hipSuccess)
+		e = hipMemcpy(d.trans, t->host.trans.data(), t->host.trans.size() * 8, hipMemcpyHostToDevice);
+	d.device = dev;
+	if (e != hipSuccess) {
+		FreeCountingDevice(&d);
+		return HipFail(e, "uploading the counting table");
+	}
+	t->dev = d;
+	return PIRE_HIP_OK;
+}
+
+template <int RMAX, bool ADV>
+void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+{
+	*err = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingKernel<RMAX, ADV>),
+	                           hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (*err != hipSuccess)
+		return;
+	hipLaunchKernelGGL((CountingKernel<RMAX, ADV>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+	*err = hipGetLastError();
+}
+
+int LaunchCounting(CountingParams p, int kind, hipStream_t stream)
+{
+	if (p.n == 0)
+		return PIRE_HIP_OK;
+	int dev = 0, cus = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e == hipSuccess)
+		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (e != hipSuccess)
+		return HipFail(e, "device query");
+	const uint64_t tableBytes = uint64_t(p.states) * p.letters * 8;
+	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;   // several 256-thread blocks per CU stay resident
+	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
+	const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
+	if (p.regexps <= 8) {
+		if (adv)
+			LaunchOne<8, true>(p, blocks, ldsBytes, stream, &e);
+		else
+			LaunchOne<8, false>(p, blocks, ldsBytes, stream, &e);
+	} else {
+		if (adv)
+			LaunchOne<16, true>(p, blocks, ldsBytes, stream, &e);
+		else
+			LaunchOne<16, false>(p, blocks, ldsBytes, stream, &e);
+	}
+	if (e != hipSuccess)
+		return HipFail(e, "counting kernel launch");
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+}  // namespace pirehip
+
+using namespace pirehip;
+
+extern "C" {
+
+int pire_hip_counting_table_create(const void* save_blob, size_t len, pire_hip_counting_table** out)
+{
+	if (!out) {
+		SetError("null out pointer");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	std::unique_ptr<pire_hip_counting_table> t(new (std::nothrow) pire_hip_counting_table);
+	if (!t) {
+		SetError("out of memory");
+		return PIRE_HIP_ENOMEM;
+	}
+	if (int rc = BuildCountingHost(save_blob, len, &t->host))
+		return rc;
+	*out = t.release();
+	return PIRE_HIP_OK;
+}
+
+void pire_hip_counting_table_destroy(pire_hip_counting_table* t)
+{
+	if (!t)
+		return;
+	FreeCountingDevice(&t->dev);
+	delete t;
+}
+
+int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_counting_info* out)
+{
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	memset(out, 0, sizeof(*out));
+	out->states = t->host.states;
+	out->letters = t->host.letters;
+	out->regexps = t->host.regexps;
+	out->initial = t->host.initial;
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
+                          uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* streamPtr)
+{
+	if (!t || (n && (!offsets || !out_results)) || (kind != PIRE_HIP_COUNTING_BASIC && kind != PIRE_HIP_COUNTING_ADVANCED)) {
+		SetError("bad argument");
+		return PIRE_HIP_EINVAL;
+	}
+	if (n == 0)
+		return PIRE_HIP_OK;
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (int rc = UploadCounting(t))
+		return rc;
+	CountingParams p;
+	memset(&p, 0, sizeof(p));
+	p.letterOf = t->dev.letterOf;
+	p.trans = t->dev.trans;
+	p.states = t->host.states;
+	p.letters = t->host.letters;
+	p.regexps = t->host.regexps;
+	p.initial = t->host.initial;
+	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+	p.n = n;
+	const uint32_t R = std::max<uint32_t>(t->host.regexps, 1);
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		p.outIdx = out_state_idx;
+		p.outResults = out_results;
+		return LaunchCounting(p, kind, stream);
+	}
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i] > offsets[i + 1]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
+		}
+	const uint64_t textBytes = offsets[n];
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	void *dText = nullptr, *dOffs = nullptr, *dIdx = nullptr, *dRes = nullptr;
+	hipError_t e = hipMalloc(&dText, textBytes ? textBytes : 16);
+	if (e == hipSuccess)
+		e = hipMalloc(&dOffs, (n + 1) * 8);
+	if (e == hipSuccess)
+		e = hipMalloc(&dIdx, n * 4);
+	if (e == hipSuccess)
+		e = hipMalloc(&dRes, n * R * 4);
+	if (e == hipSuccess && textBytes)
+		e = hipMemcpyAsync(dText, text, textBytes, hipMemcpyHostToDevice, stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(dOffs, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
+	int rc = PIRE_HIP_OK;
+	if (e == hipSuccess) {
+		p.text = static_cast<const uint8_t*>(dText);
+		p.offsets = static_cast<const uint64_t*>(dOffs);
+		p.outIdx = static_cast<uint32_t*>(dIdx);
+		p.outResults = static_cast<uint32_t*>(dRes);
+		rc = LaunchCounting(p, kind, stream);
+		if (rc == PIRE_HIP_OK) {
+			if (out_state_idx)
+				e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess && t->host.regexps)
+				e = hipMemcpyAsync(out_results, dRes, n * t->host.regexps * 4, hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(stream);
+		}
+	}
+	for (void* q : {dText, dOffs, dIdx, dRes})
+		if (q)
+			(void)hipFree(q);
+	if (rc != PIRE_HIP_OK)
+		return rc;
+	if (e != hipSuccess)
+		return HipFail(e, "counting run (staging)");
+	return PIRE_HIP_OK;
+}
+
+}  // extern "C"

@@ -992,8 +992,10 @@ struct HalfCounters<true> {
 	}
 	__device__ __forceinline__ void Store(const ScanParams& p, uint32_t* out, uint64_t s)
 	{
-		for (uint32_t r = 0; r < p.regexps; ++r)
-			out[s * p.regexps + r] = c[r];
+#pragma unroll
+		for (int r = 0; r < 8; ++r)      // static indices only: a runtime index would put c[] into scratch
+			if (uint32_t(r) < p.regexps)
+				out[s * p.regexps + r] = c[r];
 	}
 };
 

@@ -342,6 +342,47 @@ def main():
             entry[key] = {"idx": [int(x) for x in idx], "final": [int(x) for x in fin], "results": res.tolist()}
         entry["strings_hex"] = [x.hex() for x in strings]
 
+    # CountingScanner / AdvancedCountingScanner (extra/count.h): the reference's vectors, tests/count_ut.cpp:95-103,
+    # plus a 3-regexp glue (count_ut.cpp:203-260 style)
+    from oracle.binding import RefCountingScanner
+    COUNT = [
+        ("[a-z]+", "\\s", b"abc def, abc def ghi, abc", 3),
+        ("\\w", "", b"abc abcdef abcd abcdefgh ac", 8),
+        ("http", ".*", b"http://aaa, http://bbb, something in the middle, http://ccc, end", 3),
+        ("abc", ".*", b"abcabcabcabc", 4),
+        ("[a-z]+", ".*", b"abc def\0 abc\0 def ghi, abc\0", 6),
+    ]
+    counting = []
+    rng = np.random.RandomState(80)
+    extra = [bytes(rng.choice(np.frombuffer(b"abc def,http:/\n", dtype=np.uint8), size=int(k))) for k in rng.randint(0, 90, size=40)]
+    for k, (re_, sep, text, expect) in enumerate(COUNT):
+        for kind, kname in ((0, "basic"), (1, "advanced")):
+            sc = RefCountingScanner.compile(kind, [re_], [sep])
+            strings = [text] + extra
+            idx, res = sc.run_strings(strings)
+            assert int(res[0, 0]) == expect, (re_, sep, kind, res[0], expect)
+            nidx, nres = sc.run_strings(strings, flags=0)
+            name = "count%d_%s" % (k, kname)
+            blob = sc.save()
+            counting.append({"name": name, "source": "tests/count_ut.cpp:95-103", "re": [re_], "sep": [sep], "kind": kind,
+                             "states": sc.size, "letters": sc.letters, "regexps": sc.regexps, "expect_first": expect,
+                             "blob": write_blob(name, blob), "strings_hex": [x.hex() for x in strings],
+                             "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
+                             "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
+    for kind, kname in ((0, "basic"), (1, "advanced")):
+        res_, seps_ = ["[a-z]+", "http", "abc"], ["\\s", ".*", ".*"]
+        sc = RefCountingScanner.compile(kind, res_, seps_)
+        strings = [c[2] for c in COUNT] + extra
+        idx, res = sc.run_strings(strings)
+        nidx, nres = sc.run_strings(strings, flags=0)
+        name = "count_glued3_%s" % kname
+        blob = sc.save()
+        counting.append({"name": name, "source": "CountingScanner::Glue of three count_ut.cpp:95-103 scanners", "re": res_,
+                         "sep": seps_, "kind": kind, "states": sc.size, "letters": sc.letters, "regexps": sc.regexps,
+                         "expect_first": None, "blob": write_blob(name, blob), "strings_hex": [x.hex() for x in strings],
+                         "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
+                         "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
+
     # Scanner::Glue parts: every pattern of set_a / set_d compiled on its own (bench.cpp:114-129 glues such scanners
     # left to right); gluing these blobs must reproduce the big sets' tables, state for state.
     glue_parts = []
@@ -356,7 +397,7 @@ def main():
 
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "glue_parts": glue_parts, "corpus": corpus}, f, indent=1)
+                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "counting": counting, "glue_parts": glue_parts, "corpus": corpus}, f, indent=1)
     print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners,", len(simple), "simple scanners")
 
 

@@ -1,0 +1,94 @@
+"""Pire::CountingScanner / AdvancedCountingScanner (extra/count.h): the first scanners on the path
+whose Action is not a no-op.  Known answers are the reference's own, tests/count_ut.cpp:95-103."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests import helpers as H
+
+
+def cases():
+    return H.golden().get("counting", [])
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pire_amd
+
+    return pire_amd
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_oracle_matches_golden(case):
+    o = ob.OracleCountingScanner(H.load_blob(case["blob"]), case["kind"])
+    assert (o.size, o.letters, o.regexps) == (case["states"], case["letters"], case["regexps"])
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    for key, flags in (("be", 3), ("none", 0)):
+        idx, res = o.run_strings(strings, flags=flags)
+        assert idx.tolist() == case[key]["idx"] and res.tolist() == case[key]["results"]
+    if case["expect_first"] is not None:
+        assert case["be"]["results"][0][0] == case["expect_first"]          # the number written in count_ut.cpp
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_oracle_vs_live_reference(case):
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    blob = H.load_blob(case["blob"])
+    r, o = ob.RefCountingScanner.load(case["kind"], blob), ob.OracleCountingScanner(blob, case["kind"])
+    assert r.save() == blob
+    rng = np.random.RandomState(9)
+    strings = H.random_strings(rng, 500, 120, b"abc def,http:/\n") + H.random_strings(rng, 100, 60)
+    for flags in (3, 0, 1, 2):
+        ri, rr = r.run_strings(strings, flags=flags)
+        oi, orr = o.run_strings(strings, flags=flags)
+        assert (ri == oi).all() and (rr == orr).all()
+
+
+def test_product_ingests_counting_tables(pa):
+    for case in cases():
+        blob = H.load_blob(case["blob"])
+        t = pa.CountingTable(blob, case["kind"])
+        o = ob.OracleCountingScanner(blob, case["kind"])
+        assert (t.Size, t.LettersCount, t.RegexpsCount, t.initial) == (o.size, o.letters, o.regexps, o.initial)
+    with pytest.raises(pa.PireHipError):
+        pa.CountingTable(H.load_blob(cases()[0]["blob"])[:100], 0)
+    with pytest.raises(pa.PireHipError):                                   # a Scanner blob is not a LoadedScanner
+        pa.CountingTable(H.load_blob([c for c in H.all_cases() if c["name"] == "survey_known_answer"][0]["blob"]), 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_gpu_counting_parity(case, pa):
+    assert pa.device_count() > 0
+    blob = H.load_blob(case["blob"])
+    t, o = pa.CountingTable(blob, case["kind"]), ob.OracleCountingScanner(blob, case["kind"])
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    for key, flags in (("be", 3), ("none", 0)):
+        idx, res = t.run_strings(strings, flags=flags)
+        assert idx.tolist() == case[key]["idx"] and res.tolist() == case[key]["results"]
+    rng = np.random.RandomState(21)
+    many = H.random_strings(rng, 6000, 400, b"abc def,http:/\n") + [b""] * 3 + H.random_strings(rng, 500, 100)
+    for flags in (3, 0, 1, 2):
+        oi, orr = o.run_strings(many, flags=flags)
+        gi, gr = t.run_strings(many, flags=flags)
+        assert (gi == oi).all() and (gr == orr).all()
+    assert orr.sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_counting_sixteen_regexps(pa):
+    """The 16-counter instantiation (more than 8 regexps glued)."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    res_ = ["a", "b", "c", "ab", "bc", "ca", "[ab]+", "[bc]+", "d", "abc"]
+    seps = [".*"] * len(res_)
+    for kind in (0, 1):
+        blob = ob.RefCountingScanner.compile(kind, res_, seps).save()
+        t, o = pa.CountingTable(blob, kind), ob.OracleCountingScanner(blob, kind)
+        assert t.RegexpsCount == len(res_)
+        rng = np.random.RandomState(22)
+        many = H.random_strings(rng, 3000, 200, b"abcd ")
+        oi, orr = o.run_strings(many)
+        gi, gr = t.run_strings(many)
+        assert (gi == oi).all() and (gr == orr).all() and gr.sum() > 0
