@@ -370,6 +370,90 @@ private:
 };
 
 /*
+ * Batched Runner over a Pire::CountingScanner or Pire::AdvancedCountingScanner (extra/count.h; include <pire/extra.h>
+ * before this header): per string State::Result(r) for every glued regexp (count.h:206) after
+ * Initialize + Begin() + Run() + End(), as tests/count_ut.cpp:54-63 drives them.
+ */
+#ifdef PIRE_EXTRA_COUNT_H
+template <class CountScanner>
+struct CountingKind;
+template <>
+struct CountingKind<Pire::CountingScanner> {
+	enum { Value = PIRE_HIP_COUNTING_BASIC };
+};
+template <>
+struct CountingKind<Pire::AdvancedCountingScanner> {
+	enum { Value = PIRE_HIP_COUNTING_ADVANCED };
+};
+
+template <class CountScanner>
+class CountingBatchRunner {
+public:
+	explicit CountingBatchRunner(const CountScanner& sc)
+	    : m_table(nullptr), m_regexps(sc.RegexpsCount()), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false)
+	{
+		std::ostringstream out;
+		sc.Save(&out);                                    // LoadedScanner::Save, scanner_io.cpp:172-189
+		const std::string blob = out.str();
+		Check(pire_hip_counting_table_create(blob.data(), blob.size(), &m_table));
+	}
+	~CountingBatchRunner() { pire_hip_counting_table_destroy(m_table); }
+
+	CountingBatchRunner& Begin() { m_flags |= PIRE_HIP_RUN_BEGIN; return *this; }
+	CountingBatchRunner& End() { m_flags |= PIRE_HIP_RUN_END; return *this; }
+	CountingBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_text = text;
+		m_offsets = offsets;
+		m_n = n;
+		m_ran = false;
+		return *this;
+	}
+	CountingBatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_ownText.clear();
+		m_ownOffsets.assign(1, 0);
+		for (size_t i = 0; i < strings.size(); ++i) {
+			m_ownText.append(strings[i]);
+			m_ownOffsets.push_back(m_ownText.size());
+		}
+		return Run(m_ownText.data(), m_ownOffsets.data(), strings.size());
+	}
+
+	/* State::Result(r) of string i. */
+	size_t Result(size_t i, size_t r) { Execute(); return m_results[i * m_regexps + r]; }
+	const std::vector<uint32_t>& Results() { Execute(); return m_results; }       // [n][RegexpsCount()]
+	const std::vector<uint32_t>& StateIndices() { Execute(); return m_idx; }      // StateIndex(State()) per string
+
+private:
+	void Execute()
+	{
+		if (m_ran)
+			return;
+		m_idx.assign(m_n, 0);
+		m_results.assign(m_n * (m_regexps ? m_regexps : 1), 0);
+		static const uint64_t kNoOffsets[1] = {0};
+		Check(pire_hip_counting_run(m_table, CountingKind<CountScanner>::Value, m_text, m_n ? m_offsets : kNoOffsets, m_n,
+		                            m_flags, m_idx.data(), m_results.data(), nullptr));
+		m_ran = true;
+	}
+
+	CountingBatchRunner(const CountingBatchRunner&);
+	CountingBatchRunner& operator=(const CountingBatchRunner&);
+	pire_hip_counting_table* m_table;
+	size_t m_regexps;
+	uint32_t m_flags;
+	const char* m_text;
+	const uint64_t* m_offsets;
+	size_t m_n;
+	bool m_ran;
+	std::vector<uint32_t> m_idx, m_results;
+	ystring m_ownText;
+	std::vector<uint64_t> m_ownOffsets;
+};
+#endif  // PIRE_EXTRA_COUNT_H
+
+/*
  * Batched Runner over a Pire::SlowScanner (scanners/slow.h): Matches(sc, str) per string, i.e.
  * Final(Runner(sc).Begin().Run(str).End().State()).
  */

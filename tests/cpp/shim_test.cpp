@@ -10,6 +10,7 @@
 #include <vector>
 
 #include <pire/pire.h>
+#include <pire/extra.h>
 #include <pire_hip/batch_runner.hpp>
 
 static int g_checks = 0, g_fail = 0;
@@ -250,10 +251,55 @@ static void TestScannerPair()
 	CHECK(fin[0] && fin[1] && fin[2] && !fin[3] && !fin[4] && fin[5] && !fin[6]);
 }
 
+// Pire::CountingScanner / AdvancedCountingScanner (extra/count.h), built and driven as tests/count_ut.cpp:54-93 does.
+template <class CountScanner>
+static void TestCounting()
+{
+	const char* res[] = {"[a-z]+", "http", "abc"};
+	const char* seps[] = {"\\s", ".*", ".*"};
+	std::vector<Pire::ystring> strings;
+	const char* fixed[] = {"abc def, abc def ghi, abc", "http://aaa, http://bbb, something in the middle, http://ccc, end",
+	                       "abcabcabcabc", "", "x"};
+	for (size_t i = 0; i < sizeof(fixed) / sizeof(fixed[0]); ++i)
+		strings.push_back(fixed[i]);
+	unsigned seed = 4242;
+	for (int i = 0; i < 500; ++i) {
+		Pire::ystring s;
+		seed = seed * 1103515245u + 12345u;
+		const size_t len = (seed >> 16) % 120;
+		for (size_t k = 0; k < len; ++k) {
+			seed = seed * 1103515245u + 12345u;
+			s.push_back("abc def,http:/\n"[(seed >> 16) % 15]);
+		}
+		strings.push_back(s);
+	}
+	CountScanner glued;
+	for (int k = 0; k < 3; ++k) {
+		CountScanner one(Parse(res[k], false), Parse(seps[k], false));
+		glued = k == 0 ? one : CountScanner::Glue(glued, one);
+	}
+	CHECK(glued.RegexpsCount() == 3);
+	Pire::Hip::CountingBatchRunner<CountScanner> gpu(glued);
+	gpu.Begin().Run(strings).End();
+	for (size_t i = 0; i < strings.size(); ++i) {
+		typename CountScanner::State st;
+		glued.Initialize(st);
+		Pire::Step(glued, st, Pire::BeginMark);
+		Pire::Run(glued, st, strings[i].data(), strings[i].data() + strings[i].size());
+		Pire::Step(glued, st, Pire::EndMark);
+		for (int r = 0; r < 3; ++r)
+			CHECK(gpu.Result(i, r) == st.Result(r));
+		CHECK(gpu.StateIndices()[i] == glued.StateIndex(st));
+	}
+	CHECK(gpu.Result(0, 0) == 3 && gpu.Result(1, 1) == 3 && gpu.Result(2, 2) == 4);   // count_ut.cpp:97, 102, 103
+}
+
 int main()
 {
 	try {
 		TestPrefixAndSlow();
+		TestCounting<Pire::CountingScanner>();
+		TestCounting<Pire::AdvancedCountingScanner>();
 		TestScannerPair();
 		TestHalfFinal();
 		TestSimpleScanner();
