@@ -25,6 +25,7 @@
 #include <cstdio>
 
 #include "internal.h"
+#include "walk.h"
 
 namespace pirehip {
 
@@ -1130,16 +1131,21 @@ __global__ __launch_bounds__(256) void PrefixKernel(PrefixParams q)
 			stop = !q.longest;
 		}
 		const bool foundAtStart = stop;
-		for (uint64_t i = 0; i < len && !stop; ++i) {
-			st = SlowStep(p, lds, L, st, text[i]);
-			f = StateFlags(p, lds, L, st);
-			if (f & kFinal) {
-				pos = (long long)(i + 1);
-				if (!q.longest)
-					stop = true;                         // ShortestPrefixPred: Stop on the first Final
-			}
-			if (f & kDead)
-				stop = true;                             // both predicates stop on a dead state
+		if (!stop) {
+			uint64_t i = 0;
+			WalkBytes(text, text + len, [&](uint32_t byte) {   // line-aligned vector loads instead of byte loads
+				st = SlowStep(p, lds, L, st, byte);
+				f = StateFlags(p, lds, L, st);
+				++i;
+				if (f & kFinal) {
+					pos = (long long)i;
+					if (!q.longest)
+						stop = true;                     // ShortestPrefixPred: Stop on the first Final
+				}
+				if (f & kDead)
+					stop = true;                         // both predicates stop on a dead state
+				return !stop;
+			});
 		}
 		if (q.throughEnd && !foundAtStart) {
 			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
