@@ -1228,15 +1228,22 @@ namespace {
 
 int DeviceCUs(int* cus)
 {
+	// asked on every launch: cache per device (hipGetDeviceProperties is far too slow for that)
+	static std::atomic<int> cached[64];
 	int dev = 0;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess)
 		return HipFail(e, "hipGetDevice");
-	hipDeviceProp_t prop;
-	e = hipGetDeviceProperties(&prop, dev);
-	if (e != hipSuccess)
-		return HipFail(e, "hipGetDeviceProperties");
-	*cus = prop.multiProcessorCount;
+	const bool slot = dev >= 0 && dev < 64;
+	int v = slot ? cached[dev].load(std::memory_order_relaxed) : 0;
+	if (v == 0) {
+		e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+		if (e != hipSuccess)
+			return HipFail(e, "hipDeviceGetAttribute(multiprocessor count)");
+		if (slot)
+			cached[dev].store(v, std::memory_order_relaxed);
+	}
+	*cus = v;
 	return PIRE_HIP_OK;
 }
 
