@@ -221,10 +221,20 @@ def main():
     pire_amd.corpus_fill_device(text.data_ptr(), SEED, first, n, length, length, plants, stream)
     out_idx = torch.empty(n, dtype=torch.int32, device=dev)
     out_fin = torch.empty(n, dtype=torch.uint8, device=dev)
-    counts = torch.zeros(table.RegexpsCount + 2, dtype=torch.int64, device=dev)
+    # two counter buffers, used alternately: the all-reduce of step k (RCCL runs it on its own stream) then overlaps
+    # the scan of step k+1 instead of sitting between two kernels
+    count_bufs = [torch.zeros(table.RegexpsCount + 2, dtype=torch.int64, device=dev) for _ in range(2)]
     flags = pb.FLAG_BEGIN | pb.FLAG_END
+    step_no = [0]
+    pending = [None, None]   # the outstanding all-reduce of each buffer
 
     def step(ev=None):
+        slot = step_no[0] & 1
+        counts = count_bufs[slot]
+        step_no[0] += 1
+        if pending[slot] is not None:
+            pending[slot].wait()   # stream-level wait for the reduction issued two steps ago: long finished
+            pending[slot] = None
         counts.zero_()
         if ev:
             ev[0].record()
@@ -232,9 +242,13 @@ def main():
                                  counts.data_ptr(), 0, stream)
         if ev:
             ev[1].record()
-        pd.allreduce_counts(counts)   # the path's only exchange: 80 B of match counters (RCCL all-reduce)
+        pending[slot] = pd.allreduce_counts(counts, async_op=True)   # the path's only exchange: 80 B of counters
 
     def fence():
+        for k in (0, 1):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         pd.barrier()
         torch.cuda.synchronize()
 
@@ -257,7 +271,7 @@ def main():
     kernel_ms = [a.elapsed_time(b) for a, b in events]
     kernel_name = pb.last_kernel()
 
-    total_counts = counts.cpu().numpy().astype(np.uint64)
+    total_counts = count_bufs[(step_no[0] - 1) & 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
     gpu_idx = out_idx.cpu().numpy().astype(np.uint32)
     gpu_fin = out_fin.cpu().numpy()
 

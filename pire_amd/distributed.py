@@ -39,13 +39,17 @@ def init(backend: str, device=None):
         dist.init_process_group(backend=backend)
 
 
-def allreduce_counts(counts):
-    """Sum the match counters over all ranks in place (no-op for a single process)."""
+def allreduce_counts(counts, async_op: bool = False):
+    """Sum the match counters over all ranks in place (no-op for a single process).
+
+    async_op=True returns the collective's work handle (or None): the caller's stream is NOT made to wait for the
+    reduction, so the next scan can run while RCCL moves its 80 bytes; call .wait() before touching `counts` again."""
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-    return counts
+        work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, async_op=async_op)
+        return work if async_op else counts
+    return None if async_op else counts
 
 
 def max_over_ranks(seconds: float, device=None) -> float:

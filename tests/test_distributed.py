@@ -53,7 +53,12 @@ def _worker(rank, world, port, n_total, length, q):
         for r in o.accepted(i):
             counts[2 + r] += 1
     t = torch.from_numpy(counts)
+    t2 = t.clone()
     pd.allreduce_counts(t)
+    work = pd.allreduce_counts(t2, async_op=True)      # what bench.py uses to overlap the reduce with the next scan
+    assert work is not None
+    work.wait()
+    assert (t2 == t).all()
     slowest = pd.max_over_ranks(1.0 + rank)
     pd.barrier()
     if rank == 0:
