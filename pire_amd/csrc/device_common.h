@@ -1,0 +1,376 @@
+// Device-side pieces shared by the scan kernels (tiled.hip, ragged.hip, exact.hip): the LDS image of the table, the
+// exact step, the 16-byte chunk walk with its trap / compact / full re-walk, end-of-string bookkeeping and the launch
+// helpers.  Everything here is inline: the file is included by several translation units.
+//
+// HIP kernels of the scan path for gfx950 (MI355X / CDNA4).  No MFMA: the path is a byte-gather DFA walk.
+//
+// What is computed (per input string, one string per lane):
+//     st = start;  for each byte b:  st = Next(st, b);   [Begin/End marks around it]
+// which is Pire::Run / Pire::Step of /root/reference/pire/run.h:50-57, 271-275 over the table of
+// /root/reference/pire/scanners/multi.h:163-192 (Next = row[letters[ch]]).
+//
+// Device table layout (built in table.cpp, described in DESIGN.md section 3):
+//   * states are renumbered "hot first" (perm ids); the reference's ids come back through origOfPerm[]
+//   * hot rows: up to 255 states have a DENSE row of 256 u8 entries in LDS, indexed directly by the input
+//     byte (the byte->letter-class translation of multi.h:163-166 is folded in).  One LDS gather per byte:
+//         addr = v_perm_b32(st, word, sel)   = (st << 8) | byte_k(word)
+//         st   = ds_read_u8(addr)
+//     An entry is the next hot id, or the trap id H ("left the hot set"); row H maps every byte to H.
+//   * everything else: nextPerm[perm * letters + cls[byte]] (u32) in HBM/L2 -- the exact, slow step.
+// A lane that leaves the hot set is re-walked exactly through the slow step for the 16-byte chunk in which it
+// trapped, so results never depend on which rows are hot.
+
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "internal.h"
+
+namespace pirehip {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
+constexpr uint32_t kDebugNoStep = 1u << 29;     // internal, never set through the C ABI
+constexpr uint32_t kDebugNoColdCount = 1u << 28;
+constexpr uint32_t kDebugNoHist = 1u << 27;
+constexpr uint32_t kDebugNoPartial = 1u << 26;   // ragged kernel timing experiments only (results are wrong)
+constexpr uint32_t kDebugNoFinish = 1u << 25;
+constexpr uint32_t kDebugNoTrap = 1u << 24;
+
+// Cooperative load of the LDS-resident part of the table.
+__device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+{
+	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+	// dense rows: 256-byte rows in HBM, `pitch`-byte rows in LDS (dword copies: 260 is only 4-byte aligned)
+	const uint32_t* src = reinterpret_cast<const uint32_t*>(p.hotRows);
+	uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+	const uint32_t pitchDw = L.pitch / 4;
+	for (uint32_t i = tid; i < (p.hot + 1) * 64; i += nthr)
+		dst[(i >> 6) * pitchDw + (i & 63)] = src[i];
+	for (uint32_t i = tid; i < 256 / 4; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.flagsOff)[i] = reinterpret_cast<const uint32_t*>(p.hotFlags)[i];
+	for (uint32_t i = tid; i < 264 / 2; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.clsOff)[i] = reinterpret_cast<const uint32_t*>(p.cls)[i];
+	if (p.outCounts)
+		for (uint32_t i = tid; i < p.regexps + 2; i += nthr)
+			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
+	for (uint32_t i = tid; i < 256; i += nthr)
+		reinterpret_cast<uint32_t*>(lds + L.histOff)[i] = 0;
+	if (p.compact) {
+		for (uint32_t i = tid; i < L.compactBytes / 16; i += nthr)
+			reinterpret_cast<u32x4*>(lds + L.compactOff)[i] = reinterpret_cast<const u32x4*>(p.compactRows)[i];
+		for (uint32_t i = tid; i < 256; i += nthr)
+			lds[L.cls8Off + i] = uint8_t(2 * p.cls[i]);
+	}
+	__syncthreads();
+}
+
+// The exact step for any state: multi.h:169-192 on the perm-numbered table.
+__device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                             uint32_t st, uint32_t byte)
+{
+	if (st < p.hot) {
+		const uint32_t e = lds[st * L.pitch + byte];
+		if (e != p.hot)
+			return e;
+	}
+	const uint32_t c = reinterpret_cast<const uint16_t*>(lds + L.clsOff)[byte];
+	return p.nextPerm[size_t(st) * p.letters + c];
+}
+
+__device__ __forceinline__ uint32_t SlowStepWord(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                                 uint32_t st, uint32_t w)
+{
+	st = SlowStep(p, lds, L, st, w & 0xFF);
+	st = SlowStep(p, lds, L, st, (w >> 8) & 0xFF);
+	st = SlowStep(p, lds, L, st, (w >> 16) & 0xFF);
+	st = SlowStep(p, lds, L, st, w >> 24);
+	return st;
+}
+
+// Start state of string s (perm id): Initialize() or the caller's resume state, then Begin() if asked.
+__device__ __forceinline__ uint32_t StartState(const ScanParams& p, uint64_t s)
+{
+	if (!p.initIdx)
+		return p.startPerm;   // host folded Initialize()+Begin() into one id
+	uint32_t st = p.permOfOrig[p.initIdx[s]];
+	if (p.flags & PIRE_HIP_RUN_BEGIN)
+		st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+	return st;
+}
+
+// End(), outputs and block-local match counters for one finished string.  One 16-byte record load replaces the
+// chain  nextPerm[EndMark] -> flags -> origOfPerm -> acceptMask  of dependent lookups.
+__device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint64_t s,
+                                       bool active, uint32_t st)
+{
+	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+	const u32x4 raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
+	const uint64_t mask = (uint64_t(raw.w) << 32) | raw.z;
+	if (active) {
+		if (p.outIdx)
+			p.outIdx[s] = orig;
+		if (p.outFinal)
+			p.outFinal[s] = fl & kFinal;
+	}
+	if (p.outCounts) {
+		uint32_t* cnt = reinterpret_cast<uint32_t*>(lds + L.countsOff);
+		const int lane = threadIdx.x & 63;
+		const unsigned long long finals = __ballot(active && (fl & kFinal));
+		const unsigned long long actives = __ballot(active);
+		if (lane == 0) {
+			atomicAdd(&cnt[0], (uint32_t)__popcll(finals));
+			atomicAdd(&cnt[1], (uint32_t)__popcll(actives));
+		}
+		if (p.acceptMaskPerm) {
+			const uint64_t m = active ? mask : 0;
+			for (uint32_t r = 0; r < p.regexps; ++r) {
+				const unsigned long long b = __ballot((m >> r) & 1);
+				if (lane == 0 && b)
+					atomicAdd(&cnt[2 + r], (uint32_t)__popcll(b));
+			}
+		} else if (active) {
+			for (uint64_t k = p.acceptOffPerm[endPerm]; k < p.acceptOffPerm[endPerm + 1]; ++k)
+				atomicAdd(&cnt[2 + p.acceptIds[k]], 1u);
+		}
+	}
+}
+
+__device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+{
+	__syncthreads();
+	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + L.histOff);
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+		if (hist[i])
+			atomicAdd(&p.visitHot[i], hist[i]);
+	if (!p.outCounts)
+		return;
+	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + L.countsOff);
+	for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
+		if (cnt[i])
+			atomicAdd(&p.outCounts[i], (unsigned long long)cnt[i]);
+}
+
+
+// ---- the 16-byte chunk: LDS fast path, trap, compact re-walk, full re-walk -----------------------------------------
+
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
+__device__ __forceinline__ uint32_t HotLookup(uint32_t addr)
+{
+	return *reinterpret_cast<LdsBytePtr>(static_cast<uintptr_t>(addr));
+}
+typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
+__device__ __forceinline__ uint32_t LdsU16(uint32_t addr)
+{
+	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(addr));
+}
+
+// Compact tier: the exact walk of one 16-byte chunk for a lane whose state has a compact row, LDS
+// only and branch free.  Row entries are the LDS address / 4 of the next state's row, so a step is
+//   class2 = cls8[byte]            (off the dependent chain: 16 independent ds_read_u8)
+//   row    = u16[row * 4 + class2] (the chain: v_lshl_add_u32 + ds_read_u16)
+// Targets without a row lead to the absorbing escape row (id == p.compact): the caller then re-walks the chunk
+// through the full table in HBM.  Returns the state id after the chunk (<= p.compact).
+__device__ __forceinline__ uint32_t CompactChunk(const ScanParams& p, const LdsLayout& L, const u32x4 v, uint32_t st)
+{
+	const uint32_t pitch = CompactPitch(p.letters);
+	uint32_t row = (L.compactOff >> 2) + st * (pitch >> 2);
+	const uint32_t clsBase = L.cls8Off;   // multiple of 256: v_perm_b32 glues the byte under it
+	// rolled on purpose: this code is instantiated once per unrolled chunk of the callers, and the kernels have to
+	// stay well inside the 64 KiB instruction cache (measured: the unrolled form cost the tiled kernel 5%)
+	u32x4 w = v;
+#pragma unroll 1
+	for (int i = 0; i < 4; ++i) {
+		const uint32_t x = w.x;
+		const uint32_t c0 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060500u));
+		const uint32_t c1 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060501u));
+		const uint32_t c2 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060502u));
+		const uint32_t c3 = HotLookup(__builtin_amdgcn_perm(clsBase, x, 0x0c060503u));
+		row = LdsU16((row << 2) + c0);
+		row = LdsU16((row << 2) + c1);
+		row = LdsU16((row << 2) + c2);
+		row = LdsU16((row << 2) + c3);
+		w.x = w.y;
+		w.y = w.z;
+		w.z = w.w;
+	}
+	return LdsU16((row << 2) + p.letters * 2);
+}
+
+// Same for the first `count` (1..15) bytes of v, rolled.
+__device__ __forceinline__ uint32_t CompactPartial(const ScanParams& p, const LdsLayout& L, u32x4 v, uint32_t st,
+                                                   uint32_t count)
+{
+	const uint32_t pitch = CompactPitch(p.letters);
+	uint32_t row = (L.compactOff >> 2) + st * (pitch >> 2);
+	const uint32_t clsBase = L.cls8Off;
+#pragma unroll 1
+	for (uint32_t i = 0; __any(i < count); ++i) {
+		const uint32_t c = HotLookup(__builtin_amdgcn_perm(clsBase, v.x, 0x0c060500u));
+		const uint32_t nr = LdsU16((row << 2) + c);
+		row = i < count ? nr : row;
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return LdsU16((row << 2) + p.letters * 2);
+}
+
+// Exact re-walk of one 16-byte chunk for the lanes that trapped.  Deliberately a rolled loop (the chunk is shifted
+// through as a 128-bit value): this is the cold path, and keeping it small keeps the hot loop dense in the I-cache.
+__device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
+                                           uint32_t st)
+{
+#pragma unroll 1
+	for (int i = 0; i < 16; ++i) {
+		st = SlowStep(p, lds, L, st, v.x & 0xFF);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return st;
+}
+
+// 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
+template <int ROT>
+__device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                          const u32x4 v, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
+{
+	const uint32_t hs0 = hs;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		if (ROT == 1) {
+			// rows are 65 dwords apart, so row r is rotated by r banks: lanes in different states reading the same
+			// byte>>2 no longer hit the same bank.  The byte is extracted off the dependent chain; the chain
+			// itself stays one VALU (v_mad_u32_u24) + one ds_read_u8.
+			const uint32_t b0 = x & 0xFF, b1 = (x >> 8) & 0xFF, b2 = (x >> 16) & 0xFF, b3 = x >> 24;
+			hs = HotLookup(__umul24(hs, kRotPitch) + b0);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b1);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b2);
+			hs = HotLookup(__umul24(hs, kRotPitch) + b3);
+		} else {
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0400u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0401u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0402u));
+			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
+		}
+	}
+	if (hs == p.hot && !(p.flags & kDebugNoTrap)) {
+		// left the dense rows somewhere in this chunk: exact re-walk from the chunk's start state, through the
+		// compact rows in LDS when the state has one, through the full table in HBM when that escapes too
+		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+		uint32_t f = p.compact;
+		if (st0 < p.compact)
+			f = CompactChunk(p, L, v, st0);
+		if (f == p.compact)
+			f = SlowChunk(p, lds, L, v, st0);
+		if (f < p.hot) {
+			hs = f;
+		} else {
+			hs = p.hot;
+			cold = f;
+			// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
+			// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
+			// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
+			if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
+				atomicAdd(&p.visitCold[f], 1u);
+		}
+	}
+}
+
+
+__device__ __forceinline__ void ZeroTile(u32x4 (&r)[8])
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		r[k] = u32x4{0, 0, 0, 0};
+}
+
+__device__ __forceinline__ uint64_t Uniform64(uint64_t v)
+{
+	const uint32_t lo = __builtin_amdgcn_readfirstlane(uint32_t(v));
+	const uint32_t hi = __builtin_amdgcn_readfirstlane(uint32_t(v >> 32));
+	return (uint64_t(hi) << 32) | lo;
+}
+
+// One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1
+// ahead (index clamped to the last tile, so the steady-state loop has no conditional loads), wait until the
+// current slot has landed, transpose it into lane-owns-string order, walk it.
+
+// ---- launch helpers --------------------------------------------------------------------------------------------------
+
+inline int DeviceCUs(int* cus)
+{
+	// asked on every launch: cache per device (hipGetDeviceProperties is far too slow for that)
+	static std::atomic<int> cached[64];
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	const bool slot = dev >= 0 && dev < 64;
+	int v = slot ? cached[dev].load(std::memory_order_relaxed) : 0;
+	if (v == 0) {
+		e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev);
+		if (e != hipSuccess)
+			return HipFail(e, "hipDeviceGetAttribute(multiprocessor count)");
+		if (slot)
+			cached[dev].store(v, std::memory_order_relaxed);
+	}
+	*cus = v;
+	return PIRE_HIP_OK;
+}
+
+template <class K>
+int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hipStream_t stream)
+{
+	int cus = 0;
+	int rc = DeviceCUs(&cus);
+	if (rc)
+		return rc;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	int perCu = 0;
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, ldsBytes);
+	if (e != hipSuccess)
+		return HipFail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+	if (getenv("PIRE_HIP_DEBUG_LAUNCH"))
+		fprintf(stderr, "pire_hip: threads %d lds %u -> %d blocks/CU\n", threads, ldsBytes, perCu);
+	if (perCu < 1)
+		perCu = 1;
+	const uint64_t ntasks = (p.n + 63) / 64;
+	const uint64_t wavesPerBlock = uint64_t(threads) / 64;
+	uint64_t blocks = (ntasks + wavesPerBlock - 1) / wavesPerBlock;
+	blocks = std::min<uint64_t>(blocks, uint64_t(cus) * perCu);
+	if (blocks == 0)
+		blocks = 1;
+	hipLaunchKernelGGL(kernel, dim3(unsigned(blocks)), dim3(threads), ldsBytes, stream, p);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "kernel launch");
+	return PIRE_HIP_OK;
+}
+
+inline int CheckCounts(const ScanParams& p)
+{
+	if (p.outCounts && p.regexps > kMaxLdsCountRegexps) {
+		SetError("out_counts is supported for scanners with at most 1024 regexps");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	return PIRE_HIP_OK;
+}
+
+
+}  // namespace pirehip

@@ -1,0 +1,342 @@
+// The one-string-per-lane exact kernels: generic scan (any offsets / alignment / length), HalfFinalScanner counting,
+// LongestPrefix / ShortestPrefix, single Step().  DESIGN.md sections 4.4 - 4.6.
+
+#include "device_common.h"
+#include "walk.h"
+
+namespace pirehip {
+
+// ------------------------------------------------------------------------------------------ generic kernel
+// Any offsets, any alignment, any length (including 0).  One string per lane, exact step per byte.
+
+__global__ __launch_bounds__(256) void ScanGenericKernel(ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
+	LoadTableToLds(p, lds, L);
+
+	const uint64_t nrounds = (p.n + 63) / 64;
+	const uint32_t wavesPerBlock = blockDim.x >> 6;
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint64_t task = uint64_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6); task < nrounds;
+	     task += uint64_t(gridDim.x) * wavesPerBlock) {
+		const uint64_t s = task * 64 + lane;
+		const bool active = s < p.n;
+		uint32_t st = 0;
+		if (active) {
+			st = StartState(p, s);
+			uint64_t b, e;
+			if (p.offsets) {
+				b = p.offsets[s];
+				e = p.offsets[s + 1];
+			} else {
+				b = s * p.stride;
+				e = b + p.len;
+			}
+			const uint8_t* ptr = p.text + b;
+			const uint8_t* end = p.text + e;
+			while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+				st = SlowStep(p, lds, L, st, *ptr);
+				++ptr;
+			}
+			for (; ptr + 16 <= end; ptr += 16) {
+				const u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
+				st = SlowStepWord(p, lds, L, st, v.x);
+				st = SlowStepWord(p, lds, L, st, v.y);
+				st = SlowStepWord(p, lds, L, st, v.z);
+				st = SlowStepWord(p, lds, L, st, v.w);
+			}
+			for (; ptr < end; ++ptr)
+				st = SlowStep(p, lds, L, st, *ptr);
+		}
+		Finish(p, lds, L, s, active, st);
+	}
+	FlushCounts(p, lds, L);
+}
+
+// ------------------------------------------------------------------------------------------ HalfFinalScanner
+// Pire::HalfFinalScanner (scanners/half_final.h) is a Scanner whose Initialize and every Step end with TakeAction:
+// if the new state is Final, every entry of its final list bumps the per-regexp match counter of the string
+// (half_final.h:137-164).  Same table, same walk, plus State::Result(r) per string.  First version: the generic
+// kernel's exact walk with a one-compare Final test per step -- the hot set is ordered non-final first, so
+// "hot and Final" is `st >= hotFinalLo`, cold states look their flags up -- and, for up to 8 regexps, counters in
+// registers fed from a packed increment word per state (hot states: LDS).
+
+template <bool PACKED>
+struct HalfCounters;
+
+template <>
+struct HalfCounters<true> {
+	uint32_t c[8];
+	__device__ __forceinline__ void Init(const ScanParams&, uint32_t*, uint64_t)
+	{
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			c[r] = 0;
+	}
+	__device__ __forceinline__ void Take(const ScanParams& p, const uint64_t* incHot, uint32_t st)
+	{
+		const uint64_t inc = st < p.hot ? incHot[st] : p.incPerm[st];
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			c[r] += uint32_t(inc >> (8 * r)) & 0xFFu;
+	}
+	__device__ __forceinline__ void Store(const ScanParams& p, uint32_t* out, uint64_t s)
+	{
+#pragma unroll
+		for (int r = 0; r < 8; ++r)      // static indices only: a runtime index would put c[] into scratch
+			if (uint32_t(r) < p.regexps)
+				out[s * p.regexps + r] = c[r];
+	}
+};
+
+template <>
+struct HalfCounters<false> {
+	uint32_t* row;
+	__device__ __forceinline__ void Init(const ScanParams& p, uint32_t* out, uint64_t s)
+	{
+		row = out + s * p.regexps;
+		for (uint32_t r = 0; r < p.regexps; ++r)
+			row[r] = 0;
+	}
+	__device__ __forceinline__ void Take(const ScanParams& p, const uint64_t*, uint32_t st)
+	{
+		for (uint64_t k = p.acceptOffPerm[st]; k < p.acceptOffPerm[st + 1]; ++k)
+			row[p.acceptIds[k]] += 1;   // the lane owns the row: plain read-modify-write
+	}
+	__device__ __forceinline__ void Store(const ScanParams&, uint32_t*, uint64_t) {}
+};
+
+__device__ __forceinline__ bool IsFinalState(const ScanParams& p, uint32_t st)
+{
+	return st >= p.hotFinalLo && (st < p.hot || (p.flagsPerm[st] & kFinal));
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256) void HalfFinalKernel(ScanParams p, uint32_t* outResults)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	uint64_t* incHot = reinterpret_cast<uint64_t*>(lds + L.total);
+	if (PACKED)
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+			incHot[i] = p.incPerm[i];
+	LoadTableToLds(p, lds, L);
+
+	const uint64_t nrounds = (p.n + 63) / 64;
+	const uint32_t wavesPerBlock = blockDim.x >> 6;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t initial = p.startPerm;   // Initialize(): the launcher passes flags without BEGIN to FillParams
+	for (uint64_t task = uint64_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6); task < nrounds;
+	     task += uint64_t(gridDim.x) * wavesPerBlock) {
+		const uint64_t s = task * 64 + lane;
+		if (s >= p.n)
+			continue;
+		HalfCounters<PACKED> cnt;
+		cnt.Init(p, outResults, s);
+		uint32_t st = initial;
+		if (IsFinalState(p, st))
+			cnt.Take(p, incHot, st);                       // Initialize ends with TakeAction, half_final.h:142
+		if (p.flags & PIRE_HIP_RUN_BEGIN) {
+			st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+			if (IsFinalState(p, st))
+				cnt.Take(p, incHot, st);
+		}
+		const uint8_t* ptr = p.text + p.offsets[s];
+		const uint8_t* end = p.text + p.offsets[s + 1];
+		auto step = [&](uint32_t byte) {
+			st = SlowStep(p, lds, L, st, byte);
+			if (IsFinalState(p, st))
+				cnt.Take(p, incHot, st);
+		};
+		while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+			step(*ptr);
+			++ptr;
+		}
+		for (; ptr + 16 <= end; ptr += 16) {
+			u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				step(v.x & 0xFF);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
+		}
+		for (; ptr < end; ++ptr)
+			step(*ptr);
+		if (p.flags & PIRE_HIP_RUN_END) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			if (IsFinalState(p, st))
+				cnt.Take(p, incHot, st);
+		}
+		cnt.Store(p, outResults, s);
+		if (p.outIdx)
+			p.outIdx[s] = p.origOfPerm[st];
+		if (p.outFinal)
+			p.outFinal[s] = p.flagsPerm[st] & kFinal;
+	}
+}
+
+// ------------------------------------------------------------------------------------------ prefix searches
+// Pire::LongestPrefix / ShortestPrefix (run.h:277-311) with LongestPrefixPred / ShortestPrefixPred (run.h:69-100):
+// the same walk, but after every byte Final(state) records the position and Dead(state) (or, for the shortest
+// prefix, the first Final) ends it.  One string per lane, exact step (dense row first); the early exit is per lane.
+
+struct PrefixParams {
+	ScanParams scan;
+	uint32_t longest, throughEnd;
+	long long* outLen;
+};
+
+__device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t st)
+{
+	return st < p.hot ? lds[L.flagsOff + st] : p.flagsPerm[st];
+}
+
+__global__ __launch_bounds__(256) void PrefixKernel(PrefixParams q)
+{
+	const ScanParams& p = q.scan;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	LoadTableToLds(p, lds, L);
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		const uint8_t* text = p.text + b;
+		const uint64_t len = e - b;
+		uint32_t st = p.startPerm;                       // Initialize (+ BeginMark if throughBeginMark), run.h:280-283
+		long long pos = -1;
+		bool stop = false;
+		uint32_t f = StateFlags(p, lds, L, st);
+		if (f & kFinal) {
+			pos = 0;                                     // run.h:284 / 301-302
+			stop = !q.longest;
+		}
+		const bool foundAtStart = stop;
+		if (!stop) {
+			uint64_t i = 0;
+			WalkBytes(text, text + len, [&](uint32_t byte) {   // line-aligned vector loads instead of byte loads
+				st = SlowStep(p, lds, L, st, byte);
+				f = StateFlags(p, lds, L, st);
+				++i;
+				if (f & kFinal) {
+					pos = (long long)i;
+					if (!q.longest)
+						stop = true;                     // ShortestPrefixPred: Stop on the first Final
+				}
+				if (f & kDead)
+					stop = true;                         // both predicates stop on a dead state
+				return !stop;
+			});
+		}
+		if (q.throughEnd && !foundAtStart) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			if (StateFlags(p, lds, L, st) & kFinal) {
+				if (q.longest || pos < 0)
+					pos = (long long)len;                // run.h:286-290 / 305-309
+			}
+		}
+		q.outLen[s] = pos;
+	}
+}
+
+// ------------------------------------------------------------------------------------------ single Step()
+
+__global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateIdx, uint64_t n, uint32_t cls)
+{
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n) {
+		const uint32_t st = p.permOfOrig[stateIdx[i]];
+		stateIdx[i] = p.origOfPerm[p.nextPerm[size_t(st) * p.letters + cls]];
+	}
+}
+
+
+// ------------------------------------------------------------------------------------------ launchers
+
+int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p0))
+		return rc;
+	ScanParams p = p0;
+	p.compact = 0;   // small blocks, several per CU: no room (and no need) for the warm rows
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
+	return LaunchScan(ScanGenericKernel, p, 256, L.total, stream);
+}
+
+
+int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long* outLen, hipStream_t stream)
+{
+	if (p0.n == 0)
+		return PIRE_HIP_OK;
+	ScanParams p = p0;
+	p.compact = 0;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(PrefixKernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	PrefixParams q;
+	q.scan = p;
+	q.longest = longest ? 1 : 0;
+	q.throughEnd = throughEnd ? 1 : 0;
+	q.outLen = outLen;
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 2)));
+	hipLaunchKernelGGL(PrefixKernel, dim3(blocks), dim3(256), L.total, stream, q);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "prefix kernel launch");
+	return PIRE_HIP_OK;
+}
+
+int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stream)
+{
+	if (p0.n == 0)
+		return PIRE_HIP_OK;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	ScanParams p = p0;
+	p.compact = 0;
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	const uint32_t ldsBytes = L.total + 256 * 8;
+	const bool packed = p.incPerm != nullptr;
+	const void* fn = packed ? reinterpret_cast<const void*>(HalfFinalKernel<true>) : reinterpret_cast<const void*>(HalfFinalKernel<false>);
+	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 2)));
+	if (packed)
+		hipLaunchKernelGGL(HalfFinalKernel<true>, dim3(blocks), dim3(256), ldsBytes, stream, p, outResults);
+	else
+		hipLaunchKernelGGL(HalfFinalKernel<false>, dim3(blocks), dim3(256), ldsBytes, stream, p, outResults);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "half-final kernel launch");
+	return PIRE_HIP_OK;
+}
+int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream)
+{
+	if (n == 0)
+		return PIRE_HIP_OK;
+	const unsigned blocks = unsigned((n + 255) / 256);
+	hipLaunchKernelGGL(StepKernel, dim3(blocks), dim3(256), 0, stream, p, stateIdx, n, cls);
+	hipError_t e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "step kernel launch");
+	return PIRE_HIP_OK;
+}
+
+
+}  // namespace pirehip

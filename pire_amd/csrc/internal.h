@@ -214,7 +214,7 @@ int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostT
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
 void FreeDeviceTable(DeviceTable* d);
 
-// kernels.hip
+// tiled.hip / ragged.hip / exact.hip / corpus.hip
 int LaunchGeneric(const ScanParams& p, hipStream_t stream);
 int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);

@@ -1,0 +1,427 @@
+// The ragged kernel (offset batches, pire_hip_run).  DESIGN.md section 4.4.
+
+#include "device_common.h"
+
+namespace pirehip {
+
+// ------------------------------------------------------------------------------------------ ragged kernel
+// Variable-length strings given by offsets -- the natural input of the reference's callers (URLs, log lines, one
+// Runner per string: bench.cpp:244, pigrep.cpp:42).  One string per lane, but a lane is NOT tied to a string: when
+// its string ends it takes the next one, so a wave stays full however uneven the lengths are.
+//
+//   * work distribution: blocks take ranges of `blockGrab` strings from one global counter (a few thousand atomics
+//     per launch, not one per wave: same-address device atomics run at well under 100 per microsecond); waves take
+//     64 strings at a time from their block's range in LDS; lanes take single strings from their wave's range by
+//     ballot + mbcnt.
+//   * every lane walks its string in windows of up to 128 bytes (8 x global_load_dwordx4 from its own address).  A
+//     window starts at the string's current byte whatever its alignment, so a string of <= 128 bytes is ONE window; a
+//     longer string cuts its first window at a 16-byte boundary and is aligned from then on.  The window of the NEXT iteration -- the same string's next 128 bytes, or the first window of
+//     the lane's pending next string, whose offsets were fetched an iteration earlier -- is in flight while the
+//     current one is walked; nothing on the common path makes the compiler wait for memory during the walk (the
+//     end-of-string records of the hot states are in LDS for that reason).
+//   * a window is walked as whole 16-byte chunks with the LDS fast path of the tiled kernel, then ONE pass for the
+//     <= 15 bytes behind the last whole chunk of every lane that has some: each lane picks its chunk, walks all 16
+//     bytes unrolled and keeps the state after its last real byte (no loop, no branches).
+//   * nothing is read past the 16-byte block that holds the last byte of the text: a window that would reach further
+//     is walked byte by byte from memory instead.
+
+struct RaggedWork {
+	unsigned long long next, end;   // the block's current range of string indices
+	uint32_t lock, exhausted;
+	uint32_t pad[2];
+};
+static_assert(kRaggedFinBytes + sizeof(RaggedWork) == kRaggedLdsExtra, "LDS budget of the warm rows (internal.h)");
+
+__device__ __forceinline__ void IssueTileLane(u32x4 (&r)[8], uint64_t src)
+{
+	asm volatile(
+		"global_load_dwordx4 %0, %8, off\n\t"
+		"global_load_dwordx4 %1, %8, off offset:16\n\t"
+		"global_load_dwordx4 %2, %8, off offset:32\n\t"
+		"global_load_dwordx4 %3, %8, off offset:48\n\t"
+		"global_load_dwordx4 %4, %8, off offset:64\n\t"
+		"global_load_dwordx4 %5, %8, off offset:80\n\t"
+		"global_load_dwordx4 %6, %8, off offset:96\n\t"
+		"global_load_dwordx4 %7, %8, off offset:112"
+		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+		: "v"(src));
+}
+
+__device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
+{
+	asm volatile("s_waitcnt vmcnt(0)"
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+}
+
+// Exact walk of the first `count` (0..15) bytes of v; lanes with a smaller count idle (one rolled loop per wave).
+__device__ __forceinline__ uint32_t SlowPartial(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
+                                                uint32_t st, uint32_t count)
+{
+#pragma unroll 1
+	for (uint32_t i = 0; __any(i < count); ++i) {
+		if (i < count)
+			st = SlowStep(p, lds, L, st, v.x & 0xFF);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return st;
+}
+
+// The first `count` (0..15) bytes of v through the LDS fast path: the whole chunk is walked, unrolled like StepChunk,
+// and the state after byte `count` is kept (v_cmp + v_cndmask per byte, no loop, no branches); lanes with count == 0
+// keep their state.  What the walk reads past `count` is ignored.  Exact re-walk on a trap like StepChunk.
+__device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
+                                            uint32_t count, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
+{
+	const uint32_t hs0 = hs;
+	uint32_t h = hs, snap = hs;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
+		snap = count == uint32_t(4 * w + 1) ? h : snap;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
+		snap = count == uint32_t(4 * w + 2) ? h : snap;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
+		snap = count == uint32_t(4 * w + 3) ? h : snap;
+		if (w < 3) {
+			h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
+			snap = count == uint32_t(4 * w + 4) ? h : snap;
+		}
+	}
+	hs = snap;
+	if (count != 0 && hs == p.hot && !(p.flags & kDebugNoTrap)) {
+		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+		uint32_t f = p.compact;
+		if (st0 < p.compact)
+			f = CompactPartial(p, L, v, st0, count);
+		if (f == p.compact)
+			f = SlowPartial(p, lds, L, v, st0, count);
+		if (f < p.hot) {
+			hs = f;
+		} else {
+			hs = p.hot;
+			cold = f;
+			if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
+				atomicAdd(&p.visitCold[f], 1u);
+		}
+	}
+}
+
+__device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
+                                             uint32_t s, bool active, uint32_t st)
+{
+	u32x4 raw = {0, 0, 0, 0};
+	if (active) {
+		if (st < p.hot) {
+			raw = *reinterpret_cast<const u32x4*>(&finHot[st]);
+		} else {
+			const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+			raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+		}
+	}
+	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
+	if (active) {
+		if (p.outIdx)
+			p.outIdx[s] = orig;
+		if (p.outFinal)
+			p.outFinal[s] = fl & kFinal;
+	}
+	if (p.outCounts) {
+		uint32_t* cnt = reinterpret_cast<uint32_t*>(lds + L.countsOff);
+		const int lane = threadIdx.x & 63;
+		const unsigned long long finals = __ballot(active && (fl & kFinal));
+		const unsigned long long actives = __ballot(active);
+		if (lane == 0) {
+			atomicAdd(&cnt[0], (uint32_t)__popcll(finals));
+			atomicAdd(&cnt[1], (uint32_t)__popcll(actives));
+		}
+		if (p.acceptMaskPerm) {
+			// only ended strings that accept anything get here: most ends accept nothing
+			const uint64_t m = active ? ((uint64_t(raw.w) << 32) | raw.z) : 0;
+			if (__any(m != 0))
+				for (uint32_t r = 0; r < p.regexps; ++r) {
+					const unsigned long long b = __ballot((m >> r) & 1);
+					if (lane == 0 && b)
+						atomicAdd(&cnt[2 + r], (uint32_t)__popcll(b));
+				}
+		} else if (active) {
+			for (uint64_t k = p.acceptOffPerm[endPerm]; k < p.acceptOffPerm[endPerm + 1]; ++k)
+				atomicAdd(&cnt[2 + p.acceptIds[k]], 1u);
+		}
+	}
+}
+
+// Per-lane walking state of the ragged kernel.
+struct RaggedLane {
+	uint64_t pos, end;   // absolute addresses of the unread part of the current string
+	uint32_t sIdx;
+	uint32_t hs, cold;
+	bool busy;           // has a current string
+	bool loaded;         // the current window is in the tile registers (else: walk it from memory)
+	// pending next string: its offsets are fetched one iteration before it starts
+	uint64_t pendPos, pendEnd;
+	uint32_t sIdxN;
+	bool pend;
+};
+
+// Wave-uniform range of strings still to hand out, refilled from the block's range, refilled from the global counter.
+struct RaggedRange {
+	uint64_t next, end;
+	bool exhausted;
+};
+
+__device__ __forceinline__ void GrabWaveRange(const ScanParams& p, volatile RaggedWork* work,
+                                              unsigned long long* workCounter, uint32_t blockGrab, RaggedRange& R)
+{
+	unsigned long long r0 = 0, r1 = 0;
+	if ((threadIdx.x & 63) == 0) {
+		while (atomicCAS(const_cast<uint32_t*>(&work->lock), 0u, 1u) != 0u)
+			__builtin_amdgcn_s_sleep(2);
+		unsigned long long nx = work->next, en = work->end;
+		if (nx >= en && !work->exhausted) {
+			const unsigned long long base = atomicAdd(workCounter, (unsigned long long)blockGrab);
+			if (base >= p.n) {
+				work->exhausted = 1;
+			} else {
+				nx = base;
+				en = base + blockGrab < p.n ? base + blockGrab : p.n;
+			}
+		}
+		const unsigned long long take = en - nx < 64 ? en - nx : 64;
+		r0 = nx;
+		r1 = nx + take;
+		work->next = r1;
+		work->end = en;
+		__threadfence_block();
+		atomicExch(const_cast<uint32_t*>(&work->lock), 0u);
+	}
+	R.next = Uniform64(r0);
+	R.end = Uniform64(r1);
+	R.exhausted = R.next >= R.end;
+}
+
+// Give every lane without a pending string the next unassigned one.  Returns (per lane) whether it got one.
+__device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile RaggedWork* work,
+                                              unsigned long long* workCounter, uint32_t blockGrab, RaggedRange& R,
+                                              RaggedLane& S)
+{
+	bool need = !S.pend, got = false;
+	for (;;) {
+		const unsigned long long mask = __ballot(need);
+		if (!mask)
+			break;
+		if (R.next >= R.end) {
+			if (R.exhausted)
+				break;
+			GrabWaveRange(p, work, workCounter, blockGrab, R);
+			if (R.exhausted)
+				break;
+		}
+		const uint64_t avail = R.end - R.next;
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0));
+		if (need && rank < avail) {
+			S.sIdxN = uint32_t(R.next) + rank;
+			S.pend = true;
+			need = false;
+			got = true;
+		}
+		const uint64_t want = uint64_t(__popcll(mask));
+		R.next += want < avail ? want : avail;
+	}
+	return got;
+}
+
+// One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
+// Returns false when the wave has nothing left to do.
+__device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
+                                            volatile RaggedWork* work, unsigned long long* workCounter,
+                                            uint32_t blockGrab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
+                                            RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter)
+{
+	WaitAllLoads(cur);
+
+	// ---- this window: starts at the string's current byte, whatever its alignment.  A string that fits takes one
+	// window; a longer one cuts its first window at a 16-byte boundary so that all the following ones are aligned.
+	const uint64_t left = S.end - S.pos;
+	const uint32_t nb = !S.busy ? 0u : left <= 128u ? uint32_t(left) : 128u - (uint32_t(S.pos) & 15u);
+	const bool ends = S.busy && nb == left;
+
+	// ---- the next window: the same string's next bytes, or the pending string's first window
+	const bool cont = S.busy && !ends;
+	const bool takeNew = !cont && S.pend;
+	const uint64_t nPos = cont ? S.pos + nb : S.pendPos;
+	const uint64_t nEnd = cont ? S.end : S.pendEnd;
+	const uint32_t nIdx = cont ? S.sIdx : S.sIdxN;
+	const bool nBusy = cont || takeNew;
+	const bool nLoad = nBusy && nEnd > nPos && nPos + 128 <= safeEnd;
+	// unconditional (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
+	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives
+	if (!(p.flags & kDebugNoRefill))
+		IssueTileLane(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows));
+	if (takeNew)
+		S.pend = false;
+	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
+	// end of this iteration, so the one wait the compiler inserts for them sits behind the walk
+	const bool got = AssignPending(p, work, workCounter, blockGrab, R, S);
+	uint64_t offB = 0, offE = 0;
+	if (__any(got)) {
+		const uint64_t* offPtr = p.offsets + (got ? S.sIdxN : 0u);
+		offB = offPtr[0];
+		offE = offPtr[1];
+	}
+
+	// ---- walk the current window
+	if ((threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
+	if (p.flags & kDebugNoStep) {
+		// timing experiments: no walk at all
+	} else if (__any(nb != 0)) {
+		if (__any(nb != 0 && S.loaded)) {
+			const uint32_t nbl = S.loaded ? nb : 0u;
+			const uint32_t full = nbl >> 4, tail = nbl & 15u;
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				if (uint32_t(k) < full)
+					StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
+				// all the partial last chunks of the wave in ONE pass: pick each lane's chunk, walk it with a snapshot
+				u32x4 v = cur[0];
+#pragma unroll
+				for (int k = 1; k < 8; ++k)
+					if (full == uint32_t(k))
+						v = cur[k];
+				StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
+			}
+		}
+		if (nb != 0 && !S.loaded) {
+			// the last bytes of the whole buffer: exact steps straight from memory
+			uint32_t st = S.hs != p.hot ? S.hs : S.cold;
+			const uint8_t* q = reinterpret_cast<const uint8_t*>(S.pos);
+			for (uint32_t i = 0; i < nb; ++i)
+				st = SlowStep(p, lds, L, st, q[i]);
+			S.hs = st < p.hot ? st : p.hot;
+			S.cold = st;
+		}
+	}
+	if (__any(ends) && !(p.flags & kDebugNoFinish))
+		FinishRagged(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
+
+	// ---- move on
+	if (got) {
+		S.pendPos = textBase + offB;
+		S.pendEnd = textBase + offE;
+	}
+	if (takeNew) {
+		const uint32_t st = StartState(p, nIdx);
+		S.hs = st < p.hot ? st : p.hot;
+		S.cold = st;
+	}
+	S.pos = nPos;
+	S.end = nEnd;
+	S.sIdx = nIdx;
+	S.busy = nBusy;
+	S.loaded = nLoad;
+	return __any(nBusy || S.pend);
+}
+
+__global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned long long* workCounter,
+                                                         uint32_t blockGrab)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
+	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
+	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + L.total + kRaggedFinBytes);
+	{
+		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+			finHot[i] = recs[i];
+		if (threadIdx.x == 0) {
+			work->next = 0;
+			work->end = 0;
+			work->lock = 0;
+			work->exhausted = 0;
+		}
+	}
+	LoadTableToLds(p, lds, L);   // ends with a barrier
+
+	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
+	const uint64_t safeEnd = (textBase + p.offsets[p.n] + 15) & ~uint64_t(15);
+
+	RaggedRange R = {0, 0, false};
+	RaggedLane S;
+	S.pos = S.end = textBase;
+	S.sIdx = 0;
+	S.hs = S.cold = 0;
+	S.busy = S.loaded = S.pend = false;
+	S.sIdxN = 0;
+	S.pendPos = S.pendEnd = textBase;
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+
+	if (AssignPending(p, work, workCounter, blockGrab, R, S)) {
+		S.pendPos = textBase + p.offsets[S.sIdxN];
+		S.pendEnd = textBase + p.offsets[S.sIdxN + 1];
+	}
+	for (uint32_t iter = 0;; iter += 2) {
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, blockGrab, textBase, safeEnd, R, S, a, b, iter))
+			break;
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, blockGrab, textBase, safeEnd, R, S, b, a, iter + 1))
+			break;
+	}
+	FlushCounts(p, lds, L);
+}
+
+
+// ------------------------------------------------------------------------------------------ launcher
+
+bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
+{
+	// one string per lane with dynamic re-assignment: worth it from a few waves' worth of strings
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096;
+}
+
+int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	hipError_t e = hipMemsetAsync(workCounter, 0, sizeof(unsigned long long), stream);
+	if (e != hipSuccess)
+		return HipFail(e, "hipMemsetAsync(work counter)");
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
+	const uint32_t ldsBytes = L.total + kRaggedLdsExtra;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	// one string per lane: spread the waves over every CU before stacking them (4..16 waves per block, 1 block per CU)
+	const uint64_t waves = (p.n + 63) / 64;
+	const uint64_t wavesPerBlock = std::min<uint64_t>(16, std::max<uint64_t>(4, (waves + cus - 1) / cus));
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), (waves + wavesPerBlock - 1) / wavesPerBlock));
+	// strings a block takes from the global counter at a time: ~8 grabs per block keep the tail balanced; batches
+	// that barely fill the lanes are simply split evenly
+	const uint64_t perBlock = (p.n + blocks - 1) / blocks, lanes = wavesPerBlock * 64;
+	uint64_t grab = std::min<uint64_t>(16384, std::max<uint64_t>(perBlock / 8, std::min(perBlock, lanes)));
+	grab = (grab + 63) / 64 * 64;
+	ScanParams q = p;
+	if (const char* dbg = getenv("PIRE_HIP_DEBUG_RAGGED")) {   // timing experiments: 1 no partial passes, 2 no finish, 4 no traps
+		const int m = atoi(dbg);
+		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
+		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
+	}
+	hipLaunchKernelGGL(ScanRaggedKernel, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream, q,
+	                   workCounter, uint32_t(grab));
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "ragged kernel launch");
+	return PIRE_HIP_OK;
+}
+
+
+}  // namespace pirehip

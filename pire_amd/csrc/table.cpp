@@ -104,7 +104,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
 	// inside the hot set the order is free: non-final states first, so that "hot and Final" is one compare
-	// (HalfFinalScanner's per-step TakeAction, kernels.hip HalfFinalKernel)
+	// (HalfFinalScanner's per-step TakeAction, exact.hip HalfFinalKernel)
 	std::stable_partition(order.begin(), order.begin() + t.hot, [&](uint32_t s) { return !(t.flags[s] & kFinal); });
 	t.hotFinalLo = 0;
 	while (t.hotFinalLo < t.hot && !(t.flags[order[t.hotFinalLo]] & kFinal))

@@ -1,0 +1,308 @@
+// The tiled kernel (fixed-length records): the benchmark kernel of the path.  DESIGN.md section 4.3.
+
+#include "device_common.h"
+
+namespace pirehip {
+
+// ------------------------------------------------------------------------------------------ tiled kernel
+// Fixed-length records, 16-byte aligned.  Each lane streams ITS OWN string straight from HBM in 128-byte
+// tiles (8 x global_load_dwordx4 = exactly one cache line per lane per tile), double-buffered in VGPRs, and
+// walks the tile out of registers with one LDS gather per byte.  No LDS staging: measured on MI355X
+// (profiles/micro_loadpath_r01.log) the per-lane line-sized access streams at the same ~6.2 TB/s as a fully
+// coalesced read, so all of the LDS is left for the table.
+
+// ---- tile loads -------------------------------------------------------------------------------------------
+// A tile is 128 bytes (one cache line) of each of the wave's 64 strings.  It is fetched with 8 x
+// global_load_dwordx4 in which EIGHT ADJACENT LANES COVER ONE WHOLE LINE: instruction j, lane l reads
+//     chunk (l & 7) of string  s0 + (l & ~7) + j        (16 bytes)
+// so every instruction touches 8 full lines instead of 64 partial ones.  Measured on MI355X
+// (profiles/r01_pmc_summary_strided_16w_nbuf3.txt): with one-line-per-lane loads the L1 (TCP) tag pipeline was the
+// binding unit -- TA busy 75 %, TA stalled by TC 56 %, 0.63 lane-accesses/clk/CU -- and `nt` could not be used
+// because each line was touched by 8 separate instructions.  With whole-line instructions the same bytes cost
+// 1/8 of the L1 accesses and stream with `nt`.
+// After the loads, lane 8g+k holds in register j chunk k of string 8g+j; an 8x8 transpose across each group of 8
+// lanes (TransposeTile, DPP only, no LDS) leaves lane 8g+j with chunks 0..7 of its own string in registers 0..7.
+//
+// The loads are issued from inline asm and waited for with hand-counted s_waitcnt vmcnt(N).  Reason (measured,
+// DESIGN.md section 6): hipcc's own wait insertion turns every loop-carried prefetch into `s_waitcnt vmcnt(0)` at
+// the tile boundary, which collapses an N-deep register pipeline to depth 1.  Counting is safe with foreign VMEM
+// ops in the queue: loads return in order among themselves, so "at most 8*k outstanding" implies every load issued
+// before the last k tiles has landed; extra compiler-issued ops only make the wait stricter.
+// "+v": the tile registers are updated IN PLACE, so the compiler has no reason to copy a slot that is in flight.
+template <bool NT>
+__device__ __forceinline__ void IssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride)
+{
+	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
+	if (NT)
+		asm volatile(
+			"global_load_dwordx4 %0, %8, %9 nt\n\t"
+			"global_load_dwordx4 %1, %8, %10 nt\n\t"
+			"global_load_dwordx4 %2, %8, %11 nt\n\t"
+			"global_load_dwordx4 %3, %8, %12 nt\n\t"
+			"global_load_dwordx4 %4, %8, %13 nt\n\t"
+			"global_load_dwordx4 %5, %8, %14 nt\n\t"
+			"global_load_dwordx4 %6, %8, %15 nt\n\t"
+			"global_load_dwordx4 %7, %8, %16 nt"
+			: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+			: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+	else
+		asm volatile(
+			"global_load_dwordx4 %0, %8, %9\n\t"
+			"global_load_dwordx4 %1, %8, %10\n\t"
+			"global_load_dwordx4 %2, %8, %11\n\t"
+			"global_load_dwordx4 %3, %8, %12\n\t"
+			"global_load_dwordx4 %4, %8, %13\n\t"
+			"global_load_dwordx4 %5, %8, %14\n\t"
+			"global_load_dwordx4 %6, %8, %15\n\t"
+			"global_load_dwordx4 %7, %8, %16"
+			: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+			: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+}
+
+// Wait until at most TILES_BEHIND tiles issued after `r` are still in flight; names r so nothing reads it earlier.
+template <int TILES_BEHIND>
+__device__ __forceinline__ void WaitTile(u32x4 (&r)[8])
+{
+	asm volatile("s_waitcnt vmcnt(%8)"
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+	             : "n"(TILES_BEHIND * 8));
+}
+
+// One butterfly stage of the 8x8 transpose: exchange (register bit D) with (lane bit D) for the pair x = reg k,
+// y = reg k|D:   x'[l] = (l & D) ? y[l ^ D] : x[l],    y'[l] = (l & D) ? y[l] : x[l ^ D].
+// D = 4: two bank-masked DPP moves (row_shr:4 into banks 1,3; row_shl:4 into banks 0,2).
+__device__ __forceinline__ void Butterfly4(uint32_t& x, uint32_t& y)
+{
+	const uint32_t nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
+	const uint32_t ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
+	x = nx;
+	y = ny;
+}
+
+// D = 1 or 2: the partner lane sits in the same quad; one FUSED v_cndmask_b32_dpp per output (hipcc does not form
+// it from v_mov_dpp + v_cndmask: the select mask would have to be inverted for half of them).  `lo` = lanes whose
+// bit D is clear, `hi` = lanes whose bit D is set (64-bit wave masks).  Four pairs per statement, one column.
+#define PIRE_BFLY_QUAD(PERM)                                                                                           \
+	asm volatile("s_nop 1\n\t"                                                                                     \
+	             "s_mov_b64 vcc, %16\n\t"                                                                           \
+	             "v_cndmask_b32_dpp %0, %9, %8, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
+	             "v_cndmask_b32_dpp %2, %11, %10, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %4, %13, %12, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %6, %15, %14, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "s_mov_b64 vcc, %17\n\t"                                                                           \
+	             "v_cndmask_b32_dpp %1, %8, %9, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
+	             "v_cndmask_b32_dpp %3, %10, %11, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %5, %12, %13, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
+	             "v_cndmask_b32_dpp %7, %14, %15, vcc " PERM " row_mask:0xf bank_mask:0xf"                          \
+	             : "=&v"(nx0), "=&v"(ny0), "=&v"(nx1), "=&v"(ny1), "=&v"(nx2), "=&v"(ny2), "=&v"(nx3), "=&v"(ny3)    \
+	             : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "s"(lo), "s"(hi)          \
+	             : "vcc")
+
+// v_cndmask: D = vcc ? src1 : src0, DPP permutes src0.  With vcc = lo:  x' = lo ? x : perm(y);  with vcc = hi:
+// y' = hi ? y : perm(x).
+template <int D>
+__device__ __forceinline__ void ButterflyQuad4(uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1, uint32_t& x2,
+                                               uint32_t& y2, uint32_t& x3, uint32_t& y3, uint64_t lo, uint64_t hi)
+{
+	uint32_t nx0, ny0, nx1, ny1, nx2, ny2, nx3, ny3;
+	if (D == 1)
+		PIRE_BFLY_QUAD("quad_perm:[1,0,3,2]");
+	else
+		PIRE_BFLY_QUAD("quad_perm:[2,3,0,1]");
+	x0 = nx0; y0 = ny0; x1 = nx1; y1 = ny1; x2 = nx2; y2 = ny2; x3 = nx3; y3 = ny3;
+}
+
+__device__ __forceinline__ void TransposeTile(u32x4 (&r)[8], uint32_t lane)
+{
+	(void)lane;
+	const uint64_t lo1 = 0x5555555555555555ull, hi1 = 0xAAAAAAAAAAAAAAAAull;   // lane bit 0 clear / set
+	const uint64_t lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;   // lane bit 1 clear / set
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		uint32_t d[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			d[k] = r[k][w];
+		ButterflyQuad4<1>(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], lo1, hi1);
+		ButterflyQuad4<2>(d[0], d[2], d[1], d[3], d[4], d[6], d[5], d[7], lo2, hi2);
+		Butterfly4(d[0], d[4]); Butterfly4(d[1], d[5]); Butterfly4(d[2], d[6]); Butterfly4(d[3], d[7]);
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+			r[k][w] = d[k];
+		__builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the transpose's temporaries to ~10 VGPRs
+	}
+}
+
+// The hot rows sit at LDS byte address 0 (the kernels declare no static __shared__, so the dynamic region
+// starts at 0): the v_perm result IS the ds_read address, with no base add in the dependent chain.
+
+template <int ROT>
+__device__ __forceinline__ void StepTile(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                         const u32x4 (&r)[8], uint32_t& hs, uint32_t& cold, uint32_t tile)
+{
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		StepChunk<ROT>(p, lds, L, r[k], hs, cold, (tile * 8 + k) & 63);
+}
+
+// Wave-wide early out (north_star: "wavefront ballot/any for early-out on dead states"): once every lane sits
+// in a row whose every transition is a self loop, the rest of the text cannot change any state.  This is the
+// GPU counterpart of the NO_EXIT_MASK return of multi.h:955-958, 979-982.
+__device__ __forceinline__ bool AllAbsorbing(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t hs)
+{
+	const bool a = hs != p.hot && (lds[L.flagsOff + hs] & kAbsorbing);
+	return __all(a);
+}
+
+
+template <int NBUF, bool NT, int ROT>
+__device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
+                                      uint64_t chainBase, uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile,
+                                      u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
+{
+	// Refill target: the next tile of this task, or -- on the task's last tile -- tile 0 of the wave's NEXT task
+	// (chainBase; equals this task's last tile when there is nothing to chain to), so that neither the HBM
+	// latency of a task's first tile nor a duplicate load of its last tile is ever paid.
+	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
+	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
+		IssueTile<NT>(refill, voff, ahead, p.stride);
+	WaitTile<NBUF - 1>(cur);
+	TransposeTile(cur, lane);
+	if (lane == (t & 63) && !(p.flags & kDebugNoHist))   // visit sample: one lane per wave per tile, rotating
+		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs, 1u);
+	if (p.flags & kDebugNoStep) {      // measurement knob only (PIRE_HIP_DEBUG_NOSTEP): stream + transpose, no walk
+		hs ^= (cur[0].x ^ cur[7].w) & 1;
+		return;
+	}
+	StepTile<ROT>(p, lds, L, cur, hs, cold, t);
+}
+
+// Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
+// the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
+// gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
+template <int WAVES, int NBUF, bool NT, int MINW, int ROT>
+__global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
+{
+	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
+	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
+	static_assert(NBUF == 2, "ring depth");
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT == 1 ? kRotPitch : 256u, CompactBytes(p));
+	LoadTableToLds(p, lds, L);
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = p.n / 64;                // whole tasks only
+	const uint32_t ntiles = uint32_t(p.len / 128);   // >= 1 (TiledEligible)
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t groups = ntiles / NBUF;
+	const uint32_t rem = ntiles % NBUF;
+	// per-lane byte offset inside a task's tile: string (lane & ~7) [+ j per instruction], chunk (lane & 7)
+	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
+
+	// Ring slots: tile t lives in slot t % 2.
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+
+	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
+	const bool chain = rem == 0;
+	bool primed = false;   // slot a already holds (or is receiving) tile 0 of the task about to start
+	const uint64_t taskStep = uint64_t(gridDim.x) * WAVES;
+	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += taskStep) {
+		const uint64_t s0 = task * 64;
+		const uint64_t s = s0 + lane;
+		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
+		const bool hasNext = chain && task + taskStep < ntasks;
+		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
+		                                   : rowBase + uint64_t(lastTile) * 128;
+
+		uint32_t cold = StartState(p, s);
+		uint32_t hs = cold < p.hot ? cold : p.hot;
+
+		bool done = false;
+		if (!primed)
+			IssueTile<NT>(a, voff, rowBase, p.stride);
+		for (uint32_t g = 0; g < groups && !done; ++g) {
+			const uint32_t t = g * 2;
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t, lastTile, a, b, hs, cold);
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
+			done = AllAbsorbing(p, lds, L, hs);
+		}
+		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
+		if (!done && rem == 1) {
+			WaitTile<0>(a);
+			TransposeTile(a, lane);
+			StepTile<ROT>(p, lds, L, a, hs, cold, lastTile);
+		}
+
+		uint32_t st = hs != p.hot ? hs : cold;
+		// tail shorter than a tile: exact steps straight from memory
+		if (!done) {
+			const uint8_t* base = p.text + s * p.stride;
+			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
+				st = SlowStep(p, lds, L, st, base[i]);
+		}
+		Finish(p, lds, L, s, true, st);
+	}
+	FlushCounts(p, lds, L);
+}
+
+
+// ------------------------------------------------------------------------------------------ launcher
+
+bool TiledEligible(const ScanParams& p)
+{
+	return p.offsets == nullptr && p.n >= 64 && p.len >= 128 && (p.stride % 16) == 0 && p.stride * 64 < (1ull << 31) &&
+	       (reinterpret_cast<uintptr_t>(p.text) % 16) == 0;
+}
+
+int LaunchTiled(const ScanParams& p, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	// Variant knob for A/B measurements; the default is the measured best.
+	static const int variant = [] {
+		const char* v = getenv("PIRE_HIP_TILED_VARIANT");
+		return v ? atoi(v) : 0;
+	}();
+	static const bool noload = getenv("PIRE_HIP_DEBUG_NOLOAD") != nullptr;
+	ScanParams q = p;
+	static const bool nostep = getenv("PIRE_HIP_DEBUG_NOSTEP") != nullptr;
+	if (noload)
+		q.flags |= kDebugNoRefill;
+	if (nostep)
+		q.flags |= kDebugNoStep;
+	if (getenv("PIRE_HIP_DEBUG_NOCOLDCOUNT"))
+		q.flags |= kDebugNoColdCount;
+	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
+		q.flags |= kDebugNoHist;
+	if (variant == 1)
+		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
+	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
+	int rc;
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(q));
+	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(q));
+	switch (variant) {
+	case 1:  rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 1>, q, 1024, L.total, stream); break;   // bank-rotated rows
+	case 2:  rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream); break; // no nt
+	default: rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream); break;
+	}
+	if (rc != PIRE_HIP_OK || q.n == p.n)
+		return rc;
+	ScanParams tail = p;
+	tail.flags &= ~(kDebugNoRefill | kDebugNoStep | kDebugNoColdCount | kDebugNoHist);
+	tail.n = p.n - q.n;
+	tail.text = p.text + q.n * p.stride;
+	if (p.initIdx)
+		tail.initIdx = p.initIdx + q.n;
+	if (p.outIdx)
+		tail.outIdx = p.outIdx + q.n;
+	if (p.outFinal)
+		tail.outFinal = p.outFinal + q.n;
+	return LaunchGeneric(tail, stream);
+}
+
+
+}  // namespace pirehip
