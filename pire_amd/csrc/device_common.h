@@ -44,31 +44,66 @@ constexpr uint32_t kDebugNoPartial = 1u << 26;   // ragged kernel timing experim
 constexpr uint32_t kDebugNoFinish = 1u << 25;
 constexpr uint32_t kDebugNoTrap = 1u << 24;
 
+// Block-wide copy of `count16` 16-byte units from global memory to LDS with up to BATCH loads per thread in flight
+// before the first store: a copy loop that waits for every single load pays one memory latency per iteration, and at
+// kernel start (cold caches, 256 blocks asking at once) that added up to tens of microseconds per launch.
+template <int BATCH>
+__device__ __forceinline__ void CopyToLds16(uint8_t* dst, const void* src, uint32_t count16)
+{
+	const u32x4* s = reinterpret_cast<const u32x4*>(src);
+	u32x4* d = reinterpret_cast<u32x4*>(dst);
+	for (uint32_t base = threadIdx.x; base < count16; base += blockDim.x * BATCH) {
+		u32x4 v[BATCH];
+#pragma unroll
+		for (int k = 0; k < BATCH; ++k) {
+			const uint32_t i = base + uint32_t(k) * blockDim.x;
+			if (i < count16)
+				v[k] = s[i];
+		}
+#pragma unroll
+		for (int k = 0; k < BATCH; ++k) {
+			const uint32_t i = base + uint32_t(k) * blockDim.x;
+			if (i < count16)
+				d[i] = v[k];
+		}
+	}
+}
+
 // Cooperative load of the LDS-resident part of the table.
 __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
 {
 	const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-	// dense rows: 256-byte rows in HBM, `pitch`-byte rows in LDS (dword copies: 260 is only 4-byte aligned)
-	const uint32_t* src = reinterpret_cast<const uint32_t*>(p.hotRows);
-	uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
-	const uint32_t pitchDw = L.pitch / 4;
-	for (uint32_t i = tid; i < (p.hot + 1) * 64; i += nthr)
-		dst[(i >> 6) * pitchDw + (i & 63)] = src[i];
-	for (uint32_t i = tid; i < 256 / 4; i += nthr)
-		reinterpret_cast<uint32_t*>(lds + L.flagsOff)[i] = reinterpret_cast<const uint32_t*>(p.hotFlags)[i];
-	for (uint32_t i = tid; i < 264 / 2; i += nthr)
-		reinterpret_cast<uint32_t*>(lds + L.clsOff)[i] = reinterpret_cast<const uint32_t*>(p.cls)[i];
+	// the small pieces: fetched first, stored last, so that their latency hides behind the big copies
+	uint32_t flagsWord = 0, clsWord = 0, cls8 = 0;
+	if (tid < 256 / 4)
+		flagsWord = reinterpret_cast<const uint32_t*>(p.hotFlags)[tid];
+	if (tid < 264 / 2)
+		clsWord = reinterpret_cast<const uint32_t*>(p.cls)[tid];
+	if (p.compact && tid < 256)
+		cls8 = p.cls[tid];
+	if (L.pitch == 256) {
+		CopyToLds16<8>(lds, p.hotRows, (p.hot + 1) * 16);
+	} else {
+		// 260-byte pitch (bank-rotated variant): 256-byte rows in HBM, dword copies
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(p.hotRows);
+		uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
+		const uint32_t pitchDw = L.pitch / 4;
+		for (uint32_t i = tid; i < (p.hot + 1) * 64; i += nthr)
+			dst[(i >> 6) * pitchDw + (i & 63)] = src[i];
+	}
+	if (p.compact)
+		CopyToLds16<8>(lds + L.compactOff, p.compactRows, L.compactBytes / 16);
+	if (tid < 256 / 4)
+		reinterpret_cast<uint32_t*>(lds + L.flagsOff)[tid] = flagsWord;
+	if (tid < 264 / 2)
+		reinterpret_cast<uint32_t*>(lds + L.clsOff)[tid] = clsWord;
+	if (p.compact && tid < 256)
+		lds[L.cls8Off + tid] = uint8_t(2 * cls8);
 	if (p.outCounts)
 		for (uint32_t i = tid; i < p.regexps + 2; i += nthr)
 			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
 	for (uint32_t i = tid; i < 256; i += nthr)
 		reinterpret_cast<uint32_t*>(lds + L.histOff)[i] = 0;
-	if (p.compact) {
-		for (uint32_t i = tid; i < L.compactBytes / 16; i += nthr)
-			reinterpret_cast<u32x4*>(lds + L.compactOff)[i] = reinterpret_cast<const u32x4*>(p.compactRows)[i];
-		for (uint32_t i = tid; i < 256; i += nthr)
-			lds[L.cls8Off + i] = uint8_t(2 * p.cls[i]);
-	}
 	__syncthreads();
 }
 
