@@ -274,12 +274,15 @@ int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64
  * through LoadedScanner::Save (scanner_io.cpp:172-189) with the same header, so the caller says which TakeAction
  * the table was built for: PIRE_HIP_COUNTING_BASIC = CountingScanner (increment, then reset; count.h:251-257),
  * PIRE_HIP_COUNTING_ADVANCED = AdvancedCountingScanner (reset, then increment; count.h:287-295).
+ * PIRE_HIP_COUNTING_NOGLUELIMIT = NoGlueLimitCountingScanner, whose blob also carries the action lists.
  * Pinned by tests/count_ut.cpp:95-200.
  */
 typedef struct pire_hip_counting_table pire_hip_counting_table;
 
 #define PIRE_HIP_COUNTING_BASIC 0
 #define PIRE_HIP_COUNTING_ADVANCED 1
+#define PIRE_HIP_COUNTING_NOGLUELIMIT 2   /* NoGlueLimitCountingScanner: its own Save() form (count.cpp:1009-1018), any
+                                            number of regexps; resets before increments (count.h:404-437) */
 
 typedef struct pire_hip_counting_info {
 	uint32_t states;    /* Size(), loaded.h:112 */

@@ -370,7 +370,7 @@ private:
 };
 
 /*
- * Batched Runner over a Pire::CountingScanner or Pire::AdvancedCountingScanner (extra/count.h; include <pire/extra.h>
+ * Batched Runner over a Pire::CountingScanner, AdvancedCountingScanner or NoGlueLimitCountingScanner (extra/count.h; include <pire/extra.h>
  * before this header): per string State::Result(r) for every glued regexp (count.h:206) after
  * Initialize + Begin() + Run() + End(), as tests/count_ut.cpp:54-63 drives them.
  */
@@ -385,6 +385,10 @@ template <>
 struct CountingKind<Pire::AdvancedCountingScanner> {
 	enum { Value = PIRE_HIP_COUNTING_ADVANCED };
 };
+template <>
+struct CountingKind<Pire::NoGlueLimitCountingScanner> {
+	enum { Value = PIRE_HIP_COUNTING_NOGLUELIMIT };
+};
 
 template <class CountScanner>
 class CountingBatchRunner {
@@ -393,7 +397,7 @@ public:
 	    : m_table(nullptr), m_regexps(sc.RegexpsCount()), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false)
 	{
 		std::ostringstream out;
-		sc.Save(&out);                                    // LoadedScanner::Save, scanner_io.cpp:172-189
+		sc.Save(&out);                                    // LoadedScanner::Save, scanner_io.cpp:172-189 / count.cpp:1009-1018
 		const std::string blob = out.str();
 		Check(pire_hip_counting_table_create(blob.data(), blob.size(), &m_table));
 	}

@@ -32,6 +32,8 @@ struct oracle_count {
 	loaded_locals m;
 	uint8_t letters[MAX_CHAR];
 	transition* jumps;
+	uint32_t type;          /* 4 LoadedScanner, 5 NoGlueLimitCountingScanner (common.h:39-40) */
+	uint32_t* actions;      /* type 5: Actions[0] = length, then per action: resets count, ids, increments count, ids */
 };
 
 /* CountingState, count.h:204-234 */
@@ -63,7 +65,8 @@ int oracle_count_load(const void* blob, size_t len, oracle_count** out, char* er
 		return fail(err, errlen, "EOF reached while loading scanner header");
 	memcpy(&h, p, sizeof(h));
 	/* type LoadedScanner = 4 (common.h:39); hdrsize = sizeof(Locals) */
-	if (h.magic != 0x45524950u || h.ptr_size != 8 || h.max_word_size != 16 || h.type != 4 || h.hdr_size != sizeof(loaded_locals))
+	if (h.magic != 0x45524950u || h.ptr_size != 8 || h.max_word_size != 16 || (h.type != 4 && h.type != 5) ||
+	    h.hdr_size != sizeof(loaded_locals))
 		return fail(err, errlen, "Serialized regexp incompatible with your system");
 	if (h.version != 7 && h.version != 6)
 		return fail(err, errlen, "You are trying to used an incompatible version of a serialized regexp");
@@ -76,7 +79,8 @@ int oracle_count_load(const void* blob, size_t len, oracle_count** out, char* er
 	memcpy(&sc->m, p + pos, sizeof(loaded_locals));           /* scanner_io.cpp:202 */
 	pos += sizeof(loaded_locals);
 	njumps = (size_t)sc->m.states_count * sc->m.letters_count;
-	if (sc->m.states_count == 0 || sc->m.letters_count == 0 || sc->m.regexps_count > MAX_RE_COUNT ||
+	sc->type = h.type;
+	if (sc->m.states_count == 0 || sc->m.letters_count == 0 || (h.type == 4 && sc->m.regexps_count > MAX_RE_COUNT) ||
 	    len < pos + MAX_CHAR + njumps * 8 + sc->m.states_count) {
 		free(sc);
 		return fail(err, errlen, "EOF reached while loading scanner buffer");
@@ -91,6 +95,27 @@ int oracle_count_load(const void* blob, size_t len, oracle_count** out, char* er
 	memcpy(sc->jumps, p + pos, njumps * sizeof(transition));   /* scanner_io.cpp:207 */
 	/* version 6 carries an extra, ignored action array; the tags follow (scanner_io.cpp:208-212): neither is used
 	 * by the counting scanners' Next/TakeAction */
+	pos += njumps * 8;
+	if (h.version == 6)
+		pos += align8(njumps * 4);
+	pos += align8(sc->m.states_count);
+	if (h.type == 5) {
+		/* NoGlueLimitCountingScanner::Load, count.cpp:1020-1035: u32 size (0 = no table), then size-1 more words */
+		uint32_t size;
+		if (len < pos + 4) {
+			oracle_count_free(sc);
+			return fail(err, errlen, "EOF reached while loading the action table");
+		}
+		memcpy(&size, p + pos, 4);
+		if (size) {
+			if (len < pos + (size_t)size * 4) {
+				oracle_count_free(sc);
+				return fail(err, errlen, "EOF reached while loading the action table");
+			}
+			sc->actions = (uint32_t*)malloc((size_t)size * 4);
+			memcpy(sc->actions, p + pos, (size_t)size * 4);
+		}
+	}
 	*out = sc;
 	return 0;
 }
@@ -99,6 +124,7 @@ void oracle_count_free(oracle_count* sc)
 {
 	if (sc) {
 		free(sc->jumps);
+		free(sc->actions);
 		free(sc);
 	}
 }
@@ -173,6 +199,38 @@ static inline void step(const oracle_count* sc, int kind, count_state* s, uint32
 	take_action(kind, s, x.action);
 }
 
+/* NoGlueLimitCountingScanner::TakeActionImpl, count.h:404-437, on NoGlueLimitCountingState (count.h:306-325):
+ * Reset(id): current = 0;  Increment(id): ++current, total = max(total, current).  Resets before increments. */
+static inline void noglue_take_action(const oracle_count* sc, uint32_t* current, uint32_t* total, uint32_t a)
+{
+	if (!a)
+		return;
+	if (sc->actions) {
+		const uint32_t* act = sc->actions + a;
+		uint32_t n;
+		for (n = *act++; n--;)
+			current[*act++] = 0;
+		for (n = *act++; n--;) {
+			const uint32_t id = *act++;
+			if (++current[id] > total[id])
+				total[id] = current[id];
+		}
+	} else {                       /* one regexp, no table: the raw Increment/Reset action bits (count.h:429-436) */
+		if (a & 2u)
+			current[0] = 0;
+		if (a & 1u)
+			if (++current[0] > total[0])
+				total[0] = current[0];
+	}
+}
+
+static inline void noglue_step(const oracle_count* sc, uint64_t* st, uint32_t* current, uint32_t* total, uint32_t ch)
+{
+	const transition x = sc->jumps[*st / 8 + sc->letters[ch]];   /* Next, count.h:148-153 */
+	*st += (uint64_t)(int64_t)(int32_t)x.shift;
+	noglue_take_action(sc, current, total, x.action);
+}
+
 void oracle_count_run(const oracle_count* sc, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                       uint32_t flags, uint32_t* out_idx, uint64_t* results)
 {
@@ -180,6 +238,29 @@ void oracle_count_run(const oracle_count* sc, int kind, const void* text, const 
 	const uint32_t R = sc->m.regexps_count;
 	uint64_t i, k;
 	uint32_t r;
+	if (kind == ORACLE_COUNT_NOGLUELIMIT) {
+		uint32_t* current = (uint32_t*)malloc(sizeof(uint32_t) * (R ? R : 1));
+		uint32_t* total = (uint32_t*)malloc(sizeof(uint32_t) * (R ? R : 1));
+		for (i = 0; i < n; ++i) {
+			uint64_t st = sc->m.initial;                                  /* Initialize, count.h:398-401 */
+			memset(current, 0, sizeof(uint32_t) * (R ? R : 1));
+			memset(total, 0, sizeof(uint32_t) * (R ? R : 1));
+			if (flags & 1)
+				noglue_step(sc, &st, current, total, BEGIN_MARK);
+			for (k = offsets[i]; k < offsets[i + 1]; ++k)
+				noglue_step(sc, &st, current, total, t[k]);
+			if (flags & 2)
+				noglue_step(sc, &st, current, total, END_MARK);
+			if (out_idx)
+				out_idx[i] = state_idx(sc, st);
+			if (results)
+				for (r = 0; r < R; ++r)
+					results[i * R + r] = current[r] > total[r] ? current[r] : total[r];
+		}
+		free(current);
+		free(total);
+		return;
+	}
 	for (i = 0; i < n; ++i) {
 		count_state s;
 		memset(&s, 0, sizeof(s));           /* Initialize, count.h:127-133 */

@@ -22,7 +22,12 @@ extern "C" {
 
 typedef struct oracle_count oracle_count;
 
-enum { ORACLE_COUNT_BASIC = 0 /* CountingScanner */, ORACLE_COUNT_ADVANCED = 1 /* AdvancedCountingScanner */ };
+enum {
+	ORACLE_COUNT_BASIC = 0,      /* CountingScanner */
+	ORACLE_COUNT_ADVANCED = 1,   /* AdvancedCountingScanner */
+	ORACLE_COUNT_NOGLUELIMIT = 2 /* NoGlueLimitCountingScanner: its own serialised form (type 5 + action lists), any
+	                                number of regexps (count.h:330-504, count.cpp:1009-1040) */
+};
 
 /* LoadedScanner::Load, scanner_io.cpp:195-215 + Header::Validate, scanners/common.h:65-77. */
 int oracle_count_load(const void* blob, size_t len, oracle_count** out, char* err, size_t errlen);

@@ -640,9 +640,10 @@ int pire_ref_half_run(void* hh, const void* text, const uint64_t* offsets, uint6
 
 extern "C++" {
 struct RefCount {
-	int kind;                               // 0 CountingScanner, 1 AdvancedCountingScanner
+	int kind;                               // 0 CountingScanner, 1 AdvancedCountingScanner, 2 NoGlueLimitCountingScanner
 	Pire::CountingScanner cs;
 	Pire::AdvancedCountingScanner as;
+	Pire::NoGlueLimitCountingScanner ns;
 };
 
 template <class Sc>
@@ -684,6 +685,11 @@ void* pire_ref_count_compile(int kind, const char* const* res, const char* const
 				h->as = i == 0 ? one : Pire::AdvancedCountingScanner::Glue(h->as, one);
 				if (i && h->as.Empty())
 					throw Pire::Error("AdvancedCountingScanner::Glue failed");
+			} else if (kind == 2) {
+				Pire::NoGlueLimitCountingScanner one(re, sep);
+				h->ns = i == 0 ? one : Pire::NoGlueLimitCountingScanner::Glue(h->ns, one);
+				if (i && h->ns.Empty())
+					throw Pire::Error("NoGlueLimitCountingScanner::Glue failed");
 			} else {
 				throw Pire::Error("unknown counting scanner kind");
 			}
@@ -703,8 +709,10 @@ void* pire_ref_count_load(int kind, const void* blob, size_t len)
 		Pire::MemoryInput in(static_cast<const char*>(blob), len);
 		if (kind == 0)
 			h->cs.Load(&in);                                         // LoadedScanner::Load, scanner_io.cpp:191-215
-		else
+		else if (kind == 1)
 			h->as.Load(&in);
+		else
+			h->ns.Load(&in);                                         // count.cpp:1020-1040
 		return h.release();
 	} catch (const std::exception& e) {
 		SetErr(e.what());
@@ -720,8 +728,10 @@ size_t pire_ref_count_save(void* hh, void* buf, size_t cap)         // LoadedSca
 	std::ostringstream out;
 	if (h->kind == 0)
 		h->cs.Save(&out);
-	else
+	else if (h->kind == 1)
 		h->as.Save(&out);
+	else
+		h->ns.Save(&out);                                            // count.cpp:1009-1018
 	const std::string s = out.str();
 	if (buf && cap >= s.size())
 		memcpy(buf, s.data(), s.size());
@@ -731,17 +741,17 @@ size_t pire_ref_count_save(void* hh, void* buf, size_t cap)         // LoadedSca
 size_t pire_ref_count_size(void* hh)
 {
 	RefCount* h = static_cast<RefCount*>(hh);
-	return h->kind == 0 ? h->cs.Size() : h->as.Size();
+	return h->kind == 0 ? h->cs.Size() : h->kind == 1 ? h->as.Size() : h->ns.Size();
 }
 size_t pire_ref_count_regexps(void* hh)
 {
 	RefCount* h = static_cast<RefCount*>(hh);
-	return h->kind == 0 ? h->cs.RegexpsCount() : h->as.RegexpsCount();
+	return h->kind == 0 ? h->cs.RegexpsCount() : h->kind == 1 ? h->as.RegexpsCount() : h->ns.RegexpsCount();
 }
 size_t pire_ref_count_letters(void* hh)
 {
 	RefCount* h = static_cast<RefCount*>(hh);
-	return h->kind == 0 ? h->cs.LettersCount() : h->as.LettersCount();
+	return h->kind == 0 ? h->cs.LettersCount() : h->kind == 1 ? h->as.LettersCount() : h->ns.LettersCount();
 }
 
 int pire_ref_count_run(void* hh, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
@@ -752,8 +762,10 @@ int pire_ref_count_run(void* hh, const void* text, const uint64_t* offsets, uint
 	auto range = [&](uint64_t lo, uint64_t hi) {
 		if (h->kind == 0)
 			CountRun(h->cs, t, offsets, lo, hi, flags, outIdx, results);
-		else
+		else if (h->kind == 1)
 			CountRun(h->as, t, offsets, lo, hi, flags, outIdx, results);
+		else
+			CountRun(h->ns, t, offsets, lo, hi, flags, outIdx, results);
 	};
 	if (threads <= 1) {
 		range(0, n);

@@ -31,12 +31,15 @@ struct CountingHost {
 	uint32_t states = 0, letters = 0, regexps = 0, initial = 0;
 	std::vector<uint8_t> letterOf;     // [264] m_letters
 	std::vector<uint64_t> trans;       // [states*letters] next state index | action << 32
+	uint32_t type = 4;                 // ScannerIOTypes: 4 LoadedScanner, 5 NoGlueLimitCountingScanner
+	std::vector<uint32_t> actions;     // type 5: [0] = length; per action: resets count, ids, increments count, ids
 };
 
 struct CountingDevice {
 	int device = -1;
 	uint8_t* letterOf = nullptr;
 	uint64_t* trans = nullptr;
+	uint32_t* actions = nullptr;
 };
 
 }  // namespace pirehip
@@ -57,6 +60,8 @@ struct CountingParams {
 	uint64_t n;
 	uint32_t* outIdx;
 	uint32_t* outResults;
+	const uint32_t* actions;   // NoGlueLimitCountingScanner action lists, or null (single regexp: raw action bits)
+	uint32_t* scratch;         // NoGlueLimit with more than 16 regexps: current[n][regexps]
 };
 
 // CountingState minus the state pointer (count.h:204-234).  Only bits 16..31 of m_updatedMask are ever read
@@ -94,6 +99,38 @@ struct Counters {
 			updated &= ~m;
 		}
 	}
+	// NoGlueLimitCountingState (count.h:306-325): Reset(id): current = 0;  Increment(id): ++current, total = max
+	__device__ __forceinline__ void ResetId(uint32_t id)
+	{
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r)
+			current[r] = uint32_t(r) == id ? 0u : current[r];
+	}
+	__device__ __forceinline__ void IncrementId(uint32_t id)
+	{
+#pragma unroll
+		for (int r = 0; r < RMAX; ++r)
+			if (uint32_t(r) == id) {
+				++current[r];
+				total[r] = total[r] > current[r] ? total[r] : current[r];
+			}
+	}
+	// NoGlueLimitCountingScanner::TakeActionImpl, count.h:404-437: resets first, then increments
+	__device__ __forceinline__ void TakeNoGlue(const uint32_t* actions, uint32_t a)
+	{
+		if (actions) {
+			const uint32_t* act = actions + a;
+			for (uint32_t n = *act++; n--;)
+				ResetId(*act++);
+			for (uint32_t n = *act++; n--;)
+				IncrementId(*act++);
+		} else {
+			if (a & 2u)
+				ResetId(0);
+			if (a & 1u)
+				IncrementId(0);
+		}
+	}
 	template <bool ADVANCED>
 	__device__ __forceinline__ void Take(uint32_t a)
 	{
@@ -112,7 +149,8 @@ struct Counters {
 	}
 };
 
-template <int RMAX, bool ADVANCED>
+// KIND: PIRE_HIP_COUNTING_BASIC / _ADVANCED / _NOGLUELIMIT (the latter with at most RMAX regexps: counters in registers)
+template <int RMAX, int KIND>
 __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -134,8 +172,12 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 			const uint64_t x = trans[st * p.letters + letterOf[ch]];
 			st = uint32_t(x);
 			const uint32_t a = uint32_t(x >> 32);
-			if (a)
-				c.template Take<ADVANCED>(a);
+			if (a) {
+				if (KIND == PIRE_HIP_COUNTING_NOGLUELIMIT)
+					c.TakeNoGlue(p.actions, a);
+				else
+					c.template Take<KIND == PIRE_HIP_COUNTING_ADVANCED>(a);
+			}
 		};
 		if (p.flags & PIRE_HIP_RUN_BEGIN)
 			step(kBeginMark);
@@ -175,6 +217,57 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 	}
 }
 
+// NoGlueLimitCountingScanner with more than 16 regexps: the counters of a string live in its own rows of two global
+// arrays (current: scratch, total: the result array itself -- Result(r) == total[r], because Increment keeps
+// total >= current and Reset only clears current); the lane owns the rows, so plain read-modify-write.
+__global__ __launch_bounds__(256) void CountingWideKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* letterOf = lds;
+	uint64_t* transLds = reinterpret_cast<uint64_t*>(lds + 272);
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		letterOf[i] = p.letterOf[i];
+	if (p.transInLds)
+		for (uint32_t i = threadIdx.x; i < p.states * p.letters; i += blockDim.x)
+			transLds[i] = p.trans[i];
+	__syncthreads();
+	const uint64_t* trans = p.transInLds ? transLds : p.trans;
+	const uint32_t R = p.regexps;
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint32_t* current = p.scratch + s * R;
+		uint32_t* total = p.outResults + s * R;
+		for (uint32_t r = 0; r < R; ++r)
+			current[r] = total[r] = 0;
+		uint32_t st = p.initial;
+		auto step = [&](uint32_t ch) {
+			const uint64_t x = trans[st * p.letters + letterOf[ch]];
+			st = uint32_t(x);
+			const uint32_t a = uint32_t(x >> 32);
+			if (a) {
+				const uint32_t* act = p.actions + a;
+				for (uint32_t n = *act++; n--;)
+					current[*act++] = 0;
+				for (uint32_t n = *act++; n--;) {
+					const uint32_t id = *act++;
+					const uint32_t c = ++current[id];
+					if (c > total[id])
+						total[id] = c;
+				}
+			}
+		};
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			step(kBeginMark);
+		const uint8_t* ptr = p.text + p.offsets[s];
+		const uint8_t* end = p.text + p.offsets[s + 1];
+		for (; ptr < end; ++ptr)
+			step(*ptr);
+		if (p.flags & PIRE_HIP_RUN_END)
+			step(kEndMark);
+		if (p.outIdx)
+			p.outIdx[s] = st;
+	}
+}
+
 namespace {
 
 struct RefHeader {
@@ -199,7 +292,9 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 	RefHeader h;
 	memcpy(&h, p, sizeof(h));
 	// Header::Validate, common.h:65-77; type LoadedScanner = 4, common.h:39
-	if (h.magic != 0x45524950u || h.ptrSize != 8 || h.maxWordSize != 16 || h.type != 4 || h.hdrSize != sizeof(LoadedLocals))
+	// type LoadedScanner = 4, NoGlueLimitCountingScanner = 5 (common.h:39-40)
+	if (h.magic != 0x45524950u || h.ptrSize != 8 || h.maxWordSize != 16 || (h.type != 4 && h.type != 5) ||
+	    h.hdrSize != sizeof(LoadedLocals))
 		return Bad("Serialized regexp incompatible with your system");
 	if (h.version != 7 && h.version != 6)
 		return Bad("You are trying to used an incompatible version of a serialized regexp");
@@ -209,7 +304,7 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 		return Bad("EOF reached while reading the scanner locals");
 	memcpy(&m, p + pos, sizeof(m));
 	pos += sizeof(m);
-	if (m.statesCount == 0 || m.lettersCount == 0 || m.lettersCount > 256 || m.regexpsCount > kMaxReCount)
+	if (m.statesCount == 0 || m.lettersCount == 0 || m.lettersCount > 256 || (h.type == 4 && m.regexpsCount > kMaxReCount))
 		return Bad("Corrupt scanner: bad state, letter or regexp count");
 	const size_t njumps = size_t(m.statesCount) * m.lettersCount;
 	if (len < pos + 264 + njumps * 8 + m.statesCount)
@@ -219,6 +314,7 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 	t.states = m.statesCount;
 	t.letters = m.lettersCount;
 	t.regexps = m.regexpsCount;
+	t.type = h.type;
 	const uint64_t stateSize = uint64_t(m.lettersCount) * 8;   // StateSize(), loaded.h:171-174
 	if (m.initial % stateSize != 0 || m.initial / stateSize >= m.statesCount)
 		return Bad("Corrupt scanner: initial state out of range");
@@ -239,6 +335,44 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 				return Bad("Corrupt scanner: transition out of range");
 			t.trans[size_t(s) * m.lettersCount + l] = uint64_t(dest) / stateSize | (uint64_t(action) << 32);
 		}
+	if (h.type == 5) {
+		// NoGlueLimitCountingScanner::Load, count.cpp:1020-1035: behind the (8-byte padded) tags a u32 length
+		// (0 = no table: one regexp, raw action bits), then length-1 more words
+		pos += njumps * 8;
+		if (h.version == 6)
+			pos += (njumps * 4 + 7) / 8 * 8;
+		pos += (size_t(m.statesCount) + 7) / 8 * 8;
+		uint32_t size = 0;
+		if (len < pos + 4)
+			return Bad("EOF reached while reading the action table");
+		memcpy(&size, p + pos, 4);
+		if (size) {
+			if (len < pos + size_t(size) * 4)
+				return Bad("EOF reached while reading the action table");
+			t.actions.resize(size);
+			memcpy(t.actions.data(), p + pos, size_t(size) * 4);
+			// every action word of the table must point at two well-formed lists
+			for (uint64_t x : t.trans) {
+				const uint32_t a = uint32_t(x >> 32);
+				if (!a)
+					continue;
+				size_t q = a;
+				for (int list = 0; list < 2; ++list) {
+					if (q >= size)
+						return Bad("Corrupt scanner: action out of range");
+					const uint32_t cnt = t.actions[q++];
+					if (q + cnt > size)
+						return Bad("Corrupt scanner: action list out of range");
+					for (uint32_t k = 0; k < cnt; ++k)
+						if (t.actions[q + k] >= m.regexpsCount)
+							return Bad("Corrupt scanner: regexp id out of range");
+					q += cnt;
+				}
+			}
+		} else if (m.regexpsCount > 1) {
+			return Bad("Corrupt scanner: several regexps without an action table");
+		}
+	}
 	return PIRE_HIP_OK;
 }
 
@@ -250,6 +384,8 @@ void FreeCountingDevice(CountingDevice* d)
 		(void)hipFree(d->letterOf);
 	if (d->trans)
 		(void)hipFree(d->trans);
+	if (d->actions)
+		(void)hipFree(d->actions);
 	*d = CountingDevice();
 }
 
@@ -270,6 +406,11 @@ int UploadCounting(pire_hip_counting_table* t)
 		e = hipMemcpy(d.letterOf, t->host.letterOf.data(), 264, hipMemcpyHostToDevice);
 	if (e == hipSuccess)
 		e = hipMemcpy(d.trans, t->host.trans.data(), t->host.trans.size() * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess && !t->host.actions.empty()) {
+		e = hipMalloc(reinterpret_cast<void**>(&d.actions), t->host.actions.size() * 4);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.actions, t->host.actions.data(), t->host.actions.size() * 4, hipMemcpyHostToDevice);
+	}
 	d.device = dev;
 	if (e != hipSuccess) {
 		FreeCountingDevice(&d);
@@ -279,14 +420,14 @@ int UploadCounting(pire_hip_counting_table* t)
 	return PIRE_HIP_OK;
 }
 
-template <int RMAX, bool ADV>
+template <int RMAX, int KIND>
 void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
-	*err = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingKernel<RMAX, ADV>),
+	*err = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingKernel<RMAX, KIND>),
 	                           hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (*err != hipSuccess)
 		return;
-	hipLaunchKernelGGL((CountingKernel<RMAX, ADV>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+	hipLaunchKernelGGL((CountingKernel<RMAX, KIND>), dim3(blocks), dim3(256), ldsBytes, stream, p);
 	*err = hipGetLastError();
 }
 
@@ -304,17 +445,25 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream)
 	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;   // several 256-thread blocks per CU stay resident
 	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
 	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
-	const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
-	if (p.regexps <= 8) {
-		if (adv)
-			LaunchOne<8, true>(p, blocks, ldsBytes, stream, &e);
-		else
-			LaunchOne<8, false>(p, blocks, ldsBytes, stream, &e);
+	if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT && p.regexps > kMaxReCount) {
+		e = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingWideKernel),
+		                        hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(CountingWideKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+			e = hipGetLastError();
+		}
+	} else if (p.regexps <= 8) {
+		switch (kind) {
+		case PIRE_HIP_COUNTING_BASIC: LaunchOne<8, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
+		case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<8, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
+		default: LaunchOne<8, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
+		}
 	} else {
-		if (adv)
-			LaunchOne<16, true>(p, blocks, ldsBytes, stream, &e);
-		else
-			LaunchOne<16, false>(p, blocks, ldsBytes, stream, &e);
+		switch (kind) {
+		case PIRE_HIP_COUNTING_BASIC: LaunchOne<16, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
+		case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<16, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
+		default: LaunchOne<16, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
+		}
 	}
 	if (e != hipSuccess)
 		return HipFail(e, "counting kernel launch");
@@ -371,9 +520,20 @@ int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_
 int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                           uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* streamPtr)
 {
-	if (!t || (n && (!offsets || !out_results)) || (kind != PIRE_HIP_COUNTING_BASIC && kind != PIRE_HIP_COUNTING_ADVANCED)) {
+	if (!t || (n && (!offsets || !out_results)) || (kind != PIRE_HIP_COUNTING_BASIC && kind != PIRE_HIP_COUNTING_ADVANCED && kind != PIRE_HIP_COUNTING_NOGLUELIMIT)) {
 		SetError("bad argument");
 		return PIRE_HIP_EINVAL;
+	}
+	// the serialised form decides between the classes: a type-5 blob is a NoGlueLimitCountingScanner and nothing
+	// else; a LoadedScanner blob run as NOGLUELIMIT is the reference's "AdvancedScannerCompatibilityMode"
+	// (count.cpp:1036-1039), i.e. AdvancedCountingScanner semantics
+	if ((t->host.type == 5) != (kind == PIRE_HIP_COUNTING_NOGLUELIMIT)) {
+		if (t->host.type == 4 && kind == PIRE_HIP_COUNTING_NOGLUELIMIT) {
+			kind = PIRE_HIP_COUNTING_ADVANCED;
+		} else {
+			SetError("this table was serialised by a NoGlueLimitCountingScanner: run it with PIRE_HIP_COUNTING_NOGLUELIMIT");
+			return PIRE_HIP_EINVAL;
+		}
 	}
 	if (n == 0)
 		return PIRE_HIP_OK;
@@ -382,6 +542,26 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 		return rc;
 	CountingParams p;
 	memset(&p, 0, sizeof(p));
+	p.actions = t->dev.actions;
+	// more than 16 regexps: per-string `current` rows in a temporary device array (freed after the stream is drained)
+	void* scratch = nullptr;
+	struct ScratchGuard {
+		void*& q;
+		hipStream_t s;
+		~ScratchGuard()
+		{
+			if (q) {
+				(void)hipStreamSynchronize(s);
+				(void)hipFree(q);
+			}
+		}
+	} scratchGuard{scratch, stream};
+	if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT && t->host.regexps > kMaxReCount) {
+		hipError_t se = hipMalloc(&scratch, size_t(n) * t->host.regexps * 4);
+		if (se != hipSuccess)
+			return HipFail(se, "hipMalloc(counting scratch)");
+		p.scratch = static_cast<uint32_t*>(scratch);
+	}
 	p.letterOf = t->dev.letterOf;
 	p.trans = t->dev.trans;
 	p.states = t->host.states;

@@ -300,6 +300,7 @@ int main()
 		TestPrefixAndSlow();
 		TestCounting<Pire::CountingScanner>();
 		TestCounting<Pire::AdvancedCountingScanner>();
+		TestCounting<Pire::NoGlueLimitCountingScanner>();
 		TestScannerPair();
 		TestHalfFinal();
 		TestSimpleScanner();

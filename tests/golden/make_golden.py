@@ -356,7 +356,7 @@ def main():
     rng = np.random.RandomState(80)
     extra = [bytes(rng.choice(np.frombuffer(b"abc def,http:/\n", dtype=np.uint8), size=int(k))) for k in rng.randint(0, 90, size=40)]
     for k, (re_, sep, text, expect) in enumerate(COUNT):
-        for kind, kname in ((0, "basic"), (1, "advanced")):
+        for kind, kname in ((0, "basic"), (1, "advanced"), (2, "noglue")):
             sc = RefCountingScanner.compile(kind, [re_], [sep])
             strings = [text] + extra
             idx, res = sc.run_strings(strings)
@@ -369,7 +369,7 @@ def main():
                              "blob": write_blob(name, blob), "strings_hex": [x.hex() for x in strings],
                              "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
                              "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
-    for kind, kname in ((0, "basic"), (1, "advanced")):
+    for kind, kname in ((0, "basic"), (1, "advanced"), (2, "noglue")):
         res_, seps_ = ["[a-z]+", "http", "abc"], ["\\s", ".*", ".*"]
         sc = RefCountingScanner.compile(kind, res_, seps_)
         strings = [c[2] for c in COUNT] + extra
@@ -382,6 +382,22 @@ def main():
                          "expect_first": None, "blob": write_blob(name, blob), "strings_hex": [x.hex() for x in strings],
                          "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
                          "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
+
+    # NoGlueLimitCountingScanner with more than MAX_RE_COUNT = 16 regexps (what the class exists for, count.h:330-344)
+    res_ = [c for c in "abcdefghijklmnopq"]
+    seps_ = ["\\s"] * len(res_)
+    sc = RefCountingScanner.compile(2, res_, seps_)
+    wide_strings = [b"abc abc def qqq, a b c", b"", b"zzz"] + [bytes(rng.choice(np.frombuffer(b"abcdefghijklmnopqrs  \n", dtype=np.uint8), size=int(k)))
+                                                             for k in rng.randint(0, 120, size=40)]
+    idx, res = sc.run_strings(wide_strings)
+    nidx, nres = sc.run_strings(wide_strings, flags=0)
+    blob = sc.save()
+    counting.append({"name": "count_wide17_noglue", "source": "NoGlueLimitCountingScanner::Glue of 17 scanners (count.h:330-344)",
+                     "re": res_, "sep": seps_, "kind": 2, "states": sc.size, "letters": sc.letters, "regexps": sc.regexps,
+                     "expect_first": None, "blob": write_blob("count_wide17_noglue", blob),
+                     "strings_hex": [x.hex() for x in wide_strings],
+                     "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
+                     "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
 
     # Scanner::Glue parts: every pattern of set_a / set_d compiled on its own (bench.cpp:114-129 glues such scanners
     # left to right); gluing these blobs must reproduce the big sets' tables, state for state.

@@ -53,6 +53,10 @@ def test_product_ingests_counting_tables(pa):
         assert (t.Size, t.LettersCount, t.RegexpsCount, t.initial) == (o.size, o.letters, o.regexps, o.initial)
     with pytest.raises(pa.PireHipError):
         pa.CountingTable(H.load_blob(cases()[0]["blob"])[:100], 0)
+    # a NoGlueLimitCountingScanner blob cannot be run as one of the other classes (its actions are list indices)
+    noglue = [c for c in cases() if c["kind"] == 2][0]
+    with pytest.raises(pa.PireHipError):
+        pa.CountingTable(H.load_blob(noglue["blob"]), 0).run_strings([b"abc"])
     with pytest.raises(pa.PireHipError):                                   # a Scanner blob is not a LoadedScanner
         pa.CountingTable(H.load_blob([c for c in H.all_cases() if c["name"] == "survey_known_answer"][0]["blob"]), 0)
 
