@@ -372,3 +372,58 @@ def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name):
     assert (gi3 == oi).all() and (gf3 == of).all()
     # the host-side view stays in the reference's numbering
     assert t.Final(int(oi[0])) == bool(of[0])
+
+
+def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
+    """A table handle is immutable and shareable between host threads: four threads, each on its own
+    stream, run ragged and tiled batches on ONE table at the same time; every result must equal the oracle's."""
+    import threading
+
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.upload()
+    rng = np.random.RandomState(12)
+    jobs = []
+    for k in range(4):
+        strings = H.random_strings(rng, 3000, 300, b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet")
+        text, offs = H.pack(strings)
+        jobs.append((text, offs, o.run(text, offs, threads=2)))
+    n, length = 2048, 512
+    data = ob.corpus_fill(99, 0, n, length, H.plants_for(big), threads=4)
+    ref_tiled = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            text, offs, (oi, of) = jobs[k]
+            d = torch.as_tensor(np.array(text), device="cuda")
+            do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+            dd = torch.as_tensor(data, device="cuda")
+            idx = torch.empty(len(offs) - 1, dtype=torch.int32, device="cuda")
+            fin = torch.empty(len(offs) - 1, dtype=torch.uint8, device="cuda")
+            idx2 = torch.empty(n, dtype=torch.int32, device="cuda")
+            fin2 = torch.empty(n, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(20):
+                t.run_device(d.data_ptr(), do.data_ptr(), len(offs) - 1, BE, idx.data_ptr(), fin.data_ptr(), 0, 0,
+                             stream.cuda_stream)
+                t.run_strided_device(dd.data_ptr(), n, length, length, BE, idx2.data_ptr(), fin2.data_ptr(), 0, 0,
+                                     stream.cuda_stream)
+                stream.synchronize()
+                if not ((idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()):
+                    errors.append("ragged mismatch in thread %d" % k)
+                if not ((idx2.cpu().numpy().astype(np.uint32) == ref_tiled[0]).all() and
+                        (fin2.cpu().numpy() == ref_tiled[1]).all()):
+                    errors.append("tiled mismatch in thread %d" % k)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
