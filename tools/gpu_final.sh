@@ -41,3 +41,8 @@ print("PCIe-inclusive host-pointer mode: %d x %d B (%.0f MiB pageable host memor
 PY
 echo "== ragged batches through pire_hip_run (offsets), set_a table, after two adapt() passes"
 for c in urls loglines uniform2k uniform8k fixed4096; do PYTHONPATH=. timeout 120 python tools/ragged_case.py $c 3 2>&1 | grep "^ragged"; PYTHONPATH=. timeout 120 python tools/ragged_case.py $c 3 generic 2>&1 | grep "^generic"; done | tee gpurun_out/final/ragged_cases.log
+echo "== secondary kernels"
+PYTHONPATH=. timeout 200 python tools/prefix_case.py 2>&1 | grep "Prefix" | tee gpurun_out/final/prefix.log
+PYTHONPATH=. timeout 200 python tools/half_final_case.py half_5 2>&1 | grep "half_final\|reference" | tee gpurun_out/final/half_final.log
+PYTHONPATH=. timeout 200 python tools/counting_case.py count_glued3_advanced 2>&1 | grep "counting\|reference" | tee gpurun_out/final/counting.log
+tests/cpp/bin/shim_test 2>&1 | tail -1 | tee gpurun_out/final/shim.log
