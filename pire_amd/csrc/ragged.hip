@@ -9,7 +9,7 @@ namespace pirehip {
 // Runner per string: bench.cpp:244, pigrep.cpp:42).  One string per lane, but a lane is NOT tied to a string: when
 // its string ends it takes the next one, so a wave stays full however uneven the lengths are.
 //
-//   * work distribution: blocks take ranges of `blockGrab` strings from one global counter (a few thousand atomics
+//   * work distribution: blocks take ranges of `grab.block` strings from one global counter (a few thousand atomics
 //     per launch, not one per wave: same-address device atomics run at well under 100 per microsecond); waves take
 //     64 strings at a time from their block's range in LDS; lanes take single strings from their wave's range by
 //     ballot + mbcnt.
@@ -24,6 +24,13 @@ namespace pirehip {
 //     bytes unrolled and keeps the state after its last real byte (no loop, no branches).
 //   * nothing is read past the 16-byte block that holds the last byte of the text: a window that would reach further
 //     is walked byte by byte from memory instead.
+
+
+// How many strings a block takes from the global counter at a time, and a wave from its block's range (one visit of
+// the block lock each).
+struct RaggedGrab {
+	uint32_t block, wave;
+};
 
 struct RaggedWork {
 	unsigned long long next, end;   // the block's current range of string indices
@@ -174,7 +181,7 @@ struct RaggedRange {
 };
 
 __device__ __forceinline__ void GrabWaveRange(const ScanParams& p, volatile RaggedWork* work,
-                                              unsigned long long* workCounter, uint32_t blockGrab, RaggedRange& R)
+                                              unsigned long long* workCounter, RaggedGrab grab, RaggedRange& R)
 {
 	unsigned long long r0 = 0, r1 = 0;
 	if ((threadIdx.x & 63) == 0) {
@@ -182,15 +189,15 @@ __device__ __forceinline__ void GrabWaveRange(const ScanParams& p, volatile Ragg
 			__builtin_amdgcn_s_sleep(2);
 		unsigned long long nx = work->next, en = work->end;
 		if (nx >= en && !work->exhausted) {
-			const unsigned long long base = atomicAdd(workCounter, (unsigned long long)blockGrab);
+			const unsigned long long base = atomicAdd(workCounter, (unsigned long long)grab.block);
 			if (base >= p.n) {
 				work->exhausted = 1;
 			} else {
 				nx = base;
-				en = base + blockGrab < p.n ? base + blockGrab : p.n;
+				en = base + grab.block < p.n ? base + grab.block : p.n;
 			}
 		}
-		const unsigned long long take = en - nx < 64 ? en - nx : 64;
+		const unsigned long long take = en - nx < grab.wave ? en - nx : grab.wave;
 		r0 = nx;
 		r1 = nx + take;
 		work->next = r1;
@@ -205,7 +212,7 @@ __device__ __forceinline__ void GrabWaveRange(const ScanParams& p, volatile Ragg
 
 // Give every lane without a pending string the next unassigned one.  Returns (per lane) whether it got one.
 __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile RaggedWork* work,
-                                              unsigned long long* workCounter, uint32_t blockGrab, RaggedRange& R,
+                                              unsigned long long* workCounter, RaggedGrab grab, RaggedRange& R,
                                               RaggedLane& S)
 {
 	bool need = !S.pend, got = false;
@@ -216,7 +223,7 @@ __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile Ragg
 		if (R.next >= R.end) {
 			if (R.exhausted)
 				break;
-			GrabWaveRange(p, work, workCounter, blockGrab, R);
+			GrabWaveRange(p, work, workCounter, grab, R);
 			if (R.exhausted)
 				break;
 		}
@@ -238,7 +245,7 @@ __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile Ragg
 // Returns false when the wave has nothing left to do.
 __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                             volatile RaggedWork* work, unsigned long long* workCounter,
-                                            uint32_t blockGrab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
+                                            RaggedGrab grab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
                                             RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter)
 {
 	WaitAllLoads(cur);
@@ -265,7 +272,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		S.pend = false;
 	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
 	// end of this iteration, so the one wait the compiler inserts for them sits behind the walk
-	const bool got = AssignPending(p, work, workCounter, blockGrab, R, S);
+	const bool got = AssignPending(p, work, workCounter, grab, R, S);
 	uint64_t offB = 0, offE = 0;
 	if (__any(got)) {
 		const uint64_t* offPtr = p.offsets + (got ? S.sIdxN : 0u);
@@ -328,7 +335,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 }
 
 __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned long long* workCounter,
-                                                         uint32_t blockGrab)
+                                                         RaggedGrab grab)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
@@ -362,14 +369,14 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	ZeroTile(a);
 	ZeroTile(b);
 
-	if (AssignPending(p, work, workCounter, blockGrab, R, S)) {
+	if (AssignPending(p, work, workCounter, grab, R, S)) {
 		S.pendPos = textBase + p.offsets[S.sIdxN];
 		S.pendEnd = textBase + p.offsets[S.sIdxN + 1];
 	}
 	for (uint32_t iter = 0;; iter += 2) {
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, blockGrab, textBase, safeEnd, R, S, a, b, iter))
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter))
 			break;
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, blockGrab, textBase, safeEnd, R, S, b, a, iter + 1))
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1))
 			break;
 	}
 	FlushCounts(p, lds, L);
@@ -407,8 +414,14 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 	// strings a block takes from the global counter at a time: ~8 grabs per block keep the tail balanced; batches
 	// that barely fill the lanes are simply split evenly
 	const uint64_t perBlock = (p.n + blocks - 1) / blocks, lanes = wavesPerBlock * 64;
-	uint64_t grab = std::min<uint64_t>(16384, std::max<uint64_t>(perBlock / 8, std::min(perBlock, lanes)));
-	grab = (grab + 63) / 64 * 64;
+	uint64_t blockGrab = std::min<uint64_t>(16384, std::max<uint64_t>(perBlock / 8, std::min(perBlock, lanes)));
+	blockGrab = (blockGrab + 63) / 64 * 64;
+	// a wave takes several windows' worth of strings per visit of the block lock when there is plenty (otherwise the
+	// 16 waves of a block queue up behind the lock every iteration), one lane-fill when a block grab barely feeds
+	// its waves
+	RaggedGrab grab;
+	grab.block = uint32_t(blockGrab);
+	grab.wave = uint32_t(std::min<uint64_t>(256, std::max<uint64_t>(64, blockGrab / (2 * wavesPerBlock) / 64 * 64)));
 	ScanParams q = p;
 	if (const char* dbg = getenv("PIRE_HIP_DEBUG_RAGGED")) {   // timing experiments: 1 no partial passes, 2 no finish, 4 no traps
 		const int m = atoi(dbg);
@@ -416,7 +429,7 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
 	}
 	hipLaunchKernelGGL(ScanRaggedKernel, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream, q,
-	                   workCounter, uint32_t(grab));
+	                   workCounter, grab);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "ragged kernel launch");
