@@ -112,6 +112,14 @@ int pire_hip_table_create_from_file(const char* path, pire_hip_table** out);
  * an error.  The result is a table like any other: run it, adapt it, glue it further.
  */
 int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out);
+/*
+ * The same product, with the state discovery (Impl::Determine's loop, determine.h:100-122) done on the GPU: a
+ * level-synchronous breadth-first search over state pairs whose new states are numbered by the position of their
+ * first occurrence inside the level -- which is exactly the order in which the sequential reference loop meets them,
+ * so the result is identical to pire_hip_table_glue() and to the scanner the reference would glue.  Needs a HIP
+ * device (PIRE_HIP_ENODEVICE otherwise).  Worth it for large products (tens of thousands of states).
+ */
+int pire_hip_table_glue_gpu(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out);
 
 /* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
 int pire_hip_table_upload(pire_hip_table* t);

@@ -81,6 +81,7 @@ ABI = [
     ("pire_hip_table_mmap", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("pire_hip_table_create_from_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_glue", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_table_glue_gpu", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_upload", C.c_int, [C.c_void_p]),
     ("pire_hip_table_adapt", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("pire_hip_table_destroy", None, [C.c_void_p]),
@@ -198,10 +199,11 @@ class Table:
         return cls(_handle=h), used.value
 
     @classmethod
-    def glue(cls, lhs: "Table", rhs: "Table", max_size: int = 0):
-        """Scanner::Glue(lhs, rhs, maxSize) on two ingested tables (host side, reference numbering)."""
+    def glue(cls, lhs: "Table", rhs: "Table", max_size: int = 0, gpu: bool = False):
+        """Scanner::Glue(lhs, rhs, maxSize) on two ingested tables (reference numbering); gpu=True: BFS on the device."""
         h = C.c_void_p()
-        _check(lib().pire_hip_table_glue(lhs._h, rhs._h, max_size, C.byref(h)))
+        fn = lib().pire_hip_table_glue_gpu if gpu else lib().pire_hip_table_glue
+        _check(fn(lhs._h, rhs._h, max_size, C.byref(h)))
         return cls(_handle=h)
 
     def __del__(self):

@@ -322,7 +322,9 @@ int pire_hip_table_create_from_file(const char* path, pire_hip_table** out)
 	return rc;
 }
 
-int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
+namespace {
+
+int GlueImpl(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out, bool onDevice)
 {
 	if (!lhs || !rhs || !out) {
 		SetError("null argument");
@@ -334,11 +336,24 @@ int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, si
 		SetError("out of memory");
 		return PIRE_HIP_ENOMEM;
 	}
-	if (int rc = GlueHostTables(lhs->host, rhs->host, max_size, &t->host))
+	if (int rc = GlueHostTables(lhs->host, rhs->host, max_size, &t->host, onDevice))
 		return rc;
 	*out = t.release();
 	return PIRE_HIP_OK;
 }
+
+}  // namespace
+
+int pire_hip_table_glue_gpu(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
+{
+	return GlueImpl(lhs, rhs, max_size, out, true);
+}
+
+int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
+{
+	return GlueImpl(lhs, rhs, max_size, out, false);
+}
+
 
 int pire_hip_table_upload(pire_hip_table* t)
 {

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pire_hip.h"
@@ -210,7 +211,16 @@ int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_H
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t);
 void EnsureRanked(pire_hip_table* t);
-int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out);
+struct GlueProduct {
+	std::vector<std::pair<uint32_t, uint32_t>> states;   // numbered product states (lhs state, rhs state)
+	std::vector<uint32_t> next;                          // [states * letters]
+	bool failed = false;                                 // more than maxSize new states: the glue yields an empty scanner
+};
+int GlueBfsHost(const HostTable& a, const HostTable& b, const std::vector<uint32_t>& la, const std::vector<uint32_t>& lb,
+                size_t maxSize, GlueProduct* out);
+int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint32_t>& la,
+                  const std::vector<uint32_t>& lb, size_t maxSize, GlueProduct* out);   // glue.hip
+int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out, bool onDevice = false);
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
 void FreeDeviceTable(DeviceTable* d);
 

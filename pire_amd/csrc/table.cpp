@@ -576,7 +576,40 @@ int UploadTable(pire_hip_table* t)
 // numbers it -- ScannerGlueCommon/LettersEquality (glue.h:35-159) for the letter classes, Impl::Determine
 // (determine.h:91-137) for the breadth-first state numbering, ScannerGlueTask::AcceptStates (multi.h:1024-1043) for
 // flags and final lists.  `out` is an empty scanner when more than maxSize new states are needed (Failure()).
-int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out)
+// breadth-first product construction (determine.h:100-122), sequential host version
+int GlueBfsHost(const HostTable& a, const HostTable& b, const std::vector<uint32_t>& la, const std::vector<uint32_t>& lb,
+                size_t maxSize, GlueProduct* out)
+{
+	const uint32_t LC = uint32_t(la.size());
+	std::vector<std::pair<uint32_t, uint32_t>>& states = out->states;
+	std::vector<uint32_t>& next = out->next;
+	std::unordered_map<uint64_t, uint32_t> index;
+	auto keyOf = [](uint32_t x, uint32_t y) { return (uint64_t(x) << 32) | y; };
+	states.clear();
+	next.clear();
+	states.emplace_back(a.initial, b.initial);
+	index.emplace(keyOf(a.initial, b.initial), 0u);
+	out->failed = false;
+	for (size_t i = 0; i < states.size() && !out->failed; ++i) {
+		const uint32_t sa = states[i].first, sb = states[i].second;
+		next.resize((i + 1) * size_t(LC));
+		for (uint32_t l = 0; l < LC; ++l) {
+			const uint32_t na = a.next[size_t(sa) * a.letters + la[l]], nb = b.next[size_t(sb) * b.letters + lb[l]];
+			auto ins = index.emplace(keyOf(na, nb), uint32_t(states.size()));
+			if (ins.second) {
+				if (!maxSize--) {   // determine.h:112-113
+					out->failed = true;
+					break;
+				}
+				states.emplace_back(na, nb);
+			}
+			next[i * size_t(LC) + l] = ins.first->second;
+		}
+	}
+	return PIRE_HIP_OK;
+}
+
+int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out, bool onDevice)
 {
 	if (a.scannerType != 1 || b.scannerType != 1)
 		return Bad("Glue is defined for Pire::Scanner tables");
@@ -619,35 +652,18 @@ int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostT
 	const uint32_t LC = uint32_t(rep.size());
 	t.letters = LC;
 
-	// breadth-first product construction (determine.h:100-122)
-	std::vector<std::pair<uint32_t, uint32_t>> states;
-	std::unordered_map<uint64_t, uint32_t> index;
-	auto keyOf = [](uint32_t x, uint32_t y) { return (uint64_t(x) << 32) | y; };
-	states.emplace_back(a.initial, b.initial);
-	index.emplace(keyOf(a.initial, b.initial), 0u);
 	std::vector<uint32_t> la(LC), lb(LC);
 	for (uint32_t l = 0; l < LC; ++l) {
 		la[l] = a.cls[rep[l]];
 		lb[l] = b.cls[rep[l]];
 	}
+	GlueProduct prod;
+	if (int rc = onDevice ? GlueBfsDevice(a, b, la, lb, maxSize, &prod) : GlueBfsHost(a, b, la, lb, maxSize, &prod))
+		return rc;
+	const bool failed = prod.failed;
+	std::vector<std::pair<uint32_t, uint32_t>>& states = prod.states;
+	t.next.swap(prod.next);
 	std::vector<uint32_t>& next = t.next;
-	bool failed = false;
-	for (size_t i = 0; i < states.size() && !failed; ++i) {
-		const uint32_t sa = states[i].first, sb = states[i].second;
-		next.resize((i + 1) * size_t(LC));
-		for (uint32_t l = 0; l < LC; ++l) {
-			const uint32_t na = a.next[size_t(sa) * a.letters + la[l]], nb = b.next[size_t(sb) * b.letters + lb[l]];
-			auto ins = index.emplace(keyOf(na, nb), uint32_t(states.size()));
-			if (ins.second) {
-				if (!maxSize--) {   // determine.h:112-113
-					failed = true;
-					break;
-				}
-				states.emplace_back(na, nb);
-			}
-			next[i * size_t(LC) + l] = ins.first->second;
-		}
-	}
 	if (failed) {
 		// task.Failure() = Scanner(): the empty scanner (glue.h:146, multi.h:121)
 		HostTable e;

@@ -91,3 +91,40 @@ def test_gpu_glued_table_scans_like_the_reference_one(pa, name):
     oi, of = o.run_strings(many)
     gi, gf = t.run_strings(many)
     assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["set_d", "set_a"])
+def test_gpu_side_glue_equals_host_glue_and_reference(pa, name):
+    """pire_hip_table_glue_gpu: the level-synchronous BFS on the device numbers the product exactly like the
+    sequential loop (every intermediate of the 8-way glue is produced on the GPU and glued further)."""
+    assert pa.device_count() > 0
+    parts = [g for g in H.golden()["glue_parts"] if g["name"] == name][0]["parts"]
+    blobs = [H.load_blob(p["blob"]) for p in parts]
+    t = pa.Table(blobs[0])
+    for b in blobs[1:]:
+        t = pa.Table.glue(t, pa.Table(b), gpu=True)
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    o = ob.OracleScanner(H.load_blob(big["blob"]))
+    rng = np.random.RandomState(2)
+    assert_same_table(t, o, sample_states=sorted(set(rng.randint(0, o.size, size=400).tolist() + [0, o.initial, o.size - 1])))
+    # and the failure rule (determine.h:112-113) is the same on both sides
+    a, b2 = pa.Table(blobs[0]), pa.Table(blobs[1])
+    full = pa.Table.glue(a, b2, gpu=True)
+    host = pa.Table.glue(a, b2)
+    assert full.Size == host.Size
+    assert not pa.Table.glue(a, b2, full.Size - 1, gpu=True).Empty
+    assert pa.Table.glue(a, b2, full.Size - 2, gpu=True).Empty
+    c = big["corpus"]
+    data = ob.corpus_fill(c["seed"], 0, c["n"], c["len"], H.plants_for(big))
+    idx, fin = t.run_strided_host(data)
+    assert idx.tolist() == c["idx"] and fin.tolist() == c["final"]
+
+
+def test_gpu_glue_without_device_fails_loudly(pa):
+    if pa.device_count() > 0:
+        pytest.skip("a GPU is present")
+    parts = [g for g in H.golden()["glue_parts"] if g["name"] == "set_d"][0]["parts"]
+    a, b = pa.Table(H.load_blob(parts[0]["blob"])), pa.Table(H.load_blob(parts[1]["blob"]))
+    with pytest.raises(pa.PireHipError):
+        pa.Table.glue(a, b, gpu=True)
