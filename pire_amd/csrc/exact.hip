@@ -9,7 +9,7 @@ namespace pirehip {
 // ------------------------------------------------------------------------------------------ generic kernel
 // Any offsets, any alignment, any length (including 0).  One string per lane, exact step per byte.
 
-__global__ __launch_bounds__(256) void ScanGenericKernel(ScanParams p)
+__global__ __launch_bounds__(1024) void ScanGenericKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
@@ -113,7 +113,7 @@ __device__ __forceinline__ bool IsFinalState(const ScanParams& p, uint32_t st)
 }
 
 template <bool PACKED>
-__global__ __launch_bounds__(256) void HalfFinalKernel(ScanParams p, uint32_t* outResults)
+__global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* outResults)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
@@ -195,7 +195,7 @@ __device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_
 	return st < p.hot ? lds[L.flagsOff + st] : p.flagsPerm[st];
 }
 
-__global__ __launch_bounds__(256) void PrefixKernel(PrefixParams q)
+__global__ __launch_bounds__(1024) void PrefixKernel(PrefixParams q)
 {
 	const ScanParams& p = q.scan;
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -262,6 +262,17 @@ __global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateI
 
 // ------------------------------------------------------------------------------------------ launchers
 
+namespace {
+
+// The dense rows take 66 KB of LDS, so at most two blocks share a CU: big batches get 1024-thread blocks (16-32 waves
+// per CU to hide the per-byte lookup latency), small ones 256-thread blocks (more CUs busy).
+int ExactBlockThreads(uint64_t n)
+{
+	return n >= 128 * 1024 ? 1024 : 256;
+}
+
+}  // namespace
+
 int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 {
 	if (int rc = CheckCounts(p0))
@@ -269,7 +280,7 @@ int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 	ScanParams p = p0;
 	p.compact = 0;   // small blocks, several per CU: no room (and no need) for the warm rows
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
-	return LaunchScan(ScanGenericKernel, p, 256, L.total, stream);
+	return LaunchScan(ScanGenericKernel, p, ExactBlockThreads(p.n), L.total, stream);
 }
 
 
@@ -292,8 +303,9 @@ int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long*
 	q.longest = longest ? 1 : 0;
 	q.throughEnd = throughEnd ? 1 : 0;
 	q.outLen = outLen;
-	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 2)));
-	hipLaunchKernelGGL(PrefixKernel, dim3(blocks), dim3(256), L.total, stream, q);
+	const unsigned threads = unsigned(ExactBlockThreads(p.n));
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + threads - 1) / threads, uint64_t(cus) * 2)));
+	hipLaunchKernelGGL(PrefixKernel, dim3(blocks), dim3(threads), L.total, stream, q);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "prefix kernel launch");
@@ -316,11 +328,12 @@ int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stre
 	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
-	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 2)));
+	const unsigned threads = unsigned(ExactBlockThreads(p.n));
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + threads - 1) / threads, uint64_t(cus) * 2)));
 	if (packed)
-		hipLaunchKernelGGL(HalfFinalKernel<true>, dim3(blocks), dim3(256), ldsBytes, stream, p, outResults);
+		hipLaunchKernelGGL(HalfFinalKernel<true>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults);
 	else
-		hipLaunchKernelGGL(HalfFinalKernel<false>, dim3(blocks), dim3(256), ldsBytes, stream, p, outResults);
+		hipLaunchKernelGGL(HalfFinalKernel<false>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "half-final kernel launch");

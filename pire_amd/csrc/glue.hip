@@ -28,7 +28,6 @@ namespace pirehip {
 
 namespace {
 
-constexpr uint32_t kEmptyVal = 0xFFFFFFFFu;
 constexpr uint32_t kTentative = 0x80000000u;          // | position inside the level
 constexpr uint64_t kEmptyKey = ~uint64_t(0);
 

@@ -32,6 +32,14 @@ idx = torch.empty(m, dtype=torch.int32, device="cuda")
 fin = torch.empty(m, dtype=torch.uint8, device="cuda")
 res = torch.empty((m, R), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
+if len(sys.argv) > 2 and sys.argv[2] == "adapt":
+    # let a plain Scanner pass over the same text feed the visit counters, then re-rank the dense rows
+    t.run_device(d.data_ptr(), do.data_ptr(), m, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+    torch.cuda.synchronize()
+    print("adapt: rows changed", t.adapt())
+    t.run_device(d.data_ptr(), do.data_ptr(), m, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+    torch.cuda.synchronize()
+    print("adapt: rows changed", t.adapt())
 ts = []
 for _ in range(4):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
