@@ -85,7 +85,7 @@ __device__ __forceinline__ void SlowStep(const uint32_t* masks, uint32_t letters
 }
 
 template <int K>
-__global__ __launch_bounds__(256) void SlowScanKernel(SlowParams p)
+__global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint8_t* ldsLetter = lds;                                        // 264 bytes
@@ -330,13 +330,17 @@ int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
-	int dev = 0;
-	hipDeviceProp_t prop;
-	if ((e = hipGetDevice(&dev)) != hipSuccess || (e = hipGetDeviceProperties(&prop, dev)) != hipSuccess)
-		return HipFail(e, "hipGetDeviceProperties");
-	const uint64_t want = (p.n + 255) / 256;
-	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(prop.multiProcessorCount) * 4)));
-	hipLaunchKernelGGL(SlowScanKernel<K>, dim3(blocks), dim3(256), ldsBytes, stream, p);
+	int dev = 0, cus = 0;
+	if ((e = hipGetDevice(&dev)) != hipSuccess ||
+	    (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess)
+		return HipFail(e, "device query");
+	// big batches: 1024-thread blocks, as many per CU as the LDS copy of the masks allows (32 waves per CU at most);
+	// small ones: 256-thread blocks so that more CUs take part
+	const unsigned threads = p.n >= 128 * 1024 ? 1024 : 256;
+	const uint64_t perCu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / threads, (160 * 1024) / std::max<uint32_t>(ldsBytes, 1)));
+	const uint64_t want = (p.n + threads - 1) / threads;
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(cus) * perCu)));
+	hipLaunchKernelGGL(SlowScanKernel<K>, dim3(blocks), dim3(threads), ldsBytes, stream, p);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "slow kernel launch");
