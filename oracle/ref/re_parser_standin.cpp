@@ -111,13 +111,13 @@ Fsm& ToFsm(const Encoding& encoding, Any* value)
 
 class Parser {
 public:
-	explicit Parser(Lexer& lexer): m_lexer(lexer), m_token(0) { Advance(); }
+	explicit Parser(Lexer& lexer): m_lexer(lexer), m_token(0), m_have(false) {}
 
 	/* regexp : alternative  -- re_parser.y:82-90 */
 	void ParseRegexp()
 	{
 		Value top = Alternative();
-		if (m_token != 0)
+		if (Tok() != 0)
 			throw SyntaxError();
 		ToFsm(Enc(), top.get());
 		Pire::DoSwap(m_lexer.Retval(), *top);
@@ -126,32 +126,44 @@ public:
 private:
 	const Encoding& Enc() const { return m_lexer.Encoding(); }
 
-	/* Token fetch with the value boxed as bison's yylex does -- re_parser.y:163-176. */
-	void Advance()
+	/* Token fetch with the value boxed as bison's yylex does -- re_parser.y:163-176.
+	 *
+	 * The lookahead is fetched LAZILY, only when a decision needs it.  This mirrors the generated parser, which
+	 * performs default reductions without reading a lookahead token: after shifting ')' (or a YRE_COUNT) the only
+	 * possible action is the reduction whose semantic action calls Lexer::Parenthesized (re_parser.y:148, 158), so
+	 * that call happens BEFORE the next token is lexed.  Lexer features keep state between their Lex() and
+	 * Parenthesized() calls (extra/capture.cpp:40-87 counts '(' tokens), so the interleaving is observable:
+	 * tests/capture_ut.cpp (SlowCapturing, a group directly followed by '(') fails with an eager lookahead. */
+	int Tok()
 	{
-		Term t = m_lexer.Lex();
-		m_value.reset(t.Value().Empty() ? nullptr : new Any(t.Value()));
-		m_token = t.Type();
+		if (!m_have) {
+			Term t = m_lexer.Lex();
+			m_value.reset(t.Value().Empty() ? nullptr : new Any(t.Value()));
+			m_token = t.Type();
+			m_have = true;
+		}
+		return m_token;
 	}
 
+	/* Consume the current token (its value is returned); the next one is NOT fetched yet. */
 	Value Shift()
 	{
-		Value v = std::move(m_value);
-		Advance();
-		return v;
+		Tok();
+		m_have = false;
+		return std::move(m_value);
 	}
 
-	bool AtTerm() const
+	bool AtTerm()
 	{
-		return m_token == YRE_LETTERS || m_token == YRE_DOT
-			|| m_token == '^' || m_token == '$' || m_token == '(';
+		const int t = Tok();
+		return t == YRE_LETTERS || t == YRE_DOT || t == '^' || t == '$' || t == '(';
 	}
 
 	/* alternative : conjunction | alternative '|' conjunction  -- re_parser.y:92-95 */
 	Value Alternative()
 	{
 		Value lhs = Conjunction();
-		while (m_token == '|') {
+		while (Tok() == '|') {
 			Shift();
 			Value rhs = Conjunction();
 			Fsm& l = ToFsm(Enc(), lhs.get());
@@ -164,7 +176,7 @@ private:
 	Value Conjunction()
 	{
 		Value lhs = Negation();
-		while (m_token == YRE_AND) {
+		while (Tok() == YRE_AND) {
 			Shift();
 			Value rhs = Negation();
 			Fsm& l = ToFsm(Enc(), lhs.get());
@@ -176,7 +188,7 @@ private:
 	/* negation : concatenation | YRE_NOT concatenation  -- re_parser.y:102-105 */
 	Value Negation()
 	{
-		if (m_token != YRE_NOT)
+		if (Tok() != YRE_NOT)
 			return Concatenation();
 		Shift();
 		Value body = Concatenation();
@@ -205,7 +217,7 @@ private:
 	Value Iteration()
 	{
 		Value base = ParseTerm();
-		if (m_token != YRE_COUNT)
+		if (Tok() != YRE_COUNT)
 			return base;
 		Value count = Shift();
 
@@ -236,10 +248,10 @@ private:
 	/* term : LETTERS | DOT | '^' | '$' | '(' alternative ')'  -- re_parser.y:153-159 */
 	Value ParseTerm()
 	{
-		if (m_token == '(') {
+		if (Tok() == '(') {
 			Shift();
 			Value inner = Alternative();
-			if (m_token != ')')
+			if (Tok() != ')')
 				throw SyntaxError();
 			Shift();
 			// as in the grammar action, $2 is used as an Fsm here
@@ -253,6 +265,7 @@ private:
 
 	Lexer& m_lexer;
 	int    m_token;
+	bool   m_have;     // m_token / m_value hold an unconsumed lookahead
 	Value  m_value;
 };
 

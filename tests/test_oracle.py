@@ -154,4 +154,4 @@ def test_reference_own_unit_tests_pass_with_standin_parser():
     r = subprocess.run([os.path.join(here, "_ref", "pire_test")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert "OK(39 tests)" in r.stdout          # pire_ut + easy_ut (26) + count_ut (13)
+    assert "OK(50 tests)" in r.stdout          # pire_ut + easy_ut (26) + count_ut (13) + capture_ut (11)
