@@ -312,6 +312,22 @@ int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_
 int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                           uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* stream);
 
+/* ---- Pire::CapturingScanner (extra/capture.h) ------------------------------------------------------ */
+
+/*
+ * The capturing scanner of pire/extra/capture.h:49-162: one regexp, the substring matched by ONE pair of parentheses
+ * (built with Features::Capture(i), extra/capture.cpp).  It is a LoadedScanner table too (create it with
+ * pire_hip_counting_table_create): transitions carry BeginCapture = 1 / EndCapture = 2, TakeAction records the step
+ * counter (capture.h:96-116), Final comes from the state tags (capture.h:134).  Per string i, after
+ * Initialize; Begin(); Run(); End() (tests/capture_ut.cpp:75-83):
+ *   out_begin[i], out_end[i] = State::Begin(), State::End(): 1-based byte positions (the BeginMark step is counted;
+ *                              the captured text is [begin - 1, end - 1), capture_ut.cpp:85-91), -1 where unset;
+ *                              State::Captured() == (out_begin[i] >= 0 && out_end[i] >= 0)
+ *   out_final[i], out_state_idx[i] (nullable) = Final / StateIndex of the end state.
+ */
+int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                         uint32_t* out_state_idx, uint8_t* out_final, int64_t* out_begin, int64_t* out_end, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

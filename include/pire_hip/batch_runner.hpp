@@ -458,6 +458,83 @@ private:
 #endif  // PIRE_EXTRA_COUNT_H
 
 /*
+ * Batched Runner over a Pire::CapturingScanner (extra/capture.h:49-162; include <pire/extra.h> before this header):
+ * per string State::Captured(), Begin(), End() and Final after Initialize + Begin() + Run() + End(), as
+ * tests/capture_ut.cpp:75-83 drives it.  The captured text of string i is
+ * [text + offsets[i] + Begin(i) - 1, text + offsets[i] + End(i) - 1) (capture_ut.cpp:85-91).
+ */
+#ifdef PIRE_EXTRA_CAPTURE_H
+class CaptureBatchRunner {
+public:
+	explicit CaptureBatchRunner(const Pire::CapturingScanner& sc)
+	    : m_table(nullptr), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false)
+	{
+		std::ostringstream out;
+		sc.Save(&out);                                    // LoadedScanner::Save, scanner_io.cpp:172-189
+		const std::string blob = out.str();
+		Check(pire_hip_counting_table_create(blob.data(), blob.size(), &m_table));
+	}
+	~CaptureBatchRunner() { pire_hip_counting_table_destroy(m_table); }
+
+	CaptureBatchRunner& Begin() { m_flags |= PIRE_HIP_RUN_BEGIN; return *this; }
+	CaptureBatchRunner& End() { m_flags |= PIRE_HIP_RUN_END; return *this; }
+	CaptureBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_text = text;
+		m_offsets = offsets;
+		m_n = n;
+		m_ran = false;
+		return *this;
+	}
+	CaptureBatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_ownText.clear();
+		m_ownOffsets.assign(1, 0);
+		for (size_t i = 0; i < strings.size(); ++i) {
+			m_ownText.append(strings[i]);
+			m_ownOffsets.push_back(m_ownText.size());
+		}
+		return Run(m_ownText.data(), m_ownOffsets.data(), strings.size());
+	}
+
+	bool Captured(size_t i) { Execute(); return m_begin[i] >= 0 && m_end[i] >= 0; }     // State::Captured()
+	size_t Begin(size_t i) { Execute(); return size_t(m_begin[i]); }                    // State::Begin() (npos if unset)
+	size_t End(size_t i) { Execute(); return size_t(m_end[i]); }                        // State::End()
+	bool Final(size_t i) { Execute(); return m_final[i] != 0; }
+	size_t StateIndex(size_t i) { Execute(); return m_idx[i]; }
+
+private:
+	void Execute()
+	{
+		if (m_ran)
+			return;
+		m_idx.assign(m_n, 0);
+		m_final.assign(m_n, 0);
+		m_begin.assign(m_n, -1);
+		m_end.assign(m_n, -1);
+		static const uint64_t kNoOffsets[1] = {0};
+		Check(pire_hip_capture_run(m_table, m_text, m_n ? m_offsets : kNoOffsets, m_n, m_flags, m_idx.data(), m_final.data(),
+		                           m_begin.data(), m_end.data(), nullptr));
+		m_ran = true;
+	}
+
+	CaptureBatchRunner(const CaptureBatchRunner&);
+	CaptureBatchRunner& operator=(const CaptureBatchRunner&);
+	pire_hip_counting_table* m_table;
+	uint32_t m_flags;
+	const char* m_text;
+	const uint64_t* m_offsets;
+	size_t m_n;
+	bool m_ran;
+	std::vector<uint32_t> m_idx;
+	std::vector<uint8_t> m_final;
+	std::vector<int64_t> m_begin, m_end;
+	ystring m_ownText;
+	std::vector<uint64_t> m_ownOffsets;
+};
+#endif  // PIRE_EXTRA_CAPTURE_H
+
+/*
  * Batched Runner over a Pire::SlowScanner (scanners/slow.h): Matches(sc, str) per string, i.e.
  * Final(Runner(sc).Begin().Run(str).End().State()).
  */

@@ -127,6 +127,8 @@ def oracle_lib():
         L.oracle_count_next.restype = C.c_uint32
         L.oracle_count_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u64p]
         L.oracle_count_run.restype = None
+        L.oracle_capture_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u8p, i64p, i64p]
+        L.oracle_capture_run.restype = None
         L.oracle_simple_load.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
         L.oracle_simple_load.restype = C.c_int
         L.oracle_simple_free.argtypes = [C.c_void_p]
@@ -364,6 +366,20 @@ class OracleCountingScanner:
         text, offs = pack_strings(strings)
         return self.run(text, offs, **kw)
 
+    def capture(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        """The table walked as a Pire::CapturingScanner: (idx, final, captured, begin, end)."""
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        cap = np.empty(n, dtype=np.uint8)
+        b = np.empty(n, dtype=np.int64)
+        e = np.empty(n, dtype=np.int64)
+        self._L.oracle_capture_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                   _ptr(idx, u32p), _ptr(fin, u8p), _ptr(cap, u8p), _ptr(b, i64p), _ptr(e, i64p))
+        return idx, fin, cap, b, e
+
 
 # --------------------------------------------------------------------------- reference library
 
@@ -446,6 +462,17 @@ def ref_lib():
             getattr(L, name).restype = C.c_size_t
         L.pire_ref_count_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u64p, C.c_int]
         L.pire_ref_count_run.restype = C.c_int
+        L.pire_ref_capture_compile.argtypes = [C.c_char_p, C.c_int, C.c_char_p]
+        L.pire_ref_capture_compile.restype = C.c_void_p
+        L.pire_ref_capture_load.argtypes = [C.c_void_p, C.c_size_t]
+        L.pire_ref_capture_load.restype = C.c_void_p
+        L.pire_ref_capture_free.argtypes = [C.c_void_p]
+        L.pire_ref_capture_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.pire_ref_capture_save.restype = C.c_size_t
+        L.pire_ref_capture_size.argtypes = [C.c_void_p]
+        L.pire_ref_capture_size.restype = C.c_size_t
+        L.pire_ref_capture_run.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u8p, u8p, i64p, i64p]
+        L.pire_ref_capture_run.restype = C.c_int
         L.pire_ref_simple_compile.argtypes = [C.c_char_p, C.c_char_p]
         L.pire_ref_simple_compile.restype = C.c_void_p
         L.pire_ref_simple_empty.argtypes = []
@@ -519,6 +546,55 @@ class RefSlowScanner:
         if rc != 0:
             raise RuntimeError(self._L.pire_ref_last_error().decode())
         return fin, bits
+
+    def run_strings(self, strings, **kw):
+        text, offs = pack_strings(strings)
+        return self.run(text, offs, **kw)
+
+
+class RefCapturingScanner:
+    """The real Pire::CapturingScanner behind a C ABI (built like tests/capture_ut.cpp:39-53)."""
+
+    def __init__(self, handle):
+        self._L = ref_lib()
+        if not handle:
+            raise ValueError("reference: " + self._L.pire_ref_last_error().decode())
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def compile(cls, pattern, index, options="i"):
+        p = pattern.encode("latin-1") if isinstance(pattern, str) else pattern
+        return cls(ref_lib().pire_ref_capture_compile(p, index, options.encode()))
+
+    @classmethod
+    def load(cls, blob: bytes):
+        return cls(ref_lib().pire_ref_capture_load(bytes(blob), len(blob)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.pire_ref_capture_free(self._h)
+            self._h = None
+
+    size = property(lambda s: s._L.pire_ref_capture_size(s._h))
+
+    def save(self) -> bytes:
+        n = self._L.pire_ref_capture_save(self._h, None, 0)
+        buf = C.create_string_buffer(n)
+        self._L.pire_ref_capture_save(self._h, buf, n)
+        return buf.raw
+
+    def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        cap = np.empty(n, dtype=np.uint8)
+        b = np.empty(n, dtype=np.int64)
+        e = np.empty(n, dtype=np.int64)
+        self._L.pire_ref_capture_run(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), n, flags,
+                                     _ptr(idx, u32p), _ptr(fin, u8p), _ptr(cap, u8p), _ptr(b, i64p), _ptr(e, i64p))
+        return idx, fin, cap, b, e
 
     def run_strings(self, strings, **kw):
         text, offs = pack_strings(strings)

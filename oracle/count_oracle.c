@@ -32,6 +32,7 @@ struct oracle_count {
 	loaded_locals m;
 	uint8_t letters[MAX_CHAR];
 	transition* jumps;
+	uint8_t* tags;           /* m_tags[states] (loaded.h:242) */
 	uint32_t type;          /* 4 LoadedScanner, 5 NoGlueLimitCountingScanner (common.h:39-40) */
 	uint32_t* actions;      /* type 5: Actions[0] = length, then per action: resets count, ids, increments count, ids */
 };
@@ -98,6 +99,8 @@ int oracle_count_load(const void* blob, size_t len, oracle_count** out, char* er
 	pos += njumps * 8;
 	if (h.version == 6)
 		pos += align8(njumps * 4);
+	sc->tags = (uint8_t*)malloc(sc->m.states_count);
+	memcpy(sc->tags, p + pos, sc->m.states_count);            /* scanner_io.cpp:212 */
 	pos += align8(sc->m.states_count);
 	if (h.type == 5) {
 		/* NoGlueLimitCountingScanner::Load, count.cpp:1020-1035: u32 size (0 = no table), then size-1 more words */
@@ -124,6 +127,7 @@ void oracle_count_free(oracle_count* sc)
 {
 	if (sc) {
 		free(sc->jumps);
+		free(sc->tags);
 		free(sc->actions);
 		free(sc);
 	}
@@ -276,5 +280,55 @@ void oracle_count_run(const oracle_count* sc, int kind, const void* text, const 
 		if (results)
 			for (r = 0; r < R; ++r)           /* Result(i) = max(current, total), count.h:206 */
 				results[i * R + r] = s.current[r] > s.total[r] ? s.current[r] : s.total[r];
+	}
+}
+
+/* ------------------------------------------------------------------ CapturingScanner */
+
+typedef struct {
+	uint64_t state, begin, end, counter;   /* State, capture.h:59-87 */
+} capture_state;
+
+#define CAPTURE_NPOS (~(uint64_t)0)
+
+/* Step = Next + TakeAction (run.h:50-57) */
+static inline void capture_step(const oracle_count* sc, capture_state* s, uint32_t ch)
+{
+	/* NextTranslated, capture.h:109-116: move, count the step */
+	const transition x = sc->jumps[s->state / 8 + sc->letters[ch]];
+	const int captured = s->begin != CAPTURE_NPOS && s->end != CAPTURE_NPOS;
+	s->state += (uint64_t)(int64_t)(int32_t)x.shift;
+	++s->counter;
+	/* TakeAction, capture.h:96-102 */
+	if ((x.action & 1u) && !captured)
+		s->begin = s->counter - 1;
+	else if ((x.action & 2u) && !captured)
+		s->end = s->counter - 1;
+}
+
+void oracle_capture_run(const oracle_count* sc, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                        uint32_t* out_idx, uint8_t* out_final, uint8_t* out_captured, int64_t* out_begin,
+                        int64_t* out_end)
+{
+	const uint8_t* t = (const uint8_t*)text;
+	uint64_t i, k;
+	for (i = 0; i < n; ++i) {
+		capture_state s = { sc->m.initial, CAPTURE_NPOS, CAPTURE_NPOS, 0 };   /* Initialize, capture.h:89-94 */
+		if (flags & 1)
+			capture_step(sc, &s, BEGIN_MARK);
+		for (k = offsets[i]; k < offsets[i + 1]; ++k)
+			capture_step(sc, &s, t[k]);
+		if (flags & 2)
+			capture_step(sc, &s, END_MARK);
+		if (out_idx)
+			out_idx[i] = state_idx(sc, s.state);
+		if (out_final)
+			out_final[i] = (sc->tags[state_idx(sc, s.state)] & 1u) != 0;   /* Final, capture.h:134; FinalFlag = 1 */
+		if (out_captured)
+			out_captured[i] = s.begin != CAPTURE_NPOS && s.end != CAPTURE_NPOS;   /* Captured(), capture.h:61 */
+		if (out_begin)
+			out_begin[i] = (int64_t)s.begin;
+		if (out_end)
+			out_end[i] = (int64_t)s.end;
 	}
 }

@@ -45,6 +45,16 @@ uint32_t oracle_count_next(const oracle_count* sc, uint32_t idx, uint32_t letter
 void oracle_count_run(const oracle_count* sc, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                       uint32_t flags, uint32_t* out_idx, uint64_t* results);
 
+/*
+ * Pire::CapturingScanner (extra/capture.h:49-162), also a LoadedScanner table: actions BeginCapture = 1 /
+ * EndCapture = 2 on transitions, Final from the tags.  Per string: Initialize; Begin() if flags&1; Run; End() if
+ * flags&2 (tests/capture_ut.cpp:75-83); out_begin/out_end = State::Begin()/End() (-1 = npos), out_captured =
+ * State::Captured().  Pinned by tests/capture_ut.cpp:93-153.
+ */
+void oracle_capture_run(const oracle_count* sc, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                        uint32_t* out_idx, uint8_t* out_final, uint8_t* out_captured, int64_t* out_begin,
+                        int64_t* out_end);
+
 #ifdef __cplusplus
 }
 #endif

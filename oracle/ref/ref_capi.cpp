@@ -779,4 +779,90 @@ int pire_ref_count_run(void* hh, const void* text, const uint64_t* offsets, uint
 	return 0;
 }
 
+/* ---- Pire::CapturingScanner (extra/capture.h:49-162): one regexp, the substring matched by ONE pair of parentheses.
+ * Built as tests/capture_ut.cpp:39-53 builds it. ---------------------------------------------------------------- */
+
+extern "C++" {
+struct RefCapture {
+	Pire::CapturingScanner sc;
+};
+}
+
+void* pire_ref_capture_compile(const char* pattern, int index, const char* options)
+{
+	try {
+		std::unique_ptr<RefCapture> h(new RefCapture);
+		Pire::Lexer lexer;
+		lexer.Assign(pattern, pattern + strlen(pattern));
+		for (const char* o = options ? options : ""; *o; ++o)
+			if (*o == 'i')
+				lexer.AddFeature(Pire::Features::CaseInsensitive());
+		lexer.AddFeature(Pire::Features::Capture(size_t(index)));    // extra/capture.cpp:30-131
+		Pire::Fsm fsm = lexer.Parse();
+		fsm.Surround();
+		fsm.Determine();
+		h->sc = fsm.Compile<Pire::CapturingScanner>();
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void* pire_ref_capture_load(const void* blob, size_t len)
+{
+	try {
+		std::unique_ptr<RefCapture> h(new RefCapture);
+		Pire::MemoryInput in(static_cast<const char*>(blob), len);
+		h->sc.Load(&in);                                             // LoadedScanner::Load, scanner_io.cpp:191-215
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
+void pire_ref_capture_free(void* h) { delete static_cast<RefCapture*>(h); }
+
+size_t pire_ref_capture_save(void* h, void* buf, size_t cap)
+{
+	std::ostringstream out;
+	static_cast<RefCapture*>(h)->sc.Save(&out);
+	const std::string s = out.str();
+	if (buf && cap >= s.size())
+		memcpy(buf, s.data(), s.size());
+	return s.size();
+}
+
+size_t pire_ref_capture_size(void* h) { return static_cast<RefCapture*>(h)->sc.Size(); }
+
+/* tests/capture_ut.cpp:75-83 (RunRegexp).  begin/end: State::Begin()/End() (1-based, counted from the BeginMark step,
+ * capture.h:96-101, 108-115), -1 where npos; captured = State::Captured(). */
+int pire_ref_capture_run(void* hh, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags, uint32_t* outIdx,
+                         uint8_t* outFinal, uint8_t* outCaptured, int64_t* outBegin, int64_t* outEnd)
+{
+	const Pire::CapturingScanner& sc = static_cast<RefCapture*>(hh)->sc;
+	const char* t = static_cast<const char*>(text);
+	for (uint64_t i = 0; i < n; ++i) {
+		Pire::CapturingScanner::State st;
+		sc.Initialize(st);
+		if (flags & FLAG_BEGIN)
+			Pire::Step(sc, st, Pire::BeginMark);
+		Pire::Run(sc, st, t + offsets[i], t + offsets[i + 1]);
+		if (flags & FLAG_END)
+			Pire::Step(sc, st, Pire::EndMark);
+		if (outIdx)
+			outIdx[i] = uint32_t(sc.StateIndex(st));
+		if (outFinal)
+			outFinal[i] = sc.Final(st) ? 1 : 0;
+		if (outCaptured)
+			outCaptured[i] = st.Captured() ? 1 : 0;
+		if (outBegin)
+			outBegin[i] = int64_t(st.Begin());     // npos == (size_t)-1 == -1
+		if (outEnd)
+			outEnd[i] = int64_t(st.End());
+	}
+	return 0;
+}
+
 } // extern "C"

@@ -113,6 +113,8 @@ ABI = [
     ("pire_hip_counting_table_get_info", C.c_int, [C.c_void_p, C.POINTER(CountingInfo)]),
     ("pire_hip_counting_run", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
+    ("pire_hip_capture_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
     ("pire_hip_set_timing", C.c_int, [C.c_int]),
     ("pire_hip_last_kernel_ms", C.c_float, []),
@@ -447,6 +449,21 @@ class CountingTable:
         if strings:
             offs[1:] = np.cumsum([len(s) for s in strings], dtype=np.uint64)
         return self.run(np.frombuffer(b"".join(strings), dtype=np.uint8), offs, **kw)
+
+    def capture(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
+        """The table walked as a Pire::CapturingScanner: (StateIndex, Final, captured, begin, end) for host strings."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        b = np.empty(n, dtype=np.int64)
+        e = np.empty(n, dtype=np.int64)
+        _check(lib().pire_hip_capture_run(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                          flags & ~FLAG_ON_DEVICE, idx.ctypes.data, fin.ctypes.data, b.ctypes.data,
+                                          e.ctypes.data, None))
+        return idx, fin, ((b >= 0) & (e >= 0)).astype(np.uint8), b, e
 
     def run_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_results_ptr=0, stream: int = 0):
         _check(lib().pire_hip_counting_run(self._h, self.kind, text_ptr or None, offsets_ptr or None, n,

@@ -32,6 +32,7 @@ struct CountingHost {
 	std::vector<uint8_t> letterOf;     // [264] m_letters
 	std::vector<uint64_t> trans;       // [states*letters] next state index | action << 32
 	uint32_t type = 4;                 // ScannerIOTypes: 4 LoadedScanner, 5 NoGlueLimitCountingScanner
+	std::vector<uint8_t> tags;         // [states] m_tags (CapturingScanner: bit 0 = Final, capture.h:56, 134)
 	std::vector<uint32_t> actions;     // type 5: [0] = length; per action: resets count, ids, increments count, ids
 };
 
@@ -40,6 +41,7 @@ struct CountingDevice {
 	uint8_t* letterOf = nullptr;
 	uint64_t* trans = nullptr;
 	uint32_t* actions = nullptr;
+	uint8_t* tags = nullptr;
 };
 
 }  // namespace pirehip
@@ -62,6 +64,11 @@ struct CountingParams {
 	uint32_t* outResults;
 	const uint32_t* actions;   // NoGlueLimitCountingScanner action lists, or null (single regexp: raw action bits)
 	uint32_t* scratch;         // NoGlueLimit with more than 16 regexps: current[n][regexps]
+	// CapturingScanner run
+	const uint8_t* tags;
+	uint8_t* outFinal;
+	long long* outBegin;
+	long long* outEnd;
 };
 
 // CountingState minus the state pointer (count.h:204-234).  Only bits 16..31 of m_updatedMask are ever read
@@ -268,6 +275,72 @@ __global__ __launch_bounds__(256) void CountingWideKernel(CountingParams p)
 	}
 }
 
+// Pire::CapturingScanner (extra/capture.h:49-162): the same LoadedScanner walk; the state carries the step counter and
+// the begin / end of the one captured group (capture.h:59-87).  TakeAction, capture.h:96-102: a BeginCapture (1)
+// action records counter - 1 as begin, otherwise an EndCapture (2) action records it as end, both only until the
+// capture is complete.  Positions count steps, the BeginMark step included (tests/capture_ut.cpp:85-91 subtracts 1).
+__global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* letterOf = lds;
+	uint64_t* transLds = reinterpret_cast<uint64_t*>(lds + 272);
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		letterOf[i] = p.letterOf[i];
+	if (p.transInLds)
+		for (uint32_t i = threadIdx.x; i < p.states * p.letters; i += blockDim.x)
+			transLds[i] = p.trans[i];
+	__syncthreads();
+	const uint64_t* trans = p.transInLds ? transLds : p.trans;
+	// 32-bit positions (a string is shorter than 4 GiB); widened to the reference's size_t / npos on output
+	constexpr uint32_t npos = ~uint32_t(0);
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint32_t st = p.initial;
+		uint32_t begin = npos, end = npos, counter = 0;     // Initialize, capture.h:89-94
+		auto step = [&](uint32_t ch) {
+			const uint64_t x = trans[st * p.letters + letterOf[ch]];
+			st = uint32_t(x);
+			++counter;                                        // NextTranslated, capture.h:109-116
+			const uint32_t a = uint32_t(x >> 32);
+			// TakeAction, capture.h:96-102, as two selects (an if / else-if on two variables became a store through
+			// a selected stack address, i.e. scratch)
+			const bool open = !(begin != npos && end != npos);
+			const bool setBegin = (a & 1u) && open;
+			const bool setEnd = !(a & 1u) && (a & 2u) && open;
+			begin = setBegin ? counter - 1 : begin;
+			end = setEnd ? counter - 1 : end;
+		};
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			step(kBeginMark);
+		const uint8_t* ptr = p.text + p.offsets[s];
+		const uint8_t* stop = p.text + p.offsets[s + 1];
+		while (ptr < stop && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+			step(*ptr);
+			++ptr;
+		}
+		for (; ptr + 16 <= stop; ptr += 16) {
+			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				step(v.x & 0xFF);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
+		}
+		for (; ptr < stop; ++ptr)
+			step(*ptr);
+		if (p.flags & PIRE_HIP_RUN_END)
+			step(kEndMark);
+		if (p.outIdx)
+			p.outIdx[s] = st;
+		if (p.outFinal)
+			p.outFinal[s] = p.tags[st] & 1u;                  // Final, capture.h:134 (FinalFlag = 1)
+		p.outBegin[s] = begin == npos ? -1ll : (long long)begin;   // npos -> -1
+		p.outEnd[s] = end == npos ? -1ll : (long long)end;
+	}
+}
+
 namespace {
 
 struct RefHeader {
@@ -335,6 +408,14 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 				return Bad("Corrupt scanner: transition out of range");
 			t.trans[size_t(s) * m.lettersCount + l] = uint64_t(dest) / stateSize | (uint64_t(action) << 32);
 		}
+	{
+		size_t tpos = pos + njumps * 8;
+		if (h.version == 6)
+			tpos += (njumps * 4 + 7) / 8 * 8;   // the ignored per-transition action array of the old format
+		if (len < tpos + m.statesCount)
+			return Bad("EOF reached while reading the scanner tags");
+		t.tags.assign(p + tpos, p + tpos + m.statesCount);
+	}
 	if (h.type == 5) {
 		// NoGlueLimitCountingScanner::Load, count.cpp:1020-1035: behind the (8-byte padded) tags a u32 length
 		// (0 = no table: one regexp, raw action bits), then length-1 more words
@@ -386,6 +467,8 @@ void FreeCountingDevice(CountingDevice* d)
 		(void)hipFree(d->trans);
 	if (d->actions)
 		(void)hipFree(d->actions);
+	if (d->tags)
+		(void)hipFree(d->tags);
 	*d = CountingDevice();
 }
 
@@ -410,6 +493,11 @@ int UploadCounting(pire_hip_counting_table* t)
 		e = hipMalloc(reinterpret_cast<void**>(&d.actions), t->host.actions.size() * 4);
 		if (e == hipSuccess)
 			e = hipMemcpy(d.actions, t->host.actions.data(), t->host.actions.size() * 4, hipMemcpyHostToDevice);
+	}
+	if (e == hipSuccess) {
+		e = hipMalloc(reinterpret_cast<void**>(&d.tags), t->host.tags.size() + 16);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.tags, t->host.tags.data(), t->host.tags.size(), hipMemcpyHostToDevice);
 	}
 	d.device = dev;
 	if (e != hipSuccess) {
@@ -623,6 +711,112 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 		return rc;
 	if (e != hipSuccess)
 		return HipFail(e, "counting run (staging)");
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                         uint32_t* out_state_idx, uint8_t* out_final, int64_t* out_begin, int64_t* out_end, void* streamPtr)
+{
+	if (!t || (n && (!offsets || !out_begin || !out_end))) {
+		SetError("bad argument");
+		return PIRE_HIP_EINVAL;
+	}
+	if (t->host.type != 4) {
+		SetError("a CapturingScanner serialises as a LoadedScanner (type 4) table");
+		return PIRE_HIP_EINVAL;
+	}
+	if (n == 0)
+		return PIRE_HIP_OK;
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (int rc = UploadCounting(t))
+		return rc;
+	CountingParams p;
+	memset(&p, 0, sizeof(p));
+	p.letterOf = t->dev.letterOf;
+	p.trans = t->dev.trans;
+	p.tags = t->dev.tags;
+	p.states = t->host.states;
+	p.letters = t->host.letters;
+	p.regexps = t->host.regexps;
+	p.initial = t->host.initial;
+	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+	p.n = n;
+	int dev = 0, cus = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e == hipSuccess)
+		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (e != hipSuccess)
+		return HipFail(e, "device query");
+	const uint64_t tableBytes = uint64_t(p.states) * p.letters * 8;
+	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;
+	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, uint64_t(cus) * 8)));
+	e = hipFuncSetAttribute(reinterpret_cast<const void*>(CaptureKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		p.outIdx = out_state_idx;
+		p.outFinal = out_final;
+		p.outBegin = reinterpret_cast<long long*>(out_begin);
+		p.outEnd = reinterpret_cast<long long*>(out_end);
+		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+		e = hipGetLastError();
+		return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "capture kernel launch");
+	}
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i] > offsets[i + 1]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
+		}
+	const uint64_t textBytes = offsets[n];
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	void *dText = nullptr, *dOffs = nullptr, *dIdx = nullptr, *dFin = nullptr, *dB = nullptr, *dE = nullptr;
+	e = hipMalloc(&dText, textBytes ? textBytes : 16);
+	if (e == hipSuccess)
+		e = hipMalloc(&dOffs, (n + 1) * 8);
+	if (e == hipSuccess)
+		e = hipMalloc(&dIdx, n * 4);
+	if (e == hipSuccess)
+		e = hipMalloc(&dFin, n);
+	if (e == hipSuccess)
+		e = hipMalloc(&dB, n * 8);
+	if (e == hipSuccess)
+		e = hipMalloc(&dE, n * 8);
+	if (e == hipSuccess && textBytes)
+		e = hipMemcpyAsync(dText, text, textBytes, hipMemcpyHostToDevice, stream);
+	if (e == hipSuccess)
+		e = hipMemcpyAsync(dOffs, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
+	if (e == hipSuccess) {
+		p.text = static_cast<const uint8_t*>(dText);
+		p.offsets = static_cast<const uint64_t*>(dOffs);
+		p.outIdx = static_cast<uint32_t*>(dIdx);
+		p.outFinal = static_cast<uint8_t*>(dFin);
+		p.outBegin = static_cast<long long*>(dB);
+		p.outEnd = static_cast<long long*>(dE);
+		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+		e = hipGetLastError();
+		if (e == hipSuccess && out_state_idx)
+			e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess && out_final)
+			e = hipMemcpyAsync(out_final, dFin, n, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(out_begin, dB, n * 8, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(out_end, dE, n * 8, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(stream);
+	}
+	for (void* q : {dText, dOffs, dIdx, dFin, dB, dE})
+		if (q)
+			(void)hipFree(q);
+	if (e != hipSuccess)
+		return HipFail(e, "capture run");
 	return PIRE_HIP_OK;
 }
 

@@ -294,10 +294,66 @@ static void TestCounting()
 	CHECK(gpu.Result(0, 0) == 3 && gpu.Result(1, 1) == 3 && gpu.Result(2, 2) == 4);   // count_ut.cpp:97, 102, 103
 }
 
+// Pire::CapturingScanner (extra/capture.h), compiled and driven as tests/capture_ut.cpp:39-91 does.
+static void TestCapture()
+{
+	const char* regexp = "google_id\\s*=\\s*[\'\"]([a-z0-9]+)[\'\"]\\s*;";
+	Pire::Lexer lexer;
+	lexer.Assign(regexp, regexp + strlen(regexp));
+	lexer.AddFeature(Pire::Features::CaseInsensitive());
+	lexer.AddFeature(Pire::Features::Capture(1));
+	Pire::Fsm fsm = lexer.Parse();
+	fsm.Surround();
+	fsm.Determine();
+	Pire::CapturingScanner sc = fsm.Compile<Pire::CapturingScanner>();
+	std::vector<Pire::ystring> strings;
+	const char* fixed[] = {"google_id = 'abcde';", "var google_id = 'abcde'; eval(google_id);", "google_id != 'abcde';",
+	                       "google_id = 'abcde'; google_id = 'xyz';", "var google_id = 'abc de'; google_id = 'xyz';", ""};
+	for (size_t i = 0; i < sizeof(fixed) / sizeof(fixed[0]); ++i)
+		strings.push_back(fixed[i]);
+	unsigned seed = 99;
+	for (int i = 0; i < 400; ++i) {
+		Pire::ystring s;
+		for (int part = 0; part < 3; ++part) {
+			seed = seed * 1103515245u + 12345u;
+			if ((seed >> 16) & 1) {
+				s += fixed[(seed >> 17) % 5];
+			} else {
+				const size_t len = (seed >> 17) % 20;
+				for (size_t k = 0; k < len; ++k) {
+					seed = seed * 1103515245u + 12345u;
+					s.push_back("google_id ='x1;"[(seed >> 16) % 15]);
+				}
+			}
+		}
+		strings.push_back(s);
+	}
+	Pire::Hip::CaptureBatchRunner gpu(sc);
+	gpu.Begin().Run(strings).End();
+	size_t captured = 0;
+	for (size_t i = 0; i < strings.size(); ++i) {
+		Pire::CapturingScanner::State st;
+		sc.Initialize(st);
+		Pire::Step(sc, st, Pire::BeginMark);
+		Pire::Run(sc, st, strings[i].data(), strings[i].data() + strings[i].size());
+		Pire::Step(sc, st, Pire::EndMark);
+		CHECK(gpu.Captured(i) == st.Captured());
+		CHECK(gpu.Begin(i) == st.Begin() && gpu.End(i) == st.End());
+		CHECK(gpu.Final(i) == sc.Final(st));
+		CHECK(gpu.StateIndex(i) == sc.StateIndex(st));
+		captured += st.Captured() ? 1 : 0;
+	}
+	CHECK(captured > 4);
+	CHECK(gpu.Captured(0) && Pire::ystring(strings[0].data() + gpu.Begin(0) - 1, strings[0].data() + gpu.End(0) - 1) == "abcde");
+	CHECK(gpu.Captured(4) && Pire::ystring(strings[4].data() + gpu.Begin(4) - 1, strings[4].data() + gpu.End(4) - 1) == "xyz");
+	CHECK(!gpu.Captured(2));
+}
+
 int main()
 {
 	try {
 		TestPrefixAndSlow();
+		TestCapture();
 		TestCounting<Pire::CountingScanner>();
 		TestCounting<Pire::AdvancedCountingScanner>();
 		TestCounting<Pire::NoGlueLimitCountingScanner>();

@@ -399,6 +399,35 @@ def main():
                      "be": {"idx": [int(x) for x in idx], "results": res.tolist()},
                      "none": {"idx": [int(x) for x in nidx], "results": nres.tolist()}})
 
+    # CapturingScanner (extra/capture.h): the reference's vectors, tests/capture_ut.cpp:93-153
+    from oracle.binding import RefCapturingScanner
+    CAPTURE = [
+        ("capture_google", "capture_ut.cpp:93-129 (Trivial, Sequential)", "google_id\\s*=\\s*['\"]([a-z0-9]+)['\"]\\s*;", 1,
+         [(b"google_id = 'abcde';", b"abcde"), (b"var google_id = 'abcde'; eval(google_id);", b"abcde"),
+          (b"google_id != 'abcde';", None), (b"google_id = 'abcde'; google_id = 'xyz';", b"abcde"),
+          (b"var google_id = 'abc de'; google_id = 'xyz';", b"xyz")]),
+        ("capture_digits", "capture_ut.cpp:131-141 (NegatedTerminator)", "=(\\d+)[^\\d]", 1, [(b"=12345;", b"12345")]),
+        ("capture_path", "capture_ut.cpp:143-153 (FakeEdges)", "(/to-match-with)", 1,
+         [(b"/some/table/path/to-match-with", b"/to-match-with")]),
+    ]
+    capturing = []
+    for name, source, pat, index, items in CAPTURE:
+        sc = RefCapturingScanner.compile(pat, index, "i")
+        strings = [s_ for s_, _ in items]
+        strings += [bytes(rng.choice(np.frombuffer(b"google_id = 'ab1'; /to-match-with =12;x", dtype=np.uint8), size=int(k)))
+                    for k in rng.randint(0, 100, size=30)]
+        strings += [s_ + b" tail" for s_, _ in items] + [b"xx " + s_ for s_, _ in items]
+        idx, fin, cap, b, e = sc.run_strings(strings)
+        for (s_, want), c_, b_, e_ in zip(items, cap, b, e):
+            got = s_[b_ - 1:e_ - 1] if c_ else None           # capture_ut.cpp:85-91
+            assert got == want, (name, s_, got, want)
+        blob = sc.save()
+        capturing.append({"name": name, "source": source, "pattern": pat, "index": index, "states": sc.size,
+                          "blob": write_blob(name, blob), "strings_hex": [x.hex() for x in strings],
+                          "expect_hex": [None if w is None else w.hex() for _, w in items],
+                          "idx": [int(x) for x in idx], "final": [int(x) for x in fin], "captured": [int(x) for x in cap],
+                          "begin": [int(x) for x in b], "end": [int(x) for x in e]})
+
     # Scanner::Glue parts: every pattern of set_a / set_d compiled on its own (bench.cpp:114-129 glues such scanners
     # left to right); gluing these blobs must reproduce the big sets' tables, state for state.
     glue_parts = []
@@ -413,7 +442,7 @@ def main():
 
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "reference": "yandex/pire @ /root/reference (v0.0.6)",
-                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "counting": counting, "glue_parts": glue_parts, "corpus": corpus}, f, indent=1)
+                   "cases": cases, "big": big, "slow": slow, "simple": simple, "half_final": half, "counting": counting, "capturing": capturing, "glue_parts": glue_parts, "corpus": corpus}, f, indent=1)
     print("wrote", len(cases), "cases,", len(big), "big sets,", len(slow), "slow scanners,", len(simple), "simple scanners")
 
 

@@ -1,0 +1,72 @@
+"""Pire::CapturingScanner (extra/capture.h): the substring matched by one pair of parentheses.  Known answers are the
+reference's own, tests/capture_ut.cpp:93-153."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests import helpers as H
+
+
+def cases():
+    return H.golden().get("capturing", [])
+
+
+@pytest.fixture(scope="module")
+def pa():
+    import pire_amd
+
+    return pire_amd
+
+
+def check(case, result):
+    idx, fin, cap, b, e = result
+    assert idx.tolist() == case["idx"] and fin.tolist() == case["final"] and cap.tolist() == case["captured"]
+    assert b.tolist() == case["begin"] and e.tolist() == case["end"]
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    for s, want, c_, b_, e_ in zip(strings, case["expect_hex"], cap, b, e):
+        got = s[b_ - 1:e_ - 1] if c_ else None               # tests/capture_ut.cpp:85-91
+        assert got == (None if want is None else bytes.fromhex(want))
+
+
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_oracle_matches_golden_and_reference(case):
+    blob = H.load_blob(case["blob"])
+    o = ob.OracleCountingScanner(blob, 0)
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    check(case, o.capture(*ob.pack_strings(strings)))
+    if ob.ref_available():
+        r = ob.RefCapturingScanner.load(blob)
+        assert r.save() == blob
+        rng = np.random.RandomState(3)
+        pool = [bytes.fromhex(h) for h in case["strings_hex"][:5]]
+        many = []
+        for _ in range(400):
+            parts = [pool[rng.randint(0, len(pool))] if rng.randint(0, 2) else
+                     bytes(rng.choice(np.frombuffer(b"google_id ='\";x1/", dtype=np.uint8), size=rng.randint(0, 12)))
+                     for _ in range(rng.randint(0, 4))]
+            many.append(b"".join(parts))
+        for flags in (3, 0, 1, 2):
+            a, b = r.run_strings(many, flags=flags), o.capture(*ob.pack_strings(many), flags=flags)
+            assert all((x == y).all() for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
+def test_gpu_capture_parity(case, pa):
+    assert pa.device_count() > 0
+    blob = H.load_blob(case["blob"])
+    t, o = pa.CountingTable(blob, 0), ob.OracleCountingScanner(blob, 0)
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    check(case, t.capture(*H.pack(strings)))
+    rng = np.random.RandomState(5)
+    pool = strings[:5]
+    many = []
+    for _ in range(5000):
+        parts = [pool[rng.randint(0, len(pool))] if rng.randint(0, 2) else
+                 bytes(rng.choice(np.frombuffer(b"google_id ='\";x1/", dtype=np.uint8), size=rng.randint(0, 40)))
+                 for _ in range(rng.randint(0, 6))]
+        many.append(b"".join(parts))
+    for flags in (3, 0, 1, 2):
+        a, b = o.capture(*ob.pack_strings(many), flags=flags), t.capture(*H.pack(many), flags=flags)
+        assert all((x == y).all() for x, y in zip(a, b))
+    assert a[2].sum() > 0
