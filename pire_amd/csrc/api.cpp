@@ -36,38 +36,6 @@ int HipFail(hipError_t e, const char* what)
 
 namespace {
 
-// Owns temporary device buffers of the host-pointer mode.
-struct Staging {
-	std::vector<void*> ptrs;
-	~Staging()
-	{
-		for (void* p : ptrs)
-			(void)hipFree(p);
-	}
-	int Alloc(void** out, size_t bytes)
-	{
-		*out = nullptr;
-		hipError_t e = hipMalloc(out, bytes ? bytes : 16);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMalloc(staging)");
-		ptrs.push_back(*out);
-		return PIRE_HIP_OK;
-	}
-	template <class T>
-	int In(const T* host, size_t count, const T** dev, hipStream_t s)
-	{
-		void* d;
-		if (int rc = Alloc(&d, count * sizeof(T)))
-			return rc;
-		if (count) {
-			hipError_t e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, s);
-			if (e != hipSuccess)
-				return HipFail(e, "hipMemcpy(H2D)");
-		}
-		*dev = static_cast<const T*>(d);
-		return PIRE_HIP_OK;
-	}
-};
 
 int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 {

@@ -676,41 +676,30 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 		SetError("null text pointer with non-empty strings");
 		return PIRE_HIP_EINVAL;
 	}
-	void *dText = nullptr, *dOffs = nullptr, *dIdx = nullptr, *dRes = nullptr;
-	hipError_t e = hipMalloc(&dText, textBytes ? textBytes : 16);
-	if (e == hipSuccess)
-		e = hipMalloc(&dOffs, (n + 1) * 8);
-	if (e == hipSuccess)
-		e = hipMalloc(&dIdx, n * 4);
-	if (e == hipSuccess)
-		e = hipMalloc(&dRes, n * R * 4);
-	if (e == hipSuccess && textBytes)
-		e = hipMemcpyAsync(dText, text, textBytes, hipMemcpyHostToDevice, stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(dOffs, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
-	int rc = PIRE_HIP_OK;
-	if (e == hipSuccess) {
-		p.text = static_cast<const uint8_t*>(dText);
-		p.offsets = static_cast<const uint64_t*>(dOffs);
-		p.outIdx = static_cast<uint32_t*>(dIdx);
-		p.outResults = static_cast<uint32_t*>(dRes);
-		rc = LaunchCounting(p, kind, stream);
-		if (rc == PIRE_HIP_OK) {
-			if (out_state_idx)
-				e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
-			if (e == hipSuccess && t->host.regexps)
-				e = hipMemcpyAsync(out_results, dRes, n * t->host.regexps * 4, hipMemcpyDeviceToHost, stream);
-			if (e == hipSuccess)
-				e = hipStreamSynchronize(stream);
-		}
-	}
-	for (void* q : {dText, dOffs, dIdx, dRes})
-		if (q)
-			(void)hipFree(q);
-	if (rc != PIRE_HIP_OK)
+	Staging stage;
+	const uint8_t* dText = nullptr;
+	const uint64_t* dOffs = nullptr;
+	void *dIdx = nullptr, *dRes = nullptr;
+	int rc;
+	if ((rc = stage.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream)) ||
+	    (rc = stage.In(offsets, size_t(n + 1), &dOffs, stream)) || (rc = stage.Alloc(&dIdx, n * 4)) ||
+	    (rc = stage.Alloc(&dRes, n * R * 4)))
 		return rc;
+	p.text = dText;
+	p.offsets = dOffs;
+	p.outIdx = static_cast<uint32_t*>(dIdx);
+	p.outResults = static_cast<uint32_t*>(dRes);
+	if ((rc = LaunchCounting(p, kind, stream)))
+		return rc;
+	hipError_t e = hipSuccess;
+	if (out_state_idx)
+		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && t->host.regexps)
+		e = hipMemcpyAsync(out_results, dRes, n * t->host.regexps * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(stream);
 	if (e != hipSuccess)
-		return HipFail(e, "counting run (staging)");
+		return HipFail(e, "counting run (copy back / synchronize)");
 	return PIRE_HIP_OK;
 }
 
@@ -776,45 +765,33 @@ int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uin
 		SetError("null text pointer with non-empty strings");
 		return PIRE_HIP_EINVAL;
 	}
-	void *dText = nullptr, *dOffs = nullptr, *dIdx = nullptr, *dFin = nullptr, *dB = nullptr, *dE = nullptr;
-	e = hipMalloc(&dText, textBytes ? textBytes : 16);
+	Staging stage;
+	const uint8_t* dText = nullptr;
+	const uint64_t* dOffs = nullptr;
+	void *dIdx = nullptr, *dFin = nullptr, *dB = nullptr, *dE = nullptr;
+	int rc;
+	if ((rc = stage.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream)) ||
+	    (rc = stage.In(offsets, size_t(n + 1), &dOffs, stream)) || (rc = stage.Alloc(&dIdx, n * 4)) ||
+	    (rc = stage.Alloc(&dFin, n)) || (rc = stage.Alloc(&dB, n * 8)) || (rc = stage.Alloc(&dE, n * 8)))
+		return rc;
+	p.text = dText;
+	p.offsets = dOffs;
+	p.outIdx = static_cast<uint32_t*>(dIdx);
+	p.outFinal = static_cast<uint8_t*>(dFin);
+	p.outBegin = static_cast<long long*>(dB);
+	p.outEnd = static_cast<long long*>(dE);
+	hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+	e = hipGetLastError();
+	if (e == hipSuccess && out_state_idx)
+		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess && out_final)
+		e = hipMemcpyAsync(out_final, dFin, n, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess)
-		e = hipMalloc(&dOffs, (n + 1) * 8);
+		e = hipMemcpyAsync(out_begin, dB, n * 8, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess)
-		e = hipMalloc(&dIdx, n * 4);
+		e = hipMemcpyAsync(out_end, dE, n * 8, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess)
-		e = hipMalloc(&dFin, n);
-	if (e == hipSuccess)
-		e = hipMalloc(&dB, n * 8);
-	if (e == hipSuccess)
-		e = hipMalloc(&dE, n * 8);
-	if (e == hipSuccess && textBytes)
-		e = hipMemcpyAsync(dText, text, textBytes, hipMemcpyHostToDevice, stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(dOffs, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
-	if (e == hipSuccess) {
-		p.text = static_cast<const uint8_t*>(dText);
-		p.offsets = static_cast<const uint64_t*>(dOffs);
-		p.outIdx = static_cast<uint32_t*>(dIdx);
-		p.outFinal = static_cast<uint8_t*>(dFin);
-		p.outBegin = static_cast<long long*>(dB);
-		p.outEnd = static_cast<long long*>(dE);
-		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
-		e = hipGetLastError();
-		if (e == hipSuccess && out_state_idx)
-			e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
-		if (e == hipSuccess && out_final)
-			e = hipMemcpyAsync(out_final, dFin, n, hipMemcpyDeviceToHost, stream);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(out_begin, dB, n * 8, hipMemcpyDeviceToHost, stream);
-		if (e == hipSuccess)
-			e = hipMemcpyAsync(out_end, dE, n * 8, hipMemcpyDeviceToHost, stream);
-		if (e == hipSuccess)
-			e = hipStreamSynchronize(stream);
-	}
-	for (void* q : {dText, dOffs, dIdx, dFin, dB, dE})
-		if (q)
-			(void)hipFree(q);
+		e = hipStreamSynchronize(stream);
 	if (e != hipSuccess)
 		return HipFail(e, "capture run");
 	return PIRE_HIP_OK;

@@ -207,6 +207,41 @@ __host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)
 void SetError(const std::string& msg);
 int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_HIP_ENODEVICE / ENOMEM
 
+// Owns the temporary device buffers of a host-pointer call (PCIe-inclusive convenience mode): everything is freed when
+// the call returns, after it has synchronised its stream.
+struct Staging {
+	std::vector<void*> ptrs;
+	~Staging()
+	{
+		for (void* p : ptrs)
+			(void)hipFree(p);
+	}
+	int Alloc(void** out, size_t bytes)
+	{
+		*out = nullptr;
+		hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMalloc(staging)");
+		ptrs.push_back(*out);
+		return PIRE_HIP_OK;
+	}
+	template <class T>
+	int In(const T* host, size_t count, const T** dev, hipStream_t s)
+	{
+		void* d;
+		if (int rc = Alloc(&d, count * sizeof(T)))
+			return rc;
+		if (count) {
+			hipError_t e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, s);
+			if (e != hipSuccess)
+				return HipFail(e, "hipMemcpy(H2D)");
+		}
+		*dev = static_cast<const T*>(d);
+		return PIRE_HIP_OK;
+	}
+};
+
+
 // table.cpp
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t);
