@@ -257,8 +257,11 @@ def main():
     fence()
     # One-time table optimisation, outside the timed region (like table creation): re-rank the LDS-resident rows
     # from the visit counters the warm-up passes left on the device, then one more untimed pass.
-    adapted_rows = table.adapt() if args.warmup > 0 and not args.no_adapt else 0
-    if adapted_rows:
+    adapted_rows = 0
+    if args.warmup > 0 and not args.no_adapt:
+        adapted_rows = table.adapt()
+        # unconditionally, not "if adapted_rows": the step contains a collective, and ranks whose shard needed no
+        # re-ranking must not skip it
         step()
         fence()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
