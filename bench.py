@@ -332,7 +332,7 @@ def main():
                              "per_regexp": [int(c) for c in total_counts[2:]]},
         }
         assert int(total_counts[1]) == n * world, "match-count reduce lost strings"
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the reported CPU baseline belongs to the N=1 line only
             sample = min(n, 1 << args.cpu_sample_log2)
             res["cpu_baseline"] = cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin)
         print(json.dumps(res))
