@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-adapt", action="store_true", help="do not call pire_hip_table_adapt() after the warm-up")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -199,10 +201,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    local_dev = local if args.backend == "nccl" else local % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
-        pd.init("nccl", dev)   # "nccl" is RCCL on ROCm
+        pd.init(args.backend, dev)   # "nccl" is RCCL on ROCm
 
     big = [b for b in H.big_sets() if b["name"] == args.set][0]
     blob = H.load_blob(big["blob"])
