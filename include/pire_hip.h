@@ -203,7 +203,9 @@ int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t c
  * (half_final.h:137-164): the number of -- possibly intersecting -- matches.  Per string i:
  *   out_results[i * RegexpsCount() + r] = State::Result(r)   (half_final.h:90-92; u32: a count is <= length + 3)
  *   out_state_idx / out_final (nullable)  = StateIndex / Final of the end state, as pire_hip_run.
- * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE.  Pinned by tests/count_ut.cpp:541-550, 575.
+ * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE (| PIRE_HIP_RUN_GENERIC: keep the
+ * one-string-per-lane kernel; by default batches of >= 256 strings with <= 8 regexps take the ragged kernel, which
+ * re-walks exactly only the 16-byte chunks that touched a Final state).  Pinned by tests/count_ut.cpp:541-550, 575.
  */
 int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                             uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* stream);
@@ -212,12 +214,13 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
  * Pire::LongestPrefix / Pire::ShortestPrefix (run.h:277-311) for n strings: out_len[i] = length of the longest
  * (shortest) prefix of string i the scanner accepts, or -1 where the reference returns a null pointer.
  * through_begin / through_end as the reference's throughBeginMark / throughEndMark.  Scanning stops at the first
- * dead state (pire_ut.cpp:475-483).  flags: only PIRE_HIP_RUN_ON_DEVICE is looked at.
+ * dead state (pire_ut.cpp:475-483).  flags: PIRE_HIP_RUN_ON_DEVICE, PIRE_HIP_RUN_GENERIC (as above).
  */
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
-/* Name of the kernel the last run on this thread dispatched to ("tiled", "generic"); diagnostics. */
+/* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
+ * "prefix", "ragged_half_final", "half_final"); diagnostics. */
 const char* pire_hip_last_kernel(void);
 
 /* Milliseconds the most recent kernel launched by this thread took, measured with hipEvents on the

@@ -331,7 +331,7 @@ class Table:
                                              out_idx_ptr or None, out_final_ptr or None, out_results_ptr or None,
                                              stream or None))
 
-    def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False):
+    def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False, generic=False):
         """LongestPrefix / ShortestPrefix lengths (-1 = no prefix) for host strings."""
         text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
                                     else text, dtype=np.uint8)
@@ -339,13 +339,15 @@ class Table:
         n = len(offsets) - 1
         out = np.empty(n, dtype=np.int64)
         _check(lib().pire_hip_prefix(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
-                                     int(longest), int(through_begin), int(through_end), 0, out.ctypes.data, None))
+                                     int(longest), int(through_begin), int(through_end), FLAG_GENERIC if generic else 0,
+                                     out.ctypes.data, None))
         return out
 
     def prefix_device(self, text_ptr: int, offsets_ptr: int, n: int, longest: bool, out_len_ptr: int,
-                      through_begin=False, through_end=False, stream: int = 0):
+                      through_begin=False, through_end=False, stream: int = 0, generic=False):
         _check(lib().pire_hip_prefix(self._h, text_ptr or None, offsets_ptr or None, n, int(longest), int(through_begin),
-                                     int(through_end), FLAG_ON_DEVICE, out_len_ptr or None, stream or None))
+                                     int(through_end), FLAG_ON_DEVICE | (FLAG_GENERIC if generic else 0),
+                                     out_len_ptr or None, stream or None))
 
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))

@@ -62,6 +62,9 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->compact = h.compact;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
+	p->hotDeadLo = h.hotDeadLo;
+	p->deadShare = h.deadShare;
+	p->finalShare = h.finalShare;
 	p->states = h.states;
 	p->letters = h.letters;
 	p->regexps = h.regexps;
@@ -74,6 +77,16 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 		start = h.next[size_t(start) * h.letters + h.cls[kBeginMark]];  // Begin(), run.h:375
 	p->startPerm = h.permOfOrig[start];
 	return PIRE_HIP_OK;
+}
+
+}  // namespace
+void NoteKernel(const char* name) { g_lastKernel = name; }
+namespace {
+
+// One slot of the table's ring of ragged work counters per launch (launches of one table may overlap on streams).
+unsigned long long* NextWorkSlot(pire_hip_table* t)
+{
+	return t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots;
 }
 
 int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,
@@ -134,7 +147,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		// need 128 readable bytes at `text` for the ragged kernel, which the caller guarantees by passing a batch
 		// (a batch with less than 4 KiB of text is not worth a GPU launch; use PIRE_HIP_RUN_GENERIC to force the
 		// offset-exact kernel)
-		return Dispatch(p, stream, t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots, offsets ? ~0ull : 0);
+		return Dispatch(p, stream, NextWorkSlot(t), offsets ? ~0ull : 0);
 	}
 
 	// Host-pointer mode: stage through HBM.  (PCIe-inclusive; the benchmark never times this mode.)
@@ -189,7 +202,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return HipFail(e, "hipMemcpy(counts)");
 		p.outCounts = static_cast<unsigned long long*>(dCnt);
 	}
-	if (int rc = Dispatch(p, stream, t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots, textBytes))
+	if (int rc = Dispatch(p, stream, NextWorkSlot(t), textBytes))
 		return rc;
 	hipError_t e = hipSuccess;
 	if (outIdx)
@@ -504,13 +517,14 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	if (n == 0)
 		return PIRE_HIP_OK;
 	const uint32_t R = t->host.regexps;
-	g_lastKernel = "half_final";
+	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
+	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
 		p.outIdx = out_state_idx;
 		p.outFinal = out_final;
-		return LaunchHalfFinal(p, out_results, stream);
+		return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
 	}
 	Staging st;
 	for (uint64_t i = 0; i < n; ++i)
@@ -538,7 +552,7 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 		return rc;
 	p.outIdx = static_cast<uint32_t*>(dIdx);
 	p.outFinal = static_cast<uint8_t*>(dFin);
-	if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream))
+	if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t)))
 		return rc;
 	hipError_t e = hipSuccess;
 	if (out_state_idx)
@@ -571,7 +585,8 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
-		return LaunchPrefix(p, longest != 0, through_end != 0, reinterpret_cast<long long*>(out_len), stream);
+		return LaunchPrefix(p, longest != 0, through_end != 0, reinterpret_cast<long long*>(out_len), stream,
+		                    (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t));
 	}
 	Staging st;
 	for (uint64_t i = 0; i < n; ++i)
@@ -593,7 +608,8 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	void* dOut = nullptr;
 	if (int rc = st.Alloc(&dOut, size_t(n) * 8))
 		return rc;
-	if (int rc = LaunchPrefix(p, longest != 0, through_end != 0, static_cast<long long*>(dOut), stream))
+	if (int rc = LaunchPrefix(p, longest != 0, through_end != 0, static_cast<long long*>(dOut), stream,
+	                          (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t)))
 		return rc;
 	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess)

@@ -130,6 +130,18 @@ __device__ __forceinline__ uint32_t SlowStepWord(const ScanParams& p, const uint
 	return st;
 }
 
+// Final(state) on a perm id: the hot set is ordered non-final first, so a hot state is Final iff id >= hotFinalLo.
+__device__ __forceinline__ bool IsFinalState(const ScanParams& p, uint32_t st)
+{
+	return st >= p.hotFinalLo && (st < p.hot || (p.flagsPerm[st] & kFinal));
+}
+
+// Row flags (kFinal | kDead) of a perm id: LDS for the dense rows, memory otherwise.
+__device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t st)
+{
+	return st < p.hot ? lds[L.flagsOff + st] : p.flagsPerm[st];
+}
+
 // Start state of string s (perm id): Initialize() or the caller's resume state, then Begin() if asked.
 __device__ __forceinline__ uint32_t StartState(const ScanParams& p, uint64_t s)
 {

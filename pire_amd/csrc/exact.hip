@@ -107,11 +107,6 @@ struct HalfCounters<false> {
 	__device__ __forceinline__ void Store(const ScanParams&, uint32_t*, uint64_t) {}
 };
 
-__device__ __forceinline__ bool IsFinalState(const ScanParams& p, uint32_t st)
-{
-	return st >= p.hotFinalLo && (st < p.hot || (p.flagsPerm[st] & kFinal));
-}
-
 template <bool PACKED>
 __global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* outResults)
 {
@@ -189,11 +184,6 @@ struct PrefixParams {
 	uint32_t longest, throughEnd;
 	long long* outLen;
 };
-
-__device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint32_t st)
-{
-	return st < p.hot ? lds[L.flagsOff + st] : p.flagsPerm[st];
-}
 
 __global__ __launch_bounds__(1024) void PrefixKernel(PrefixParams q)
 {
@@ -284,10 +274,22 @@ int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 }
 
 
-int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long* outLen, hipStream_t stream)
+int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
+                 unsigned long long* workCounter)
 {
 	if (p0.n == 0)
 		return PIRE_HIP_OK;
+	// A search that is over after a few bytes (a lexer's token scanner is Dead right behind the token; the first
+	// Final state of a dense scanner comes at once) reads a 16-byte block or two per string in the kernel below and
+	// a whole 128-byte window in the ragged one: measured 6.8 against 2.5 TB/s of text on log lines.  Everything that
+	// walks on takes the ragged kernel (2.6 - 5.6 x faster).  The shares come from the byte model of table.cpp.
+	const bool quick = (p0.deadShare > 0.5f || (!longest && p0.finalShare > 0.25f)) &&
+	                   !getenv("PIRE_HIP_RAGGED_ACT_ALWAYS");   // knob: tests and A/B measurements
+	if (workCounter && !quick && RaggedActEligible(p0)) {
+		NoteKernel("ragged_prefix");
+		return LaunchRaggedPrefix(p0, workCounter, longest, throughEnd, outLen, stream);
+	}
+	NoteKernel("prefix");
 	ScanParams p = p0;
 	p.compact = 0;
 	int cus = 0;
@@ -312,10 +314,15 @@ int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long*
 	return PIRE_HIP_OK;
 }
 
-int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stream)
+int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter)
 {
 	if (p0.n == 0)
 		return PIRE_HIP_OK;
+	if (workCounter && p0.incPerm && RaggedActEligible(p0)) {
+		NoteKernel("ragged_half_final");
+		return LaunchRaggedHalfFinal(p0, workCounter, outResults, stream);
+	}
+	NoteKernel("half_final");
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;

@@ -109,6 +109,8 @@ struct HostTable {
 	std::vector<uint32_t> permOfOrig, origOfPerm;
 	uint32_t hot = 0;                 // number of states with a dense LDS row; trap id == hot
 	uint32_t hotFinalLo = 0;          // hot perm ids >= this are Final (the hot set is ordered non-final first)
+	uint32_t hotDeadLo = 0;           // hot perm ids in [hotDeadLo, hotFinalLo) are Dead (ordered plain, Dead, Final)
+	float deadShare = 0, finalShare = 0;   // share of the byte model's visits that fall on Dead / Final states
 	bool incPacked = false;           // regexps <= 8 and every final-list multiplicity <= 255: inc64 is usable
 	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
@@ -185,6 +187,8 @@ struct ScanParams {
 	uint32_t compact;        // 0 = tier off
 	const uint64_t* incPerm; // nullable
 	uint32_t hotFinalLo;
+	uint32_t hotDeadLo;
+	float deadShare, finalShare;   // host-side hints for the choice of kernel (any choice is correct)
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;
@@ -265,9 +269,15 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
+void NoteKernel(const char* name);   // what pire_hip_last_kernel() reports (thread local)
+bool RaggedActEligible(const ScanParams& p);
+int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);
+int LaunchRaggedPrefix(const ScanParams& p, unsigned long long* workCounter, bool longest, bool throughEnd,
+                       long long* outLen, hipStream_t stream);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
-int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream);
-int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream);
+int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter);
+int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
+                 unsigned long long* workCounter);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);
 

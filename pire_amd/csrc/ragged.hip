@@ -117,6 +117,260 @@ __device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* 
 	}
 }
 
+// ------------------------------------------------------------------------------------------ scans with actions
+// HalfFinalScanner counting and the prefix searches are the same walk plus something to do whenever the walk is in a
+// Final state.  The fast path does not look: it only keeps the MAXIMUM of the 16 dense-row ids a chunk went through
+// (one v_max3_u32 per two bytes).  The hot set is ordered non-final first and the trap id is the largest of all, so
+// "max >= hotFinalLo" says "this chunk visited a hot Final state or left the dense rows": only then is the chunk
+// re-walked exactly, from its start state, with the action called after every step.  Scans that are rarely in a
+// Final state run at nearly the speed of the plain ragged kernel; scans that always are degrade to the exact walk
+// the one-string-per-lane kernels of exact.hip do all the time.
+struct NoAct {
+	static constexpr bool kActive = false;
+	struct Lane {};
+};
+
+// Pire::HalfFinalScanner (scanners/half_final.h:137-164): Initialize and every Step end with TakeAction -- a Final
+// state bumps the match counter of every regexp in its final list.  Up to 8 regexps, counters in registers, fed
+// from the packed increment word of the state (table.cpp, inc64).
+struct HalfFinalAct {
+	static constexpr bool kActive = true;
+	uint32_t* results;
+	struct Lane {
+		uint32_t c[8];
+	};
+	__device__ __forceinline__ bool Wants(const Lane&) const { return true; }
+	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotFinalLo; }
+	// the packed increments of the dense-row states, next to the table in LDS
+	__device__ __forceinline__ void LoadLds(const ScanParams& p, uint8_t* area) const
+	{
+		uint64_t* incHot = reinterpret_cast<uint64_t*>(area);
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+			incHot[i] = p.incPerm[i];
+	}
+	__device__ __forceinline__ void Take(Lane& al, uint64_t inc) const
+	{
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			al.c[r] += uint32_t(inc >> (8 * r)) & 0xFFu;
+	}
+	// after a step inside the dense rows that ended in h >= Threshold()
+	__device__ __forceinline__ void HotStep(const ScanParams&, const uint8_t*, const LdsLayout&, const uint8_t* area,
+	                                        Lane& al, uint32_t h, uint64_t) const
+	{
+		Take(al, reinterpret_cast<const uint64_t*>(area)[h]);
+	}
+	__device__ __forceinline__ void Step(const ScanParams& p, const uint8_t*, const LdsLayout&, Lane& al, uint32_t st,
+	                                     uint64_t) const
+	{
+		if (IsFinalState(p, st))
+			Take(al, p.incPerm[st]);
+	}
+	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                          uint32_t, uint64_t addr) const
+	{
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			al.c[r] = 0;
+		uint32_t st = p.startPerm;                         // Initialize ends with TakeAction, half_final.h:142
+		Step(p, lds, L, al, st, addr);
+		if (p.flags & PIRE_HIP_RUN_BEGIN) {
+			st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+			Step(p, lds, L, al, st, addr);
+		}
+		return st;
+	}
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                       uint32_t s, uint32_t st, uint64_t end) const
+	{
+		if (p.flags & PIRE_HIP_RUN_END) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			Step(p, lds, L, al, st, end);
+		}
+#pragma unroll
+		for (int r = 0; r < 8; ++r)      // static indices only: a runtime index would put c[] into scratch
+			if (uint32_t(r) < p.regexps)
+				results[size_t(s) * p.regexps + r] = al.c[r];
+		if (p.outIdx)
+			p.outIdx[s] = p.origOfPerm[st];
+		if (p.outFinal)
+			p.outFinal[s] = p.flagsPerm[st] & kFinal;
+	}
+};
+
+// Pire::LongestPrefix / ShortestPrefix (run.h:277-311, predicates 69-100): the position after the last (first) step
+// that ended in a Final state; a Dead state ends the search.  A lane whose search is over stops re-walking (its
+// state no longer matters) and idles through the rest of its string.
+struct PrefixAct {
+	static constexpr bool kActive = true;
+	long long* outLen;
+	uint32_t longest, throughEnd;
+	struct Lane {
+		uint64_t begin;
+		long long pos;
+		uint32_t stop;   // 1 search over, 2 Final before the first byte (shortest: answered at once), 4 ended Dead
+	};
+	__device__ __forceinline__ bool Wants(const Lane& al) const { return !(al.stop & 1u); }
+	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotDeadLo; }
+	__device__ __forceinline__ void LoadLds(const ScanParams&, uint8_t*) const {}
+	__device__ __forceinline__ void HotStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
+	                                        Lane& al, uint32_t h, uint64_t after) const
+	{
+		Step(p, lds, L, al, h, after);
+	}
+	__device__ __forceinline__ void Step(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                     uint32_t st, uint64_t after) const
+	{
+		if (al.stop & 1u)
+			return;
+		const uint32_t f = StateFlags(p, lds, L, st);
+		if (f & kFinal) {
+			al.pos = (long long)(after - al.begin);
+			if (!longest)
+				al.stop |= 1u;                             // ShortestPrefixPred stops on the first Final
+		}
+		if (f & kDead)
+			al.stop |= 5u;                                 // both predicates stop on a dead state
+	}
+	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                          uint32_t, uint64_t addr) const
+	{
+		al.begin = addr;
+		al.pos = -1;
+		al.stop = 0;
+		const uint32_t st = p.startPerm;                   // Initialize (+ BeginMark), run.h:280-283
+		if (StateFlags(p, lds, L, st) & kFinal) {
+			al.pos = 0;                                    // run.h:284 / 301-302
+			if (!longest)
+				al.stop = 3u;
+		}
+		return st;
+	}
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                       uint32_t s, uint32_t st, uint64_t end) const
+	{
+		// a search that ended Dead stays not-Final through EndMark; one that was answered before the first byte
+		// does not look at EndMark at all; a shortest prefix already found is kept (run.h:286-290 / 305-309)
+		if (throughEnd && !(al.stop & 6u) && (longest || al.pos < 0)) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			if (StateFlags(p, lds, L, st) & kFinal)
+				al.pos = (long long)(end - al.begin);
+		}
+		outLen[s] = al.pos;
+	}
+};
+
+// Exact walk of the first `count` (<= 16) bytes of v with the action after every step; `addr` is the address of
+// byte 0.  Rolled: this is the cold path.
+template <class Act>
+__device__ __forceinline__ uint32_t ActBytes(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
+                                             uint32_t st, uint32_t count, const Act& act, typename Act::Lane& al,
+                                             uint64_t addr)
+{
+#pragma unroll 1
+	for (uint32_t i = 0; i < count; ++i) {
+		st = SlowStep(p, lds, L, st, v.x & 0xFF);
+		act.Step(p, lds, L, al, st, addr + i + 1);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return st;
+}
+
+// The same for a chunk that stayed inside the dense rows (the usual reason for a re-walk: it touched a Final state):
+// LDS only, one compare per step on top of the lookup, the action only where the compare says so.
+template <class Act>
+__device__ __forceinline__ uint32_t ActHotBytes(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
+                                                const uint8_t* area, u32x4 v, uint32_t h, uint32_t count,
+                                                const Act& act, typename Act::Lane& al, uint64_t addr)
+{
+	const uint32_t thr = act.Threshold(p);
+#pragma unroll 1
+	for (uint32_t w = 0; w < 16; w += 4) {
+		const uint32_t x = v.x;
+#pragma unroll
+		for (uint32_t j = 0; j < 4; ++j) {
+			const uint32_t nh = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u + j));
+			if (w + j < count) {
+				h = nh;
+				if (h >= thr)
+					act.HotStep(p, lds, L, area, al, h, addr + w + j + 1);
+			}
+		}
+		v.x = v.y;
+		v.y = v.z;
+		v.z = v.w;
+	}
+	return h;
+}
+
+// StepChunk with the visit test: 16 bytes through the dense rows, keeping the largest id seen.
+template <class Act>
+__device__ __forceinline__ void StepChunkAct(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
+                                             uint32_t& hs, uint32_t& cold, const uint8_t* area, const Act& act,
+                                             typename Act::Lane& al, uint64_t addr)
+{
+	const uint32_t hs0 = hs;
+	uint32_t h = hs, m = 0;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
+		const uint32_t h1 = h;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
+		m = max(m, max(h1, h));
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
+		const uint32_t h3 = h;
+		h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
+		m = max(m, max(h3, h));
+	}
+	hs = h;
+	if (m >= act.Threshold(p) && act.Wants(al)) {
+		if (m < p.hot) {
+			(void)ActHotBytes(p, lds, L, area, v, hs0, 16u, act, al, addr);   // ends in h again
+		} else {
+			const uint32_t st = ActBytes(p, lds, L, v, hs0 != p.hot ? hs0 : cold, 16u, act, al, addr);
+			hs = st < p.hot ? st : p.hot;
+			cold = st;
+		}
+	}
+}
+
+// StepPartial with the visit test: only the first `count` steps count.
+template <class Act>
+__device__ __forceinline__ void StepPartialAct(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
+                                               uint32_t count, uint32_t& hs, uint32_t& cold, const uint8_t* area,
+                                               const Act& act, typename Act::Lane& al, uint64_t addr)
+{
+	const uint32_t hs0 = hs;
+	uint32_t h = hs, snap = hs, m = 0;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if (w == 3 && j == 3)
+				break;
+			h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u + uint32_t(j)));
+			const bool in = count >= uint32_t(4 * w + j + 1);
+			m = max(m, in ? h : 0u);
+			snap = count == uint32_t(4 * w + j + 1) ? h : snap;
+		}
+	}
+	hs = snap;
+	if (count != 0 && m >= act.Threshold(p) && act.Wants(al)) {
+		if (m < p.hot) {
+			(void)ActHotBytes(p, lds, L, area, v, hs0, count, act, al, addr);
+		} else {
+			const uint32_t st = ActBytes(p, lds, L, v, hs0 != p.hot ? hs0 : cold, count, act, al, addr);
+			hs = st < p.hot ? st : p.hot;
+			cold = st;
+		}
+	}
+}
+
 __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                              uint32_t s, bool active, uint32_t st)
 {
@@ -243,16 +497,21 @@ __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile Ragg
 
 // One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
 // Returns false when the wave has nothing left to do.
+template <class Act>
 __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                             volatile RaggedWork* work, unsigned long long* workCounter,
                                             RaggedGrab grab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
-                                            RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter)
+                                            RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter,
+                                            const Act& act, typename Act::Lane& al)
 {
 	WaitAllLoads(cur);
 
 	// ---- this window: starts at the string's current byte, whatever its alignment.  A string that fits takes one
 	// window; a longer one cuts its first window at a 16-byte boundary so that all the following ones are aligned.
-	const uint64_t left = S.end - S.pos;
+	uint64_t left = S.end - S.pos;
+	if constexpr (Act::kActive)
+		if (S.busy && !act.Wants(al))
+			left = 0;   // the search is over: the rest of the string is not needed, the lane moves on
 	const uint32_t nb = !S.busy ? 0u : left <= 128u ? uint32_t(left) : 128u - (uint32_t(S.pos) & 15u);
 	const bool ends = S.busy && nb == left;
 
@@ -291,8 +550,13 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			const uint32_t full = nbl >> 4, tail = nbl & 15u;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				if (uint32_t(k) < full)
-					StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+				if (uint32_t(k) < full) {
+					if constexpr (Act::kActive)
+						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
+						             S.pos + 16u * k);
+					else
+						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+				}
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
 				// all the partial last chunks of the wave in ONE pass: pick each lane's chunk, walk it with a snapshot
 				u32x4 v = cur[0];
@@ -300,21 +564,32 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 				for (int k = 1; k < 8; ++k)
 					if (full == uint32_t(k))
 						v = cur[k];
-				StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
+				if constexpr (Act::kActive)
+					StepPartialAct(p, lds, L, v, tail, S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
+					               S.pos + 16u * full);
+				else
+					StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
 			}
 		}
 		if (nb != 0 && !S.loaded) {
 			// the last bytes of the whole buffer: exact steps straight from memory
 			uint32_t st = S.hs != p.hot ? S.hs : S.cold;
 			const uint8_t* q = reinterpret_cast<const uint8_t*>(S.pos);
-			for (uint32_t i = 0; i < nb; ++i)
+			for (uint32_t i = 0; i < nb; ++i) {
 				st = SlowStep(p, lds, L, st, q[i]);
+				if constexpr (Act::kActive)
+					act.Step(p, lds, L, al, st, S.pos + i + 1);
+			}
 			S.hs = st < p.hot ? st : p.hot;
 			S.cold = st;
 		}
 	}
-	if (__any(ends) && !(p.flags & kDebugNoFinish))
+	if constexpr (Act::kActive) {
+		if (ends)
+			act.Finish(p, lds, L, al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
+	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
 		FinishRagged(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
+	}
 
 	// ---- move on
 	if (got) {
@@ -322,7 +597,11 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		S.pendEnd = textBase + offE;
 	}
 	if (takeNew) {
-		const uint32_t st = StartState(p, nIdx);
+		uint32_t st;
+		if constexpr (Act::kActive)
+			st = act.Start(p, lds, L, al, nIdx, nPos);
+		else
+			st = StartState(p, nIdx);
 		S.hs = st < p.hot ? st : p.hot;
 		S.cold = st;
 	}
@@ -334,17 +613,22 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	return __any(nBusy || S.pend);
 }
 
+template <class Act>
 __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned long long* workCounter,
-                                                         RaggedGrab grab)
+                                                         RaggedGrab grab, Act act)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
 	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + L.total + kRaggedFinBytes);
 	{
-		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
-		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
-			finHot[i] = recs[i];
+		if constexpr (!Act::kActive) {
+			const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+			for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+				finHot[i] = recs[i];
+		} else {
+			act.LoadLds(p, reinterpret_cast<uint8_t*>(finHot));   // the actions' own LDS data take that place
+		}
 		if (threadIdx.x == 0) {
 			work->next = 0;
 			work->end = 0;
@@ -365,6 +649,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	S.busy = S.loaded = S.pend = false;
 	S.sIdxN = 0;
 	S.pendPos = S.pendEnd = textBase;
+	typename Act::Lane al = {};
 	u32x4 a[8], b[8];
 	ZeroTile(a);
 	ZeroTile(b);
@@ -374,9 +659,9 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 		S.pendEnd = textBase + p.offsets[S.sIdxN + 1];
 	}
 	for (uint32_t iter = 0;; iter += 2) {
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter))
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))
 			break;
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1))
+		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al))
 			break;
 	}
 	FlushCounts(p, lds, L);
@@ -391,10 +676,11 @@ bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096;
 }
 
-int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
+namespace {
+
+template <class Act>
+int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Act& act, hipStream_t stream)
 {
-	if (int rc = CheckCounts(p))
-		return rc;
 	hipError_t e = hipMemsetAsync(workCounter, 0, sizeof(unsigned long long), stream);
 	if (e != hipSuccess)
 		return HipFail(e, "hipMemsetAsync(work counter)");
@@ -403,8 +689,8 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        int(ldsBytes));
+	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel<Act>),
+	                        hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	// one string per lane: spread the waves over every CU before stacking them (4..16 waves per block, 1 block per CU)
@@ -428,12 +714,51 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
 		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
 	}
-	hipLaunchKernelGGL(ScanRaggedKernel, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream, q,
-	                   workCounter, grab);
+	hipLaunchKernelGGL(ScanRaggedKernel<Act>, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
+	                   q, workCounter, grab, act);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "ragged kernel launch");
 	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
+int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	return LaunchRaggedT(p, workCounter, NoAct(), stream);
+}
+
+// The walks with actions take the ragged kernel from a few waves' worth of strings (below that, and for tables
+// whose counters do not pack, the one-string-per-lane kernels of exact.hip).
+bool RaggedActEligible(const ScanParams& p)
+{
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && !getenv("PIRE_HIP_NO_RAGGED_ACT");
+}
+
+int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream)
+{
+	ScanParams p = p0;
+	p.compact = 0;        // the re-walk with actions goes through the full table
+	p.outCounts = nullptr;
+	HalfFinalAct act;
+	act.results = outResults;
+	return LaunchRaggedT(p, workCounter, act, stream);
+}
+
+int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bool longest, bool throughEnd,
+                       long long* outLen, hipStream_t stream)
+{
+	ScanParams p = p0;
+	p.compact = 0;
+	p.outCounts = nullptr;
+	PrefixAct act;
+	act.outLen = outLen;
+	act.longest = longest ? 1 : 0;
+	act.throughEnd = throughEnd ? 1 : 0;
+	return LaunchRaggedT(p, workCounter, act, stream);
 }
 
 

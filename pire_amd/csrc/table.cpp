@@ -103,11 +103,16 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
-	// inside the hot set the order is free: non-final states first, so that "hot and Final" is one compare
-	// (HalfFinalScanner's per-step TakeAction, exact.hip HalfFinalKernel)
-	std::stable_partition(order.begin(), order.begin() + t.hot, [&](uint32_t s) { return !(t.flags[s] & kFinal); });
-	t.hotFinalLo = 0;
-	while (t.hotFinalLo < t.hot && !(t.flags[order[t.hotFinalLo]] & kFinal))
+	// inside the hot set the order is free: plain states first, then Dead ones, then Final ones, so that "hot and
+	// Final" and "hot and Final or Dead" are one compare each (HalfFinalScanner's per-step TakeAction, the prefix
+	// searches' stop conditions; ragged.hip tests the largest id a 16-byte chunk went through against them)
+	auto rankOf = [&](uint32_t s) { return (t.flags[s] & kFinal) ? 2 : (t.flags[s] & kDead) ? 1 : 0; };
+	std::stable_sort(order.begin(), order.begin() + t.hot, [&](uint32_t a, uint32_t b) { return rankOf(a) < rankOf(b); });
+	t.hotDeadLo = 0;
+	while (t.hotDeadLo < t.hot && rankOf(order[t.hotDeadLo]) == 0)
+		++t.hotDeadLo;
+	t.hotFinalLo = t.hotDeadLo;
+	while (t.hotFinalLo < t.hot && rankOf(order[t.hotFinalLo]) == 1)
 		++t.hotFinalLo;
 	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
@@ -156,6 +161,18 @@ void ChooseHotAndPermute(HostTable& t)
 		mass[afterBegin] += 1.0;
 		mass[t.initial] += 1.0;
 	}
+	// where the model's text spends its time: searches over scanners that are soon Dead (lexers) or soon Final end
+	// after a few bytes, which decides between the kernels of the prefix searches (exact.hip LaunchPrefix)
+	double all = 0, dead = 0, fin = 0;
+	for (uint32_t s = 0; s < N; ++s) {
+		all += mass[s];
+		if (t.flags[s] & kDead)
+			dead += mass[s];
+		if (t.flags[s] & kFinal)
+			fin += mass[s];
+	}
+	t.deadShare = all > 0 ? float(dead / all) : 0.0f;
+	t.finalShare = all > 0 ? float(fin / all) : 0.0f;
 	const double top = *std::max_element(mass.begin(), mass.end());
 	t.priorMass.resize(N);
 	for (uint32_t s = 0; s < N; ++s)
