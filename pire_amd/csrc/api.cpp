@@ -147,6 +147,10 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		// need 128 readable bytes at `text` for the ragged kernel, which the caller guarantees by passing a batch
 		// (a batch with less than 4 KiB of text is not worth a GPU launch; use PIRE_HIP_RUN_GENERIC to force the
 		// offset-exact kernel)
+		// Few long strings starve a one-string-per-lane kernel: cut them into segments (segmented.hip).  With
+		// device offsets the host does not know the lengths, so only fixed-length records qualify here.
+		if (!offsets && !(flags & PIRE_HIP_RUN_GENERIC) && n && SegmentedEligible(n, n * len))
+			return RunSegmented(t, p, nullptr, stream);
 		return Dispatch(p, stream, NextWorkSlot(t), offsets ? ~0ull : 0);
 	}
 
@@ -202,8 +206,12 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return HipFail(e, "hipMemcpy(counts)");
 		p.outCounts = static_cast<unsigned long long*>(dCnt);
 	}
-	if (int rc = Dispatch(p, stream, NextWorkSlot(t), textBytes))
+	if (!(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes)) {
+		if (int rc = RunSegmented(t, p, offsets, stream))
+			return rc;
+	} else if (int rc = Dispatch(p, stream, NextWorkSlot(t), textBytes)) {
 		return rc;
+	}
 	hipError_t e = hipSuccess;
 	if (outIdx)
 		e = hipMemcpyAsync(outIdx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(1024) void ScanGenericKernel(ScanParams p)
 			uint64_t b, e;
 			if (p.offsets) {
 				b = p.offsets[s];
-				e = p.offsets[s + 1];
+				e = p.ends ? p.ends[s] : p.offsets[s + 1];
 			} else {
 				b = s * p.stride;
 				e = b + p.len;

@@ -162,6 +162,8 @@ struct pire_hip_table {
 	pirehip::DeviceTable dev;
 	std::mutex uploadMutex;
 	std::atomic<uint32_t> workSlot{0};   // round-robin over dev.workCounter[kWorkSlots]
+	std::mutex segMutex;
+	std::vector<uint32_t> segModes;      // segmented.hip: mode representatives (state indices) earlier calls learned
 };
 
 namespace pirehip {
@@ -196,6 +198,9 @@ struct ScanParams {
 	// batch
 	const uint8_t* text;
 	const uint64_t* offsets; // nullable: then string i = [i*stride, i*stride+len)
+	const uint64_t* ends;    // nullable: string i = [offsets[i], ends[i]) -- strings may overlap or leave gaps (the
+	                         // segments of segmented.hip); then textEnd = bytes readable at `text`
+	uint64_t textEnd;
 	uint64_t n, len, stride;
 	const uint32_t* initIdx; // nullable
 	uint32_t* outIdx;        // nullable
@@ -269,6 +274,10 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
+// segmented.hip: few long strings, cut into segments that are scanned in parallel (speculatively; the chain of
+// segments is then followed on the host, so the call synchronises its stream)
+bool SegmentedEligible(uint64_t n, uint64_t totalBytes);
+int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream);
 void NoteKernel(const char* name);   // what pire_hip_last_kernel() reports (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);

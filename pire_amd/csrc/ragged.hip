@@ -534,9 +534,10 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	const bool got = AssignPending(p, work, workCounter, grab, R, S);
 	uint64_t offB = 0, offE = 0;
 	if (__any(got)) {
-		const uint64_t* offPtr = p.offsets + (got ? S.sIdxN : 0u);
+		const uint32_t which = got ? S.sIdxN : 0u;
+		const uint64_t* offPtr = p.offsets + which;
 		offB = offPtr[0];
-		offE = offPtr[1];
+		offE = p.ends ? p.ends[which] : offPtr[1];
 	}
 
 	// ---- walk the current window
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	LoadTableToLds(p, lds, L);   // ends with a barrier
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
-	const uint64_t safeEnd = (textBase + p.offsets[p.n] + 15) & ~uint64_t(15);
+	const uint64_t safeEnd = (textBase + (p.ends ? p.textEnd : p.offsets[p.n]) + 15) & ~uint64_t(15);
 
 	RaggedRange R = {0, 0, false};
 	RaggedLane S;
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 
 	if (AssignPending(p, work, workCounter, grab, R, S)) {
 		S.pendPos = textBase + p.offsets[S.sIdxN];
-		S.pendEnd = textBase + p.offsets[S.sIdxN + 1];
+		S.pendEnd = textBase + (p.ends ? p.ends[S.sIdxN] : p.offsets[S.sIdxN + 1]);
 	}
 	for (uint32_t iter = 0;; iter += 2) {
 		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))

@@ -41,7 +41,7 @@ def half_tables():
     return out
 
 
-@pytest.mark.parametrize("name,blob,alphabet", half_tables(), ids=lambda v: v if isinstance(v, str) else None)
+@pytest.mark.parametrize("name,blob,alphabet", half_tables(), ids=[t[0] for t in half_tables()])
 def test_ragged_half_final_matches_oracle_and_exact_kernel(name, blob, alphabet):
     import pire_amd
     from pire_amd import binding as pb
@@ -80,7 +80,7 @@ def prefix_tables():
     return out
 
 
-@pytest.mark.parametrize("name,blob", prefix_tables(), ids=lambda v: v if isinstance(v, str) else None)
+@pytest.mark.parametrize("name,blob", prefix_tables(), ids=[t[0] for t in prefix_tables()])
 def test_ragged_prefix_matches_oracle_and_exact_kernel(name, blob):
     import pire_amd
     from pire_amd import binding as pb

@@ -1,0 +1,123 @@
+"""Few long strings (segmented.hip): strings are cut into segments that are scanned in parallel from GUESSED start
+states (one guess per learned mode of the automaton); the host follows the chain of segments and accepts only what was
+computed from the state the chain is really in -- so the results must be the reference's whatever the automaton and
+however bad the guesses.  Tiny segments and warm-ups (environment knobs) make wrong guesses common on short test
+strings; a parity automaton never forgets its start state, so its guesses are coin tosses until every state is a mode."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def tables():
+    out = []
+    for name in ("survey_known_answer", "inline_glue3", "set_a", "set_d"):
+        c = [x for x in H.all_cases() + H.big_sets() if x["name"] == name][0]
+        out.append((name, H.load_blob(c["blob"])))
+    if ob.ref_available():
+        # even number of a's / b's: the state after any text depends on where the walk started, for ever
+        out.append(("parity", ob.RefScanner.compile(["(b*ab*a)*b*", "(a*ba*b)*a*"], ["n", "n"]).save()))
+    return out
+
+
+ALPHABET = b"abc ABCDEFGHIJKLMNOPQRSTUVWXYZ hello wd0123456789-()@net"
+
+
+def strings_for(rng, name):
+    lens = [0, 1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4096, 4097, 20000] + [int(x) for x in rng.randint(0, 3000, size=40)]
+    a = np.frombuffer(b"ab" if name == "parity" else ALPHABET, dtype=np.uint8)
+    out = [a[rng.randint(0, len(a), size=k)].tobytes() for k in lens]
+    if name != "parity":
+        tails = [b" hello   world", b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", b" http://yandex.ru/", b"(123) 456-7890", b"abc", b"xn"]
+        out = [s + (tails[i % len(tails)] if i % 3 == 0 else b"") for i, s in enumerate(out)]
+    return out
+
+
+@pytest.mark.parametrize("name,blob", tables(), ids=[n for n, _ in tables()])
+@pytest.mark.parametrize("seg,warm,modes,budget", [(64, 0, 6, 32), (100, 16, 1, 0), (256, 256, 6, 32), (128, 32, 2, 1),
+                                                   (4096, 256, 3, 4)])
+def test_segmented_scan_is_exact(name, blob, seg, warm, modes, budget, monkeypatch):
+    import pire_amd
+    from pire_amd import binding as pb
+
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", str(warm))
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_MODES", str(modes))      # 1: nothing is learned
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BUDGET", str(budget))    # 0: every surprise ends in the plain walk
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(seg * 7 + warm)
+    strings = strings_for(rng, name)
+    text, offs = H.pack(strings)
+    for flags in (3, 0, 1, 2):
+        oi, of = o.run(*ob.pack_strings(strings), flags=flags)
+        gi, gf, cnt = t.run(text, offs, flags=flags, counts=True)
+        assert pb.last_kernel() == "segmented"
+        assert (gi == oi).all() and (gf == of).all(), (name, flags, np.nonzero(gi != oi)[0][:5])
+        assert cnt[0] == int(of.sum()) and cnt[1] == len(strings)
+        xi, xf = t.run(text, offs, flags=flags | pb.FLAG_GENERIC)
+        assert pb.last_kernel() == "generic"
+        assert (xi == oi).all() and (xf == of).all()
+    # resume states (RunHelper(sc, st), run.h:391-392): every string from a state reached by another text
+    pre = [s[:7] for s in strings]
+    init, _ = o.run(*ob.pack_strings(pre), flags=1)
+    oi, of = o.run(*ob.pack_strings(strings), flags=2, init_idx=init)
+    gi, gf = t.run(text, offs, flags=2, init_idx=init)
+    assert (gi == oi).all() and (gf == of).all()
+
+
+def test_segmented_fixed_length_records_host_and_device(monkeypatch):
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", "512")
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", "64")
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    n, length = 37, 5000 + 8          # not a multiple of the segment size; stride 16-byte aligned
+    data = ob.corpus_fill(big["corpus"]["seed"], 0, n, length, H.plants_for(big))
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs)
+    gi, gf, cnt = t.run_strided_host(data, counts=True)
+    assert pb.last_kernel() == "segmented"
+    assert (gi == oi).all() and (gf == of).all() and cnt[1] == n and cnt[0] == int(of.sum())
+    d = torch.as_tensor(np.array(data), device="cuda")
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    t.run_strided_device(d.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0,
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert pb.last_kernel() == "segmented"
+    assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()
+
+
+def test_one_long_string_takes_the_segmented_path_by_itself():
+    """No knobs: 8 strings of 4 MiB are few and long -- the library cuts them up on its own."""
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    n, length = 8, 4 << 20
+    data = ob.corpus_fill(big["corpus"]["seed"], 0, n * (length // 4096), 4096, H.plants_for(big)).reshape(n, length)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs)
+    d = torch.as_tensor(np.array(data), device="cuda")
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+    t.run_strided_device(d.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), cnt.data_ptr(), 0,
+                         torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert pb.last_kernel() == "segmented"
+    assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()
+    assert int(cnt[1]) == n and int(cnt[0]) == int(of.sum())
+    gi, gf = t.run(data.reshape(-1), offs)            # host pointers, offsets
+    assert pb.last_kernel() == "segmented"
+    assert (gi == oi).all() and (gf == of).all()
