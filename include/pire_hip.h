@@ -226,7 +226,7 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
 /* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
- * "prefix", "ragged_half_final", "half_final"); diagnostics. */
+ * "prefix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
 
 /* Milliseconds the most recent kernel launched by this thread took, measured with hipEvents on the

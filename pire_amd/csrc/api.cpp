@@ -129,6 +129,8 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		return PIRE_HIP_EINVAL;
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	// only the public bits: the upper ones are the kernels' internal switches (device_common.h)
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC;
 	ScanParams p;
 	if (int rc = FillParams(t, &p, flags))
 		return rc;

@@ -43,6 +43,7 @@ constexpr uint32_t kDebugNoHist = 1u << 27;
 constexpr uint32_t kDebugNoPartial = 1u << 26;   // ragged kernel timing experiments only (results are wrong)
 constexpr uint32_t kDebugNoFinish = 1u << 25;
 constexpr uint32_t kDebugNoTrap = 1u << 24;
+constexpr uint32_t kPermIds = 1u << 23;   // internal (segmented.hip): initIdx holds, outIdx receives, DEVICE state ids
 
 // Block-wide copy of `count16` 16-byte units from global memory to LDS with up to BATCH loads per thread in flight
 // before the first store: a copy loop that waits for every single load pays one memory latency per iteration, and at
@@ -143,14 +144,19 @@ __device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_
 }
 
 // Start state of string s (perm id): Initialize() or the caller's resume state, then Begin() if asked.
+__device__ __forceinline__ uint32_t StartStateFrom(const ScanParams& p, uint32_t init)
+{
+	uint32_t st = (p.flags & kPermIds) ? init : p.permOfOrig[init];
+	if (p.flags & PIRE_HIP_RUN_BEGIN)
+		st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+	return st;
+}
+
 __device__ __forceinline__ uint32_t StartState(const ScanParams& p, uint64_t s)
 {
 	if (!p.initIdx)
 		return p.startPerm;   // host folded Initialize()+Begin() into one id
-	uint32_t st = p.permOfOrig[p.initIdx[s]];
-	if (p.flags & PIRE_HIP_RUN_BEGIN)
-		st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
-	return st;
+	return StartStateFrom(p, p.initIdx[s]);
 }
 
 // End(), outputs and block-local match counters for one finished string.  One 16-byte record load replaces the
@@ -164,7 +170,7 @@ __device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const 
 	const uint64_t mask = (uint64_t(raw.w) << 32) | raw.z;
 	if (active) {
 		if (p.outIdx)
-			p.outIdx[s] = orig;
+			p.outIdx[s] = (p.flags & kPermIds) ? endPerm : orig;
 		if (p.outFinal)
 			p.outFinal[s] = fl & kFinal;
 	}

@@ -386,7 +386,7 @@ __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, 
 	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
 	if (active) {
 		if (p.outIdx)
-			p.outIdx[s] = orig;
+			p.outIdx[s] = (p.flags & kPermIds) ? endPerm : orig;
 		if (p.outFinal)
 			p.outFinal[s] = fl & kFinal;
 	}
@@ -425,6 +425,7 @@ struct RaggedLane {
 	// pending next string: its offsets are fetched one iteration before it starts
 	uint64_t pendPos, pendEnd;
 	uint32_t sIdxN;
+	uint32_t pendInit;   // its resume state (only with init states), fetched with the offsets
 	bool pend;
 };
 
@@ -533,11 +534,14 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	// end of this iteration, so the one wait the compiler inserts for them sits behind the walk
 	const bool got = AssignPending(p, work, workCounter, grab, R, S);
 	uint64_t offB = 0, offE = 0;
+	uint32_t initV = 0;
 	if (__any(got)) {
 		const uint32_t which = got ? S.sIdxN : 0u;
 		const uint64_t* offPtr = p.offsets + which;
 		offB = offPtr[0];
 		offE = p.ends ? p.ends[which] : offPtr[1];
+		if (p.initIdx)
+			initV = p.initIdx[which];
 	}
 
 	// ---- walk the current window
@@ -593,16 +597,18 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	}
 
 	// ---- move on
+	const uint32_t startInit = S.pendInit;   // of the string that starts now (takeNew), before the refill below
 	if (got) {
 		S.pendPos = textBase + offB;
 		S.pendEnd = textBase + offE;
+		S.pendInit = initV;
 	}
 	if (takeNew) {
 		uint32_t st;
 		if constexpr (Act::kActive)
 			st = act.Start(p, lds, L, al, nIdx, nPos);
 		else
-			st = StartState(p, nIdx);
+			st = p.initIdx ? StartStateFrom(p, startInit) : p.startPerm;
 		S.hs = st < p.hot ? st : p.hot;
 		S.cold = st;
 	}
@@ -649,6 +655,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	S.hs = S.cold = 0;
 	S.busy = S.loaded = S.pend = false;
 	S.sIdxN = 0;
+	S.pendInit = 0;
 	S.pendPos = S.pendEnd = textBase;
 	typename Act::Lane al = {};
 	u32x4 a[8], b[8];
@@ -658,6 +665,8 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	if (AssignPending(p, work, workCounter, grab, R, S)) {
 		S.pendPos = textBase + p.offsets[S.sIdxN];
 		S.pendEnd = textBase + (p.ends ? p.ends[S.sIdxN] : p.offsets[S.sIdxN + 1]);
+		if (p.initIdx)
+			S.pendInit = p.initIdx[S.sIdxN];
 	}
 	for (uint32_t iter = 0;; iter += 2) {
 		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))

@@ -12,22 +12,28 @@
 //           string's start state; further modes are learned from the states the chain finds itself in unexpectedly
 //           (two modes cover 99.96-100 % of the segments of the benchmark tables).
 //   scan    per mode one batch through the ordinary kernels: every segment from its guess -> its end state.
-//   chain   the host walks each string's segments: in state `cur` at the start of segment k it looks for a mode
-//           whose guess for k IS cur and takes that mode's end state -- an exact result, because a DFA step depends
-//           on nothing but the state and the bytes.  No mode matches: segment k is scanned from `cur` on the
-//           device (all strings' pending segments in one small batch), a state that keeps turning up becomes a
-//           mode, and when the budget of such round trips is spent the rest of the string is walked the plain way.
-//           So the result is exact whatever the automaton; the speed depends on how well it forgets.
+//   chain   in state `cur` at the start of segment k the chain looks for a mode whose guess for k IS cur and takes
+//           that mode's end state -- an exact result, because a DFA step depends on nothing but the state and the
+//           bytes.  On the device this is function composition: segment k maps "the mode whose guess is the true
+//           state at k" to the same for k+1 (or to "none"); an inclusive scan composes the maps, and every segment
+//           reads the mode it is really entered in.  Where the chain breaks (no mode predicted the true state),
+//           the host is told the segment and the state: that segment is scanned from that state (all strings'
+//           breaks in one small batch) and patched in as a one-segment mode; a state that keeps breaking chains
+//           becomes a real mode; when the budget of such round trips is spent the rest of the string is walked the
+//           plain way.  So the result is exact whatever the automaton; the speed depends on how well it forgets.
 //   finish  End(), outputs and match counters exactly like the other kernels.
 //
 // Results are the reference's (run.h:271-275 walks the same bytes in the same order); only the schedule differs.
-// The call synchronises its stream (the chain runs on the host).
+// The call synchronises its stream (the host reads, per round, whether and where chains broke).
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <unordered_map>
 #include <vector>
 
@@ -36,6 +42,12 @@
 namespace pirehip {
 
 namespace {
+
+constexpr uint32_t kMaxModes = 6;          // learned modes; slot kMaxModes is the patch slot
+constexpr uint32_t kSlots = kMaxModes + 1; // bytes 0..6 of a map; byte 7 = kResetMap or 0
+constexpr uint64_t kResetMap = 1ull << 56; // the map ignores its input (first segment of a string)
+constexpr uint32_t kNoSlot = 0xFF;
+constexpr uint32_t kNoState = 0xFFFFFFFFu;
 
 struct SegGeometry {
 	uint64_t segBytes, warmBytes;
@@ -48,7 +60,26 @@ struct SegArrays {
 	uint64_t* segBegin;            // [nSeg] byte offsets into text
 	uint64_t* segEnd;
 	uint64_t* warmBegin;
+	uint32_t* segStr;              // [nSeg] string of the segment
+	uint32_t* segJ;                // [nSeg] index of the segment inside its string
 	uint32_t* initSeg;             // [nSeg] caller's resume state of the segment's string (only with init states)
+};
+
+// guess / end state (DEVICE state ids: the batches run with kPermIds) of every segment under every slot
+struct SlotArrays {
+	uint32_t* guess[kSlots];
+	uint32_t* end[kSlots];
+	uint32_t count;                // slots in use below kMaxModes
+};
+
+struct ChainArrays {
+	uint64_t* maps;                // [nSeg] slot at k -> slot at k+1, 7 x u8 (+ kResetMap)
+	uint64_t* prefix;              // [nSeg] inclusive composition
+	uint32_t* finalState;          // [nStrings]
+	uint32_t* strDone;             // [nStrings] 1: finalState set by the plain walk
+	uint32_t* breakSeg;            // [nStrings] first segment no slot predicted (kNoState: none)
+	uint32_t* breakState;          // [nStrings] the state the chain is in there
+	uint32_t* broken;              // [1]
 };
 
 __device__ __forceinline__ void StringOfSegment(const SegGeometry& g, uint64_t seg, uint64_t* str, uint64_t* j)
@@ -91,11 +122,118 @@ __global__ void SegmentPrepKernel(ScanParams p, SegGeometry g, SegArrays a)
 	a.segBegin[seg] = b;
 	a.segEnd[seg] = e;
 	a.warmBegin[seg] = b - w;
+	a.segStr[seg] = uint32_t(s);
+	a.segJ[seg] = uint32_t(j);
 	if (a.initSeg)
-		a.initSeg[seg] = p.initIdx[s];
+		a.initSeg[seg] = p.permOfOrig[p.initIdx[s]];
 }
 
-// finish: one lane per string; endIdx[s] = the state index (reference numbering) string s ended in, before End().
+__global__ void SegmentFillKernel(uint32_t* dst, uint32_t value, uint64_t n)
+{
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n)
+		dst[i] = value;
+}
+
+// The map of segment k: entered in slot i (i.e. in state guess[i][k]) it ends in end[i][k]; which slot of k+1 has
+// that state as its guess?  The first segment of a string is entered in slot 0 whatever came before it, so its map
+// is constant -- which also restarts the composition at every string.
+__global__ void SegmentMapKernel(SegGeometry g, SegArrays a, SlotArrays sl, ChainArrays c)
+{
+	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (k >= g.nSeg)
+		return;
+	const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
+	uint64_t map = 0;
+	if (!last) {
+		uint32_t nextGuess[kSlots];
+#pragma unroll
+		for (uint32_t j = 0; j < kSlots; ++j)
+			nextGuess[j] = (j < sl.count || j == kMaxModes) ? sl.guess[j][k + 1] : kNoState;
+#pragma unroll
+		for (uint32_t i = 0; i < kSlots; ++i) {
+			uint32_t to = kNoSlot;
+			if (i < sl.count || i == kMaxModes) {
+				const uint32_t e = sl.end[i][k];
+				const bool live = sl.guess[i][k] != kNoState;   // the patch slot is empty almost everywhere
+#pragma unroll
+				for (uint32_t j = kSlots; j-- > 0;)
+					if (live && nextGuess[j] == e)
+						to = j;
+			}
+			map |= uint64_t(to) << (8 * i);
+		}
+	}
+	if (a.segJ[k] == 0) {
+		// entered in slot 0 whatever came before -- even a broken chain of the string in front
+		const uint64_t to0 = map & 0xFF;
+		map = to0 * 0x0001010101010101ull | kResetMap;
+	}
+	c.maps[k] = map;
+}
+
+struct ComposeMaps {
+	__host__ __device__ __forceinline__ uint64_t operator()(const uint64_t& first, const uint64_t& then) const
+	{
+		if (then & kResetMap)
+			return then;
+		uint64_t out = first & kResetMap;   // a constant map stays constant
+#pragma unroll
+		for (uint32_t i = 0; i < kSlots; ++i) {
+			const uint32_t mid = uint32_t(first >> (8 * i)) & 0xFF;
+			const uint32_t to = mid == kNoSlot ? kNoSlot : uint32_t(then >> (8 * mid)) & 0xFF;
+			out |= uint64_t(to) << (8 * i);
+		}
+		return out;
+	}
+};
+
+// Every segment reads the slot it is really entered in; the first segment of a string nobody predicted reports
+// itself; the last segment of a resolved string delivers the string's end state.
+__global__ void SegmentResolveKernel(SegGeometry g, SegArrays a, SlotArrays sl, ChainArrays c)
+{
+	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (k >= g.nSeg)
+		return;
+	const uint32_t str = a.segStr[k];
+	if (c.strDone[str])
+		return;
+	const uint32_t j = a.segJ[k];
+	const uint32_t slot = j == 0 ? 0u : uint32_t(c.prefix[k - 1]) & 0xFF;
+	if (slot == kNoSlot) {
+		const uint32_t before = j == 1 ? 0u : uint32_t(c.prefix[k - 2]) & 0xFF;
+		if (before != kNoSlot) {   // the chain was intact up to segment k-1: this is where it breaks
+			c.breakSeg[str] = uint32_t(k);
+			c.breakState[str] = sl.end[before][k - 1];
+			atomicAdd(c.broken, 1u);
+		}
+		return;
+	}
+	const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
+	if (last)
+		c.finalState[str] = sl.end[slot][k];
+}
+
+// Patch: segment breakSeg[i] of broken string i was scanned from breakState[i]; enter it as that segment's patch
+// slot -- or, after the plain walk to the end of the string, as the string's end state.
+__global__ void SegmentPatchKernel(const uint32_t* strings, const uint32_t* results, uint32_t m, uint32_t plain,
+                                   SlotArrays sl, ChainArrays c)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= m)
+		return;
+	const uint32_t str = strings[i];
+	if (plain) {
+		c.finalState[str] = results[i];
+		c.strDone[str] = 1;
+	} else {
+		const uint32_t k = c.breakSeg[str];
+		sl.guess[kMaxModes][k] = c.breakState[str];
+		sl.end[kMaxModes][k] = results[i];
+	}
+}
+
+// finish: one lane per string; endIdx[s] = the device state id string s ended in, before End().
 __global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const uint32_t* endIdx)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -108,7 +246,7 @@ __global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const 
 	     task += uint64_t(gridDim.x) * wavesPerBlock) {
 		const uint64_t s = task * 64 + lane;
 		const bool active = s < p.n;
-		Finish(p, lds, L, s, active, active ? p.permOfOrig[endIdx[s]] : 0u);
+		Finish(p, lds, L, s, active, active ? endIdx[s] : 0u);
 	}
 	FlushCounts(p, lds, L);
 }
@@ -119,25 +257,46 @@ uint64_t EnvBytes(const char* name, uint64_t fallback)
 	return v && *v ? uint64_t(strtoull(v, nullptr, 10)) : fallback;
 }
 
-// Stream-ordered scratch: freed on the stream when the call returns, i.e. after everything enqueued before.
+// Stream-ordered scratch: ONE allocation per call, made while the stream is still idle (allocating from the pool
+// with kernels in flight cost about a millisecond per call), carved up as the call goes, freed on the stream when
+// the call returns, i.e. after everything enqueued before.
 struct StreamScratch {
 	hipStream_t stream;
-	std::vector<void*> ptrs;
+	uint8_t* base = nullptr;
+	size_t size = 0, used = 0;
 	explicit StreamScratch(hipStream_t s) : stream(s) {}
 	~StreamScratch()
 	{
-		for (void* p : ptrs)
-			(void)hipFreeAsync(p, stream);
+		if (base)
+			(void)hipFreeAsync(base, stream);
+	}
+	int Reserve(size_t bytes)
+	{
+		// keep freed scratch in the device's pool: by default it goes back to the driver at the next synchronize
+		int dev = 0;
+		hipMemPool_t pool;
+		if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+			uint64_t keep = 1ull << 30;
+			(void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+		}
+		void* d = nullptr;
+		hipError_t e = hipMallocAsync(&d, bytes, stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(segments)");
+		base = static_cast<uint8_t*>(d);
+		size = bytes;
+		return PIRE_HIP_OK;
 	}
 	template <class T>
 	int Alloc(T** out, size_t count)
 	{
-		void* d = nullptr;
-		hipError_t e = hipMallocAsync(&d, std::max<size_t>(count * sizeof(T), 16), stream);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMallocAsync(segments)");
-		ptrs.push_back(d);
-		*out = static_cast<T*>(d);
+		const size_t bytes = (std::max<size_t>(count * sizeof(T), 16) + 255) & ~size_t(255);
+		if (used + bytes > size) {
+			SetError("segmented scan: scratch arena too small");
+			return PIRE_HIP_ENOMEM;
+		}
+		*out = reinterpret_cast<T*>(base + used);
+		used += bytes;
 		return PIRE_HIP_OK;
 	}
 };
@@ -148,26 +307,6 @@ int ScanBatch(const ScanParams& q, pire_hip_table* t, hipStream_t stream)
 		return LaunchRagged(q, t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots, stream);
 	return LaunchGeneric(q, stream);
 }
-
-}  // namespace
-
-// Worth it when the lanes would starve: few strings, long ones.  PIRE_HIP_SEGMENT_BYTES forces the mode (tests).
-bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
-{
-	if (getenv("PIRE_HIP_NO_SEGMENTS") || n == 0 || n >= (1ull << 31))
-		return false;
-	if (getenv("PIRE_HIP_SEGMENT_BYTES"))
-		return true;
-	return n <= 32768 && totalBytes / n >= 32768;
-}
-
-namespace {
-
-struct Mode {
-	uint32_t* dGuess = nullptr;
-	uint32_t* dEnd = nullptr;
-	std::vector<uint32_t> guess, end;   // host copies
-};
 
 #define PIRE_TRY(expr)                                                                                                 \
 	do {                                                                                                           \
@@ -182,24 +321,46 @@ int HipOk(hipError_t e, const char* what)
 
 }  // namespace
 
+// Worth it when the lanes would starve: few strings, long ones.  PIRE_HIP_SEGMENT_BYTES forces the mode (tests).
+bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
+{
+	if (getenv("PIRE_HIP_NO_SEGMENTS") || n == 0 || n >= (1ull << 31))
+		return false;
+	if (getenv("PIRE_HIP_SEGMENT_BYTES"))
+		return true;
+	return n <= 32768 && totalBytes / n >= 32768;
+}
+
 // p: the original batch with DEVICE pointers (strided, or offsets on the device); hostOffsets: the same offsets on
 // the host (nullptr for strided batches) -- the host has to know the lengths to cut the strings up.
 int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream)
 {
 	PIRE_TRY(CheckCounts(p));
+	// diagnostics (PIRE_HIP_SEGMENT_STATS): where the host's time goes, with the stream drained at every mark
+	const bool wantStats = getenv("PIRE_HIP_SEGMENT_STATS") != nullptr;
+	auto t0 = std::chrono::steady_clock::now();
+	std::string timeline;
+	auto mark = [&](const char* what) {
+		if (!wantStats)
+			return;
+		(void)hipStreamSynchronize(stream);
+		const auto t1 = std::chrono::steady_clock::now();
+		char buf[64];
+		snprintf(buf, sizeof(buf), " %s %.0f us;", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+		timeline += buf;
+		t0 = t1;
+	};
 	const uint64_t n = p.n;
 	const uint64_t total = hostOffsets ? hostOffsets[n] - hostOffsets[0] : n * p.len;
 	int cus = 0;
 	PIRE_TRY(DeviceCUs(&cus));
-	// segments: a quarter of the lanes' worth of them (the chain on the host costs per segment), a multiple of the
-	// 128-byte window, long against the warm-up
-	const uint64_t wanted = uint64_t(cus) * 256;
+	// segments: as many as there are lanes, a multiple of the 128-byte window, long against the warm-up
+	const uint64_t wanted = uint64_t(cus) * 1024;
 	uint64_t segBytes = std::min<uint64_t>(1u << 20, std::max<uint64_t>(4096, (total / wanted + 127) / 128 * 128));
 	segBytes = EnvBytes("PIRE_HIP_SEGMENT_BYTES", segBytes);
 	const uint64_t warmBytes = EnvBytes("PIRE_HIP_SEGMENT_WARMUP", 256);
-	const size_t maxModes = size_t(std::max<uint64_t>(1, EnvBytes("PIRE_HIP_SEGMENT_MODES", 6)));
+	const uint32_t maxModes = uint32_t(std::min<uint64_t>(kMaxModes, std::max<uint64_t>(1, EnvBytes("PIRE_HIP_SEGMENT_MODES", 6))));
 	uint64_t budget = EnvBytes("PIRE_HIP_SEGMENT_BUDGET", 32);   // round trips for segments no mode predicted
-	const bool wantStats = getenv("PIRE_HIP_SEGMENT_STATS") != nullptr;
 	if (segBytes == 0) {
 		SetError("PIRE_HIP_SEGMENT_BYTES must be positive");
 		return PIRE_HIP_EINVAL;
@@ -227,6 +388,16 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	}
 	const uint64_t S = g.nSeg;
 	StreamScratch scratch(stream);
+	size_t tempBytes = 0;
+	PIRE_TRY(HipOk(hipcub::DeviceScan::InclusiveScan(nullptr, tempBytes, static_cast<uint64_t*>(nullptr),
+	                                                 static_cast<uint64_t*>(nullptr), ComposeMaps(), int(S), stream), "hipcub::DeviceScan"));
+	{
+		const size_t perSeg = 3 * 8 + 3 * 4            // the cut
+		                      + (size_t(maxModes) + 1) * 8 + 4   // guess + end per slot, the constant init array
+		                      + 2 * 8;                 // maps, prefix
+		const size_t perString = 5 * 4 + 2 * 8 + 3 * 4 + 4;
+		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + tempBytes + 64 * 256));
+	}
 	if (hostOffsets) {
 		uint32_t* d = nullptr;
 		PIRE_TRY(scratch.Alloc(&d, n + 1));
@@ -239,19 +410,18 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	PIRE_TRY(scratch.Alloc(&a.segBegin, S));
 	PIRE_TRY(scratch.Alloc(&a.segEnd, S));
 	PIRE_TRY(scratch.Alloc(&a.warmBegin, S));
+	PIRE_TRY(scratch.Alloc(&a.segStr, S));
+	PIRE_TRY(scratch.Alloc(&a.segJ, S));
 	if (p.initIdx)
 		PIRE_TRY(scratch.Alloc(&a.initSeg, S));
 	const unsigned blocks = unsigned((S + 255) / 256);
 	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a);
-	std::vector<uint64_t> segBegin(S), segEnd(S);   // the host's copy of the cut (same arithmetic)
-	for (uint64_t i = 0; i < n; ++i) {
+	// the host's copy of the cut (same arithmetic), for the batches of broken chains
+	auto segBeginOf = [&](uint64_t i, uint32_t k) {
 		const uint64_t B = hostOffsets ? hostOffsets[i] : i * p.stride;
-		const uint64_t E = hostOffsets ? hostOffsets[i + 1] : B + p.len;
-		for (uint32_t k = strFirst[i]; k < strFirst[i + 1]; ++k) {
-			segBegin[k] = B + uint64_t(k - strFirst[i]) * segBytes;
-			segEnd[k] = std::min(E, segBegin[k] + segBytes);
-		}
-	}
+		return B + uint64_t(k - strFirst[i]) * segBytes;
+	};
+	auto stringEndOf = [&](uint64_t i) { return hostOffsets ? hostOffsets[i + 1] : i * p.stride + p.len; };
 
 	ScanParams q = p;   // the segment batches: same table, same text
 	q.len = q.stride = 0;
@@ -259,175 +429,175 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	q.outFinal = nullptr;
 	q.outCounts = nullptr;
 
-	// ---- one mode: warm-up from its representative (mode 0: the string's own start state, and the first segment's
-	// warm-up is empty, so its guess is the true start state), then the scan proper from the guesses
-	std::vector<Mode> modes;
+	// ---- slots
+	SlotArrays sl = {};
+	PIRE_TRY(scratch.Alloc(&sl.guess[kMaxModes], S));   // the patch slot: empty
+	PIRE_TRY(scratch.Alloc(&sl.end[kMaxModes], S));
+	hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, sl.guess[kMaxModes], kNoState, S);
+	hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, sl.end[kMaxModes], kNoState, S);
 	uint32_t* dConst = nullptr;
+	// one mode: warm-up from its representative (mode 0: the string's own start state, and the first segment's
+	// warm-up is empty, so its guess is the true start state), then the scan proper from the guesses
 	auto addMode = [&](bool first, uint32_t representative) -> int {
-		Mode m;
-		PIRE_TRY(scratch.Alloc(&m.dGuess, S));
-		PIRE_TRY(scratch.Alloc(&m.dEnd, S));
+		const uint32_t m = sl.count;
+		PIRE_TRY(scratch.Alloc(&sl.guess[m], S));
+		PIRE_TRY(scratch.Alloc(&sl.end[m], S));
 		q.n = S;
 		q.offsets = a.warmBegin;
 		q.ends = a.segBegin;
 		if (first) {
 			q.initIdx = a.initSeg;                       // nullable: then startPerm (Initialize + Begin folded)
-			q.flags = p.flags & PIRE_HIP_RUN_BEGIN;
+			q.flags = (p.flags & PIRE_HIP_RUN_BEGIN) | kPermIds;
 		} else {
 			if (!dConst)
 				PIRE_TRY(scratch.Alloc(&dConst, S));
-			PIRE_TRY(HipOk(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(dConst), int(representative), S, stream), "hipMemsetD32"));
+			hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, dConst, representative, S);
 			q.initIdx = dConst;
-			q.flags = 0;
+			q.flags = kPermIds;
 		}
-		q.outIdx = m.dGuess;
+		q.outIdx = sl.guess[m];
 		PIRE_TRY(ScanBatch(q, t, stream));
 		q.offsets = a.segBegin;
 		q.ends = a.segEnd;
-		q.initIdx = m.dGuess;
-		q.flags = 0;
-		q.outIdx = m.dEnd;
+		q.initIdx = sl.guess[m];
+		q.flags = kPermIds;
+		q.outIdx = sl.end[m];
 		PIRE_TRY(ScanBatch(q, t, stream));
-		m.guess.resize(S);
-		m.end.resize(S);
-		PIRE_TRY(HipOk(hipMemcpyAsync(m.guess.data(), m.dGuess, S * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
-		PIRE_TRY(HipOk(hipMemcpyAsync(m.end.data(), m.dEnd, S * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
-		PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));
-		modes.push_back(std::move(m));
+		sl.count = m + 1;
 		return PIRE_HIP_OK;
 	};
+	mark("setup");
 	PIRE_TRY(addMode(true, 0));
+	mark("mode 0");
 	// the modes earlier calls on this table learned: the automaton is the same, the text probably similar
-	std::vector<uint32_t> known;
 	{
-		std::lock_guard<std::mutex> lock(t->segMutex);
-		known = t->segModes;
+		std::vector<uint32_t> known;
+		{
+			std::lock_guard<std::mutex> lock(t->segMutex);
+			known = t->segModes;
+		}
+		for (uint32_t r : known)   // kept as reference state indices: adapt() renumbers the device ids
+			if (sl.count < maxModes && r < t->host.states)
+				PIRE_TRY(addMode(false, t->host.permOfOrig[r]));
 	}
-	for (uint32_t r : known)
-		if (modes.size() < maxModes)
-			PIRE_TRY(addMode(false, r));
 
+	mark("known modes");
 	// ---- the chain
-	std::vector<uint32_t> cur(n), at(n);          // per string: state at the start of segment at[i]
-	std::vector<uint32_t> finalState(n);
-	for (uint64_t i = 0; i < n; ++i) {
-		at[i] = strFirst[i];
-		cur[i] = modes[0].guess[strFirst[i]];
-	}
-	std::vector<uint64_t> pending;                // strings stopped at a segment no mode predicted
-	std::unordered_map<uint32_t, uint32_t> surprises;
-	uint64_t nPredicted = 0, nWalked = 0, nPlain = 0;
+	ChainArrays c = {};
+	PIRE_TRY(scratch.Alloc(&c.maps, S));
+	PIRE_TRY(scratch.Alloc(&c.prefix, S));
+	PIRE_TRY(scratch.Alloc(&c.finalState, n));
+	PIRE_TRY(scratch.Alloc(&c.strDone, n));
+	PIRE_TRY(scratch.Alloc(&c.breakSeg, n));
+	PIRE_TRY(scratch.Alloc(&c.breakState, n));
+	PIRE_TRY(scratch.Alloc(&c.broken, 1));
+	PIRE_TRY(HipOk(hipMemsetAsync(c.strDone, 0, n * 4, stream), "hipMemset"));
+	PIRE_TRY(HipOk(hipMemsetAsync(c.breakSeg, 0xFF, n * 4, stream), "hipMemset"));   // kNoState: not broken
+	uint8_t* dTemp = nullptr;
+	PIRE_TRY(scratch.Alloc(&dTemp, tempBytes));
+	uint32_t *dExStr = nullptr, *dExInit = nullptr, *dExOut = nullptr;
 	uint64_t *dExB = nullptr, *dExE = nullptr;
-	uint32_t *dExI = nullptr, *dExO = nullptr;
+	std::vector<uint32_t> breakSeg(n), breakState(n), exStr, exInit;
 	std::vector<uint64_t> exB, exE;
-	std::vector<uint32_t> exI, exO;
-	std::vector<uint64_t> todo(n);
-	for (uint64_t i = 0; i < n; ++i)
-		todo[i] = i;
-	while (!todo.empty()) {
-		pending.clear();
-		for (uint64_t i : todo) {
-			uint32_t k = at[i], c = cur[i];
-			const uint32_t last = strFirst[i + 1];
-			while (k < last) {
-				bool hit = false;
-				for (const Mode& m : modes)
-					if (m.guess[k] == c) {
-						c = m.end[k];
-						hit = true;
-						break;
-					}
-				if (!hit)
-					break;
-				++k;
-				++nPredicted;
-			}
-			at[i] = k;
-			cur[i] = c;
-			if (k < last)
-				pending.push_back(i);
-			else
-				finalState[i] = c;
-		}
-		todo.clear();
-		if (pending.empty())
+	std::unordered_map<uint32_t, uint32_t> surprises;
+	uint64_t nWalked = 0, nPlain = 0, rounds = 0;
+	for (;;) {
+		++rounds;
+		PIRE_TRY(HipOk(hipMemsetAsync(c.broken, 0, 4, stream), "hipMemset"));
+		hipLaunchKernelGGL(SegmentMapKernel, dim3(blocks), dim3(256), 0, stream, g, a, sl, c);
+		PIRE_TRY(HipOk(hipcub::DeviceScan::InclusiveScan(dTemp, tempBytes, c.maps, c.prefix, ComposeMaps(), int(S), stream), "hipcub::DeviceScan"));
+		hipLaunchKernelGGL(SegmentResolveKernel, dim3(blocks), dim3(256), 0, stream, g, a, sl, c);
+		uint32_t broken = 0;
+		PIRE_TRY(HipOk(hipMemcpyAsync(&broken, c.broken, 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
+		PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));
+		if (!broken)
 			break;
-		// a state that keeps surprising us is a mode of the automaton the guesses do not know yet
+		// where and in which state: the host only orchestrates, the states stay on the device
+		PIRE_TRY(HipOk(hipMemcpyAsync(breakSeg.data(), c.breakSeg, n * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
+		PIRE_TRY(HipOk(hipMemcpyAsync(breakState.data(), c.breakState, n * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
+		PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));
+		exStr.clear();
+		for (uint64_t i = 0; i < n; ++i)
+			if (breakSeg[i] != kNoState && breakSeg[i] > strFirst[i] && breakSeg[i] < strFirst[i + 1])
+				exStr.push_back(uint32_t(i));
+		// (breakSeg is cleared before every round, so only the strings that broke in THIS round have an entry)
+		if (exStr.size() != broken) {
+			SetError("segmented scan: inconsistent chain state");
+			return PIRE_HIP_EUNSUPPORTED;
+		}
+		// A state that breaks chains round after round is a mode of the automaton the guesses do not know yet: a
+		// sticky mode breaks the chain again at the very next segment, a transient state does it once.  (Counting
+		// rounds, not strings: a mode costs two scans of everything, a round trip only the broken segments.)
 		uint32_t best = 0, bestCount = 0;
-		for (uint64_t i : pending) {
-			const uint32_t c = ++surprises[cur[i]];
-			if (c > bestCount) {
-				best = cur[i];
-				bestCount = c;
+		{
+			std::vector<uint32_t> seen;
+			for (uint32_t i : exStr)
+				seen.push_back(breakState[i]);
+			std::sort(seen.begin(), seen.end());
+			seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+			for (uint32_t v : seen) {
+				const uint32_t cnt = ++surprises[v];
+				if (cnt > bestCount) {
+					best = v;
+					bestCount = cnt;
+				}
 			}
 		}
-		if (modes.size() < maxModes && (bestCount >= 2 || budget == 0)) {
+		if (sl.count < maxModes && (bestCount >= 2 || budget == 0)) {
 			PIRE_TRY(addMode(false, best));
 			{
 				std::lock_guard<std::mutex> lock(t->segMutex);
-				if (std::find(t->segModes.begin(), t->segModes.end(), best) == t->segModes.end() && t->segModes.size() < 8)
-					t->segModes.push_back(best);
+				const uint32_t orig = t->host.origOfPerm[best];
+				if (std::find(t->segModes.begin(), t->segModes.end(), orig) == t->segModes.end() && t->segModes.size() < kMaxModes)
+					t->segModes.push_back(orig);
 			}
 			surprises.erase(best);
-			todo = pending;
+			PIRE_TRY(HipOk(hipMemsetAsync(c.breakSeg, 0xFF, n * 4, stream), "hipMemset"));
 			continue;
 		}
-		// scan the pending segments from the states the chain is in -- or, when the budget of such round trips is
-		// spent, the whole rest of those strings, the plain sequential way
+		// scan the broken segments from the states the chains are in -- or, when the budget of such round trips
+		// is spent, the whole rest of those strings, the plain sequential way
 		const bool plain = budget == 0;
 		if (!plain)
 			--budget;
-		const size_t m = pending.size();
+		const size_t m = exStr.size();
 		exB.resize(m);
 		exE.resize(m);
-		exI.resize(m);
-		exO.resize(m);
+		exInit.resize(m);
 		for (size_t j = 0; j < m; ++j) {
-			const uint64_t i = pending[j];
-			exB[j] = segBegin[at[i]];
-			exE[j] = plain ? segEnd[strFirst[i + 1] - 1] : segEnd[at[i]];
-			exI[j] = cur[i];
+			const uint64_t i = exStr[j];
+			exB[j] = segBeginOf(i, breakSeg[i]);
+			exE[j] = plain ? stringEndOf(i) : std::min(stringEndOf(i), exB[j] + segBytes);
+			exInit[j] = breakState[i];
 		}
 		if (!dExB) {
 			PIRE_TRY(scratch.Alloc(&dExB, n));
 			PIRE_TRY(scratch.Alloc(&dExE, n));
-			PIRE_TRY(scratch.Alloc(&dExI, n));
-			PIRE_TRY(scratch.Alloc(&dExO, n));
+			PIRE_TRY(scratch.Alloc(&dExStr, n));
+			PIRE_TRY(scratch.Alloc(&dExInit, n));
+			PIRE_TRY(scratch.Alloc(&dExOut, n));
 		}
 		PIRE_TRY(HipOk(hipMemcpyAsync(dExB, exB.data(), m * 8, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
 		PIRE_TRY(HipOk(hipMemcpyAsync(dExE, exE.data(), m * 8, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
-		PIRE_TRY(HipOk(hipMemcpyAsync(dExI, exI.data(), m * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
+		PIRE_TRY(HipOk(hipMemcpyAsync(dExStr, exStr.data(), m * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
+		PIRE_TRY(HipOk(hipMemcpyAsync(dExInit, exInit.data(), m * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
 		q.n = m;
 		q.offsets = dExB;
 		q.ends = dExE;
-		q.initIdx = dExI;
-		q.flags = 0;
-		q.outIdx = dExO;
+		q.initIdx = dExInit;
+		q.flags = kPermIds;
+		q.outIdx = dExOut;
 		PIRE_TRY(ScanBatch(q, t, stream));
-		PIRE_TRY(HipOk(hipMemcpyAsync(exO.data(), dExO, m * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
+		hipLaunchKernelGGL(SegmentPatchKernel, dim3(unsigned((m + 255) / 256)), dim3(256), 0, stream, dExStr, dExOut, uint32_t(m),
+		                   plain ? 1u : 0u, sl, c);
+		PIRE_TRY(HipOk(hipMemsetAsync(c.breakSeg, 0xFF, n * 4, stream), "hipMemset"));
+		// the host vectors are sources of async copies: they are rewritten only after the next synchronize
 		PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));
-		for (size_t j = 0; j < m; ++j) {
-			const uint64_t i = pending[j];
-			cur[i] = exO[j];
-			if (plain) {
-				nPlain += strFirst[i + 1] - at[i];
-				at[i] = strFirst[i + 1];
-				finalState[i] = cur[i];
-			} else {
-				++nWalked;
-				++at[i];
-				if (at[i] == strFirst[i + 1])
-					finalState[i] = cur[i];
-				else
-					todo.push_back(i);
-			}
-		}
+		(plain ? nPlain : nWalked) += m;
 	}
 
+	mark("chain");
 	// ---- finish
-	uint32_t* dFinal = nullptr;
-	PIRE_TRY(scratch.Alloc(&dFinal, n));
-	PIRE_TRY(HipOk(hipMemcpyAsync(dFinal, finalState.data(), n * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(H2D)"));
 	{
 		ScanParams f = p;
 		f.compact = 0;
@@ -437,16 +607,17 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		const unsigned threads = n >= 4096 ? 1024 : 256;
 		const uint64_t tasks = (n + 63) / 64;
 		const unsigned cblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((tasks * 64 + threads - 1) / threads, uint64_t(cus))));
-		hipLaunchKernelGGL(SegmentFinishKernel, dim3(cblocks), dim3(threads), L.total, stream, f, dFinal);
+		hipLaunchKernelGGL(SegmentFinishKernel, dim3(cblocks), dim3(threads), L.total, stream, f, c.finalState);
 	}
 	PIRE_TRY(HipOk(hipGetLastError(), "segmented scan launch"));
-	PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));   // finalState is the source of the copy above
-	NoteKernel("segmented");
-	if (wantStats)
-		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %zu modes; segments "
-		                "predicted %llu, scanned again from the chain's state %llu, left to the plain walk %llu\n",
+	NoteKernel(nPlain ? "segmented+plain" : "segmented");   // "+plain": some strings ended in the sequential walk
+	if (wantStats) {
+		mark("finish");
+		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %u modes, %llu chain "
+		                "rounds; segments scanned again from the chain's state %llu, strings left to the plain walk %llu;%s\n",
 		        (unsigned long long)n, (unsigned long long)S, (unsigned long long)segBytes, (unsigned long long)warmBytes,
-		        modes.size(), (unsigned long long)nPredicted, (unsigned long long)nWalked, (unsigned long long)nPlain);
+		        sl.count, (unsigned long long)rounds, (unsigned long long)nWalked, (unsigned long long)nPlain, timeline.c_str());
+	}
 	return PIRE_HIP_OK;
 }
 

@@ -54,7 +54,7 @@ def test_segmented_scan_is_exact(name, blob, seg, warm, modes, budget, monkeypat
     for flags in (3, 0, 1, 2):
         oi, of = o.run(*ob.pack_strings(strings), flags=flags)
         gi, gf, cnt = t.run(text, offs, flags=flags, counts=True)
-        assert pb.last_kernel() == "segmented"
+        assert pb.last_kernel().startswith("segmented")      # "+plain" where the budget of repairs ran out
         assert (gi == oi).all() and (gf == of).all(), (name, flags, np.nonzero(gi != oi)[0][:5])
         assert cnt[0] == int(of.sum()) and cnt[1] == len(strings)
         xi, xf = t.run(text, offs, flags=flags | pb.FLAG_GENERIC)
@@ -96,7 +96,8 @@ def test_segmented_fixed_length_records_host_and_device(monkeypatch):
 
 
 def test_one_long_string_takes_the_segmented_path_by_itself():
-    """No knobs: 8 strings of 4 MiB are few and long -- the library cuts them up on its own."""
+    """No knobs: 8 strings of 4 MiB are few and long -- the library cuts them up on its own, and on this (forgetful)
+    automaton every chain must resolve without the sequential walk, whatever the other strings' chains do."""
     import torch
     import pire_amd
     from pire_amd import binding as pb
