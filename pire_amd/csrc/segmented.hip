@@ -30,6 +30,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -321,14 +322,22 @@ int HipOk(hipError_t e, const char* what)
 
 }  // namespace
 
-// Worth it when the lanes would starve: few strings, long ones.  PIRE_HIP_SEGMENT_BYTES forces the mode (tests).
+// Worth it when the lanes would starve.  One string per lane walks ~25 MB/s per lane however many lanes are busy
+// (measured: 1 024 x 1 MiB 40 ms, 16 384 x 64 KiB 2.6 ms); the segmented scan does ~1.1 TB/s plus ~0.15 ms of fixed
+// cost (profiles/r01_long_strings.log).  Either is exact; PIRE_HIP_SEGMENT_BYTES forces this one (tests).
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 {
-	if (getenv("PIRE_HIP_NO_SEGMENTS") || n == 0 || n >= (1ull << 31))
+	if (getenv("PIRE_HIP_NO_SEGMENTS") || n == 0 || n >= (1ull << 20))
 		return false;
 	if (getenv("PIRE_HIP_SEGMENT_BYTES"))
 		return true;
-	return n <= 32768 && totalBytes / n >= 32768;
+	const double mean = double(totalBytes) / double(n);
+	if (mean < 8192.0)
+		return false;
+	const double lanes = 256.0 * 1024.0;
+	const double plain = std::ceil(double(n) / lanes) * mean / 25e6;
+	const double segmented = double(totalBytes) / 1.1e12 + 150e-6;
+	return plain > 1.5 * segmented;
 }
 
 // p: the original batch with DEVICE pointers (strided, or offsets on the device); hostOffsets: the same offsets on
