@@ -527,6 +527,9 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	if (n == 0)
 		return PIRE_HIP_OK;
 	const uint32_t R = t->host.regexps;
+	if (int rc = EnsureActDist(t))
+		return rc;
+	p.actDist = t->dev.distFinalPerm;
 	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
 	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
@@ -592,6 +595,9 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	p.n = n;
 	if (n == 0)
 		return PIRE_HIP_OK;
+	if (int rc = EnsureActDist(t))
+		return rc;
+	p.actDist = t->dev.distFlaggedPerm;
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;

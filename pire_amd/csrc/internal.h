@@ -111,6 +111,9 @@ struct HostTable {
 	uint32_t hotFinalLo = 0;          // hot perm ids >= this are Final (the hot set is ordered non-final first)
 	uint32_t hotDeadLo = 0;           // hot perm ids in [hotDeadLo, hotFinalLo) are Dead (ordered plain, Dead, Final)
 	float deadShare = 0, finalShare = 0;   // share of the byte model's visits that fall on Dead / Final states
+	// steps (text bytes only, capped at 255) from every state to the nearest Final / Final-or-Dead state: the ragged
+	// kernel with actions skips the exact re-walk of a trapped chunk that cannot reach one (table.cpp EnsureActDist)
+	std::vector<uint8_t> distFinal, distFlagged;   // [states], reference numbering; empty until first needed
 	bool incPacked = false;           // regexps <= 8 and every final-list multiplicity <= 255: inc64 is usable
 	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
@@ -144,6 +147,8 @@ struct DeviceTable {
 	struct FinRec* finSelf = nullptr; // [states] end-of-string record when End() is not requested
 	struct FinRec* finEnd = nullptr;  // [states] end-of-string record after Step(EndMark)
 	uint64_t* incPerm = nullptr;      // [states] packed per-regexp increments of HalfFinalScanner::TakeAction, or null
+	uint8_t* distFinalPerm = nullptr;    // [states] HostTable::distFinal by device id (uploaded when first needed)
+	uint8_t* distFlaggedPerm = nullptr;
 	uint16_t* compactRows = nullptr;  // [(compact+1) rows] LDS address / 4 of the next state's row (last row = escape), padded
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
@@ -191,6 +196,7 @@ struct ScanParams {
 	uint32_t hotFinalLo;
 	uint32_t hotDeadLo;
 	float deadShare, finalShare;   // host-side hints for the choice of kernel (any choice is correct)
+	const uint8_t* actDist;        // nullable: steps to the nearest state the action cares about (ragged kernel with actions)
 	uint32_t states, letters, regexps, hot;
 	uint32_t startPerm;      // perm id every string starts in (Initialize(), then Begin() if requested)
 	uint32_t beginCls, endCls;
@@ -255,6 +261,7 @@ struct Staging {
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t);
 void EnsureRanked(pire_hip_table* t);
+int EnsureActDist(pire_hip_table* t);   // after UploadTable: dev.distFinalPerm / distFlaggedPerm are there
 struct GlueProduct {
 	std::vector<std::pair<uint32_t, uint32_t>> states;   // numbered product states (lhs state, rhs state)
 	std::vector<uint32_t> next;                          // [states * letters]

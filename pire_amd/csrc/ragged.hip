@@ -327,11 +327,23 @@ __device__ __forceinline__ void StepChunkAct(const ScanParams& p, const uint8_t*
 		m = max(m, max(h3, h));
 	}
 	hs = h;
-	if (m >= act.Threshold(p) && act.Wants(al)) {
+	if (m >= act.Threshold(p) && act.Wants(al) && !(p.flags & kDebugNoTrap)) {
 		if (m < p.hot) {
 			(void)ActHotBytes(p, lds, L, area, v, hs0, 16u, act, al, addr);   // ends in h again
 		} else {
-			const uint32_t st = ActBytes(p, lds, L, v, hs0 != p.hot ? hs0 : cold, 16u, act, al, addr);
+			const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+			uint32_t st;
+			if (p.actDist && p.actDist[st0] > 16) {
+				// the chunk left the dense rows but cannot reach a state the action cares about: the plain
+				// trap path (compact rows in LDS first) moves the state on, there is nothing else to do
+				st = p.compact;
+				if (st0 < p.compact)
+					st = CompactChunk(p, L, v, st0);
+				if (st == p.compact)
+					st = SlowChunk(p, lds, L, v, st0);
+			} else {
+				st = ActBytes(p, lds, L, v, st0, 16u, act, al, addr);
+			}
 			hs = st < p.hot ? st : p.hot;
 			cold = st;
 		}
@@ -360,11 +372,21 @@ __device__ __forceinline__ void StepPartialAct(const ScanParams& p, const uint8_
 		}
 	}
 	hs = snap;
-	if (count != 0 && m >= act.Threshold(p) && act.Wants(al)) {
+	if (count != 0 && m >= act.Threshold(p) && act.Wants(al) && !(p.flags & kDebugNoTrap)) {
 		if (m < p.hot) {
 			(void)ActHotBytes(p, lds, L, area, v, hs0, count, act, al, addr);
 		} else {
-			const uint32_t st = ActBytes(p, lds, L, v, hs0 != p.hot ? hs0 : cold, count, act, al, addr);
+			const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+			uint32_t st;
+			if (p.actDist && p.actDist[st0] > 16) {
+				st = p.compact;
+				if (st0 < p.compact)
+					st = CompactPartial(p, L, v, st0, count);
+				if (st == p.compact)
+					st = SlowPartial(p, lds, L, v, st0, count);
+			} else {
+				st = ActBytes(p, lds, L, v, st0, count, act, al, addr);
+			}
 			hs = st < p.hot ? st : p.hot;
 			cold = st;
 		}
@@ -750,8 +772,9 @@ bool RaggedActEligible(const ScanParams& p)
 
 int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream)
 {
-	ScanParams p = p0;
-	p.compact = 0;        // the re-walk with actions goes through the full table
+	ScanParams p = p0;    // with the compact rows: trapped chunks that cannot reach a Final state use them (actDist)
+	if (!p.actDist)
+		p.compact = 0;
 	p.outCounts = nullptr;
 	HalfFinalAct act;
 	act.results = outResults;
@@ -762,7 +785,8 @@ int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bo
                        long long* outLen, hipStream_t stream)
 {
 	ScanParams p = p0;
-	p.compact = 0;
+	if (!p.actDist)
+		p.compact = 0;
 	p.outCounts = nullptr;
 	PrefixAct act;
 	act.outLen = outLen;

@@ -461,7 +461,8 @@ void FreeDeviceTable(DeviceTable* d)
 		return;
 	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
-	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm};
+	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm,
+	                d->distFinalPerm, d->distFlaggedPerm};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -730,6 +731,71 @@ int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostT
 	                    // or inspected, not for the intermediates of a left-to-right glue
 	*out = std::move(t);
 	return PIRE_HIP_OK;
+}
+
+// Distance, in text bytes, from every state to the nearest Final (Final or Dead) state, capped: round r marks the
+// states that reach a marked state of round r-1 on some byte.  Only distances up to one 16-byte chunk matter.
+static std::vector<uint8_t> DistanceTo(const HostTable& h, uint8_t flagMask)
+{
+	const uint32_t N = h.states, C = h.letters;
+	std::vector<uint8_t> isByteLetter(C, 0);
+	for (uint32_t b = 0; b < 256; ++b)
+		isByteLetter[h.cls[b]] = 1;
+	std::vector<uint32_t> letters;
+	for (uint32_t c = 0; c < C; ++c)
+		if (isByteLetter[c])
+			letters.push_back(c);
+	std::vector<uint8_t> dist(N, 255);
+	std::vector<uint32_t> open;
+	for (uint32_t s = 0; s < N; ++s) {
+		if (h.flags[s] & flagMask)
+			dist[s] = 0;
+		else
+			open.push_back(s);
+	}
+	for (uint32_t r = 1; r <= 17 && !open.empty(); ++r) {
+		std::vector<uint32_t> still, reached;
+		for (uint32_t s : open) {
+			bool hit = false;
+			const uint32_t* row = &h.next[size_t(s) * C];
+			for (uint32_t c : letters)
+				if (dist[row[c]] == r - 1) {
+					hit = true;
+					break;
+				}
+			(hit ? reached : still).push_back(s);
+		}
+		for (uint32_t s : reached)
+			dist[s] = uint8_t(r);
+		open.swap(still);
+	}
+	return dist;
+}
+
+int EnsureActDist(pire_hip_table* t)
+{
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
+	HostTable& h = t->host;
+	DeviceTable& d = t->dev;
+	if (d.device < 0) {
+		SetError("EnsureActDist before UploadTable");
+		return PIRE_HIP_EINVAL;
+	}
+	if (d.distFinalPerm && d.distFlaggedPerm)
+		return PIRE_HIP_OK;
+	if (h.distFinal.empty()) {
+		h.distFinal = DistanceTo(h, kFinal);
+		h.distFlagged = DistanceTo(h, kFinal | kDead);
+	}
+	const uint32_t N = h.states;
+	std::vector<uint8_t> a(N), b(N);
+	for (uint32_t pid = 0; pid < N; ++pid) {
+		a[pid] = h.distFinal[h.origOfPerm[pid]];
+		b[pid] = h.distFlagged[h.origOfPerm[pid]];
+	}
+	if (int rc = Put(&d.distFinalPerm, a, &d.bytes))
+		return rc;
+	return Put(&d.distFlaggedPerm, b, &d.bytes);
 }
 
 void EnsureRanked(pire_hip_table* t)

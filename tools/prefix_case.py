@@ -26,6 +26,15 @@ d = torch.as_tensor(text, device="cuda")
 do = torch.as_tensor(offs.astype(np.int64), device="cuda")
 dout = torch.empty(m, dtype=torch.int64, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
+import sys
+if len(sys.argv) > 1 and sys.argv[1] == "adapt":
+    # a plain Scanner pass over the same text feeds the visit counters, then the dense rows are re-ranked
+    idx = torch.empty(m, dtype=torch.int32, device="cuda")
+    fin = torch.empty(m, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        t.run_device(d.data_ptr(), do.data_ptr(), m, 0, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        print("adapt: rows changed", t.adapt())
 for longest in (True, False):
     best = 1e9
     for _ in range(4):
@@ -38,8 +47,8 @@ for longest in (True, False):
     out = dout.cpu().numpy()
     name = "LongestPrefix" if longest else "ShortestPrefix"
     scanned = int(np.where(out >= 0, out, lens.astype(np.int64)).sum()) if not longest else total
-    print("%s: %d strings, %.3f GiB: kernel %.3f ms -> %.1f GB/s of text (%.1f GB/s of bytes actually walked)"
-          % (name, m, total / 2**30, best, total / best / 1e6, scanned / best / 1e6))
+    print("%s (%s): %d strings, %.3f GiB: kernel %.3f ms -> %.1f GB/s of text (%.1f GB/s of bytes actually walked)"
+          % (name, pb.last_kernel(), m, total / 2**30, best, total / best / 1e6, scanned / best / 1e6))
     if ob.ref_available():
         r = ob.RefScanner.load(blob)
         k = 1 << 15
