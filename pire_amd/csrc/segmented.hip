@@ -1,8 +1,8 @@
 // Long strings: a DFA walk is sequential, and one string per lane means that a few long strings leave the chip idle
 // (one lane walks ~24 MB/s; a single 1 GiB string would take 45 s).  This file cuts long strings into segments and
 // scans the segments in parallel -- speculatively, because the start state of a segment is the end state of the one
-// before it -- and then follows the chain of segments on the host, accepting only what was computed from the state
-// the chain is really in.
+// before it -- and then resolves the chain of segments, accepting only what was computed from the state the chain
+// is really in.
 //
 //   guess   Regexp automata mostly forget: after a few dozen bytes the state rarely depends on where the walk began.
 //           So a segment guesses its start state by walking the W bytes in front of it (its warm-up) from the
