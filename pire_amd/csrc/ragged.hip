@@ -393,6 +393,7 @@ __device__ __forceinline__ void StepPartialAct(const ScanParams& p, const uint8_
 	}
 }
 
+template <bool EXT>
 __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                              uint32_t s, bool active, uint32_t st)
 {
@@ -408,7 +409,7 @@ __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, 
 	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
 	if (active) {
 		if (p.outIdx)
-			p.outIdx[s] = (p.flags & kPermIds) ? endPerm : orig;
+			p.outIdx[s] = (EXT && (p.flags & kPermIds)) ? endPerm : orig;
 		if (p.outFinal)
 			p.outFinal[s] = fl & kFinal;
 	}
@@ -520,7 +521,10 @@ __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile Ragg
 
 // One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
 // Returns false when the wave has nothing left to do.
-template <class Act>
+// EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
+// state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
+// A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
+template <class Act, bool EXT>
 __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                             volatile RaggedWork* work, unsigned long long* workCounter,
                                             RaggedGrab grab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
@@ -561,9 +565,13 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		const uint32_t which = got ? S.sIdxN : 0u;
 		const uint64_t* offPtr = p.offsets + which;
 		offB = offPtr[0];
-		offE = p.ends ? p.ends[which] : offPtr[1];
-		if (p.initIdx)
-			initV = p.initIdx[which];
+		if constexpr (EXT) {
+			offE = p.ends ? p.ends[which] : offPtr[1];
+			if (p.initIdx)
+				initV = p.initIdx[which];
+		} else {
+			offE = offPtr[1];
+		}
 	}
 
 	// ---- walk the current window
@@ -615,22 +623,27 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		if (ends)
 			act.Finish(p, lds, L, al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
-		FinishRagged(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
+		FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
 	}
 
 	// ---- move on
-	const uint32_t startInit = S.pendInit;   // of the string that starts now (takeNew), before the refill below
+	uint32_t startInit = 0;
+	if constexpr (EXT)
+		startInit = S.pendInit;   // of the string that starts now (takeNew), before the refill below
 	if (got) {
 		S.pendPos = textBase + offB;
 		S.pendEnd = textBase + offE;
-		S.pendInit = initV;
+		if constexpr (EXT)
+			S.pendInit = initV;
 	}
 	if (takeNew) {
 		uint32_t st;
 		if constexpr (Act::kActive)
 			st = act.Start(p, lds, L, al, nIdx, nPos);
-		else
+		else if constexpr (EXT)
 			st = p.initIdx ? StartStateFrom(p, startInit) : p.startPerm;
+		else
+			st = p.startPerm;   // batches with resume states take the EXT instantiation
 		S.hs = st < p.hot ? st : p.hot;
 		S.cold = st;
 	}
@@ -642,7 +655,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	return __any(nBusy || S.pend);
 }
 
-template <class Act>
+template <class Act, bool EXT>
 __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned long long* workCounter,
                                                          RaggedGrab grab, Act act)
 {
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	LoadTableToLds(p, lds, L);   // ends with a barrier
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
-	const uint64_t safeEnd = (textBase + (p.ends ? p.textEnd : p.offsets[p.n]) + 15) & ~uint64_t(15);
+	const uint64_t safeEnd = (textBase + ((EXT && p.ends) ? p.textEnd : p.offsets[p.n]) + 15) & ~uint64_t(15);
 
 	RaggedRange R = {0, 0, false};
 	RaggedLane S;
@@ -686,14 +699,14 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 
 	if (AssignPending(p, work, workCounter, grab, R, S)) {
 		S.pendPos = textBase + p.offsets[S.sIdxN];
-		S.pendEnd = textBase + (p.ends ? p.ends[S.sIdxN] : p.offsets[S.sIdxN + 1]);
-		if (p.initIdx)
+		S.pendEnd = textBase + ((EXT && p.ends) ? p.ends[S.sIdxN] : p.offsets[S.sIdxN + 1]);
+		if (EXT && p.initIdx)
 			S.pendInit = p.initIdx[S.sIdxN];
 	}
 	for (uint32_t iter = 0;; iter += 2) {
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))
+		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))
 			break;
-		if (!RaggedPhase(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al))
+		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al))
 			break;
 	}
 	FlushCounts(p, lds, L);
@@ -710,7 +723,7 @@ bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 
 namespace {
 
-template <class Act>
+template <class Act, bool EXT>
 int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Act& act, hipStream_t stream)
 {
 	hipError_t e = hipMemsetAsync(workCounter, 0, sizeof(unsigned long long), stream);
@@ -721,7 +734,7 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel<Act>),
+	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel<Act, EXT>),
 	                        hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
@@ -746,7 +759,7 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
 		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
 	}
-	hipLaunchKernelGGL(ScanRaggedKernel<Act>, dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
+	hipLaunchKernelGGL((ScanRaggedKernel<Act, EXT>), dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
 	                   q, workCounter, grab, act);
 	e = hipGetLastError();
 	if (e != hipSuccess)
@@ -760,7 +773,9 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 {
 	if (int rc = CheckCounts(p))
 		return rc;
-	return LaunchRaggedT(p, workCounter, NoAct(), stream);
+	if (p.ends || p.initIdx || (p.flags & kPermIds))
+		return LaunchRaggedT<NoAct, true>(p, workCounter, NoAct(), stream);
+	return LaunchRaggedT<NoAct, false>(p, workCounter, NoAct(), stream);
 }
 
 // The walks with actions take the ragged kernel from a few waves' worth of strings (below that, and for tables
@@ -778,7 +793,7 @@ int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter,
 	p.outCounts = nullptr;
 	HalfFinalAct act;
 	act.results = outResults;
-	return LaunchRaggedT(p, workCounter, act, stream);
+	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);
 }
 
 int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bool longest, bool throughEnd,
@@ -792,7 +807,7 @@ int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bo
 	act.outLen = outLen;
 	act.longest = longest ? 1 : 0;
 	act.throughEnd = throughEnd ? 1 : 0;
-	return LaunchRaggedT(p, workCounter, act, stream);
+	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);
 }
 
 
