@@ -35,7 +35,7 @@ def pa():
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_scanner_all_kernels(pa, seed):
+def test_random_scanner_all_kernels(pa, seed, monkeypatch):
     if not ob.ref_available():
         pytest.skip("oracle/_ref not built")
     import torch
@@ -90,6 +90,22 @@ def test_random_scanner_all_kernels(pa, seed):
     assert (lp == gp).all()
     sp, gs = o.prefix(text, offs, False), t.prefix(text, offs, False)
     assert (sp == gs).all()
+    # the segmented scan (few long strings), forced onto longer strings of the same alphabet with segments and
+    # warm-ups small enough for the guesses to fail often; and the half-final counting where the table allows it
+    long_strings = [bytes(alphabet[rng.randint(0, len(alphabet), size=int(n))]) for n in rng.randint(0, 5000, size=40)]
+    ltext, loffs = H.pack(long_strings)
+    oi, of = o.run(ltext, loffs, threads=4)
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(int(rng.choice([48, 128, 400]))))
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", str(int(rng.choice([0, 8, 64]))))
+    gi, gf, cnt = t.run(ltext, loffs, counts=True)
+    assert pb.last_kernel().startswith("segmented")
+    assert (gi == oi).all() and (gf == of).all(), (pats, opts)
+    assert cnt[0] == int(of.sum()) and cnt[1] == len(long_strings)
+    monkeypatch.delenv("PIRE_HIP_SEGMENT_BYTES")
+    if t.RegexpsCount <= 8:
+        hi, hf, hr = o.run_half_final(text, offs)
+        gi, gf, gr = t.run_half_final(text, offs)
+        assert (gi == hi).all() and (gf == hf).all() and (gr == hr).all(), (pats, opts)
 
 
 def test_many_letter_classes_disable_the_compact_tier(pa):
