@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Latency of small host-pointer calls (the C++ shim's BatchRunner / pigrep use): pire_hip_run with host text."""
+import time
+
+import numpy as np
+
+import pire_amd
+from tests import helpers as H
+
+big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+t = pire_amd.Table(H.load_blob(big["blob"]))
+t.upload()
+rng = np.random.RandomState(1)
+for n, ln in ((10, 100), (1000, 100), (10000, 100), (1000, 4096), (100000, 100)):
+    lens = rng.randint(ln // 2, ln + 1, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    text = rng.randint(32, 127, size=int(offs[-1])).astype(np.uint8)
+    t.run(text, offs)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        t.run(text, offs)
+        ts.append(time.perf_counter() - t0)
+    print("%7d strings x ~%4d B (%8.1f KiB): median %.0f us, min %.0f us per call" % (n, ln, offs[-1] / 1024, 1e6 * np.median(ts), 1e6 * min(ts)))
