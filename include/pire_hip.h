@@ -180,7 +180,7 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
  * Few long strings (strings of 8 KiB or more on average, too few of them to keep the lanes busy; lengths known to
  * the host: host pointers, or pire_hip_run_strided) are cut into segments that are scanned in parallel from guessed
  * start states; the chain of segments is then composed on the device and only results computed from the true state
- * are accepted, so the answers are the same (pire_amd/csrc/segmented.hip: one 1 GiB string in 0.9 ms instead of
+ * are accepted, so the answers are the same (pire_amd/csrc/segmented.hip: one 1 GiB string in 0.54 ms instead of
  * 45 s).  Such a call synchronises `stream` even with PIRE_HIP_RUN_ON_DEVICE.
  * PIRE_HIP_RUN_GENERIC (or the environment variable PIRE_HIP_NO_SEGMENTS) keeps one string per lane.
  */

@@ -438,6 +438,21 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	q.outFinal = nullptr;
 	q.outCounts = nullptr;
 
+	// how many leading segments lie on a regular grid of fixed-length records (see addMode)
+	uint64_t gridSegs = 0;
+	if (!hostOffsets && !getenv("PIRE_HIP_SEGMENT_NO_GRID")) {
+		if (n == 1)
+			gridSegs = p.len / segBytes;
+		else if (p.stride == p.len && p.len % segBytes == 0)
+			gridSegs = S;
+		ScanParams probe = q;
+		probe.offsets = nullptr;
+		probe.n = gridSegs;
+		probe.len = probe.stride = segBytes;
+		if (!TiledEligible(probe))
+			gridSegs = 0;
+	}
+
 	// ---- slots
 	SlotArrays sl = {};
 	PIRE_TRY(scratch.Alloc(&sl.guess[kMaxModes], S));   // the patch slot: empty
@@ -466,12 +481,28 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		}
 		q.outIdx = sl.guess[m];
 		PIRE_TRY(ScanBatch(q, t, stream));
-		q.offsets = a.segBegin;
-		q.ends = a.segEnd;
-		q.initIdx = sl.guess[m];
+		// the scan proper: the leading `gridSegs` segments are fixed-length records on a regular grid (a single
+		// string's full segments; several strings whose length is a multiple of the segment) -> the tiled kernel,
+		// twice as fast as the ragged one; whatever is left (tails) goes to the ragged / generic kernel
 		q.flags = kPermIds;
-		q.outIdx = sl.end[m];
-		PIRE_TRY(ScanBatch(q, t, stream));
+		if (gridSegs) {
+			ScanParams r = q;
+			r.offsets = nullptr;
+			r.ends = nullptr;
+			r.n = gridSegs;
+			r.len = r.stride = segBytes;
+			r.initIdx = sl.guess[m];
+			r.outIdx = sl.end[m];
+			PIRE_TRY(LaunchTiled(r, stream));
+		}
+		if (gridSegs < S) {
+			q.n = S - gridSegs;
+			q.offsets = a.segBegin + gridSegs;
+			q.ends = a.segEnd + gridSegs;
+			q.initIdx = sl.guess[m] + gridSegs;
+			q.outIdx = sl.end[m] + gridSegs;
+			PIRE_TRY(ScanBatch(q, t, stream));
+		}
 		sl.count = m + 1;
 		return PIRE_HIP_OK;
 	};

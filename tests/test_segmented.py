@@ -122,3 +122,29 @@ def test_one_long_string_takes_the_segmented_path_by_itself():
     gi, gf = t.run(data.reshape(-1), offs)            # host pointers, offsets
     assert pb.last_kernel() == "segmented"
     assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.parametrize("length,seg", [((1 << 20) + 1000, 2048), ((1 << 20), 4096), (300000, 1024)])
+def test_single_string_grid_segments_through_the_tiled_kernel_plus_tail(length, seg, monkeypatch):
+    """One string on the device: its full segments are fixed-length records (tiled kernel), the tail is not."""
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    data = ob.corpus_fill(big["corpus"]["seed"], 0, (length + 4095) // 4096, 4096, H.plants_for(big)).reshape(-1)[:length]
+    oi, of = o.run(data, np.array([0, length], dtype=np.uint64))
+    d = torch.as_tensor(np.array(data), device="cuda")
+    idx = torch.empty(1, dtype=torch.int32, device="cuda")
+    fin = torch.empty(1, dtype=torch.uint8, device="cuda")
+    for grid in (True, False):
+        if not grid:
+            monkeypatch.setenv("PIRE_HIP_SEGMENT_NO_GRID", "1")
+        t.run_strided_device(d.data_ptr(), 1, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0,
+                             torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert pb.last_kernel() == "segmented"
+        assert int(idx[0]) == int(oi[0]) and int(fin[0]) == int(of[0])
