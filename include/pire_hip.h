@@ -49,7 +49,12 @@ enum {
 	PIRE_HIP_RUN_ON_DEVICE = 1u << 2,   /* text/offsets/init/out pointers are DEVICE pointers; the call only */
 	                                    /* enqueues work on `stream`. Without it they are HOST pointers and  */
 	                                    /* the call copies in, runs, copies out and synchronises.            */
-	PIRE_HIP_RUN_GENERIC   = 1u << 3    /* force the generic (offset-driven) kernel; testing/diagnostics     */
+	PIRE_HIP_RUN_GENERIC   = 1u << 3,   /* force the generic (offset-driven) kernel; testing/diagnostics     */
+	PIRE_HIP_RUN_HOST_OFFSETS = 1u << 4 /* with ON_DEVICE, pire_hip_run only: `offsets` is a HOST pointer (the  */
+	                                    /* text stays resident on the device, the caller knows where its        */
+	                                    /* documents start).  The call copies the offsets and synchronises      */
+	                                    /* `stream` before it returns; because the host then knows the lengths, */
+	                                    /* few long strings get the segmented scan described at pire_hip_run.   */
 };
 
 typedef struct pire_hip_table pire_hip_table;

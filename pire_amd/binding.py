@@ -15,6 +15,7 @@ FLAG_BEGIN = 1
 FLAG_END = 2
 FLAG_ON_DEVICE = 4
 FLAG_GENERIC = 8
+FLAG_HOST_OFFSETS = 16
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -304,6 +305,14 @@ class Table:
         _check(lib().pire_hip_run_strided(self._h, text_ptr or None, n, length, stride, flags | FLAG_ON_DEVICE,
                                           init_ptr or None, out_idx_ptr or None, out_final_ptr or None,
                                           out_counts_ptr or None, stream or None))
+
+    def run_device_host_offsets(self, text_ptr: int, offsets: np.ndarray, flags, out_idx_ptr=0, out_final_ptr=0,
+                                out_counts_ptr=0, init_ptr=0, stream: int = 0):
+        """Resident text (device pointer), offsets on the host (PIRE_HIP_RUN_HOST_OFFSETS); outputs on the device."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(lib().pire_hip_run(self._h, text_ptr or None, offsets.ctypes.data, len(offsets) - 1,
+                                  flags | FLAG_ON_DEVICE | FLAG_HOST_OFFSETS, init_ptr or None, out_idx_ptr or None,
+                                  out_final_ptr or None, out_counts_ptr or None, stream or None))
 
     def run_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_final_ptr=0,
                    out_counts_ptr=0, init_ptr=0, stream: int = 0):

@@ -130,7 +130,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	// only the public bits: the upper ones are the kernels' internal switches (device_common.h)
-	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC;
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC | PIRE_HIP_RUN_HOST_OFFSETS;
 	ScanParams p;
 	if (int rc = FillParams(t, &p, flags))
 		return rc;
@@ -145,6 +145,35 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		p.outIdx = outIdx;
 		p.outFinal = outFinal;
 		p.outCounts = reinterpret_cast<unsigned long long*>(outCounts);
+		if ((flags & PIRE_HIP_RUN_HOST_OFFSETS) && offsets && n) {
+			// resident text, offsets known to the host: copy them into stream-ordered scratch
+			for (uint64_t i = 0; i < n; ++i)
+				if (offsets[i] > offsets[i + 1]) {
+					SetError("offsets must be non-decreasing");
+					return PIRE_HIP_EINVAL;
+				}
+			void* d = nullptr;
+			hipError_t e = hipMallocAsync(&d, (n + 1) * 8, stream);
+			if (e != hipSuccess)
+				return HipFail(e, "hipMallocAsync(offsets)");
+			e = hipMemcpyAsync(d, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
+			int rc = e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemcpy(offsets)");
+			p.offsets = static_cast<const uint64_t*>(d);
+			const uint64_t textBytes = offsets[n];
+			if (!rc) {
+				if (!(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes - offsets[0]))
+					rc = RunSegmented(t, p, offsets, stream);
+				else
+					rc = Dispatch(p, stream, NextWorkSlot(t), textBytes);
+			}
+			(void)hipFreeAsync(d, stream);
+			if (!rc) {
+				e = hipStreamSynchronize(stream);   // the caller's offsets array was the source of an async copy
+				if (e != hipSuccess)
+					rc = HipFail(e, "hipStreamSynchronize");
+			}
+			return rc;
+		}
 		// device offsets: the total text size is not known on the host; n >= 256 strings of unknown length still
 		// need 128 readable bytes at `text` for the ragged kernel, which the caller guarantees by passing a batch
 		// (a batch with less than 4 KiB of text is not worth a GPU launch; use PIRE_HIP_RUN_GENERIC to force the

@@ -148,3 +148,34 @@ def test_single_string_grid_segments_through_the_tiled_kernel_plus_tail(length, 
         torch.cuda.synchronize()
         assert pb.last_kernel() == "segmented"
         assert int(idx[0]) == int(oi[0]) and int(fin[0]) == int(of[0])
+
+
+def test_resident_text_with_host_offsets():
+    """PIRE_HIP_RUN_HOST_OFFSETS: the text stays on the device, the offsets come from the host -- which is what lets
+    a batch of few long documents take the segmented scan; many short ones take the ragged kernel as usual."""
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    total = 6 << 20
+    data = ob.corpus_fill(big["corpus"]["seed"], 0, total // 4096, 4096, H.plants_for(big)).reshape(-1)
+    d = torch.as_tensor(np.array(data), device="cuda")
+    rng = np.random.RandomState(12)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n, kernel in ((5, "segmented"), (20000, "ragged")):
+        cuts = np.sort(rng.choice(np.arange(1, total), size=n - 1, replace=False)).astype(np.uint64)
+        offs = np.concatenate([[0], cuts, [total]]).astype(np.uint64)
+        oi, of = o.run(data, offs, threads=4)
+        idx = torch.empty(n, dtype=torch.int32, device="cuda")
+        fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+        cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+        t.run_device_host_offsets(d.data_ptr(), offs, 3, idx.data_ptr(), fin.data_ptr(), cnt.data_ptr(), 0, stream)
+        assert pb.last_kernel() == kernel
+        torch.cuda.synchronize()
+        assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()
+        assert int(cnt[1]) == n and int(cnt[0]) == int(of.sum())
+    with pytest.raises(pb.PireHipError):
+        t.run_device_host_offsets(d.data_ptr(), np.array([0, 10, 5], dtype=np.uint64), 3, 0, 0, 0, 0, stream)
