@@ -179,3 +179,47 @@ def test_resident_text_with_host_offsets():
         assert int(cnt[1]) == n and int(cnt[0]) == int(of.sum())
     with pytest.raises(pb.PireHipError):
         t.run_device_host_offsets(d.data_ptr(), np.array([0, 10, 5], dtype=np.uint64), 3, 0, 0, 0, 0, stream)
+
+
+def test_concurrent_threads_segmented_scans_on_one_table():
+    """Four host threads, each on its own stream, run segmented scans of different texts on ONE table (learning and
+    sharing its modes) at the same time; every result must equal the oracle's."""
+    import threading
+
+    import torch
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    t.upload()
+    n, length = 3, 1 << 20
+    jobs = []
+    for k in range(4):
+        data = ob.corpus_fill(1000 + k, 0, n * (length // 4096), 4096, H.plants_for(big), threads=4).reshape(n, length)
+        jobs.append((data, o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=2)))
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            data, (oi, of) = jobs[k]
+            d = torch.as_tensor(np.array(data), device="cuda")
+            idx = torch.empty(n, dtype=torch.int32, device="cuda")
+            fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for _ in range(10):
+                t.run_strided_device(d.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0,
+                                     stream.cuda_stream)
+                stream.synchronize()
+                if not ((idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()):
+                    errors.append("mismatch in thread %d" % k)
+        except Exception as e:   # noqa: BLE001 -- reported below
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
