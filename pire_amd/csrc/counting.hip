@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -540,18 +542,27 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream)
 			hipLaunchKernelGGL(CountingWideKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
 			e = hipGetLastError();
 		}
-	} else if (p.regexps <= 8) {
-		switch (kind) {
-		case PIRE_HIP_COUNTING_BASIC: LaunchOne<8, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
-		case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<8, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
-		default: LaunchOne<8, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
-		}
 	} else {
-		switch (kind) {
-		case PIRE_HIP_COUNTING_BASIC: LaunchOne<16, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
-		case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<16, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
-		default: LaunchOne<16, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
-		}
+		// counters in registers, as many as the scanner has regexps (rounded up to 1, 2, 4, 8, 16): TakeAction touches
+		// every counter slot, so a single-regexp scanner should not pay for eight
+		auto launch = [&](auto rmax) {
+			constexpr int R = decltype(rmax)::value;
+			switch (kind) {
+			case PIRE_HIP_COUNTING_BASIC: LaunchOne<R, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
+			case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<R, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
+			default: LaunchOne<R, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
+			}
+		};
+		if (p.regexps <= 1)
+			launch(std::integral_constant<int, 1>());
+		else if (p.regexps <= 2)
+			launch(std::integral_constant<int, 2>());
+		else if (p.regexps <= 4)
+			launch(std::integral_constant<int, 4>());
+		else if (p.regexps <= 8)
+			launch(std::integral_constant<int, 8>());
+		else
+			launch(std::integral_constant<int, 16>());
 	}
 	if (e != hipSuccess)
 		return HipFail(e, "counting kernel launch");
