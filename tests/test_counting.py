@@ -96,3 +96,28 @@ def test_gpu_counting_sixteen_regexps(pa):
         oi, orr = o.run_strings(many)
         gi, gr = t.run_strings(many)
         assert (gi == oi).all() and (gr == orr).all() and gr.sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 9])
+def test_gpu_counting_every_counter_instantiation(pa, k):
+    """The counters live in 1, 2, 4, 8 or 16 register slots depending on the number of regexps: every instantiation,
+    all three scanner classes, against the oracle (and through it the reference)."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    res_ = ["a", "b", "ab", "[ab]+", "c", "bc", "d", "abc", "ca"][:k]
+    seps = [".*", "\\s", ".*", "c", ".*", ".*", "\\s", ".*", ".*"][:k]
+    rng = np.random.RandomState(30 + k)
+    many = H.random_strings(rng, 2000, 300, b"abcd \n") + [b"", b"a", b"ab ab ab"]
+    for kind in (0, 1, 2):
+        try:
+            blob = ob.RefCountingScanner.compile(kind, res_, seps).save()
+        except ValueError:
+            continue            # this class cannot glue that many
+        t, o = pa.CountingTable(blob, kind), ob.OracleCountingScanner(blob, kind)
+        assert t.RegexpsCount == k
+        for flags in (3, 0):
+            oi, orr = o.run_strings(many, flags=flags)
+            gi, gr = t.run_strings(many, flags=flags)
+            assert (gi == oi).all() and (gr == orr).all(), (k, kind, flags)
+        assert orr.sum() > 0
