@@ -217,7 +217,9 @@ int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t c
  *   out_state_idx / out_final (nullable)  = StateIndex / Final of the end state, as pire_hip_run.
  * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE (| PIRE_HIP_RUN_GENERIC: keep the
  * one-string-per-lane kernel; by default batches of >= 256 strings with <= 8 regexps take the ragged kernel, which
- * re-walks exactly only the 16-byte chunks that touched a Final state).  Pinned by tests/count_ut.cpp:541-550, 575.
+ * re-walks exactly only the 16-byte chunks that touched a Final state).  PIRE_HIP_RUN_HOST_OFFSETS as for
+ * pire_hip_run; few long strings of host-known length are counted segment-wise after the segmented scan has resolved
+ * every segment's true start state.  Pinned by tests/count_ut.cpp:541-550, 575.
  */
 int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                             uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* stream);

@@ -340,6 +340,14 @@ class Table:
                                              out_idx_ptr or None, out_final_ptr or None, out_results_ptr or None,
                                              stream or None))
 
+    def run_half_final_device_host_offsets(self, text_ptr: int, offsets: np.ndarray, flags, out_idx_ptr=0,
+                                           out_final_ptr=0, out_results_ptr=0, stream: int = 0):
+        """Resident text, offsets on the host (PIRE_HIP_RUN_HOST_OFFSETS); outputs on the device."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _check(lib().pire_hip_run_half_final(self._h, text_ptr or None, offsets.ctypes.data, len(offsets) - 1,
+                                             flags | FLAG_ON_DEVICE | FLAG_HOST_OFFSETS, out_idx_ptr or None,
+                                             out_final_ptr or None, out_results_ptr or None, stream or None))
+
     def prefix(self, text, offsets, longest: bool, through_begin=False, through_end=False, generic=False):
         """LongestPrefix / ShortestPrefix lengths (-1 = no prefix) for host strings."""
         text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))

@@ -561,12 +561,58 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	p.actDist = t->dev.distFinalPerm;
 	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
 	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
+	// few long strings: the segmented scan resolves every segment's true start state, then the segments are counted
+	// in parallel (segmented.hip); needs the lengths on the host and counters that pack.  false: not done.
+	auto segmented = [&](const uint64_t* hostOffsets, uint32_t* dResults, bool* done) -> int {
+		*done = false;
+		if (exactOnly || !p.incPerm || !SegmentedEligible(n, hostOffsets[n] - hostOffsets[0]))
+			return PIRE_HIP_OK;
+		ScanParams ps;
+		if (int rc = FillParams(t, &ps, flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END)))   // Begin() folded into the start
+			return rc;
+		ps.n = n;
+		ps.text = p.text;
+		ps.offsets = p.offsets;
+		ps.outIdx = p.outIdx;
+		ps.outFinal = p.outFinal;
+		bool incomplete = false;
+		if (int rc = RunSegmented(t, ps, hostOffsets, stream, dResults, &incomplete))
+			return rc;
+		*done = !incomplete;
+		return PIRE_HIP_OK;
+	};
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
 		p.outIdx = out_state_idx;
 		p.outFinal = out_final;
-		return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
+		if (!(flags & PIRE_HIP_RUN_HOST_OFFSETS))
+			return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
+		// resident text, offsets known to the host (see pire_hip_run)
+		for (uint64_t i = 0; i < n; ++i)
+			if (offsets[i] > offsets[i + 1]) {
+				SetError("offsets must be non-decreasing");
+				return PIRE_HIP_EINVAL;
+			}
+		void* d = nullptr;
+		hipError_t e = hipMallocAsync(&d, (n + 1) * 8, stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(offsets)");
+		e = hipMemcpyAsync(d, offsets, (n + 1) * 8, hipMemcpyHostToDevice, stream);
+		int rc = e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemcpy(offsets)");
+		p.offsets = static_cast<const uint64_t*>(d);
+		bool counted = false;
+		if (!rc)
+			rc = segmented(offsets, out_results, &counted);
+		if (!rc && !counted)
+			rc = LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
+		(void)hipFreeAsync(d, stream);
+		if (!rc) {
+			e = hipStreamSynchronize(stream);   // the caller's offsets array was the source of an async copy
+			if (e != hipSuccess)
+				rc = HipFail(e, "hipStreamSynchronize");
+		}
+		return rc;
 	}
 	Staging st;
 	for (uint64_t i = 0; i < n; ++i)
@@ -594,8 +640,12 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 		return rc;
 	p.outIdx = static_cast<uint32_t*>(dIdx);
 	p.outFinal = static_cast<uint8_t*>(dFin);
-	if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t)))
+	bool counted = false;
+	if (int rc = segmented(offsets, static_cast<uint32_t*>(dRes), &counted))
 		return rc;
+	if (!counted)
+		if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t)))
+			return rc;
 	hipError_t e = hipSuccess;
 	if (out_state_idx)
 		e = hipMemcpyAsync(out_state_idx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);

@@ -284,7 +284,9 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 // segmented.hip: few long strings, cut into segments that are scanned in parallel (speculatively; the chain of
 // segments is then followed on the host, so the call synchronises its stream)
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes);
-int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream);
+int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream,
+                 uint32_t* halfFinalResults = nullptr,    // non-null: also HalfFinalScanner counts, [n][regexps] ...
+                 bool* halfFinalIncomplete = nullptr);    // ... unless some string ended in the plain walk (then true)
 void NoteKernel(const char* name);   // what pire_hip_last_kernel() reports (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);

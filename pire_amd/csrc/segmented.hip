@@ -76,6 +76,7 @@ struct SlotArrays {
 struct ChainArrays {
 	uint64_t* maps;                // [nSeg] slot at k -> slot at k+1, 7 x u8 (+ kResetMap)
 	uint64_t* prefix;              // [nSeg] inclusive composition
+	uint32_t* trueStart;           // nullable, [nSeg]: the state every segment is really entered in
 	uint32_t* finalState;          // [nStrings]
 	uint32_t* strDone;             // [nStrings] 1: finalState set by the plain walk
 	uint32_t* breakSeg;            // [nStrings] first segment no slot predicted (kNoState: none)
@@ -210,6 +211,8 @@ __global__ void SegmentResolveKernel(SegGeometry g, SegArrays a, SlotArrays sl, 
 		}
 		return;
 	}
+	if (c.trueStart)
+		c.trueStart[k] = sl.guess[slot][k];
 	const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
 	if (last)
 		c.finalState[str] = sl.end[slot][k];
@@ -250,6 +253,83 @@ __global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const 
 		Finish(p, lds, L, s, active, active ? endIdx[s] : 0u);
 	}
 	FlushCounts(p, lds, L);
+}
+
+// HalfFinalScanner counting (scanners/half_final.h:137-164) over segments whose TRUE start states are known from the
+// resolved chain: nothing is speculative here, every segment counts the Final states of its own steps -- Initialize
+// and Begin() belong to a string's first segment, End() to its last -- and the counts of a string's segments add up.
+// One segment per lane, exact step per byte (the segments are equally long: no lane waits for another).
+__global__ __launch_bounds__(256) void SegmentHalfFinalKernel(ScanParams p, SegGeometry g, SegArrays a, const uint32_t* trueStart,
+                                                              const uint32_t* strDone, uint32_t initialPerm, uint32_t* results)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, 0);
+	unsigned int* blockSum = reinterpret_cast<unsigned int*>(lds + L.total);   // [8] counts of the block's first string
+	if (threadIdx.x < 8)
+		blockSum[threadIdx.x] = 0;
+	LoadTableToLds(p, lds, L);   // ends with a barrier
+	const uint64_t k0 = uint64_t(blockIdx.x) * blockDim.x;
+	const uint64_t k = k0 + threadIdx.x;
+	const uint32_t firstStr = k0 < g.nSeg ? a.segStr[k0] : 0;
+	if (k < g.nSeg && !strDone[a.segStr[k]]) {
+		uint32_t c[8];
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			c[r] = 0;
+		auto take = [&](uint32_t st) {
+			if (IsFinalState(p, st)) {
+				const uint64_t inc = p.incPerm[st];
+#pragma unroll
+				for (int r = 0; r < 8; ++r)
+					c[r] += uint32_t(inc >> (8 * r)) & 0xFFu;
+			}
+		};
+		uint32_t st = trueStart[k];
+		if (a.segJ[k] == 0) {
+			take(initialPerm);                                   // Initialize ends with TakeAction, half_final.h:142
+			if (p.flags & PIRE_HIP_RUN_BEGIN)
+				take(st);                                        // st IS the state after Begin()
+		}
+		const uint8_t* q = p.text + a.segBegin[k];
+		const uint8_t* qe = p.text + a.segEnd[k];
+		for (; q < qe && (reinterpret_cast<uintptr_t>(q) & 15); ++q) {
+			st = SlowStep(p, lds, L, st, *q);
+			take(st);
+		}
+		for (; q + 16 <= qe; q += 16) {
+			u32x4 v = *reinterpret_cast<const u32x4*>(q);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				st = SlowStep(p, lds, L, st, v.x & 0xFF);
+				take(st);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
+		}
+		for (; q < qe; ++q) {
+			st = SlowStep(p, lds, L, st, *q);
+			take(st);
+		}
+		const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
+		if (last && (p.flags & PIRE_HIP_RUN_END)) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			take(st);
+		}
+		const uint32_t str = a.segStr[k];
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			if (uint32_t(r) < p.regexps && c[r]) {
+				if (str == firstStr)
+					atomicAdd(&blockSum[r], c[r]);
+				else
+					atomicAdd(&results[size_t(str) * p.regexps + r], c[r]);
+			}
+	}
+	__syncthreads();
+	if (threadIdx.x < p.regexps && threadIdx.x < 8 && blockSum[threadIdx.x])
+		atomicAdd(&results[size_t(firstStr) * p.regexps + threadIdx.x], blockSum[threadIdx.x]);
 }
 
 uint64_t EnvBytes(const char* name, uint64_t fallback)
@@ -342,7 +422,10 @@ bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 
 // p: the original batch with DEVICE pointers (strided, or offsets on the device); hostOffsets: the same offsets on
 // the host (nullptr for strided batches) -- the host has to know the lengths to cut the strings up.
-int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream)
+// halfFinalResults (nullable, device, [n][regexps], packed increments required): the table is walked as a
+// HalfFinalScanner; p.startPerm must then be Initialize() with Begin() folded in (it is for every other caller too).
+int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream,
+                 uint32_t* halfFinalResults, bool* halfFinalIncomplete)
 {
 	PIRE_TRY(CheckCounts(p));
 	// diagnostics (PIRE_HIP_SEGMENT_STATS): where the host's time goes, with the stream drained at every mark
@@ -403,7 +486,8 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	{
 		const size_t perSeg = 3 * 8 + 3 * 4            // the cut
 		                      + (size_t(maxModes) + 1) * 8 + 4   // guess + end per slot, the constant init array
-		                      + 2 * 8;                 // maps, prefix
+		                      + 2 * 8                  // maps, prefix
+		                      + 4;                     // true start states (half-final counting)
 		const size_t perString = 5 * 4 + 2 * 8 + 3 * 4 + 4;
 		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + tempBytes + 64 * 256));
 	}
@@ -526,6 +610,8 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	ChainArrays c = {};
 	PIRE_TRY(scratch.Alloc(&c.maps, S));
 	PIRE_TRY(scratch.Alloc(&c.prefix, S));
+	if (halfFinalResults)
+		PIRE_TRY(scratch.Alloc(&c.trueStart, S));
 	PIRE_TRY(scratch.Alloc(&c.finalState, n));
 	PIRE_TRY(scratch.Alloc(&c.strDone, n));
 	PIRE_TRY(scratch.Alloc(&c.breakSeg, n));
@@ -637,6 +723,23 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	}
 
 	mark("chain");
+	if (halfFinalIncomplete)
+		*halfFinalIncomplete = nPlain != 0;
+	if (halfFinalResults && !nPlain) {
+		// every segment now knows the state it is really entered in (not so after a plain walk: the caller then
+		// counts the whole batch with the one-string-per-lane kernel)
+		PIRE_TRY(HipOk(hipMemsetAsync(halfFinalResults, 0, n * size_t(p.regexps) * 4, stream), "hipMemset"));
+		ScanParams hp = p;
+		hp.compact = 0;
+		const LdsLayout L = MakeLayout(hp.hot, 0, kRotPitch, 0);
+		const uint32_t ldsBytes = L.total + 64;
+		PIRE_TRY(HipOk(hipFuncSetAttribute(reinterpret_cast<const void*>(SegmentHalfFinalKernel),
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)), "hipFuncSetAttribute(LDS)"));
+		const uint32_t initialPerm = t->host.permOfOrig[t->host.initial];
+		hipLaunchKernelGGL(SegmentHalfFinalKernel, dim3(blocks), dim3(256), ldsBytes, stream, hp, g, a, c.trueStart, c.strDone,
+		                   initialPerm, halfFinalResults);
+		mark("half-final counts");
+	}
 	// ---- finish
 	{
 		ScanParams f = p;

@@ -223,3 +223,34 @@ def test_concurrent_threads_segmented_scans_on_one_table():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("seg,modes,budget", [(96, 6, 32), (256, 1, 0), (4096, 6, 32)])
+def test_segmented_half_final_counting(seg, modes, budget, monkeypatch):
+    """HalfFinalScanner counting of few long strings: the chain gives every segment its true start state, the segments
+    are then counted in parallel; a chain that had to fall back to the plain walk hands the batch to the ordinary
+    half-final kernel.  Either way Result(r), StateIndex and Final are the oracle's."""
+    import pire_amd
+    from pire_amd import binding as pb
+
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_MODES", str(modes))
+    monkeypatch.setenv("PIRE_HIP_SEGMENT_BUDGET", str(budget))
+    g = H.golden()
+    tables = [(c["name"], H.load_blob(c["blob"]), b"abcde w") for c in g["half_final"] if c["regexps"] <= 8][:3]
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    tables.append(("set_d", H.load_blob(big["blob"]), ALPHABET))
+    rng = np.random.RandomState(seg)
+    for name, blob, alphabet in tables:
+        t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+        a = np.frombuffer(alphabet, dtype=np.uint8)
+        strings = [a[rng.randint(0, len(a), size=k)].tobytes() for k in (0, 1, 95, 96, 97, 1000, 5000, 20000, 333)]
+        text, offs = H.pack(strings)
+        for flags in (3, 0, 1, 2):
+            oi, of, orr = o.run_half_final(*ob.pack_strings(strings), flags=flags)
+            gi, gf, gr = t.run_half_final(text, offs, flags=flags)
+            if budget:
+                assert pb.last_kernel().startswith("segmented")
+            assert (gi == oi).all() and (gf == of).all(), (name, flags)
+            assert (gr == orr).all(), (name, flags, gr.tolist(), orr.tolist())
+        assert orr.sum() > 0
