@@ -38,8 +38,8 @@ WORKLOADS = {"set_a": "C3: 8 regexps glued via Scanner::Glue, LDS-resident dense
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-strings", type=int, default=20, help="strings per GPU = 2^this (headline: 20)")
     ap.add_argument("--len", type=int, default=4096, help="bytes per string (headline: 4096)")
     ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")

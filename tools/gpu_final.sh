@@ -13,7 +13,7 @@ timeout 900 python bench.py 2>&1 | tail -1 | tee gpurun_out/final/bench_n1.json
 echo "== bench C2 single pattern (parity config, informational)"
 timeout 600 python bench.py --set c2_single --steps 10 --warmup 2 --cpu-sample-log2 18 2>&1 | tail -1 | cut -c1-700 | tee gpurun_out/final/bench_c2.json
 echo "== rocprofv3 kernel stats of the bench command"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -o stats -- python bench.py --steps 20 --warmup 3 --no-cpu > gpurun_out/final/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/stats -o stats -- python bench.py --no-cpu > gpurun_out/final/stats.log 2>&1
 cat gpurun_out/final/stats/stats_kernel_stats.csv | head -5
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" \
