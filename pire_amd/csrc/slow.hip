@@ -28,6 +28,7 @@ struct SlowHost {
 	bool empty = false;
 	std::vector<uint8_t> letterOf;     // [264] letter of each Char (m_letters, slow.h:349)
 	std::vector<uint32_t> masks;       // [states*letters][words]
+	std::vector<uint32_t> single;      // [states*letters][2] the (up to two) targets of the jump list, or kSlowMulti
 	std::vector<uint32_t> finals;      // [words] bitset of final states
 };
 
@@ -35,8 +36,12 @@ struct SlowDevice {
 	int device = -1;
 	uint8_t* letterOf = nullptr;
 	uint32_t* masks = nullptr;
+	uint32_t* single = nullptr;
 	uint32_t* finals = nullptr;
 };
+
+constexpr uint32_t kSlowNone = 0xFFFFFFFFu;    // no target / empty list slot
+constexpr uint32_t kSlowMulti = 0xFFFFFFFEu;   // more than two targets: the step takes the bitset form
 
 }  // namespace pirehip
 
@@ -50,8 +55,9 @@ namespace pirehip {
 struct SlowParams {
 	const uint8_t* letterOf;
 	const uint32_t* masks;
+	const uint32_t* single;
 	const uint32_t* finals;
-	uint32_t states, letters, start, words, flags, masksInLds;
+	uint32_t states, letters, start, words, flags, masksInLds, singleInLds;
 	const uint8_t* text;
 	const uint64_t* offsets;   // nullable: strided
 	uint64_t n, len, stride;
@@ -84,20 +90,151 @@ __device__ __forceinline__ void SlowStep(const uint32_t* masks, uint32_t letters
 		cur[k] = next[k];
 }
 
+// The active set of one lane: on real text an NFA has one or two active states (measured: 1.3 - 1.8 on the fixtures),
+// but WHICH states differs from lane to lane, so a bitset walk -- "for every word, for every set bit" -- makes a wave
+// pay for the union of its lanes' words (7 - 8 iterations per byte for 1.4 active states).  The set is therefore kept
+// as a LIST of up to four state ids while it fits: a step is four independent lookups, the same for every lane.
+// Both forms hold exactly the reference's set (slow.h:63-74) -- a list may name a state twice, which changes
+// nothing -- so the results do not depend on the form.
+template <int K>
+struct SlowLane {
+	uint32_t lst[4];     // list form: state ids, kSlowNone = empty slot (anywhere)
+	uint32_t cur[K];     // bitset form
+	bool bits;           // which form is valid
+
+	__device__ __forceinline__ void Start(uint32_t start)
+	{
+		lst[0] = start;
+		lst[1] = lst[2] = lst[3] = kSlowNone;
+		bits = false;
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			cur[k] = 0;
+	}
+	__device__ __forceinline__ void ListToBits()
+	{
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			cur[k] = 0;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			const uint32_t s = lst[i];
+			if (s != kSlowNone) {
+#pragma unroll
+				for (int k = 0; k < K; ++k)
+					cur[k] |= (s >> 5) == uint32_t(k) ? (1u << (s & 31)) : 0u;
+			}
+		}
+		bits = true;
+	}
+	// back to the list form when at most four states are active
+	__device__ __forceinline__ void BitsToListIfSmall()
+	{
+		uint32_t count = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k)
+			count += __popc(cur[k]);
+		if (count > 4)
+			return;
+		uint32_t n[4] = {kSlowNone, kSlowNone, kSlowNone, kSlowNone};
+		uint32_t used = 0;
+#pragma unroll
+		for (int k = 0; k < K; ++k) {
+			uint32_t b = cur[k];
+			while (b) {
+				const uint32_t s = uint32_t(k) * 32 + __builtin_ctz(b);
+				b &= b - 1;
+				n[0] = used == 0 ? s : n[0];
+				n[1] = used == 1 ? s : n[1];
+				n[2] = used == 2 ? s : n[2];
+				n[3] = used == 3 ? s : n[3];
+				++used;
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i)
+			lst[i] = n[i];
+		bits = false;
+	}
+	__device__ __forceinline__ void Step(const uint32_t* masks, const uint2* single, uint32_t letters, uint32_t letter)
+	{
+		if (!bits) {
+			// Every state moves to its (first) target IN PLACE -- no compaction, no duplicate check: a duplicate only
+			// wastes a slot.  A second target (the one row in a hundred where the set grows, e.g. the start state
+			// meeting the pattern's first letter) is put into a free slot; two of them in one step, no free slot, or
+			// a row with three targets send the lane to the bitset form.  Branch free (bitwise and / or on 0/1
+			// values): the short-circuit forms compiled into hundreds of tiny basic blocks.
+			uint32_t n[4], extra = kSlowNone, extras = 0, overflow = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const uint32_t s = lst[i];
+				const uint32_t invalid = s == kSlowNone ? kSlowNone : 0u;
+				const uint2 r = single[(invalid ? 0u : s) * letters + letter];
+				const uint32_t t0 = r.x | invalid, t1 = r.y | invalid;
+				overflow |= uint32_t(t0 == kSlowMulti);
+				n[i] = t0;
+				const uint32_t has = uint32_t(t1 != kSlowNone);
+				extra = has ? t1 : extra;
+				extras += has;
+			}
+			if (__any(extras != 0)) {
+				overflow |= uint32_t(extras > 1);
+				uint32_t placed = uint32_t(extras != 1);
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const uint32_t take = uint32_t(n[j] == kSlowNone) & (placed ^ 1u);
+					n[j] = take ? extra : n[j];
+					placed |= take;
+				}
+				overflow |= placed ^ 1u;
+			}
+			if (!overflow) {
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+					lst[i] = n[i];
+				return;
+			}
+			ListToBits();   // the OLD set; the step is redone in the bitset form
+		}
+		SlowStep<K>(masks, letters, cur, letter);
+		BitsToListIfSmall();
+	}
+	__device__ __forceinline__ bool Final(const uint32_t* finals) const
+	{
+		bool fin = false;
+		if (bits) {
+#pragma unroll
+			for (int k = 0; k < K; ++k)
+				fin = fin || (cur[k] & finals[k]) != 0;
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				fin = fin || (lst[i] != kSlowNone && ((finals[lst[i] >> 5] >> (lst[i] & 31)) & 1u));
+		}
+		return fin;
+	}
+};
+
 template <int K>
 __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint8_t* ldsLetter = lds;                                        // 264 bytes
-	uint32_t* ldsMasks = reinterpret_cast<uint32_t*>(lds + 272);
+	uint32_t* ldsSingle = reinterpret_cast<uint32_t*>(lds + 272);
+	const uint32_t entries = p.states * p.letters;
+	uint32_t* ldsMasks = ldsSingle + (p.singleInLds ? 2 * entries : 0);
 	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
 		ldsLetter[i] = p.letterOf[i];
-	const uint32_t maskWords = p.states * p.letters * K;
+	if (p.singleInLds)
+		for (uint32_t i = threadIdx.x; i < 2 * entries; i += blockDim.x)
+			ldsSingle[i] = p.single[i];
+	const uint32_t maskWords = entries * K;
 	if (p.masksInLds)
 		for (uint32_t i = threadIdx.x; i < maskWords; i += blockDim.x)
 			ldsMasks[i] = p.masks[i];
 	__syncthreads();
 	const uint32_t* masks = p.masksInLds ? ldsMasks : p.masks;
+	const uint2* single = reinterpret_cast<const uint2*>(p.singleInLds ? ldsSingle : p.single);
 
 	const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
 	unsigned long long finals = 0, strings = 0;
@@ -110,41 +247,40 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 			b = s * p.stride;
 			e = b + p.len;
 		}
-		uint32_t cur[K];
-#pragma unroll
-		for (int k = 0; k < K; ++k)   // Initialize, slow.h:89-95 (selects, so that cur[] stays in registers)
-			cur[k] = (uint32_t(k) == (p.start >> 5)) ? (1u << (p.start & 31)) : 0u;
+		SlowLane<K> lane;
+		lane.Start(p.start);                                             // Initialize, slow.h:89-95
 		if (p.flags & PIRE_HIP_RUN_BEGIN)
-			SlowStep<K>(masks, p.letters, cur, ldsLetter[kBeginMark]);   // Begin(), run.h:375
+			lane.Step(masks, single, p.letters, ldsLetter[kBeginMark]);  // Begin(), run.h:375
 		const uint8_t* ptr = p.text + b;
 		const uint8_t* end = p.text + e;
 		// Run<SlowScanner>, slow.h:436-451 -- byte by byte; 16-byte vector loads where the pointer allows
 		for (; ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15); ++ptr)
-			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);
+			lane.Step(masks, single, p.letters, ldsLetter[*ptr]);
 		for (; ptr + 16 <= end; ptr += 16) {
-			const uint4 v = *reinterpret_cast<const uint4*>(ptr);
-			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-			for (int i = 0; i < 4; ++i)
-#pragma unroll
-				for (int j = 0; j < 4; ++j)
-					SlowStep<K>(masks, p.letters, cur, ldsLetter[(w[i] >> (8 * j)) & 0xFF]);
+			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				lane.Step(masks, single, p.letters, ldsLetter[v.x & 0xFF]);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
 		}
 		for (; ptr < end; ++ptr)
-			SlowStep<K>(masks, p.letters, cur, ldsLetter[*ptr]);
+			lane.Step(masks, single, p.letters, ldsLetter[*ptr]);
 		if (p.flags & PIRE_HIP_RUN_END)
-			SlowStep<K>(masks, p.letters, cur, ldsLetter[kEndMark]);     // End(), run.h:376
-		bool fin = false;
-#pragma unroll
-		for (int k = 0; k < K; ++k)
-			fin = fin || (cur[k] & p.finals[k]) != 0;                    // Final, slow.h:152-158
+			lane.Step(masks, single, p.letters, ldsLetter[kEndMark]);    // End(), run.h:376
+		const bool fin = lane.Final(p.finals);                           // Final, slow.h:152-158
 		if (p.outFinal)
 			p.outFinal[s] = fin ? 1 : 0;
 		if (p.outBits) {
+			if (!lane.bits)
+				lane.ListToBits();
 #pragma unroll
 			for (int k = 0; k < K; ++k)
 				if (uint32_t(k) < p.words)
-					p.outBits[s * p.words + k] = cur[k];
+					p.outBits[s * p.words + k] = lane.cur[k];
 		}
 		finals += fin ? 1 : 0;
 		strings += 1;
@@ -204,6 +340,7 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 		h.words = 1;
 		h.letterOf.assign(kMaxChar, 0);
 		h.masks.assign(1, 0);
+		h.single.assign(2, kSlowNone);
 		h.finals.assign(1, 0);
 		return PIRE_HIP_OK;
 	}
@@ -252,6 +389,27 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 			h.masks[i * h.words + (tgt >> 5)] |= 1u << (tgt & 31);
 		}
 	}
+	// the first two distinct targets of every jump list, for the list form of the walk: [2*i] and [2*i+1], kSlowNone
+	// where there is none; three or more distinct targets: [2*i] = kSlowMulti
+	h.single.assign(size_t(states) * letters * 2, kSlowNone);
+	for (size_t i = 0; i + 1 < npos; ++i) {
+		uint32_t t0 = kSlowNone, t1 = kSlowNone;
+		bool multi = false;
+		for (uint64_t k = jumpPos[i]; k < jumpPos[i + 1]; ++k) {
+			uint32_t tgt;
+			memcpy(&tgt, p + pos + size_t(k) * 4, 4);
+			if (t0 == kSlowNone)
+				t0 = tgt;
+			else if (tgt == t0)
+				continue;
+			else if (t1 == kSlowNone)
+				t1 = tgt;
+			else if (tgt != t1)
+				multi = true;
+		}
+		h.single[2 * i] = multi ? kSlowMulti : t0;
+		h.single[2 * i + 1] = multi ? kSlowNone : t1;
+	}
 	return PIRE_HIP_OK;
 }
 
@@ -276,6 +434,7 @@ void FreeSlowDevice(SlowDevice* d)
 		return;
 	if (d->letterOf) (void)hipFree(d->letterOf);
 	if (d->masks) (void)hipFree(d->masks);
+	if (d->single) (void)hipFree(d->single);
 	if (d->finals) (void)hipFree(d->finals);
 	*d = SlowDevice();
 }
@@ -309,7 +468,8 @@ int UploadSlow(pire_hip_slow_table* t)
 		finals[w] = h.finals[w];
 	SlowDevice d;
 	int rc;
-	if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.masks, masks)) || (rc = PutSlow(&d.finals, finals))) {
+	if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.masks, masks)) || (rc = PutSlow(&d.single, h.single)) ||
+	    (rc = PutSlow(&d.finals, finals))) {
 		d.device = dev;
 		FreeSlowDevice(&d);
 		return rc;
@@ -324,8 +484,10 @@ int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
 {
 	SlowParams p = p0;
 	const size_t maskBytes = size_t(p.states) * p.letters * K * 4;
-	p.masksInLds = maskBytes <= 150 * 1024 ? 1 : 0;
-	const uint32_t ldsBytes = uint32_t(272 + (p.masksInLds ? maskBytes : 0));
+	const size_t singleBytes = size_t(p.states) * p.letters * 8;
+	p.singleInLds = singleBytes <= 64 * 1024 ? 1 : 0;
+	p.masksInLds = maskBytes + (p.singleInLds ? singleBytes : 0) <= 150 * 1024 ? 1 : 0;
+	const uint32_t ldsBytes = uint32_t(272 + (p.singleInLds ? singleBytes : 0) + (p.masksInLds ? maskBytes : 0));
 	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SlowScanKernel<K>),
 	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
 	if (e != hipSuccess)
@@ -362,6 +524,7 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 	memset(&p, 0, sizeof(p));
 	p.letterOf = t->dev.letterOf;
 	p.masks = t->dev.masks;
+	p.single = t->dev.single;
 	p.finals = t->dev.finals;
 	p.states = h.states;
 	p.letters = h.letters;
