@@ -102,3 +102,31 @@ def test_slow_gpu_strided_device_batch():
     assert (bits.cpu().numpy().astype(np.uint32) == obits).all()
     assert cnt.cpu().numpy().tolist() == [int(of.sum()), n]
     assert of.sum() >= n // 3
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ob.ref_available(), reason="oracle/_ref/libpire_ref.so not built")
+@pytest.mark.parametrize("pat,opt,alphabet", [
+    ("a.{30}$", "", b"ab"),                      # every second byte starts a chain: lists overflow at once
+    ("x.{40}$", "u", b"xyz\xd0\xb0 "),            # UTF-8 automaton, dense triggers
+    ("(ab|cd)*e.{3}f", "", b"abcdef"),           # rows with several targets
+    ("(a|ab|abc|abcd|abcde)+f", "", b"abcdef"),   # many targets per row, sets that stay large
+    ("[a-c]+d.{2,9}$", "i", b"abcdABCD. "),
+    ("^a.{5}b", "", b"ab"),
+    ("hello.{20}world", "", b"helowrd abcxyz0123456789"),   # sparse: the list form nearly all the time
+])
+def test_slow_gpu_list_and_bitset_forms_agree_with_the_oracle(pat, opt, alphabet):
+    """The kernel keeps a lane's active set as a short list while it fits and as a bitset otherwise; dense and sparse
+    triggers push lanes through both forms and back.  Final and the full state set must be the oracle's."""
+    import pire_amd
+
+    r = ob.RefSlowScanner.compile(pat, opt)
+    blob = r.save()
+    t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
+    rng = np.random.RandomState(31)
+    strings = H.random_strings(rng, 3000, 200, alphabet) + [b"", b"a", alphabet * 40]
+    for flags in (BE, 0, ob.FLAG_BEGIN, ob.FLAG_END):
+        of, obits = o.run_strings(strings, flags=flags)
+        gf, gb = t.run_strings(strings, flags=flags)
+        assert (gf == of).all(), (pat, flags)
+        assert (gb == obits).all(), (pat, flags)
