@@ -121,3 +121,24 @@ def test_gpu_counting_every_counter_instantiation(pa, k):
             gi, gr = t.run_strings(many, flags=flags)
             assert (gi == oi).all() and (gr == orr).all(), (k, kind, flags)
         assert orr.sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["count0_advanced", "count0_basic", "count_glued3_advanced", "count0_noglue"])
+def test_gpu_counting_big_batches(pa, name):
+    """Tens of thousands of strings (several per lane): every length from 0 up, unaligned starts, strings that end
+    inside a 16-byte block."""
+    case = [c for c in cases() if c["name"] == name]
+    if not case:
+        pytest.skip("fixture not present")
+    case = case[0]
+    blob = H.load_blob(case["blob"])
+    t, o = pa.CountingTable(blob, case["kind"]), ob.OracleCountingScanner(blob, case["kind"])
+    rng = np.random.RandomState(40)
+    many = ([b"", b"a", b"ab cd"] + H.random_strings(rng, 30000, 120, b"abc def,http:/\n") +
+            H.random_strings(rng, 200, 3000, b"abcdefgh \n") + [b""] * 5)
+    for flags in (3, 0):
+        oi, orr = o.run_strings(many, flags=flags)
+        gi, gr = t.run_strings(many, flags=flags)
+        assert (gi == oi).all() and (gr == orr).all(), (name, flags)
+    assert orr.sum() > 0
