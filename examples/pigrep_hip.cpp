@@ -55,12 +55,11 @@ void GrepStream(std::istream& in, const Pire::Hip::Table<Pire::Scanner>& table, 
 
 void Usage()
 {
-	std::cerr << "Usage: pigrep_hip [-i] [-u] [-x] [-e pattern | pattern] [file [file2...]]\n"
-	          << "  -i    Be case insensitive\n"
-	          << "  -u    Interpret input sequence and pattern as UTF-8 strings\n"
-	          << "  -x    Enable extended syntax (\"re1&re2\" for conjunction and \"~re\" for negation)\n"
-	          << "  -e    Specify regexp pattern (useful if it begins with a dash)\n"
-	          << "When no files are given, stdin is examined." << std::endl;
+	std::cerr << "pigrep_hip: print the lines a Pire regexp matches, scanning on the GPU\n"
+	             "  pigrep_hip [-i] [-u] [-x] (-e PATTERN | PATTERN) [FILE...]\n"
+	             "    -i  ignore case            -u  pattern and text are UTF-8\n"
+	             "    -x  allow re1&re2 and ~re  -e  next argument is the pattern, even if it starts with '-'\n"
+	             "  no FILE (or '-'): standard input; several FILEs: lines are prefixed with the file name\n";
 	exit(1);
 }
 
