@@ -484,6 +484,12 @@ class CountingTable:
                                           e.ctypes.data, None))
         return idx, fin, ((b >= 0) & (e >= 0)).astype(np.uint8), b, e
 
+    def capture_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_final_ptr=0,
+                       out_begin_ptr=0, out_end_ptr=0, stream: int = 0):
+        _check(lib().pire_hip_capture_run(self._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
+                                          out_idx_ptr or None, out_final_ptr or None, out_begin_ptr or None,
+                                          out_end_ptr or None, stream or None))
+
     def run_device(self, text_ptr: int, offsets_ptr: int, n: int, flags, out_idx_ptr=0, out_results_ptr=0, stream: int = 0):
         _check(lib().pire_hip_counting_run(self._h, self.kind, text_ptr or None, offsets_ptr or None, n,
                                            flags | FLAG_ON_DEVICE, out_idx_ptr or None, out_results_ptr or None,
