@@ -349,9 +349,40 @@ static void TestCapture()
 	CHECK(!gpu.Captured(2));
 }
 
+// A few long strings: the library cuts them into segments scanned in parallel (segmented.hip); what comes back must
+// still be the State the one-byte-at-a-time Runner of the reference ends in.
+static void TestLongStrings()
+{
+	Pire::Scanner sc = Pire::Scanner::Glue(Parse("hello\\s+w.+d$").Compile<Pire::Scanner>(),
+	                                       Parse("[0-9]{3}-[0-9]{4}").Compile<Pire::Scanner>());
+	std::vector<Pire::ystring> strings;
+	unsigned seed = 12345;
+	for (int k = 0; k < 3; ++k) {
+		Pire::ystring s;
+		const size_t len = (size_t(1) << 20) + 777 * k;
+		s.reserve(len + 32);
+		while (s.size() < len) {
+			seed = seed * 1664525u + 1013904223u;
+			const unsigned r = seed >> 16;
+			if (r % 5000 == 0)
+				s += "hello   w";
+			else if (r % 7000 == 1)
+				s += " 555-1234 ";
+			else
+				s += char(' ' + r % 95);
+		}
+		if (k == 1)
+			s += "orld";
+		strings.push_back(s);
+	}
+	CompareAll(sc, strings);
+	CHECK(std::string(pire_hip_last_kernel()).find("segmented") == 0);
+}
+
 int main()
 {
 	try {
+		TestLongStrings();
 		TestPrefixAndSlow();
 		TestCapture();
 		TestCounting<Pire::CountingScanner>();
