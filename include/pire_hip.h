@@ -216,7 +216,7 @@ int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t c
  *   out_results[i * RegexpsCount() + r] = State::Result(r)   (half_final.h:90-92; u32: a count is <= length + 3)
  *   out_state_idx / out_final (nullable)  = StateIndex / Final of the end state, as pire_hip_run.
  * flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE (| PIRE_HIP_RUN_GENERIC: keep the
- * one-string-per-lane kernel; by default batches of >= 256 strings with <= 8 regexps take the ragged kernel, which
+ * one-string-per-lane kernel; by default batches of >= 256 strings take the ragged kernel, which
  * re-walks exactly only the 16-byte chunks that touched a Final state).  PIRE_HIP_RUN_HOST_OFFSETS as for
  * pire_hip_run; few long strings of host-known length are counted segment-wise after the segmented scan has resolved
  * every segment's true start state.  Pinned by tests/count_ut.cpp:541-550, 575.

@@ -318,7 +318,7 @@ int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stre
 {
 	if (p0.n == 0)
 		return PIRE_HIP_OK;
-	if (workCounter && p0.incPerm && RaggedActEligible(p0)) {
+	if (workCounter && RaggedActEligible(p0)) {
 		NoteKernel("ragged_half_final");
 		return LaunchRaggedHalfFinal(p0, workCounter, outResults, stream);
 	}

@@ -198,6 +198,58 @@ struct HalfFinalAct {
 	}
 };
 
+// The same for tables whose counters do not pack (more than 8 regexps, or a state that bumps one counter more than
+// 255 times): the lane owns row s of the result array and read-modify-writes it -- only in the exact re-walks, i.e.
+// where a Final state really was visited.
+struct HalfFinalWideAct {
+	static constexpr bool kActive = true;
+	uint32_t* results;
+	struct Lane {
+		uint32_t* row;
+	};
+	__device__ __forceinline__ bool Wants(const Lane&) const { return true; }
+	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotFinalLo; }
+	__device__ __forceinline__ void LoadLds(const ScanParams&, uint8_t*) const {}
+	__device__ __forceinline__ void Step(const ScanParams& p, const uint8_t*, const LdsLayout&, Lane& al, uint32_t st,
+	                                     uint64_t) const
+	{
+		if (IsFinalState(p, st))
+			for (uint64_t k = p.acceptOffPerm[st]; k < p.acceptOffPerm[st + 1]; ++k)
+				al.row[p.acceptIds[k]] += 1;
+	}
+	__device__ __forceinline__ void HotStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
+	                                        Lane& al, uint32_t h, uint64_t after) const
+	{
+		Step(p, lds, L, al, h, after);
+	}
+	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                          uint32_t s, uint64_t addr) const
+	{
+		al.row = results + size_t(s) * p.regexps;
+		for (uint32_t r = 0; r < p.regexps; ++r)
+			al.row[r] = 0;
+		uint32_t st = p.startPerm;                         // Initialize ends with TakeAction, half_final.h:142
+		Step(p, lds, L, al, st, addr);
+		if (p.flags & PIRE_HIP_RUN_BEGIN) {
+			st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+			Step(p, lds, L, al, st, addr);
+		}
+		return st;
+	}
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
+	                                       uint32_t s, uint32_t st, uint64_t end) const
+	{
+		if (p.flags & PIRE_HIP_RUN_END) {
+			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
+			Step(p, lds, L, al, st, end);
+		}
+		if (p.outIdx)
+			p.outIdx[s] = p.origOfPerm[st];
+		if (p.outFinal)
+			p.outFinal[s] = p.flagsPerm[st] & kFinal;
+	}
+};
+
 // Pire::LongestPrefix / ShortestPrefix (run.h:277-311, predicates 69-100): the position after the last (first) step
 // that ended in a Final state; a Dead state ends the search.  A lane whose search is over stops re-walking (its
 // state no longer matters) and idles through the rest of its string.
@@ -791,6 +843,11 @@ int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter,
 	if (!p.actDist)
 		p.compact = 0;
 	p.outCounts = nullptr;
+	if (!p.incPerm) {     // counters that do not pack: rows of the result array
+		HalfFinalWideAct wide;
+		wide.results = outResults;
+		return LaunchRaggedT<decltype(wide), false>(p, workCounter, wide, stream);
+	}
 	HalfFinalAct act;
 	act.results = outResults;
 	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);

@@ -168,3 +168,27 @@ def test_prefix_kernel_choice_follows_the_scanner(monkeypatch):
         got = t.prefix(text, offs, True)
         assert pb.last_kernel() == kernel
         assert (got == o.prefix(text, offs, True)).all()
+
+
+def test_ragged_half_final_with_counters_that_do_not_pack():
+    """More than 8 regexps: the lane read-modify-writes its row of the result array in the exact re-walks."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref/libpire_ref.so not built")
+    import pire_amd
+    from pire_amd import binding as pb
+
+    pats = ["ab+", "b", "a", "(ab)+", "c", "bc", "abc", "b+", "[ab]c", "ca", "d+"]
+    blob = ob.RefHalfFinalScanner.compile(pats, [ob.RefHalfFinalScanner.NONGREEDY_SIMPLE] * len(pats)).save()
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(3)
+    for alphabet in (b"abcd", b"abcdefghijklmnopqrstuvwxyz    "):
+        strings = length_mix(rng, 3000, alphabet)
+        text, offs = H.pack(strings)
+        for flags in (3, 0):
+            oi, of, orr = o.run_half_final(*ob.pack_strings(strings), flags=flags)
+            gi, gf, gr = t.run_half_final(text, offs, flags=flags)
+            assert pb.last_kernel() == "ragged_half_final"
+            assert (gi == oi).all() and (gf == of).all() and (gr == orr).all()
+            xi, xf, xr = t.run_half_final(text, offs, flags=flags | pb.FLAG_GENERIC)
+            assert (xr == orr).all()
+        assert orr.sum() > 0
