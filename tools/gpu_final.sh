@@ -47,6 +47,9 @@ PYTHONPATH=. timeout 200 python tools/half_final_case.py half_5 2>&1 | grep "hal
 PYTHONPATH=. timeout 200 python tools/counting_case.py count_glued3_advanced 2>&1 | grep "counting\|reference" | tee gpurun_out/final/counting.log
 PYTHONPATH=. timeout 200 python tools/actions_case.py 2>&1 | grep -v amdgpu.ids > gpurun_out/final/actions.log; tail -4 gpurun_out/final/actions.log | cut -c1-200
 LONG_TOTAL_LOG2=30 PYTHONPATH=. timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm" | tee gpurun_out/final/long_strings.log | cut -c1-200
+PYTHONPATH=. timeout 200 python tools/long_half_final.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/final/long_half_final.log | cut -c1-200
+PYTHONPATH=. timeout 200 python tools/capture_case.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/final/capture.log | cut -c1-200
+timeout 300 python bench.py --set slow_x40_utf8 --log2-strings 18 --len 16384 --steps 5 --warmup 1 2>&1 | tail -1 | tee gpurun_out/final/bench_c5b.json | cut -c1-200
 tests/cpp/bin/shim_test 2>&1 | tail -1 | tee gpurun_out/final/shim.log
 echo "== pigrep example"
 examples/bin/pigrep_hip -i "lds.*bytes" DESIGN.md | head -2
