@@ -12,7 +12,7 @@ namespace pirehip {
 __global__ __launch_bounds__(1024) void ScanGenericKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	LoadTableToLds(p, lds, L);
 
 	const uint64_t nrounds = (p.n + 63) / 64;
@@ -39,13 +39,12 @@ __global__ __launch_bounds__(1024) void ScanGenericKernel(ScanParams p)
 				st = SlowStep(p, lds, L, st, *ptr);
 				++ptr;
 			}
-			for (; ptr + 16 <= end; ptr += 16) {
-				const u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
-				st = SlowStepWord(p, lds, L, st, v.x);
-				st = SlowStepWord(p, lds, L, st, v.y);
-				st = SlowStepWord(p, lds, L, st, v.z);
-				st = SlowStepWord(p, lds, L, st, v.w);
-			}
+			// whole 16-byte chunks: the dense-row fast path of the other kernels (one v_perm + one LDS byte per step,
+			// exact re-walk of a chunk that leaves the dense rows); this halves the time a lone lane needs per byte
+			uint32_t hs = st < p.hot ? st : p.hot, cold = st;
+			for (; ptr + 16 <= end; ptr += 16)
+				StepChunk<0>(p, lds, L, *reinterpret_cast<const u32x4*>(ptr), hs, cold, uint32_t(reinterpret_cast<uintptr_t>(ptr) >> 4) & 63);
+			st = hs != p.hot ? hs : cold;
 			for (; ptr < end; ++ptr)
 				st = SlowStep(p, lds, L, st, *ptr);
 		}
@@ -269,7 +268,7 @@ int LaunchGeneric(const ScanParams& p0, hipStream_t stream)
 		return rc;
 	ScanParams p = p0;
 	p.compact = 0;   // small blocks, several per CU: no room (and no need) for the warm rows
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(p));
+	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	return LaunchScan(ScanGenericKernel, p, ExactBlockThreads(p.n), L.total, stream);
 }
 
