@@ -259,11 +259,11 @@ __global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const 
 // resolved chain: nothing is speculative here, every segment counts the Final states of its own steps -- Initialize
 // and Begin() belong to a string's first segment, End() to its last -- and the counts of a string's segments add up.
 // One segment per lane, exact step per byte (the segments are equally long: no lane waits for another).
-__global__ __launch_bounds__(256) void SegmentHalfFinalKernel(ScanParams p, SegGeometry g, SegArrays a, const uint32_t* trueStart,
+__global__ __launch_bounds__(1024) void SegmentHalfFinalKernel(ScanParams p, SegGeometry g, SegArrays a, const uint32_t* trueStart,
                                                               const uint32_t* strDone, uint32_t initialPerm, uint32_t* results)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, 0);
+	const LdsLayout L = MakeLayout(p.hot, 0, 256u, 0);   // dense rows at LDS address 0, 256 bytes apart (HotLookup)
 	unsigned int* blockSum = reinterpret_cast<unsigned int*>(lds + L.total);   // [8] counts of the block's first string
 	if (threadIdx.x < 8)
 		blockSum[threadIdx.x] = 0;
@@ -296,17 +296,48 @@ __global__ __launch_bounds__(256) void SegmentHalfFinalKernel(ScanParams p, SegG
 			st = SlowStep(p, lds, L, st, *q);
 			take(st);
 		}
-		for (; q + 16 <= qe; q += 16) {
-			u32x4 v = *reinterpret_cast<const u32x4*>(q);
+		// whole chunks: the dense-row fast path keeps the largest id the 16 steps went through; the hot set is ordered
+		// Final last and the trap id is the largest of all, so only a chunk that touched a Final state or left the
+		// dense rows is walked again, exactly, with the action (the scheme of ragged.hip, "scans with actions")
+		{
+			uint32_t hs = st < p.hot ? st : p.hot, cold = st;
+			u32x4 ahead = q + 16 <= qe ? *reinterpret_cast<const u32x4*>(q) : u32x4{0, 0, 0, 0};
+			for (; q + 16 <= qe; q += 16) {
+				const u32x4 v = ahead;
+				if (q + 32 <= qe)   // the next chunk is on its way while this one is walked
+					ahead = *reinterpret_cast<const u32x4*>(q + 16);
+				const uint32_t hs0 = hs;
+				uint32_t h = hs, m = 0;
+#pragma unroll
+				for (int w = 0; w < 4; ++w) {
+					const uint32_t x = v[w];
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
+					const uint32_t h1 = h;
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
+					m = max(m, max(h1, h));
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
+					const uint32_t h3 = h;
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
+					m = max(m, max(h3, h));
+				}
+				hs = h;
+				if (m >= p.hotFinalLo) {
+					uint32_t w = hs0 != p.hot ? hs0 : cold;
+					u32x4 u = v;
 #pragma unroll 1
-			for (int i = 0; i < 16; ++i) {
-				st = SlowStep(p, lds, L, st, v.x & 0xFF);
-				take(st);
-				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-				v.w >>= 8;
+					for (int i = 0; i < 16; ++i) {
+						w = SlowStep(p, lds, L, w, u.x & 0xFF);
+						take(w);
+						u.x = __builtin_amdgcn_alignbit(u.y, u.x, 8);
+						u.y = __builtin_amdgcn_alignbit(u.z, u.y, 8);
+						u.z = __builtin_amdgcn_alignbit(u.w, u.z, 8);
+						u.w >>= 8;
+					}
+					hs = w < p.hot ? w : p.hot;
+					cold = w;
+				}
 			}
+			st = hs != p.hot ? hs : cold;
 		}
 		for (; q < qe; ++q) {
 			st = SlowStep(p, lds, L, st, *q);
@@ -731,13 +762,14 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		PIRE_TRY(HipOk(hipMemsetAsync(halfFinalResults, 0, n * size_t(p.regexps) * 4, stream), "hipMemset"));
 		ScanParams hp = p;
 		hp.compact = 0;
-		const LdsLayout L = MakeLayout(hp.hot, 0, kRotPitch, 0);
+		const LdsLayout L = MakeLayout(hp.hot, 0, 256u, 0);
 		const uint32_t ldsBytes = L.total + 64;
 		PIRE_TRY(HipOk(hipFuncSetAttribute(reinterpret_cast<const void*>(SegmentHalfFinalKernel),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)), "hipFuncSetAttribute(LDS)"));
 		const uint32_t initialPerm = t->host.permOfOrig[t->host.initial];
-		hipLaunchKernelGGL(SegmentHalfFinalKernel, dim3(blocks), dim3(256), ldsBytes, stream, hp, g, a, c.trueStart, c.strDone,
-		                   initialPerm, halfFinalResults);
+		// 1024-thread blocks: the dense rows take 66 KB of LDS, so this is 16 waves per CU instead of 8
+		hipLaunchKernelGGL(SegmentHalfFinalKernel, dim3(unsigned((S + 1023) / 1024)), dim3(1024), ldsBytes, stream, hp, g, a,
+		                   c.trueStart, c.strDone, initialPerm, halfFinalResults);
 		mark("half-final counts");
 	}
 	// ---- finish
