@@ -73,3 +73,30 @@ def test_pigrep_hip_fails_loudly_without_gpu():
         pytest.skip("needs the built example and no GPU")
     rc, out, err = run("pigrep_hip", ["kernel"], ["DESIGN.md"])
     assert rc != 0 and out == b"" and b"pigrep_hip:" in err
+
+
+@pytest.mark.gpu
+def test_pigrep_hip_on_a_file_with_very_long_lines(tmp_path):
+    """Lines of a megabyte and more next to short ones: the batch goes through the segmented scan; same output."""
+    if not os.path.exists(os.path.join(BIN, "pigrep_hip")):
+        pytest.skip("examples/bin was not built (needs /root/reference at build time)")
+    import random
+
+    rnd = random.Random(7)
+    words = [b"alpha", b"beta", b"gamma delta", b"0123456789", b"   ", b"needle-42", b"x"]
+    lines = []
+    for k in range(6):
+        parts, size = [], 0
+        target = (1 << 20) + 1000 * k if k % 2 == 0 else rnd.randint(10, 300)
+        while size < target:
+            w = words[rnd.randrange(len(words) - 1)] if k != 4 else words[rnd.randrange(len(words))]
+            parts.append(w)
+            size += len(w)
+        lines.append(b" ".join(parts))
+    path = tmp_path / "long_lines.txt"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    for args in (["needle-[0-9]+"], ["-i", "GAMMA\\s+delta$"], ["^alpha"]):
+        want = run("pigrep_ref", args, [str(path)])
+        got = run("pigrep_hip", args, [str(path)])
+        assert got[0] == 0, got[2][-2000:]
+        assert got[1] == want[1]
