@@ -363,6 +363,46 @@ __global__ __launch_bounds__(1024) void SegmentHalfFinalKernel(ScanParams p, Seg
 		atomicAdd(&results[size_t(firstStr) * p.regexps + threadIdx.x], blockSum[threadIdx.x]);
 }
 
+// The same for a handful of strings without the 66 KB table fill: the end-of-string record straight from memory, the
+// counters straight to the caller's array (one atomic per wave and counter).
+__global__ __launch_bounds__(256) void SegmentFinishSmallKernel(ScanParams p, const uint32_t* endIdx)
+{
+	const uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	const bool active = s < p.n;
+	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+	u32x4 raw = {0, 0, 0, 0};
+	if (active)
+		raw = *reinterpret_cast<const u32x4*>(&recs[endIdx[s]]);
+	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
+	if (active) {
+		if (p.outIdx)
+			p.outIdx[s] = orig;
+		if (p.outFinal)
+			p.outFinal[s] = fl & kFinal;
+	}
+	if (!p.outCounts)
+		return;
+	const int lane = threadIdx.x & 63;
+	const unsigned long long finals = __ballot(active && (fl & kFinal));
+	const unsigned long long actives = __ballot(active);
+	if (lane == 0 && actives) {
+		atomicAdd(&p.outCounts[0], (unsigned long long)__popcll(finals));
+		atomicAdd(&p.outCounts[1], (unsigned long long)__popcll(actives));
+	}
+	if (p.acceptMaskPerm) {
+		const uint64_t m = active ? ((uint64_t(raw.w) << 32) | raw.z) : 0;
+		if (__any(m != 0))
+			for (uint32_t r = 0; r < p.regexps; ++r) {
+				const unsigned long long b = __ballot((m >> r) & 1);
+				if (lane == 0 && b)
+					atomicAdd(&p.outCounts[2 + r], (unsigned long long)__popcll(b));
+			}
+	} else if (active) {
+		for (uint64_t k = p.acceptOffPerm[endPerm]; k < p.acceptOffPerm[endPerm + 1]; ++k)
+			atomicAdd(&p.outCounts[2 + p.acceptIds[k]], 1ull);
+	}
+}
+
 uint64_t EnvBytes(const char* name, uint64_t fallback)
 {
 	const char* v = getenv(name);
@@ -773,13 +813,15 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		mark("half-final counts");
 	}
 	// ---- finish
-	{
+	if (n <= 4096) {
+		hipLaunchKernelGGL(SegmentFinishSmallKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, p, c.finalState);
+	} else {
 		ScanParams f = p;
 		f.compact = 0;
 		const LdsLayout L = MakeLayout(f.hot, f.outCounts ? f.regexps : 0, kRotPitch, 0);
 		PIRE_TRY(HipOk(hipFuncSetAttribute(reinterpret_cast<const void*>(SegmentFinishKernel),
 		                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total)), "hipFuncSetAttribute(LDS)"));
-		const unsigned threads = n >= 4096 ? 1024 : 256;
+		const unsigned threads = 1024;
 		const uint64_t tasks = (n + 63) / 64;
 		const unsigned cblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((tasks * 64 + threads - 1) / threads, uint64_t(cus))));
 		hipLaunchKernelGGL(SegmentFinishKernel, dim3(cblocks), dim3(threads), L.total, stream, f, c.finalState);
