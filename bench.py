@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log2-strings", type=int, default=20, help="strings per GPU = 2^this (headline: 20)")
+    ap.add_argument("--strings", type=int, default=0, help="strings per GPU, any number (overrides --log2-strings)")
     ap.add_argument("--len", type=int, default=4096, help="bytes per string (headline: 4096)")
     ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
@@ -212,7 +213,7 @@ def main():
     table = pire_amd.Table(blob)
     table.upload()
     plants = H.plants_for(big)
-    n = 1 << args.log2_strings
+    n = args.strings or (1 << args.log2_strings)
     length = args.len
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -275,7 +276,7 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = pd.max_over_ranks(elapsed, dev)
     kernel_ms = [a.elapsed_time(b) for a, b in events]
-    kernel_name = pb.last_kernel()
+    kernel_name = pb.last_kernel_symbol()   # the instantiation the library actually launched
 
     total_counts = count_bufs[(step_no[0] - 1) & 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
     gpu_idx = out_idx.cpu().numpy().astype(np.uint32)
@@ -312,7 +313,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {
-                "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), 2^{args.log2_strings} x {length} B "
+                "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), "
+                            f"{'2^%d' % args.log2_strings if not args.strings else n} x {length} B "
                             f"strings per GPU, Begin().Run().End() per string, match-count reduce",
                 "patterns": big["patterns"],
                 "table": {"states": info.states, "letters": info.letters, "regexps": info.regexps,
@@ -326,7 +328,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                                   if traffic else None,
-                "kernel": f"pirehip::ScanTiledKernel<16,2,true,5> ({kernel_name})", "kernel_avg_ms": round(avg_ms, 4),
+                "kernel": kernel_name, "kernel_avg_ms": round(avg_ms, 4),
                 "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),

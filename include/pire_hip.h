@@ -233,9 +233,12 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
-/* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
+/* Name of the kernel the last run on this thread dispatched to ("tiled", "tiled2", "ragged", "generic", "ragged_prefix",
  * "prefix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
+/* The instantiation behind it where there are several (e.g. "pirehip::ScanTiled2Kernel<12,nt,3>" for "tiled2",
+ * the two-chains-per-lane form of the tiled kernel); otherwise the same string as pire_hip_last_kernel(). */
+const char* pire_hip_last_kernel_symbol(void);
 
 /* Milliseconds the most recent kernel launched by this thread took, measured with hipEvents on the
  * launch stream when timing was enabled with pire_hip_set_timing(1).  Synchronises the stream. */

@@ -117,6 +117,7 @@ ABI = [
     ("pire_hip_capture_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
+    ("pire_hip_last_kernel_symbol", C.c_char_p, []),
     ("pire_hip_set_timing", C.c_int, [C.c_int]),
     ("pire_hip_last_kernel_ms", C.c_float, []),
     ("pire_hip_last_error", C.c_char_p, []),
@@ -537,6 +538,10 @@ class BatchRunner:
 
 def last_kernel() -> str:
     return lib().pire_hip_last_kernel().decode()
+
+
+def last_kernel_symbol() -> str:
+    return lib().pire_hip_last_kernel_symbol().decode()
 
 
 def set_timing(enabled: bool):

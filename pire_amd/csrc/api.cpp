@@ -21,6 +21,7 @@ namespace pirehip {
 namespace {
 thread_local std::string g_error;
 thread_local const char* g_lastKernel = "none";
+thread_local const char* g_lastSymbol = nullptr;
 thread_local bool g_timing = false;
 thread_local float g_lastMs = -1.0f;
 }  // namespace
@@ -39,11 +40,12 @@ namespace {
 
 int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 {
-	if (int rc = UploadTable(t))
+	DeviceTable d;   // a copy of the current device's image (pointers), taken under the table's lock
+	if (int rc = UploadTable(t, &d))
 		return rc;
 	const HostTable& h = t->host;
-	const DeviceTable& d = t->dev;
 	memset(p, 0, sizeof(*p));
+	p->workBase = d.workCounter;
 	p->hotRows = d.hotRows;
 	p->hotFlags = d.hotFlags;
 	p->cls = d.cls;
@@ -80,13 +82,17 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 }
 
 }  // namespace
-void NoteKernel(const char* name) { g_lastKernel = name; }
+void NoteKernel(const char* name, const char* symbol)
+{
+	g_lastKernel = name;
+	g_lastSymbol = symbol;
+}
 namespace {
 
 // One slot of the table's ring of ragged work counters per launch (launches of one table may overlap on streams).
-unsigned long long* NextWorkSlot(pire_hip_table* t)
+unsigned long long* NextWorkSlot(pire_hip_table* t, const ScanParams& p)
 {
-	return t->dev.workCounter + t->workSlot.fetch_add(1) % kWorkSlots;
+	return p.workBase + t->workSlot.fetch_add(1) % kWorkSlots;
 }
 
 int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,
@@ -102,7 +108,7 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 			return HipFail(hipGetLastError(), "hipEventCreate");
 		(void)hipEventRecord(ev0, stream);
 	}
-	g_lastKernel = tiled ? "tiled" : ragged ? "ragged" : "generic";
+	NoteKernel(tiled ? "tiled" : ragged ? "ragged" : "generic");
 	int rc = tiled ? LaunchTiled(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
@@ -164,7 +170,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 				if (!(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes - offsets[0]))
 					rc = RunSegmented(t, p, offsets, stream);
 				else
-					rc = Dispatch(p, stream, NextWorkSlot(t), textBytes);
+					rc = Dispatch(p, stream, NextWorkSlot(t, p), textBytes);
 			}
 			(void)hipFreeAsync(d, stream);
 			if (!rc) {
@@ -182,7 +188,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		// device offsets the host does not know the lengths, so only fixed-length records qualify here.
 		if (!offsets && !(flags & PIRE_HIP_RUN_GENERIC) && n && SegmentedEligible(n, n * len))
 			return RunSegmented(t, p, nullptr, stream);
-		return Dispatch(p, stream, NextWorkSlot(t), offsets ? ~0ull : 0);
+		return Dispatch(p, stream, NextWorkSlot(t, p), offsets ? ~0ull : 0);
 	}
 
 	// Host-pointer mode: stage through HBM.  (PCIe-inclusive; the benchmark never times this mode.)
@@ -240,7 +246,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	if (!(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes)) {
 		if (int rc = RunSegmented(t, p, offsets, stream))
 			return rc;
-	} else if (int rc = Dispatch(p, stream, NextWorkSlot(t), textBytes)) {
+	} else if (int rc = Dispatch(p, stream, NextWorkSlot(t, p), textBytes)) {
 		return rc;
 	}
 	hipError_t e = hipSuccess;
@@ -266,6 +272,7 @@ extern "C" {
 
 const char* pire_hip_last_error(void) { return g_error.c_str(); }
 const char* pire_hip_last_kernel(void) { return g_lastKernel; }
+const char* pire_hip_last_kernel_symbol(void) { return g_lastSymbol ? g_lastSymbol : g_lastKernel; }
 
 int pire_hip_set_timing(int enabled)
 {
@@ -381,7 +388,8 @@ int pire_hip_table_upload(pire_hip_table* t)
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
 	}
-	return UploadTable(t);
+	DeviceTable image;
+	return UploadTable(t, &image);
 }
 
 int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows)
@@ -397,7 +405,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)
 		return;
-	FreeDeviceTable(&t->dev);
+	FreeAllDeviceTables(t);
 	delete t;
 }
 
@@ -423,7 +431,9 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 	out->compact_states = h.compact;
 	out->scanner_type = h.scannerType;
 	out->reserved = 0;
-	out->device_bytes = t->dev.bytes;
+	out->device_bytes = 0;   // all images (one per device the table has run on)
+	for (int k = 0; k < kMaxDevices; ++k)
+		out->device_bytes += t->devs[k].device >= 0 ? t->devs[k].bytes : 0;
 	out->adaptations = h.adaptations;
 	out->last_trap_samples = h.lastTrapSamples;
 	out->ref_buf_size = h.refBufSize;
@@ -556,9 +566,10 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	if (n == 0)
 		return PIRE_HIP_OK;
 	const uint32_t R = t->host.regexps;
-	if (int rc = EnsureActDist(t))
+	const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
+	if (int rc = EnsureActDist(t, &distFinal, &distFlagged))
 		return rc;
-	p.actDist = t->dev.distFinalPerm;
+	p.actDist = distFinal;
 	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
 	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
 	// few long strings: the segmented scan resolves every segment's true start state, then the segments are counted
@@ -587,7 +598,7 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 		p.outIdx = out_state_idx;
 		p.outFinal = out_final;
 		if (!(flags & PIRE_HIP_RUN_HOST_OFFSETS))
-			return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
+			return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t, p));
 		// resident text, offsets known to the host (see pire_hip_run)
 		for (uint64_t i = 0; i < n; ++i)
 			if (offsets[i] > offsets[i + 1]) {
@@ -605,7 +616,7 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 		if (!rc)
 			rc = segmented(offsets, out_results, &counted);
 		if (!rc && !counted)
-			rc = LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t));
+			rc = LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t, p));
 		(void)hipFreeAsync(d, stream);
 		if (!rc) {
 			e = hipStreamSynchronize(stream);   // the caller's offsets array was the source of an async copy
@@ -644,7 +655,7 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	if (int rc = segmented(offsets, static_cast<uint32_t*>(dRes), &counted))
 		return rc;
 	if (!counted)
-		if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t)))
+		if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t, p)))
 			return rc;
 	hipError_t e = hipSuccess;
 	if (out_state_idx)
@@ -674,14 +685,15 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	p.n = n;
 	if (n == 0)
 		return PIRE_HIP_OK;
-	if (int rc = EnsureActDist(t))
+	const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
+	if (int rc = EnsureActDist(t, &distFinal, &distFlagged))
 		return rc;
-	p.actDist = t->dev.distFlaggedPerm;
+	p.actDist = distFlagged;
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
 		return LaunchPrefix(p, longest != 0, through_end != 0, reinterpret_cast<long long*>(out_len), stream,
-		                    (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t));
+		                    (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t, p));
 	}
 	Staging st;
 	for (uint64_t i = 0; i < n; ++i)
@@ -704,7 +716,7 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	if (int rc = st.Alloc(&dOut, size_t(n) * 8))
 		return rc;
 	if (int rc = LaunchPrefix(p, longest != 0, through_end != 0, static_cast<long long*>(dOut), stream,
-	                          (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t)))
+	                          (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t, p)))
 		return rc;
 	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess)

@@ -50,7 +50,8 @@ struct CountingDevice {
 
 struct pire_hip_counting_table {
 	pirehip::CountingHost host;
-	pirehip::CountingDevice dev;
+	pirehip::CountingDevice devs[pirehip::kMaxDevices];   // one image per HIP device, as in pire_hip_table
+	std::mutex uploadMutex;
 };
 
 namespace pirehip {
@@ -474,15 +475,22 @@ void FreeCountingDevice(CountingDevice* d)
 	*d = CountingDevice();
 }
 
-int UploadCounting(pire_hip_counting_table* t)
+// Image of the current device (built on first use), copied out under the table's lock.
+int UploadCounting(pire_hip_counting_table* t, CountingDevice* image)
 {
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
 	int dev = -1;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess)
 		return HipFail(e, "hipGetDevice");
-	if (t->dev.device == dev)
+	if (dev < 0 || dev >= kMaxDevices) {
+		SetError("HIP device ordinal out of range");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	if (t->devs[dev].device == dev) {
+		*image = t->devs[dev];
 		return PIRE_HIP_OK;
-	FreeCountingDevice(&t->dev);
+	}
 	CountingDevice d;
 	e = hipMalloc(reinterpret_cast<void**>(&d.letterOf), 272);
 	if (e == hipSuccess)
@@ -506,7 +514,8 @@ int UploadCounting(pire_hip_counting_table* t)
 		FreeCountingDevice(&d);
 		return HipFail(e, "uploading the counting table");
 	}
-	t->dev = d;
+	t->devs[dev] = d;
+	*image = d;
 	return PIRE_HIP_OK;
 }
 
@@ -598,7 +607,15 @@ void pire_hip_counting_table_destroy(pire_hip_counting_table* t)
 {
 	if (!t)
 		return;
-	FreeCountingDevice(&t->dev);
+	int cur = -1;
+	(void)hipGetDevice(&cur);
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->devs[k].device >= 0) {
+			(void)hipSetDevice(k);
+			FreeCountingDevice(&t->devs[k]);
+		}
+	if (cur >= 0)
+		(void)hipSetDevice(cur);
 	delete t;
 }
 
@@ -637,11 +654,12 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 	if (n == 0)
 		return PIRE_HIP_OK;
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
-	if (int rc = UploadCounting(t))
+	CountingDevice image;
+	if (int rc = UploadCounting(t, &image))
 		return rc;
 	CountingParams p;
 	memset(&p, 0, sizeof(p));
-	p.actions = t->dev.actions;
+	p.actions = image.actions;
 	// more than 16 regexps: per-string `current` rows in a temporary device array (freed after the stream is drained)
 	void* scratch = nullptr;
 	struct ScratchGuard {
@@ -661,8 +679,8 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 			return HipFail(se, "hipMalloc(counting scratch)");
 		p.scratch = static_cast<uint32_t*>(scratch);
 	}
-	p.letterOf = t->dev.letterOf;
-	p.trans = t->dev.trans;
+	p.letterOf = image.letterOf;
+	p.trans = image.trans;
 	p.states = t->host.states;
 	p.letters = t->host.letters;
 	p.regexps = t->host.regexps;
@@ -728,13 +746,14 @@ int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uin
 	if (n == 0)
 		return PIRE_HIP_OK;
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
-	if (int rc = UploadCounting(t))
+	CountingDevice image;
+	if (int rc = UploadCounting(t, &image))
 		return rc;
 	CountingParams p;
 	memset(&p, 0, sizeof(p));
-	p.letterOf = t->dev.letterOf;
-	p.trans = t->dev.trans;
-	p.tags = t->dev.tags;
+	p.letterOf = image.letterOf;
+	p.trans = image.trans;
+	p.tags = image.tags;
 	p.states = t->host.states;
 	p.letters = t->host.letters;
 	p.regexps = t->host.regexps;

@@ -36,13 +36,21 @@ namespace pirehip {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr uint32_t kDebugNoRefill = 1u << 30;   // internal, never set through the C ABI
-constexpr uint32_t kDebugNoStep = 1u << 29;     // internal, never set through the C ABI
+// Timing-experiment knobs (walk stale registers, skip the walk, skip the end-of-string work ...): they make a kernel
+// return WRONG results, so they exist only in a -DPIRE_HIP_TUNING build (tools/ab).  In the product library the masks
+// are 0 and every test of them folds away.
+#ifdef PIRE_HIP_TUNING
+constexpr uint32_t kDebugNoRefill = 1u << 30;
+constexpr uint32_t kDebugNoStep = 1u << 29;
 constexpr uint32_t kDebugNoColdCount = 1u << 28;
 constexpr uint32_t kDebugNoHist = 1u << 27;
-constexpr uint32_t kDebugNoPartial = 1u << 26;   // ragged kernel timing experiments only (results are wrong)
+constexpr uint32_t kDebugNoPartial = 1u << 26;
 constexpr uint32_t kDebugNoFinish = 1u << 25;
 constexpr uint32_t kDebugNoTrap = 1u << 24;
+#else
+constexpr uint32_t kDebugNoRefill = 0, kDebugNoStep = 0, kDebugNoColdCount = 0, kDebugNoHist = 0, kDebugNoPartial = 0,
+                   kDebugNoFinish = 0, kDebugNoTrap = 0;
+#endif
 constexpr uint32_t kPermIds = 1u << 23;   // internal (segmented.hip): initIdx holds, outIdx receives, DEVICE state ids
 
 // Block-wide copy of `count16` 16-byte units from global memory to LDS with up to BATCH loads per thread in flight
@@ -197,19 +205,25 @@ __device__ __forceinline__ void Finish(const ScanParams& p, uint8_t* lds, const 
 	}
 }
 
-__device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+// `tid`: the caller's thread index (a kernel that is short of registers recomputes it instead of keeping it alive).
+__device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint32_t tid)
 {
 	__syncthreads();
 	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + L.histOff);
-	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+	for (uint32_t i = tid; i < 256; i += blockDim.x)
 		if (hist[i])
 			atomicAdd(&p.visitHot[i], hist[i]);
 	if (!p.outCounts)
 		return;
 	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + L.countsOff);
-	for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
+	for (uint32_t i = tid; i < p.regexps + 2; i += blockDim.x)
 		if (cnt[i])
 			atomicAdd(&p.outCounts[i], (unsigned long long)cnt[i]);
+}
+
+__device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsLayout& L)
+{
+	FlushCounts(p, lds, L, threadIdx.x);
 }
 
 
@@ -385,7 +399,7 @@ inline int DeviceCUs(int* cus)
 }
 
 template <class K>
-int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hipStream_t stream)
+int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hipStream_t stream, int tasksPerBlock = 0)
 {
 	int cus = 0;
 	int rc = DeviceCUs(&cus);
@@ -399,12 +413,14 @@ int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hi
 	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, ldsBytes);
 	if (e != hipSuccess)
 		return HipFail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+#ifdef PIRE_HIP_TUNING
 	if (getenv("PIRE_HIP_DEBUG_LAUNCH"))
 		fprintf(stderr, "pire_hip: threads %d lds %u -> %d blocks/CU\n", threads, ldsBytes, perCu);
+#endif
 	if (perCu < 1)
 		perCu = 1;
 	const uint64_t ntasks = (p.n + 63) / 64;
-	const uint64_t wavesPerBlock = uint64_t(threads) / 64;
+	const uint64_t wavesPerBlock = tasksPerBlock ? uint64_t(tasksPerBlock) : uint64_t(threads) / 64;
 	uint64_t blocks = (ntasks + wavesPerBlock - 1) / wavesPerBlock;
 	blocks = std::min<uint64_t>(blocks, uint64_t(cus) * perCu);
 	if (blocks == 0)

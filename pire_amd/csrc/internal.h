@@ -162,9 +162,14 @@ struct DeviceTable {
 
 namespace pirehip { constexpr uint32_t kWorkSlots = 1024; }
 
+namespace pirehip { constexpr int kMaxDevices = 64; }
+
 struct pire_hip_table {
 	pirehip::HostTable host;
-	pirehip::DeviceTable dev;
+	// One image per HIP device (devs[d].device == d once uploaded), so that one handle serves every GPU of the node,
+	// from one host thread or from several.  Guarded by uploadMutex; the run entry points COPY the image's pointers
+	// while holding it (UploadTable) and never look at devs[] afterwards.
+	pirehip::DeviceTable devs[pirehip::kMaxDevices];
 	std::mutex uploadMutex;
 	std::atomic<uint32_t> workSlot{0};   // round-robin over dev.workCounter[kWorkSlots]
 	std::mutex segMutex;
@@ -212,6 +217,7 @@ struct ScanParams {
 	uint32_t* outIdx;        // nullable
 	uint8_t* outFinal;       // nullable
 	unsigned long long* outCounts;  // nullable
+	unsigned long long* workBase;   // host side only: the ring of ragged work counters of the image in use
 };
 
 __host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)
@@ -259,9 +265,11 @@ struct Staging {
 
 // table.cpp
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
-int UploadTable(pire_hip_table* t);
+int UploadTable(pire_hip_table* t, DeviceTable* image);   // image of the CURRENT device (built on first use), copied out
 void EnsureRanked(pire_hip_table* t);
-int EnsureActDist(pire_hip_table* t);   // after UploadTable: dev.distFinalPerm / distFlaggedPerm are there
+// after UploadTable, current device: the per-state distance tables (built on first use)
+int EnsureActDist(pire_hip_table* t, const uint8_t** distFinalPerm, const uint8_t** distFlaggedPerm);
+void FreeAllDeviceTables(pire_hip_table* t);
 struct GlueProduct {
 	std::vector<std::pair<uint32_t, uint32_t>> states;   // numbered product states (lhs state, rhs state)
 	std::vector<uint32_t> next;                          // [states * letters]
@@ -287,7 +295,7 @@ bool SegmentedEligible(uint64_t n, uint64_t totalBytes);
 int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream,
                  uint32_t* halfFinalResults = nullptr,    // non-null: also HalfFinalScanner counts, [n][regexps] ...
                  bool* halfFinalIncomplete = nullptr);    // ... unless some string ended in the plain walk (then true)
-void NoteKernel(const char* name);   // what pire_hip_last_kernel() reports (thread local)
+void NoteKernel(const char* name, const char* symbol = nullptr);   // what pire_hip_last_kernel[_symbol]() report (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);
 int LaunchRaggedPrefix(const ScanParams& p, unsigned long long* workCounter, bool longest, bool throughEnd,

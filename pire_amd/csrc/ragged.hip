@@ -806,11 +806,13 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 	grab.block = uint32_t(blockGrab);
 	grab.wave = uint32_t(std::min<uint64_t>(256, std::max<uint64_t>(64, blockGrab / (2 * wavesPerBlock) / 64 * 64)));
 	ScanParams q = p;
+#ifdef PIRE_HIP_TUNING
 	if (const char* dbg = getenv("PIRE_HIP_DEBUG_RAGGED")) {   // timing experiments: 1 no partial passes, 2 no finish, 4 no traps
 		const int m = atoi(dbg);
 		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
 		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
 	}
+#endif
 	hipLaunchKernelGGL((ScanRaggedKernel<Act, EXT>), dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
 	                   q, workCounter, grab, act);
 	e = hipGetLastError();

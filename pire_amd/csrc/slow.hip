@@ -47,7 +47,8 @@ constexpr uint32_t kSlowMulti = 0xFFFFFFFEu;   // more than two targets: the ste
 
 struct pire_hip_slow_table {
 	pirehip::SlowHost host;
-	pirehip::SlowDevice dev;
+	pirehip::SlowDevice devs[pirehip::kMaxDevices];   // one image per HIP device, as in pire_hip_table
+	std::mutex uploadMutex;
 };
 
 namespace pirehip {
@@ -445,15 +446,22 @@ int DeviceK(uint32_t words)
 	return words <= 1 ? 1 : words <= 2 ? 2 : words <= 4 ? 4 : words <= 8 ? 8 : 0;
 }
 
-int UploadSlow(pire_hip_slow_table* t)
+// Image of the current device (built on first use), copied out under the table's lock.
+int UploadSlow(pire_hip_slow_table* t, SlowDevice* image)
 {
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
 	int dev = -1;
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess)
 		return HipFail(e, "hipGetDevice");
-	if (t->dev.device == dev)
+	if (dev < 0 || dev >= kMaxDevices) {
+		SetError("HIP device ordinal out of range");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	if (t->devs[dev].device == dev) {
+		*image = t->devs[dev];
 		return PIRE_HIP_OK;
-	FreeSlowDevice(&t->dev);
+	}
 	const SlowHost& h = t->host;
 	const int K = DeviceK(h.words);
 	if (K == 0) {
@@ -475,7 +483,8 @@ int UploadSlow(pire_hip_slow_table* t)
 		return rc;
 	}
 	d.device = dev;
-	t->dev = d;
+	t->devs[dev] = d;
+	*image = d;
 	return PIRE_HIP_OK;
 }
 
@@ -516,16 +525,17 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
 	}
-	if (int rc = UploadSlow(t))
+	SlowDevice image;
+	if (int rc = UploadSlow(t, &image))
 		return rc;
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	const SlowHost& h = t->host;
 	SlowParams p;
 	memset(&p, 0, sizeof(p));
-	p.letterOf = t->dev.letterOf;
-	p.masks = t->dev.masks;
-	p.single = t->dev.single;
-	p.finals = t->dev.finals;
+	p.letterOf = image.letterOf;
+	p.masks = image.masks;
+	p.single = image.single;
+	p.finals = image.finals;
 	p.states = h.states;
 	p.letters = h.letters;
 	p.start = h.start;
@@ -633,7 +643,15 @@ void pire_hip_slow_table_destroy(pire_hip_slow_table* t)
 {
 	if (!t)
 		return;
-	FreeSlowDevice(&t->dev);
+	int cur = -1;
+	(void)hipGetDevice(&cur);
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->devs[k].device >= 0) {
+			(void)hipSetDevice(k);
+			FreeSlowDevice(&t->devs[k]);
+		}
+	if (cur >= 0)
+		(void)hipSetDevice(cur);
 	delete t;
 }
 

@@ -469,7 +469,20 @@ void FreeDeviceTable(DeviceTable* d)
 	*d = DeviceTable();
 }
 
-int UploadTable(pire_hip_table* t)
+void FreeAllDeviceTables(pire_hip_table* t)
+{
+	int cur = -1;
+	(void)hipGetDevice(&cur);
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->devs[k].device >= 0) {
+			(void)hipSetDevice(k);
+			FreeDeviceTable(&t->devs[k]);
+		}
+	if (cur >= 0)
+		(void)hipSetDevice(cur);
+}
+
+int UploadTable(pire_hip_table* t, DeviceTable* image)
 {
 	EnsureRanked(t);
 	std::lock_guard<std::mutex> lock(t->uploadMutex);
@@ -477,9 +490,14 @@ int UploadTable(pire_hip_table* t)
 	hipError_t e = hipGetDevice(&dev);
 	if (e != hipSuccess)
 		return HipFail(e, "hipGetDevice");
-	if (t->dev.device == dev)
+	if (dev < 0 || dev >= kMaxDevices) {
+		SetError("HIP device ordinal out of range");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	if (t->devs[dev].device == dev) {
+		*image = t->devs[dev];
 		return PIRE_HIP_OK;
-	FreeDeviceTable(&t->dev);
+	}
 
 	const HostTable& h = t->host;
 	const uint32_t N = h.states, C = h.letters;
@@ -585,7 +603,8 @@ int UploadTable(pire_hip_table* t)
 		return rc;
 	}
 	d.device = dev;
-	t->dev = d;
+	t->devs[dev] = d;
+	*image = d;
 	return PIRE_HIP_OK;
 }
 
@@ -772,30 +791,42 @@ static std::vector<uint8_t> DistanceTo(const HostTable& h, uint8_t flagMask)
 	return dist;
 }
 
-int EnsureActDist(pire_hip_table* t)
+int EnsureActDist(pire_hip_table* t, const uint8_t** distFinalPerm, const uint8_t** distFlaggedPerm)
 {
 	std::lock_guard<std::mutex> lock(t->uploadMutex);
 	HostTable& h = t->host;
-	DeviceTable& d = t->dev;
-	if (d.device < 0) {
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	if (dev < 0 || dev >= kMaxDevices || t->devs[dev].device != dev) {
 		SetError("EnsureActDist before UploadTable");
 		return PIRE_HIP_EINVAL;
 	}
-	if (d.distFinalPerm && d.distFlaggedPerm)
-		return PIRE_HIP_OK;
+	DeviceTable& d = t->devs[dev];
 	if (h.distFinal.empty()) {
 		h.distFinal = DistanceTo(h, kFinal);
 		h.distFlagged = DistanceTo(h, kFinal | kDead);
 	}
 	const uint32_t N = h.states;
-	std::vector<uint8_t> a(N), b(N);
-	for (uint32_t pid = 0; pid < N; ++pid) {
-		a[pid] = h.distFinal[h.origOfPerm[pid]];
-		b[pid] = h.distFlagged[h.origOfPerm[pid]];
+	// the two arrays independently: a failed second upload must not leak or re-upload the first
+	if (!d.distFinalPerm) {
+		std::vector<uint8_t> a(N);
+		for (uint32_t pid = 0; pid < N; ++pid)
+			a[pid] = h.distFinal[h.origOfPerm[pid]];
+		if (int rc = Put(&d.distFinalPerm, a, &d.bytes))
+			return rc;
 	}
-	if (int rc = Put(&d.distFinalPerm, a, &d.bytes))
-		return rc;
-	return Put(&d.distFlaggedPerm, b, &d.bytes);
+	if (!d.distFlaggedPerm) {
+		std::vector<uint8_t> b(N);
+		for (uint32_t pid = 0; pid < N; ++pid)
+			b[pid] = h.distFlagged[h.origOfPerm[pid]];
+		if (int rc = Put(&d.distFlaggedPerm, b, &d.bytes))
+			return rc;
+	}
+	*distFinalPerm = d.distFinalPerm;
+	*distFlaggedPerm = d.distFlaggedPerm;
+	return PIRE_HIP_OK;
 }
 
 void EnsureRanked(pire_hip_table* t)
@@ -811,19 +842,38 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 {
 	if (changedRows)
 		*changedRows = 0;
-	if (t->dev.device < 0)
-		return PIRE_HIP_OK;   // never ran: nothing observed
-	hipError_t e = hipDeviceSynchronize();
-	if (e != hipSuccess)
-		return HipFail(e, "hipDeviceSynchronize");
 	HostTable& h = t->host;
 	const uint32_t N = h.states, H = h.hot;
-	std::vector<uint32_t> hot(256), cold(N);
-	e = hipMemcpy(hot.data(), t->dev.visitHot, 256 * 4, hipMemcpyDeviceToHost);
-	if (e == hipSuccess)
-		e = hipMemcpy(cold.data(), t->dev.visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
-	if (e != hipSuccess)
-		return HipFail(e, "hipMemcpy(visit counters)");
+	// what every device that ever ran this table saw, summed
+	std::vector<uint64_t> hot(256, 0), cold(N, 0);
+	{
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		int cur = -1;
+		hipError_t e = hipGetDevice(&cur);
+		if (e != hipSuccess)
+			return HipFail(e, "hipGetDevice");
+		bool any = false;
+		std::vector<uint32_t> bufHot(256), bufCold(N);
+		for (int k = 0; k < kMaxDevices; ++k) {
+			if (t->devs[k].device < 0)
+				continue;
+			any = true;
+			if ((e = hipSetDevice(k)) == hipSuccess && (e = hipDeviceSynchronize()) == hipSuccess &&
+			    (e = hipMemcpy(bufHot.data(), t->devs[k].visitHot, 256 * 4, hipMemcpyDeviceToHost)) == hipSuccess)
+				e = hipMemcpy(bufCold.data(), t->devs[k].visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
+			if (e != hipSuccess) {
+				(void)hipSetDevice(cur);
+				return HipFail(e, "visit counters");
+			}
+			for (uint32_t i = 0; i < 256; ++i)
+				hot[i] += bufHot[i];
+			for (uint32_t i = 0; i < N; ++i)
+				cold[i] += bufCold[i];
+		}
+		(void)hipSetDevice(cur);
+		if (!any)
+			return PIRE_HIP_OK;   // never ran: nothing observed
+	}
 	// hot ids are sampled once per wave per 128-byte tile (1 of 64*128 lane-steps), cold ids once per trapped
 	// 16-byte chunk for one rotating lane of 64 (1 of 64*16 lane-steps): bring both to "lane-steps".
 	std::vector<double> score(N);
@@ -841,7 +891,13 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());
 	if (coldSamples == 0) {
-		(void)hipMemset(t->dev.visitHot, 0, 256 * 4);
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		int cur = -1;
+		(void)hipGetDevice(&cur);
+		for (int k = 0; k < kMaxDevices; ++k)
+			if (t->devs[k].device >= 0 && hipSetDevice(k) == hipSuccess)
+				(void)hipMemset(t->devs[k].visitHot, 0, 256 * 4);
+		(void)hipSetDevice(cur);
 		return PIRE_HIP_OK;   // nothing trapped: the current rows already cover the traffic
 	}
 	PermuteByScore(h, score);
@@ -852,8 +908,13 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 	if (changedRows)
 		*changedRows = uint32_t(diff.size());
 	h.adaptations++;
-	FreeDeviceTable(&t->dev);
-	return UploadTable(t);
+	// every image holds the old numbering: drop them all (synchronised above), each device re-uploads on its next run
+	{
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		FreeAllDeviceTables(t);
+	}
+	DeviceTable d;
+	return UploadTable(t, &d);
 }
 
 }  // namespace pirehip
