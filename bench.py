@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment launches the N ranks itself (it re-executes
+itself under torch.distributed.run on 127.0.0.1); under an external launcher it is one of the ranks.
+
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 8 regexps glued with
 Scanner::Glue ("set_a", patterns of the reference's own tools/bench/run-bench), 2^20 strings x 4 KiB per GPU,
 synthetic corpus generated on the device (oracle/corpus.h definition, planted witnesses), Begin().Run().End()
@@ -13,11 +16,19 @@ Inputs are resident in HBM when the timed region starts.  Multi-GPU: one process
 by string index (rank r owns global strings [r*n, (r+1)*n)), no data-path collective; the only exchange is the
 all-reduce (RCCL) of the uint64[regexps+2] match counters per step.  Weak scaling.
 
+Other workloads (informational lines of the same shape): `--set c2_single|set_b|set_d` (BASELINE configs 2 / 5a),
+`--set slow_x40_utf8` (config 5b, SlowScanner), `--corpus cxx` (C++ source text instead of the synthetic corpus,
+the kind of file the reference's tools/bench/run-bench scans; `--one-string` scans it as ONE string as the
+reference's bench does, through the segmented scan).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,7 +54,12 @@ def parse():
     ap.add_argument("--log2-strings", type=int, default=20, help="strings per GPU = 2^this (headline: 20)")
     ap.add_argument("--strings", type=int, default=0, help="strings per GPU, any number (overrides --log2-strings)")
     ap.add_argument("--len", type=int, default=4096, help="bytes per string (headline: 4096)")
+    ap.add_argument("--stride", type=int, default=0, help="bytes between strings in memory (default: --len, contiguous)")
     ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")
+    ap.add_argument("--corpus", default="synthetic", choices=["synthetic", "cxx"],
+                    help="cxx: this repository's C++/HIP sources repeated to the batch size (the reference's "
+                         "run-bench repeats its own C++ file) instead of the synthetic corpus")
+    ap.add_argument("--one-string", action="store_true", help="with --corpus cxx: the whole text as ONE string")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-adapt", action="store_true", help="do not call pire_hip_table_adapt() after the warm-up")
@@ -52,22 +68,46 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin):
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: run the N ranks under torch.distributed.run ourselves."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def cxx_corpus_bytes() -> np.ndarray:
+    """The C++ text the `--corpus cxx` workload repeats: every C++/HIP source of this repository, in a fixed order."""
+    files = sorted(glob.glob(os.path.join(ROOT, "pire_amd", "csrc", "*")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "pire_hip", "*")) +
+                   glob.glob(os.path.join(ROOT, "oracle", "*.c")) + glob.glob(os.path.join(ROOT, "tests", "cpp", "*.cpp")))
+    data = b"".join(open(f, "rb").read() for f in files if os.path.isfile(f))
+    assert len(data) > 100000, "source corpus not found"
+    return np.frombuffer(data, dtype=np.uint8)
+
+
+def cpu_baseline(blob, host_strings, length, gpu_idx, gpu_fin):
     """The reference's own Runner(sc).Begin().Run().End() (oracle/_ref, kind 'reference') -- or the C port
-    (kind 'port') if the prebuilt reference library is not on this box -- timed on this host's cores over the
-    first `sample` strings of rank 0's corpus; also the parity check of the GPU results on that sample."""
+    (kind 'port') if the prebuilt reference library is not on this box -- timed on this host's cores over
+    `host_strings` (the first strings of rank 0's batch, [k, length] u8); also the parity check of the GPU results
+    on that sample.  The only place of the benchmark that touches oracle/ (test infrastructure)."""
     from oracle import binding as ob
 
     cores = os.cpu_count() or 1
     threads = min(cores, 256)
-    t0 = time.time()
-    host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=threads)
-    gen_s = time.time() - t0
-    text = host.reshape(-1)
+    sample = host_strings.shape[0]
+    text = host_strings.reshape(-1)
     offs = np.arange(sample + 1, dtype=np.uint64) * length
     nbytes = sample * length
-    out = {"cores": threads, "host_cores": cores, "sample": f"first {sample} strings x {length} B of rank 0's corpus "
-           f"({nbytes / 2**20:.0f} MiB), Begin().Run().End() per string", "corpus_gen_s": round(gen_s, 3)}
+    out = {"cores": threads, "host_cores": cores, "sample": f"first {sample} strings x {length} B of rank 0's batch "
+           f"({nbytes / 2**20:.0f} MiB), Begin().Run().End() per string"}
     runs = {}
     if ob.ref_available():
         try:
@@ -119,15 +159,14 @@ def bench_slow(args):
 
     import pire_amd
     from pire_amd import binding as pb
-    from oracle import binding as ob
-    from tests import helpers as H
+    from pire_amd import workloads as W
 
-    case = [c for c in H.golden()["slow"] if c["name"] == args.set][0]
-    blob = H.load_blob(case["blob"])
+    case = W.slow_case(args.set)
+    blob = W.load_blob(case["blob"])
     table = pire_amd.SlowTable(blob)
     torch.cuda.set_device(0)
-    n, length = 1 << args.log2_strings, args.len
-    plants = ob.make_plants([(b"x" + b"y" * 40, True), (b"zx" + b"w" * 39, True)])   # one witness, one near miss
+    n, length = args.strings or (1 << args.log2_strings), args.len
+    plants = pb.make_plants([(b"x" + b"y" * 40, True), (b"zx" + b"w" * 39, True)])   # one witness, one near miss
     text = torch.empty((n, length), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     pire_amd.corpus_fill_device(text.data_ptr(), SEED, 0, n, length, length, plants, stream)
@@ -156,7 +195,7 @@ def bench_slow(args):
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"C5b: SlowScanner {case['pattern']!r} ({case['options'] or 'latin1'}), "
-                                  f"{case['geometry']['states']} NFA states, 2^{args.log2_strings} x {length} B strings",
+                                  f"{case['geometry']['states']} NFA states, {n} x {length} B strings",
                       "strings_per_gpu": n, "string_bytes": length},
            "roofline": {"bound": "hbm", "achieved": round(n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -164,10 +203,12 @@ def bench_slow(args):
                         "kernel": "pirehip::SlowScanKernel", "kernel_avg_ms": round(float(np.mean(ms)), 4)},
            "match_counts": {"final": int(cnt[0].item()), "strings": int(cnt[1].item())}}
     if not args.no_cpu:
-        sample = min(n, 1 << min(args.cpu_sample_log2, 12))
-        host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=8)
+        from oracle import binding as ob   # the cpu_baseline leg: the checker, never the thing measured
+
+        sample = min(n, 1 << min(args.cpu_sample_log2, 16))
+        host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=min(os.cpu_count() or 1, 64))
         offs = np.arange(sample + 1, dtype=np.uint64) * length
-        threads = min(os.cpu_count() or 1, 64)
+        threads = min(os.cpu_count() or 1, 256)
         if ob.ref_available():
             ref = ob.RefSlowScanner.load(blob)
             t0 = time.time()
@@ -188,6 +229,8 @@ def bench_slow(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     if args.set.startswith("slow_"):
         return bench_slow(args)
     import torch
@@ -196,35 +239,54 @@ def main():
     import pire_amd
     from pire_amd import binding as pb
     from pire_amd import distributed as pd
-    from tests import helpers as H
+    from pire_amd import workloads as W
 
     rank, local, world = pd.world_info()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
-    local_dev = local if args.backend == "nccl" else local % torch.cuda.device_count()
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this box has {ndev} "
+                         "(--backend gloo runs the ranks on the GPUs there are, for control-flow tests)")
+    local_dev = local % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
         pd.init(args.backend, dev)   # "nccl" is RCCL on ROCm
 
-    big = [b for b in H.big_sets() if b["name"] == args.set][0]
-    blob = H.load_blob(big["blob"])
+    big = W.pattern_set(args.set)
+    blob = W.load_blob(big["blob"])
     table = pire_amd.Table(blob)
     table.upload()
-    plants = H.plants_for(big)
+    plants = W.plants_for(big)
     n = args.strings or (1 << args.log2_strings)
     length = args.len
+    stride = args.stride or length
+    assert stride >= length and (args.corpus == "synthetic" or stride == length)
     stream = torch.cuda.current_stream().cuda_stream
 
     # rank r owns global strings shard_range(n*world, r, world) = [r*n, (r+1)*n): generated in place, never
     # crosses PCIe or xGMI
     first, last = pd.shard_range(n * world, rank, world)
     assert last - first == n
-    text = torch.empty((n, length), dtype=torch.uint8, device=dev)
-    pire_amd.corpus_fill_device(text.data_ptr(), SEED, first, n, length, length, plants, stream)
-    out_idx = torch.empty(n, dtype=torch.int32, device=dev)
-    out_fin = torch.empty(n, dtype=torch.uint8, device=dev)
+    base_text = None
+    if args.corpus == "cxx":
+        # C++ source text: the sources tiled over the whole (global) batch; this rank's shard starts at byte first*length
+        base_text = cxx_corpus_bytes()
+        f = len(base_text)
+        total = n * length
+        reps = total // f + 3
+        start = (first * length) % f
+        tiled = torch.as_tensor(base_text, device=dev).repeat(reps)
+        text = tiled[start:start + total].clone().view(n, length)
+        del tiled
+    else:
+        text = torch.empty((n, stride), dtype=torch.uint8, device=dev)
+        pire_amd.corpus_fill_device(text.data_ptr(), SEED, first, n, length, stride, plants, stream)
+    run_n, run_len = (1, n * length) if args.one_string else (n, length)
+    run_stride = run_len if args.one_string else stride
+    out_idx = torch.empty(run_n, dtype=torch.int32, device=dev)
+    out_fin = torch.empty(run_n, dtype=torch.uint8, device=dev)
     # two counter buffers, used alternately: the all-reduce of step k (RCCL runs it on its own stream) then overlaps
     # the scan of step k+1 instead of sitting between two kernels
     count_bufs = [torch.zeros(table.RegexpsCount + 2, dtype=torch.int64, device=dev) for _ in range(2)]
@@ -242,8 +304,8 @@ def main():
         counts.zero_()
         if ev:
             ev[0].record()
-        table.run_strided_device(text.data_ptr(), n, length, length, flags, out_idx.data_ptr(), out_fin.data_ptr(),
-                                 counts.data_ptr(), 0, stream)
+        table.run_strided_device(text.data_ptr(), run_n, run_len, run_stride, flags, out_idx.data_ptr(),
+                                 out_fin.data_ptr(), counts.data_ptr(), 0, stream)
         if ev:
             ev[1].record()
         pending[slot] = pd.allreduce_counts(counts, async_op=True)   # the path's only exchange: 80 B of counters
@@ -256,26 +318,32 @@ def main():
         pd.barrier()
         torch.cuda.synchronize()
 
+    def timed(steps):
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(events[k])
+        fence()
+        elapsed = pd.max_over_ranks(time.perf_counter() - t0, dev)
+        return elapsed, [a.elapsed_time(b) for a, b in events]
+
     for _ in range(args.warmup):
         step()
     fence()
+    # The table as it comes out of pire_hip_table_create (dense rows ranked by the a-priori byte model): a short timed
+    # leg, reported as value_before_adapt.
+    cold_steps = max(1, min(args.steps, 10))
+    cold_elapsed, cold_ms = timed(cold_steps)
     # One-time table optimisation, outside the timed region (like table creation): re-rank the LDS-resident rows
-    # from the visit counters the warm-up passes left on the device, then one more untimed pass.
+    # from the visit counters the passes so far left on the device, then one more untimed pass.
     adapted_rows = 0
-    if args.warmup > 0 and not args.no_adapt:
+    if not args.no_adapt:
         adapted_rows = table.adapt()
         # unconditionally, not "if adapted_rows": the step contains a collective, and ranks whose shard needed no
         # re-ranking must not skip it
         step()
-        fence()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    fence()
-    elapsed = time.perf_counter() - t0
-    elapsed = pd.max_over_ranks(elapsed, dev)
-    kernel_ms = [a.elapsed_time(b) for a, b in events]
+    elapsed, kernel_ms = timed(args.steps)
     kernel_name = pb.last_kernel_symbol()   # the instantiation the library actually launched
 
     total_counts = count_bufs[(step_no[0] - 1) & 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
@@ -285,19 +353,29 @@ def main():
     if rank == 0:
         scanned = float(n) * length * args.steps * world
         value = scanned / elapsed / 1e9
-        algo_bytes = n * (length + 5)                     # input read once + u32 state idx + u8 final per string
+        algo_bytes = n * length + 5 * run_n                # input read once + u32 state idx + u8 final per string
         avg_ms = float(np.mean(kernel_ms))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         info = table.refresh_info()
         # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3 requires)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("workload") == f"{args.set} 2^{args.log2_strings} x {length}":
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic = traffic_src = None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                if pmc.get("workload") == f"{args.set} 2^{args.log2_strings} x {length}" and not args.strings \
+                        and args.corpus == "synthetic":
+                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], name
+                    break
+            except (OSError, ValueError, KeyError):
+                pass
+        if args.corpus == "cxx":
+            data = (f"C++ source text: this repository's {len(base_text)} bytes of C++/HIP sources repeated (the reference's "
+                    "tools/bench/run-bench repeats its own C++ file)")
+            shape = f"ONE string of {n * length} B" if args.one_string else f"{n} x {length} B records"
+        else:
+            data = "synthetic"
+            shape = f"{'2^%d' % args.log2_strings if not args.strings else n} x {length} B strings per GPU"
         res = {
             "metric": "scanned GB/s (whole node) + ns/byte, 8-regex glued Scanner, 4KiB strings",
             "value": round(value, 2),
@@ -311,35 +389,43 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": "synthetic",
+            "data": data,
+            "value_before_adapt": round(float(n) * length * cold_steps * world / cold_elapsed / 1e9, 2),
             "config": {
-                "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), "
-                            f"{'2^%d' % args.log2_strings if not args.strings else n} x {length} B "
-                            f"strings per GPU, Begin().Run().End() per string, match-count reduce",
+                "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), {shape}, "
+                            f"Begin().Run().End() per string, match-count reduce",
                 "patterns": big["patterns"],
                 "table": {"states": info.states, "letters": info.letters, "regexps": info.regexps,
                           "ref_buf_bytes": int(info.ref_buf_size), "lds_dense_rows": info.hot_states,
                           "lds_table_bytes": info.lds_table_bytes, "rows_promoted_by_adapt": adapted_rows},
-                "strings_per_gpu": n, "string_bytes": length, "corpus_seed": SEED,
+                "strings_per_gpu": run_n, "string_bytes": run_len, "string_stride": run_stride, "corpus_seed": SEED,
                 "parallelism": f"shard-by-string x{world}",
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+                "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                                   if traffic else None,
                 "kernel": kernel_name, "kernel_avg_ms": round(avg_ms, 4),
                 "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
+                "kernel_avg_ms_before_adapt": round(float(np.mean(cold_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
             },
             "match_counts": {"final": int(total_counts[0]), "strings": int(total_counts[1]),
                              "per_regexp": [int(c) for c in total_counts[2:]]},
         }
-        assert int(total_counts[1]) == n * world, "match-count reduce lost strings"
-        if not args.no_cpu and world == 1:   # the reported CPU baseline belongs to the N=1 line only
+        assert int(total_counts[1]) == run_n * world, "match-count reduce lost strings"
+        if not args.no_cpu and world == 1 and not args.one_string:   # the reported CPU baseline belongs to the N=1 line
             sample = min(n, 1 << args.cpu_sample_log2)
-            res["cpu_baseline"] = cpu_baseline(blob, plants, length, sample, gpu_idx, gpu_fin)
+            if args.corpus == "cxx":
+                f = len(base_text)
+                host = np.resize(base_text, sample * length + f)[:sample * length].reshape(sample, length)
+            else:
+                from oracle import binding as ob   # host twin of the corpus generator (oracle/corpus.c)
+
+                host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=min(os.cpu_count() or 1, 256))
+            res["cpu_baseline"] = cpu_baseline(blob, host, length, gpu_idx, gpu_fin)
         print(json.dumps(res))
         sys.stdout.flush()
     if world > 1:

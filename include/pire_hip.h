@@ -233,11 +233,11 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
-/* Name of the kernel the last run on this thread dispatched to ("tiled", "tiled2", "ragged", "generic", "ragged_prefix",
+/* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
  * "prefix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
-/* The instantiation behind it where there are several (e.g. "pirehip::ScanTiled2Kernel<12,nt,3>" for "tiled2",
- * the two-chains-per-lane form of the tiled kernel); otherwise the same string as pire_hip_last_kernel(). */
+/* The instantiation behind it where there are several (e.g. "pirehip::ScanTiledKernel<16,2,nt,5>" for "tiled");
+ * otherwise the same string as pire_hip_last_kernel(). */
 const char* pire_hip_last_kernel_symbol(void);
 
 /* Milliseconds the most recent kernel launched by this thread took, measured with hipEvents on the
@@ -285,10 +285,21 @@ const char* pire_hip_last_error(void);
 int pire_hip_device_count(void);
 
 /* ---- benchmark utility (not part of the reference surface) ------------------------------------------ */
+/* Witnesses planted into the synthetic corpus: string s carries plant (s mod (nplants+1)) - 1, none when that is
+ * -1; at_tail: at the end of the string (for '$'-anchored patterns), otherwise at a generated offset. */
+#define PIRE_HIP_CORPUS_MAX_PLANTS 16
+#define PIRE_HIP_CORPUS_PLANT_BYTES 64
+typedef struct pire_hip_corpus_plants {
+	uint32_t nplants;
+	uint32_t len[PIRE_HIP_CORPUS_MAX_PLANTS];
+	uint32_t at_tail[PIRE_HIP_CORPUS_MAX_PLANTS];
+	uint8_t  bytes[PIRE_HIP_CORPUS_MAX_PLANTS][PIRE_HIP_CORPUS_PLANT_BYTES];
+} pire_hip_corpus_plants;
+
 /*
  * Fill device memory with the synthetic corpus of SURVEY.md section 8d: string s occupies
- * out[(s-first)*stride, +len).  `plants` is a host pointer to a corpus_plants struct (oracle/corpus.h layout)
- * or NULL.  Bit-identical with oracle/corpus.c for the same (seed, s).
+ * out[(s-first)*stride, +len).  `plants` is a host pointer to a pire_hip_corpus_plants (the layout of
+ * oracle/corpus.h, the generator's CPU twin) or NULL.  Bit-identical with oracle/corpus.c for the same (seed, s).
  */
 int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,
                          uint64_t stride, const void* plants, void* stream);

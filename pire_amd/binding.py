@@ -10,6 +10,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(HERE, "libpire_hip.so")
+if os.environ.get("PIRE_HIP_LIB"):   # an alternative build of the same library (tools/ab: tuning / older builds)
+    _LIB_PATH = os.path.abspath(os.environ["PIRE_HIP_LIB"])
 
 FLAG_BEGIN = 1
 FLAG_END = 2
@@ -552,8 +554,39 @@ def last_kernel_ms() -> float:
     return float(lib().pire_hip_last_kernel_ms())
 
 
+CORPUS_MAX_PLANTS = 16
+CORPUS_PLANT_BYTES = 64
+
+
+class CorpusPlants(C.Structure):
+    """pire_hip_corpus_plants (include/pire_hip.h)."""
+    _fields_ = [
+        ("nplants", C.c_uint32),
+        ("len", C.c_uint32 * CORPUS_MAX_PLANTS),
+        ("at_tail", C.c_uint32 * CORPUS_MAX_PLANTS),
+        ("bytes", (C.c_uint8 * CORPUS_PLANT_BYTES) * CORPUS_MAX_PLANTS),
+    ]
+
+
+def make_plants(plants) -> CorpusPlants:
+    """plants: sequence of (witness_bytes, at_tail_bool)."""
+    p = CorpusPlants()
+    if len(plants) > CORPUS_MAX_PLANTS:
+        raise ValueError("too many plants")
+    p.nplants = len(plants)
+    for i, (w, tail) in enumerate(plants):
+        if len(w) > CORPUS_PLANT_BYTES:
+            raise ValueError("plant too long")
+        p.len[i] = len(w)
+        p.at_tail[i] = 1 if tail else 0
+        for k, b in enumerate(w):
+            p.bytes[i][k] = b
+    return p
+
+
 def corpus_fill_device(out_ptr: int, seed: int, first: int, count: int, length: int, stride: int, plants=None,
                        stream: int = 0):
-    """Generate the synthetic corpus in device memory (plants: oracle.binding.CorpusPlants or None)."""
+    """Generate the synthetic corpus in device memory (plants: a CorpusPlants of this module or of oracle.binding --
+    the same layout -- or None)."""
     p = C.byref(plants) if plants is not None else None
     _check(lib().pire_hip_corpus_fill(out_ptr, seed, first, count, length, stride, p, stream or None))

@@ -5,9 +5,9 @@
 namespace pirehip {
 
 // ------------------------------------------------------------------------------------------ tiled kernel
-// Fixed-length records, 16-byte aligned.  A wave streams 128-byte tiles (one cache line of each of its 64 -- or, with
-// two chains per lane, 128 -- strings) straight from HBM into VGPRs with whole-line loads, transposes them in
-// registers so that every lane owns the bytes of its own string(s), and walks them with one LDS gather per byte.
+// Fixed-length records, 16-byte aligned.  A wave streams 128-byte tiles (one cache line of each of its 64 strings)
+// straight from HBM into VGPRs with whole-line loads, transposes them in registers so that every lane owns the
+// bytes of its own string, and walks them with one LDS gather per byte.
 // No LDS staging: all of the LDS is left for the table (profiles/micro_loadpath_r01.log: the register path streams
 // as fast as a fully coalesced read).
 
@@ -189,7 +189,6 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT == 1 ? kRotPitch : 256u, CompactBytes(p));
-	LoadTableToLds(p, lds, L);
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -208,9 +207,15 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 
 	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
 	const bool chain = rem == 0;
-	bool primed = false;   // slot a already holds (or is receiving) tile 0 of the task about to start
 	const uint64_t taskStep = uint64_t(gridDim.x) * WAVES;
-	for (uint64_t task = uint64_t(blockIdx.x) * WAVES + wave; task < ntasks; task += taskStep) {
+	const uint64_t firstTask = uint64_t(blockIdx.x) * WAVES + wave;
+	// The first tile of the wave's first task is requested BEFORE the table is copied into LDS: its HBM latency (a
+	// few microseconds when all 4 096 waves of a launch ask at once) then hides behind the copy.
+	bool primed = firstTask < ntasks;   // slot a already holds (or is receiving) tile 0 of the task about to start
+	if (primed)
+		IssueTile<NT>(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), p.stride);
+	LoadTableToLds(p, lds, L);
+	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
 		const uint64_t s0 = task * 64;
 		const uint64_t s = s0 + lane;
 		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
@@ -250,204 +255,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 }
 
 
-// ------------------------------------------------------------------------------------------ two chains per lane
-// The dependent chain  v_perm -> ds_read_u8 -> s_waitcnt  has a round trip of ~68 clocks on an idle LDS
-// (profiles/micro_lds_r01.log: 16 waves x 1 chain top out at 36 lookups/ns/CU even when nothing conflicts), so 16
-// waves with ONE chain each can never keep the LDS array busy through their own transposes, trap tests and tile
-// waits.  ScanTiled2Kernel gives every lane TWO strings (a task is 128 strings, two tiles are walked with their
-// lookups interleaved: one chain's LDS latency hides behind the other's) and runs 12 waves per CU (3 per SIMD, 168
-// VGPRs: four register tiles) = 24 chains per CU instead of 16.
-//
-// Task order: chain slot q = wave + c*WAVES of block b walks tasks (r*Q + q)*gridDim + b, r = 0, 1, ... (Q = 2*WAVES
-// slots per block).  Every round of Q*gridDim tasks is spread evenly over the blocks, and a partial last round
-// fills the first chain of every wave before any second chain, so that all CUs finish together.  A wave whose
-// second chain has nothing left walks alone (the one-chain step) and points the idle chain's loads at one line.
-
-// Two 16-byte chunks, one per chain, lookups interleaved.
-__device__ __forceinline__ void StepChunk2(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 vA,
-                                           const u32x4 vB, uint32_t& hsA, uint32_t& coldA, uint32_t& hsB, uint32_t& coldB,
-                                           uint32_t sampleLane)
-{
-	const uint32_t hsA0 = hsA, hsB0 = hsB;
-#pragma unroll
-	for (int w = 0; w < 4; ++w) {
-		const uint32_t xA = vA[w], xB = vB[w];
-		hsA = HotLookup(__builtin_amdgcn_perm(hsA, xA, 0x0c0c0400u));
-		hsB = HotLookup(__builtin_amdgcn_perm(hsB, xB, 0x0c0c0400u));
-		hsA = HotLookup(__builtin_amdgcn_perm(hsA, xA, 0x0c0c0401u));
-		hsB = HotLookup(__builtin_amdgcn_perm(hsB, xB, 0x0c0c0401u));
-		hsA = HotLookup(__builtin_amdgcn_perm(hsA, xA, 0x0c0c0402u));
-		hsB = HotLookup(__builtin_amdgcn_perm(hsB, xB, 0x0c0c0402u));
-		hsA = HotLookup(__builtin_amdgcn_perm(hsA, xA, 0x0c0c0403u));
-		hsB = HotLookup(__builtin_amdgcn_perm(hsB, xB, 0x0c0c0403u));
-	}
-	if (__any(hsA == p.hot || hsB == p.hot)) {
-		// ONE instance of the exact re-walk serves both chains (a rolled loop over the chain): the code stays small
-#pragma unroll 1
-		for (int c = 0; c < 2; ++c) {
-			const u32x4 v = c ? vB : vA;
-			uint32_t h = c ? hsB : hsA, cd = c ? coldB : coldA;
-			const uint32_t h0 = c ? hsB0 : hsA0;
-			if (h == p.hot) {
-				const uint32_t st0 = h0 != p.hot ? h0 : cd;
-				uint32_t f = p.compact;
-				if (st0 < p.compact)
-					f = CompactChunk(p, L, v, st0);
-				if (f == p.compact)
-					f = SlowChunk(p, lds, L, v, st0);
-				if (f < p.hot) {
-					h = f;
-				} else {
-					cd = f;
-					if ((threadIdx.x & 63) == sampleLane)
-						atomicAdd(&p.visitCold[f], 1u);   // sampled, see StepChunk
-				}
-			}
-			if (c) {
-				hsB = h;
-				coldB = cd;
-			} else {
-				hsA = h;
-				coldA = cd;
-			}
-		}
-	}
-}
-
-template <bool NT>
-__device__ __forceinline__ void Phase2(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint64_t (&rowBase)[2],
-                                       const uint64_t (&chainBase)[2], const uint64_t (&strideC)[2],
-                                       const uint32_t (&voffC)[2], bool two, uint32_t lane, uint32_t t, uint32_t lastTile,
-                                       u32x4 (&curA)[8], u32x4 (&curB)[8], u32x4 (&refA)[8], u32x4 (&refB)[8],
-                                       uint32_t (&hs)[2], uint32_t (&cold)[2])
-{
-	const uint64_t aheadA = t < lastTile ? rowBase[0] + uint64_t(t + 1) * 128 : chainBase[0];
-	const uint64_t aheadB = t < lastTile ? rowBase[1] + uint64_t(t + 1) * 128 * (strideC[1] != 0) : chainBase[1];
-	IssueTile<NT>(refA, voffC[0], aheadA, strideC[0]);
-	IssueTile<NT>(refB, voffC[1], aheadB, strideC[1]);
-	WaitTile<2>(curA);                      // at most the 16 loads just issued are outstanding: both current tiles landed
-	asm volatile("" : "+v"(curB[0]), "+v"(curB[1]), "+v"(curB[2]), "+v"(curB[3]), "+v"(curB[4]), "+v"(curB[5]),
-	             "+v"(curB[6]), "+v"(curB[7]));   // ... and nothing reads curB before that wait
-	TransposeTile(curA, lane);
-	if (lane == (t & 63))
-		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs[0], 1u);
-	if (two) {
-		TransposeTile(curB, lane);
-#pragma unroll
-		for (int k = 0; k < 8; ++k)
-			StepChunk2(p, lds, L, curA[k], curB[k], hs[0], cold[0], hs[1], cold[1], (t * 8 + k) & 63);
-	} else {
-#pragma unroll 1
-		for (int k2 = 0; k2 < 2; ++k2) {   // the lone chain: rolled by four chunks, this is the tail of a launch
-			if (k2 == 0) {
-				StepChunk<0>(p, lds, L, curA[0], hs[0], cold[0], (t * 8 + 0) & 63);
-				StepChunk<0>(p, lds, L, curA[1], hs[0], cold[0], (t * 8 + 1) & 63);
-				StepChunk<0>(p, lds, L, curA[2], hs[0], cold[0], (t * 8 + 2) & 63);
-				StepChunk<0>(p, lds, L, curA[3], hs[0], cold[0], (t * 8 + 3) & 63);
-			} else {
-				StepChunk<0>(p, lds, L, curA[4], hs[0], cold[0], (t * 8 + 4) & 63);
-				StepChunk<0>(p, lds, L, curA[5], hs[0], cold[0], (t * 8 + 5) & 63);
-				StepChunk<0>(p, lds, L, curA[6], hs[0], cold[0], (t * 8 + 6) & 63);
-				StepChunk<0>(p, lds, L, curA[7], hs[0], cold[0], (t * 8 + 7) & 63);
-			}
-		}
-	}
-}
-
-template <int WAVES, bool NT, int MINW>
-__global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiled2Kernel(ScanParams p)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
-	LoadTableToLds(p, lds, L);
-
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint64_t ntasks = p.n / 64;                // whole tasks only
-	const uint32_t ntiles = uint32_t(p.len / 128);   // even and >= 2 (Tiled2Eligible)
-	const uint32_t lastTile = ntiles - 1;
-	const uint32_t groups = ntiles / 2;
-	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
-	const uint32_t voffIdle = (lane & 7u) * 16;      // an idle chain re-reads one line (L1/L2 hits, no HBM traffic)
-	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
-
-	u32x4 a0[8], a1[8], b0[8], b1[8];   // ring slots: chain A tiles t%2 = 0 / 1, chain B likewise
-	ZeroTile(a0);
-	ZeroTile(a1);
-	ZeroTile(b0);
-	ZeroTile(b1);
-
-	const uint64_t G = gridDim.x, Q = 2 * WAVES;
-	bool primed = false;
-	for (uint64_t r = 0;; ++r) {
-		uint64_t task[2], nextTask[2];
-		task[0] = (r * Q + wave) * G + blockIdx.x;
-		task[1] = (r * Q + WAVES + wave) * G + blockIdx.x;
-		if (task[0] >= ntasks)
-			break;
-		nextTask[0] = task[0] + Q * G;
-		nextTask[1] = task[1] + Q * G;
-		const bool two = task[1] < ntasks;
-		uint64_t rowBase[2], chainBase[2], strideC[2];
-		uint32_t voffC[2], hs[2], cold[2];
-#pragma unroll
-		for (int c = 0; c < 2; ++c) {
-			const bool act = c == 0 || two;
-			const bool hasNext = nextTask[c] < ntasks;
-			rowBase[c] = act ? Uniform64(textBase + task[c] * 64 * p.stride) : textBase;
-			chainBase[c] = hasNext ? Uniform64(textBase + nextTask[c] * 64 * p.stride)
-			                       : (act ? rowBase[c] + uint64_t(lastTile) * 128 : textBase);
-			strideC[c] = act ? p.stride : 0;
-			voffC[c] = act ? voff : voffIdle;
-			// a chain that goes idle next round parks its prefetch on one line as well
-			cold[c] = act ? StartState(p, task[c] * 64 + lane) : 0;
-			hs[c] = cold[c] < p.hot ? cold[c] : p.hot;
-		}
-		// prefetch of an idle chain's "next" tile: chainBase = textBase with the per-lane offsets of a live chain would
-		// read 64 lines; the idle offsets are only in force from the next round on, which is fine -- it is one tile
-		if (!primed) {
-			IssueTile<NT>(a0, voffC[0], rowBase[0], strideC[0]);
-			IssueTile<NT>(b0, voffC[1], rowBase[1], strideC[1]);
-		}
-		bool done = false;
-		for (uint32_t g = 0; g < groups && !done; ++g) {
-			const uint32_t t = g * 2;
-			Phase2<NT>(p, lds, L, rowBase, chainBase, strideC, voffC, two, lane, t, lastTile, a0, b0, a1, b1, hs, cold);
-			Phase2<NT>(p, lds, L, rowBase, chainBase, strideC, voffC, two, lane, t + 1, lastTile, a1, b1, a0, b0, hs, cold);
-			done = AllAbsorbing(p, lds, L, hs[0]) && (!two || AllAbsorbing(p, lds, L, hs[1]));
-		}
-		primed = nextTask[0] < ntasks && !done;
-#pragma unroll 1
-		for (int c = 0; c < (two ? 2 : 1); ++c) {
-			const uint32_t h = c ? hs[1] : hs[0], cd = c ? cold[1] : cold[0];
-			uint32_t st = h != p.hot ? h : cd;
-			const uint64_t sc = (c ? task[1] : task[0]) * 64 + lane;
-			if (!done) {
-				const uint8_t* base = p.text + sc * p.stride;
-				for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
-					st = SlowStep(p, lds, L, st, base[i]);
-			}
-			Finish(p, lds, L, sc, true, st);
-		}
-	}
-	// the thread index, recomputed: keeping v0 alive through the loop costs a register the four tiles need
-	FlushCounts(p, lds, L, wave * 64 + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
-}
-
 // ------------------------------------------------------------------------------------------ launcher
 
 bool TiledEligible(const ScanParams& p)
 {
 	return p.offsets == nullptr && p.n >= 64 && p.len >= 128 && (p.stride % 16) == 0 && p.stride * 64 < (1ull << 31) &&
 	       (reinterpret_cast<uintptr_t>(p.text) % 16) == 0;
-}
-
-// Two chains per lane need an even number of tiles (the ring runs straight through task boundaries) and enough
-// tasks that the second chains are not mostly idle.
-static bool Tiled2Eligible(const ScanParams& p, int cus)
-{
-	const uint64_t ntiles = p.len / 128;
-	return ntiles >= 2 && ntiles % 2 == 0 && p.n / 64 >= uint64_t(cus) * 16;
 }
 
 int LaunchTiled(const ScanParams& p, hipStream_t stream)
@@ -472,13 +285,8 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	int rc;
-	int cus = 0;
-	if ((rc = DeviceCUs(&cus)))
-		return rc;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, CompactBytes(q));
 	const LdsLayout L256 = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(q));
-	const bool two = variant == 5 ? (p.len / 128) % 2 == 0 : Tiled2Eligible(q, cus);   // 5: two chains whatever the batch size
-	const bool use2 = two && variant != 1 && variant != 2 && variant != 3;
 	switch (variant) {
 	case 1:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,rot>");
@@ -488,21 +296,9 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,plain,5>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream);   // no nt
 		break;
-	case 4:
-		if (use2) {
-			NoteKernel("tiled2", "pirehip::ScanTiled2Kernel<8,nt,2>");
-			rc = LaunchScan(ScanTiled2Kernel<8, true, 2>, q, 512, L256.total, stream, 16);
-			break;
-		}
-		[[fallthrough]];
 	default:
-		if (use2) {
-			NoteKernel("tiled2", "pirehip::ScanTiled2Kernel<12,nt,3>");
-			rc = LaunchScan(ScanTiled2Kernel<12, true, 3>, q, 768, L256.total, stream, 24);
-		} else {   // 3: one chain per lane whatever the batch
-			NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");
-			rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
-		}
+		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
 		break;
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)

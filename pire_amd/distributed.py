@@ -39,14 +39,27 @@ def init(backend: str, device=None):
         dist.init_process_group(backend=backend)
 
 
+def _gloo_with_device_tensor(t) -> bool:
+    import torch.distributed as dist
+
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
 def allreduce_counts(counts, async_op: bool = False):
     """Sum the match counters over all ranks in place (no-op for a single process).
 
     async_op=True returns the collective's work handle (or None): the caller's stream is NOT made to wait for the
-    reduction, so the next scan can run while RCCL moves its 80 bytes; call .wait() before touching `counts` again."""
+    reduction, so the next scan can run while RCCL moves its 80 bytes; call .wait() before touching `counts` again.
+    With the gloo backend (control-flow tests on a box with fewer GPUs than ranks) device counters are reduced
+    through the host, synchronously."""
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if _gloo_with_device_tensor(counts):
+            host = counts.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            counts.copy_(host)
+            return None if async_op else counts
         work = dist.all_reduce(counts, op=dist.ReduceOp.SUM, async_op=async_op)
         return work if async_op else counts
     return None if async_op else counts
@@ -58,7 +71,8 @@ def max_over_ranks(seconds: float, device=None) -> float:
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device if device is not None else "cpu")
+    on = device if device is not None and dist.get_backend() != "gloo" else "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=on)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -228,62 +228,6 @@ def test_tiled_kernel_shapes_vs_oracle(pa, torch_cuda, name, n, length):
     assert (cnt == expected_counts(o, oi, of)).all()
 
 
-@pytest.fixture
-def two_chains(monkeypatch):
-    """Forces the two-chains-per-lane tiled kernel (ScanTiled2Kernel) whatever the batch size: by default it only
-    takes batches that fill the chip."""
-    monkeypatch.setenv("PIRE_HIP_TILED_VARIANT", "5")
-
-
-@pytest.mark.parametrize("name", ["set_a", "set_d", "set_b", "c2_single"])
-@pytest.mark.parametrize("n,length", [(64, 256), (128, 256), (129, 4096 + 48), (192, 512 + 16), (1000, 1024),
-                                      (64 * 24 * 3 + 64 * 7 + 5, 512), (64 * 24 * 2, 256), (4097, 128 * 4 + 16)])
-def test_two_chain_tiled_kernel_shapes_vs_oracle(pa, torch_cuda, two_chains, name, n, length):
-    """ScanTiled2Kernel on batches that leave second chains idle (fewer tasks than chain slots, partial last
-    rounds), chain across task boundaries, have tails shorter than a tile and strings beyond the last whole task."""
-    torch = torch_cuda
-    big = [b for b in H.big_sets() if b["name"] == name][0]
-    blob = H.load_blob(big["blob"])
-    t, o = pa.Table(blob), ob.OracleScanner(blob)
-    data = ob.corpus_fill(n * 37 + length, 0, n, length, H.plants_for(big), threads=4)
-    offs = np.arange(n + 1, dtype=np.uint64) * length
-    oi, of = o.run(data.reshape(-1), offs, threads=4)
-    d = torch.as_tensor(data, device="cuda")
-    gi, gf, cnt = dev_run_strided(torch, t, d)
-    assert pa.binding.last_kernel() == "tiled2"
-    assert (gi == oi).all() and (gf == of).all()
-    assert (cnt == expected_counts(o, oi, of)).all()
-    # resumed scan: first half with Begin(), second half from the reported states with End()
-    half = (length // 256) * 128
-    if half >= 256 and (half // 128) % 2 == 0:
-        i1, _, _ = dev_run_strided(torch, t, d[:, :half].contiguous(), flags=pa.binding.FLAG_BEGIN, counts=False)
-        i2, f2, _ = dev_run_strided(torch, t, d[:, half:].contiguous(), flags=pa.binding.FLAG_END, init=i1,
-                                    counts=False)
-        assert (i2 == oi).all() and (f2 == of).all()
-
-
-def test_two_chain_cold_states_are_exact(pa, torch_cuda, two_chains):
-    """The trap / exact re-walk of the two-chain kernel (one rolled instance serving both chains)."""
-    torch = torch_cuda
-    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
-    blob = H.load_blob(big["blob"])
-    t, o = pa.Table(blob), ob.OracleScanner(blob)
-    rng = np.random.RandomState(6)
-    alphabet = np.frombuffer(b"abcdeaxHedInrTailhello w", dtype=np.uint8)
-    n, length = 64 * 24 + 64 * 9, 1024
-    data = alphabet[rng.randint(0, len(alphabet), size=(n, length))].astype(np.uint8)
-    for i in range(n):
-        for w in (b"HeadInnerInner", b"abc", b"aaa", b"adddde", b"hello   w"):
-            q = rng.randint(0, length - 20)
-            data[i, q:q + len(w)] = np.frombuffer(w, dtype=np.uint8)
-    offs = np.arange(n + 1, dtype=np.uint64) * length
-    oi, of = o.run(data.reshape(-1), offs, threads=4)
-    gi, gf, cnt = dev_run_strided(torch, t, torch.as_tensor(data, device="cuda"))
-    assert pa.binding.last_kernel() == "tiled2"
-    assert (gi == oi).all() and (gf == of).all()
-    assert (cnt == expected_counts(o, oi, of)).all()
-
-
 def test_cold_states_are_exact(pa, torch_cuda):
     """Text that drives set_d far outside its 255 dense rows: the trap / exact re-walk path must stay bit-exact."""
     torch = torch_cuda

@@ -86,6 +86,76 @@ static std::vector<uint8_t> make_table(int spread, double stay0)
     return t;
 }
 
+
+// MODE u16: rows of 256 u16 entries, an entry is the LDS byte address of the next row; the step is
+//   addr = v_dot4_u32_u8(x, 2 << 8k, row) = row + 2 * byte_k ;  row = ds_read_u16(addr)
+typedef const __attribute__((address_space(3))) uint16_t* LdsH;
+__device__ __forceinline__ uint32_t rd16(uint32_t a) { return *reinterpret_cast<LdsH>(static_cast<uintptr_t>(a)); }
+
+template <int WAVES, int ILP>
+__global__ __launch_bounds__(WAVES * 64) void chain16_kernel(const uint16_t* __restrict__ table, uint32_t words, uint32_t* out, int iters, uint32_t seed)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lds)[i] = reinterpret_cast<const uint32_t*>(table)[i];
+    __syncthreads();
+    uint32_t r[16];
+    uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + seed;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; w |= (0x20u + (((h >> 8) & 0xFF) * 95 >> 8)) << (8 * b); }
+        r[k] = w;
+    }
+    uint32_t st = 0, st2 = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            st = rd16(__builtin_amdgcn_udot4(r[k], 0x00000002u, st, false));
+            if (ILP == 2) st2 = rd16(__builtin_amdgcn_udot4(r[15 - k], 0x02000000u, st2, false));
+            st = rd16(__builtin_amdgcn_udot4(r[k], 0x00000200u, st, false));
+            if (ILP == 2) st2 = rd16(__builtin_amdgcn_udot4(r[15 - k], 0x00020000u, st2, false));
+            st = rd16(__builtin_amdgcn_udot4(r[k], 0x00020000u, st, false));
+            if (ILP == 2) st2 = rd16(__builtin_amdgcn_udot4(r[15 - k], 0x00000200u, st2, false));
+            st = rd16(__builtin_amdgcn_udot4(r[k], 0x02000000u, st, false));
+            if (ILP == 2) st2 = rd16(__builtin_amdgcn_udot4(r[15 - k], 0x00000002u, st2, false));
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = st + st2;
+}
+
+static std::vector<uint16_t> make_table16(const std::vector<uint8_t>& t8, int rows, uint32_t pitch)
+{
+    std::vector<uint16_t> t(size_t(rows) * pitch / 2 + 8, 0);
+    for (int s = 0; s < rows; ++s)
+        for (int b = 0; b < 256; ++b) {
+            uint32_t nx = t8[s * 256 + b];
+            if (nx >= (uint32_t)rows) nx = 0;
+            t[(size_t(s) * pitch) / 2 + b] = uint16_t(nx * pitch);
+        }
+    return t;
+}
+
+template <int WAVES, int ILP>
+static void run16(const char* name, const uint16_t* dtab, uint32_t bytes, uint32_t* out, int cus, int iters)
+{
+    auto k = chain16_kernel<WAVES, ILP>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    k<<<cus, WAVES * 64, bytes>>>(dtab, bytes / 4, out, 4, 1); CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a)); k<<<cus, WAVES * 64, bytes>>>(dtab, bytes / 4, out, iters, r); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float m; CK(hipEventElapsedTime(&m, a, b)); ms.push_back(m);
+    }
+    CK(hipGetLastError());
+    std::sort(ms.begin(), ms.end());
+    const double steps = (double)cus * WAVES * 64 * iters * 64.0 * ILP;
+    const double tps = steps / (ms[2] * 1e-3);
+    printf("%-52s %8.3f ms  %7.2f Tsteps/s  %6.2f steps/ns/CU\n", name, ms[2], tps / 1e12, tps / 1e9 / cus);
+    fflush(stdout);
+}
+
 template <int MODE, int WAVES>
 static void run(const char* name, const uint8_t* dtab, uint32_t* out, int cus, int blocksPerCu, int iters)
 {
@@ -133,10 +203,25 @@ int main()
         run<0, 16>("u8   32 waves/CU (2 blocks)", dtab, out, cus, 2, iters);
         run<1, 16>("b32 aligned+alignbyte 16 waves/CU", dtab, out, cus, 1, iters);
         run<1, 16>("b32 aligned+alignbyte 32 waves/CU", dtab, out, cus, 2, iters);
-        run<2, 16>("b32 at byte address 16 waves/CU", dtab, out, cus, 1, iters);
-        run<2, 16>("b32 at byte address 32 waves/CU", dtab, out, cus, 2, iters);
         run<3, 16>("u8 ILP2 16 waves/CU", dtab, out, cus, 1, iters);
         run<3, 16>("u8 ILP2 32 waves/CU", dtab, out, cus, 2, iters);
+        {
+            uint16_t* d16; 
+            for (uint32_t pitch : {512u, 516u, 580u}) {
+                auto t16 = make_table16(t, 112, pitch);
+                CK(hipMalloc(&d16, t16.size() * 2));
+                CK(hipMemcpy(d16, t16.data(), t16.size() * 2, hipMemcpyHostToDevice));
+                char nm[96];
+                snprintf(nm, sizeof nm, "u16+dot4 pitch %u 16 waves/CU", pitch);
+                run16<16, 1>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
+                snprintf(nm, sizeof nm, "u16+dot4 pitch %u 12 waves/CU ILP2", pitch);
+                run16<12, 2>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
+                CK(hipFree(d16));
+            }
+        }
+        run<0, 12>("u8   12 waves/CU (1 block)", dtab, out, cus, 1, iters);
+        run<3, 12>("u8 ILP2 12 waves/CU", dtab, out, cus, 1, iters);
+        run<3, 8>("u8 ILP2 8 waves/CU", dtab, out, cus, 1, iters);
         run<0, 8>("u8   8 waves/CU (1 block)", dtab, out, cus, 1, iters);
         run<0, 4>("u8   4 waves/CU (1 block)", dtab, out, cus, 1, iters);
     }
