@@ -280,6 +280,51 @@ int pire_hip_slow_run_strided(pire_hip_slow_table* t, const void* text, uint64_t
                               uint32_t flags, uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts,
                               void* stream);
 
+/* ---- one process, several GPUs (BASELINE config C4) --------------------------- */
+/*
+ * The path shards by string: a string's walk depends on nothing but the table and its own bytes (run.h:271-275),
+ * so GPU g scans its contiguous range of strings with no data-path exchange; the only collective is the sum of the
+ * uint64[regexps+2] match counters -- one all-reduce over RCCL (xGMI) per batch, latency bound (80 bytes for 8
+ * regexps).  The reference has no counterpart (a single-threaded CPU library); this is the C-ABI form of what
+ * bench.py does with one process per GPU.  One table handle serves every device (it keeps an image per device).
+ * RCCL is loaded at run time; without it (or when the communicator cannot be built) the per-device counters are
+ * summed on the host -- pire_hip_multi_reduce_backend() says which ("rccl" or "host (...reason)").
+ */
+typedef struct pire_hip_multi pire_hip_multi;
+
+/* One shard: fixed-length records resident on ITS device (pointers are device pointers of that device). */
+typedef struct pire_hip_shard {
+	const void*     text;
+	uint64_t        n, len, stride;
+	const uint32_t* init_state_idx;   /* nullable */
+	uint32_t*       out_state_idx;    /* nullable */
+	uint8_t*        out_final;        /* nullable */
+} pire_hip_shard;
+
+/* devices == NULL: HIP devices 0 .. ndev-1 (ndev <= 0: all of them).  Creates one stream and one counter buffer per
+ * device and, for two or more distinct devices, the RCCL communicator (ncclCommInitAll). */
+int  pire_hip_multi_create(const int* devices, int ndev, pire_hip_multi** out);
+void pire_hip_multi_destroy(pire_hip_multi* m);
+int  pire_hip_multi_device_count(const pire_hip_multi* m);
+const char* pire_hip_multi_reduce_backend(const pire_hip_multi* m);
+
+/*
+ * Scan shards[g] on device g of `m` (all devices run concurrently, each on its own stream), then reduce the match
+ * counters: out_counts (host memory, uint64[regexps+2], nullable) RECEIVES the totals over all shards (it is not
+ * accumulated into).  flags: PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC.  Returns when every
+ * device has finished.  The caller's current device is restored.
+ */
+int pire_hip_multi_run_strided(pire_hip_multi* m, pire_hip_table* t, const pire_hip_shard* shards, uint32_t flags,
+                               uint64_t* out_counts);
+/*
+ * Convenience form for a batch in HOST memory: strings [lo_g, hi_g) -- contiguous, balanced ranges -- are copied to
+ * device g, scanned, and the per-string results copied back into the caller's arrays (PCIe-inclusive, like the
+ * host-pointer mode of pire_hip_run).
+ */
+int pire_hip_multi_run_strided_host(pire_hip_multi* m, pire_hip_table* t, const void* text, uint64_t n, uint64_t len,
+                                    uint64_t stride, uint32_t flags, const uint32_t* init_state_idx,
+                                    uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts);
+
 /* ---- errors ---------------------------------------------------------------------------------------- */
 const char* pire_hip_last_error(void);
 int pire_hip_device_count(void);

@@ -15,6 +15,7 @@ from .binding import (  # noqa: F401
     SlowTable,
     CountingTable,
     BatchRunner,
+    MultiRunner,
     build,
     corpus_fill_device,
     device_count,

@@ -118,6 +118,13 @@ ABI = [
                                         C.c_void_p, C.c_void_p]),
     ("pire_hip_capture_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_multi_create", C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    ("pire_hip_multi_destroy", None, [C.c_void_p]),
+    ("pire_hip_multi_device_count", C.c_int, [C.c_void_p]),
+    ("pire_hip_multi_reduce_backend", C.c_char_p, [C.c_void_p]),
+    ("pire_hip_multi_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("pire_hip_multi_run_strided_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                                  C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
     ("pire_hip_last_kernel_symbol", C.c_char_p, []),
     ("pire_hip_set_timing", C.c_int, [C.c_int]),
@@ -536,6 +543,59 @@ class BatchRunner:
     def Final(self):
         """operator bool of RunHelper, per string (run.h:380)."""
         return self._go()[1].astype(bool)
+
+
+class Shard(C.Structure):
+    """pire_hip_shard (include/pire_hip.h)."""
+    _fields_ = [("text", C.c_void_p), ("n", C.c_uint64), ("len", C.c_uint64), ("stride", C.c_uint64),
+                ("init_state_idx", C.c_void_p), ("out_state_idx", C.c_void_p), ("out_final", C.c_void_p)]
+
+
+class MultiRunner:
+    """pire_hip_multi: one process, several GPUs, strings sharded by index, match counters reduced over RCCL."""
+
+    def __init__(self, devices=None, ndev: int = 0):
+        h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().pire_hip_multi_create(arr, len(devices), C.byref(h)))
+        else:
+            _check(lib().pire_hip_multi_create(None, ndev, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and _lib is not None:
+            _lib.pire_hip_multi_destroy(h)
+
+    @property
+    def device_count(self) -> int:
+        return lib().pire_hip_multi_device_count(self._h)
+
+    @property
+    def reduce_backend(self) -> str:
+        return lib().pire_hip_multi_reduce_backend(self._h).decode()
+
+    def run_shards(self, table: "Table", shards, flags=FLAG_BEGIN | FLAG_END, counts=True):
+        """shards: one (text_ptr, n, len, stride, init_ptr, out_idx_ptr, out_final_ptr) per device (device pointers)."""
+        arr = (Shard * len(shards))()
+        for i, (text, n, length, stride, init, oi, of) in enumerate(shards):
+            arr[i] = Shard(text or None, n, length, stride, init or None, oi or None, of or None)
+        cnt = np.zeros(table.RegexpsCount + 2, dtype=np.uint64) if counts else None
+        _check(lib().pire_hip_multi_run_strided(self._h, table._h, arr, flags, _np_ptr(cnt)))
+        return cnt
+
+    def run_strided_host(self, table: "Table", text2d: np.ndarray, flags=FLAG_BEGIN | FLAG_END, init_idx=None):
+        text2d = np.ascontiguousarray(text2d, dtype=np.uint8)
+        n, length = text2d.shape
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        cnt = np.zeros(table.RegexpsCount + 2, dtype=np.uint64)
+        _check(lib().pire_hip_multi_run_strided_host(self._h, table._h, text2d.ctypes.data if text2d.size else None, n,
+                                                     length, length, flags, _np_ptr(init), idx.ctypes.data,
+                                                     fin.ctypes.data, cnt.ctypes.data))
+        return idx, fin, cnt
 
 
 def last_kernel() -> str:

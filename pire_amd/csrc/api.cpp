@@ -14,6 +14,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <new>
+#include <stdexcept>
+
 #include "internal.h"
 
 namespace pirehip {
@@ -27,6 +30,29 @@ thread_local float g_lastMs = -1.0f;
 }  // namespace
 
 void SetError(const std::string& msg) { g_error = msg; }
+
+int HandleException() noexcept
+{
+	try {
+		try {
+			throw;
+		} catch (const std::bad_alloc&) {
+			g_error = "out of memory";
+			return PIRE_HIP_ENOMEM;
+		} catch (const std::length_error&) {
+			g_error = "out of memory (a table of that size cannot be built)";
+			return PIRE_HIP_ENOMEM;
+		} catch (const std::exception& e) {
+			g_error = std::string("internal error: ") + e.what();
+			return PIRE_HIP_EINVAL;
+		} catch (...) {
+			g_error = "internal error";
+			return PIRE_HIP_EINVAL;
+		}
+	} catch (...) {   // building the message failed too
+		return PIRE_HIP_ENOMEM;
+	}
+}
 
 int HipFail(hipError_t e, const char* what)
 {
@@ -218,9 +244,17 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	if (offsets)
 		if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
 			return rc;
-	if (init)
+	if (init) {
+		// host-side array: checking it costs nothing next to the transfer (device-side arrays are the caller's
+		// responsibility, as a state is in the reference: Runner(sc, st) trusts st, run.h:368)
+		for (uint64_t i = 0; i < n; ++i)
+			if (init[i] >= t->host.states) {
+				SetError("init_state_idx out of range");
+				return PIRE_HIP_EINVAL;
+			}
 		if (int rc = st.In(init, size_t(n), &p.initIdx, stream))
 			return rc;
+	}
 	void* dIdx = nullptr;
 	void* dFin = nullptr;
 	void* dCnt = nullptr;
@@ -275,25 +309,29 @@ const char* pire_hip_last_kernel(void) { return g_lastKernel; }
 const char* pire_hip_last_kernel_symbol(void) { return g_lastSymbol ? g_lastSymbol : g_lastKernel; }
 
 int pire_hip_set_timing(int enabled)
-{
+try {
 	g_timing = enabled != 0;
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 float pire_hip_last_kernel_ms(void) { return g_lastMs; }
 
 int pire_hip_device_count(void)
-{
+try {
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess) {
 		(void)hipGetLastError();
 		return 0;
 	}
 	return n;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** out)
-{
+try {
 	if (!out) {
 		SetError("null out pointer");
 		return PIRE_HIP_EINVAL;
@@ -308,20 +346,24 @@ int pire_hip_table_create(const void* save_blob, size_t len, pire_hip_table** ou
 		return rc;
 	*out = t.release();
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_mmap(const void* image, size_t size, pire_hip_table** out, size_t* consumed)
-{
+try {
 	if (consumed)
 		*consumed = 0;
 	const int rc = pire_hip_table_create(image, size, out);
 	if (rc == PIRE_HIP_OK && consumed)
 		*consumed = size_t((*out)->host.blobBytes);
 	return rc;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_create_from_file(const char* path, pire_hip_table** out)
-{
+try {
 	if (!path || !out) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -347,6 +389,8 @@ int pire_hip_table_create_from_file(const char* path, pire_hip_table** out)
 	const int rc = pire_hip_table_create(map, size_t(st.st_size), out);   // the image is decoded, nothing aliases it
 	munmap(map, size_t(st.st_size));
 	return rc;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 namespace {
@@ -372,33 +416,41 @@ int GlueImpl(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_si
 }  // namespace
 
 int pire_hip_table_glue_gpu(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
-{
+try {
 	return GlueImpl(lhs, rhs, max_size, out, true);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out)
-{
+try {
 	return GlueImpl(lhs, rhs, max_size, out, false);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 
 int pire_hip_table_upload(pire_hip_table* t)
-{
+try {
 	if (!t) {
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
 	}
 	DeviceTable image;
 	return UploadTable(t, &image);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows)
-{
+try {
 	if (!t) {
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
 	}
 	return AdaptTable(t, changed_rows);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 void pire_hip_table_destroy(pire_hip_table* t)
@@ -410,7 +462,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 }
 
 int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
-{
+try {
 	if (!t || !out) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -438,6 +490,8 @@ int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)
 	out->last_trap_samples = h.lastTrapSamples;
 	out->ref_buf_size = h.refBufSize;
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 static int CheckIdx(const pire_hip_table* t, uint32_t idx)
@@ -454,21 +508,25 @@ static int CheckIdx(const pire_hip_table* t, uint32_t idx)
 }
 
 int pire_hip_table_final(const pire_hip_table* t, uint32_t idx)
-{
+try {
 	if (int rc = CheckIdx(t, idx))
 		return rc;
 	return (t->host.flags[idx] & kFinal) ? 1 : 0;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_dead(const pire_hip_table* t, uint32_t idx)
-{
+try {
 	if (int rc = CheckIdx(t, idx))
 		return rc;
 	return (t->host.flags[idx] & kDead) ? 1 : 0;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_accepted_regexps(const pire_hip_table* t, uint32_t idx, const uint64_t** begin, size_t* count)
-{
+try {
 	if (int rc = CheckIdx(t, idx))
 		return rc;
 	if (!begin || !count) {
@@ -479,15 +537,19 @@ int pire_hip_table_accepted_regexps(const pire_hip_table* t, uint32_t idx, const
 	*begin = h.acceptIds.data() + h.acceptOff[idx];
 	*count = size_t(h.acceptOff[idx + 1] - h.acceptOff[idx]);
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_table_letter_class(const pire_hip_table* t, uint32_t ch)
-{
+try {
 	if (!t || ch >= kMaxChar) {
 		SetError("bad argument");
 		return PIRE_HIP_EINVAL;
 	}
 	return t->host.cls[ch];
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int64_t pire_hip_table_next(const pire_hip_table* t, uint32_t idx, uint32_t ch)
@@ -503,7 +565,7 @@ int64_t pire_hip_table_next(const pire_hip_table* t, uint32_t idx, uint32_t ch)
 }
 
 int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8_t* hot_rows)
-{
+try {
 	if (!t) {
 		SetError("null table");
 		return PIRE_HIP_EINVAL;
@@ -515,12 +577,14 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
 	if (hot_rows)
 		memcpy(hot_rows, h.hotRows.data(), h.hotRows.size());
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_run(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                  const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts,
                  void* stream)
-{
+try {
 	if (n && !offsets) {
 		SetError("null offsets");
 		return PIRE_HIP_EINVAL;
@@ -536,23 +600,27 @@ int pire_hip_run(pire_hip_table* t, const void* text, const uint64_t* offsets, u
 			               out_counts, stream);
 	}
 	return RunImpl(t, text, offsets, n, 0, 0, flags, init_state_idx, out_state_idx, out_final, out_counts, stream);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_run_strided(pire_hip_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
                          uint32_t flags, const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final,
                          uint64_t* out_counts, void* stream)
-{
+try {
 	if (stride < len) {
 		SetError("stride smaller than len");
 		return PIRE_HIP_EINVAL;
 	}
 	return RunImpl(t, text, nullptr, n, len, stride, flags, init_state_idx, out_state_idx, out_final, out_counts,
 	               stream);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                             uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* streamPtr)
-{
+try {
 	if (!t || (n && (!offsets || !out_results))) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -669,11 +737,13 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 	if (e != hipSuccess)
 		return HipFail(e, "copy back / synchronize");
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* streamPtr)
-{
+try {
 	if (!t || (n && (!offsets || !out_len))) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -724,10 +794,12 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
 	if (e != hipSuccess)
 		return HipFail(e, "copy back / synchronize");
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream)
-{
+try {
 	if (!t || (n && !state_idx) || ch >= kMaxCharUnaligned || ch == kEpsilon) {
 		SetError("bad argument");
 		return PIRE_HIP_EINVAL;
@@ -736,17 +808,21 @@ int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t c
 	if (int rc = FillParams(t, &p, 0))
 		return rc;
 	return LaunchStep(p, state_idx, n, t->host.cls[ch], static_cast<hipStream_t>(stream));
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,
                          uint64_t stride, const void* plants, void* stream)
-{
+try {
 	if (!device_out && count && len) {
 		SetError("null output");
 		return PIRE_HIP_EINVAL;
 	}
 	return LaunchCorpusFill(static_cast<uint8_t*>(device_out), seed, first, count, len, stride, plants,
 	                        static_cast<hipStream_t>(stream));
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 }  // extern "C"

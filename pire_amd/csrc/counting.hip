@@ -586,7 +586,7 @@ using namespace pirehip;
 extern "C" {
 
 int pire_hip_counting_table_create(const void* save_blob, size_t len, pire_hip_counting_table** out)
-{
+try {
 	if (!out) {
 		SetError("null out pointer");
 		return PIRE_HIP_EINVAL;
@@ -601,6 +601,8 @@ int pire_hip_counting_table_create(const void* save_blob, size_t len, pire_hip_c
 		return rc;
 	*out = t.release();
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 void pire_hip_counting_table_destroy(pire_hip_counting_table* t)
@@ -620,7 +622,7 @@ void pire_hip_counting_table_destroy(pire_hip_counting_table* t)
 }
 
 int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_counting_info* out)
-{
+try {
 	if (!t || !out) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -631,11 +633,13 @@ int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_
 	out->regexps = t->host.regexps;
 	out->initial = t->host.initial;
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                           uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* streamPtr)
-{
+try {
 	if (!t || (n && (!offsets || !out_results)) || (kind != PIRE_HIP_COUNTING_BASIC && kind != PIRE_HIP_COUNTING_ADVANCED && kind != PIRE_HIP_COUNTING_NOGLUELIMIT)) {
 		SetError("bad argument");
 		return PIRE_HIP_EINVAL;
@@ -730,11 +734,13 @@ int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text
 	if (e != hipSuccess)
 		return HipFail(e, "counting run (copy back / synchronize)");
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                          uint32_t* out_state_idx, uint8_t* out_final, int64_t* out_begin, int64_t* out_end, void* streamPtr)
-{
+try {
 	if (!t || (n && (!offsets || !out_begin || !out_end))) {
 		SetError("bad argument");
 		return PIRE_HIP_EINVAL;
@@ -825,6 +831,8 @@ int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uin
 	if (e != hipSuccess)
 		return HipFail(e, "capture run");
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 }  // extern "C"

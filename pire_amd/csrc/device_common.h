@@ -154,6 +154,7 @@ __device__ __forceinline__ uint32_t StateFlags(const ScanParams& p, const uint8_
 // Start state of string s (perm id): Initialize() or the caller's resume state, then Begin() if asked.
 __device__ __forceinline__ uint32_t StartStateFrom(const ScanParams& p, uint32_t init)
 {
+	init = init < p.states ? init : 0;   // a resume index the scanner does not have must not read outside the table
 	uint32_t st = (p.flags & kPermIds) ? init : p.permOfOrig[init];
 	if (p.flags & PIRE_HIP_RUN_BEGIN)
 		st = p.nextPerm[size_t(st) * p.letters + p.beginCls];

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateI
 {
 	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (i < n) {
-		const uint32_t st = p.permOfOrig[stateIdx[i]];
+		const uint32_t in = stateIdx[i];
+		const uint32_t st = p.permOfOrig[in < p.states ? in : 0];   // never read outside the table
 		stateIdx[i] = p.origOfPerm[p.nextPerm[size_t(st) * p.letters + cls]];
 	}
 }

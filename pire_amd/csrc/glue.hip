@@ -46,7 +46,11 @@ struct GlueDev {
 	uint32_t* ranks;
 	uint32_t* nextOut;      // [cap * LC]
 	uint32_t cap;
+	uint32_t maxProbe;      // probes before a lookup gives up (the table is then far too full: more pairs than cap)
+	uint32_t* overflow;     // set when that happened
 };
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t HashPair(uint64_t key, uint32_t mask)
 {
@@ -66,13 +70,17 @@ __device__ __forceinline__ uint64_t TargetOf(const GlueDev& g, uint32_t i, uint3
 // Finds the slot of `key`, claiming an empty one if it is not in the table yet.
 __device__ __forceinline__ uint32_t SlotOf(const GlueDev& g, uint64_t key)
 {
+	// Bounded: one level may meet far more distinct pairs than the table has slots (an exploding product -- exactly
+	// the case in which Glue is about to fail); unbounded probing of a full table would spin for ever.
 	uint32_t h = HashPair(key, g.hashMask);
-	for (;;) {
+	for (uint32_t probes = 0; probes < g.maxProbe; ++probes) {
 		const unsigned long long seen = atomicCAS(&g.keys[h], kEmptyKey, key);
 		if (seen == kEmptyKey || seen == key)
 			return h;
 		h = (h + 1) & g.hashMask;
 	}
+	*g.overflow = 1;
+	return kNoSlot;
 }
 
 __global__ void GlueInsert(GlueDev g, uint32_t lo, uint32_t count)
@@ -81,7 +89,9 @@ __global__ void GlueInsert(GlueDev g, uint32_t lo, uint32_t count)
 	if (pos >= count)
 		return;
 	const uint64_t key = TargetOf(g, lo + pos / g.LC, pos % g.LC);
-	atomicMin(&g.vals[SlotOf(g, key)], kTentative | pos);
+	const uint32_t slot = SlotOf(g, key);
+	if (slot != kNoSlot)
+		atomicMin(&g.vals[slot], kTentative | pos);
 }
 
 __global__ void GlueMark(GlueDev g, uint32_t lo, uint32_t count)
@@ -90,7 +100,8 @@ __global__ void GlueMark(GlueDev g, uint32_t lo, uint32_t count)
 	if (pos >= count)
 		return;
 	const uint64_t key = TargetOf(g, lo + pos / g.LC, pos % g.LC);
-	g.marks[pos] = g.vals[SlotOf(g, key)] == (kTentative | pos) ? 1u : 0u;
+	const uint32_t slot = SlotOf(g, key);
+	g.marks[pos] = slot != kNoSlot && g.vals[slot] == (kTentative | pos) ? 1u : 0u;
 }
 
 __global__ void GlueAssign(GlueDev g, uint32_t lo, uint32_t hi, uint32_t count)
@@ -104,7 +115,9 @@ __global__ void GlueAssign(GlueDev g, uint32_t lo, uint32_t hi, uint32_t count)
 		g.stA[idx] = uint32_t(key >> 32);
 		g.stB[idx] = uint32_t(key);
 	}
-	g.vals[SlotOf(g, key)] = idx;
+	const uint32_t slot = SlotOf(g, key);
+	if (slot != kNoSlot)
+		g.vals[slot] = idx;
 }
 
 __global__ void GlueFill(GlueDev g, uint32_t lo, uint32_t count)
@@ -113,7 +126,8 @@ __global__ void GlueFill(GlueDev g, uint32_t lo, uint32_t count)
 	if (pos >= count)
 		return;
 	const uint32_t i = lo + pos / g.LC, l = pos % g.LC;
-	g.nextOut[size_t(i) * g.LC + l] = g.vals[SlotOf(g, TargetOf(g, i, l))];
+	const uint32_t slot = SlotOf(g, TargetOf(g, i, l));
+	g.nextOut[size_t(i) * g.LC + l] = slot != kNoSlot ? g.vals[slot] : 0u;
 }
 
 struct DevBuf {
@@ -155,21 +169,23 @@ int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint
 	const uint32_t LC = uint32_t(la.size());
 	// the glue fails once more than maxSize NEW states are needed (determine.h:112-113), i.e. beyond maxSize + 1 states
 	if (maxSize > (1u << 22))
-		maxSize = 1u << 22;
+		return GlueBfsHost(a, b, la, lb, maxSize, out);   // beyond what the device buffers are sized for: host version
 	const uint32_t cap = uint32_t(maxSize) + 1;
 	uint32_t hashSize = 1;
 	while (hashSize < 4u * (cap + 64))
 		hashSize <<= 1;
 	const size_t maxPositions = size_t(cap) * LC;
 
-	DevBuf dNextA, dNextB, dLa, dLb, dStA, dStB, dKeys, dVals, dMarks, dRanks, dNext, dTemp;
+	DevBuf dNextA, dNextB, dLa, dLb, dStA, dStB, dKeys, dVals, dMarks, dRanks, dNext, dTemp, dOverflow;
 	int rc;
 	if ((rc = Upload(&dNextA, a.next)) || (rc = Upload(&dNextB, b.next)) || (rc = Upload(&dLa, la)) || (rc = Upload(&dLb, lb)) ||
 	    (rc = dStA.Alloc(size_t(cap) * 4)) || (rc = dStB.Alloc(size_t(cap) * 4)) || (rc = dKeys.Alloc(size_t(hashSize) * 8)) ||
 	    (rc = dVals.Alloc(size_t(hashSize) * 4)) || (rc = dMarks.Alloc(maxPositions * 4)) ||
-	    (rc = dRanks.Alloc(maxPositions * 4)) || (rc = dNext.Alloc(maxPositions * 4)))
+	    (rc = dRanks.Alloc(maxPositions * 4)) || (rc = dNext.Alloc(maxPositions * 4)) || (rc = dOverflow.Alloc(4)))
 		return rc;
 	hipError_t e = hipMemset(dKeys.p, 0xFF, size_t(hashSize) * 8);
+	if (e == hipSuccess)
+		e = hipMemset(dOverflow.p, 0, 4);
 	if (e == hipSuccess)
 		e = hipMemset(dVals.p, 0xFF, size_t(hashSize) * 4);
 	if (e != hipSuccess)
@@ -192,6 +208,8 @@ int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint
 	g.ranks = dRanks.As<uint32_t>();
 	g.nextOut = dNext.As<uint32_t>();
 	g.cap = cap;
+	g.maxProbe = std::min<uint32_t>(hashSize, 1u << 14);
+	g.overflow = dOverflow.As<uint32_t>();
 
 	// state 0 = (lhs initial, rhs initial), numbered before the loop (determine.h:105-106)
 	{
@@ -231,12 +249,16 @@ int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint
 			return HipFail(e, "hipcub::DeviceScan::ExclusiveSum");
 		hipLaunchKernelGGL(GlueAssign, dim3(blocks), dim3(256), 0, nullptr, g, lo, hi, count);
 		hipLaunchKernelGGL(GlueFill, dim3(blocks), dim3(256), 0, nullptr, g, lo, count);
-		uint32_t lastRank = 0, lastMark = 0;
+		uint32_t lastRank = 0, lastMark = 0, overflow = 0;
 		e = hipMemcpy(&lastRank, &g.ranks[count - 1], 4, hipMemcpyDeviceToHost);   // synchronises the level
 		if (e == hipSuccess)
 			e = hipMemcpy(&lastMark, &g.marks[count - 1], 4, hipMemcpyDeviceToHost);
+		if (e == hipSuccess)
+			e = hipMemcpy(&overflow, g.overflow, 4, hipMemcpyDeviceToHost);
 		if (e != hipSuccess)
 			return HipFail(e, "glue level (kernels / copy back)");
+		if (overflow)   // the pair table filled up inside a level: let the sequential version decide (it is exact)
+			return GlueBfsHost(a, b, la, lb, maxSize, out);
 		const uint64_t fresh = uint64_t(lastRank) + lastMark;
 		if (uint64_t(hi) + fresh > cap) {   // more than maxSize new states in total: task.Failure()
 			out->failed = true;

@@ -226,6 +226,9 @@ __host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)
 }
 
 void SetError(const std::string& msg);
+// Inside a catch (...) of an extern "C" entry point: std::bad_alloc / std::length_error (blob fields that ask for
+// absurd sizes) -> PIRE_HIP_ENOMEM, anything else -> PIRE_HIP_EINVAL; the message goes to pire_hip_last_error().
+int HandleException() noexcept;
 int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_HIP_ENODEVICE / ENOMEM
 
 // Owns the temporary device buffers of a host-pointer call (PCIe-inclusive convenience mode): everything is freed when

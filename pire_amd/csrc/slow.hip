@@ -622,7 +622,7 @@ using namespace pirehip;
 extern "C" {
 
 int pire_hip_slow_table_create(const void* save_blob, size_t len, pire_hip_slow_table** out)
-{
+try {
 	if (!out) {
 		SetError("null out pointer");
 		return PIRE_HIP_EINVAL;
@@ -637,6 +637,8 @@ int pire_hip_slow_table_create(const void* save_blob, size_t len, pire_hip_slow_
 		return rc;
 	*out = t.release();
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 void pire_hip_slow_table_destroy(pire_hip_slow_table* t)
@@ -656,7 +658,7 @@ void pire_hip_slow_table_destroy(pire_hip_slow_table* t)
 }
 
 int pire_hip_slow_table_get_info(const pire_hip_slow_table* t, pire_hip_slow_info* out)
-{
+try {
 	if (!t || !out) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
@@ -669,27 +671,33 @@ int pire_hip_slow_table_get_info(const pire_hip_slow_table* t, pire_hip_slow_inf
 	out->empty = t->host.empty ? 1 : 0;
 	out->mask_bytes = uint64_t(t->host.masks.size()) * 4;
 	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_slow_run(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                       uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts, void* stream)
-{
+try {
 	if (n && !offsets) {
 		SetError("null offsets");
 		return PIRE_HIP_EINVAL;
 	}
 	return RunSlow(t, text, offsets, n, 0, 0, flags, out_final, out_state_bits, out_counts, stream);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 int pire_hip_slow_run_strided(pire_hip_slow_table* t, const void* text, uint64_t n, uint64_t len, uint64_t stride,
                               uint32_t flags, uint8_t* out_final, uint32_t* out_state_bits, uint64_t* out_counts,
                               void* stream)
-{
+try {
 	if (stride < len) {
 		SetError("stride smaller than len");
 		return PIRE_HIP_EINVAL;
 	}
 	return RunSlow(t, text, nullptr, n, len, stride, flags, out_final, out_state_bits, out_counts, stream);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
 }  // extern "C"

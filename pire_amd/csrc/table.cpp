@@ -352,6 +352,12 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 
 	if (m.statesCount == 0 || m.lettersCount == 0 || m.lettersCount > kMaxChar)
 		return Bad("Corrupt scanner: bad state or letter count");
+	// The kernels pack a state id into 28 bits (FinRec) and index counters by regexp id: bound both here.  The
+	// reference itself never builds more than 200 000 determinised / 80 000 glued states (fsm.cpp:1018, multi.h:1100).
+	if (m.statesCount >= (1u << 28))
+		return Bad("Corrupt scanner: state count out of range");
+	if (m.regexpsCount > (1u << 20))
+		return Bad("Corrupt scanner: regexp count out of range");
 	const size_t rowSize = AlignUp(size_t(m.lettersCount) + t.headerSize, 16 / 4);
 	const size_t bufSize = AlignUp(size_t(kMaxChar) * 2 + size_t(m.finalTableSize) * 8 + size_t(m.statesCount) * 8 +
 	                                   rowSize * m.statesCount * 4,
@@ -423,6 +429,14 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 			memcpy(&id, finalTab + fi * 8, 8);
 			if (id == ~uint64_t(0))
 				break;   // End sentinel, multi.h:96, 155
+			// the kernels index counters with these ids (cnt[2 + id], row[id]): an id the scanner does not have would
+			// be an out-of-bounds device write at run time
+			if (id >= m.regexpsCount)
+				return Bad("Corrupt scanner: regexp id in the final table out of range");
+			// lists of different states may overlap in a mutated image, which would grow the decoded form
+			// quadratically: a well-formed scanner has finalTableSize entries in total (BuildFinals, multi.h:477-528)
+			if (t.acceptIds.size() >= size_t(m.finalTableSize) + t.states)
+				return Bad("Corrupt scanner: final lists overlap");
 			t.acceptIds.push_back(id);
 		}
 	}
