@@ -207,7 +207,7 @@ int main()
         run<3, 16>("u8 ILP2 32 waves/CU", dtab, out, cus, 2, iters);
         {
             uint16_t* d16; 
-            for (uint32_t pitch : {512u, 516u, 580u}) {
+            for (uint32_t pitch : {512u, 544u, 576u, 608u}) {
                 auto t16 = make_table16(t, 112, pitch);
                 CK(hipMalloc(&d16, t16.size() * 2));
                 CK(hipMemcpy(d16, t16.data(), t16.size() * 2, hipMemcpyHostToDevice));
@@ -216,6 +216,10 @@ int main()
                 run16<16, 1>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
                 snprintf(nm, sizeof nm, "u16+dot4 pitch %u 12 waves/CU ILP2", pitch);
                 run16<12, 2>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
+                snprintf(nm, sizeof nm, "u16+dot4 pitch %u 16 waves/CU ILP2", pitch);
+                run16<16, 2>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
+                snprintf(nm, sizeof nm, "u16+dot4 pitch %u 8 waves/CU", pitch);
+                run16<8, 1>(nm, d16, uint32_t(t16.size() * 2) & ~15u, out, cus, iters);
                 CK(hipFree(d16));
             }
         }
