@@ -69,7 +69,7 @@ def lib_path() -> str:
 
 def build(force: bool = False) -> str:
     """Compile libpire_hip.so in-tree for gfx950 with hipcc (works without a GPU)."""
-    cmd = ["make", "-C", os.path.join(HERE, "csrc")] + (["-B"] if force else [])
+    cmd = ["make", "-j8", "-C", os.path.join(HERE, "csrc")] + (["-B"] if force else [])
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libpire_hip.so failed:\n" + r.stdout)

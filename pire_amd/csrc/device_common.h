@@ -47,9 +47,10 @@ constexpr uint32_t kDebugNoHist = 1u << 27;
 constexpr uint32_t kDebugNoPartial = 1u << 26;
 constexpr uint32_t kDebugNoFinish = 1u << 25;
 constexpr uint32_t kDebugNoTrap = 1u << 24;
+constexpr uint32_t kDebugNoTranspose = 1u << 22;
 #else
 constexpr uint32_t kDebugNoRefill = 0, kDebugNoStep = 0, kDebugNoColdCount = 0, kDebugNoHist = 0, kDebugNoPartial = 0,
-                   kDebugNoFinish = 0, kDebugNoTrap = 0;
+                   kDebugNoFinish = 0, kDebugNoTrap = 0, kDebugNoTranspose = 0;
 #endif
 constexpr uint32_t kPermIds = 1u << 23;   // internal (segmented.hip): initIdx holds, outIdx receives, DEVICE state ids
 
@@ -420,6 +421,8 @@ int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hi
 #endif
 	if (perCu < 1)
 		perCu = 1;
+	if (const char* cap = getenv("PIRE_HIP_BLOCKS_PER_CU"))   // knob: A/B measurements
+		perCu = std::max(1, std::min(perCu, atoi(cap)));
 	const uint64_t ntasks = (p.n + 63) / 64;
 	const uint64_t wavesPerBlock = tasksPerBlock ? uint64_t(tasksPerBlock) : uint64_t(threads) / 64;
 	uint64_t blocks = (ntasks + wavesPerBlock - 1) / wavesPerBlock;

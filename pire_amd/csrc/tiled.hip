@@ -168,7 +168,8 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
 		IssueTile<NT>(refill, voff, ahead, p.stride);
 	WaitTile<NBUF - 1>(cur);
-	TransposeTile(cur, lane);
+	if (!(p.flags & kDebugNoTranspose))
+		TransposeTile(cur, lane);
 	if (lane == (t & 63) && !(p.flags & kDebugNoHist))   // visit sample: one lane per wave per tile, rotating
 		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs, 1u);
 	if (p.flags & kDebugNoStep) {      // measurement knob only (PIRE_HIP_DEBUG_NOSTEP): stream + transpose, no walk
@@ -280,6 +281,10 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoColdCount;
 	if (getenv("PIRE_HIP_DEBUG_NOHIST"))
 		q.flags |= kDebugNoHist;
+	if (getenv("PIRE_HIP_DEBUG_NOTRANSPOSE"))
+		q.flags |= kDebugNoTranspose;
+	if (getenv("PIRE_HIP_DEBUG_NOTRAP"))
+		q.flags |= kDebugNoTrap;
 #endif
 	if (variant == 1)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout

@@ -348,13 +348,18 @@ def test_full_size_config_properties(pa, torch_cuda, name, length):
 
 
 @pytest.mark.parametrize("name", ["set_d", "set_b", "set_a"])
-def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name):
+def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name, monkeypatch):
     """pire_hip_table_adapt(): after one representative batch the rows the data really visits move into LDS.
-    Results must be bit-identical before and after; the trap counter must collapse."""
+    Results must be bit-identical before and after; the trap counter must collapse.  The table starts from a prior
+    that knows nothing (PIRE_HIP_PRIOR_FLAT: dense rows = the first 255 states by index) so that there is something to
+    learn whatever the shipped prior already gets right."""
     torch = torch_cuda
     big = [b for b in H.big_sets() if b["name"] == name][0]
     blob = H.load_blob(big["blob"])
+    monkeypatch.setenv("PIRE_HIP_PRIOR_FLAT", "1")
     t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.layout()                                   # ranks the rows now, under the knob
+    monkeypatch.delenv("PIRE_HIP_PRIOR_FLAT")
     n, length = 8192, 2048
     data = ob.corpus_fill(77, 0, n, length, H.plants_for(big), threads=4)
     oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
