@@ -158,15 +158,15 @@ __device__ __forceinline__ bool AllAbsorbing(const ScanParams& p, const uint8_t*
 
 template <int NBUF, bool NT, int ROT>
 __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
-                                      uint64_t chainBase, uint32_t voff, uint32_t lane, uint32_t t, uint32_t lastTile,
-                                      u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
+                                      uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
+                                      uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
 {
 	// Refill target: the next tile of this task, or -- on the task's last tile -- tile 0 of the wave's NEXT task
 	// (chainBase; equals this task's last tile when there is nothing to chain to), so that neither the HBM
 	// latency of a task's first tile nor a duplicate load of its last tile is ever paid.
 	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
 	if (!(p.flags & kDebugNoRefill))   // measurement knob only (PIRE_HIP_DEBUG_NOLOAD): walk stale registers
-		IssueTile<NT>(refill, voff, ahead, p.stride);
+		IssueTile<NT>(refill, voff, ahead, istride);
 	WaitTile<NBUF - 1>(cur);
 	if (!(p.flags & kDebugNoTranspose))
 		TransposeTile(cur, lane);
@@ -200,6 +200,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	const uint32_t rem = ntiles % NBUF;
 	// per-lane byte offset inside a task's tile: string (lane & ~7) [+ j per instruction], chunk (lane & 7)
 	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
+	// (Tried: instruction j covering the 8 CONSECUTIVE strings 8j .. 8j+7 -- same transpose, lane 8g+j then owns string
+	// 8j+g.  Identical times, profiles/r02_tiled_trmap.log.  What does matter is that a CU's 16 waves work on ADJACENT
+	// tasks: wave-major task numbering costs 14 %, profiles/r02_tiled_taskmap.log -- lines of strings 64 KiB apart share
+	// DRAM rows and the waves of one CU stay in phase.)
+	const uint64_t istride = p.stride;
+	const uint32_t mine = lane;   // this lane's string inside a task
 
 	// Ring slots: tile t lives in slot t % 2.
 	u32x4 a[8], b[8];
@@ -209,16 +215,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
 	const bool chain = rem == 0;
 	const uint64_t taskStep = uint64_t(gridDim.x) * WAVES;
-	const uint64_t firstTask = uint64_t(blockIdx.x) * WAVES + wave;
+	const uint64_t firstTask = (p.flags & kDebugTaskMap) ? uint64_t(wave) * gridDim.x + blockIdx.x   // measurement knob
+	                                                      : uint64_t(blockIdx.x) * WAVES + wave;
 	// The first tile of the wave's first task is requested BEFORE the table is copied into LDS: its HBM latency (a
 	// few microseconds when all 4 096 waves of a launch ask at once) then hides behind the copy.
 	bool primed = firstTask < ntasks;   // slot a already holds (or is receiving) tile 0 of the task about to start
 	if (primed)
-		IssueTile<NT>(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), p.stride);
+		IssueTile<NT>(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), istride);
 	LoadTableToLds(p, lds, L);
 	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
 		const uint64_t s0 = task * 64;
-		const uint64_t s = s0 + lane;
+		const uint64_t s = s0 + mine;
 		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
 		const bool hasNext = chain && task + taskStep < ntasks;
 		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
@@ -229,11 +236,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 
 		bool done = false;
 		if (!primed)
-			IssueTile<NT>(a, voff, rowBase, p.stride);
+			IssueTile<NT>(a, voff, rowBase, istride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
 			const uint32_t t = g * 2;
-			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t, lastTile, a, b, hs, cold);
-			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, lane, t + 1, lastTile, b, a, hs, cold);
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold);
+			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold);
 			done = AllAbsorbing(p, lds, L, hs);
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
@@ -285,6 +292,8 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoTranspose;
 	if (getenv("PIRE_HIP_DEBUG_NOTRAP"))
 		q.flags |= kDebugNoTrap;
+	if (getenv("PIRE_HIP_DEBUG_TASKMAP"))
+		q.flags |= kDebugTaskMap;
 #endif
 	if (variant == 1)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
