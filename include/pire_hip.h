@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PIRE_HIP_ABI_VERSION 2
+#define PIRE_HIP_ABI_VERSION 3
 
 enum {
 	PIRE_HIP_OK        =  0,
@@ -324,6 +324,22 @@ int pire_hip_multi_run_strided(pire_hip_multi* m, pire_hip_table* t, const pire_
 int pire_hip_multi_run_strided_host(pire_hip_multi* m, pire_hip_table* t, const void* text, uint64_t n, uint64_t len,
                                     uint64_t stride, uint32_t flags, const uint32_t* init_state_idx,
                                     uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts);
+
+/* ---- memory helpers ------------------------------------------------------------------------------- */
+/*
+ * Thin wrappers over the HIP runtime so that a caller of this ABI (and the header-only C++ shim) need not link HIP
+ * itself.  Text placed in pire_hip_host_alloc() memory is pinned: the host-pointer mode of pire_hip_run then moves it
+ * by plain DMA, overlapped chunk by chunk with the scan (pageable text is staged by the runtime; both are measured in
+ * DESIGN.md).  Copies are asynchronous on `stream` (NULL = default stream); synchronise before reading the result.
+ */
+int  pire_hip_host_alloc(size_t bytes, void** out);
+void pire_hip_host_free(void* p);
+int  pire_hip_device_alloc(size_t bytes, void** out);
+void pire_hip_device_free(void* p);
+int  pire_hip_copy_to_device(void* dst_device, const void* src_host, size_t bytes, void* stream);
+int  pire_hip_copy_to_host(void* dst_host, const void* src_device, size_t bytes, void* stream);
+int  pire_hip_memset_device(void* dst_device, int value, size_t bytes, void* stream);
+int  pire_hip_stream_synchronize(void* stream);
 
 /* ---- errors ---------------------------------------------------------------------------------------- */
 const char* pire_hip_last_error(void);

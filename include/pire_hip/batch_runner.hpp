@@ -93,17 +93,53 @@ private:
 	size_t m_base, m_stride;
 };
 
-/* Batched twin of Pire::RunHelper (run.h:365-386). */
+/* A device buffer owned by the shim (grown on demand, freed with its owner). */
+class DeviceBuffer {
+public:
+	DeviceBuffer() : m_ptr(nullptr), m_bytes(0) {}
+	~DeviceBuffer() { pire_hip_device_free(m_ptr); }
+	void* Reserve(size_t bytes)
+	{
+		if (bytes > m_bytes) {
+			pire_hip_device_free(m_ptr);
+			m_ptr = nullptr;
+			m_bytes = 0;
+			Check(pire_hip_device_alloc(bytes, &m_ptr));
+			m_bytes = bytes;
+		}
+		return m_ptr;
+	}
+	void* Get() const { return m_ptr; }
+
+private:
+	DeviceBuffer(const DeviceBuffer&);
+	DeviceBuffer& operator=(const DeviceBuffer&);
+	void* m_ptr;
+	size_t m_bytes;
+};
+
+/*
+ * Batched twin of Pire::RunHelper (run.h:365-386).
+ *
+ * Two ways to hand the text over:
+ *   Run(text, offsets, n)                     host pointers: the library moves the text over PCIe chunk by chunk,
+ *                                             overlapped with the scan (PCIe bound, ~50 GB/s);
+ *   RunDevice(text, offsets, n, stream)       DEVICE pointers: the text is already resident in HBM (a corpus that was
+ *   RunDeviceStrided(text, n, len, stride, ..) loaded once, the output of another kernel); the scan runs at the speed
+ *                                             of the C ABI (TB/s).  Results stay on the device until asked for:
+ *                                             MatchCounts() moves 8 * (regexps + 2) bytes, States()/Finals() 5 bytes
+ *                                             per string; DeviceStateIndices()/DeviceFinals() move nothing.
+ */
 template <class Scanner>
 class BatchRunner {
 public:
 	typedef typename Scanner::State State;
 
 	explicit BatchRunner(const Scanner& sc)
-	    : m_own(new Table<Scanner>(sc)), m_table(m_own), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false) {}
+	    : m_own(new Table<Scanner>(sc)), m_table(m_own) { Reset(); }
 	/* Re-use one device table for many batches. */
 	explicit BatchRunner(const Table<Scanner>& table)
-	    : m_own(nullptr), m_table(&table), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false) {}
+	    : m_own(nullptr), m_table(&table) { Reset(); }
 	~BatchRunner() { delete m_own; }
 
 	/* RunHelper(sc, st): resume every string from a previously returned state (run.h:368, 391-392). */
@@ -124,6 +160,34 @@ public:
 		m_text = text;
 		m_offsets = offsets;
 		m_n = n;
+		m_onDevice = false;
+		m_ran = false;
+		return *this;
+	}
+
+	/* The same with DEVICE pointers (text and offsets resident in HBM); `stream` is a hipStream_t or null. */
+	BatchRunner& RunDevice(const void* deviceText, const uint64_t* deviceOffsets, size_t n, void* stream = nullptr)
+	{
+		m_text = static_cast<const char*>(deviceText);
+		m_offsets = deviceOffsets;
+		m_n = n;
+		m_len = m_stride = 0;
+		m_stream = stream;
+		m_onDevice = true;
+		m_ran = false;
+		return *this;
+	}
+
+	/* Device-resident fixed-length records: string i = text[i * stride, i * stride + len). */
+	BatchRunner& RunDeviceStrided(const void* deviceText, size_t n, size_t len, size_t stride, void* stream = nullptr)
+	{
+		m_text = static_cast<const char*>(deviceText);
+		m_offsets = nullptr;
+		m_n = n;
+		m_len = len;
+		m_stride = stride;
+		m_stream = stream;
+		m_onDevice = true;
 		m_ran = false;
 		return *this;
 	}
@@ -143,14 +207,14 @@ public:
 	/* RunHelper::State() per string (run.h:378). */
 	const std::vector<State>& States()
 	{
-		Execute();
+		Fetch();
 		return m_states;
 	}
 
 	/* operator bool of RunHelper per string (run.h:380): Final(State()). */
 	const std::vector<char>& Finals()
 	{
-		Execute();
+		Fetch();
 		return m_final;
 	}
 
@@ -158,31 +222,90 @@ public:
 	const std::vector<uint64_t>& MatchCounts()
 	{
 		Execute();
+		if (m_onDevice && !m_countsFetched) {
+			Check(pire_hip_copy_to_host(m_counts.data(), m_devCounts.Get(), m_counts.size() * 8, m_stream));
+			Check(pire_hip_stream_synchronize(m_stream));
+			m_countsFetched = true;
+		}
 		return m_counts;
 	}
 
+	/* After RunDevice*: the results where the scan left them -- uint32 StateIndex and uint8 Final per string, device
+	 * memory owned by this runner, valid until its next Run*; ordered after the scan on the stream given to RunDevice. */
+	const uint32_t* DeviceStateIndices() { Execute(); return static_cast<const uint32_t*>(m_devIdx.Get()); }
+	const uint8_t* DeviceFinals() { Execute(); return static_cast<const uint8_t*>(m_devFin.Get()); }
+
 private:
+	void Reset()
+	{
+		m_flags = 0;
+		m_text = nullptr;
+		m_offsets = nullptr;
+		m_n = m_len = m_stride = 0;
+		m_stream = nullptr;
+		m_onDevice = m_ran = m_fetched = m_countsFetched = false;
+	}
+
 	void Execute()
 	{
 		if (m_ran)
 			return;
 		if (!m_init.empty() && m_init.size() != m_n)
 			throw Pire::Error("pire_hip: From() and Run() disagree on the number of strings");
-		std::vector<uint32_t> idx(m_n);
-		std::vector<uint8_t> fin(m_n);
 		pire_hip_table_info info;
 		Check(pire_hip_table_get_info(m_table->Handle(), &info));
 		m_counts.assign(size_t(info.regexps) + 2, 0);
 		static const uint64_t kNoOffsets[1] = {0};
-		Check(pire_hip_run(m_table->Handle(), m_text, m_n ? m_offsets : kNoOffsets, m_n, m_flags,
-		                   m_init.empty() ? nullptr : m_init.data(), idx.data(), fin.data(), m_counts.data(), nullptr));
+		if (m_onDevice) {
+			uint32_t* idx = static_cast<uint32_t*>(m_devIdx.Reserve(m_n * 4));
+			uint8_t* fin = static_cast<uint8_t*>(m_devFin.Reserve(m_n));
+			uint64_t* cnt = static_cast<uint64_t*>(m_devCounts.Reserve(m_counts.size() * 8));
+			Check(pire_hip_memset_device(cnt, 0, m_counts.size() * 8, m_stream));
+			const uint32_t* init = nullptr;
+			if (!m_init.empty()) {
+				init = static_cast<const uint32_t*>(m_devInit.Reserve(m_n * 4));
+				Check(pire_hip_copy_to_device(m_devInit.Get(), m_init.data(), m_n * 4, m_stream));
+			}
+			const uint32_t flags = m_flags | PIRE_HIP_RUN_ON_DEVICE;
+			if (m_offsets || !m_n)
+				Check(pire_hip_run(m_table->Handle(), m_text, m_offsets, m_n, flags, init, idx, fin, cnt, m_stream));
+			else
+				Check(pire_hip_run_strided(m_table->Handle(), m_text, m_n, m_len, m_stride, flags, init, idx, fin, cnt,
+				                           m_stream));
+			if (!m_init.empty())
+				Check(pire_hip_stream_synchronize(m_stream));   // m_init was the source of an asynchronous copy
+			m_fetched = m_countsFetched = false;
+		} else {
+			m_idx.resize(m_n);
+			m_fin.resize(m_n);
+			Check(pire_hip_run(m_table->Handle(), m_text, m_n ? m_offsets : kNoOffsets, m_n, m_flags,
+			                   m_init.empty() ? nullptr : m_init.data(), m_idx.data(), m_fin.data(), m_counts.data(), nullptr));
+			m_fetched = false;
+			m_countsFetched = true;
+		}
+		m_ran = true;
+	}
+
+	/* Per-string results on the host, as Scanner::State values. */
+	void Fetch()
+	{
+		Execute();
+		if (m_fetched)
+			return;
+		if (m_onDevice) {
+			m_idx.resize(m_n);
+			m_fin.resize(m_n);
+			Check(pire_hip_copy_to_host(m_idx.data(), m_devIdx.Get(), m_n * 4, m_stream));
+			Check(pire_hip_copy_to_host(m_fin.data(), m_devFin.Get(), m_n, m_stream));
+			Check(pire_hip_stream_synchronize(m_stream));
+		}
 		m_states.resize(m_n);
 		m_final.resize(m_n);
 		for (size_t i = 0; i < m_n; ++i) {
-			m_states[i] = m_table->ToState(idx[i]);
-			m_final[i] = char(fin[i]);
+			m_states[i] = m_table->ToState(m_idx[i]);
+			m_final[i] = char(m_fin[i]);
 		}
-		m_ran = true;
+		m_fetched = true;
 	}
 
 	BatchRunner(const BatchRunner&);
@@ -193,12 +316,15 @@ private:
 	uint32_t m_flags;
 	const char* m_text;
 	const uint64_t* m_offsets;
-	size_t m_n;
-	bool m_ran;
-	std::vector<uint32_t> m_init;
+	size_t m_n, m_len, m_stride;
+	void* m_stream;
+	bool m_onDevice, m_ran, m_fetched, m_countsFetched;
+	std::vector<uint32_t> m_init, m_idx;
+	std::vector<uint8_t> m_fin;
 	std::vector<State> m_states;
 	std::vector<char> m_final;
 	std::vector<uint64_t> m_counts;
+	DeviceBuffer m_devIdx, m_devFin, m_devCounts, m_devInit;
 	ystring m_ownText;
 	std::vector<uint64_t> m_ownOffsets;
 };

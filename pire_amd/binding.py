@@ -131,6 +131,14 @@ ABI = [
     ("pire_hip_last_kernel_ms", C.c_float, []),
     ("pire_hip_last_error", C.c_char_p, []),
     ("pire_hip_device_count", C.c_int, []),
+    ("pire_hip_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_host_free", None, [C.c_void_p]),
+    ("pire_hip_device_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    ("pire_hip_device_free", None, [C.c_void_p]),
+    ("pire_hip_copy_to_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("pire_hip_copy_to_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("pire_hip_memset_device", C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    ("pire_hip_stream_synchronize", C.c_int, [C.c_void_p]),
     ("pire_hip_corpus_fill", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                        C.c_void_p, C.c_void_p]),
 ]

@@ -2,8 +2,10 @@
 // host-pointer convenience mode, kernel selection.  There is deliberately no CPU implementation of the walk
 // here: without a HIP device the run entry points fail with PIRE_HIP_ENODEVICE.
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -151,6 +153,272 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 	return rc;
 }
 
+// ---- host-pointer mode, chunked ---------------------------------------------------------------------------------------
+// The batch is cut into chunks of whole strings (up to kHostChunkBytes of text each).  Chunk k goes
+//     H2D text (+ its offsets / resume states)  ->  scan  ->  D2H results (into pinned staging)
+// on stream k % 2 of a staging arena, so that the transfer of chunk k+1 overlaps the scan and the result copies of
+// chunk k, the device staging is bounded whatever the batch size, and nothing is allocated per call: arenas (two
+// streams, two sets of buffers grown on demand) are pooled per device for the life of the process.
+// Measured (profiles/r02_pcie_probe.log, r02_host_mode.log): a scan is ~1 % of its own transfer, so the overlap buys
+// little; what matters is (a) no hipMalloc/hipFree per call, (b) results never copied device -> PAGEABLE host inside
+// the loop (that call blocks until the chunk's scan is over and serialises everything), (c) LARGE chunks -- the
+// runtime stages pageable memory faster in few big copies (53 GB/s for 1 GiB at once, 47 in 32 MiB pieces).  Pinned
+// text (pire_hip_host_alloc) is plain DMA at 57 GB/s.
+constexpr size_t kHostChunkBytes = size_t(256) << 20;
+constexpr size_t kHostChunkSlack = 4096;        // the kernels read whole 16-byte blocks around a string's ends
+constexpr uint64_t kHostChunkStrings = 1u << 22;
+
+struct HostArena {
+	int device = -1;
+	hipStream_t stream[2] = {nullptr, nullptr};
+	hipEvent_t done[2] = {nullptr, nullptr};
+	hipEvent_t ready = nullptr;
+	// per slot, grown on demand
+	uint8_t* text[2] = {nullptr, nullptr};
+	size_t textCap[2] = {0, 0};
+	uint64_t* offs[2] = {nullptr, nullptr};
+	uint32_t* init[2] = {nullptr, nullptr};
+	uint32_t* idx[2] = {nullptr, nullptr};
+	uint8_t* fin[2] = {nullptr, nullptr};
+	// results land in pinned host memory first: a device-to-host copy into the caller's (pageable) arrays would block
+	// the host until the chunk's scan is over, and with it the transfer of the next chunk
+	uint32_t* hostIdx[2] = {nullptr, nullptr};
+	uint8_t* hostFin[2] = {nullptr, nullptr};
+	size_t stringCap[2] = {0, 0};
+	unsigned long long* counts = nullptr;
+	size_t countBytes = 0;
+};
+
+std::mutex g_arenaMutex;
+std::vector<HostArena*> g_arenas[kMaxDevices];
+
+void FreeSlotStrings(HostArena* a, int k)
+{
+	(void)hipFree(a->offs[k]);
+	(void)hipFree(a->init[k]);
+	(void)hipFree(a->idx[k]);
+	(void)hipFree(a->fin[k]);
+	(void)hipHostFree(a->hostIdx[k]);
+	(void)hipHostFree(a->hostFin[k]);
+	a->offs[k] = nullptr;
+	a->init[k] = a->idx[k] = a->hostIdx[k] = nullptr;
+	a->fin[k] = a->hostFin[k] = nullptr;
+	a->stringCap[k] = 0;
+}
+
+void DestroyArena(HostArena* a)
+{
+	for (int k = 0; k < 2; ++k) {
+		if (a->stream[k])
+			(void)hipStreamDestroy(a->stream[k]);
+		if (a->done[k])
+			(void)hipEventDestroy(a->done[k]);
+		(void)hipFree(a->text[k]);
+		FreeSlotStrings(a, k);
+	}
+	(void)hipFree(a->counts);
+	if (a->ready)
+		(void)hipEventDestroy(a->ready);
+	delete a;
+}
+
+// Slot k of the arena can take `textBytes` of text and `strings` strings (the slot is idle when this is called).
+int ReserveSlot(HostArena* a, int k, size_t textBytes, size_t strings)
+{
+	hipError_t e = hipSuccess;
+	if (textBytes > a->textCap[k]) {
+		(void)hipFree(a->text[k]);
+		a->text[k] = nullptr;
+		a->textCap[k] = 0;
+		e = hipMalloc(reinterpret_cast<void**>(&a->text[k]), textBytes);
+		if (e == hipSuccess)
+			a->textCap[k] = textBytes;
+	}
+	if (e == hipSuccess && strings > a->stringCap[k]) {
+		FreeSlotStrings(a, k);
+		e = hipMalloc(reinterpret_cast<void**>(&a->offs[k]), (strings + 1) * 8);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&a->init[k]), strings * 4);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&a->idx[k]), strings * 4);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&a->fin[k]), strings);
+		if (e == hipSuccess)
+			e = hipHostMalloc(reinterpret_cast<void**>(&a->hostIdx[k]), strings * 4, hipHostMallocDefault);
+		if (e == hipSuccess)
+			e = hipHostMalloc(reinterpret_cast<void**>(&a->hostFin[k]), strings, hipHostMallocDefault);
+		if (e == hipSuccess)
+			a->stringCap[k] = strings;
+	}
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "staging arena");
+}
+
+int AcquireArena(size_t countBytes, HostArena** out)
+{
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+		return HipFail(e == hipSuccess ? hipErrorInvalidDevice : e, "hipGetDevice");
+	{
+		std::lock_guard<std::mutex> lock(g_arenaMutex);
+		auto& pool = g_arenas[dev];
+		for (size_t i = 0; i < pool.size(); ++i)
+			if (pool[i]->countBytes >= countBytes) {
+				*out = pool[i];
+				pool.erase(pool.begin() + i);
+				return PIRE_HIP_OK;
+			}
+	}
+	std::unique_ptr<HostArena, void (*)(HostArena*)> a(new HostArena, DestroyArena);
+	a->device = dev;
+	a->countBytes = std::max<size_t>(countBytes, 1024);
+	for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+		e = hipStreamCreateWithFlags(&a->stream[k], hipStreamNonBlocking);
+		if (e == hipSuccess)
+			e = hipEventCreateWithFlags(&a->done[k], hipEventDisableTiming);
+	}
+	if (e == hipSuccess)
+		e = hipMalloc(reinterpret_cast<void**>(&a->counts), a->countBytes);
+	if (e == hipSuccess)
+		e = hipEventCreateWithFlags(&a->ready, hipEventDisableTiming);
+	if (e != hipSuccess)
+		return HipFail(e, "staging arena");
+	*out = a.release();
+	return PIRE_HIP_OK;
+}
+
+void ReleaseArena(HostArena* a)
+{
+	std::lock_guard<std::mutex> lock(g_arenaMutex);
+	g_arenas[a->device].push_back(a);
+}
+
+// Returns PIRE_HIP_OK and *done = true when it handled the batch; *done = false (nothing touched) when the batch does
+// not fit the chunking (a string longer than a chunk) and the caller should take the one-shot path.
+int RunHostPipelined(pire_hip_table* t, const ScanParams& base, const uint8_t* text, const uint64_t* offsets, uint64_t n,
+                     uint64_t len, uint64_t stride, const uint32_t* init, uint32_t* outIdx, uint8_t* outFinal,
+                     uint64_t* outCounts, bool* done)
+{
+	*done = false;
+	// chunk boundaries: [first[c], first[c+1]) strings, text bytes [lo, hi) of the caller's buffer
+	std::vector<uint64_t> first{0};
+	if (offsets) {
+		while (first.back() < n) {
+			const uint64_t f = first.back();
+			const uint64_t limit = offsets[f] + kHostChunkBytes;
+			uint64_t l = uint64_t(std::upper_bound(offsets + f + 1, offsets + n + 1, limit) - offsets) - 1;   // last string that still fits
+			l = std::min<uint64_t>(l, f + kHostChunkStrings);
+			if (l == f)
+				return PIRE_HIP_OK;   // a single string larger than a chunk: not this path
+			first.push_back(l);
+		}
+	} else {
+		if (stride > kHostChunkBytes / 64)
+			return PIRE_HIP_OK;
+		uint64_t per = std::min<uint64_t>(kHostChunkBytes / stride, kHostChunkStrings) & ~uint64_t(1023);
+		if (per == 0)
+			per = kHostChunkBytes / stride;
+		for (uint64_t f = per; f < n; f += per)
+			first.push_back(f);
+		first.push_back(n);
+	}
+	const size_t cntBytes = (size_t(t->host.regexps) + 2) * 8;
+	HostArena* arena = nullptr;
+	if (int rc = AcquireArena(cntBytes, &arena))
+		return rc;
+	struct Return {
+		HostArena* a;
+		~Return()
+		{
+			// whatever happened, nothing of this call may still be in flight when the arena goes back to the pool
+			(void)hipStreamSynchronize(a->stream[0]);
+			(void)hipStreamSynchronize(a->stream[1]);
+			ReleaseArena(a);
+		}
+	} giveBack{arena};
+	*done = true;
+	hipError_t e = hipSuccess;
+	if (outCounts) {
+		// the counters are accumulated into: start from the caller's values, both streams wait for them
+		e = hipMemcpyAsync(arena->counts, outCounts, cntBytes, hipMemcpyHostToDevice, arena->stream[0]);
+		if (e == hipSuccess)
+			e = hipEventRecord(arena->ready, arena->stream[0]);
+		if (e == hipSuccess)
+			e = hipStreamWaitEvent(arena->stream[1], arena->ready, 0);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(counts)");
+	}
+	// results of the chunk that used slot k last: out of the pinned staging into the caller's arrays
+	auto drain = [&](size_t c) -> hipError_t {
+		const int k = int(c & 1);
+		hipError_t err = hipEventSynchronize(arena->done[k]);
+		if (err != hipSuccess)
+			return err;
+		const uint64_t f = first[c], cnt = first[c + 1] - f;
+		if (outIdx)
+			memcpy(outIdx + f, arena->hostIdx[k], cnt * 4);
+		if (outFinal)
+			memcpy(outFinal + f, arena->hostFin[k], cnt);
+		return hipSuccess;
+	};
+	const size_t chunks = first.size() - 1;
+	for (size_t c = 0; c < chunks; ++c) {
+		const int k = int(c & 1);
+		hipStream_t s = arena->stream[k];
+		const uint64_t f = first[c], cnt = first[c + 1] - f;
+		if (c >= 2 && (e = drain(c - 2)) != hipSuccess)
+			return HipFail(e, "hipEventSynchronize");
+		{
+			const uint64_t bytes = offsets ? offsets[f + cnt] - (offsets[f] & ~uint64_t(255)) : (cnt - 1) * stride + len;
+			if (int rc = ReserveSlot(arena, k, size_t(bytes) + 2 * kHostChunkSlack, size_t(cnt)))
+				return rc;
+		}
+		ScanParams p = base;
+		p.n = cnt;
+		uint64_t lo, hi;
+		if (offsets) {
+			lo = offsets[f] & ~uint64_t(255);   // keeps every string's alignment as it is in the caller's buffer
+			hi = offsets[f + cnt];
+			p.text = arena->text[k] - lo;       // so that the caller's offsets address the staged copy
+			e = hipMemcpyAsync(arena->offs[k], offsets + f, (cnt + 1) * 8, hipMemcpyHostToDevice, s);
+			p.offsets = arena->offs[k];
+		} else {
+			lo = f * stride;
+			hi = (f + cnt - 1) * stride + len;
+			p.text = arena->text[k];
+			p.offsets = nullptr;
+		}
+		if (e == hipSuccess && hi > lo)
+			e = hipMemcpyAsync(arena->text[k], text + lo, hi - lo, hipMemcpyHostToDevice, s);
+		if (e == hipSuccess && init) {
+			e = hipMemcpyAsync(arena->init[k], init + f, cnt * 4, hipMemcpyHostToDevice, s);
+			p.initIdx = arena->init[k];
+		}
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(H2D)");
+		p.outIdx = outIdx ? arena->idx[k] : nullptr;
+		p.outFinal = outFinal ? arena->fin[k] : nullptr;
+		p.outCounts = outCounts ? arena->counts : nullptr;
+		if (int rc = Dispatch(p, s, NextWorkSlot(t, p), hi - lo))
+			return rc;
+		if (outIdx)
+			e = hipMemcpyAsync(arena->hostIdx[k], arena->idx[k], cnt * 4, hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess && outFinal)
+			e = hipMemcpyAsync(arena->hostFin[k], arena->fin[k], cnt, hipMemcpyDeviceToHost, s);
+		if (e == hipSuccess)
+			e = hipEventRecord(arena->done[k], s);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMemcpy(D2H)");
+	}
+	for (size_t c = chunks >= 2 ? chunks - 2 : 0; c < chunks && e == hipSuccess; ++c)
+		e = drain(c);
+	if (e == hipSuccess && outCounts)
+		e = hipMemcpy(outCounts, arena->counts, cntBytes, hipMemcpyDeviceToHost);
+	if (e != hipSuccess)
+		return HipFail(e, "copy back / synchronize");
+	return PIRE_HIP_OK;
+}
+
 // Shared body of pire_hip_run / pire_hip_run_strided.
 int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint64_t len, uint64_t stride,
             uint32_t flags, const uint32_t* init, uint32_t* outIdx, uint8_t* outFinal, uint64_t* outCounts,
@@ -237,6 +505,22 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		SetError("null text pointer with non-empty strings");
 		return PIRE_HIP_EINVAL;
 	}
+	if (init)
+		for (uint64_t i = 0; i < n; ++i)
+			if (init[i] >= t->host.states) {
+				// host-side array: checking it costs nothing next to the transfer (device-side arrays are the caller's
+				// responsibility, as a state is in the reference: Runner(sc, st) trusts st, run.h:368)
+				SetError("init_state_idx out of range");
+				return PIRE_HIP_EINVAL;
+			}
+	const bool segmented = !(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes);
+	if (!segmented && textBytes >= (size_t(8) << 20) && !g_timing && !getenv("PIRE_HIP_HOST_ONE_SHOT")) {
+		bool done = false;
+		const int rc = RunHostPipelined(t, p, static_cast<const uint8_t*>(text), offsets, n, len, stride, init, outIdx,
+		                                outFinal, outCounts, &done);
+		if (rc || done)
+			return rc;
+	}
 	const uint8_t* dText = nullptr;
 	if (int rc = st.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream))
 		return rc;
@@ -244,17 +528,9 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	if (offsets)
 		if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
 			return rc;
-	if (init) {
-		// host-side array: checking it costs nothing next to the transfer (device-side arrays are the caller's
-		// responsibility, as a state is in the reference: Runner(sc, st) trusts st, run.h:368)
-		for (uint64_t i = 0; i < n; ++i)
-			if (init[i] >= t->host.states) {
-				SetError("init_state_idx out of range");
-				return PIRE_HIP_EINVAL;
-			}
+	if (init)
 		if (int rc = st.In(init, size_t(n), &p.initIdx, stream))
 			return rc;
-	}
 	void* dIdx = nullptr;
 	void* dFin = nullptr;
 	void* dCnt = nullptr;
@@ -277,7 +553,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return HipFail(e, "hipMemcpy(counts)");
 		p.outCounts = static_cast<unsigned long long*>(dCnt);
 	}
-	if (!(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes)) {
+	if (segmented) {
 		if (int rc = RunSegmented(t, p, offsets, stream))
 			return rc;
 	} else if (int rc = Dispatch(p, stream, NextWorkSlot(t, p), textBytes)) {
@@ -810,6 +1086,78 @@ try {
 	return LaunchStep(p, state_idx, n, t->host.cls[ch], static_cast<hipStream_t>(stream));
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
+}
+
+int pire_hip_host_alloc(size_t bytes, void** out)
+try {
+	if (!out) {
+		SetError("null out pointer");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	hipError_t e = hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault);
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipHostMalloc");
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+void pire_hip_host_free(void* p)
+{
+	if (p)
+		(void)hipHostFree(p);
+}
+
+int pire_hip_device_alloc(size_t bytes, void** out)
+try {
+	if (!out) {
+		SetError("null out pointer");
+		return PIRE_HIP_EINVAL;
+	}
+	*out = nullptr;
+	hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMalloc");
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+void pire_hip_device_free(void* p)
+{
+	if (p)
+		(void)hipFree(p);
+}
+
+int pire_hip_copy_to_device(void* dst_device, const void* src_host, size_t bytes, void* stream)
+try {
+	hipError_t e = bytes ? hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream))
+	                     : hipSuccess;
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemcpyAsync(H2D)");
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+int pire_hip_copy_to_host(void* dst_host, const void* src_device, size_t bytes, void* stream)
+try {
+	hipError_t e = bytes ? hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream))
+	                     : hipSuccess;
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemcpyAsync(D2H)");
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+int pire_hip_memset_device(void* dst_device, int value, size_t bytes, void* stream)
+try {
+	hipError_t e = bytes ? hipMemsetAsync(dst_device, value, bytes, static_cast<hipStream_t>(stream)) : hipSuccess;
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemsetAsync");
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+int pire_hip_stream_synchronize(void* stream)
+try {
+	hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipStreamSynchronize");
+} catch (...) {
+	return pirehip::HandleException();
 }
 
 int pire_hip_corpus_fill(void* device_out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len,

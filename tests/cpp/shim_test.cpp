@@ -379,9 +379,100 @@ static void TestLongStrings()
 	CHECK(std::string(pire_hip_last_kernel()).find("segmented") == 0);
 }
 
+// Device-resident text (RunDevice / RunDeviceStrided) and the pipelined host-pointer mode (batches of >= 64 MiB), both
+// against the reference Runner on a sample and against each other on the whole batch; prints the rates of the three
+// ways to hand a batch over (informational: the numbers quoted in DESIGN.md come from this line).
+#include <chrono>
+static double Now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static void TestDeviceMode()
+{
+	typedef Pire::Scanner Scanner;
+	Scanner sc = Scanner::Glue(Parse("hello\\s+w.+d$").Compile<Scanner>(), Parse("Head(Inner)*Tail").Compile<Scanner>());
+	const size_t n = size_t(1) << 16, len = 4096;              // 256 MiB: host mode takes the chunked pipeline
+	void* pinnedRaw = nullptr;
+	Pire::Hip::Check(pire_hip_host_alloc(n * len, &pinnedRaw));
+	char* pinned = static_cast<char*>(pinnedRaw);
+	std::vector<char> pageable(n * len);
+	uint64_t h = 88172645463325252ull;
+	for (size_t i = 0; i < n * len; i += 8) {                  // printable bytes, xorshift64
+		h ^= h << 13; h ^= h >> 7; h ^= h << 17;
+		for (int b = 0; b < 8; ++b)
+			pageable[i + b] = char(0x20 + ((h >> (8 * b)) & 0xFF) % 95);
+	}
+	const char* w1 = "hello   world";
+	const char* w2 = "HeadInnerInnerTail";
+	for (size_t s = 0; s < n; s += 3) {
+		memcpy(&pageable[s * len + len - strlen(w1)], w1, strlen(w1));          // '$'-anchored: at the tail
+		if (s % 2 == 0)
+			memcpy(&pageable[s * len + 1000 + s % 1000], w2, strlen(w2));       // unanchored: somewhere
+	}
+	memcpy(pinned, pageable.data(), n * len);
+	std::vector<uint64_t> offs(n + 1);
+	for (size_t i = 0; i <= n; ++i)
+		offs[i] = i * len;
+
+	Pire::Hip::Table<Scanner> table(sc);
+	// host pointers, pageable and pinned
+	Pire::Hip::BatchRunner<Scanner> host(table);
+	host.Begin().Run(pageable.data(), offs.data(), n).End().MatchCounts();      // warm-up: uploads the table
+	double t0 = Now();
+	Pire::Hip::BatchRunner<Scanner> host2(table);
+	const std::vector<Scanner::State> viaHost = host2.Begin().Run(pageable.data(), offs.data(), n).End().States();
+	const double hostSec = Now() - t0;
+	t0 = Now();
+	Pire::Hip::BatchRunner<Scanner> host3(table);
+	const std::vector<Scanner::State> viaPinned = host3.Begin().Run(pinned, offs.data(), n).End().States();
+	const double pinnedSec = Now() - t0;
+	CHECK(viaHost.size() == n && viaPinned == viaHost);
+	CHECK(host2.MatchCounts() == host3.MatchCounts() && host2.MatchCounts()[1] == n);
+	for (size_t i = 0; i < n; i += 997) {
+		Scanner::State want = Pire::Runner(sc).Begin().Run(pageable.data() + i * len, len).End().State();
+		CHECK(viaHost[i] == want);
+	}
+	CHECK(host2.MatchCounts()[0] >= n / 3);
+
+	// device-resident text
+	void* dText = nullptr;
+	void* dOffs = nullptr;
+	Pire::Hip::Check(pire_hip_device_alloc(n * len, &dText));
+	Pire::Hip::Check(pire_hip_device_alloc((n + 1) * 8, &dOffs));
+	Pire::Hip::Check(pire_hip_copy_to_device(dText, pinned, n * len, nullptr));
+	Pire::Hip::Check(pire_hip_copy_to_device(dOffs, offs.data(), (n + 1) * 8, nullptr));
+	Pire::Hip::Check(pire_hip_stream_synchronize(nullptr));
+	Pire::Hip::BatchRunner<Scanner> dev(table);
+	dev.Begin().End();
+	CHECK(dev.RunDeviceStrided(dText, n, len, len).MatchCounts() == host2.MatchCounts());
+	CHECK(dev.States() == viaHost);
+	const int reps = 20;
+	t0 = Now();
+	for (int r = 0; r < reps; ++r)
+		dev.RunDeviceStrided(dText, n, len, len).MatchCounts();
+	const double devSec = (Now() - t0) / reps;
+	CHECK(dev.RunDevice(dText, static_cast<const uint64_t*>(dOffs), n).MatchCounts() == host2.MatchCounts());   // ragged kernel
+	CHECK(dev.States() == viaHost);
+	CHECK(dev.DeviceStateIndices() != nullptr && dev.DeviceFinals() != nullptr);
+	// resumed states on the device: first halves, then second halves from the returned states
+	{
+		Pire::Hip::BatchRunner<Scanner> a(table), b(table);
+		const std::vector<Scanner::State> mid = a.Begin().RunDeviceStrided(dText, n, len / 2, len).States();
+		const std::vector<Scanner::State> end =
+		    b.From(mid).RunDeviceStrided(static_cast<const char*>(dText) + len / 2, n, len / 2, len).End().States();
+		CHECK(end == viaHost);
+	}
+	const double gb = double(n * len) / 1e9;
+	printf("shim rates, %zu x %zu B (%.0f MiB): host pointers pageable %.1f GB/s, pinned (pire_hip_host_alloc) %.1f GB/s, "
+	       "device-resident (RunDeviceStrided + MatchCounts) %.1f GB/s\n",
+	       n, len, double(n * len) / 1048576.0, gb / hostSec, gb / pinnedSec, gb / devSec);
+	pire_hip_device_free(dText);
+	pire_hip_device_free(dOffs);
+	pire_hip_host_free(pinned);
+}
+
 int main()
 {
 	try {
+		TestDeviceMode();
 		TestLongStrings();
 		TestPrefixAndSlow();
 		TestCapture();
