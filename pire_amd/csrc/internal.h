@@ -119,6 +119,7 @@ struct HostTable {
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
+	std::vector<double> seenMass;     // [states] what the scans so far visited (lane-steps, halved at every adapt(); orig numbering)
 	std::vector<double> priorMass;    // [states] expected visits under the byte model, max-normalised (orig numbering)
 	uint64_t lastTrapSamples = 0;     // cold-state samples seen by the most recent pire_hip_table_adapt()
 	uint32_t adaptations = 0;

@@ -13,9 +13,11 @@ namespace pirehip {
 //     per launch, not one per wave: same-address device atomics run at well under 100 per microsecond); waves take
 //     64 strings at a time from their block's range in LDS; lanes take single strings from their wave's range by
 //     ballot + mbcnt.
-//   * every lane walks its string in windows of up to 128 bytes (8 x global_load_dwordx4 from its own address).  A
-//     window starts at the string's current byte whatever its alignment, so a string of <= 128 bytes is ONE window; a
-//     longer string cuts its first window at a 16-byte boundary and is aligned from then on.  The window of the NEXT iteration -- the same string's next 128 bytes, or the first window of
+//   * every lane walks its string in windows of up to 128 bytes.  A window starts at the string's current byte
+//     whatever its alignment, so a string of <= 128 bytes is ONE window; a longer string cuts its first window at the
+//     next 128-byte line boundary and reads whole aligned lines from then on.  The 64 windows of a wave are fetched by
+//     groups of 8 lanes (IssueTileGroup: 8 lanes x 16 bytes = one window per instruction and group) and transposed in
+//     registers.  The window of the NEXT iteration -- the same string's next 128 bytes, or the first window of
 //     the lane's pending next string, whose offsets were fetched an iteration earlier -- is in flight while the
 //     current one is walked; nothing on the common path makes the compiler wait for memory during the walk (the
 //     end-of-string records of the hot states are in LDS for that reason).
@@ -33,7 +35,12 @@ struct RaggedGrab {
 };
 
 struct RaggedWork {
-	unsigned long long next, end;   // the block's current range of string indices
+	// the block's current range of string indices, in ONE word: end << 32 | next.  Waves take from it with a plain
+	// ds_add_rtn_u64 (no lock: with short strings every wave comes here every iteration or two, and queueing 16 waves
+	// behind a spin lock was the largest single cost of such batches); only the refill from the global counter, a few
+	// times per block and launch, is serialised.
+	unsigned long long range;
+	unsigned long long pad0;
 	uint32_t lock, exhausted;
 	uint32_t pad[2];
 };
@@ -52,6 +59,32 @@ __device__ __forceinline__ void IssueTileLane(u32x4 (&r)[8], uint64_t src)
 		"global_load_dwordx4 %7, %8, off offset:112"
 		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
 		: "v"(src));
+}
+
+// The same 64 windows fetched by GROUPS of 8 lanes: instruction j loads, in every group, the window of lane 8g+j --
+// lane 8g+c reads its bytes [16c, 16c+16) -- so that an instruction touches the 1-2 cache lines of 8 windows instead of
+// one line of each of 64 strings (and of 64 different ones again 16 bytes further): the L1 tag pipeline was the binding
+// unit of this kernel (profiles/r02_ragged_pmc_*_before.txt: 0.98 L1 accesses per clock and CU on URLs, HBM traffic
+// 1.6-1.8 x the text because lines were evicted between the 8 instructions that touched them).  The tile then holds,
+// in lane 8g+c, register j = chunk c of the window of lane 8g+j: TransposeTile() (the tiled kernel's) puts every
+// lane's own window into its registers 0..7, and the walk is what it was.
+// `src` = this lane's window address (any alignment); the addresses travel inside the group through ds_bpermute.
+// (Tried: per-lane loads and no transpose in the iterations in which every lane of the wave is in the middle of a long
+// string -- one whole line per lane is the better pattern there: fixed 4 KiB strings 3.3 against 2.8 TB/s.  A transpose
+// under a wave-uniform branch made hipcc spill 170-320 bytes per lane, tile registers included; not kept.  Fixed-length
+// batches belong to the tiled kernel anyway.)
+__device__ __forceinline__ void IssueTileGroup(u32x4 (&r)[8], uint64_t src, uint32_t lane)
+{
+	const uint32_t lo = uint32_t(src), hi = uint32_t(src >> 32);
+	const uint32_t sel = (lane & ~7u) << 2;      // byte index of lane 8g for ds_bpermute
+	const uint32_t mine = (lane & 7u) << 4;      // this lane's 16 bytes of every window of its group
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t l = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * j), int(lo)));
+		const uint32_t h = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * j), int(hi)));
+		const uint64_t a = ((uint64_t(h) << 32) | l) + mine;
+		asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r[j]) : "v"(a));
+	}
 }
 
 __device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
@@ -125,8 +158,15 @@ __device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* 
 // re-walked exactly, from its start state, with the action called after every step.  Scans that are rarely in a
 // Final state run at nearly the speed of the plain ragged kernel; scans that always are degrade to the exact walk
 // the one-string-per-lane kernels of exact.hip do all the time.
+#ifdef PIRE_HIP_RAGGED_LANE_LOADS   // A/B builds (tools/ab): every kernel with the per-lane loads of round 1
+constexpr bool kRaggedGroupLoads = false;
+#else
+constexpr bool kRaggedGroupLoads = true;
+#endif
+
 struct NoAct {
 	static constexpr bool kActive = false;
+	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	struct Lane {};
 };
 
@@ -135,6 +175,7 @@ struct NoAct {
 // from the packed increment word of the state (table.cpp, inc64).
 struct HalfFinalAct {
 	static constexpr bool kActive = true;
+	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	uint32_t* results;
 	struct Lane {
 		uint32_t c[8];
@@ -203,6 +244,7 @@ struct HalfFinalAct {
 // where a Final state really was visited.
 struct HalfFinalWideAct {
 	static constexpr bool kActive = true;
+	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	uint32_t* results;
 	struct Lane {
 		uint32_t* row;
@@ -255,6 +297,9 @@ struct HalfFinalWideAct {
 // state no longer matters) and idles through the rest of its string.
 struct PrefixAct {
 	static constexpr bool kActive = true;
+	// per-lane loads: with the transpose's temporaries on top of its own per-lane state this instantiation needs more
+	// than the 128 VGPRs of 16 waves per CU (12 bytes of scratch -- and a spilled tile register is unsafe)
+	static constexpr bool kGroupLoads = false;
 	long long* outLen;
 	uint32_t longest, throughEnd;
 	struct Lane {
@@ -515,25 +560,37 @@ __device__ __forceinline__ void GrabWaveRange(const ScanParams& p, volatile Ragg
 {
 	unsigned long long r0 = 0, r1 = 0;
 	if ((threadIdx.x & 63) == 0) {
-		while (atomicCAS(const_cast<uint32_t*>(&work->lock), 0u, 1u) != 0u)
-			__builtin_amdgcn_s_sleep(2);
-		unsigned long long nx = work->next, en = work->end;
-		if (nx >= en && !work->exhausted) {
-			const unsigned long long base = atomicAdd(workCounter, (unsigned long long)grab.block);
-			if (base >= p.n) {
-				work->exhausted = 1;
+		unsigned long long* range = const_cast<unsigned long long*>(&work->range);
+		for (;;) {
+			const unsigned long long old = atomicAdd(range, (unsigned long long)grab.wave);
+			const unsigned long long nx = old & 0xFFFFFFFFull, en = old >> 32;
+			if (nx < en) {
+				r0 = nx;
+				r1 = nx + grab.wave < en ? nx + grab.wave : en;
+				break;
+			}
+			// the block's range is used up (the add overshot `next`: harmless, the refill rewrites the word; it cannot
+			// wrap either: at most 16 waves overshoot by grab.wave <= 256 each, and n < 2^32 - 2^16 is checked by the
+			// launcher)
+			if (work->exhausted)
+				break;
+			if (atomicCAS(const_cast<uint32_t*>(&work->lock), 0u, 1u) == 0u) {
+				const unsigned long long cur = *const_cast<volatile unsigned long long*>(range);
+				if ((cur & 0xFFFFFFFFull) >= (cur >> 32) && !work->exhausted) {   // still empty: this wave refills
+					const unsigned long long base = atomicAdd(workCounter, (unsigned long long)grab.block);
+					if (base >= p.n) {
+						work->exhausted = 1;
+					} else {
+						const unsigned long long e2 = base + grab.block < p.n ? base + grab.block : p.n;
+						atomicExch(range, (e2 << 32) | base);
+					}
+				}
+				__threadfence_block();
+				atomicExch(const_cast<uint32_t*>(&work->lock), 0u);
 			} else {
-				nx = base;
-				en = base + grab.block < p.n ? base + grab.block : p.n;
+				__builtin_amdgcn_s_sleep(2);   // another wave is refilling
 			}
 		}
-		const unsigned long long take = en - nx < grab.wave ? en - nx : grab.wave;
-		r0 = nx;
-		r1 = nx + take;
-		work->next = r1;
-		work->end = en;
-		__threadfence_block();
-		atomicExch(const_cast<uint32_t*>(&work->lock), 0u);
 	}
 	R.next = Uniform64(r0);
 	R.end = Uniform64(r1);
@@ -584,14 +641,19 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
                                             const Act& act, typename Act::Lane& al)
 {
 	WaitAllLoads(cur);
+	if constexpr (Act::kGroupLoads)
+		TransposeTile(cur, threadIdx.x & 63);
 
 	// ---- this window: starts at the string's current byte, whatever its alignment.  A string that fits takes one
-	// window; a longer one cuts its first window at a 16-byte boundary so that all the following ones are aligned.
+	// window; a longer one cuts its first window at a line boundary so that all the following ones are whole lines.
 	uint64_t left = S.end - S.pos;
 	if constexpr (Act::kActive)
 		if (S.busy && !act.Wants(al))
 			left = 0;   // the search is over: the rest of the string is not needed, the lane moves on
-	const uint32_t nb = !S.busy ? 0u : left <= 128u ? uint32_t(left) : 128u - (uint32_t(S.pos) & 15u);
+	// a string that does not fit one window cuts its first window at the next 128-byte LINE boundary: from then on it
+	// reads whole aligned lines, each exactly once (cut at 16-byte boundaries only, every line of a long string was
+	// fetched by two windows 5-10 us apart and often twice from HBM: 1.7 x the text, profiles/r02_ragged_pmc_*)
+	const uint32_t nb = !S.busy ? 0u : left <= 128u ? uint32_t(left) : 128u - (uint32_t(S.pos) & 127u);
 	const bool ends = S.busy && nb == left;
 
 	// ---- the next window: the same string's next bytes, or the pending string's first window
@@ -604,8 +666,12 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	const bool nLoad = nBusy && nEnd > nPos && nPos + 128 <= safeEnd;
 	// unconditional (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
 	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives
-	if (!(p.flags & kDebugNoRefill))
-		IssueTileLane(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows));
+	if (!(p.flags & kDebugNoRefill)) {
+		if constexpr (Act::kGroupLoads)
+			IssueTileGroup(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows), threadIdx.x & 63);
+		else
+			IssueTileLane(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows));
+	}
 	if (takeNew)
 		S.pend = false;
 	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
@@ -724,8 +790,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 			act.LoadLds(p, reinterpret_cast<uint8_t*>(finHot));   // the actions' own LDS data take that place
 		}
 		if (threadIdx.x == 0) {
-			work->next = 0;
-			work->end = 0;
+			work->range = 0;
 			work->lock = 0;
 			work->exhausted = 0;
 		}
@@ -770,7 +835,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 {
 	// one string per lane with dynamic re-assignment: worth it from a few waves' worth of strings
-	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && totalBytesHint >= 4096;
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) - (1ull << 16) && totalBytesHint >= 4096;
 }
 
 namespace {
@@ -836,7 +901,7 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 // whose counters do not pack, the one-string-per-lane kernels of exact.hip).
 bool RaggedActEligible(const ScanParams& p)
 {
-	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) && !getenv("PIRE_HIP_NO_RAGGED_ACT");
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) - (1ull << 16) && !getenv("PIRE_HIP_NO_RAGGED_ACT");
 }
 
 int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream)

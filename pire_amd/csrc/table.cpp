@@ -1028,8 +1028,14 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 	}
 	// hot ids are sampled once per wave per 128-byte tile (1 of 64*128 lane-steps), cold ids once per trapped
 	// 16-byte chunk for one rotating lane of 64 (1 of 64*16 lane-steps): bring both to "lane-steps".
+	// The estimates are remembered from one adapt() to the next (halved each time): the counters are samples, a state
+	// that carries 1e-5 of the steps often has none in a given batch, and a ranking from the latest counters alone
+	// dropped such rows at every other call only to see them trap again (URL batches: 35-43 rows changed at EVERY
+	// adapt(), trap re-walks 19 % of the kernel time; profiles/r02_ragged_ablation.log).
 	std::vector<double> score(N);
 	uint64_t coldSamples = 0;
+	if (h.seenMass.size() != N)
+		h.seenMass.assign(N, 0.0);
 	for (uint32_t pid = 0; pid < N; ++pid) {
 		const uint32_t o = h.origOfPerm[pid];
 		double est = double(cold[pid]) * 1024.0;
@@ -1037,7 +1043,8 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 			est += double(hot[pid]) * 8192.0;
 		if (pid >= H)
 			coldSamples += cold[pid];
-		score[o] = est + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
+		h.seenMass[o] = 0.5 * h.seenMass[o] + est;
+		score[o] = h.seenMass[o] + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
 	}
 	h.lastTrapSamples = coldSamples;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);

@@ -69,70 +69,7 @@ __device__ __forceinline__ void WaitTile(u32x4 (&r)[8])
 	             : "n"(TILES_BEHIND * 8));
 }
 
-// One butterfly stage of the 8x8 transpose: exchange (register bit D) with (lane bit D) for the pair x = reg k,
-// y = reg k|D:   x'[l] = (l & D) ? y[l ^ D] : x[l],    y'[l] = (l & D) ? y[l] : x[l ^ D].
-// D = 4: two bank-masked DPP moves (row_shr:4 into banks 1,3; row_shl:4 into banks 0,2).
-__device__ __forceinline__ void Butterfly4(uint32_t& x, uint32_t& y)
-{
-	const uint32_t nx = __builtin_amdgcn_update_dpp(x, y, 0x114, 0xF, 0xA, false);
-	const uint32_t ny = __builtin_amdgcn_update_dpp(y, x, 0x104, 0xF, 0x5, false);
-	x = nx;
-	y = ny;
-}
-
-// D = 1 or 2: the partner lane sits in the same quad; one FUSED v_cndmask_b32_dpp per output (hipcc does not form
-// it from v_mov_dpp + v_cndmask: the select mask would have to be inverted for half of them).  `lo` = lanes whose
-// bit D is clear, `hi` = lanes whose bit D is set (64-bit wave masks).  Four pairs per statement, one column.
-#define PIRE_BFLY_QUAD(PERM)                                                                                           \
-	asm volatile("s_nop 1\n\t"                                                                                     \
-	             "s_mov_b64 vcc, %16\n\t"                                                                           \
-	             "v_cndmask_b32_dpp %0, %9, %8, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
-	             "v_cndmask_b32_dpp %2, %11, %10, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
-	             "v_cndmask_b32_dpp %4, %13, %12, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
-	             "v_cndmask_b32_dpp %6, %15, %14, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
-	             "s_mov_b64 vcc, %17\n\t"                                                                           \
-	             "v_cndmask_b32_dpp %1, %8, %9, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                       \
-	             "v_cndmask_b32_dpp %3, %10, %11, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
-	             "v_cndmask_b32_dpp %5, %12, %13, vcc " PERM " row_mask:0xf bank_mask:0xf\n\t"                     \
-	             "v_cndmask_b32_dpp %7, %14, %15, vcc " PERM " row_mask:0xf bank_mask:0xf"                          \
-	             : "=&v"(nx0), "=&v"(ny0), "=&v"(nx1), "=&v"(ny1), "=&v"(nx2), "=&v"(ny2), "=&v"(nx3), "=&v"(ny3)    \
-	             : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "s"(lo), "s"(hi)          \
-	             : "vcc")
-
-// v_cndmask: D = vcc ? src1 : src0, DPP permutes src0.  With vcc = lo:  x' = lo ? x : perm(y);  with vcc = hi:
-// y' = hi ? y : perm(x).
-template <int D>
-__device__ __forceinline__ void ButterflyQuad4(uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1, uint32_t& x2,
-                                               uint32_t& y2, uint32_t& x3, uint32_t& y3, uint64_t lo, uint64_t hi)
-{
-	uint32_t nx0, ny0, nx1, ny1, nx2, ny2, nx3, ny3;
-	if (D == 1)
-		PIRE_BFLY_QUAD("quad_perm:[1,0,3,2]");
-	else
-		PIRE_BFLY_QUAD("quad_perm:[2,3,0,1]");
-	x0 = nx0; y0 = ny0; x1 = nx1; y1 = ny1; x2 = nx2; y2 = ny2; x3 = nx3; y3 = ny3;
-}
-
-__device__ __forceinline__ void TransposeTile(u32x4 (&r)[8], uint32_t lane)
-{
-	(void)lane;
-	const uint64_t lo1 = 0x5555555555555555ull, hi1 = 0xAAAAAAAAAAAAAAAAull;   // lane bit 0 clear / set
-	const uint64_t lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;   // lane bit 1 clear / set
-#pragma unroll
-	for (int w = 0; w < 4; ++w) {
-		uint32_t d[8];
-#pragma unroll
-		for (int k = 0; k < 8; ++k)
-			d[k] = r[k][w];
-		ButterflyQuad4<1>(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], lo1, hi1);
-		ButterflyQuad4<2>(d[0], d[2], d[1], d[3], d[4], d[6], d[5], d[7], lo2, hi2);
-		Butterfly4(d[0], d[4]); Butterfly4(d[1], d[5]); Butterfly4(d[2], d[6]); Butterfly4(d[3], d[7]);
-#pragma unroll
-		for (int k = 0; k < 8; ++k)
-			r[k][w] = d[k];
-		__builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the transpose's temporaries to ~10 VGPRs
-	}
-}
+// (Butterfly4 / ButterflyQuad4 / TransposeTile: device_common.h, shared with the ragged kernel.)
 
 // The hot rows sit at LDS byte address 0 (the kernels declare no static __shared__, so the dynamic region
 // starts at 0): the v_perm result IS the ds_read address, with no base add in the dependent chain.

@@ -44,4 +44,7 @@ for r in range(reps + 2):
     torch.cuda.synchronize()
     if r >= 2:
         ts.append(a.elapsed_time(b))
+torch.cuda.synchronize()
+ch = t.adapt()
+print("after the timed runs: adapt changed", ch, "rows; trap samples seen", t.refresh_info().last_trap_samples)
 print("%s %s: %d strings, %.3f GiB, min %.3f ms -> %.1f GB/s" % (pb.last_kernel(), case, m, total / 2**30, min(ts), total / min(ts) / 1e6))
