@@ -166,7 +166,8 @@ def bench_slow(args):
     table = pire_amd.SlowTable(blob)
     torch.cuda.set_device(0)
     n, length = args.strings or (1 << args.log2_strings), args.len
-    plants = pb.make_plants([(b"x" + b"y" * 40, True), (b"zx" + b"w" * 39, True)])   # one witness, one near miss
+    gap = int(case["pattern"].split("{")[1].split("}")[0]) if "{" in case["pattern"] else 40
+    plants = pb.make_plants([(b"x" + b"y" * min(gap, 60), True), (b"zx" + b"w" * min(gap - 1, 59), True)])   # witness (for x.{40}$) / near miss
     text = torch.empty((n, length), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
     pire_amd.corpus_fill_device(text.data_ptr(), SEED, 0, n, length, length, plants, stream)

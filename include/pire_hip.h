@@ -250,7 +250,10 @@ float pire_hip_last_kernel_ms(void);
  * Pire::SlowScanner (pire/scanners/slow.h:51-420): NFA simulation for patterns whose DFA would not fit anywhere
  * (e.g. /x.{40}$/).  Its state is the SET of active NFA states (slow.h:63-74), so results are the Final flag
  * (slow.h:152-158) and, optionally, the set itself as a bitset.  Ingests SlowScanner::Save() bytes
- * (pire/scanner_io.cpp:71-111).  GPU limit: 256 NFA states (8-word sets in registers).
+ * (pire/scanner_io.cpp:71-111).  Up to 256 NFA states the set of a string lives in the registers of ONE lane
+ * (one string per lane); larger automata -- the reference has no limit, easy.h:155-161 falls back to this scanner
+ * exactly when determinisation blows up -- keep the reference's sparse jump lists and give every string a whole wave
+ * (the set is a bitset in LDS, or in device memory when 2 * states / 8 bytes do not fit there).
  */
 typedef struct pire_hip_slow_table pire_hip_slow_table;
 

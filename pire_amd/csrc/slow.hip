@@ -10,6 +10,10 @@
 // Device form: for every (state, letter) a K-word bitmask of the jump list (the CSR lists of the reference turned
 // into rows), kept in LDS when it fits; a step is  next = OR over active s of mask[s][letter].  Work per byte is
 // O(active states * K), as in the reference -- this is the scanner for automata whose DFA would not fit anywhere.
+// That form holds up to 256 NFA states (8 words per lane).  Beyond it (SlowWideKernel, below) the reference's own
+// sparse form is kept -- the CSR jump lists -- and ONE WAVE walks one string: the set is a bitset of any size in LDS
+// (or in device memory when it does not fit), the wave finds the active states word by word and its lanes share the
+// targets of every active state's jump list.  No limit on the number of states but the scanner's own (2^20 here).
 
 #include <hip/hip_runtime.h>
 
@@ -30,6 +34,10 @@ struct SlowHost {
 	std::vector<uint32_t> masks;       // [states*letters][words]
 	std::vector<uint32_t> single;      // [states*letters][2] the (up to two) targets of the jump list, or kSlowMulti
 	std::vector<uint32_t> finals;      // [words] bitset of final states
+	// the reference's sparse form (m_jumpPos / m_jumps, slow.h:351-352), kept for scanners of more than 256 states
+	std::vector<uint32_t> jumpPos;     // [states*letters + 1]
+	std::vector<uint32_t> jumps;       // targets
+	bool wide = false;                 // more than 256 states: masks / single are not built
 };
 
 struct SlowDevice {
@@ -38,6 +46,8 @@ struct SlowDevice {
 	uint32_t* masks = nullptr;
 	uint32_t* single = nullptr;
 	uint32_t* finals = nullptr;
+	uint32_t* jumpPos = nullptr;
+	uint32_t* jumps = nullptr;
 };
 
 constexpr uint32_t kSlowNone = 0xFFFFFFFFu;    // no target / empty list slot
@@ -58,6 +68,9 @@ struct SlowParams {
 	const uint32_t* masks;
 	const uint32_t* single;
 	const uint32_t* finals;
+	const uint32_t* jumpPos;   // wide form
+	const uint32_t* jumps;
+	uint32_t* scratch;         // wide form, sets that do not fit the LDS: [waves][2][words]
 	uint32_t states, letters, start, words, flags, masksInLds, singleInLds;
 	const uint8_t* text;
 	const uint64_t* offsets;   // nullable: strided
@@ -299,6 +312,151 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 	}
 }
 
+// ---- more than 256 NFA states: one wave per string, sparse jump lists ---------------------------------------------------
+// cur / next are bitsets of `words` words (LDS, or device memory through the same flat pointers).  A step
+//   next = {};  for every active state s:  for every t in jumps[jumpPos[s*letters+l] .. jumpPos[s*letters+l+1]):  next |= {t}
+// is NextTranslated (slow.h:103-130) with the wave as the worker: lanes scan 64 words of `cur` at a time, the non-zero
+// ones are broadcast one by one (readlane), every set bit is an active state, and its jump list is spread over the lanes
+// (atomic OR into `next`: duplicates fall together as in the reference's flags.Test / Set).
+// The sets are shared by the 64 lanes of ONE wave and nobody else; every phase (clear, scatter, read) ends with a fence
+// + wave barrier.  LDS form: a workgroup-scope fence is a wait for the wave's own LDS operations, which the hardware
+// keeps in order.  Device-memory form: words are read and written with relaxed device-scope atomics and the fence is
+// device scope, so that a lane never meets a stale L1 line of a word another lane of its wave wrote.
+template <bool SETS_LDS>
+__device__ __forceinline__ void WideSync()
+{
+	if (SETS_LDS)
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+	else
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+	__builtin_amdgcn_wave_barrier();
+}
+template <bool SETS_LDS>
+__device__ __forceinline__ uint32_t WideLoad(const uint32_t* q)
+{
+	if (SETS_LDS)
+		return *q;
+	return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool SETS_LDS>
+__device__ __forceinline__ void WideStore(uint32_t* q, uint32_t v)
+{
+	if (SETS_LDS)
+		*q = v;
+	else
+		__hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+struct WideTables {
+	const uint32_t* pos;     // jumpPos: LDS copy or device memory
+	const uint32_t* jumps;
+};
+
+template <bool SETS_LDS>
+__device__ __forceinline__ void WideStep(const SlowParams& p, const WideTables& T, uint32_t*& cur, uint32_t*& next,
+                                         uint32_t letter, uint32_t lane)
+{
+	for (uint32_t w = lane; w < p.words; w += 64)
+		WideStore<SETS_LDS>(&next[w], 0u);
+	WideSync<SETS_LDS>();
+	for (uint32_t w0 = 0; w0 < p.words; w0 += 64) {
+		const uint32_t mine = w0 + lane < p.words ? WideLoad<SETS_LDS>(&cur[w0 + lane]) : 0u;
+		unsigned long long nz = __ballot(mine != 0);
+		while (nz) {
+			const int j = __builtin_ctzll(nz);
+			nz &= nz - 1;
+			uint32_t bits = uint32_t(__builtin_amdgcn_readlane(int(mine), j));
+			const uint32_t base = (w0 + uint32_t(j)) * 32;
+			while (bits) {
+				const uint32_t s = base + uint32_t(__builtin_ctz(bits));
+				bits &= bits - 1;
+				const uint32_t* pos = T.pos + size_t(s) * p.letters + letter;
+				const uint32_t lo = pos[0], hi = pos[1];
+				for (uint32_t k = lo + lane; k < hi; k += 64) {
+					const uint32_t t = T.jumps[k];
+					atomicOr(&next[t >> 5], 1u << (t & 31));
+				}
+			}
+		}
+	}
+	WideSync<SETS_LDS>();
+	uint32_t* tmp = cur;
+	cur = next;
+	next = tmp;
+}
+
+// LDS: [264 letters, padded to 272][jumpPos when posInLds][jumps when jumpsInLds][2 * words per wave when SETS_LDS]
+template <bool SETS_LDS>
+__global__ __launch_bounds__(1024) void SlowWideKernel(SlowParams p, uint32_t wavesPerBlock, uint32_t posInLds,
+                                                       uint32_t jumpsInLds, uint32_t njumps)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* ldsLetter = lds;
+	uint32_t* ldsPos = reinterpret_cast<uint32_t*>(lds + 272);
+	const uint32_t npos = p.states * p.letters + 1;
+	uint32_t* ldsJumps = ldsPos + (posInLds ? npos : 0);
+	uint32_t* ldsSets = ldsJumps + (jumpsInLds ? njumps : 0);
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		ldsLetter[i] = p.letterOf[i];
+	if (posInLds)
+		for (uint32_t i = threadIdx.x; i < npos; i += blockDim.x)
+			ldsPos[i] = p.jumpPos[i];
+	if (jumpsInLds)
+		for (uint32_t i = threadIdx.x; i < njumps; i += blockDim.x)
+			ldsJumps[i] = p.jumps[i];
+	__syncthreads();
+	WideTables T;
+	T.pos = posInLds ? ldsPos : p.jumpPos;
+	T.jumps = jumpsInLds ? ldsJumps : p.jumps;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint64_t gwave = uint64_t(blockIdx.x) * wavesPerBlock + wave;
+	uint32_t* setA = SETS_LDS ? ldsSets + size_t(wave) * 2 * p.words : p.scratch + gwave * 2 * p.words;
+	uint32_t* setB = setA + p.words;
+	unsigned long long finals = 0, strings = 0;
+	for (uint64_t s = gwave; s < p.n; s += uint64_t(gridDim.x) * wavesPerBlock) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		uint32_t *cur = setA, *next = setB;
+		for (uint32_t w = lane; w < p.words; w += 64)                    // Initialize, slow.h:89-95: { start }
+			WideStore<SETS_LDS>(&cur[w], (p.start >> 5) == w ? 1u << (p.start & 31) : 0u);
+		WideSync<SETS_LDS>();
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			WideStep<SETS_LDS>(p, T, cur, next, ldsLetter[kBeginMark], lane);         // Begin(), run.h:375
+		for (uint64_t i = b; i < e; i += 64) {                           // Run<SlowScanner>, slow.h:436-451
+			const uint32_t mine = i + lane < e ? p.text[i + lane] : 0u;  // 64 bytes per load, one per lane
+			const uint32_t cnt = e - i < 64 ? uint32_t(e - i) : 64u;
+			for (uint32_t k = 0; k < cnt; ++k)
+				WideStep<SETS_LDS>(p, T, cur, next, ldsLetter[__builtin_amdgcn_readlane(int(mine), int(k))], lane);
+		}
+		if (p.flags & PIRE_HIP_RUN_END)
+			WideStep<SETS_LDS>(p, T, cur, next, ldsLetter[kEndMark], lane);           // End(), run.h:376
+		bool fin = false;                                                // Final, slow.h:152-158
+		for (uint32_t w = lane; w < p.words; w += 64) {
+			const uint32_t v = WideLoad<SETS_LDS>(&cur[w]);
+			fin = fin || (v & p.finals[w]) != 0;
+			if (p.outBits)
+				p.outBits[s * p.words + w] = v;
+		}
+		fin = __any(fin);
+		if (p.outFinal && lane == 0)
+			p.outFinal[s] = fin ? 1 : 0;
+		finals += fin ? 1 : 0;
+		strings += 1;
+		WideSync<SETS_LDS>();
+	}
+	if (p.outCounts && lane == 0 && strings) {
+		atomicAdd(&p.outCounts[0], finals);
+		atomicAdd(&p.outCounts[1], strings);
+	}
+}
+
 namespace {
 
 size_t Up8(size_t v) { return (v + 7) & ~size_t(7); }
@@ -378,18 +536,34 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 	const uint64_t njumps = jumpPos[npos - 1];
 	if (len < pos + Up8(size_t(njumps) * 4))
 		return BadSlow("EOF reached while reading SlowScanner jumps");
-	h.masks.assign(size_t(states) * letters * h.words, 0);
-	for (size_t i = 0; i + 1 < npos; ++i) {
+	if (njumps >= (1ull << 32))
+		return BadSlow("Corrupt SlowScanner: too many jumps");
+	for (size_t i = 0; i + 1 < npos; ++i)
 		if (jumpPos[i] > jumpPos[i + 1] || jumpPos[i + 1] > njumps)
 			return BadSlow("Corrupt SlowScanner: jump positions not monotone");
+	for (uint64_t k = 0; k < njumps; ++k) {
+		uint32_t tgt;
+		memcpy(&tgt, p + pos + size_t(k) * 4, 4);
+		if (tgt >= states)
+			return BadSlow("Corrupt SlowScanner: jump target out of range");
+	}
+	h.wide = h.words > 8;
+	if (h.wide) {
+		// more than 256 states: the sparse form as it is (a dense (state, letter) -> set matrix would be quadratic)
+		h.jumpPos.resize(npos);
+		for (size_t i = 0; i < npos; ++i)
+			h.jumpPos[i] = uint32_t(jumpPos[i]);
+		h.jumps.resize(size_t(njumps));
+		memcpy(h.jumps.data(), p + pos, size_t(njumps) * 4);
+		return PIRE_HIP_OK;
+	}
+	h.masks.assign(size_t(states) * letters * h.words, 0);
+	for (size_t i = 0; i + 1 < npos; ++i)
 		for (uint64_t k = jumpPos[i]; k < jumpPos[i + 1]; ++k) {
 			uint32_t tgt;
 			memcpy(&tgt, p + pos + size_t(k) * 4, 4);
-			if (tgt >= states)
-				return BadSlow("Corrupt SlowScanner: jump target out of range");
 			h.masks[i * h.words + (tgt >> 5)] |= 1u << (tgt & 31);
 		}
-	}
 	// the first two distinct targets of every jump list, for the list form of the walk: [2*i] and [2*i+1], kSlowNone
 	// where there is none; three or more distinct targets: [2*i] = kSlowMulti
 	h.single.assign(size_t(states) * letters * 2, kSlowNone);
@@ -437,6 +611,8 @@ void FreeSlowDevice(SlowDevice* d)
 	if (d->masks) (void)hipFree(d->masks);
 	if (d->single) (void)hipFree(d->single);
 	if (d->finals) (void)hipFree(d->finals);
+	if (d->jumpPos) (void)hipFree(d->jumpPos);
+	if (d->jumps) (void)hipFree(d->jumps);
 	*d = SlowDevice();
 }
 
@@ -463,11 +639,21 @@ int UploadSlow(pire_hip_slow_table* t, SlowDevice* image)
 		return PIRE_HIP_OK;
 	}
 	const SlowHost& h = t->host;
-	const int K = DeviceK(h.words);
-	if (K == 0) {
-		SetError("SlowScanner with more than 256 NFA states is not supported on the GPU yet");
-		return PIRE_HIP_EUNSUPPORTED;
+	if (h.wide) {
+		SlowDevice d;
+		int rc;
+		if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.finals, h.finals)) ||
+		    (rc = PutSlow(&d.jumpPos, h.jumpPos)) || (rc = PutSlow(&d.jumps, h.jumps))) {
+			d.device = dev;
+			FreeSlowDevice(&d);
+			return rc;
+		}
+		d.device = dev;
+		t->devs[dev] = d;
+		*image = d;
+		return PIRE_HIP_OK;
 	}
+	const int K = DeviceK(h.words);
 	std::vector<uint32_t> masks(size_t(h.states) * h.letters * K, 0), finals(K, 0);
 	for (size_t i = 0; i < size_t(h.states) * h.letters; ++i)
 		for (uint32_t w = 0; w < h.words; ++w)
@@ -518,6 +704,56 @@ int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
 	return PIRE_HIP_OK;
 }
 
+// One wave per string.  LDS budget, in this order: the two sets of every wave (16 waves per block, fewer when the sets
+// are large; device memory from the stream-ordered pool when not even one wave's fit), then jumpPos, then the jumps.
+int LaunchSlowWide(const SlowParams& p0, uint32_t njumps, hipStream_t stream)
+{
+	SlowParams p = p0;
+	int dev = 0, cus = 0;
+	hipError_t e;
+	if ((e = hipGetDevice(&dev)) != hipSuccess ||
+	    (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess)
+		return HipFail(e, "device query");
+	const size_t setBytes = size_t(p.words) * 8;   // cur + next of one wave
+	const size_t ldsRoom = 158 * 1024 - 272;
+	uint32_t waves = uint32_t(std::min<size_t>(16, ldsRoom / setBytes));
+	const char* knob = getenv("PIRE_HIP_SLOW_SETS_IN_MEMORY");   // tests: the device-memory form for any size
+	const bool inLds = waves >= 1 && !(knob && knob[0] == '1');
+	if (!inLds)
+		waves = 16;
+	size_t room = ldsRoom - (inLds ? waves * setBytes : 0);
+	const size_t posBytes = (size_t(p.states) * p.letters + 1) * 4, jumpBytes = size_t(njumps) * 4;
+	const uint32_t posInLds = posBytes <= room ? 1 : 0;
+	if (posInLds)
+		room -= posBytes;
+	const uint32_t jumpsInLds = posInLds && jumpBytes <= room ? 1 : 0;
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((p.n + waves - 1) / waves, uint64_t(cus)));
+	void* scratch = nullptr;
+	if (!inLds) {
+		e = hipMallocAsync(&scratch, blocks * waves * setBytes, stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(slow scanner sets)");
+		p.scratch = static_cast<uint32_t*>(scratch);
+	}
+	const uint32_t ldsBytes = uint32_t(272 + (inLds ? waves * setBytes : 0) + (posInLds ? posBytes : 0) + (jumpsInLds ? jumpBytes : 0));
+	const void* fn = inLds ? reinterpret_cast<const void*>(SlowWideKernel<true>) : reinterpret_cast<const void*>(SlowWideKernel<false>);
+	e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	if (inLds)
+		hipLaunchKernelGGL(SlowWideKernel<true>, dim3(unsigned(blocks)), dim3(waves * 64), ldsBytes, stream, p, waves, posInLds,
+		                   jumpsInLds, njumps);
+	else
+		hipLaunchKernelGGL(SlowWideKernel<false>, dim3(unsigned(blocks)), dim3(waves * 64), ldsBytes, stream, p, waves, posInLds,
+		                   jumpsInLds, njumps);
+	e = hipGetLastError();
+	if (scratch)
+		(void)hipFreeAsync(scratch, stream);
+	if (e != hipSuccess)
+		return HipFail(e, "slow kernel launch");
+	return PIRE_HIP_OK;
+}
+
 int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint64_t len, uint64_t stride,
             uint32_t flags, uint8_t* outFinal, uint32_t* outBits, uint64_t* outCounts, void* streamPtr)
 {
@@ -536,6 +772,8 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 	p.masks = image.masks;
 	p.single = image.single;
 	p.finals = image.finals;
+	p.jumpPos = image.jumpPos;
+	p.jumps = image.jumps;
 	p.states = h.states;
 	p.letters = h.letters;
 	p.start = h.start;
@@ -548,6 +786,8 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 		return PIRE_HIP_OK;
 	const int K = DeviceK(h.words);
 	auto launch = [&](const SlowParams& q) {
+		if (h.wide)
+			return LaunchSlowWide(q, uint32_t(h.jumps.size()), stream);
 		switch (K) {
 		case 1: return LaunchSlowK<1>(q, stream);
 		case 2: return LaunchSlowK<2>(q, stream);

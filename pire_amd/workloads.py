@@ -40,6 +40,10 @@ def slow_case(name: str) -> dict:
     for c in _golden()["slow"]:
         if c["name"] == name:
             return c
+    with open(os.path.join(GOLDEN, "slow_wide.json")) as f:   # SlowScanners of more than 256 NFA states
+        for c in json.load(f)["slow_wide"]:
+            if c["name"] == name:
+                return c
     raise KeyError(name)
 
 

@@ -130,3 +130,92 @@ def test_slow_gpu_list_and_bitset_forms_agree_with_the_oracle(pat, opt, alphabet
         gf, gb = t.run_strings(strings, flags=flags)
         assert (gf == of).all(), (pat, flags)
         assert (gb == obits).all(), (pat, flags)
+
+
+# ---- more than 256 NFA states: the wave-per-string form (slow.hip SlowWideKernel) ------------------------------------
+import hashlib
+import json
+import os
+
+
+def _wide_cases():
+    with open(os.path.join(H.GOLDEN, "slow_wide.json")) as f:
+        return json.load(f)["slow_wide"]
+
+
+WIDE = _wide_cases()
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: c["name"])
+def test_slow_wide_oracle_matches_golden(case):
+    """The oracle restates slow.h for any number of states; the fixtures come from the unmodified reference."""
+    o = ob.OracleSlowScanner(H.load_blob(case["blob"]))
+    g = case["geometry"]
+    assert (o.size, o.letters, o.words) == (g["states"], g["letters"], g["words"]) and o.size > 256
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    fin, bits = o.run_strings(strings)
+    assert fin.tolist() == case["final"]
+    assert [hashlib.sha256(bytes(np.ascontiguousarray(b))).hexdigest() for b in bits] == case["bits_sha256"]
+    for f, want in zip(fin, case["ref_expect"]):
+        assert bool(f) == want
+
+
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: c["name"])
+def test_slow_wide_table_ingest_without_gpu(case):
+    import pire_amd
+
+    t = pire_amd.SlowTable(H.load_blob(case["blob"]))
+    g = case["geometry"]
+    assert (t.Size, t.LettersCount, t.words) == (g["states"], g["letters"], g["words"])
+    blob = bytearray(H.load_blob(case["blob"]))
+    blob[-3] = blob[-7] = 0xFF      # the last jump target (or the padding word behind it and the one before): far outside
+    with pytest.raises(pire_amd.PireHipError):
+        pire_amd.SlowTable(bytes(blob))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: c["name"])
+def test_slow_wide_gpu_matches_golden_and_oracle(case):
+    import pire_amd
+
+    blob = H.load_blob(case["blob"])
+    t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
+    strings = [bytes.fromhex(h) for h in case["strings_hex"]]
+    fin, bits, cnt = t.run_strings(strings, counts=True)
+    assert fin.tolist() == case["final"]
+    assert [hashlib.sha256(bytes(np.ascontiguousarray(b))).hexdigest() for b in bits] == case["bits_sha256"]
+    assert cnt.tolist() == [sum(case["final"]), len(strings)]
+    rng = np.random.RandomState(19)
+    more = H.random_strings(rng, 600, 900, b"ax.yd ef\xd0\xb6bcx") + [b""] * 3 + H.random_strings(rng, 100, 100)
+    for flags in (BE, 0, ob.FLAG_BEGIN, ob.FLAG_END):
+        of, obits = o.run_strings(more, flags=flags)
+        gf, gbits = t.run_strings(more, flags=flags)
+        assert (gf == of).all() and (gbits == obits).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ob.ref_available(), reason="oracle/_ref/libpire_ref.so not built")
+def test_slow_wide_gpu_sets_in_device_memory():
+    """x.{6000}$ has 12 007 states (two sets of 376 words per wave); the UTF-8 x.{1500}$ 7 507.  Both run with the sets
+    in LDS and -- forced with the PIRE_HIP_SLOW_SETS_IN_MEMORY knob -- with the sets in device memory, the form
+    automata too large for the LDS take.  All against the oracle on strings around the gap length."""
+    import pire_amd
+
+    for pat, opt, gap in (("x.{6000}$", "", 6000), ("x.{1500}$", "u", 1500)):
+        r = ob.RefSlowScanner.compile(pat, opt)
+        blob = r.save()
+        o = ob.OracleSlowScanner(blob)
+        rng = np.random.RandomState(5)
+        strings = [b"zx" + b"y" * k for k in (gap - 1, gap, gap + 1)]
+        strings += [b"x" + bytes(rng.choice(np.frombuffer(b"xyz", dtype=np.uint8), size=k)) for k in (gap, 17)]
+        strings += [bytes(rng.choice(np.frombuffer(b"xy", dtype=np.uint8), size=gap + 40)) for _ in range(6)] + [b""]
+        of, obits = o.run_strings(strings)
+        for knob in ("0", "1"):
+            os.environ["PIRE_HIP_SLOW_SETS_IN_MEMORY"] = knob
+            try:
+                t = pire_amd.SlowTable(blob)
+                gf, gb = t.run_strings(strings)
+            finally:
+                os.environ.pop("PIRE_HIP_SLOW_SETS_IN_MEMORY")
+            assert (gf == of).all() and (gb == obits).all(), (pat, knob)
+        assert of[1] == 1 and of[0] == 0 and of[2] == 0
