@@ -233,8 +233,19 @@ int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t*
 int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
+/*
+ * Pire::LongestSuffix / Pire::ShortestSuffix (run.h:313-362) for n strings: every string is walked BACKWARDS from its
+ * last byte (the scanner is normally compiled from Fsm::Reverse(), pire_ut.cpp:283).  out_len[i] = length of the
+ * longest (shortest) suffix accepted -- the reference returns the pointer (last byte) - out_len[i] -- or -1 where the
+ * reference returns a null pointer.  through_end / through_begin as the reference's throughEndMark / throughBeginMark
+ * (in that order: the walk starts at the end).  Scanning stops at the first dead state.  flags: PIRE_HIP_RUN_ON_DEVICE.
+ * Pinned by tests/pire_ut.cpp:278-306 (PrefixSuffix) and 470-471 (ScanBoundaries on reversed texts).
+ */
+int pire_hip_suffix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
+                    int through_end, int through_begin, uint32_t flags, int64_t* out_len, void* stream);
+
 /* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
- * "prefix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
+ * "prefix", "suffix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
 /* The instantiation behind it where there are several (e.g. "pirehip::ScanTiledKernel<16,2,nt,5>" for "tiled");
  * otherwise the same string as pire_hip_last_kernel(). */

@@ -365,6 +365,39 @@ std::vector<const char*> BatchShortestPrefix(const Table<Scanner>& t, const char
 }
 
 /*
+ * Batched Pire::LongestSuffix / Pire::ShortestSuffix (run.h:313-362): every string is walked backwards from its last
+ * byte.  Returns, per string, the pointer the reference returns -- one before the suffix's first byte, i.e.
+ * (last byte) - length -- or null.
+ */
+template <class Scanner>
+std::vector<const char*> BatchSuffix(const Table<Scanner>& table, bool longest, const char* text, const uint64_t* offsets,
+                                     size_t n, bool throughEndMark = false, bool throughBeginMark = false)
+{
+	std::vector<int64_t> len(n);
+	static const uint64_t kNoOffsets[1] = {0};
+	Check(pire_hip_suffix(table.Handle(), text, n ? offsets : kNoOffsets, n, longest ? 1 : 0, throughEndMark ? 1 : 0,
+	                      throughBeginMark ? 1 : 0, 0, len.data(), nullptr));
+	std::vector<const char*> out(n);
+	for (size_t i = 0; i < n; ++i)
+		out[i] = len[i] < 0 ? nullptr : text + offsets[i + 1] - 1 - len[i];
+	return out;
+}
+
+template <class Scanner>
+std::vector<const char*> BatchLongestSuffix(const Table<Scanner>& t, const char* text, const uint64_t* offsets, size_t n,
+                                            bool throughEndMark = false, bool throughBeginMark = false)
+{
+	return BatchSuffix(t, true, text, offsets, n, throughEndMark, throughBeginMark);
+}
+
+template <class Scanner>
+std::vector<const char*> BatchShortestSuffix(const Table<Scanner>& t, const char* text, const uint64_t* offsets, size_t n,
+                                             bool throughEndMark = false, bool throughBeginMark = false)
+{
+	return BatchSuffix(t, false, text, offsets, n, throughEndMark, throughBeginMark);
+}
+
+/*
  * Batched twin of Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94): both scanners over the same strings,
  * State = pair of the two states (pair.h:35), Final = either (pair.h:69-72).  The two walks are independent
  * (pair.h:52-66), so this is two device passes over the resident text, one per table.

@@ -100,6 +100,8 @@ def oracle_lib():
         L.oracle_run_shortcut.restype = None
         L.oracle_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
         L.oracle_prefix.restype = None
+        L.oracle_suffix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
+        L.oracle_suffix.restype = None
         L.corpus_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p,
                                   C.c_void_p, C.c_int]
         L.corpus_fill.restype = None
@@ -230,6 +232,20 @@ class OracleScanner:
         self._L.oracle_prefix(self._h, int(longest), text.ctypes.data if text.size else None,
                               _ptr(offsets, u64p), n, int(through_begin), int(through_end), _ptr(out, i64p))
         return out
+
+
+def _oracle_suffix(self, text, offsets, longest: bool, through_end=False, through_begin=False):
+    """LongestSuffix / ShortestSuffix (run.h:313-362): suffix length per string, -1 = the reference's null."""
+    text = _as_text(text)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.empty(n, dtype=np.int64)
+    self._L.oracle_suffix(self._h, int(longest), text.ctypes.data if text.size else None,
+                          _ptr(offsets, u64p), n, int(through_end), int(through_begin), _ptr(out, i64p))
+    return out
+
+
+OracleScanner.suffix = _oracle_suffix
 
 
 class OracleSlowScanner:
@@ -424,6 +440,8 @@ def ref_lib():
         L.pire_ref_run.restype = C.c_int
         L.pire_ref_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
         L.pire_ref_prefix.restype = C.c_int
+        L.pire_ref_suffix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
+        L.pire_ref_suffix.restype = C.c_int
         L.pire_ref_slow_compile.argtypes = [C.c_char_p, C.c_char_p]
         L.pire_ref_slow_compile.restype = C.c_void_p
         L.pire_ref_slow_load.argtypes = [C.c_void_p, C.c_size_t]
@@ -853,6 +871,21 @@ class RefScanner:
         if rc != 0:
             raise RuntimeError(self._L.pire_ref_last_error().decode())
         return out
+
+
+def _ref_suffix(self, text, offsets, longest: bool, through_end=False, through_begin=False):
+    text = _as_text(text)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.empty(n, dtype=np.int64)
+    rc = self._L.pire_ref_suffix(self._h, int(longest), text.ctypes.data if text.size else None,
+                                 _ptr(offsets, u64p), n, int(through_end), int(through_begin), _ptr(out, i64p))
+    if rc != 0:
+        raise RuntimeError(self._L.pire_ref_last_error().decode())
+    return out
+
+
+RefScanner.suffix = _ref_suffix
 
 
 # --------------------------------------------------------------------------- corpus (host mirror)

@@ -559,3 +559,62 @@ void oracle_prefix(const oracle_scanner* sc, int longest, const void* text, cons
 		out_len[i] = pos ? (int64_t)(pos - begin) : -1;
 	}
 }
+
+/* ------------------------------------------------------------------ suffixes */
+
+/* LongestSuffix / ShortestSuffix (run.h:313-362): the text is walked BACKWARDS from its last byte (the scanner is
+ * normally compiled from Fsm::Reverse()).  out_len = length of the suffix, i.e. the reference's return pointer is
+ * (last byte) - out_len; -1 where the reference returns null. */
+void oracle_suffix(const oracle_scanner* sc, int longest, const void* text, const uint64_t* offsets,
+                   uint64_t n, int through_end, int through_begin, int64_t* out_len)
+{
+	static const uint8_t k_empty[2] = {0, 0};
+	const uint8_t* t = text ? (const uint8_t*)text : k_empty + 1;
+	uint64_t i;
+	for (i = 0; i < n; ++i) {
+		const uint8_t* rbegin0 = t + offsets[i + 1] - 1;   /* last byte */
+		const uint8_t* rend = t + offsets[i] - 1;          /* one before the first */
+		const uint8_t* rbegin = rbegin0;
+		uint64_t st;
+		if (sc->empty) {
+			out_len[i] = -1;
+			continue;
+		}
+		st = sc->m.initial;
+		if (through_end)
+			st = next_state(sc, st, ORACLE_END_MARK);
+		if (longest) {
+			/* run.h:315-342 */
+			int have = 0;
+			int64_t pos = 0;
+			while (rbegin != rend && !(row_flags(sc, st) & 2)) {
+				if (row_flags(sc, st) & 1) {
+					have = 1;
+					pos = rbegin0 - rbegin;
+				}
+				st = next_state(sc, st, *rbegin);
+				--rbegin;
+			}
+			if (row_flags(sc, st) & 1) {
+				have = 1;
+				pos = rbegin0 - rbegin;
+			}
+			if (through_begin) {
+				st = next_state(sc, st, ORACLE_BEGIN_MARK);
+				if (row_flags(sc, st) & 1) {
+					have = 1;
+					pos = rbegin0 - rbegin;
+				}
+			}
+			out_len[i] = have ? pos : -1;
+		} else {
+			/* run.h:345-361 */
+			for (; rbegin != rend && !(row_flags(sc, st) & 1) && !(row_flags(sc, st) & 2); --rbegin)
+				st = next_state(sc, st, *rbegin);
+			if (through_begin)
+				st = next_state(sc, st, ORACLE_BEGIN_MARK);
+			out_len[i] = (row_flags(sc, st) & 1) ? (int64_t)(rbegin0 - rbegin) : -1;
+		}
+	}
+}
+

@@ -95,6 +95,9 @@ void oracle_run_shortcut(const oracle_scanner* sc, const void* text, const uint6
 void oracle_run_half_final(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
                            uint32_t flags, uint32_t* out_idx, uint8_t* out_final, uint64_t* results);
 
+/* LongestSuffix / ShortestSuffix (run.h:313-362): suffix length or -1 (the text is walked backwards). */
+void oracle_suffix(const oracle_scanner* sc, int longest, const void* text, const uint64_t* offsets,
+                   uint64_t n, int through_end, int through_begin, int64_t* out_len);
 /* LongestPrefix / ShortestPrefix (run.h:277-311): prefix length or -1. */
 void oracle_prefix(const oracle_scanner* sc, int longest, const void* text, const uint64_t* offsets,
                    uint64_t n, int through_begin, int through_end, int64_t* out_len);

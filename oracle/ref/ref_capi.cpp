@@ -46,9 +46,10 @@ Pire::Fsm ParseOne(const char* pattern, const char* options)
 {
 	Pire::Lexer lexer;
 	Pire::TVector<Pire::wchar32> ucs4;
-	bool surround = true;
+	bool surround = true, reverse = false;
 	for (const char* o = options ? options : ""; *o; ++o) {
 		switch (*o) {
+		case 'r': reverse = true; break;   // Fsm::Reverse(), for the suffix searches (pire_ut.cpp:283)
 		case 'i': lexer.AddFeature(Pire::Features::CaseInsensitive()); break;
 		case 'u': lexer.SetEncoding(Pire::Encodings::Utf8()); break;
 		case 'n': surround = false; break;
@@ -61,6 +62,8 @@ Pire::Fsm ParseOne(const char* pattern, const char* options)
 	Pire::Fsm fsm = lexer.Parse();
 	if (surround)
 		fsm.Surround();           // fsm.cpp:1198-1203; bench.cpp:101-102,116-117
+	if (reverse)
+		fsm = fsm.Reverse();
 	return fsm;
 }
 
@@ -279,6 +282,31 @@ int pire_ref_prefix(void* h, int longest, const void* text, const uint64_t* offs
 			const char* p = longest ? Pire::LongestPrefix(sc, b, e, throughBegin != 0, throughEnd != 0)
 			                        : Pire::ShortestPrefix(sc, b, e, throughBegin != 0, throughEnd != 0);
 			outLen[i] = p ? static_cast<int64_t>(p - b) : -1;
+		}
+		return 0;
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return -1;
+	}
+}
+
+/*
+ * LongestSuffix / ShortestSuffix -- run.h:313-362.  Writes the suffix length ((last byte) - returned pointer), or -1
+ * for the reference's null return.
+ */
+int pire_ref_suffix(void* h, int longest, const void* text, const uint64_t* offsets, uint64_t n,
+                    int throughEnd, int throughBegin, int64_t* outLen)
+{
+	try {
+		const Scanner& sc = static_cast<RefScanner*>(h)->reloc;
+		static const char kEmpty[2] = {0, 0};
+		const char* t = text ? static_cast<const char*>(text) : kEmpty + 1;
+		for (uint64_t i = 0; i < n; ++i) {
+			const char* rbegin = t + offsets[i + 1] - 1;
+			const char* rend = t + offsets[i] - 1;
+			const char* p = longest ? Pire::LongestSuffix(sc, rbegin, rend, throughEnd != 0, throughBegin != 0)
+			                        : Pire::ShortestSuffix(sc, rbegin, rend, throughEnd != 0, throughBegin != 0);
+			outLen[i] = p ? static_cast<int64_t>(rbegin - p) : -1;
 		}
 		return 0;
 	} catch (const std::exception& e) {

@@ -104,6 +104,8 @@ ABI = [
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_prefix", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                   C.c_void_p, C.c_void_p]),
+    ("pire_hip_suffix", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                  C.c_void_p, C.c_void_p]),
     ("pire_hip_slow_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_slow_table_destroy", None, [C.c_void_p]),
     ("pire_hip_slow_table_get_info", C.c_int, [C.c_void_p, C.POINTER(SlowInfo)]),
@@ -383,6 +385,22 @@ class Table:
         _check(lib().pire_hip_prefix(self._h, text_ptr or None, offsets_ptr or None, n, int(longest), int(through_begin),
                                      int(through_end), FLAG_ON_DEVICE | (FLAG_GENERIC if generic else 0),
                                      out_len_ptr or None, stream or None))
+
+    def suffix(self, text, offsets, longest: bool, through_end=False, through_begin=False):
+        """LongestSuffix / ShortestSuffix lengths (-1 = the reference's null) for host strings, walked backwards."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        out = np.empty(n, dtype=np.int64)
+        _check(lib().pire_hip_suffix(self._h, text.ctypes.data if text.size else None, offsets.ctypes.data, n,
+                                     int(longest), int(through_end), int(through_begin), 0, out.ctypes.data, None))
+        return out
+
+    def suffix_device(self, text_ptr: int, offsets_ptr: int, n: int, longest: bool, out_len_ptr: int,
+                      through_end=False, through_begin=False, stream: int = 0):
+        _check(lib().pire_hip_suffix(self._h, text_ptr or None, offsets_ptr or None, n, int(longest), int(through_end),
+                                     int(through_begin), FLAG_ON_DEVICE, out_len_ptr or None, stream or None))
 
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))

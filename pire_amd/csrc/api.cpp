@@ -1074,6 +1074,61 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+int pire_hip_suffix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
+                    int through_end, int through_begin, uint32_t flags, int64_t* out_len, void* streamPtr)
+try {
+	if (!t || (n && (!offsets || !out_len))) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	ScanParams p;
+	if (int rc = FillParams(t, &p, 0))
+		return rc;
+	if (through_end) {   // Initialize, then Step(EndMark): run.h:319-320 / 349-350
+		const HostTable& h = t->host;
+		p.startPerm = h.permOfOrig[h.next[size_t(h.initial) * h.letters + h.cls[kEndMark]]];
+	}
+	p.n = n;
+	if (n == 0)
+		return PIRE_HIP_OK;
+	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
+		p.text = static_cast<const uint8_t*>(text);
+		p.offsets = offsets;
+		return LaunchSuffix(p, longest != 0, through_begin != 0, reinterpret_cast<long long*>(out_len), stream);
+	}
+	Staging st;
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i] > offsets[i + 1]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
+		}
+	const uint64_t textBytes = offsets[n];
+	if (!text && textBytes) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	const uint8_t* dText = nullptr;
+	if (int rc = st.In(static_cast<const uint8_t*>(text), size_t(textBytes), &dText, stream))
+		return rc;
+	p.text = dText;
+	if (int rc = st.In(offsets, size_t(n + 1), &p.offsets, stream))
+		return rc;
+	void* dOut = nullptr;
+	if (int rc = st.Alloc(&dOut, size_t(n) * 8))
+		return rc;
+	if (int rc = LaunchSuffix(p, longest != 0, through_begin != 0, static_cast<long long*>(dOut), stream))
+		return rc;
+	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
+	if (e == hipSuccess)
+		e = hipStreamSynchronize(stream);
+	if (e != hipSuccess)
+		return HipFail(e, "copy back / synchronize");
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();
+}
+
 int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t ch, void* stream)
 try {
 	if (!t || (n && !state_idx) || ch >= kMaxCharUnaligned || ch == kEpsilon) {

@@ -237,6 +237,87 @@ __global__ __launch_bounds__(1024) void PrefixKernel(PrefixParams q)
 	}
 }
 
+// ------------------------------------------------------------------------------------------ suffix searches
+// Pire::LongestSuffix / ShortestSuffix (run.h:313-362): the text is walked BACKWARDS from its last byte (the scanner
+// comes from Fsm::Reverse()).  One string per lane; 16-byte blocks are read from the top down, only blocks that hold at
+// least one byte of the string.  out = length of the suffix (the reference returns the pointer (last byte) - out), -1
+// where the reference returns null.  startPerm: Initialize() (+ Step(EndMark) when throughEndMark), folded by the host.
+struct SuffixParams {
+	ScanParams scan;
+	uint32_t longest, throughBegin;
+	long long* outLen;
+};
+
+__global__ __launch_bounds__(1024) void SuffixKernel(SuffixParams q)
+{
+	const ScanParams& p = q.scan;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	LoadTableToLds(p, lds, L);
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		const uint64_t lo = reinterpret_cast<uint64_t>(p.text) + b;   // address of the first byte
+		uint64_t cur = reinterpret_cast<uint64_t>(p.text) + e;        // one past the next byte to take
+		const uint64_t top = cur;
+		uint32_t st = p.startPerm;
+		uint32_t f = StateFlags(p, lds, L, st);
+		long long pos = -1;
+		// LongestSuffix: while (bytes left && !Dead) { if Final: pos = here; step }   run.h:326-333
+		// ShortestSuffix: while (bytes left && !Final && !Dead) step                  run.h:354-357
+		bool go = cur > lo && !(f & kDead) && (q.longest || !(f & kFinal));
+		while (go) {
+			const uint64_t block = (cur - 1) & ~uint64_t(15);
+			u32x4 v = *reinterpret_cast<const u32x4*>(block);
+			uint32_t k = uint32_t(cur - 1 - block);                          // index of the next byte inside the block
+			const uint32_t kLow = block >= lo ? 0u : uint32_t(lo - block);   // first index that belongs to the string
+			// bring byte k to the top of the 128-bit value, then peel bytes off the top
+			for (uint32_t sh = 15 - k; sh; --sh) {
+				v.w = __builtin_amdgcn_alignbit(v.w, v.z, 24);
+				v.z = __builtin_amdgcn_alignbit(v.z, v.y, 24);
+				v.y = __builtin_amdgcn_alignbit(v.y, v.x, 24);
+				v.x <<= 8;
+			}
+			for (;;) {
+				if (q.longest && (f & kFinal))
+					pos = (long long)(top - cur);
+				st = SlowStep(p, lds, L, st, v.w >> 24);
+				f = StateFlags(p, lds, L, st);
+				--cur;
+				go = cur > lo && !(f & kDead) && (q.longest || !(f & kFinal));
+				if (!go || k == kLow)
+					break;
+				--k;
+				v.w = __builtin_amdgcn_alignbit(v.w, v.z, 24);
+				v.z = __builtin_amdgcn_alignbit(v.z, v.y, 24);
+				v.y = __builtin_amdgcn_alignbit(v.y, v.x, 24);
+				v.x <<= 8;
+			}
+		}
+		const long long here = (long long)(top - cur);
+		if (q.longest) {
+			if (f & kFinal)
+				pos = here;                                              // run.h:334-335
+			if (q.throughBegin) {
+				st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
+				if (StateFlags(p, lds, L, st) & kFinal)
+					pos = here;                                          // run.h:336-340
+			}
+		} else {
+			if (q.throughBegin)
+				st = p.nextPerm[size_t(st) * p.letters + p.beginCls];    // run.h:358-359
+			pos = (StateFlags(p, lds, L, st) & kFinal) ? here : -1;      // run.h:360
+		}
+		q.outLen[s] = pos;
+	}
+}
+
 // ------------------------------------------------------------------------------------------ single Step()
 
 __global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateIdx, uint64_t n, uint32_t cls)
@@ -311,6 +392,35 @@ int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long*
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "prefix kernel launch");
+	return PIRE_HIP_OK;
+}
+
+int LaunchSuffix(const ScanParams& p0, bool longest, bool throughBegin, long long* outLen, hipStream_t stream)
+{
+	if (p0.n == 0)
+		return PIRE_HIP_OK;
+	NoteKernel("suffix");
+	ScanParams p = p0;
+	p.compact = 0;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SuffixKernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	SuffixParams q;
+	q.scan = p;
+	q.longest = longest ? 1 : 0;
+	q.throughBegin = throughBegin ? 1 : 0;
+	q.outLen = outLen;
+	const unsigned threads = unsigned(ExactBlockThreads(p.n));
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + threads - 1) / threads, uint64_t(cus) * 2)));
+	hipLaunchKernelGGL(SuffixKernel, dim3(blocks), dim3(threads), L.total, stream, q);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "suffix kernel launch");
 	return PIRE_HIP_OK;
 }
 

@@ -308,6 +308,7 @@ int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls
 int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter);
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
                  unsigned long long* workCounter);
+int LaunchSuffix(const ScanParams& p, bool longest, bool throughBegin, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);
 

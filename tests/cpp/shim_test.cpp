@@ -379,6 +379,28 @@ static void TestLongStrings()
 	CHECK(std::string(pire_hip_last_kernel()).find("segmented") == 0);
 }
 
+// PrefixSuffix of pire_ut.cpp:278-306 through the shim: the suffix that ends where a prefix search stopped.
+static void TestSuffix()
+{
+	static const char* text = "1234567890 --> middle --> end";
+	Pire::Fsm fsm = Parse("-->", false);
+	Pire::Scanner rsc = fsm.Reverse().Compile<Pire::Scanner>();
+	Pire::Hip::Table<Pire::Scanner> table(rsc);
+	const uint64_t offs[3] = {0, 14, 14 + 25};
+	Pire::ystring flat = Pire::ystring(text, 14) + Pire::ystring(text, 25);
+	for (int longest = 0; longest < 2; ++longest) {
+		std::vector<const char*> got = longest ? Pire::Hip::BatchLongestSuffix(table, flat.data(), offs, 2)
+		                                       : Pire::Hip::BatchShortestSuffix(table, flat.data(), offs, 2);
+		for (int i = 0; i < 2; ++i) {
+			const char* b = flat.data() + offs[i];
+			const char* e = flat.data() + offs[i + 1];
+			const char* want = longest ? Pire::LongestSuffix(rsc, e - 1, b - 1) : Pire::ShortestSuffix(rsc, e - 1, b - 1);
+			CHECK(got[i] == want);
+			CHECK(want != nullptr && want + 1 == e - 3);
+		}
+	}
+}
+
 // Device-resident text (RunDevice / RunDeviceStrided) and the pipelined host-pointer mode (batches of >= 64 MiB), both
 // against the reference Runner on a sample and against each other on the whole batch; prints the rates of the three
 // ways to hand a batch over (informational: the numbers quoted in DESIGN.md come from this line).
@@ -473,6 +495,7 @@ int main()
 {
 	try {
 		TestDeviceMode();
+		TestSuffix();
 		TestLongStrings();
 		TestPrefixAndSlow();
 		TestCapture();
