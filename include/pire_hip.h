@@ -139,6 +139,15 @@ int pire_hip_table_upload(pire_hip_table* t);
  */
 int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows);
 
+/*
+ * The checked build of the scan kernel (environment variable PIRE_HIP_CHECKED=1; the analogue of the reference's
+ * ValidateSkip, multi.h:925-934, which re-walks what the exit masks skipped): the wave-wide early-out on absorbing
+ * states is only noted, the text is walked to its end all the same, and every lane whose state still moved after its
+ * wave had been declared absorbing is counted.  *out receives the count since the last call (0 = the early-out was
+ * result-neutral, as it must be) and the counter is cleared.  Synchronises the devices the table ran on.
+ */
+int pire_hip_table_check_failures(pire_hip_table* t, uint64_t* out);
+
 void pire_hip_table_destroy(pire_hip_table* t);
 
 int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out);

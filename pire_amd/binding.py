@@ -133,6 +133,7 @@ ABI = [
     ("pire_hip_last_kernel_ms", C.c_float, []),
     ("pire_hip_last_error", C.c_char_p, []),
     ("pire_hip_device_count", C.c_int, []),
+    ("pire_hip_table_check_failures", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("pire_hip_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_host_free", None, [C.c_void_p]),
     ("pire_hip_device_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -401,6 +402,12 @@ class Table:
                       through_end=False, through_begin=False, stream: int = 0):
         _check(lib().pire_hip_suffix(self._h, text_ptr or None, offsets_ptr or None, n, int(longest), int(through_end),
                                      int(through_begin), FLAG_ON_DEVICE, out_len_ptr or None, stream or None))
+
+    def check_failures(self) -> int:
+        """Failures counted by the checked kernel build (PIRE_HIP_CHECKED=1) since the last call."""
+        v = C.c_uint64(0)
+        _check(lib().pire_hip_table_check_failures(self._h, C.byref(v)))
+        return int(v.value)
 
     def step_device(self, state_ptr: int, n: int, ch: int, stream: int = 0):
         _check(lib().pire_hip_step(self._h, state_ptr, n, ch, stream or None))

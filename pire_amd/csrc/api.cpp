@@ -729,6 +729,17 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+int pire_hip_table_check_failures(pire_hip_table* t, uint64_t* out)
+try {
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	return CheckFailures(t, out);
+} catch (...) {
+	return pirehip::HandleException();
+}
+
 void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)

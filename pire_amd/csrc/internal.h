@@ -48,6 +48,8 @@ struct LdsLayout {
 
 constexpr uint32_t kRotPitch = 260;
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
+constexpr uint32_t kCheckSlot = 256;                     // visitHot[256]: failures seen by the checked kernel build
+constexpr uint32_t kVisitHotSlots = 260;
 constexpr uint32_t kLdsPerBlock = 160 * 1024;            // gfx950: 160 KiB per CU, one block per CU may have it all
 constexpr uint32_t kRaggedFinBytes = 256 * 16;           // ragged kernel: end-of-string records of the hot states
 constexpr uint32_t kRaggedLdsExtra = kRaggedFinBytes + 32;
@@ -285,6 +287,7 @@ int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint
                   const std::vector<uint32_t>& lb, size_t maxSize, GlueProduct* out);   // glue.hip
 int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out, bool onDevice = false);
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
+int CheckFailures(pire_hip_table* t, uint64_t* out);
 void FreeDeviceTable(DeviceTable* d);
 
 // tiled.hip / ragged.hip / exact.hip / corpus.hip

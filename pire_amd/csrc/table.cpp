@@ -744,7 +744,7 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 		rc = Put(&d.compactRows, rows, &d.bytes);
 	}
 	if (!rc)
-		rc = Put(&d.visitHot, std::vector<uint32_t>(256, 0), &d.bytes);
+		rc = Put(&d.visitHot, std::vector<uint32_t>(kVisitHotSlots, 0), &d.bytes);
 	if (!rc)
 		rc = Put(&d.visitCold, std::vector<uint32_t>(N, 0), &d.bytes);
 	if (!rc)
@@ -988,6 +988,32 @@ void EnsureRanked(pire_hip_table* t)
 		ChooseHotAndPermute(t->host);
 		t->host.ranked = true;
 	}
+}
+
+// Failures the checked kernel build counted on any device since the last call (and clears the counters).
+int CheckFailures(pire_hip_table* t, uint64_t* out)
+{
+	*out = 0;
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
+	int cur = -1;
+	hipError_t e = hipGetDevice(&cur);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	for (int k = 0; k < kMaxDevices; ++k) {
+		if (t->devs[k].device < 0)
+			continue;
+		uint32_t v = 0;
+		if ((e = hipSetDevice(k)) == hipSuccess && (e = hipDeviceSynchronize()) == hipSuccess &&
+		    (e = hipMemcpy(&v, t->devs[k].visitHot + kCheckSlot, 4, hipMemcpyDeviceToHost)) == hipSuccess)
+			e = hipMemset(t->devs[k].visitHot + kCheckSlot, 0, 4);
+		if (e != hipSuccess) {
+			(void)hipSetDevice(cur);
+			return HipFail(e, "check counters");
+		}
+		*out += v;
+	}
+	(void)hipSetDevice(cur);
+	return PIRE_HIP_OK;
 }
 
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows)

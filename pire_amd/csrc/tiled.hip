@@ -119,7 +119,7 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
 // the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
 // gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
-template <int WAVES, int NBUF, bool NT, int MINW, int ROT>
+template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
@@ -172,6 +172,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 		uint32_t hs = cold < p.hot ? cold : p.hot;
 
 		bool done = false;
+		// CHECKED (PIRE_HIP_CHECKED=1, the analogue of the reference's ValidateSkip, multi.h:925-934): the early-out is
+		// only NOTED; the rest of the task is walked all the same, and a lane whose state moved after the wave was
+		// declared absorbing is counted (pire_hip_table_check_failures).
+		bool noted = false;
+		uint32_t hsNoted = 0;
 		if (!primed)
 			IssueTile<NT>(a, voff, rowBase, istride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
@@ -179,6 +184,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold);
 			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold);
 			done = AllAbsorbing(p, lds, L, hs);
+			if (CHECKED && done) {
+				if (!noted)
+					hsNoted = hs;
+				noted = true;
+				done = false;
+			}
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (!done && rem == 1) {
@@ -187,6 +198,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 			StepTile<ROT>(p, lds, L, a, hs, cold, lastTile);
 		}
 
+		if (CHECKED && noted && hs != hsNoted)
+			atomicAdd(&p.visitHot[kCheckSlot], 1u);
 		uint32_t st = hs != p.hot ? hs : cold;
 		// tail shorter than a tile: exact steps straight from memory
 		if (!done) {
@@ -214,7 +227,8 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		return rc;
 	// Variant knob for A/B measurements (DESIGN.md section 5 ladder); every variant returns the same results.
 	const char* variantEnv = getenv("PIRE_HIP_TILED_VARIANT");   // read per call: the tests switch it
-	const int variant = variantEnv ? atoi(variantEnv) : 0;
+	const char* checkedEnv = getenv("PIRE_HIP_CHECKED");
+	const int variant = checkedEnv && checkedEnv[0] == '1' ? 4 : variantEnv ? atoi(variantEnv) : 0;
 	ScanParams q = p;
 #ifdef PIRE_HIP_TUNING
 	if (getenv("PIRE_HIP_DEBUG_NOLOAD"))
@@ -246,6 +260,10 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	case 2:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,plain,5>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream);   // no nt
+		break;
+	case 4:   // also chosen by PIRE_HIP_CHECKED=1
+		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,checked>");
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream);
 		break;
 	default:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");

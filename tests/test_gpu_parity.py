@@ -432,3 +432,36 @@ def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch):
+    """PIRE_HIP_CHECKED=1 (the analogue of the reference's ValidateSkip, multi.h:925-934): the wave-wide early-out is
+    only noted, the text is walked to the end, and lanes whose state still moved are counted.  On a batch in which every
+    wave does go absorbing (an unanchored pattern matched early in every string) the count must be 0 and the results
+    those of the ordinary kernel and of the oracle; the ordinary kernel must really have been faster on it."""
+    torch = torch_cuda
+    case = [c for c in H.all_cases() if c["name"] == "string"][0]      # /abc/, surrounded: absorbing once it matched
+    blob = H.load_blob(case["blob"])
+    o = ob.OracleScanner(blob)
+    n, length = 4096, 2048
+    rng = np.random.RandomState(8)
+    data = rng.choice(np.frombuffer(b"abdefgh ", dtype=np.uint8), size=(n, length)).astype(np.uint8)
+    absorbing = b"xxabc"
+    idx = int(o.run_strings([absorbing], flags=ob.FLAG_BEGIN)[0][0])
+    assert all(o.next(idx, c) == idx for c in range(256)) and o.final(idx)
+    data[:, :len(absorbing)] = np.frombuffer(absorbing, dtype=np.uint8)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    t = pa.Table(blob)
+    gi, gf, cnt = dev_run_strided(torch, t, d)
+    assert (gi == oi).all() and (gf == of).all()
+    from pire_amd import binding as pb
+
+    assert pb.last_kernel_symbol().endswith("nt,5>")
+    monkeypatch.setenv("PIRE_HIP_CHECKED", "1")
+    ci, cf, ccnt = dev_run_strided(torch, t, d)
+    assert "checked" in pb.last_kernel_symbol()
+    assert (ci == oi).all() and (cf == of).all() and (ccnt == cnt).all()
+    assert t.check_failures() == 0
+    assert t.check_failures() == 0      # cleared by the read, and nothing ran in between
