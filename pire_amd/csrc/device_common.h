@@ -490,8 +490,10 @@ int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hi
 #endif
 	if (perCu < 1)
 		perCu = 1;
+#ifdef PIRE_HIP_TUNING
 	if (const char* cap = getenv("PIRE_HIP_BLOCKS_PER_CU"))   // knob: A/B measurements
 		perCu = std::max(1, std::min(perCu, atoi(cap)));
+#endif
 	const uint64_t ntasks = (p.n + 63) / 64;
 	const uint64_t wavesPerBlock = tasksPerBlock ? uint64_t(tasksPerBlock) : uint64_t(threads) / 64;
 	uint64_t blocks = (ntasks + wavesPerBlock - 1) / wavesPerBlock;

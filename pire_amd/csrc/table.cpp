@@ -231,8 +231,10 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
+#ifdef PIRE_HIP_TUNING
 	if (const char* cap = getenv("PIRE_HIP_MAX_HOT"))   // knob: A/B measurements (fewer dense rows = less LDS per block)
 		t.hot = std::min<uint32_t>(t.hot, std::max(1, atoi(cap)));
+#endif
 	// inside the hot set the order is free: plain states first, then Dead ones, then Final ones, so that "hot and
 	// Final" and "hot and Final or Dead" are one compare each (HalfFinalScanner's per-step TakeAction, the prefix
 	// searches' stop conditions; ragged.hip tests the largest id a 16-byte chunk went through against them)
