@@ -359,7 +359,7 @@ def main():
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         info = table.refresh_info()
         # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3 requires)
-        traffic = traffic_src = None
+        traffic = traffic_src = lds = None
         for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -367,6 +367,13 @@ def main():
                 if pmc.get("workload") == f"{args.set} 2^{args.log2_strings} x {length}" and not args.strings \
                         and args.corpus == "synthetic":
                     traffic, traffic_src = pmc["hbm_bytes_per_launch"], name
+                    if "lds_idx_active_cycles_per_launch" in pmc:
+                        # the secondary bound SURVEY 8(d) asks for: the dependent LDS gather (one ds_read_u8 per byte)
+                        lds = {"bank_conflict_over_idx_active": round(pmc["lds_bank_conflict_cycles_per_launch"] /
+                                                                      pmc["lds_idx_active_cycles_per_launch"], 3),
+                               "lds_cycles_per_lookup": round(pmc["lds_idx_active_cycles_per_launch"] /
+                                                              pmc["lds_instructions_per_launch"], 2),
+                               "source": f"profiles/{name} (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)"}
                     break
             except (OSError, ValueError, KeyError):
                 pass
@@ -407,6 +414,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
                                   if traffic else None,
+                "lds_gather": lds,
                 "kernel": kernel_name, "kernel_avg_ms": round(avg_ms, 4),
                 "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
                 "kernel_avg_ms_before_adapt": round(float(np.mean(cold_ms)), 4),
