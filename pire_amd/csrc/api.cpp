@@ -300,12 +300,15 @@ int RunHostPipelined(pire_hip_table* t, const ScanParams& base, const uint8_t* t
                      uint64_t* outCounts, bool* done)
 {
 	*done = false;
+	size_t chunkBytes = kHostChunkBytes;
+	if (const char* knob = getenv("PIRE_HIP_HOST_CHUNK_BYTES"))   // tests: many small chunks
+		chunkBytes = std::max<size_t>(4096, std::min<size_t>(kHostChunkBytes, strtoull(knob, nullptr, 10)));
 	// chunk boundaries: [first[c], first[c+1]) strings, text bytes [lo, hi) of the caller's buffer
 	std::vector<uint64_t> first{0};
 	if (offsets) {
 		while (first.back() < n) {
 			const uint64_t f = first.back();
-			const uint64_t limit = offsets[f] + kHostChunkBytes;
+			const uint64_t limit = offsets[f] + chunkBytes;
 			uint64_t l = uint64_t(std::upper_bound(offsets + f + 1, offsets + n + 1, limit) - offsets) - 1;   // last string that still fits
 			l = std::min<uint64_t>(l, f + kHostChunkStrings);
 			if (l == f)
@@ -313,11 +316,11 @@ int RunHostPipelined(pire_hip_table* t, const ScanParams& base, const uint8_t* t
 			first.push_back(l);
 		}
 	} else {
-		if (stride > kHostChunkBytes / 64)
+		if (stride > chunkBytes / 64)
 			return PIRE_HIP_OK;
-		uint64_t per = std::min<uint64_t>(kHostChunkBytes / stride, kHostChunkStrings) & ~uint64_t(1023);
+		uint64_t per = std::min<uint64_t>(chunkBytes / stride, kHostChunkStrings) & ~uint64_t(1023);
 		if (per == 0)
-			per = kHostChunkBytes / stride;
+			per = chunkBytes / stride;
 		for (uint64_t f = per; f < n; f += per)
 			first.push_back(f);
 		first.push_back(n);
@@ -514,7 +517,8 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 				return PIRE_HIP_EINVAL;
 			}
 	const bool segmented = !(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes);
-	if (!segmented && textBytes >= (size_t(8) << 20) && !g_timing && !getenv("PIRE_HIP_HOST_ONE_SHOT")) {
+	if (!segmented && (textBytes >= (size_t(8) << 20) || getenv("PIRE_HIP_HOST_CHUNK_BYTES")) && !g_timing &&
+	    !getenv("PIRE_HIP_HOST_ONE_SHOT")) {
 		bool done = false;
 		const int rc = RunHostPipelined(t, p, static_cast<const uint8_t*>(text), offsets, n, len, stride, init, outIdx,
 		                                outFinal, outCounts, &done);

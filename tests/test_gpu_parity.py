@@ -465,3 +465,43 @@ def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch
     assert (ci == oi).all() and (cf == of).all() and (ccnt == cnt).all()
     assert t.check_failures() == 0
     assert t.check_failures() == 0      # cleared by the read, and nothing ran in between
+
+
+@pytest.mark.gpu
+def test_host_pointer_mode_in_chunks_equals_one_shot(pa, torch_cuda, monkeypatch):
+    """The host-pointer mode cuts big batches into chunks of whole strings that go H2D -> scan -> D2H on alternating
+    streams of a pooled staging arena (api.cpp RunHostPipelined).  With a tiny chunk size (knob) a small batch takes
+    dozens of chunks: ragged strings with empty ones, strings longer than most chunks' average, offsets that do not
+    start at 0, resume states, counters accumulated into; fixed-length records too.  Everything must equal the oracle
+    and the one-shot path."""
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(41)
+    strings = H.random_strings(rng, 5000, 300, b"abcdeaxHedInrTail hello w") + [b""] * 7 + \
+        [bytes(rng.choice(np.frombuffer(b"abcx ", dtype=np.uint8), size=9000))] + H.random_strings(rng, 2000, 40, b"adexx")
+    rng.shuffle(strings)
+    text, offs = H.pack(strings)
+    pad = np.frombuffer(b"#" * 37, dtype=np.uint8)
+    text2 = np.concatenate([pad, text])           # offsets not starting at 0, odd alignment
+    offs2 = offs + np.uint64(len(pad))
+    init = rng.randint(0, o.size, size=len(strings)).astype(np.uint32)
+    want = {}
+    for name, kw in (("plain", {}), ("resume", {"init_idx": init})):
+        want[name] = o.run(text2, offs2, threads=4, **kw)
+    monkeypatch.setenv("PIRE_HIP_HOST_ONE_SHOT", "1")
+    one = t.run(text2, offs2, counts=True)
+    monkeypatch.delenv("PIRE_HIP_HOST_ONE_SHOT")
+    for chunk in ("4096", "20000", "65536"):
+        monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", chunk)
+        gi, gf, cnt = t.run(text2, offs2, counts=True)
+        assert (gi == want["plain"][0]).all() and (gf == want["plain"][1]).all(), chunk
+        assert (gi == one[0]).all() and (cnt == one[2]).all()
+        ri, rf = t.run(text2, offs2, init_idx=init)
+        assert (ri == want["resume"][0]).all() and (rf == want["resume"][1]).all(), chunk
+    # fixed-length records: 3 000 x 512 B in chunks of 64 KiB
+    data = ob.corpus_fill(5, 0, 3000, 512, H.plants_for(big), threads=4)
+    oi, of = o.run(data.reshape(-1), np.arange(3001, dtype=np.uint64) * 512, threads=4)
+    monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", "65536")
+    si, sf = t.run_strided_host(data)
+    assert (si == oi).all() and (sf == of).all()
