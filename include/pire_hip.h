@@ -243,6 +243,22 @@ int pire_hip_prefix(pire_hip_table* t, const void* text, const uint64_t* offsets
                     int through_begin, int through_end, uint32_t flags, int64_t* out_len, void* stream);
 
 /*
+ * Pire::Run(scanner1, scanner2, state1, state2, begin, end) (run.h:229-241) -- a Runner over
+ * Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94) -- for n strings: both scanners over the same text,
+ *   out_state_idx1[i], out_state_idx2[i] = StateIndex of the two end states (pair.h:79-82),
+ *   out_final[i] = Final(state1) || Final(state2)                            (pair.h:69-72).
+ * Device pointers only (flags must carry PIRE_HIP_RUN_ON_DEVICE; BEGIN / END apply to both scanners).  Fixed-length
+ * records (pire_hip_run_pair_strided; len a multiple of 256, stride of 16, text 16-byte aligned) take ONE pass with
+ * both tables' dense rows in LDS: the text is read once and the two lookups of a byte overlap; anything else, and the
+ * last n mod 64 records, takes two ordinary passes behind the same call.  Any output pointer may be NULL.
+ */
+int pire_hip_run_pair(pire_hip_table* t1, pire_hip_table* t2, const void* text, const uint64_t* offsets, uint64_t n,
+                      uint32_t flags, uint32_t* out_state_idx1, uint32_t* out_state_idx2, uint8_t* out_final, void* stream);
+int pire_hip_run_pair_strided(pire_hip_table* t1, pire_hip_table* t2, const void* text, uint64_t n, uint64_t len,
+                              uint64_t stride, uint32_t flags, uint32_t* out_state_idx1, uint32_t* out_state_idx2,
+                              uint8_t* out_final, void* stream);
+
+/*
  * Pire::LongestSuffix / Pire::ShortestSuffix (run.h:313-362) for n strings: every string is walked BACKWARDS from its
  * last byte (the scanner is normally compiled from Fsm::Reverse(), pire_ut.cpp:283).  out_len[i] = length of the
  * longest (shortest) suffix accepted -- the reference returns the pointer (last byte) - out_len[i] -- or -1 where the
@@ -254,7 +270,7 @@ int pire_hip_suffix(pire_hip_table* t, const void* text, const uint64_t* offsets
                     int through_end, int through_begin, uint32_t flags, int64_t* out_len, void* stream);
 
 /* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
- * "prefix", "suffix", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
+ * "prefix", "suffix", "pair_tiled", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
 /* The instantiation behind it where there are several (e.g. "pirehip::ScanTiledKernel<16,2,nt,5>" for "tiled");
  * otherwise the same string as pire_hip_last_kernel(). */

@@ -235,6 +235,9 @@ public:
 	const uint32_t* DeviceStateIndices() { Execute(); return static_cast<const uint32_t*>(m_devIdx.Get()); }
 	const uint8_t* DeviceFinals() { Execute(); return static_cast<const uint8_t*>(m_devFin.Get()); }
 
+	const Table<Scanner>& GetTable() const { return *m_table; }
+	uint32_t Flags() const { return m_flags; }
+
 private:
 	void Reset()
 	{
@@ -398,38 +401,63 @@ std::vector<const char*> BatchShortestSuffix(const Table<Scanner>& t, const char
 }
 
 /*
- * Batched twin of Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94): both scanners over the same strings,
- * State = pair of the two states (pair.h:35), Final = either (pair.h:69-72).  The two walks are independent
- * (pair.h:52-66), so this is two device passes over the resident text, one per table.
+ * Batched twin of Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94) and of
+ * Pire::Run(scanner1, scanner2, state1, state2, begin, end) (run.h:229-241): both scanners over the same strings, State =
+ * pair of the two states (pair.h:35), Final = either (pair.h:69-72).  Host pointers: two passes (the walks are
+ * independent, pair.h:52-66).  Device-resident fixed-length records (RunDeviceStrided): ONE fused pass with both tables
+ * in LDS -- the text is read once (pire_hip_run_pair_strided).
  */
 template <class Scanner1, class Scanner2>
 class PairBatchRunner {
 public:
 	typedef ypair<typename Scanner1::State, typename Scanner2::State> State;
 
-	PairBatchRunner(const Scanner1& s1, const Scanner2& s2) : m_first(s1), m_second(s2) {}
+	PairBatchRunner(const Scanner1& s1, const Scanner2& s2)
+	    : m_first(s1), m_second(s2), m_fused(false), m_ran(false), m_text(nullptr), m_n(0), m_len(0), m_stride(0), m_stream(nullptr) {}
 
 	PairBatchRunner& Begin() { m_first.Begin(); m_second.Begin(); return *this; }
 	PairBatchRunner& End() { m_first.End(); m_second.End(); return *this; }
 	PairBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
 	{
+		m_fused = false;
 		m_first.Run(text, offsets, n);
 		m_second.Run(text, offsets, n);
 		return *this;
 	}
 	PairBatchRunner& Run(const std::vector<ystring>& strings)
 	{
+		m_fused = false;
 		m_first.Run(strings);
 		m_second.Run(strings);
+		return *this;
+	}
+	/* Device-resident fixed-length records: one fused pass. */
+	PairBatchRunner& RunDeviceStrided(const void* deviceText, size_t n, size_t len, size_t stride, void* stream = nullptr)
+	{
+		m_fused = true;
+		m_ran = false;
+		m_text = deviceText;
+		m_n = n;
+		m_len = len;
+		m_stride = stride;
+		m_stream = stream;
 		return *this;
 	}
 
 	/* RunHelper<ScannerPair>::State() per string. */
 	std::vector<State> States()
 	{
+		std::vector<State> out;
+		if (m_fused) {
+			ExecuteFused();
+			out.resize(m_n);
+			for (size_t i = 0; i < m_n; ++i)
+				out[i] = ymake_pair(m_first.GetTable().ToState(m_idx1[i]), m_second.GetTable().ToState(m_idx2[i]));
+			return out;
+		}
 		const std::vector<typename Scanner1::State>& a = m_first.States();
 		const std::vector<typename Scanner2::State>& b = m_second.States();
-		std::vector<State> out(a.size());
+		out.resize(a.size());
 		for (size_t i = 0; i < a.size(); ++i)
 			out[i] = ymake_pair(a[i], b[i]);
 		return out;
@@ -437,6 +465,10 @@ public:
 	/* ScannerPair::Final per string (pair.h:69-72). */
 	std::vector<char> Finals()
 	{
+		if (m_fused) {
+			ExecuteFused();
+			return std::vector<char>(m_fin.begin(), m_fin.end());
+		}
 		const std::vector<char>& a = m_first.Finals();
 		const std::vector<char>& b = m_second.Finals();
 		std::vector<char> out(a.size());
@@ -448,8 +480,34 @@ public:
 	BatchRunner<Scanner2>& Second() { return m_second; }
 
 private:
+	void ExecuteFused()
+	{
+		if (m_ran)
+			return;
+		uint32_t* d1 = static_cast<uint32_t*>(m_dev1.Reserve(m_n * 4));
+		uint32_t* d2 = static_cast<uint32_t*>(m_dev2.Reserve(m_n * 4));
+		uint8_t* df = static_cast<uint8_t*>(m_devFin.Reserve(m_n));
+		Check(pire_hip_run_pair_strided(m_first.GetTable().Handle(), m_second.GetTable().Handle(), m_text, m_n, m_len, m_stride,
+		                                m_first.Flags() | PIRE_HIP_RUN_ON_DEVICE, d1, d2, df, m_stream));
+		m_idx1.resize(m_n);
+		m_idx2.resize(m_n);
+		m_fin.resize(m_n);
+		Check(pire_hip_copy_to_host(m_idx1.data(), d1, m_n * 4, m_stream));
+		Check(pire_hip_copy_to_host(m_idx2.data(), d2, m_n * 4, m_stream));
+		Check(pire_hip_copy_to_host(m_fin.data(), df, m_n, m_stream));
+		Check(pire_hip_stream_synchronize(m_stream));
+		m_ran = true;
+	}
+
 	BatchRunner<Scanner1> m_first;
 	BatchRunner<Scanner2> m_second;
+	bool m_fused, m_ran;
+	const void* m_text;
+	size_t m_n, m_len, m_stride;
+	void* m_stream;
+	std::vector<uint32_t> m_idx1, m_idx2;
+	std::vector<uint8_t> m_fin;
+	DeviceBuffer m_dev1, m_dev2, m_devFin;
 };
 
 /*

@@ -133,6 +133,10 @@ ABI = [
     ("pire_hip_last_kernel_ms", C.c_float, []),
     ("pire_hip_last_error", C.c_char_p, []),
     ("pire_hip_device_count", C.c_int, []),
+    ("pire_hip_run_pair", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_run_pair_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
+                                            C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_table_check_failures", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     ("pire_hip_host_alloc", C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_host_free", None, [C.c_void_p]),
@@ -629,6 +633,19 @@ class MultiRunner:
                                                      length, length, flags, _np_ptr(init), idx.ctypes.data,
                                                      fin.ctypes.data, cnt.ctypes.data))
         return idx, fin, cnt
+
+
+def run_pair_strided_device(t1: "Table", t2: "Table", text_ptr, n, length, stride, flags, out_idx1_ptr=0, out_idx2_ptr=0,
+                            out_final_ptr=0, stream=0):
+    """Pire::Run(sc1, sc2, ...) over device-resident fixed-length records: one fused pass (pair.hip)."""
+    _check(lib().pire_hip_run_pair_strided(t1._h, t2._h, text_ptr or None, n, length, stride, flags | FLAG_ON_DEVICE,
+                                           out_idx1_ptr or None, out_idx2_ptr or None, out_final_ptr or None, stream or None))
+
+
+def run_pair_device(t1: "Table", t2: "Table", text_ptr, offsets_ptr, n, flags, out_idx1_ptr=0, out_idx2_ptr=0,
+                    out_final_ptr=0, stream=0):
+    _check(lib().pire_hip_run_pair(t1._h, t2._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
+                                   out_idx1_ptr or None, out_idx2_ptr or None, out_final_ptr or None, stream or None))
 
 
 def last_kernel() -> str:

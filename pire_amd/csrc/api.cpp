@@ -1089,6 +1089,97 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+// Pire::Run(scanner1, scanner2, state1, state2, begin, end) (run.h:229-241) / Runner over ScannerPair (pair.h:33-94).
+static int RunPairImpl(pire_hip_table* t1, pire_hip_table* t2, const void* text, const uint64_t* offsets, uint64_t n,
+                       uint64_t len, uint64_t stride, uint32_t flags, uint32_t* outIdx1, uint32_t* outIdx2,
+                       uint8_t* outFinal, void* streamPtr)
+{
+	if (!t1 || !t2) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	if (!(flags & PIRE_HIP_RUN_ON_DEVICE)) {
+		SetError("pire_hip_run_pair takes device pointers (PIRE_HIP_RUN_ON_DEVICE): stage the text once, scan it with both");
+		return PIRE_HIP_EINVAL;
+	}
+	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC;
+	ScanParams a, b;
+	if (int rc = FillParams(t1, &a, flags))
+		return rc;
+	if (int rc = FillParams(t2, &b, flags))
+		return rc;
+	if (n == 0)
+		return PIRE_HIP_OK;
+	a.n = b.n = n;
+	a.len = b.len = len;
+	a.stride = b.stride = stride;
+	a.text = b.text = static_cast<const uint8_t*>(text);
+	a.offsets = b.offsets = offsets;
+	a.outIdx = outIdx1;
+	a.outFinal = outFinal;
+	uint64_t fused = 0;
+	if (!offsets && !(flags & PIRE_HIP_RUN_GENERIC) && PairTiledEligible(a, b)) {
+		if (int rc = LaunchPairTiled(a, b, outIdx2, stream))
+			return rc;
+		fused = n & ~uint64_t(63);
+		if (fused == n)
+			return PIRE_HIP_OK;
+	}
+	// what is left (everything, when the batch is not made of fixed-length records): two ordinary passes, Final = either
+	const uint64_t rest = n - fused;
+	void* fin2 = nullptr;
+	if (outFinal) {
+		hipError_t e = hipMallocAsync(&fin2, size_t(rest), stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(pair finals)");
+	}
+	auto shift = [&](ScanParams& p, uint32_t* idx, uint8_t* fin) {
+		p.n = rest;
+		if (!offsets)
+			p.text += fused * stride;
+		else
+			p.offsets += fused;
+		p.outIdx = idx ? idx + fused : nullptr;
+		p.outFinal = fin;
+	};
+	shift(a, outIdx1, outFinal ? outFinal + fused : nullptr);
+	shift(b, outIdx2, static_cast<uint8_t*>(fin2));
+	int rc = Dispatch(a, stream, NextWorkSlot(t1, a), offsets ? ~0ull : 0);
+	if (!rc)
+		rc = Dispatch(b, stream, NextWorkSlot(t2, b), offsets ? ~0ull : 0);
+	if (!rc && outFinal)
+		rc = LaunchOrFinal(outFinal + fused, static_cast<const uint8_t*>(fin2), rest, stream);
+	if (fin2)
+		(void)hipFreeAsync(fin2, stream);
+	return rc;
+}
+
+int pire_hip_run_pair(pire_hip_table* t1, pire_hip_table* t2, const void* text, const uint64_t* offsets, uint64_t n,
+                      uint32_t flags, uint32_t* out_state_idx1, uint32_t* out_state_idx2, uint8_t* out_final, void* stream)
+try {
+	if (n && !offsets) {
+		SetError("null offsets");
+		return PIRE_HIP_EINVAL;
+	}
+	return RunPairImpl(t1, t2, text, offsets, n, 0, 0, flags, out_state_idx1, out_state_idx2, out_final, stream);
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+int pire_hip_run_pair_strided(pire_hip_table* t1, pire_hip_table* t2, const void* text, uint64_t n, uint64_t len,
+                              uint64_t stride, uint32_t flags, uint32_t* out_state_idx1, uint32_t* out_state_idx2,
+                              uint8_t* out_final, void* stream)
+try {
+	if (stride < len) {
+		SetError("stride smaller than len");
+		return PIRE_HIP_EINVAL;
+	}
+	return RunPairImpl(t1, t2, text, nullptr, n, len, stride, flags, out_state_idx1, out_state_idx2, out_final, stream);
+} catch (...) {
+	return pirehip::HandleException();
+}
+
 int pire_hip_suffix(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, int longest,
                     int through_end, int through_begin, uint32_t flags, int64_t* out_len, void* streamPtr)
 try {

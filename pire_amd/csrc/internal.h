@@ -311,6 +311,10 @@ int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls
 int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter);
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
                  unsigned long long* workCounter);
+// pair.hip: two scanners in one pass over fixed-length records (run.h:229-241)
+bool PairTiledEligible(const ScanParams& a, const ScanParams& b);
+int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream);
+int LaunchOrFinal(uint8_t* fin, const uint8_t* other, uint64_t n, hipStream_t stream);
 int LaunchSuffix(const ScanParams& p, bool longest, bool throughBegin, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);

@@ -1,0 +1,287 @@
+// Two scanners over the same text in ONE pass: Pire::Run(scanner1, scanner2, state1, state2, begin, end)
+// (/root/reference/pire/run.h:229-241), i.e. a Runner over Pire::ScannerPair (scanners/pair.h:33-94: Next = both
+// Next()s, Final = either, StateIndex = the pair).  Fixed-length records, the tiled kernel's load path (whole-line loads
+// by groups of 8 lanes, register transpose, ring of two tiles chained across tasks) with BOTH tables' dense rows in LDS
+// and two lookups per byte and lane.  The text is read once instead of twice; the two dependent LDS chains of a lane
+// overlap each other's latency.  Anything that is not tiled-eligible takes two ordinary passes (api.cpp).
+//
+// LDS: table A's dense rows at byte 0 (its v_perm result is the ds_read address, as everywhere), table B's at the fixed
+// byte 65 280 so that its lookups are the same v_perm with the base in the instruction's 16-bit immediate offset
+// (ds_read_u8 v, addr offset:65280).  A is therefore cut to 254 dense rows + the trap row (ids >= 254 become the trap
+// id while the rows are copied in; such states are walked exactly like any state without a dense row).
+
+#include "device_common.h"
+
+namespace pirehip {
+
+constexpr uint32_t kPairHotA = 254;            // dense rows of table A (ids 0..253), trap id 254
+constexpr uint32_t kPairBaseB = 65280;         // = (kPairHotA + 1) * 256: where table B's rows start
+
+struct PairSide {
+	const uint8_t* rows;      // this table's dense rows in LDS (generic pointer)
+	const uint16_t* cls;      // [264] letter classes in LDS
+	const uint8_t* flags;     // [256] hot flags in LDS
+	uint32_t hot;             // dense rows in LDS; == trap id
+};
+
+struct PairParams {
+	ScanParams a, b;
+	uint32_t* outIdxB;
+};
+
+__device__ __forceinline__ uint32_t PairSlowStep(const ScanParams& p, const PairSide& S, uint32_t st, uint32_t byte)
+{
+	if (st < S.hot) {
+		const uint32_t e = S.rows[st * 256 + byte];
+		if (e != S.hot)
+			return e;
+	}
+	return p.nextPerm[size_t(st) * p.letters + S.cls[byte]];
+}
+
+__device__ __forceinline__ uint32_t PairSlowChunk(const ScanParams& p, const PairSide& S, u32x4 v, uint32_t st)
+{
+#pragma unroll 1
+	for (int i = 0; i < 16; ++i) {
+		st = PairSlowStep(p, S, st, v.x & 0xFF);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return st;
+}
+
+__device__ __forceinline__ uint32_t HotLookupB(uint32_t addr)
+{
+	return *reinterpret_cast<LdsBytePtr>(static_cast<uintptr_t>(addr) + kPairBaseB);   // base folded into the offset field
+}
+
+// 16 bytes through both tables; a side that leaves its dense rows is re-walked exactly for that chunk.
+__device__ __forceinline__ void PairStepChunk(const PairParams& q, const PairSide& A, const PairSide& B, const u32x4 v,
+                                              uint32_t& ha, uint32_t& ca, uint32_t& hb, uint32_t& cb)
+{
+	const uint32_t ha0 = ha, hb0 = hb;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0400u));
+		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0400u));
+		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0401u));
+		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0401u));
+		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0402u));
+		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0402u));
+		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0403u));
+		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0403u));
+	}
+	if (ha == A.hot) {
+		const uint32_t f = PairSlowChunk(q.a, A, v, ha0 != A.hot ? ha0 : ca);
+		ha = f < A.hot ? f : A.hot;
+		ca = f;
+	}
+	if (hb == B.hot) {
+		const uint32_t f = PairSlowChunk(q.b, B, v, hb0 != B.hot ? hb0 : cb);
+		hb = f < B.hot ? f : B.hot;
+		cb = f;
+	}
+}
+
+template <bool NT>
+__device__ __forceinline__ void PairIssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride)
+{
+	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
+	asm volatile(
+		"global_load_dwordx4 %0, %8, %9 nt\n\t"
+		"global_load_dwordx4 %1, %8, %10 nt\n\t"
+		"global_load_dwordx4 %2, %8, %11 nt\n\t"
+		"global_load_dwordx4 %3, %8, %12 nt\n\t"
+		"global_load_dwordx4 %4, %8, %13 nt\n\t"
+		"global_load_dwordx4 %5, %8, %14 nt\n\t"
+		"global_load_dwordx4 %6, %8, %15 nt\n\t"
+		"global_load_dwordx4 %7, %8, %16 nt"
+		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+}
+
+template <int BEHIND>
+__device__ __forceinline__ void PairWaitTile(u32x4 (&r)[8])
+{
+	asm volatile("s_waitcnt vmcnt(%8)"
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+	             : "n"(BEHIND * 8));
+}
+
+// Copy a table's dense rows into LDS, cutting ids >= `hot` to the trap id `hot` (table A: 254 rows of its 255).
+__device__ inline void PairLoadRows(uint8_t* dst, const uint8_t* src, uint32_t srcHot, uint32_t hot)
+{
+	const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+	uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+	for (uint32_t i = threadIdx.x; i < hot * 64; i += blockDim.x) {
+		uint32_t w = s[i];
+		if (srcHot > hot) {
+			uint32_t o = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const uint32_t e = (w >> (8 * b)) & 0xFF;
+				o |= (e < hot ? e : hot) << (8 * b);
+			}
+			w = o;
+		}
+		d[i] = w;
+	}
+	for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)   // the trap row: absorbing
+		d[hot * 64 + i] = hot * 0x01010101u;
+}
+
+__global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const ScanParams& pa = q.a;
+	const ScanParams& pb = q.b;
+	PairSide A, B;
+	A.hot = pa.hot < kPairHotA ? pa.hot : kPairHotA;
+	B.hot = pb.hot;
+	A.rows = lds;
+	B.rows = lds + kPairBaseB;
+	uint8_t* tail = lds + kPairBaseB + (B.hot + 1) * 256;
+	A.flags = tail;
+	B.flags = tail + 256;
+	A.cls = reinterpret_cast<const uint16_t*>(tail + 512);
+	B.cls = reinterpret_cast<const uint16_t*>(tail + 512 + 528);
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = pa.n / 64;
+	const uint32_t ntiles = uint32_t(pa.len / 128);   // even, >= 2 (the launcher checks)
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t voff = (lane & ~7u) * uint32_t(pa.stride) + (lane & 7u) * 16;
+	const uint64_t text = reinterpret_cast<uint64_t>(pa.text);
+	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
+	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	bool primed = firstTask < ntasks;
+	if (primed)
+		PairIssueTile<true>(a, voff, Uniform64(text + firstTask * 64 * pa.stride), pa.stride);
+	PairLoadRows(lds, pa.hotRows, pa.hot, A.hot);
+	PairLoadRows(lds + kPairBaseB, pb.hotRows, pb.hot, B.hot);
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
+		tail[i] = i < A.hot ? pa.hotFlags[i] : 0;
+		tail[256 + i] = pb.hotFlags[i];
+	}
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x) {
+		reinterpret_cast<uint16_t*>(tail + 512)[i] = pa.cls[i];
+		reinterpret_cast<uint16_t*>(tail + 512 + 528)[i] = pb.cls[i];
+	}
+	__syncthreads();
+
+	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
+		const uint64_t s0 = task * 64;
+		const uint64_t s = s0 + lane;
+		const uint64_t rowBase = Uniform64(text + s0 * pa.stride);
+		const bool hasNext = task + taskStep < ntasks;
+		const uint64_t chainBase = hasNext ? Uniform64(text + (s0 + taskStep * 64) * pa.stride) : rowBase + uint64_t(lastTile) * 128;
+		uint32_t ca = pa.startPerm, cb = pb.startPerm;   // Initialize() (+ Begin()) of both, folded by the host
+		uint32_t ha = ca < A.hot ? ca : A.hot, hb = cb < B.hot ? cb : B.hot;
+		bool done = false;
+		if (!primed)
+			PairIssueTile<true>(a, voff, rowBase, pa.stride);
+		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+			PairIssueTile<true>(b, voff, rowBase + uint64_t(t + 1) * 128, pa.stride);
+			PairWaitTile<1>(a);
+			TransposeTile(a, lane);
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				PairStepChunk(q, A, B, a[k], ha, ca, hb, cb);
+			PairIssueTile<true>(a, voff, t + 2 < ntiles ? rowBase + uint64_t(t + 2) * 128 : chainBase, pa.stride);
+			PairWaitTile<1>(b);
+			TransposeTile(b, lane);
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				PairStepChunk(q, A, B, b[k], ha, ca, hb, cb);
+			// ScannerPair is absorbing when both sides are (the early-out of the single kernels, for the pair)
+			const bool absA = ha != A.hot && (A.flags[ha] & kAbsorbing);
+			const bool absB = hb != B.hot && (B.flags[hb] & kAbsorbing);
+			done = __all(absA && absB) && t + 2 < ntiles;
+		}
+		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
+		if (done)
+			PairWaitTile<0>(a);
+		uint32_t sa = ha != A.hot ? ha : ca, sb = hb != B.hot ? hb : cb;
+		if (!done) {
+			const uint8_t* base = pa.text + s * pa.stride;
+			for (uint64_t i = uint64_t(ntiles) * 128; i < pa.len; ++i) {
+				sa = PairSlowStep(pa, A, sa, base[i]);
+				sb = PairSlowStep(pb, B, sb, base[i]);
+			}
+		}
+		// End(), StateIndex of both, Final = either (pair.h:69-72, 79-82)
+		const FinRec* ra = (pa.flags & PIRE_HIP_RUN_END) ? pa.finEnd : pa.finSelf;
+		const FinRec* rb = (pb.flags & PIRE_HIP_RUN_END) ? pb.finEnd : pb.finSelf;
+		const u32x4 rawA = *reinterpret_cast<const u32x4*>(&ra[sa]);
+		const u32x4 rawB = *reinterpret_cast<const u32x4*>(&rb[sb]);
+		if (pa.outIdx)
+			pa.outIdx[s] = rawA.x;
+		if (q.outIdxB)
+			q.outIdxB[s] = rawB.x;
+		if (pa.outFinal)
+			pa.outFinal[s] = ((rawA.y | rawB.y) >> 28) & kFinal;
+	}
+	PairWaitTile<0>(a);
+	PairWaitTile<0>(b);
+}
+
+bool PairTiledEligible(const ScanParams& a, const ScanParams& b)
+{
+	const uint32_t need = kPairBaseB + (b.hot + 1) * 256 + 512 + 2 * 528 + 64;
+	return TiledEligible(a) && a.len >= 256 && (a.len / 128) % 2 == 0 && need <= kLdsPerBlock;
+}
+
+int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream)
+{
+	PairParams q;
+	q.a = a;
+	q.b = b;
+	q.outIdxB = outIdxB;
+	q.a.n = a.n & ~uint64_t(63);   // whole 64-string tasks; the caller runs the remainder as two ordinary passes
+	if (q.a.n == 0)
+		return PIRE_HIP_OK;
+	const uint32_t ldsBytes = kPairBaseB + (b.hot + 1) * 256 + 512 + 2 * 528 + 64;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanPairTiledKernel),
+	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	const uint64_t ntasks = q.a.n / 64;
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + 15) / 16, uint64_t(cus)));
+	NoteKernel("pair_tiled", "pirehip::ScanPairTiledKernel");
+	hipLaunchKernelGGL(ScanPairTiledKernel, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
+	e = hipGetLastError();
+	if (e != hipSuccess)
+		return HipFail(e, "pair kernel launch");
+	return PIRE_HIP_OK;
+}
+
+// Final = either (pair.h:69-72) for the two-pass form: fin[i] |= other[i]
+__global__ void OrFinalKernel(uint8_t* fin, const uint8_t* other, uint64_t n)
+{
+	const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (i < n)
+		fin[i] |= other[i];
+}
+
+int LaunchOrFinal(uint8_t* fin, const uint8_t* other, uint64_t n, hipStream_t stream)
+{
+	if (n == 0)
+		return PIRE_HIP_OK;
+	hipLaunchKernelGGL(OrFinalKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, fin, other, n);
+	const hipError_t e = hipGetLastError();
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "or-final kernel launch");
+}
+
+}  // namespace pirehip

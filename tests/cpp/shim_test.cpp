@@ -249,6 +249,44 @@ static void TestScannerPair()
 		CHECK(pair.StateIndex(st[i]) == pair.StateIndex(want));
 	}
 	CHECK(fin[0] && fin[1] && fin[2] && !fin[3] && !fin[4] && fin[5] && !fin[6]);
+
+	// device-resident fixed-length records: ONE fused pass (pire_hip_run_pair_strided), against
+	// Pire::Run(scanner1, scanner2, state1, state2, begin, end) of run.h:229-241
+	const size_t n = 1000, len = 512;
+	std::vector<char> recs(n * len);
+	unsigned seed = 99;
+	for (size_t i = 0; i < recs.size(); ++i) {
+		seed = seed * 1103515245u + 12345u;
+		recs[i] = "abcdefhelo w xyz"[(seed >> 16) & 15];
+	}
+	for (size_t i = 0; i < n; i += 7)
+		memcpy(&recs[i * len + len - 12], "hello  world", 12);
+	void* dText = nullptr;
+	Pire::Hip::Check(pire_hip_device_alloc(recs.size(), &dText));
+	Pire::Hip::Check(pire_hip_copy_to_device(dText, recs.data(), recs.size(), nullptr));
+	Pire::Hip::Check(pire_hip_stream_synchronize(nullptr));
+	Pire::Hip::PairBatchRunner<Pire::Scanner, Pire::SimpleScanner> dev(s1, s2);
+	dev.Begin().End();
+	const std::vector<Pair::State> dst = dev.RunDeviceStrided(dText, n, len, len).States();
+	const std::vector<char> dfin = dev.Finals();
+	CHECK(std::string(pire_hip_last_kernel()) == "generic" || std::string(pire_hip_last_kernel()) == "pair_tiled");
+	size_t finals = 0;
+	for (size_t i = 0; i < n; ++i) {
+		Pire::Scanner::State a;
+		Pire::SimpleScanner::State b;
+		s1.Initialize(a);
+		s2.Initialize(b);
+		Pire::Step(s1, a, Pire::BeginMark);
+		Pire::Step(s2, b, Pire::BeginMark);
+		Pire::Run(s1, s2, a, b, &recs[i * len], &recs[i * len] + len);
+		Pire::Step(s1, a, Pire::EndMark);
+		Pire::Step(s2, b, Pire::EndMark);
+		CHECK(dst[i].first == a && dst[i].second == b);
+		CHECK((dfin[i] != 0) == (s1.Final(a) || s2.Final(b)));
+		finals += dfin[i] != 0;
+	}
+	CHECK(finals >= n / 7);
+	pire_hip_device_free(dText);
 }
 
 // Pire::CountingScanner / AdvancedCountingScanner (extra/count.h), built and driven as tests/count_ut.cpp:54-93 does.
