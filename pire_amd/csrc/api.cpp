@@ -488,7 +488,9 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		return Dispatch(p, stream, NextWorkSlot(t, p), offsets ? ~0ull : 0);
 	}
 
-	// Host-pointer mode: stage through HBM.  (PCIe-inclusive; the benchmark never times this mode.)
+	// Host-pointer mode (PCIe-inclusive; the benchmark never times this mode): batches of 8 MiB or more go through the
+	// chunked, pooled staging of RunHostPipelined; small ones, few long strings (segmented scan) and timed calls are staged
+	// in one piece.
 	if (n == 0)
 		return PIRE_HIP_OK;
 	Staging st;

@@ -40,7 +40,11 @@ def test_scan_kernels_have_no_scratch_and_no_spills():
     assert tiled, "no tiled kernel instantiation found"
     ragged = {k: v for k, v in resources("ragged.hip").items() if "ScanRaggedKernel" in k}
     assert ragged, "no ragged kernel found"
-    for name, res in list(tiled.items()) + list(ragged.items()):
+    pair = {k: v for k, v in resources("pair.hip").items() if "ScanPairTiledKernel" in k}
+    assert pair, "no fused pair kernel found"
+    for name, res in pair.items():
+        assert res["VGPRs"] <= 128, (name, res)   # 16 waves per CU, like the tiled kernel it shares the load path with
+    for name, res in list(tiled.items()) + list(ragged.items()) + list(pair.items()):
         assert res.get("ScratchSize", -1) == 0, (name, res)
         assert res.get("VGPRs Spill", -1) == 0, (name, res)   # SGPR spills go to VGPR lanes, harmless
     for name, res in tiled.items():
