@@ -110,16 +110,20 @@ __device__ __forceinline__ void SlowStep(const uint32_t* masks, uint32_t letters
 // as a LIST of up to four state ids while it fits: a step is four independent lookups, the same for every lane.
 // Both forms hold exactly the reference's set (slow.h:63-74) -- a list may name a state twice, which changes
 // nothing -- so the results do not depend on the form.
+// An empty list slot holds the id E = `states`, one past the last state: the `single` table has a row for it that
+// leads back to E, so that the step needs no "is this slot in use" test (round 2: 83 -> ~50 VALU per byte).
 template <int K>
 struct SlowLane {
-	uint32_t lst[4];     // list form: state ids, kSlowNone = empty slot (anywhere)
+	uint32_t lst[4];     // list form: state ids, E = empty slot (anywhere)
 	uint32_t cur[K];     // bitset form
+	uint32_t E;          // the empty marker (= number of states)
 	bool bits;           // which form is valid
 
-	__device__ __forceinline__ void Start(uint32_t start)
+	__device__ __forceinline__ void Start(uint32_t start, uint32_t states)
 	{
+		E = states;
 		lst[0] = start;
-		lst[1] = lst[2] = lst[3] = kSlowNone;
+		lst[1] = lst[2] = lst[3] = E;
 		bits = false;
 #pragma unroll
 		for (int k = 0; k < K; ++k)
@@ -133,7 +137,7 @@ struct SlowLane {
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			const uint32_t s = lst[i];
-			if (s != kSlowNone) {
+			if (s != E) {
 #pragma unroll
 				for (int k = 0; k < K; ++k)
 					cur[k] |= (s >> 5) == uint32_t(k) ? (1u << (s & 31)) : 0u;
@@ -150,7 +154,7 @@ struct SlowLane {
 			count += __popc(cur[k]);
 		if (count > 4)
 			return;
-		uint32_t n[4] = {kSlowNone, kSlowNone, kSlowNone, kSlowNone};
+		uint32_t n[4] = {E, E, E, E};
 		uint32_t used = 0;
 #pragma unroll
 		for (int k = 0; k < K; ++k) {
@@ -174,29 +178,28 @@ struct SlowLane {
 	{
 		if (!bits) {
 			// Every state moves to its (first) target IN PLACE -- no compaction, no duplicate check: a duplicate only
-			// wastes a slot.  A second target (the one row in a hundred where the set grows, e.g. the start state
-			// meeting the pattern's first letter) is put into a free slot; two of them in one step, no free slot, or
-			// a row with three targets send the lane to the bitset form.  Branch free (bitwise and / or on 0/1
-			// values): the short-circuit forms compiled into hundreds of tiny basic blocks.
-			uint32_t n[4], extra = kSlowNone, extras = 0, overflow = 0;
+			// wastes a slot; an empty slot (E) moves to E.  A second target (the one row in a hundred where the set
+			// grows, e.g. the start state meeting the pattern's first letter) is put into a free slot; two of them in one
+			// step, no free slot, or a row with three targets send the lane to the bitset form.  Branch free.  Row
+			// entries: x = first target, or kSlowMulti (the only value with the top bit set that x can take); y =
+			// second target, or kSlowNone (top bit set).
+			uint32_t n[4], extra = 0, extras = 0, multi = 0;
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
-				const uint32_t s = lst[i];
-				const uint32_t invalid = s == kSlowNone ? kSlowNone : 0u;
-				const uint2 r = single[(invalid ? 0u : s) * letters + letter];
-				const uint32_t t0 = r.x | invalid, t1 = r.y | invalid;
-				overflow |= uint32_t(t0 == kSlowMulti);
-				n[i] = t0;
-				const uint32_t has = uint32_t(t1 != kSlowNone);
-				extra = has ? t1 : extra;
-				extras += has;
+				const uint2 r = single[__umul24(lst[i], letters) + letter];
+				n[i] = r.x;
+				multi |= r.x;
+				const bool has = int32_t(r.y) >= 0;
+				extra = has ? r.y : extra;
+				extras += has ? 1u : 0u;
 			}
+			uint32_t overflow = multi >> 31;
 			if (__any(extras != 0)) {
 				overflow |= uint32_t(extras > 1);
 				uint32_t placed = uint32_t(extras != 1);
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
-					const uint32_t take = uint32_t(n[j] == kSlowNone) & (placed ^ 1u);
+					const uint32_t take = uint32_t(n[j] == E) & (placed ^ 1u);
 					n[j] = take ? extra : n[j];
 					placed |= take;
 				}
@@ -223,7 +226,7 @@ struct SlowLane {
 		} else {
 #pragma unroll
 			for (int i = 0; i < 4; ++i)
-				fin = fin || (lst[i] != kSlowNone && ((finals[lst[i] >> 5] >> (lst[i] & 31)) & 1u));
+				fin = fin || (lst[i] != E && ((finals[lst[i] >> 5] >> (lst[i] & 31)) & 1u));
 		}
 		return fin;
 	}
@@ -236,11 +239,12 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 	uint8_t* ldsLetter = lds;                                        // 264 bytes
 	uint32_t* ldsSingle = reinterpret_cast<uint32_t*>(lds + 272);
 	const uint32_t entries = p.states * p.letters;
-	uint32_t* ldsMasks = ldsSingle + (p.singleInLds ? 2 * entries : 0);
+	const uint32_t singleEntries = (p.states + 1) * p.letters;   // + the row of the empty marker
+	uint32_t* ldsMasks = ldsSingle + (p.singleInLds ? 2 * singleEntries : 0);
 	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
 		ldsLetter[i] = p.letterOf[i];
 	if (p.singleInLds)
-		for (uint32_t i = threadIdx.x; i < 2 * entries; i += blockDim.x)
+		for (uint32_t i = threadIdx.x; i < 2 * singleEntries; i += blockDim.x)
 			ldsSingle[i] = p.single[i];
 	const uint32_t maskWords = entries * K;
 	if (p.masksInLds)
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 			e = b + p.len;
 		}
 		SlowLane<K> lane;
-		lane.Start(p.start);                                             // Initialize, slow.h:89-95
+		lane.Start(p.start, p.states);                                   // Initialize, slow.h:89-95
 		if (p.flags & PIRE_HIP_RUN_BEGIN)
 			lane.Step(masks, single, p.letters, ldsLetter[kBeginMark]);  // Begin(), run.h:375
 		const uint8_t* ptr = p.text + b;
@@ -499,7 +503,8 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 		h.words = 1;
 		h.letterOf.assign(kMaxChar, 0);
 		h.masks.assign(1, 0);
-		h.single.assign(2, kSlowNone);
+		h.single.assign(4, kSlowNone);
+		h.single[0] = h.single[2] = 1;   // state 0 goes nowhere (its slot empties), and the empty marker E = 1 stays E
 		h.finals.assign(1, 0);
 		return PIRE_HIP_OK;
 	}
@@ -564,9 +569,12 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 			memcpy(&tgt, p + pos + size_t(k) * 4, 4);
 			h.masks[i * h.words + (tgt >> 5)] |= 1u << (tgt & 31);
 		}
-	// the first two distinct targets of every jump list, for the list form of the walk: [2*i] and [2*i+1], kSlowNone
-	// where there is none; three or more distinct targets: [2*i] = kSlowMulti
-	h.single.assign(size_t(states) * letters * 2, kSlowNone);
+	// the first two distinct targets of every jump list, for the list form of the walk: [2*i] = the first target (E =
+	// `states`, the empty marker, when the list is empty), [2*i+1] = the second or kSlowNone; three or more distinct
+	// targets: [2*i] = kSlowMulti
+	h.single.assign(size_t(states + 1) * letters * 2, kSlowNone);
+	for (uint64_t l = 0; l < letters; ++l)
+		h.single[(size_t(states) * letters + l) * 2] = uint32_t(states);   // the empty marker E = states stays E
 	for (size_t i = 0; i + 1 < npos; ++i) {
 		uint32_t t0 = kSlowNone, t1 = kSlowNone;
 		bool multi = false;
@@ -582,7 +590,7 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 			else if (tgt != t1)
 				multi = true;
 		}
-		h.single[2 * i] = multi ? kSlowMulti : t0;
+		h.single[2 * i] = multi ? kSlowMulti : t0 == kSlowNone ? uint32_t(states) : t0;   // no target: the slot empties (E)
 		h.single[2 * i + 1] = multi ? kSlowNone : t1;
 	}
 	return PIRE_HIP_OK;
@@ -679,7 +687,7 @@ int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
 {
 	SlowParams p = p0;
 	const size_t maskBytes = size_t(p.states) * p.letters * K * 4;
-	const size_t singleBytes = size_t(p.states) * p.letters * 8;
+	const size_t singleBytes = size_t(p.states + 1) * p.letters * 8;
 	p.singleInLds = singleBytes <= 64 * 1024 ? 1 : 0;
 	p.masksInLds = maskBytes + (p.singleInLds ? singleBytes : 0) <= 150 * 1024 ? 1 : 0;
 	const uint32_t ldsBytes = uint32_t(272 + (p.singleInLds ? singleBytes : 0) + (p.masksInLds ? maskBytes : 0));
