@@ -45,6 +45,24 @@ timeout 200 python tools/actions_case.py 2>&1 | grep -v amdgpu.ids > $OUT/action
 LONG_TOTAL_LOG2=30 timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm" | tee $OUT/long_strings.log | cut -c1-200
 timeout 200 python tools/long_half_final.py 2>&1 | grep -v amdgpu.ids | tee $OUT/long_half_final.log | cut -c1-200
 timeout 200 python tools/capture_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/capture.log | cut -c1-200
+timeout 200 python tools/pair_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pair.log | cut -c1-200
+for st in slow_x300 slow_x400_utf8; do timeout 400 python bench.py --set $st --log2-strings 16 --len 4096 --steps 3 --warmup 1 --cpu-sample-log2 10 2>&1 | tail -1 | cut -c1-1500; done > $OUT/bench_slow_wide.jsonl; cut -c1-200 $OUT/bench_slow_wide.jsonl
+echo "== host-pointer mode through the python binding"
+timeout 600 python - <<'PY' 2>&1 | grep -v amdgpu.ids | tee $OUT/host_mode.log
+import time, numpy as np
+import pire_amd
+from oracle import binding as ob
+from tests import helpers as H
+big=[b for b in H.big_sets() if b["name"]=="set_a"][0]
+t=pire_amd.Table(H.load_blob(big["blob"])); t.upload()
+for n,L in ((1<<16,4096),(1<<18,4096),(1<<19,4096)):
+    data=ob.corpus_fill(0x5EED5EED,0,n,L,H.plants_for(big),threads=32)
+    t.run_strided_host(data[:1024])
+    best=1e9
+    for _ in range(3):
+        t0=time.perf_counter(); idx,fin=t.run_strided_host(data); dt=time.perf_counter()-t0; best=min(best,dt)
+    print("host-pointer mode: %d x %d B (%.0f MiB pageable): %.1f ms -> %.2f GB/s" % (n,L,n*L/2**20,best*1e3,n*L/best/1e9))
+PY
 echo "== C++ shim (host pointers, pinned, device-resident) and the pigrep example"
 tests/cpp/bin/shim_test 2>&1 | tail -2 | tee $OUT/shim.log
 examples/bin/pigrep_hip -i "lds.*bytes" DESIGN.md | head -2
