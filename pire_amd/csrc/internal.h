@@ -221,6 +221,9 @@ struct ScanParams {
 	uint8_t* outFinal;       // nullable
 	unsigned long long* outCounts;  // nullable
 	unsigned long long* workBase;   // host side only: the ring of ragged work counters of the image in use
+#ifdef PIRE_HIP_TUNING
+	unsigned long long* stamps;     // timing experiments: [blocks][4] wall-clock stamps (start, table loaded, walk done, end)
+#endif
 };
 
 __host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)

@@ -157,9 +157,17 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	// The first tile of the wave's first task is requested BEFORE the table is copied into LDS: its HBM latency (a
 	// few microseconds when all 4 096 waves of a launch ask at once) then hides behind the copy.
 	bool primed = firstTask < ntasks;   // slot a already holds (or is receiving) tile 0 of the task about to start
+#ifdef PIRE_HIP_TUNING
+	if (p.stamps && threadIdx.x == 0)
+		p.stamps[blockIdx.x * 4 + 0] = wall_clock64();
+#endif
 	if (primed)
 		IssueTile<NT>(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), istride);
 	LoadTableToLds(p, lds, L);
+#ifdef PIRE_HIP_TUNING
+	if (p.stamps && threadIdx.x == 0)
+		p.stamps[blockIdx.x * 4 + 1] = wall_clock64();
+#endif
 	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
 		const uint64_t s0 = task * 64;
 		const uint64_t s = s0 + mine;
@@ -209,6 +217,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 		}
 		Finish(p, lds, L, s, true, st);
 	}
+#ifdef PIRE_HIP_TUNING
+	if (p.stamps && lane == 0)
+		atomicMax(&p.stamps[blockIdx.x * 4 + 2], wall_clock64());   // the block's last wave out of the walk
+	if (p.stamps && lane == 0)
+		atomicMin(&p.stamps[blockIdx.x * 4 + 3], wall_clock64());   // ... and its first
+#endif
 	FlushCounts(p, lds, L);
 }
 
@@ -231,6 +245,7 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	const int variant = checkedEnv && checkedEnv[0] == '1' ? 4 : variantEnv ? atoi(variantEnv) : 0;
 	ScanParams q = p;
 #ifdef PIRE_HIP_TUNING
+	q.stamps = nullptr;
 	if (getenv("PIRE_HIP_DEBUG_NOLOAD"))
 		q.flags |= kDebugNoRefill;
 	if (getenv("PIRE_HIP_DEBUG_NOSTEP"))
@@ -245,6 +260,17 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		q.flags |= kDebugNoTrap;
 	if (getenv("PIRE_HIP_DEBUG_TASKMAP"))
 		q.flags |= kDebugTaskMap;
+	static unsigned long long* stampBuf = nullptr;
+	const bool stamping = getenv("PIRE_HIP_DEBUG_STAMPS") != nullptr;
+	if (stamping) {
+		if (!stampBuf)
+			(void)hipMalloc(reinterpret_cast<void**>(&stampBuf), 1024 * 4 * 8);
+		std::vector<unsigned long long> init(1024 * 4, 0);
+		for (int b = 0; b < 1024; ++b)
+			init[b * 4 + 3] = ~0ull;
+		(void)hipMemcpy(stampBuf, init.data(), init.size() * 8, hipMemcpyHostToDevice);
+		q.stamps = stampBuf;
+	}
 #endif
 	if (variant == 1)
 		q.compact = 0;   // the compact rows hold LDS addresses of the 256-byte-pitch layout
@@ -270,6 +296,31 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
 		break;
 	}
+#ifdef PIRE_HIP_TUNING
+	if (stamping && rc == PIRE_HIP_OK) {
+		(void)hipDeviceSynchronize();
+		std::vector<unsigned long long> st(1024 * 4);
+		(void)hipMemcpy(st.data(), stampBuf, st.size() * 8, hipMemcpyDeviceToHost);
+		unsigned long long t0 = ~0ull, tEnd = 0;
+		std::vector<double> loaded, firstOut, lastOut;
+		for (int b = 0; b < 1024; ++b)
+			if (st[b * 4 + 0]) {
+				t0 = std::min(t0, st[b * 4 + 0]);
+				tEnd = std::max(tEnd, st[b * 4 + 2]);
+			}
+		for (int b = 0; b < 1024; ++b)
+			if (st[b * 4 + 0]) {   // wall_clock64 ticks at 100 MHz
+				loaded.push_back((st[b * 4 + 1] - t0) / 100.0);
+				firstOut.push_back((st[b * 4 + 3] - t0) / 100.0);
+				lastOut.push_back((st[b * 4 + 2] - t0) / 100.0);
+			}
+		auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[size_t(q * (v.size() - 1))]; };
+		fprintf(stderr, "pire_hip stamps (us from the first block's start): table loaded min %.1f median %.1f max %.1f | first wave "
+		        "of a block done min %.1f median %.1f max %.1f | last wave of a block done min %.1f median %.1f p90 %.1f max %.1f\n",
+		        pct(loaded, 0), pct(loaded, 0.5), pct(loaded, 1), pct(firstOut, 0), pct(firstOut, 0.5), pct(firstOut, 1),
+		        pct(lastOut, 0), pct(lastOut, 0.5), pct(lastOut, 0.9), pct(lastOut, 1));
+	}
+#endif
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;
 	ScanParams tail = p;
