@@ -113,7 +113,7 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 	if (p.outCounts)
 		for (uint32_t i = tid; i < p.regexps + 2; i += nthr)
 			reinterpret_cast<uint32_t*>(lds + L.countsOff)[i] = 0;
-	for (uint32_t i = tid; i < 256; i += nthr)
+	for (uint32_t i = tid; i < 256 + 4; i += nthr)   // the visit samples and, behind them, the progress counter
 		reinterpret_cast<uint32_t*>(lds + L.histOff)[i] = 0;
 	__syncthreads();
 }

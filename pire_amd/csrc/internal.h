@@ -43,6 +43,7 @@ struct LdsLayout {
 	uint32_t clsOff;       // 264 u16 (generic kernel + slow step)
 	uint32_t countsOff;    // (regexps+2) u32 block-local counters
 	uint32_t histOff;      // 256 u32: sampled visits of hot ids (feeds pire_hip_table_adapt)
+	uint32_t progOff;      // u32: tiles walked by the waves of the block (tiled kernel: keeps them in step)
 	uint32_t total;
 };
 
@@ -69,7 +70,8 @@ __host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps, 
 	l.clsOff = l.compactOff + l.compactBytes;
 	l.countsOff = l.clsOff + 528;
 	l.histOff = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
-	l.total = l.histOff + 1024;
+	l.progOff = l.histOff + 1024;   // 16 B: the tiled kernel's block-wide progress counter
+	l.total = l.progOff + 16;
 	return l;
 }
 

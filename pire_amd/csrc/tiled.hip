@@ -93,11 +93,33 @@ __device__ __forceinline__ bool AllAbsorbing(const ScanParams& p, const uint8_t*
 }
 
 
-template <int NBUF, bool NT, int ROT>
+// EQ: keep the waves of a block in step.  Every tile a wave adds 1 to a block-wide progress counter (LDS) and compares
+// 16 x its own tile count with the sum: a wave ahead of the block's average by more than a quarter tile drops its issue
+// priority, one behind raises it.  Without it the 16 waves of a block, which all do exactly the same amount of work,
+// finish up to 30 us apart (profiles/r02_tiled_block_stamps.log: age-ordered arbitration lets some waves run ahead all
+// the way) and the CU idles half empty at the end of a launch; with it 10 us.  Worth 1.3 % on the 2^20 x 4 KiB headline
+// (9 of 9 alternating pairs), 4.8 % with the single-pattern table, nothing from 8 tasks per wave up, -0.7 % on C++ text
+// (profiles/r02_tiled_equalise.log).
+template <int NBUF, bool NT, int ROT, bool EQ = false>
 __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
                                       uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
-                                      uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold)
+                                      uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs, uint32_t& cold,
+                                      uint32_t* prog = nullptr, uint32_t* myTiles = nullptr)
 {
+	if (EQ) {
+		uint32_t sum = 0;
+		if (lane == 0)
+			sum = atomicAdd(prog, 1u) + 1;
+		sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+		const uint32_t mine = ++*myTiles;
+		constexpr uint32_t margin = 4;   // in sixteenths of a tile (0 / 4 / 8: equal; 16, 32: less effect)
+		if (mine * (blockDim.x >> 6) > sum + margin)
+			__builtin_amdgcn_s_setprio(0);
+		else if (mine * (blockDim.x >> 6) + margin < sum)
+			__builtin_amdgcn_s_setprio(3);
+		else
+			__builtin_amdgcn_s_setprio(1);
+	}
 	// Refill target: the next tile of this task, or -- on the task's last tile -- tile 0 of the wave's NEXT task
 	// (chainBase; equals this task's last tile when there is nothing to chain to), so that neither the HBM
 	// latency of a task's first tile nor a duplicate load of its last tile is ever paid.
@@ -119,7 +141,7 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
 // the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
 // gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
-template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false>
+template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false, bool EQ = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
@@ -148,6 +170,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	u32x4 a[8], b[8];
 	ZeroTile(a);
 	ZeroTile(b);
+	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + L.progOff);   // zeroed with the visit samples by LoadTableToLds
+	uint32_t myTiles = 0;
 
 	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
 	const bool chain = rem == 0;
@@ -189,8 +213,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 			IssueTile<NT>(a, voff, rowBase, istride);
 		for (uint32_t g = 0; g < groups && !done; ++g) {
 			const uint32_t t = g * 2;
-			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold);
-			Phase<2, NT, ROT>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold);
+			Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold, prog, &myTiles);
+			Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold, prog, &myTiles);
 			done = AllAbsorbing(p, lds, L, hs);
 			if (CHECKED && done) {
 				if (!noted)
@@ -287,13 +311,17 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,plain,5>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream);   // no nt
 		break;
+	case 20:
+		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,free-running>");
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);   // waves not kept in step
+		break;
 	case 4:   // also chosen by PIRE_HIP_CHECKED=1
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,checked>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream);
 		break;
 	default:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream);
 		break;
 	}
 #ifdef PIRE_HIP_TUNING
