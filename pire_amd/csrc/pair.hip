@@ -176,6 +176,11 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 		reinterpret_cast<uint16_t*>(tail + 512)[i] = pa.cls[i];
 		reinterpret_cast<uint16_t*>(tail + 512 + 528)[i] = pb.cls[i];
 	}
+	// block-wide progress counter: the waves of a block are kept in step by issue priority, as in the tiled kernel
+	uint32_t* prog = reinterpret_cast<uint32_t*>(tail + 512 + 2 * 528);
+	if (threadIdx.x == 0)
+		*prog = 0;
+	uint32_t myTiles = 0;
 	__syncthreads();
 
 	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
@@ -190,6 +195,19 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 		if (!primed)
 			PairIssueTile<true>(a, voff, rowBase, pa.stride);
 		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+			{
+				uint32_t sum = 0;
+				if (lane == 0)
+					sum = atomicAdd(prog, 2u) + 2;
+				sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+				myTiles += 2;
+				if (myTiles * 16 > sum + 8)
+					__builtin_amdgcn_s_setprio(0);
+				else if (myTiles * 16 + 8 < sum)
+					__builtin_amdgcn_s_setprio(3);
+				else
+					__builtin_amdgcn_s_setprio(1);
+			}
 			PairIssueTile<true>(b, voff, rowBase + uint64_t(t + 1) * 128, pa.stride);
 			PairWaitTile<1>(a);
 			TransposeTile(a, lane);
