@@ -342,6 +342,15 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 				firstOut.push_back((st[b * 4 + 3] - t0) / 100.0);
 				lastOut.push_back((st[b * 4 + 2] - t0) / 100.0);
 			}
+		if (const char* dump = getenv("PIRE_HIP_DEBUG_STAMPS_DUMP")) {   // raw per-block stamps (us): block start loaded first-out last-out
+			if (FILE* f = fopen(dump, "w")) {
+				for (int b = 0; b < 1024; ++b)
+					if (st[b * 4 + 0])
+						fprintf(f, "%d %.2f %.2f %.2f %.2f\n", b, (st[b * 4 + 0] - t0) / 100.0, (st[b * 4 + 1] - t0) / 100.0,
+						        (st[b * 4 + 3] - t0) / 100.0, (st[b * 4 + 2] - t0) / 100.0);
+				fclose(f);
+			}
+		}
 		auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[size_t(q * (v.size() - 1))]; };
 		fprintf(stderr, "pire_hip stamps (us from the first block's start): table loaded min %.1f median %.1f max %.1f | first wave "
 		        "of a block done min %.1f median %.1f max %.1f | last wave of a block done min %.1f median %.1f p90 %.1f max %.1f\n",
