@@ -68,23 +68,57 @@ __device__ __forceinline__ void IssueTileLane(u32x4 (&r)[8], uint64_t src)
 // 1.6-1.8 x the text because lines were evicted between the 8 instructions that touched them).  The tile then holds,
 // in lane 8g+c, register j = chunk c of the window of lane 8g+j: TransposeTile() (the tiled kernel's) puts every
 // lane's own window into its registers 0..7, and the walk is what it was.
-// `src` = this lane's window address (any alignment); the addresses travel inside the group through ds_bpermute.
+// `src` = this lane's window address (any alignment); the addresses travel inside the group by DPP (GroupBroadcast).
 // (Tried: per-lane loads and no transpose in the iterations in which every lane of the wave is in the middle of a long
 // string -- one whole line per lane is the better pattern there: fixed 4 KiB strings 3.3 against 2.8 TB/s.  A transpose
 // under a wave-uniform branch made hipcc spill 170-320 bytes per lane, tile registers included; not kept.  Fixed-length
 // batches belong to the tiled kernel anyway.)
+#ifndef PIRE_HIP_RAGGED_BPERMUTE
+// lane j of every group of 8 lanes, to all 8 lanes of its group: quad broadcast, then the other quad of the group copies
+// it (row_shr:4 into banks 1 and 3, or row_shl:4 into banks 0 and 2) -- VALU only, no trip through the LDS queue
+template <int J>
+__device__ __forceinline__ uint32_t GroupBroadcast(uint32_t x)
+{
+	constexpr int q = J & 3, quad = q | (q << 2) | (q << 4) | (q << 6);
+	const int y = __builtin_amdgcn_update_dpp(0, int(x), quad, 0xF, 0xF, false);
+	if constexpr (J < 4)
+		return uint32_t(__builtin_amdgcn_update_dpp(y, y, 0x114, 0xF, 0xA, false));   // row_shr:4 -> quads 1, 3
+	else
+		return uint32_t(__builtin_amdgcn_update_dpp(y, y, 0x104, 0xF, 0x5, false));   // row_shl:4 -> quads 0, 2
+}
+#endif
+
+template <int J>
+__device__ __forceinline__ void IssueTileGroupOne(u32x4& r, uint32_t lo, uint32_t hi, uint32_t sel, uint32_t mine)
+{
+#ifndef PIRE_HIP_RAGGED_BPERMUTE
+	const uint32_t l = GroupBroadcast<J>(lo);
+	const uint32_t h = GroupBroadcast<J>(hi);
+#else   // A/B: through the LDS queue, behind the other waves' table lookups (1-3 % slower, profiles/r02_ragged_clocks.log)
+	const uint32_t l = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * J), int(lo)));
+	const uint32_t h = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * J), int(hi)));
+#endif
+	const uint64_t a = ((uint64_t(h) << 32) | l) + mine;
+	asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(a));
+}
+
+// (Tried: lanes whose chunk of a window lies behind the string's end ask for the window's first chunk instead -- a third
+// fewer distinct chunks on URLs, 1-4 % SLOWER; consecutive strings to the lanes of one load instruction instead of to
+// consecutive lanes -- half the cache lines per instruction, no difference.  The load path of this kernel is not bound
+// by lines or requests: a window is simply on its way for 0.9 iterations, section clocks in profiles/r02_ragged_clocks.log.)
 __device__ __forceinline__ void IssueTileGroup(u32x4 (&r)[8], uint64_t src, uint32_t lane)
 {
 	const uint32_t lo = uint32_t(src), hi = uint32_t(src >> 32);
 	const uint32_t sel = (lane & ~7u) << 2;      // byte index of lane 8g for ds_bpermute
 	const uint32_t mine = (lane & 7u) << 4;      // this lane's 16 bytes of every window of its group
-#pragma unroll
-	for (int j = 0; j < 8; ++j) {
-		const uint32_t l = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * j), int(lo)));
-		const uint32_t h = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * j), int(hi)));
-		const uint64_t a = ((uint64_t(h) << 32) | l) + mine;
-		asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r[j]) : "v"(a));
-	}
+	IssueTileGroupOne<0>(r[0], lo, hi, sel, mine);
+	IssueTileGroupOne<1>(r[1], lo, hi, sel, mine);
+	IssueTileGroupOne<2>(r[2], lo, hi, sel, mine);
+	IssueTileGroupOne<3>(r[3], lo, hi, sel, mine);
+	IssueTileGroupOne<4>(r[4], lo, hi, sel, mine);
+	IssueTileGroupOne<5>(r[5], lo, hi, sel, mine);
+	IssueTileGroupOne<6>(r[6], lo, hi, sel, mine);
+	IssueTileGroupOne<7>(r[7], lo, hi, sel, mine);
 }
 
 __device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
@@ -494,13 +528,19 @@ template <bool EXT>
 __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                              uint32_t s, bool active, uint32_t st)
 {
+	// The record of a dense-row state comes from LDS, the record of any other state from memory -- under a wave-uniform
+	// branch of its own, and waited for inside it.  Written as one if/else per lane the compiler merges the two into a
+	// single FLAT load through a selected pointer, and the vmcnt(0) a flat load needs drained the window prefetched for
+	// the next iteration every time a string ended: a third of the URL batch's time (profiles/r02_ragged_clocks.log).
+	const bool cold = active && st >= p.hot;
 	u32x4 raw = {0, 0, 0, 0};
-	if (active) {
-		if (st < p.hot) {
-			raw = *reinterpret_cast<const u32x4*>(&finHot[st]);
-		} else {
+	if (active && !cold)
+		raw = *reinterpret_cast<const u32x4*>(&finHot[st]);
+	if (__any(cold)) {
+		if (cold) {
 			const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
 			raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+			asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));   // the wait belongs in here
 		}
 	}
 	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
@@ -628,6 +668,27 @@ __device__ __forceinline__ bool AssignPending(const ScanParams& p, volatile Ragg
 	return got;
 }
 
+#ifdef PIRE_HIP_TUNING
+// timing experiments (PIRE_HIP_DEBUG_RAGGED_CLOCKS): shader-clock time of a wave per section of an iteration, summed
+// over the waves into ScanParams::stamps: 0 wait for the window, 1 transpose + next window's loads, 2 assignment +
+// offsets, 3 walk, 4 end of string, 5 move on (waits for the offsets), 6 before the first iteration, 7 iterations
+struct RaggedClock {
+	unsigned long long t, acc[8];
+	bool on;
+};
+#define PIRE_RCLK(c, k)                                                 \
+	do {                                                                \
+		if ((c).on) {                                                   \
+			const unsigned long long n_ = __builtin_readcyclecounter(); \
+			(c).acc[k] += n_ - (c).t;                                   \
+			(c).t = n_;                                                 \
+		}                                                               \
+	} while (0)
+#else
+struct RaggedClock {};
+#define PIRE_RCLK(c, k) do { } while (0)
+#endif
+
 // One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
 // Returns false when the wave has nothing left to do.
 // EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
@@ -638,9 +699,10 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
                                             volatile RaggedWork* work, unsigned long long* workCounter,
                                             RaggedGrab grab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
                                             RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter,
-                                            const Act& act, typename Act::Lane& al)
+                                            const Act& act, typename Act::Lane& al, RaggedClock& clk)
 {
 	WaitAllLoads(cur);
+	PIRE_RCLK(clk, 0);
 	if constexpr (Act::kGroupLoads)
 		TransposeTile(cur, threadIdx.x & 63);
 
@@ -674,6 +736,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	}
 	if (takeNew)
 		S.pend = false;
+	PIRE_RCLK(clk, 1);
 	// the offsets of newly assigned strings: plain loads issued AFTER the tile loads and looked at only at the very
 	// end of this iteration, so the one wait the compiler inserts for them sits behind the walk
 	const bool got = AssignPending(p, work, workCounter, grab, R, S);
@@ -692,6 +755,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		}
 	}
 
+	PIRE_RCLK(clk, 2);
 	// ---- walk the current window
 	if ((threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
@@ -737,12 +801,14 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			S.cold = st;
 		}
 	}
+	PIRE_RCLK(clk, 3);
 	if constexpr (Act::kActive) {
 		if (ends)
 			act.Finish(p, lds, L, al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
 		FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
 	}
+	PIRE_RCLK(clk, 4);
 
 	// ---- move on
 	uint32_t startInit = 0;
@@ -770,6 +836,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	S.sIdx = nIdx;
 	S.busy = nBusy;
 	S.loaded = nLoad;
+	PIRE_RCLK(clk, 5);
 	return __any(nBusy || S.pend);
 }
 
@@ -778,6 +845,13 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
                                                          RaggedGrab grab, Act act)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	RaggedClock clk;
+#ifdef PIRE_HIP_TUNING
+	clk.on = p.stamps != nullptr;
+	for (int k = 0; k < 8; ++k)
+		clk.acc[k] = 0;
+	clk.t = clk.on ? __builtin_readcyclecounter() : 0;
+#endif
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
 	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + L.total + kRaggedFinBytes);
@@ -820,12 +894,22 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 		if (EXT && p.initIdx)
 			S.pendInit = p.initIdx[S.sIdxN];
 	}
-	for (uint32_t iter = 0;; iter += 2) {
-		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al))
+	PIRE_RCLK(clk, 6);
+	uint32_t iter = 0;
+	for (;; iter += 2) {
+		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al, clk))
 			break;
-		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al))
+		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al, clk))
 			break;
 	}
+#ifdef PIRE_HIP_TUNING
+	if (clk.on && (threadIdx.x & 63) == 0) {
+		clk.acc[7] = iter;
+		for (int k = 0; k < 8; ++k)
+			atomicAdd(&p.stamps[k], clk.acc[k]);
+		atomicAdd(&p.stamps[8], 1ull);
+	}
+#endif
 	FlushCounts(p, lds, L);
 }
 
@@ -877,12 +961,33 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 		q.flags |= (m & 1 ? kDebugNoPartial : 0) | (m & 2 ? kDebugNoFinish : 0) | (m & 4 ? kDebugNoTrap : 0) |
 		           (m & 8 ? kDebugNoStep : 0) | (m & 16 ? kDebugNoRefill : 0);
 	}
+	static unsigned long long* clockBuf = nullptr;
+	const bool clocks = getenv("PIRE_HIP_DEBUG_RAGGED_CLOCKS") != nullptr;
+	q.stamps = nullptr;
+	if (clocks) {
+		if (!clockBuf)
+			(void)hipMalloc(reinterpret_cast<void**>(&clockBuf), 16 * 8);
+		(void)hipMemset(clockBuf, 0, 16 * 8);
+		q.stamps = clockBuf;
+	}
 #endif
 	hipLaunchKernelGGL((ScanRaggedKernel<Act, EXT>), dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
 	                   q, workCounter, grab, act);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "ragged kernel launch");
+#ifdef PIRE_HIP_TUNING
+	if (clocks) {
+		(void)hipDeviceSynchronize();
+		unsigned long long c[16];
+		(void)hipMemcpy(c, clockBuf, sizeof c, hipMemcpyDeviceToHost);
+		const double waves = double(c[8] ? c[8] : 1), iters = double(c[7] ? c[7] : 1);
+		fprintf(stderr, "pire_hip ragged clocks: %llu waves, %.1f iterations per wave; shader clocks per wave and iteration: wait %.0f | "
+		        "transpose+issue %.0f | assign+offsets %.0f | walk %.0f | end of string %.0f | move on %.0f ; before the first iteration %.0f "
+		        "per wave\n", c[8], iters / waves, c[0] / iters, c[1] / iters, c[2] / iters, c[3] / iters, c[4] / iters, c[5] / iters,
+		        c[6] / waves);
+	}
+#endif
 	return PIRE_HIP_OK;
 }
 
