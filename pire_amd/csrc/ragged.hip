@@ -331,9 +331,10 @@ struct HalfFinalWideAct {
 // state no longer matters) and idles through the rest of its string.
 struct PrefixAct {
 	static constexpr bool kActive = true;
-	// per-lane loads: with the transpose's temporaries on top of its own per-lane state this instantiation needs more
-	// than the 128 VGPRs of 16 waves per CU (12 bytes of scratch -- and a spilled tile register is unsafe)
-	static constexpr bool kGroupLoads = false;
+	// group loads like the other walks since the window addresses travel by DPP (127 VGPRs; with ds_bpermute and its
+	// address temporaries this instantiation needed 12 bytes of scratch and kept per-lane loads, which made the
+	// wait for the window twice the walk: profiles/r02_ragged_clocks.log)
+	static constexpr bool kGroupLoads = true;
 	long long* outLen;
 	uint32_t longest, throughEnd;
 	struct Lane {
