@@ -931,6 +931,21 @@ try {
 	if (int rc = EnsureActDist(t, &distFinal, &distFlagged))
 		return rc;
 	p.actDist = distFinal;
+	{   // Initialize() and Begin() of a HalfFinalScanner end with TakeAction: walked once here (ScanParams::hfStart)
+		const HostTable& h = t->host;
+		uint32_t o = h.initial;
+		auto take = [&](uint32_t st) {
+			if ((h.flags[st] & kFinal) && h.incPacked)
+				for (int r = 0; r < 8; ++r)
+					p.hfStartC[r] += uint32_t(h.inc64[st] >> (8 * r)) & 0xFFu;
+		};
+		take(o);
+		if (flags & PIRE_HIP_RUN_BEGIN) {
+			o = h.next[size_t(o) * h.letters + h.cls[kBeginMark]];
+			take(o);
+		}
+		p.hfStart = h.permOfOrig[o];
+	}
 	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
 	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
 	// few long strings: the segmented scan resolves every segment's true start state, then the segments are counted

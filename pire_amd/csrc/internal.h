@@ -223,6 +223,11 @@ struct ScanParams {
 	uint8_t* outFinal;       // nullable
 	unsigned long long* outCounts;  // nullable
 	unsigned long long* workBase;   // host side only: the ring of ragged work counters of the image in use
+	// HalfFinalScanner on the ragged kernel: the state every string starts its text in (device id) and the counts
+	// Initialize() [+ Step(BeginMark)] have already taken (half_final.h:137-164) -- the same for every string, so the
+	// host walks those two steps once instead of every lane doing them (two dependent loads) for every string
+	uint32_t hfStart;
+	uint32_t hfStartC[8];
 #ifdef PIRE_HIP_TUNING
 	unsigned long long* stamps;     // timing experiments: [blocks][4] wall-clock stamps (start, table loaded, walk done, end)
 #endif

@@ -216,12 +216,17 @@ struct HalfFinalAct {
 	};
 	__device__ __forceinline__ bool Wants(const Lane&) const { return true; }
 	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotFinalLo; }
-	// the packed increments of the dense-row states, next to the table in LDS
+	// next to the table in LDS: the packed increments of the dense-row states (2 KiB), and the first half of their
+	// end-of-string records (StateIndex, end state | flags: 2 KiB) -- the part of FinishRagged()'s records this walk needs
 	__device__ __forceinline__ void LoadLds(const ScanParams& p, uint8_t* area) const
 	{
 		uint64_t* incHot = reinterpret_cast<uint64_t*>(area);
-		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+		uint2* endHot = reinterpret_cast<uint2*>(area + 2048);
+		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x) {
 			incHot[i] = p.incPerm[i];
+			endHot[i] = make_uint2(recs[i].orig, recs[i].permFlags);
+		}
 	}
 	__device__ __forceinline__ void Take(Lane& al, uint64_t inc) const
 	{
@@ -241,35 +246,67 @@ struct HalfFinalAct {
 		if (IsFinalState(p, st))
 			Take(al, p.incPerm[st]);
 	}
-	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
-	                                          uint32_t, uint64_t addr) const
+	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t*, const LdsLayout&, Lane& al, uint32_t,
+	                                          uint64_t) const
 	{
 #pragma unroll
 		for (int r = 0; r < 8; ++r)
-			al.c[r] = 0;
-		uint32_t st = p.startPerm;                         // Initialize ends with TakeAction, half_final.h:142
-		Step(p, lds, L, al, st, addr);
-		if (p.flags & PIRE_HIP_RUN_BEGIN) {
-			st = p.nextPerm[size_t(st) * p.letters + p.beginCls];
-			Step(p, lds, L, al, st, addr);
-		}
-		return st;
+			al.c[r] = p.hfStartC[r];                       // Initialize [+ Begin] end with TakeAction: walked by the host
+		return p.hfStart;
 	}
-	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
-	                                       uint32_t s, uint32_t st, uint64_t end) const
+	// End of string: Step(EndMark) if asked -- it ends with TakeAction like every step -- then the outputs.  The end
+	// state of a dense-row state comes from LDS; anything that needs memory sits under a wave-uniform branch of its
+	// own and is waited for in there (a load on the common path would drain the prefetched window, see FinishRagged).
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t*, const LdsLayout&, const uint8_t* area,
+	                                       Lane& al, uint32_t s, uint32_t st, uint64_t) const
 	{
+		const uint64_t* incHot = reinterpret_cast<const uint64_t*>(area);
+		const uint2* endHot = reinterpret_cast<const uint2*>(area + 2048);
+		const bool cold = st >= p.hot;
+		uint32_t orig = 0, pf = 0;
+		if (!cold) {
+			const uint2 r = endHot[st];
+			orig = r.x;
+			pf = r.y;
+		}
+		if (__any(cold)) {
+			if (cold) {
+				const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+				const uint2 r = *reinterpret_cast<const uint2*>(&recs[st]);
+				orig = r.x;
+				pf = r.y;
+				asm volatile("" : "+v"(orig), "+v"(pf));   // the wait belongs in here
+			}
+		}
+		const uint32_t endSt = pf & 0x0FFFFFFFu, fl = pf >> 28;
 		if (p.flags & PIRE_HIP_RUN_END) {
-			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
-			Step(p, lds, L, al, st, end);
+			const bool fin = (fl & kFinal) != 0;
+			if (__any(fin)) {
+				uint32_t lo = 0, hi = 0;
+				if (fin && endSt < p.hot) {
+					const uint64_t inc = incHot[endSt];
+					lo = uint32_t(inc);
+					hi = uint32_t(inc >> 32);
+				}
+				if (__any(fin && endSt >= p.hot)) {
+					if (fin && endSt >= p.hot) {
+						const uint64_t inc = p.incPerm[endSt];
+						lo = uint32_t(inc);
+						hi = uint32_t(inc >> 32);
+						asm volatile("" : "+v"(lo), "+v"(hi));
+					}
+				}
+				Take(al, (uint64_t(hi) << 32) | lo);
+			}
 		}
 #pragma unroll
 		for (int r = 0; r < 8; ++r)      // static indices only: a runtime index would put c[] into scratch
 			if (uint32_t(r) < p.regexps)
 				results[size_t(s) * p.regexps + r] = al.c[r];
 		if (p.outIdx)
-			p.outIdx[s] = p.origOfPerm[st];
+			p.outIdx[s] = orig;
 		if (p.outFinal)
-			p.outFinal[s] = p.flagsPerm[st] & kFinal;
+			p.outFinal[s] = fl & kFinal;
 	}
 };
 
@@ -312,8 +349,8 @@ struct HalfFinalWideAct {
 		}
 		return st;
 	}
-	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
-	                                       uint32_t s, uint32_t st, uint64_t end) const
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
+	                                       Lane& al, uint32_t s, uint32_t st, uint64_t end) const
 	{
 		if (p.flags & PIRE_HIP_RUN_END) {
 			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
@@ -378,8 +415,8 @@ struct PrefixAct {
 		}
 		return st;
 	}
-	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, Lane& al,
-	                                       uint32_t s, uint32_t st, uint64_t end) const
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
+	                                       Lane& al, uint32_t s, uint32_t st, uint64_t end) const
 	{
 		// a search that ended Dead stays not-Final through EndMark; one that was answered before the first byte
 		// does not look at EndMark at all; a shortest prefix already found is kept (run.h:286-290 / 305-309)
@@ -805,7 +842,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	PIRE_RCLK(clk, 3);
 	if constexpr (Act::kActive) {
 		if (ends)
-			act.Finish(p, lds, L, al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
+			act.Finish(p, lds, L, reinterpret_cast<const uint8_t*>(finHot), al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
 		FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
 	}
