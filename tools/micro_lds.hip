@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -124,6 +125,39 @@ __global__ __launch_bounds__(WAVES * 64) void chain16_kernel(const uint16_t* __r
     out[blockIdx.x * blockDim.x + threadIdx.x] = st + st2;
 }
 
+// The same u16 rows with the address built by ONE full-rate VALU in the dependent chain: v_lshl_add_u32(byte, 1, row);
+// the byte is extracted off the chain (v_bfe_u32, one more VALU per byte that depends on the text only).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void chain16s_kernel(const uint16_t* __restrict__ table, uint32_t words, uint32_t* out, int iters, uint32_t seed)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+        reinterpret_cast<uint32_t*>(lds)[i] = reinterpret_cast<const uint32_t*>(table)[i];
+    __syncthreads();
+    uint32_t r[16];
+    uint32_t h = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u + seed;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        uint32_t w = 0;
+        for (int b = 0; b < 4; ++b) { h ^= h << 13; h ^= h >> 17; h ^= h << 5; w |= (0x20u + (((h >> 8) & 0xFF) * 95 >> 8)) << (8 * b); }
+        r[k] = w;
+    }
+    uint32_t st = 0;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            uint32_t x = r[k];
+            asm volatile("" : "+v"(x));   // keep the four extractions inside the loop (the real kernel pays them per byte)
+            const uint32_t b0 = __builtin_amdgcn_ubfe(x, 0, 8), b1 = __builtin_amdgcn_ubfe(x, 8, 8), b2 = __builtin_amdgcn_ubfe(x, 16, 8), b3 = x >> 24;
+            st = rd16((b0 << 1) + st);
+            st = rd16((b1 << 1) + st);
+            st = rd16((b2 << 1) + st);
+            st = rd16((b3 << 1) + st);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = st;
+}
+
 static std::vector<uint16_t> make_table16(const std::vector<uint8_t>& t8, int rows, uint32_t pitch)
 {
     std::vector<uint16_t> t(size_t(rows) * pitch / 2 + 8, 0);
@@ -156,6 +190,26 @@ static void run16(const char* name, const uint16_t* dtab, uint32_t bytes, uint32
     fflush(stdout);
 }
 
+template <int WAVES>
+static void run16s(const char* name, const uint16_t* dtab, uint32_t bytes, uint32_t* out, int cus, int iters)
+{
+    auto k = chain16s_kernel<WAVES>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    k<<<cus, WAVES * 64, bytes>>>(dtab, bytes / 4, out, 4, 1); CK(hipDeviceSynchronize());
+    std::vector<float> ms;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(a)); k<<<cus, WAVES * 64, bytes>>>(dtab, bytes / 4, out, iters, r); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float m; CK(hipEventElapsedTime(&m, a, b)); ms.push_back(m);
+    }
+    CK(hipGetLastError());
+    std::sort(ms.begin(), ms.end());
+    const double steps = (double)cus * WAVES * 64 * iters * 64.0;
+    const double tps = steps / (ms[2] * 1e-3);
+    printf("%-52s %8.3f ms  %7.2f Tsteps/s  %6.2f steps/ns/CU\n", name, ms[2], tps / 1e12, tps / 1e9 / cus);
+    fflush(stdout);
+}
+
 template <int MODE, int WAVES>
 static void run(const char* name, const uint8_t* dtab, uint32_t* out, int cus, int blocksPerCu, int iters)
 {
@@ -178,7 +232,7 @@ static void run(const char* name, const uint8_t* dtab, uint32_t* out, int cus, i
     fflush(stdout);
 }
 
-int main()
+int main(int argc, char** argv)
 {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
@@ -195,6 +249,30 @@ int main()
         {"spread 255 uniform (worst case)", 255, 0.0},
     };
     const int iters = 400;
+    if (argc > 1 && !strcmp(argv[1], "shift")) {
+        // u8 rows + v_perm (the library's step) against u16 rows + v_lshl_add_u32 at several pitches, 256 rows, 16 waves
+        for (auto& tb : tabs) {
+            auto t = make_table(tb.spread, tb.stay0);
+            CK(hipMemcpy(dtab, t.data(), 65536, hipMemcpyHostToDevice));
+            printf("--- table: %s\n", tb.n);
+            run<0, 16>("u8 + v_perm, pitch 256, 16 waves/CU", dtab, out, cus, 1, iters);
+            for (uint32_t pitch : {512u, 516u, 520u, 528u, 544u}) {
+                auto t16 = make_table16(t, 256, pitch);
+                uint16_t* d16;
+                CK(hipMalloc(&d16, t16.size() * 2));
+                CK(hipMemcpy(d16, t16.data(), t16.size() * 2, hipMemcpyHostToDevice));
+                char nm[96];
+                snprintf(nm, sizeof nm, "u16 + v_lshl_add, pitch %u, 16 waves/CU", pitch);
+                run16s<16>(nm, d16, uint32_t(t16.size() * 2 + 15) & ~15u, out, cus, iters);
+                if (pitch == 516u || pitch == 512u) {
+                    snprintf(nm, sizeof nm, "u16 + v_dot4,     pitch %u, 16 waves/CU", pitch);
+                    run16<16, 1>(nm, d16, uint32_t(t16.size() * 2 + 15) & ~15u, out, cus, iters);
+                }
+                CK(hipFree(d16));
+            }
+        }
+        return 0;
+    }
     for (auto& tb : tabs) {
         auto t = make_table(tb.spread, tb.stay0);
         CK(hipMemcpy(dtab, t.data(), 65536, hipMemcpyHostToDevice));
