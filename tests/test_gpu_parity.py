@@ -435,6 +435,51 @@ def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
 
 
 @pytest.mark.gpu
+def test_concurrent_host_pointer_calls_share_the_staging_pool(pa, monkeypatch):
+    """Host-pointer calls from several threads at once, ragged and fixed-length, small and cut into chunks
+    (PIRE_HIP_HOST_CHUNK_BYTES): the pooled staging arenas of api.cpp are taken, grown and returned under contention;
+    every result must equal the oracle's, repeatedly."""
+    import threading
+
+    monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", str(256 * 1024))
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.upload()
+    rng = np.random.RandomState(2)
+    alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet"
+    jobs = []
+    for k in range(6):
+        if k % 2 == 0:
+            strings = H.random_strings(rng, 500 + 1500 * k, 40 + 150 * k, alphabet)
+            text, offs = H.pack(strings)
+            jobs.append(("ragged", np.array(text), offs, o.run(text, offs, threads=2)))
+        else:
+            n, length = 300 * k, 256 * k
+            data = ob.corpus_fill(7 + k, 0, n, length, H.plants_for(big), threads=2)
+            jobs.append(("strided", data, None,
+                         o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=2)))
+    errors = []
+
+    def worker(k):
+        try:
+            kind, data, offs, (oi, of) = jobs[k]
+            for rep in range(6):
+                gi, gf = t.run(data, offs)[:2] if kind == "ragged" else t.run_strided_host(data)[:2]
+                if not ((gi == oi).all() and (gf == of).all()):
+                    errors.append((k, rep, int((gi != oi).sum())))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
 def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch):
     """PIRE_HIP_CHECKED=1 (the analogue of the reference's ValidateSkip, multi.h:925-934): the wave-wide early-out is
     only noted, the text is walked to the end, and lanes whose state still moved are counted.  On a batch in which every
