@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -142,6 +143,49 @@ __global__ __launch_bounds__(WAVES * 64) void strided_kernel(const uint8_t* __re
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
 }
 
+// The tiled kernel's pattern: 8 adjacent lanes cover one whole 128-byte line, instruction j reads, in every group of 8
+// lanes, string (lane & ~7) + (j % 8), line j / 8 of the visit.  LINES = 1: 128 bytes of each of the 64 strings per
+// visit (the kernel as it is); LINES = 2 / 4: 256 / 512 contiguous bytes of each string per visit.  DEPTH = visits in
+// flight per wave (1: issue, wait, consume; 2: the next visit is requested before the current one is consumed).
+template <int LINES, int WAVES, int DEPTH>
+__global__ __launch_bounds__(WAVES * 64) void group_kernel(const uint8_t* __restrict__ text, uint64_t nstr, uint32_t len, uint32_t* out)
+{
+    constexpr int NI = 8 * LINES;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const uint64_t ntasks = nstr / 64;
+    const int nvisits = len / (128 * LINES);
+    u32x4 acc = {0, 0, 0, 0};
+    u32x4 r[DEPTH][NI];
+    for (uint64_t task = (uint64_t)blockIdx.x * WAVES + wave; task < ntasks; task += (uint64_t)gridDim.x * WAVES) {
+        const uint8_t* base = text + (task * 64 + (lane & ~7)) * (uint64_t)len + (lane & 7) * 16;
+        auto issue = [&](int v, int slot) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const uint8_t* g = base + (uint64_t)(j % 8) * len + (uint32_t)v * (128 * LINES) + (j / 8) * 128;
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r[slot][j]) : "v"(g));
+            }
+        };
+        issue(0, 0);
+        for (int v = 0; v < nvisits; ++v) {
+            if (DEPTH == 2) {
+                if (v + 1 < nvisits) { issue(v + 1, (v + 1) & 1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                u32x4 x = r[DEPTH == 2 ? (v & 1) : 0][j];
+                asm volatile("" : "+v"(x));
+                acc ^= x;
+            }
+            if (DEPTH == 1 && v + 1 < nvisits) issue(v + 1, 0);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+}
+
 template <typename F>
 static double time_it(const char* name, size_t bytes, int reps, F&& launch) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -160,6 +204,8 @@ static double time_it(const char* name, size_t bytes, int reps, F&& launch) {
 }
 
 int main(int argc, char** argv) {
+    const bool groupOnly = argc > 1 && !strcmp(argv[1], "group");
+    if (groupOnly) { argc--; argv++; }
     int lg = argc > 1 ? atoi(argv[1]) : 20;
     uint32_t len = argc > 2 ? atoi(argv[2]) : 4096;
     int reps = argc > 3 ? atoi(argv[3]) : 5;
@@ -172,6 +218,14 @@ int main(int argc, char** argv) {
     uint32_t* out; CK(hipMalloc(&out, (size_t)cus * 8 * 1024 * 4));
     fill_kernel<<<cus * 8, 256>>>((uint32_t*)text, bytes / 4); CK(hipDeviceSynchronize());
 
+#define GRP(L, W, D) time_it("group pattern, " #L " line(s) per string and visit, waves=" #W " depth=" #D, bytes, reps, [&] { group_kernel<L, W, D><<<cus, W * 64>>>(text, nstr, len, out); })
+    if (groupOnly) {
+        time_it("stream coalesced nt", bytes, reps, [&] { stream_kernel<<<cus * 8, 256>>>((const u32x4*)text, bytes / 16, out, 1); });
+        for (int rep = 0; rep < 2; ++rep) {
+            GRP(1, 16, 1); GRP(1, 12, 1); GRP(1, 8, 1);   // (more than one line per visit: not debugged, faults)
+        }
+        return 0;
+    }
     time_it("stream coalesced 16B/lane, 256x8 blocks x256", bytes, reps, [&] { stream_kernel<<<cus * 8, 256>>>((const u32x4*)text, bytes / 16, out, 0); });
     time_it("stream coalesced nt", bytes, reps, [&] { stream_kernel<<<cus * 8, 256>>>((const u32x4*)text, bytes / 16, out, 1); });
     time_it("stream coalesced 1024thr x 256", bytes, reps, [&] { stream_kernel<<<cus, 1024>>>((const u32x4*)text, bytes / 16, out, 0); });
