@@ -10,6 +10,8 @@ from tests import helpers as H
 CASES = {  # name: (lo, hi, log2 strings, multiplier)
     "uniform8k": (0, 8192, 17, 1), "uniform8k_al128": (0, 64, 17, 128), "urls": (20, 200, 22, 1),
     "loglines": (64, 1024, 20, 1), "fixed4096": (32, 33, 18, 128), "uniform2k": (0, 2048, 20, 1),
+    # the same shapes at four times the size (3.4 GiB of text): how much of the small batches' time is their tail
+    "urls_x4": (20, 200, 24, 1), "loglines_x4": (64, 1024, 22, 1), "uniform2k_x4": (0, 2048, 22, 1),
 }
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
@@ -19,7 +21,7 @@ big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
 t = pire_amd.Table(H.load_blob(big["blob"]))
 t.upload()
 stream = torch.cuda.current_stream().cuda_stream
-n, L = 1 << 18, 4096
+n, L = (1 << 20, 4096) if case.endswith("_x4") else (1 << 18, 4096)
 buf = torch.empty((n, L), dtype=torch.uint8, device="cuda")
 pire_amd.corpus_fill_device(buf.data_ptr(), 0x5EED5EED, 0, n, L, L, H.plants_for(big), stream)
 m = 1 << lg
