@@ -984,7 +984,14 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 	// strings a block takes from the global counter at a time: ~8 grabs per block keep the tail balanced; batches
 	// that barely fill the lanes are simply split evenly
 	const uint64_t perBlock = (p.n + blocks - 1) / blocks, lanes = wavesPerBlock * 64;
-	uint64_t blockGrab = std::min<uint64_t>(16384, std::max<uint64_t>(perBlock / 8, std::min(perBlock, lanes)));
+	uint64_t grabDiv = 8, grabCap = 16384;
+#ifdef PIRE_HIP_TUNING
+	if (const char* e1 = getenv("PIRE_HIP_RAGGED_GRABDIV"))
+		grabDiv = std::max(1, atoi(e1));
+	if (const char* e2 = getenv("PIRE_HIP_RAGGED_GRABCAP"))
+		grabCap = std::max(64, atoi(e2));
+#endif
+	uint64_t blockGrab = std::min<uint64_t>(grabCap, std::max<uint64_t>(perBlock / grabDiv, std::min(perBlock, lanes)));
 	blockGrab = (blockGrab + 63) / 64 * 64;
 	// a wave takes several windows' worth of strings per visit of the block lock when there is plenty (otherwise the
 	// 16 waves of a block queue up behind the lock every iteration), one lane-fill when a block grab barely feeds
