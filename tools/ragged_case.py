@@ -16,6 +16,7 @@ CASES = {  # name: (lo, hi, log2 strings, multiplier)
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 flags = 3 | (pb.FLAG_GENERIC if len(sys.argv) > 3 and sys.argv[3] == "generic" else 0)
+flags |= getattr(pb, "FLAG_SHORT", 0) if len(sys.argv) > 3 and sys.argv[3] == "short" else 0   # tools/experiments/stream.hip
 lo, hi, lg, mul = CASES[case]
 big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
 t = pire_amd.Table(H.load_blob(big["blob"]))
