@@ -74,6 +74,7 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	const HostTable& h = t->host;
 	memset(p, 0, sizeof(*p));
 	p->workBase = d.workCounter;
+	p->workDevice = d.device >= 0 && d.device < kMaxDevices ? d.device : 0;
 	p->hotRows = d.hotRows;
 	p->hotFlags = d.hotFlags;
 	p->cls = d.cls;
@@ -120,7 +121,7 @@ namespace {
 // One slot of the table's ring of ragged work counters per launch (launches of one table may overlap on streams).
 unsigned long long* NextWorkSlot(pire_hip_table* t, const ScanParams& p)
 {
-	return p.workBase + t->workSlot.fetch_add(1) % kWorkSlots;
+	return WorkSlotOf(p.workBase, t->workSlot[p.workDevice].fetch_add(1));
 }
 
 int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,

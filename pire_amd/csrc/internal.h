@@ -165,7 +165,18 @@ struct DeviceTable {
 
 }  // namespace pirehip
 
-namespace pirehip { constexpr uint32_t kWorkSlots = 1024; }
+namespace pirehip {
+constexpr uint32_t kWorkSlots = 1024;
+// The ragged kernels take ranges of strings from a counter that must be zero when a launch starts.  Launch number k of a
+// table uses counter 2 * (k % kWorkSlots) + phase, phase = (k / kWorkSlots) & 1, and its first thread zeroes the OTHER
+// counter of the pair (address ^ 8) -- the one the launch that comes round to this pair next will use.  So no launch
+// pays a memset dispatch of its own (5 us in front of every ragged kernel), and a counter is dirty only between its use
+// and the next use of its pair, kWorkSlots launches later.  The array is zeroed when the image is uploaded.
+inline unsigned long long* WorkSlotOf(unsigned long long* base, uint32_t k)
+{
+	return base + 2 * (k % kWorkSlots) + ((k / kWorkSlots) & 1u);
+}
+}  // namespace pirehip
 
 namespace pirehip { constexpr int kMaxDevices = 64; }
 
@@ -176,7 +187,7 @@ struct pire_hip_table {
 	// while holding it (UploadTable) and never look at devs[] afterwards.
 	pirehip::DeviceTable devs[pirehip::kMaxDevices];
 	std::mutex uploadMutex;
-	std::atomic<uint32_t> workSlot{0};   // round-robin over dev.workCounter[kWorkSlots]
+	std::atomic<uint32_t> workSlot[pirehip::kMaxDevices] = {};   // per device image: round-robin over its counter pairs
 	std::mutex segMutex;
 	std::vector<uint32_t> segModes;      // segmented.hip: mode representatives (state indices) earlier calls learned
 };
@@ -223,6 +234,7 @@ struct ScanParams {
 	uint8_t* outFinal;       // nullable
 	unsigned long long* outCounts;  // nullable
 	unsigned long long* workBase;   // host side only: the ring of ragged work counters of the image in use
+	int workDevice;                 // host side only: the device of that image (its launch counter, internal.h WorkSlotOf)
 	// HalfFinalScanner on the ragged kernel: the state every string starts its text in (device id) and the counts
 	// Initialize() [+ Step(BeginMark)] have already taken (half_final.h:137-164) -- the same for every string, so the
 	// host walks those two steps once instead of every lane doing them (two dependent loads) for every string

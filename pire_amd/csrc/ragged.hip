@@ -902,6 +902,8 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 			act.LoadLds(p, reinterpret_cast<uint8_t*>(finHot));   // the actions' own LDS data take that place
 		}
 		if (threadIdx.x == 0) {
+			if (blockIdx.x == 0)   // the other counter of this launch's pair, for the launch that uses it next
+				*reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(workCounter) ^ 8u) = 0;
 			work->range = 0;
 			work->lock = 0;
 			work->exhausted = 0;
@@ -965,9 +967,8 @@ namespace {
 template <class Act, bool EXT>
 int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Act& act, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(workCounter, 0, sizeof(unsigned long long), stream);
-	if (e != hipSuccess)
-		return HipFail(e, "hipMemsetAsync(work counter)");
+	// (the counter is zero: the previous launch on its pair saw to it, internal.h WorkSlotOf)
+	hipError_t e;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	const uint32_t ldsBytes = L.total + kRaggedLdsExtra;
 	int cus = 0;

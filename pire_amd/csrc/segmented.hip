@@ -456,7 +456,7 @@ struct StreamScratch {
 int ScanBatch(const ScanParams& q, pire_hip_table* t, hipStream_t stream)
 {
 	if (RaggedEligible(q, ~0ull))
-		return LaunchRagged(q, q.workBase + t->workSlot.fetch_add(1) % kWorkSlots, stream);
+		return LaunchRagged(q, WorkSlotOf(q.workBase, t->workSlot[q.workDevice].fetch_add(1)), stream);
 	return LaunchGeneric(q, stream);
 }
 

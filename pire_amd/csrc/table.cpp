@@ -750,7 +750,7 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 	if (!rc)
 		rc = Put(&d.visitCold, std::vector<uint32_t>(N, 0), &d.bytes);
 	if (!rc)
-		rc = Put(&d.workCounter, std::vector<unsigned long long>(kWorkSlots, 0), &d.bytes);
+		rc = Put(&d.workCounter, std::vector<unsigned long long>(2 * kWorkSlots, 0), &d.bytes);   // pairs: internal.h
 	if (rc) {
 		d.device = dev;
 		FreeDeviceTable(&d);

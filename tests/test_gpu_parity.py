@@ -435,6 +435,45 @@ def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
 
 
 @pytest.mark.gpu
+def test_ragged_work_counters_survive_thousands_of_launches(pa, torch_cuda):
+    """The ragged kernels take string ranges from a counter that has to be zero at launch; no launch zeroes its own:
+    launch k uses counter 2 * (k % 1024) + phase and clears the other one of the pair for the launch that comes round
+    next (internal.h WorkSlotOf).  More than two full rounds of launches on one table, two batches of different sizes
+    alternating, two streams: every launch must hand out every string exactly once."""
+    torch = torch_cuda
+    from pire_amd import binding as pb
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.upload()
+    rng = np.random.RandomState(77)
+    alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet"
+    batches = []
+    for n in (300, 1500):
+        strings = H.random_strings(rng, n, 150, alphabet)
+        text, offs = H.pack(strings)
+        d = torch.as_tensor(np.array(text), device="cuda")
+        do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+        want = torch.as_tensor(o.run(text, offs)[0].astype(np.int64), device="cuda").to(torch.int32)
+        batches.append((n, d, do, want, torch.empty(n, dtype=torch.int32, device="cuda")))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    mismatches = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for k in range(2300):
+        n, d, do, want, idx = batches[k & 1]
+        st = streams[(k >> 1) & 1]
+        with torch.cuda.stream(st):
+            idx.fill_(-1)
+            t.run_device(d.data_ptr(), do.data_ptr(), n, 3, idx.data_ptr(), 0, 0, 0, st.cuda_stream)
+            mismatches += (idx != want).sum()
+        if k % 100 == 99:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert pb.last_kernel() == "ragged"
+    assert int(mismatches.item()) == 0
+
+
+@pytest.mark.gpu
 def test_concurrent_host_pointer_calls_share_the_staging_pool(pa, monkeypatch):
     """Host-pointer calls from several threads at once, ragged and fixed-length, small and cut into chunks
     (PIRE_HIP_HOST_CHUNK_BYTES): the pooled staging arenas of api.cpp are taken, grown and returned under contention;
