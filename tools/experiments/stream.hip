@@ -11,7 +11,7 @@
 // subset on every run.  Slower than what it was meant to replace, so it stops here.
 
 // The stream kernel: offset batches of SHORT strings (URLs, queries, log lines) walked as what they are in memory --
-// one contiguous text.  DESIGN.md section 4.4c.
+// one contiguous text.  DESIGN.md section 7 (ragged kernel).
 //
 // The ragged kernel gives every lane a string and a 128-byte window per iteration; on strings of ~100 bytes a window is
 // 58 % full and the cost of an iteration is per iteration, whatever is in it (profiles/r02_ragged_clocks.log).  Here the
