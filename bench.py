@@ -17,14 +17,13 @@ by string index (rank r owns global strings [r*n, (r+1)*n)), no data-path collec
 all-reduce (RCCL) of the uint64[regexps+2] match counters per step.  Weak scaling.
 
 Other workloads (informational lines of the same shape): `--set c2_single|set_b|set_d` (BASELINE configs 2 / 5a),
-`--set slow_x40_utf8` (config 5b, SlowScanner), `--corpus cxx` (C++ source text instead of the synthetic corpus,
-the kind of file the reference's tools/bench/run-bench scans; `--one-string` scans it as ONE string as the
-reference's bench does, through the segmented scan).
+`--set slow_x40_utf8` (config 5b, SlowScanner), `--corpus cxx` (the reference's own benchmark corpus,
+tools/bench/test_file, repeated as tools/bench/run-bench does, instead of the synthetic corpus; `--one-string` scans it
+as ONE string as the reference's bench does, through the segmented scan).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import glob
 import json
 import os
 import socket
@@ -40,6 +39,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 SEED = 0x5EED5EED
+SEED_HELDOUT = 0x0DDBA11   # the corpus the dense-row ranking is learned on (never the timed one)
 WORKLOADS = {"set_a": "C3: 8 regexps glued via Scanner::Glue, LDS-resident dense rows",
              "c2_single": "C2: single Scanner hello\\s+w.+d$",
              "set_b": "C5a: 8 glued regexps, 8952-state table with HBM-resident transitions",
@@ -57,12 +57,15 @@ def parse():
     ap.add_argument("--stride", type=int, default=0, help="bytes between strings in memory (default: --len, contiguous)")
     ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")
     ap.add_argument("--corpus", default="synthetic", choices=["synthetic", "cxx"],
-                    help="cxx: this repository's C++/HIP sources repeated to the batch size (the reference's "
-                         "run-bench repeats its own C++ file) instead of the synthetic corpus")
+                    help="cxx: the reference's own benchmark corpus (tools/bench/test_file, C++ text) repeated to the "
+                         "batch size as run-bench:126-138 does, instead of the synthetic corpus")
     ap.add_argument("--one-string", action="store_true", help="with --corpus cxx: the whole text as ONE string")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-adapt", action="store_true", help="do not call pire_hip_table_adapt() after the warm-up")
+    ap.add_argument("--no-adapt", action="store_true", help="do not learn the dense-row ranking on the held-out corpus")
+    ap.add_argument("--settle", type=int, default=60,
+                    help="untimed passes in front of the warm-up passes of every timed leg, so that the GPU's clocks "
+                         "have settled (an idle MI355X needs 20-30 launches, profiles/r03_warmup_curve.log); 0 = none")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -83,14 +86,12 @@ def spawn_ranks(args) -> int:
 
 
 def cxx_corpus_bytes() -> np.ndarray:
-    """The C++ text the `--corpus cxx` workload repeats: every C++/HIP source of this repository, in a fixed order."""
-    files = sorted(glob.glob(os.path.join(ROOT, "pire_amd", "csrc", "*")) +
-                   glob.glob(os.path.join(ROOT, "include", "*.h")) +
-                   glob.glob(os.path.join(ROOT, "include", "pire_hip", "*")) +
-                   glob.glob(os.path.join(ROOT, "oracle", "*.c")) + glob.glob(os.path.join(ROOT, "tests", "cpp", "*.cpp")))
-    data = b"".join(open(f, "rb").read() for f in files if os.path.isfile(f))
-    assert len(data) > 100000, "source corpus not found"
-    return np.frombuffer(data, dtype=np.uint8)
+    """The C++ text of the `--corpus cxx` workload: the reference's own benchmark corpus, tools/bench/test_file
+    (20 485 bytes; data fixture tests/golden/ref_bench_test_file.gz).  run-bench:126-138 doubles it until the big file
+    is large enough; doubling a file is repeating it, so the batch is this text repeated."""
+    from pire_amd import workloads as W
+
+    return np.frombuffer(W.ref_bench_file(), dtype=np.uint8)
 
 
 def cpu_baseline(blob, host_strings, length, gpu_idx, gpu_fin):
@@ -272,7 +273,7 @@ def main():
     assert last - first == n
     base_text = None
     if args.corpus == "cxx":
-        # C++ source text: the sources tiled over the whole (global) batch; this rank's shard starts at byte first*length
+        # the reference's benchmark text repeated over the whole (global) batch; this rank's shard starts at byte first*length
         base_text = cxx_corpus_bytes()
         f = len(base_text)
         total = n * length
@@ -288,66 +289,93 @@ def main():
     run_stride = run_len if args.one_string else stride
     out_idx = torch.empty(run_n, dtype=torch.int32, device=dev)
     out_fin = torch.empty(run_n, dtype=torch.uint8, device=dev)
-    # two counter buffers, used alternately: the all-reduce of step k (RCCL runs it on its own stream) then overlaps
-    # the scan of step k+1 instead of sitting between two kernels
-    count_bufs = [torch.zeros(table.RegexpsCount + 2, dtype=torch.int64, device=dev) for _ in range(2)]
     flags = pb.FLAG_BEGIN | pb.FLAG_END
+    # One row of match counters per step, zeroed once up front: out_counts accumulates, and a fill dispatch in front of
+    # every scan (3.6 us + its gap in round 2) is not part of the path.  The all-reduce of step k (RCCL runs it on its
+    # own stream) overlaps the scan of step k+1.
+    settle = max(0, args.settle)
+    total_steps = 2 * settle + args.warmup + args.steps + 40
+    counts_all = torch.zeros((total_steps, table.RegexpsCount + 2), dtype=torch.int64, device=dev)
     step_no = [0]
-    pending = [None, None]   # the outstanding all-reduce of each buffer
+    pending = []   # outstanding all-reduces, oldest first
 
-    def step(ev=None):
-        slot = step_no[0] & 1
-        counts = count_bufs[slot]
+    def step(tbl, ev=None):
+        counts = counts_all[step_no[0]]
         step_no[0] += 1
-        if pending[slot] is not None:
-            pending[slot].wait()   # stream-level wait for the reduction issued two steps ago: long finished
-            pending[slot] = None
-        counts.zero_()
+        while len(pending) > 1:
+            pending.pop(0).wait()   # stream-level wait for the reduction issued two steps ago: long finished
         if ev:
             ev[0].record()
-        table.run_strided_device(text.data_ptr(), run_n, run_len, run_stride, flags, out_idx.data_ptr(),
-                                 out_fin.data_ptr(), counts.data_ptr(), 0, stream)
+        tbl.run_strided_device(text.data_ptr(), run_n, run_len, run_stride, flags, out_idx.data_ptr(),
+                               out_fin.data_ptr(), counts.data_ptr(), 0, stream)
         if ev:
             ev[1].record()
-        pending[slot] = pd.allreduce_counts(counts, async_op=True)   # the path's only exchange: 80 B of counters
+        h = pd.allreduce_counts(counts, async_op=True)   # the path's only exchange: 80 B of counters
+        if h is not None:
+            pending.append(h)
 
     def fence():
-        for k in (0, 1):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        while pending:
+            pending.pop(0).wait()
         pd.barrier()
         torch.cuda.synchronize()
 
-    def timed(steps):
+    def timed(tbl, steps, warm):
+        """`warm` untimed passes, then exactly `steps` timed ones between two fences.  The events are made before the
+        first fence: nothing but the fence itself (microseconds) separates the untimed passes from the timed ones, so
+        the GPU does not fall idle in between (see `settle` below)."""
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for _ in range(warm):
+            step(tbl)
         fence()
         t0 = time.perf_counter()
         for k in range(steps):
-            step(events[k])
+            step(tbl, events[k])
         fence()
         elapsed = pd.max_over_ranks(time.perf_counter() - t0, dev)
         return elapsed, [a.elapsed_time(b) for a, b in events]
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    # The table as it comes out of pire_hip_table_create (dense rows ranked by the a-priori byte model): a short timed
-    # leg, reported as value_before_adapt.
-    cold_steps = max(1, min(args.steps, 10))
-    cold_elapsed, cold_ms = timed(cold_steps)
-    # One-time table optimisation, outside the timed region (like table creation): re-rank the LDS-resident rows
-    # from the visit counters the passes so far left on the device, then one more untimed pass.
+    # --- 1. the dense-row ranking is learned on a HELD-OUT corpus: same generator, another seed, a quarter of the size.
+    # pire_hip_table_adapt() (shim: Table<Scanner>::Adapt()) re-ranks the LDS-resident rows from the visit counters the
+    # scans left on the device; results never depend on the ranking.  The timed corpus is never seen by adapt().
     adapted_rows = 0
+    heldout = None
     if not args.no_adapt:
+        n2 = max(64, min(n, 1 << 18))
+        if args.corpus == "cxx":
+            # another cut of the same kind of text: the file reversed line by line would be another language; use the
+            # text shifted by half a file and scanned as records of the same length
+            f = len(base_text)
+            t2 = torch.as_tensor(np.roll(base_text, f // 2 + 977), device=dev).repeat(n2 * length // f + 2)
+            text2 = t2[:n2 * length].clone().view(n2, length)
+            heldout = f"the same text shifted by {f // 2 + 977} bytes, {n2} records"
+        else:
+            text2 = torch.empty((n2, stride), dtype=torch.uint8, device=dev)
+            pire_amd.corpus_fill_device(text2.data_ptr(), SEED_HELDOUT, 0, n2, length, stride, plants, stream)
+            heldout = f"synthetic corpus, seed {SEED_HELDOUT:#x}, {n2} strings"
+        n2r, l2r, s2r = (1, n2 * length, n2 * length) if args.one_string else (n2, length, stride)
+        for _ in range(3):
+            table.run_strided_device(text2.data_ptr(), n2r, l2r, s2r, flags, out_idx.data_ptr(), out_fin.data_ptr(), 0, 0,
+                                     stream)
+        torch.cuda.synchronize()
         adapted_rows = table.adapt()
-        # unconditionally, not "if adapted_rows": the step contains a collective, and ranks whose shard needed no
-        # re-ranking must not skip it
-        step()
-    elapsed, kernel_ms = timed(args.steps)
+        del text2
+    # --- 2. the table as pire_hip_table_create ranks it (a-priori byte model, never adapted): a second handle, a short
+    # timed leg on the timed corpus, reported as value_before_adapt.
+    # `settle`: an MI355X that has been idle for more than ~1 ms restarts its power management transient -- two or three
+    # launches at boost clocks, a dip to 0.8-0.9 ms per launch, recovery after 20-30 launches (~25 ms); profiles/
+    # r03_warmup_curve.log.  Every timed leg is therefore preceded by `settle` untimed passes (default 60, 40 ms of
+    # scanning) issued back to back with the W warm-up passes: the metric is the throughput of sustained scanning.
+    cold_table = pire_amd.Table(blob)
+    cold_table.upload()
+    cold_steps = max(1, min(args.steps, 10))
+    cold_elapsed, cold_ms = timed(cold_table, cold_steps, settle + args.warmup)
+    del cold_table
+    # --- 3. the timed region: settle + W warm-up passes, fence, exactly K passes, fence
+    elapsed, kernel_ms = timed(table, args.steps, settle + args.warmup)
     kernel_name = pb.last_kernel_symbol()   # the instantiation the library actually launched
 
-    total_counts = count_bufs[(step_no[0] - 1) & 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
+    total_counts = counts_all[step_no[0] - 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
     gpu_idx = out_idx.cpu().numpy().astype(np.uint32)
     gpu_fin = out_fin.cpu().numpy()
 
@@ -378,8 +406,8 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
         if args.corpus == "cxx":
-            data = (f"C++ source text: this repository's {len(base_text)} bytes of C++/HIP sources repeated (the reference's "
-                    "tools/bench/run-bench repeats its own C++ file)")
+            data = (f"C++ source text: the reference's tools/bench/test_file ({len(base_text)} bytes) repeated to the batch size, "
+                    "as tools/bench/run-bench:126-138 builds its big file")
             shape = f"ONE string of {n * length} B" if args.one_string else f"{n} x {length} B records"
         else:
             data = "synthetic"
@@ -392,6 +420,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle": settle,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -405,7 +434,8 @@ def main():
                 "patterns": big["patterns"],
                 "table": {"states": info.states, "letters": info.letters, "regexps": info.regexps,
                           "ref_buf_bytes": int(info.ref_buf_size), "lds_dense_rows": info.hot_states,
-                          "lds_table_bytes": info.lds_table_bytes, "rows_promoted_by_adapt": adapted_rows},
+                          "lds_table_bytes": info.lds_table_bytes, "rows_promoted_by_adapt": adapted_rows,
+                          "ranking_learned_on": heldout},
                 "strings_per_gpu": run_n, "string_bytes": run_len, "string_stride": run_stride, "corpus_seed": SEED,
                 "parallelism": f"shard-by-string x{world}",
             },

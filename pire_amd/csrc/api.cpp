@@ -319,9 +319,10 @@ int RunHostPipelined(pire_hip_table* t, const ScanParams& base, const uint8_t* t
 	} else {
 		if (stride > chunkBytes / 64)
 			return PIRE_HIP_OK;
-		uint64_t per = std::min<uint64_t>(chunkBytes / stride, kHostChunkStrings) & ~uint64_t(1023);
+		// stride 0 = n empty records (len == 0, pire_ut.cpp:832-837 semantics per record): chunk by string count alone
+		uint64_t per = std::min<uint64_t>(stride ? chunkBytes / stride : kHostChunkStrings, kHostChunkStrings) & ~uint64_t(1023);
 		if (per == 0)
-			per = chunkBytes / stride;
+			per = stride ? chunkBytes / stride : kHostChunkStrings;
 		for (uint64_t f = per; f < n; f += per)
 			first.push_back(f);
 		first.push_back(n);

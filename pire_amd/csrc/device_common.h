@@ -311,6 +311,30 @@ __device__ __forceinline__ uint32_t SlowChunk(const ScanParams& p, const uint8_t
 	return st;
 }
 
+// A lane left the dense rows somewhere in the chunk `v` (hs == p.hot after it): exact re-walk from the chunk's start
+// state, through the compact rows in LDS when the state has one, through the full table in HBM when that escapes too.
+__device__ __forceinline__ void TrapChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
+                                          uint32_t hs0, uint32_t& hs, uint32_t& cold, uint32_t sampleLane)
+{
+	const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
+	uint32_t f = p.compact;
+	if (st0 < p.compact)
+		f = CompactChunk(p, L, v, st0);
+	if (f == p.compact)
+		f = SlowChunk(p, lds, L, v, st0);
+	if (f < p.hot) {
+		hs = f;
+	} else {
+		hs = p.hot;
+		cold = f;
+		// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
+		// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
+		// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
+		if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
+			atomicAdd(&p.visitCold[f], 1u);
+	}
+}
+
 // 16 bytes (one dwordx4) through the hot table; lanes that leave the hot set are re-walked exactly.
 template <int ROT>
 __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* lds, const LdsLayout& L,
@@ -336,27 +360,8 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 			hs = HotLookup(__builtin_amdgcn_perm(hs, x, 0x0c0c0403u));
 		}
 	}
-	if (hs == p.hot && !(p.flags & kDebugNoTrap)) {
-		// left the dense rows somewhere in this chunk: exact re-walk from the chunk's start state, through the
-		// compact rows in LDS when the state has one, through the full table in HBM when that escapes too
-		const uint32_t st0 = hs0 != p.hot ? hs0 : cold;
-		uint32_t f = p.compact;
-		if (st0 < p.compact)
-			f = CompactChunk(p, L, v, st0);
-		if (f == p.compact)
-			f = SlowChunk(p, lds, L, v, st0);
-		if (f < p.hot) {
-			hs = f;
-		} else {
-			hs = p.hot;
-			cold = f;
-			// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
-			// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
-			// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
-			if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
-				atomicAdd(&p.visitCold[f], 1u);
-		}
-	}
+	if (hs == p.hot && !(p.flags & kDebugNoTrap))
+		TrapChunk(p, lds, L, v, hs0, hs, cold, sampleLane);
 }
 
 
@@ -440,6 +445,115 @@ __device__ __forceinline__ void TransposeTile(u32x4 (&r)[8], uint32_t lane)
 			r[k][w] = d[k];
 		__builtin_amdgcn_sched_barrier(0);   // one column at a time: keeps the transpose's temporaries to ~10 VGPRs
 	}
+}
+
+// ---- the same transpose cut into 24 SLOTS of four instructions (round 3) ---------------------------------------------
+// A wave spends 6-9 % of its time transposing (112 VALU + waits per tile during which its lookup chain stands still:
+// walk alone 0.527 ms, walk + transposes 0.586 ms).  The lookup chain leaves the wave idle for the ~64+
+// cycles of every ds_read_u8, so the transpose of the NEXT tile is issued in those shadows: one slot after each of the
+// last 24 lookups of the tile being walked (StepChunkShadow).  A slot is one half of one butterfly stage of one dword
+// column: four independent v_cndmask_b32_dpp under one mask.  Slot S: column S / 6, stage (S % 6) / 2 (lane bit 0, 1,
+// 2), half S & 1 (0: the x' = lo ? x : perm(y) outputs, kept in tmp[] because the other half still reads the old x;
+// 1: the y' outputs, after which x', y' replace x, y).  Stage 2 (lane bit 2) is the same fused select with
+// row_shr:4 / row_shl:4 and bound_ctrl:0 (lanes without a source read 0 and are the ones that select the other operand).
+#define PIRE_SLOT_ASM(PERM)                                                                                              \
+	asm volatile("s_nop 1\n\t"                                                                                       \
+	             "s_mov_b64 vcc, %12\n\t"                                                                              \
+	             "v_cndmask_b32_dpp %0, %4, %5, vcc " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+	             "v_cndmask_b32_dpp %1, %6, %7, vcc " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+	             "v_cndmask_b32_dpp %2, %8, %9, vcc " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"                \
+	             "v_cndmask_b32_dpp %3, %10, %11, vcc " PERM " row_mask:0xf bank_mask:0xf bound_ctrl:0"                   \
+	             : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                           \
+	             : "v"(m0), "v"(k0), "v"(m1), "v"(k1), "v"(m2), "v"(k2), "v"(m3), "v"(k3), "s"(mask)                      \
+	             : "vcc")
+
+// o = mask ? k : PERM(m)   for four (m, k) pairs
+template <int STAGE, bool UP>
+__device__ __forceinline__ void SlotSelect(uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3, uint32_t m0, uint32_t k0,
+                                           uint32_t m1, uint32_t k1, uint32_t m2, uint32_t k2, uint32_t m3, uint32_t k3,
+                                           uint64_t mask)
+{
+	if (STAGE == 0)
+		PIRE_SLOT_ASM("quad_perm:[1,0,3,2]");
+	else if (STAGE == 1)
+		PIRE_SLOT_ASM("quad_perm:[2,3,0,1]");
+	else if (!UP)
+		PIRE_SLOT_ASM("row_shr:4");   // lane l reads lane l - 4
+	else
+		PIRE_SLOT_ASM("row_shl:4");   // lane l reads lane l + 4
+}
+
+constexpr int kTransposeSlots = 24;
+
+template <int S>
+__device__ __forceinline__ void TransposeSlot(u32x4 (&r)[8], uint32_t (&tmp)[4])
+{
+	static_assert(S >= 0 && S < kTransposeSlots, "slot");
+	constexpr int w = S / 6, stage = (S % 6) / 2, half = S & 1;
+	constexpr int D = 1 << stage;
+	// the four pairs (x = register k, y = register k | D) of this stage, k with bit D clear, in increasing k
+	constexpr int x0 = (D == 1) ? 0 : (D == 2) ? 0 : 0, x1 = (D == 1) ? 2 : (D == 2) ? 1 : 1,
+	              x2 = (D == 1) ? 4 : (D == 2) ? 4 : 2, x3 = (D == 1) ? 6 : (D == 2) ? 5 : 3;
+	constexpr uint64_t lo = (D == 1) ? 0x5555555555555555ull : (D == 2) ? 0x3333333333333333ull : 0x0F0F0F0F0F0F0F0Full;
+	if (half == 0) {
+		// x' = (lane bit D clear) ? x : y[lane ^ D]      (the lanes with the bit set read the lane D below)
+		SlotSelect<stage, false>(tmp[0], tmp[1], tmp[2], tmp[3], r[x0 | D][w], r[x0][w], r[x1 | D][w], r[x1][w], r[x2 | D][w],
+		                         r[x2][w], r[x3 | D][w], r[x3][w], lo);
+	} else {
+		// y' = (lane bit D set) ? y : x[lane ^ D]        (the lanes with the bit clear read the lane D above)
+		uint32_t n0, n1, n2, n3;
+		SlotSelect<stage, true>(n0, n1, n2, n3, r[x0][w], r[x0 | D][w], r[x1][w], r[x1 | D][w], r[x2][w], r[x2 | D][w],
+		                        r[x3][w], r[x3 | D][w], ~lo);
+		r[x0][w] = tmp[0]; r[x1][w] = tmp[1]; r[x2][w] = tmp[2]; r[x3][w] = tmp[3];
+		r[x0 | D][w] = n0; r[x1 | D][w] = n1; r[x2 | D][w] = n2; r[x3 | D][w] = n3;
+	}
+}
+
+// The whole transpose through the slots, back to back (the prologue of a wave's ring, and the reference the tests of
+// the shadowed form are checked against: it must equal TransposeTile).
+template <int S = 0>
+__device__ __forceinline__ void TransposeBySlots(u32x4 (&r)[8], uint32_t (&tmp)[4])
+{
+	if constexpr (S < kTransposeSlots) {
+		TransposeSlot<S>(r, tmp);
+		TransposeBySlots<S + 1>(r, tmp);
+	}
+}
+
+// StepChunk with transpose slots FIRST, FIRST + 1, ... of `next` issued in the shadows of lookups SKIP .. 15 of this
+// chunk: lookup, then -- while the LDS round trip is under way -- four independent VALU instructions on registers the
+// walk does not touch.  WAIT: before the first slot the wave waits for `next` to have landed (requested most of a
+// tile-time earlier).  The sched_barriers pin the order "ds_read, slot, s_waitcnt": nothing may drift between a
+// lookup and its wait except the slot.
+template <int I, int FIRST, int SKIP, bool WAIT>
+__device__ __forceinline__ void ShadowLookups(const u32x4 v, uint32_t& hs, u32x4 (&next)[8], uint32_t (&tmp)[4])
+{
+	if constexpr (I < 16) {
+		constexpr uint32_t sel = 0x0c0c0400u + (I & 3);
+		hs = HotLookup(__builtin_amdgcn_perm(hs, v[I >> 2], sel));
+		constexpr int slot = FIRST + I - SKIP;
+		if constexpr (I >= SKIP && slot < kTransposeSlots) {
+			__builtin_amdgcn_sched_barrier(0);
+			if constexpr (WAIT && I == SKIP)
+				asm volatile("s_waitcnt vmcnt(0)"
+				             : "+v"(next[0]), "+v"(next[1]), "+v"(next[2]), "+v"(next[3]), "+v"(next[4]), "+v"(next[5]),
+				               "+v"(next[6]), "+v"(next[7]));
+			TransposeSlot<slot>(next, tmp);
+			__builtin_amdgcn_sched_barrier(0);
+		}
+		ShadowLookups<I + 1, FIRST, SKIP, WAIT>(v, hs, next, tmp);
+	}
+}
+
+template <int FIRST, int SKIP, bool WAIT>
+__device__ __forceinline__ void StepChunkShadow(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const u32x4 v,
+                                                uint32_t& hs, uint32_t& cold, uint32_t sampleLane, u32x4 (&next)[8],
+                                                uint32_t (&tmp)[4])
+{
+	const uint32_t hs0 = hs;
+	ShadowLookups<0, FIRST, SKIP, WAIT>(v, hs, next, tmp);
+	if (hs == p.hot)
+		TrapChunk(p, lds, L, v, hs0, hs, cold, sampleLane);
 }
 
 // One pipeline phase of the register ring: refill the slot that was freed one phase ago with the tile NBUF-1

@@ -168,13 +168,15 @@ struct DeviceTable {
 namespace pirehip {
 constexpr uint32_t kWorkSlots = 1024;
 // The ragged kernels take ranges of strings from a counter that must be zero when a launch starts.  Launch number k of a
-// table uses counter 2 * (k % kWorkSlots) + phase, phase = (k / kWorkSlots) & 1, and its first thread zeroes the OTHER
-// counter of the pair (address ^ 8) -- the one the launch that comes round to this pair next will use.  So no launch
-// pays a memset dispatch of its own (5 us in front of every ragged kernel), and a counter is dirty only between its use
-// and the next use of its pair, kWorkSlots launches later.  The array is zeroed when the image is uploaded.
+// table on a device uses slot k % kWorkSlots = two words {next string, blocks done}: every block adds 1 to `done` when
+// it leaves, and the block that finds itself last puts BOTH words back to zero -- so a slot is clean whenever no launch
+// is using it, whatever kinds of launches (tiled, generic, failed, n == 0) took slot numbers in between, and no launch
+// pays a memset dispatch of its own (5 us in front of every ragged kernel).  Round 2 had launch k clear the slot of
+// launch k + kWorkSlots instead, which left a slot dirty when that later launch number went to a kernel that does not
+// clear.  The array is zeroed when the image is uploaded.
 inline unsigned long long* WorkSlotOf(unsigned long long* base, uint32_t k)
 {
-	return base + 2 * (k % kWorkSlots) + ((k / kWorkSlots) & 1u);
+	return base + 2 * (k % kWorkSlots);
 }
 }  // namespace pirehip
 

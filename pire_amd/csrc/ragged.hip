@@ -902,8 +902,6 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 			act.LoadLds(p, reinterpret_cast<uint8_t*>(finHot));   // the actions' own LDS data take that place
 		}
 		if (threadIdx.x == 0) {
-			if (blockIdx.x == 0)   // the other counter of this launch's pair, for the launch that uses it next
-				*reinterpret_cast<unsigned long long*>(reinterpret_cast<uintptr_t>(workCounter) ^ 8u) = 0;
 			work->range = 0;
 			work->lock = 0;
 			work->exhausted = 0;
@@ -951,6 +949,15 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	}
 #endif
 	FlushCounts(p, lds, L);
+	// the last block out leaves the launch's slot {next string, blocks done} zeroed for whoever uses it next
+	// (internal.h WorkSlotOf): every block is past its last grab when it counts itself done
+	if (threadIdx.x == 0) {
+		__threadfence();
+		if (atomicAdd(workCounter + 1, 1ull) == gridDim.x - 1) {
+			workCounter[0] = 0;
+			workCounter[1] = 0;
+		}
+	}
 }
 
 
@@ -967,7 +974,7 @@ namespace {
 template <class Act, bool EXT>
 int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Act& act, hipStream_t stream)
 {
-	// (the counter is zero: the previous launch on its pair saw to it, internal.h WorkSlotOf)
+	// (the counter is zero: the last block of the launch that used the slot before put it back, internal.h WorkSlotOf)
 	hipError_t e;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	const uint32_t ldsBytes = L.total + kRaggedLdsExtra;

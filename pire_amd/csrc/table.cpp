@@ -171,6 +171,12 @@ std::vector<double> VisitMassOf(const HostTable& t, uint32_t start, const ByteMo
 // classes printable text has: the first state met for every distinct AcceptedRegexps set is a MODE (shortest
 // witnesses first: single matches, then texts that match two patterns, ...; the first kMaxModes of them); each gets the
 // text chain continued from it, and its witness path one visit per string.
+// Round 3: a `$`-anchored pattern only becomes Final on EndMark, which is not a text class, so the search above never
+// met its matches and the states ALONG its witness ("...ABCDEFGHIJKLMNOPQRSTUVWXYZ" at the end of a line) had no
+// mass at all: the benchmark corpus plants such tails, 40 of the 85 states it visits on set_a had no dense row and not
+// even a compact one, and the two trapped chunks per string cost 15 % of the kernel before adapt()
+// (profiles/r02_cold_ranking.txt, BENCH_r02.json value_before_adapt).  So a state whose End() is accepting is a
+// mode as well (keyed by that set, tagged): its witness path gets the same one visit per string.
 constexpr uint32_t kMaxModes = 24;
 void AddMatchModes(const HostTable& t, uint32_t hub, const ByteModel& text, double weight, std::vector<double>& mass)
 {
@@ -178,32 +184,42 @@ void AddMatchModes(const HostTable& t, uint32_t hub, const ByteModel& text, doub
 	std::vector<uint8_t> textClass(C, 0);
 	for (uint32_t b = 0x20; b <= 0x7E; ++b)
 		textClass[t.cls[b]] = 1;
-	std::vector<uint32_t> parent(N, UINT32_MAX), queue, modes;
+	const uint32_t endCls = t.cls[kEndMark];
+	std::vector<uint32_t> parent(N, UINT32_MAX), queue, modes, endModes;
 	queue.reserve(N);
 	queue.push_back(hub);
 	parent[hub] = hub;
-	std::map<std::vector<uint64_t>, uint32_t> seen;
-	for (size_t head = 0; head < queue.size() && modes.size() < kMaxModes; ++head) {
+	std::map<std::vector<uint64_t>, uint32_t> seen, seenAtEnd;
+	auto keyOf = [&](uint32_t s) {
+		return std::vector<uint64_t>(t.acceptIds.begin() + t.acceptOff[s], t.acceptIds.begin() + t.acceptOff[s + 1]);
+	};
+	for (size_t head = 0; head < queue.size() && (modes.size() < kMaxModes || endModes.size() < kMaxModes); ++head) {
 		const uint32_t s = queue[head];
-		if (t.acceptOff[s + 1] > t.acceptOff[s]) {
-			std::vector<uint64_t> key(t.acceptIds.begin() + t.acceptOff[s], t.acceptIds.begin() + t.acceptOff[s + 1]);
-			if (seen.emplace(std::move(key), s).second)
-				modes.push_back(s);
-		}
+		if (modes.size() < kMaxModes && t.acceptOff[s + 1] > t.acceptOff[s] && seen.emplace(keyOf(s), s).second)
+			modes.push_back(s);
 		const uint32_t* row = &t.next[size_t(s) * C];
+		const uint32_t e = row[endCls];
+		if (endModes.size() < kMaxModes && t.acceptOff[s + 1] == t.acceptOff[s] && t.acceptOff[e + 1] > t.acceptOff[e] &&
+		    seenAtEnd.emplace(keyOf(e), s).second)
+			endModes.push_back(s);
 		for (uint32_t c = 0; c < C; ++c)
 			if (textClass[c] && parent[row[c]] == UINT32_MAX) {
 				parent[row[c]] = s;
 				queue.push_back(row[c]);
 			}
 	}
+	const double w = weight / double(std::max<size_t>(1, modes.size() + endModes.size()));
 	for (uint32_t f : modes) {
-		const double w = weight / double(modes.size());
 		const std::vector<double> after = VisitMassOf(t, f, text, 1024);
 		for (uint32_t s = 0; s < N; ++s)
 			mass[s] += w * after[s];
 		for (uint32_t s = f; s != hub; s = parent[s])
 			mass[s] += w / 1024.0;   // the witness itself: once per string
+	}
+	for (uint32_t f : endModes) {
+		for (uint32_t s = f; s != hub; s = parent[s])
+			mass[s] += w / 1024.0;   // a match at the end of the string: its witness once per string, nothing after it
+		mass[t.next[size_t(f) * C + endCls]] += w / 1024.0;
 	}
 }
 

@@ -138,12 +138,50 @@ __device__ __forceinline__ void Phase(const ScanParams& p, const uint8_t* lds, c
 	StepTile<ROT>(p, lds, L, cur, hs, cold, t);
 }
 
+// The same phase with the transpose of the NEXT tile hidden in the walk of this one (round 3, SHADOW).  Invariant: `cur`
+// holds tile t already transposed.  The refill slot `next` (walked one phase ago) is requested first; the walk of
+// chunks 0..5 and half of chunk 6 gives it 6.5 / 8 of a tile-time to land; then one transpose slot (four independent
+// v_cndmask_b32_dpp, device_common.h TransposeSlot) follows each of the last 24 lookups, in the shadow of the LDS round
+// trip the wave would sit out anyway.  At the end `next` is transposed and the roles swap.
+template <bool NT, bool EQ>
+__device__ __forceinline__ void PhaseShadow(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
+                                            uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
+                                            uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&next)[8], uint32_t& hs, uint32_t& cold,
+                                            uint32_t* prog, uint32_t* myTiles)
+{
+	if (EQ) {
+		uint32_t sum = 0;
+		if (lane == 0)
+			sum = atomicAdd(prog, 1u) + 1;
+		sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+		const uint32_t mine = ++*myTiles;
+		constexpr uint32_t margin = 4;   // in sixteenths of a tile
+		if (mine * (blockDim.x >> 6) > sum + margin)
+			__builtin_amdgcn_s_setprio(0);
+		else if (mine * (blockDim.x >> 6) + margin < sum)
+			__builtin_amdgcn_s_setprio(3);
+		else
+			__builtin_amdgcn_s_setprio(1);
+	}
+	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
+	IssueTile<NT>(next, voff, ahead, istride);
+	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating
+		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs, 1u);
+	uint32_t tmp[4];
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+		StepChunk<0>(p, lds, L, cur[k], hs, cold, (t * 8 + k) & 63);
+	StepChunkShadow<0, 8, true>(p, lds, L, cur[6], hs, cold, (t * 8 + 6) & 63, next, tmp);
+	StepChunkShadow<8, 0, false>(p, lds, L, cur[7], hs, cold, (t * 8 + 7) & 63, next, tmp);
+}
+
 // Fixed-length records, 16-byte aligned, whole tasks of 64 strings (the host routes the < 64-string remainder to
 // the generic kernel).  NBUF register tiles per wave form a ring: tile t is walked out of registers -- one LDS
 // gather per byte -- while tiles t+1 .. t+NBUF-1 stream in from HBM.
-template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false, bool EQ = false>
+template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false, bool EQ = false, bool SHADOW = false>
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
+	static_assert(!SHADOW || (ROT == 0 && !CHECKED), "the shadowed transpose exists for the shipped layout only");
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
 	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
 	static_assert(NBUF == 2, "ring depth");
@@ -181,6 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	// The first tile of the wave's first task is requested BEFORE the table is copied into LDS: its HBM latency (a
 	// few microseconds when all 4 096 waves of a launch ask at once) then hides behind the copy.
 	bool primed = firstTask < ntasks;   // slot a already holds (or is receiving) tile 0 of the task about to start
+	bool ready = false;                 // SHADOW: ... and it is transposed
 #ifdef PIRE_HIP_TUNING
 	if (p.stamps && threadIdx.x == 0)
 		p.stamps[blockIdx.x * 4 + 0] = wall_clock64();
@@ -211,10 +250,21 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 		uint32_t hsNoted = 0;
 		if (!primed)
 			IssueTile<NT>(a, voff, rowBase, istride);
+		if (SHADOW && !ready) {
+			// the ring's invariant -- slot a holds tile 0 TRANSPOSED -- does not hold yet (a wave's first task, or
+			// the task after an early-out): this one transpose is not hidden
+			WaitTile<0>(a);
+			TransposeTile(a, lane);
+		}
 		for (uint32_t g = 0; g < groups && !done; ++g) {
 			const uint32_t t = g * 2;
-			Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold, prog, &myTiles);
-			Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold, prog, &myTiles);
+			if (SHADOW) {
+				PhaseShadow<NT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold, prog, &myTiles);
+				PhaseShadow<NT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold, prog, &myTiles);
+			} else {
+				Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, hs, cold, prog, &myTiles);
+				Phase<2, NT, ROT, EQ>(p, lds, L, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, hs, cold, prog, &myTiles);
+			}
 			done = AllAbsorbing(p, lds, L, hs);
 			if (CHECKED && done) {
 				if (!noted)
@@ -224,9 +274,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 			}
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
+		ready = primed;              // SHADOW: ... and when it is the right tile, it is transposed already
 		if (!done && rem == 1) {
-			WaitTile<0>(a);
-			TransposeTile(a, lane);
+			if (!SHADOW) {   // SHADOW: the last phase of the loop (or, without one, the prologue) left it transposed
+				WaitTile<0>(a);
+				TransposeTile(a, lane);
+			}
 			StepTile<ROT>(p, lds, L, a, hs, cold, lastTile);
 		}
 
@@ -318,6 +371,14 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	case 4:   // also chosen by PIRE_HIP_CHECKED=1
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,checked>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream);
+		break;
+	case 22:
+		// The transpose of tile t+1 in the shadows of the last 24 lookups of tile t (PhaseShadow).  Measured in round 3
+		// (profiles/r03_shadow_ab.log, one process, alternating bursts): +1.5-2 % while the clocks are low (the first
+		// ~25 launches after an idle gap), -0.8 % at settled clocks, where the kernel sits 1.5 % above its load path
+		// and the earlier deadline for the refill (6.5 / 8 of a tile-time) costs more than the hidden VALU saves.
+		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,4,shadow>");
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 4, 0, false, true, true>, q, 1024, L256.total, stream);
 		break;
 	default:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");

@@ -50,3 +50,24 @@ def slow_case(name: str) -> dict:
 def plants_for(big: dict):
     """Corpus plants of a pattern set: witness r at the tail / at a generated offset, as the fixture says."""
     return make_plants([(bytes.fromhex(h), t) for h, t in zip(big["witnesses_hex"], big["witness_at_tail"])])
+
+
+def ref_bench_file() -> bytes:
+    """The reference's benchmark corpus, tools/bench/test_file (20 485 bytes of C++ text), shipped as a data fixture
+    (tests/golden/make_ref_corpus.py); its SHA-256 is checked."""
+    import hashlib
+
+    data = load_blob("ref_bench_test_file.gz")
+    with open(os.path.join(GOLDEN, "ref_bench_test_file.json")) as f:
+        meta = json.load(f)
+    assert len(data) == meta["bytes"] and hashlib.sha256(data).hexdigest() == meta["sha256"], "corpus fixture damaged"
+    return data
+
+
+def ref_bench_corpus(total_bytes: int) -> bytes:
+    """The big file of the reference's tools/bench/run-bench:126-138: test_file doubled (`cat big big > big.new`) until
+    it is at least `total_bytes` long -- NOT truncated there, exactly like the script; callers cut what they need."""
+    data = ref_bench_file()
+    while len(data) < total_bytes:
+        data = data + data
+    return data

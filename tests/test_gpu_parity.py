@@ -436,10 +436,10 @@ def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
 
 @pytest.mark.gpu
 def test_ragged_work_counters_survive_thousands_of_launches(pa, torch_cuda):
-    """The ragged kernels take string ranges from a counter that has to be zero at launch; no launch zeroes its own:
-    launch k uses counter 2 * (k % 1024) + phase and clears the other one of the pair for the launch that comes round
-    next (internal.h WorkSlotOf).  More than two full rounds of launches on one table, two batches of different sizes
-    alternating, two streams: every launch must hand out every string exactly once."""
+    """The ragged kernels take string ranges from a counter that has to be zero at launch; no launch pays a memset:
+    launch k uses slot k % 1024 and its last block out puts the slot back to zero (internal.h WorkSlotOf).  More than
+    two full rounds of launches on one table, two batches of different sizes alternating, two streams: every launch
+    must hand out every string exactly once."""
     torch = torch_cuda
     from pire_amd import binding as pb
 
@@ -471,6 +471,88 @@ def test_ragged_work_counters_survive_thousands_of_launches(pa, torch_cuda):
     torch.cuda.synchronize()
     assert pb.last_kernel() == "ragged"
     assert int(mismatches.item()) == 0
+
+
+@pytest.mark.gpu
+def test_ragged_work_counters_with_mixed_kinds_of_launches(pa, torch_cuda):
+    """every launch of a table takes a slot NUMBER, but only ragged kernels use the slot's counter.
+    Ragged, tiled, small generic, empty and flag-forced generic launches interleaved on one table for more than two
+    rounds of the 1 024 slots: a slot a ragged launch used must be clean again for the next ragged launch that comes
+    round to it, whatever went in between (the last block of a ragged launch zeroes its own slot)."""
+    torch = torch_cuda
+    from pire_amd import binding as pb
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.upload()
+    rng = np.random.RandomState(78)
+    alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet"
+
+    def batch(n, max_len):
+        strings = H.random_strings(rng, n, max_len, alphabet)
+        text, offs = H.pack(strings)
+        d = torch.as_tensor(np.array(text), device="cuda")
+        do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+        want = torch.as_tensor(o.run(text, offs)[0].astype(np.int64), device="cuda").to(torch.int32)
+        return n, d, do, want, torch.empty(n, dtype=torch.int32, device="cuda")
+
+    ragged, small = batch(1200, 150), batch(40, 60)               # ragged kernel / generic kernel (n < 256)
+    n_t, len_t = 128, 256
+    rec = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=(n_t, len_t)).astype(np.uint8)
+    want_t = torch.as_tensor(o.run(rec.reshape(-1), np.arange(n_t + 1, dtype=np.uint64) * len_t)[0].astype(np.int64),
+                             device="cuda").to(torch.int32)
+    drec = torch.as_tensor(rec, device="cuda")
+    idx_t = torch.empty(n_t, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    mism = torch.zeros(1, dtype=torch.int64, device="cuda")
+    kinds = set()
+    # the period (7) is coprime to the 1 024 slots: over 2 500 launches every slot sees every kind of neighbour
+    for k in range(2500):
+        kind = k % 7
+        if kind in (0, 3):
+            n, d, do, want, idx = ragged
+            idx.fill_(-1)
+            t.run_device(d.data_ptr(), do.data_ptr(), n, 3, idx.data_ptr(), 0, 0, 0, stream)
+            mism += (idx != want).sum()
+        elif kind in (1, 5):
+            idx_t.fill_(-1)
+            t.run_strided_device(drec.data_ptr(), n_t, len_t, len_t, 3, idx_t.data_ptr(), 0, 0, 0, stream)
+            mism += (idx_t != want_t).sum()
+        elif kind == 2:
+            n, d, do, want, idx = small
+            idx.fill_(-1)
+            t.run_device(d.data_ptr(), do.data_ptr(), n, 3, idx.data_ptr(), 0, 0, 0, stream)
+            mism += (idx != want).sum()
+        elif kind == 4:
+            n, d, do, want, idx = ragged
+            t.run_device(d.data_ptr(), do.data_ptr(), 0, 3, idx.data_ptr(), 0, 0, 0, stream)   # n == 0: no launch
+        else:
+            n, d, do, want, idx = ragged
+            idx.fill_(-1)
+            t.run_device(d.data_ptr(), do.data_ptr(), n, 3 | pb.FLAG_GENERIC, idx.data_ptr(), 0, 0, 0, stream)
+            mism += (idx != want).sum()
+        if k < 14:
+            kinds.add(pb.last_kernel())
+        if k % 250 == 249:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    assert {"ragged", "tiled", "generic"} <= kinds, kinds
+    assert int(mism.item()) == 0
+
+
+@pytest.mark.gpu
+def test_empty_fixed_length_records_in_host_mode(pa):
+    """n > 0 records of length 0 with stride 0 and a null text pointer (what
+    Table.run_strided_host(np.zeros((n, 0))) passes) reached a division by the stride.  Every record is the empty
+    string: Begin() then End() from the initial state (pire_ut.cpp:832-837 semantics)."""
+    for case in H.all_cases()[:6]:
+        blob = H.load_blob(case["blob"])
+        t, o = pa.Table(blob), ob.OracleScanner(blob)
+        for n in (1, 5, 3000):
+            idx, fin = t.run_strided_host(np.zeros((n, 0), dtype=np.uint8))
+            oi, of = o.run(np.zeros(0, np.uint8), np.zeros(n + 1, dtype=np.uint64))
+            assert (idx == oi).all() and (fin == of).all(), case["name"]
 
 
 @pytest.mark.gpu
@@ -542,7 +624,7 @@ def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch
     assert (gi == oi).all() and (gf == of).all()
     from pire_amd import binding as pb
 
-    assert pb.last_kernel_symbol().endswith("nt,5>")
+    assert pb.last_kernel_symbol().endswith("nt,5>")   # the default instantiation (tiled.hip LaunchTiled)
     monkeypatch.setenv("PIRE_HIP_CHECKED", "1")
     ci, cf, ccnt = dev_run_strided(torch, t, d)
     assert "checked" in pb.last_kernel_symbol()
