@@ -256,6 +256,9 @@ def main():
     if world > 1:
         pd.init(args.backend, dev)   # "nccl" is RCCL on ROCm
 
+    # The library re-ranks a table's dense rows by itself when scans keep leaving them (pire_hip_config.auto_adapt).
+    # Here the ranking is learned explicitly, on a held-out corpus (step 1 below), and must not move afterwards: off.
+    pb.set_config(auto_adapt=1)
     big = W.pattern_set(args.set)
     blob = W.load_blob(big["blob"])
     table = pire_amd.Table(blob)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PIRE_HIP_ABI_VERSION 3
+#define PIRE_HIP_ABI_VERSION 4
 
 enum {
 	PIRE_HIP_OK        =  0,
@@ -58,6 +58,57 @@ enum {
 };
 
 typedef struct pire_hip_table pire_hip_table;
+
+/* ---- library configuration ------------------------------------------------------------------------
+ * The runtime knobs of the library, set through the ABI.  Process-wide; a call takes a snapshot
+ * when it starts, so pire_hip_config_set() affects the calls that start after it.  0 = the default everywhere.
+ * The environment variables of the same names in upper case with the prefix PIRE_HIP_ (PIRE_HIP_TILED_VARIANT,
+ * PIRE_HIP_NO_SEGMENTS, ...) are read ONCE, when the library is loaded, and only seed this struct: no launch path
+ * calls getenv().  `size` = sizeof(pire_hip_config) of the caller: the struct may grow at its end. */
+typedef struct pire_hip_config {
+	uint32_t size;
+	/* fixed-length records (pire_hip_run_strided) */
+	uint32_t tiled_variant;        /* 0 the shipped kernel; 2 without `nt`; 20 waves not kept in step; 22 the transpose */
+	                               /* of the next tile hidden in the walk; 1 bank-rotated rows: A/B measurements, same results */
+	uint32_t checked;              /* 1: the checked kernel build, see pire_hip_table_check_failures()                 */
+	/* tables (applies to tables created / glued afterwards) */
+	uint32_t no_compact;           /* 1: no compact LDS tier behind the dense rows                                      */
+	uint32_t prior_flat;           /* 1: an a-priori ranking that knows nothing (tests of adapt())                      */
+	/* offset batches with actions (prefix searches, HalfFinal counting) */
+	uint32_t ragged_act_always;    /* 1: never take the one-string-per-lane kernel for "quick" searches                 */
+	uint32_t no_ragged_act;        /* 1: always take it                                                                 */
+	/* few long strings: the segmented scan */
+	uint32_t no_segments;          /* 1: never                                                                          */
+	uint32_t segment_no_grid;      /* 1: every segment through the ragged kernel                                        */
+	uint32_t segment_stats;        /* 1: print a host timeline per call (synchronises at every mark)                    */
+	uint32_t segment_modes;        /* modes per call (default 6)                                                        */
+	uint64_t segment_bytes;        /* bytes per segment; non-zero also FORCES the segmented scan for every eligible call */
+	uint64_t segment_warmup;       /* warm-up bytes in front of a segment (default 256); SEGMENT_WARMUP_NONE = 0 bytes   */
+	uint64_t segment_budget;       /* chain repair rounds (default 32); SEGMENT_BUDGET_NONE = 0 rounds                   */
+	/* host-pointer mode */
+	uint64_t host_chunk_bytes;     /* staging chunk size (default 256 MiB, minimum 4096)                                */
+	uint32_t host_one_shot;        /* 1: one allocation + one copy per call instead of the pooled pipeline              */
+	/* multi-device */
+	uint32_t no_rccl;              /* 1: sum the per-device counters on the host                                        */
+	/* SlowScanner */
+	uint32_t slow_sets_in_memory;  /* 1: the wave-per-string form keeps its state sets in device memory                 */
+	uint32_t slow_no_list;         /* 1: automata of more than 256 states always take the wave-per-string form          */
+	/* adaptation of the dense-row ranking */
+	uint32_t auto_adapt;           /* 0 default (on), 1 off, 2 on: re-rank by itself when scans keep leaving the dense   */
+	                               /* rows, see pire_hip_table_adapt()                                                  */
+	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 64)           */
+	/* offset batches (pire_hip_run) */
+	uint32_t ragged_variant;       /* 0 chosen from the mean string length; 1 always the 16-wave prefetching kernel;    */
+	                               /* 2 always the 24-wave one-tile kernel                                              */
+	uint32_t reserved0;
+} pire_hip_config;
+#define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
+#define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
+
+/* Copies min(out->size, sizeof) bytes of the current configuration; out->size must be set by the caller. */
+int pire_hip_config_get(pire_hip_config* out);
+/* Replaces the configuration (fields beyond in->size keep their current values). */
+int pire_hip_config_set(const pire_hip_config* in);
 
 /* Geometry of an ingested scanner; mirrors the public getters of Pire::Scanner. */
 typedef struct pire_hip_table_info {
@@ -140,7 +191,7 @@ int pire_hip_table_upload(pire_hip_table* t);
 int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows);
 
 /*
- * The checked build of the scan kernel (environment variable PIRE_HIP_CHECKED=1; the analogue of the reference's
+ * The checked build of the scan kernel (pire_hip_config.checked = 1; the analogue of the reference's
  * ValidateSkip, multi.h:925-934, which re-walks what the exit masks skipped): the wave-wide early-out on absorbing
  * states is only noted, the text is walked to its end all the same, and every lane whose state still moved after its
  * wave had been declared absorbing is counted.  *out receives the count since the last call (0 = the early-out was

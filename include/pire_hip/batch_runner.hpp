@@ -83,6 +83,27 @@ public:
 	~Table() { pire_hip_table_destroy(m_table); }
 
 	pire_hip_table* Handle() const { return m_table; }
+
+	/* Which states have dense LDS rows is a performance choice the table makes from a byte model of text and then
+	 * corrects from what the scans really visit -- by itself (pire_hip_config.auto_adapt, on by default: a table whose
+	 * scans keep leaving the dense rows re-ranks them at the next launch), or here, explicitly, after a representative
+	 * batch.  Results never depend on it.  Returns the number of rows that entered the dense set.  Must not run
+	 * concurrently with scans on this table (the automatic form may). */
+	unsigned Adapt()
+	{
+		uint32_t changed = 0;
+		Check(pire_hip_table_adapt(m_table, &changed));
+		return changed;
+	}
+	/* The automatic form off (true) or on (false) for the whole library; see pire_hip_config. */
+	static void FreezeRanking(bool frozen)
+	{
+		pire_hip_config c;
+		c.size = sizeof(c);
+		Check(pire_hip_config_get(&c));
+		c.auto_adapt = frozen ? 1 : 0;
+		Check(pire_hip_config_set(&c));
+	}
 	typename Scanner::State ToState(uint32_t idx) const { return m_base + size_t(idx) * m_stride; }
 	uint32_t ToIndex(typename Scanner::State st) const { return uint32_t((st - m_base) / m_stride); }
 

@@ -78,8 +78,42 @@ def build(force: bool = False) -> str:
 
 _lib = None
 
+class Config(C.Structure):
+    """pire_hip_config (include/pire_hip.h): the library's runtime knobs, set through the ABI."""
+    _fields_ = [
+        ("size", C.c_uint32),
+        ("tiled_variant", C.c_uint32),
+        ("checked", C.c_uint32),
+        ("no_compact", C.c_uint32),
+        ("prior_flat", C.c_uint32),
+        ("ragged_act_always", C.c_uint32),
+        ("no_ragged_act", C.c_uint32),
+        ("no_segments", C.c_uint32),
+        ("segment_no_grid", C.c_uint32),
+        ("segment_stats", C.c_uint32),
+        ("segment_modes", C.c_uint32),
+        ("segment_bytes", C.c_uint64),
+        ("segment_warmup", C.c_uint64),
+        ("segment_budget", C.c_uint64),
+        ("host_chunk_bytes", C.c_uint64),
+        ("host_one_shot", C.c_uint32),
+        ("no_rccl", C.c_uint32),
+        ("slow_sets_in_memory", C.c_uint32),
+        ("slow_no_list", C.c_uint32),
+        ("auto_adapt", C.c_uint32),
+        ("auto_adapt_min_traps", C.c_uint32),
+        ("ragged_variant", C.c_uint32),
+        ("reserved0", C.c_uint32),
+    ]
+
+
+NONE = (1 << 64) - 1   # PIRE_HIP_SEGMENT_WARMUP_NONE / PIRE_HIP_SEGMENT_BUDGET_NONE: "really zero", 0 being "the default"
+
+
 # every symbol include/pire_hip.h declares: (name, restype, argtypes)
 ABI = [
+    ("pire_hip_config_get", C.c_int, [C.POINTER(Config)]),
+    ("pire_hip_config_set", C.c_int, [C.POINTER(Config)]),
     ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_table_mmap", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("pire_hip_table_create_from_file", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -177,6 +211,40 @@ def lib():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def get_config() -> Config:
+    c = Config()
+    c.size = C.sizeof(Config)
+    _check(lib().pire_hip_config_get(C.byref(c)))
+    return c
+
+
+def set_config(**fields) -> Config:
+    """Change the named pire_hip_config fields (process-wide); returns the configuration as it was before."""
+    old = get_config()
+    new = get_config()
+    for k, v in fields.items():
+        if k not in dict(Config._fields_) or k in ("size", "reserved0"):
+            raise KeyError(k)
+        setattr(new, k, int(v))
+    _check(lib().pire_hip_config_set(C.byref(new)))
+    return old
+
+
+class config:
+    """`with config(tiled_variant=22): ...` -- the fields changed inside the block, restored after it."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.old = set_config(**self.fields)
+        return self
+
+    def __exit__(self, *exc):
+        _check(lib().pire_hip_config_set(C.byref(self.old)))
+        return False
 
 
 def device_count() -> int:

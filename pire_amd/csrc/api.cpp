@@ -68,6 +68,8 @@ namespace {
 
 int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 {
+	MaybeAutoAdapt(t);   // a launch boundary: re-rank the dense rows first if the scans so far kept leaving them
+	std::shared_lock<std::shared_mutex> stable(t->adaptMutex);   // no adaptation while the layout is copied
 	DeviceTable d;   // a copy of the current device's image (pointers), taken under the table's lock
 	if (int rc = UploadTable(t, &d))
 		return rc;
@@ -89,6 +91,7 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	p->finEnd = d.finEnd;
 	p->visitHot = d.visitHot;
 	p->visitCold = d.visitCold;
+	p->trapSignal = d.trapSignalDev;
 	p->compactRows = d.compactRows;
 	p->compact = h.compact;
 	p->incPerm = d.incPerm;
@@ -111,6 +114,65 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 }
 
 }  // namespace
+// ---- library configuration (pire_hip_config) ----------------------------------------------------------------------------
+namespace {
+std::mutex g_cfgMutex;
+
+uint64_t EnvU64(const char* name)
+{
+	const char* v = getenv(name);
+	if (!v || !*v)
+		return 0;
+	char* end = nullptr;
+	const unsigned long long x = strtoull(v, &end, 10);
+	return end != v ? uint64_t(x) : 1;   // PIRE_HIP_NO_SEGMENTS=yes counts as set
+}
+
+// The environment seeds the defaults ONCE (static initialisation of the first GetConfig / config_set call).
+pire_hip_config SeedFromEnvironment()
+{
+	pire_hip_config c;
+	memset(&c, 0, sizeof(c));
+	c.size = sizeof(c);
+	c.tiled_variant = uint32_t(EnvU64("PIRE_HIP_TILED_VARIANT"));
+	c.checked = EnvU64("PIRE_HIP_CHECKED") == 1;
+	c.no_compact = EnvU64("PIRE_HIP_NO_COMPACT") != 0;
+	c.prior_flat = EnvU64("PIRE_HIP_PRIOR_FLAT") != 0;
+	c.ragged_act_always = EnvU64("PIRE_HIP_RAGGED_ACT_ALWAYS") != 0;
+	c.no_ragged_act = EnvU64("PIRE_HIP_NO_RAGGED_ACT") != 0;
+	c.no_segments = EnvU64("PIRE_HIP_NO_SEGMENTS") != 0;
+	c.segment_no_grid = EnvU64("PIRE_HIP_SEGMENT_NO_GRID") != 0;
+	c.segment_stats = EnvU64("PIRE_HIP_SEGMENT_STATS") != 0;
+	c.segment_modes = uint32_t(EnvU64("PIRE_HIP_SEGMENT_MODES"));
+	c.segment_bytes = EnvU64("PIRE_HIP_SEGMENT_BYTES");
+	if (getenv("PIRE_HIP_SEGMENT_WARMUP"))
+		c.segment_warmup = EnvU64("PIRE_HIP_SEGMENT_WARMUP") ? EnvU64("PIRE_HIP_SEGMENT_WARMUP") : PIRE_HIP_SEGMENT_WARMUP_NONE;
+	if (getenv("PIRE_HIP_SEGMENT_BUDGET"))
+		c.segment_budget = EnvU64("PIRE_HIP_SEGMENT_BUDGET") ? EnvU64("PIRE_HIP_SEGMENT_BUDGET") : PIRE_HIP_SEGMENT_BUDGET_NONE;
+	c.host_chunk_bytes = EnvU64("PIRE_HIP_HOST_CHUNK_BYTES");
+	c.host_one_shot = EnvU64("PIRE_HIP_HOST_ONE_SHOT") != 0;
+	c.no_rccl = EnvU64("PIRE_HIP_NO_RCCL") != 0;
+	c.slow_sets_in_memory = EnvU64("PIRE_HIP_SLOW_SETS_IN_MEMORY") == 1;
+	c.slow_no_list = EnvU64("PIRE_HIP_SLOW_NO_LIST") != 0;
+	c.auto_adapt = uint32_t(EnvU64("PIRE_HIP_AUTO_ADAPT"));
+	c.auto_adapt_min_traps = uint32_t(EnvU64("PIRE_HIP_AUTO_ADAPT_MIN_TRAPS"));
+	c.ragged_variant = uint32_t(EnvU64("PIRE_HIP_RAGGED_VARIANT"));
+	return c;
+}
+
+pire_hip_config& ConfigStorage()
+{
+	static pire_hip_config c = SeedFromEnvironment();
+	return c;
+}
+}  // namespace
+
+pire_hip_config GetConfig()
+{
+	std::lock_guard<std::mutex> lock(g_cfgMutex);
+	return ConfigStorage();
+}
+
 void NoteKernel(const char* name, const char* symbol)
 {
 	g_lastKernel = name;
@@ -302,8 +364,8 @@ int RunHostPipelined(pire_hip_table* t, const ScanParams& base, const uint8_t* t
 {
 	*done = false;
 	size_t chunkBytes = kHostChunkBytes;
-	if (const char* knob = getenv("PIRE_HIP_HOST_CHUNK_BYTES"))   // tests: many small chunks
-		chunkBytes = std::max<size_t>(4096, std::min<size_t>(kHostChunkBytes, strtoull(knob, nullptr, 10)));
+	if (const uint64_t knob = GetConfig().host_chunk_bytes)   // tests: many small chunks
+		chunkBytes = std::max<size_t>(4096, std::min<size_t>(kHostChunkBytes, size_t(knob)));
 	// chunk boundaries: [first[c], first[c+1]) strings, text bytes [lo, hi) of the caller's buffer
 	std::vector<uint64_t> first{0};
 	if (offsets) {
@@ -522,7 +584,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			}
 	const bool segmented = !(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes);
 	// every size: the pooled staging also wins on small calls (10 strings 58 -> 36 us, 3 MB 563 -> 308 us per call)
-	if (!segmented && !g_timing && !getenv("PIRE_HIP_HOST_ONE_SHOT")) {
+	if (!segmented && !g_timing && !GetConfig().host_one_shot) {
 		bool done = false;
 		const int rc = RunHostPipelined(t, p, static_cast<const uint8_t*>(text), offsets, n, len, stride, init, outIdx,
 		                                outFinal, outCounts, &done);
@@ -587,6 +649,34 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 using namespace pirehip;
 
 extern "C" {
+
+int pire_hip_config_get(pire_hip_config* out)
+{
+	if (!out || out->size < sizeof(uint32_t)) {
+		SetError("pire_hip_config_get: out->size must hold the caller's sizeof(pire_hip_config)");
+		return PIRE_HIP_EINVAL;
+	}
+	const pire_hip_config c = GetConfig();
+	const uint32_t n = std::min<uint32_t>(out->size, uint32_t(sizeof(c)));
+	memcpy(out, &c, n);
+	out->size = n;
+	return PIRE_HIP_OK;
+}
+
+int pire_hip_config_set(const pire_hip_config* in)
+{
+	if (!in || in->size < sizeof(uint32_t)) {
+		SetError("pire_hip_config_set: in->size must hold the caller's sizeof(pire_hip_config)");
+		return PIRE_HIP_EINVAL;
+	}
+	std::lock_guard<std::mutex> lock(g_cfgMutex);
+	pire_hip_config& c = ConfigStorage();
+	memcpy(&c, in, std::min<size_t>(in->size, sizeof(c)));
+	c.size = sizeof(c);
+	return PIRE_HIP_OK;
+}
+
+
 
 const char* pire_hip_last_error(void) { return g_error.c_str(); }
 const char* pire_hip_last_kernel(void) { return g_lastKernel; }
@@ -752,7 +842,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)
 		return;
-	FreeAllDeviceTables(t);
+	FreeAllDeviceTables(t);   // the retired images of automatic adaptations too
 	delete t;
 }
 
@@ -763,6 +853,7 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	EnsureRanked(const_cast<pire_hip_table*>(t));   // hot_states / lds_table_bytes describe the ranked device layout
+	std::shared_lock<std::shared_mutex> stable(const_cast<pire_hip_table*>(t)->adaptMutex);
 	const HostTable& h = t->host;
 	memset(out, 0, sizeof(*out));
 	out->abi_version = PIRE_HIP_ABI_VERSION;

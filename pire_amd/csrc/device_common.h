@@ -216,6 +216,12 @@ __device__ inline void FlushCounts(const ScanParams& p, uint8_t* lds, const LdsL
 	for (uint32_t i = tid; i < 256; i += blockDim.x)
 		if (hist[i])
 			atomicAdd(&p.visitHot[i], hist[i]);
+	if (tid == 0 && hist[kLdsTrapSlot]) {
+		// traps seen by this block: device total, and its new value into the host-visible word (internal.h DeviceTable)
+		const uint32_t total = atomicAdd(&p.visitHot[kTrapSlot], hist[kLdsTrapSlot]) + hist[kLdsTrapSlot];
+		if (p.trapSignal)
+			__hip_atomic_store(p.trapSignal, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
 	if (!p.outCounts)
 		return;
 	const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + L.countsOff);
@@ -330,8 +336,10 @@ __device__ __forceinline__ void TrapChunk(const ScanParams& p, const uint8_t* ld
 		// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
 		// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
 		// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
-		if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
+		if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount)) {
 			atomicAdd(&p.visitCold[f], 1u);
+			atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + kLdsTrapSlot, 1u);
+		}
 	}
 }
 

@@ -365,7 +365,7 @@ int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long*
 	// a whole 128-byte window in the ragged one: measured 6.8 against 2.5 TB/s of text on log lines.  Everything that
 	// walks on takes the ragged kernel (2.6 - 5.6 x faster).  The shares come from the byte model of table.cpp.
 	const bool quick = (p0.deadShare > 0.5f || (!longest && p0.finalShare > 0.25f)) &&
-	                   !getenv("PIRE_HIP_RAGGED_ACT_ALWAYS");   // knob: tests and A/B measurements
+	                   !GetConfig().ragged_act_always;   // knob: tests and A/B measurements
 	if (workCounter && !quick && RaggedActEligible(p0)) {
 		NoteKernel("ragged_prefix");
 		return LaunchRaggedPrefix(p0, workCounter, longest, throughEnd, outLen, stream);

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -50,7 +51,9 @@ struct LdsLayout {
 constexpr uint32_t kRotPitch = 260;
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
 constexpr uint32_t kCheckSlot = 256;                     // visitHot[256]: failures seen by the checked kernel build
+constexpr uint32_t kTrapSlot = 257;                      // visitHot[257]: sampled traps since the image was uploaded (device total)
 constexpr uint32_t kVisitHotSlots = 260;
+constexpr uint32_t kLdsTrapSlot = 257;                   // the same count inside a block: hist[257] in LDS (hist[256] = progress)
 constexpr uint32_t kLdsPerBlock = 160 * 1024;            // gfx950: 160 KiB per CU, one block per CU may have it all
 constexpr uint32_t kRaggedFinBytes = 256 * 16;           // ragged kernel: end-of-string records of the hot states
 constexpr uint32_t kRaggedLdsExtra = kRaggedFinBytes + 32;
@@ -160,6 +163,11 @@ struct DeviceTable {
 	unsigned long long* workCounter = nullptr;   // [kWorkSlots] ragged kernel: next string range to hand out;
 	                                             // one slot per launch so that launches on different streams
 	                                             // never share a counter
+	// Auto-adaptation signal: blocks that saw traps add them to visitHot[kTrapSlot] (device atomics) and store the new
+	// total into this word of MAPPED HOST memory (a plain system-scope store: PCIe atomics are not needed, and a
+	// late smaller value only delays the trigger), so the host can look at it at every launch without synchronising.
+	volatile uint32_t* trapSignalHost = nullptr;
+	uint32_t* trapSignalDev = nullptr;
 	uint64_t bytes = 0;
 };
 
@@ -192,7 +200,16 @@ struct pire_hip_table {
 	std::atomic<uint32_t> workSlot[pirehip::kMaxDevices] = {};   // per device image: round-robin over its counter pairs
 	std::mutex segMutex;
 	std::vector<uint32_t> segModes;      // segmented.hip: mode representatives (state indices) earlier calls learned
+	// Adaptation (table.cpp AdaptTable) rewrites host.{hot, origOfPerm, permOfOrig, hotRows, ...} and swaps the images.
+	// Run entry points hold adaptMutex SHARED while they copy what they need (api.cpp FillParams); an adaptation holds
+	// it exclusively.  Images an AUTOMATIC adaptation replaces are not freed but retired: a call on another host thread
+	// may already have copied their pointers and not have launched yet.  They go with the table (a table adapts itself
+	// at most kMaxAutoAdapts times, ~1 MB per image).
+	std::shared_mutex adaptMutex;
+	std::vector<pirehip::DeviceTable> retired;
+	uint32_t autoAdapts = 0;
 };
+namespace pirehip { constexpr uint32_t kMaxAutoAdapts = 6; }
 
 namespace pirehip {
 
@@ -213,6 +230,7 @@ struct ScanParams {
 	const FinRec* finEnd;
 	uint32_t* visitHot;
 	uint32_t* visitCold;
+	uint32_t* trapSignal;   // mapped host word (device address) for the auto-adaptation policy, or null
 	const uint16_t* compactRows;
 	uint32_t compact;        // 0 = tier off
 	const uint64_t* incPerm; // nullable
@@ -310,7 +328,9 @@ int GlueBfsHost(const HostTable& a, const HostTable& b, const std::vector<uint32
 int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint32_t>& la,
                   const std::vector<uint32_t>& lb, size_t maxSize, GlueProduct* out);   // glue.hip
 int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out, bool onDevice = false);
-int AdaptTable(pire_hip_table* t, uint32_t* changedRows);
+int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic = false);
+// the auto-adaptation policy (pire_hip_config.auto_adapt): called at every launch boundary, cheap when nothing is due
+void MaybeAutoAdapt(pire_hip_table* t);
 int CheckFailures(pire_hip_table* t, uint64_t* out);
 void FreeDeviceTable(DeviceTable* d);
 
@@ -344,3 +364,9 @@ int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count
                      const void* plantsHost, hipStream_t stream);
 
 }  // namespace pirehip
+
+namespace pirehip {
+// The library configuration (include/pire_hip.h pire_hip_config): a snapshot by value, taken once per call.
+pire_hip_config GetConfig();
+}  // namespace pirehip
+

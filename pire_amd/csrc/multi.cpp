@@ -40,7 +40,7 @@ const Rccl& LoadRccl()
 {
 	static const Rccl r = [] {
 		Rccl x;
-		if (getenv("PIRE_HIP_NO_RCCL"))   // knob: force the host reduce (tests)
+		if (pirehip::GetConfig().no_rccl)   // knob: force the host reduce (tests); looked at once, when RCCL is first wanted
 			return x;
 		for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
 			x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);

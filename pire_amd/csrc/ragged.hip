@@ -1059,7 +1059,7 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 // whose counters do not pack, the one-string-per-lane kernels of exact.hip).
 bool RaggedActEligible(const ScanParams& p)
 {
-	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) - (1ull << 16) && !getenv("PIRE_HIP_NO_RAGGED_ACT");
+	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) - (1ull << 16) && !GetConfig().no_ragged_act;
 }
 
 int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream)

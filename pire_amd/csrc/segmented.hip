@@ -403,10 +403,10 @@ __global__ __launch_bounds__(256) void SegmentFinishSmallKernel(ScanParams p, co
 	}
 }
 
-uint64_t EnvBytes(const char* name, uint64_t fallback)
+// a pire_hip_config field: 0 = the default, the *_NONE sentinel = really zero
+uint64_t Knob(uint64_t v, uint64_t fallback)
 {
-	const char* v = getenv(name);
-	return v && *v ? uint64_t(strtoull(v, nullptr, 10)) : fallback;
+	return v == 0 ? fallback : v == ~uint64_t(0) ? 0 : v;
 }
 
 // Stream-ordered scratch: ONE allocation per call, made while the stream is still idle (allocating from the pool
@@ -478,9 +478,10 @@ int HipOk(hipError_t e, const char* what)
 // cost (profiles/r01_long_strings.log).  Either is exact; PIRE_HIP_SEGMENT_BYTES forces this one (tests).
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 {
-	if (getenv("PIRE_HIP_NO_SEGMENTS") || n == 0 || n >= (1ull << 20))
+	const pire_hip_config cfg = GetConfig();
+	if (cfg.no_segments || n == 0 || n >= (1ull << 20))
 		return false;
-	if (getenv("PIRE_HIP_SEGMENT_BYTES"))
+	if (cfg.segment_bytes)
 		return true;
 	const double mean = double(totalBytes) / double(n);
 	if (mean < 8192.0)
@@ -500,7 +501,8 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 {
 	PIRE_TRY(CheckCounts(p));
 	// diagnostics (PIRE_HIP_SEGMENT_STATS): where the host's time goes, with the stream drained at every mark
-	const bool wantStats = getenv("PIRE_HIP_SEGMENT_STATS") != nullptr;
+	const pire_hip_config cfg = GetConfig();
+	const bool wantStats = cfg.segment_stats != 0;
 	auto t0 = std::chrono::steady_clock::now();
 	std::string timeline;
 	auto mark = [&](const char* what) {
@@ -520,10 +522,10 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	// segments: as many as there are lanes, a multiple of the 128-byte window, long against the warm-up
 	const uint64_t wanted = uint64_t(cus) * 1024;
 	uint64_t segBytes = std::min<uint64_t>(1u << 20, std::max<uint64_t>(4096, (total / wanted + 127) / 128 * 128));
-	segBytes = EnvBytes("PIRE_HIP_SEGMENT_BYTES", segBytes);
-	const uint64_t warmBytes = EnvBytes("PIRE_HIP_SEGMENT_WARMUP", 256);
-	const uint32_t maxModes = uint32_t(std::min<uint64_t>(kMaxModes, std::max<uint64_t>(1, EnvBytes("PIRE_HIP_SEGMENT_MODES", 6))));
-	uint64_t budget = EnvBytes("PIRE_HIP_SEGMENT_BUDGET", 32);   // round trips for segments no mode predicted
+	segBytes = Knob(cfg.segment_bytes, segBytes);
+	const uint64_t warmBytes = Knob(cfg.segment_warmup, 256);
+	const uint32_t maxModes = uint32_t(std::min<uint64_t>(kMaxModes, std::max<uint64_t>(1, Knob(cfg.segment_modes, 6))));
+	uint64_t budget = Knob(cfg.segment_budget, 32);   // round trips for segments no mode predicted
 	if (segBytes == 0) {
 		SetError("PIRE_HIP_SEGMENT_BYTES must be positive");
 		return PIRE_HIP_EINVAL;
@@ -595,7 +597,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 
 	// how many leading segments lie on a regular grid of fixed-length records (see addMode)
 	uint64_t gridSegs = 0;
-	if (!hostOffsets && !getenv("PIRE_HIP_SEGMENT_NO_GRID")) {
+	if (!hostOffsets && !cfg.segment_no_grid) {
 		if (n == 1)
 			gridSegs = p.len / segBytes;
 		else if (p.stride == p.len && p.len % segBytes == 0)

@@ -725,8 +725,7 @@ int LaunchSlowWide(const SlowParams& p0, uint32_t njumps, hipStream_t stream)
 	const size_t setBytes = size_t(p.words) * 8;   // cur + next of one wave
 	const size_t ldsRoom = 158 * 1024 - 272;
 	uint32_t waves = uint32_t(std::min<size_t>(16, ldsRoom / setBytes));
-	const char* knob = getenv("PIRE_HIP_SLOW_SETS_IN_MEMORY");   // tests: the device-memory form for any size
-	const bool inLds = waves >= 1 && !(knob && knob[0] == '1');
+	const bool inLds = waves >= 1 && !GetConfig().slow_sets_in_memory;   // (the knob: tests run the device-memory form at any size)
 	if (!inLds)
 		waves = 16;
 	size_t room = ldsRoom - (inLds ? waves * setBytes : 0);

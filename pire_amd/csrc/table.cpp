@@ -262,7 +262,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	t.hotFinalLo = t.hotDeadLo;
 	while (t.hotFinalLo < t.hot && rankOf(order[t.hotFinalLo]) == 1)
 		++t.hotFinalLo;
-	t.compact = getenv("PIRE_HIP_NO_COMPACT") ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
+	t.compact = GetConfig().no_compact ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
 	t.permOfOrig.assign(N, 0);
 	for (uint32_t pid = 0; pid < N; ++pid)
@@ -326,7 +326,7 @@ void ChooseHotAndPermute(HostTable& t)
 	}
 	t.deadShare = all > 0 ? float(dead / all) : 0.0f;
 	t.finalShare = all > 0 ? float(fin / all) : 0.0f;
-	if (getenv("PIRE_HIP_PRIOR_FLAT"))   // knob for the tests of adapt(): a prior that knows nothing (dense rows = the
+	if (GetConfig().prior_flat)   // knob for the tests of adapt(): a prior that knows nothing (dense rows = the
 		for (uint32_t s = 0; s < N; ++s)  // first 255 states by index), so that adapt() has everything to learn
 			mass[s] = 1.0 / double(1 + s);
 	const double top = *std::max_element(mass.begin(), mass.end());
@@ -636,6 +636,8 @@ void FreeDeviceTable(DeviceTable* d)
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
+	if (d->trapSignalHost)
+		(void)hipHostFree(const_cast<uint32_t*>(d->trapSignalHost));
 	*d = DeviceTable();
 }
 
@@ -648,8 +650,25 @@ void FreeAllDeviceTables(pire_hip_table* t)
 			(void)hipSetDevice(k);
 			FreeDeviceTable(&t->devs[k]);
 		}
+	for (DeviceTable& d : t->retired)
+		if (d.device >= 0) {
+			(void)hipSetDevice(d.device);
+			FreeDeviceTable(&d);
+		}
+	t->retired.clear();
 	if (cur >= 0)
 		(void)hipSetDevice(cur);
+}
+
+// An automatic adaptation replaces the images but must not free them: a call on another host thread may have copied
+// their pointers (FillParams) and not have launched its kernel yet.  They are freed with the table.
+static void RetireAllDeviceTables(pire_hip_table* t)
+{
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->devs[k].device >= 0) {
+			t->retired.push_back(t->devs[k]);
+			t->devs[k] = DeviceTable();
+		}
 }
 
 int UploadTable(pire_hip_table* t, DeviceTable* image)
@@ -767,6 +786,22 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 		rc = Put(&d.visitCold, std::vector<uint32_t>(N, 0), &d.bytes);
 	if (!rc)
 		rc = Put(&d.workCounter, std::vector<unsigned long long>(2 * kWorkSlots, 0), &d.bytes);   // pairs: internal.h
+	if (!rc) {
+		// the auto-adaptation signal: one word of mapped host memory; without it (no mapped memory on this platform)
+		// the table simply never adapts by itself
+		void* hostWord = nullptr;
+		void* devWord = nullptr;
+		if (hipHostMalloc(&hostWord, 64, hipHostMallocMapped) == hipSuccess) {
+			memset(hostWord, 0, 64);
+			if (hipHostGetDevicePointer(&devWord, hostWord, 0) == hipSuccess) {
+				d.trapSignalHost = static_cast<volatile uint32_t*>(hostWord);
+				d.trapSignalDev = static_cast<uint32_t*>(devWord);
+			} else {
+				(void)hipHostFree(hostWord);
+			}
+		}
+		(void)hipGetLastError();
+	}
 	if (rc) {
 		d.device = dev;
 		FreeDeviceTable(&d);
@@ -1034,10 +1069,49 @@ int CheckFailures(pire_hip_table* t, uint64_t* out)
 	return PIRE_HIP_OK;
 }
 
-int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
+// The policy behind pire_hip_config.auto_adapt (default on).  Every launch boundary looks at the trap totals the images'
+// blocks have stored into mapped host memory (no synchronisation, no transfer: a read of a few host words); once the
+// scans since the last ranking left the dense rows more than `auto_adapt_min_traps` sampled times (default 256 samples
+// ~ 256 Ki lane-steps re-walked) the table is re-ranked right there -- the device is drained, the counters read, the
+// rows re-ranked, the images replaced (old ones retired, not freed) -- and the launch that noticed goes on with the new
+// image.  A table adapts itself at most kMaxAutoAdapts times: the remembered estimates make the ranking converge within
+// two or three, and a workload whose traffic does not fit 255 rows must not pay a re-ranking per call.
+void MaybeAutoAdapt(pire_hip_table* t)
+{
+	if (t->autoAdapts >= kMaxAutoAdapts)
+		return;
+	const pire_hip_config cfg = GetConfig();
+	if (cfg.auto_adapt == 1)
+		return;
+	const uint64_t threshold = cfg.auto_adapt_min_traps ? cfg.auto_adapt_min_traps : 256;
+	uint64_t traps = 0;
+	{
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		for (int k = 0; k < kMaxDevices; ++k)
+			if (t->devs[k].device >= 0 && t->devs[k].trapSignalHost)
+				traps += *t->devs[k].trapSignalHost;
+	}
+	if (traps < threshold)
+		return;
+	(void)AdaptTable(t, nullptr, true);   // a performance measure: a failure here surfaces in the launch that follows
+}
+
+int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 {
 	if (changedRows)
 		*changedRows = 0;
+	std::unique_lock<std::shared_mutex> exclusive(t->adaptMutex);
+	if (automatic) {
+		// re-check under the lock: another thread may just have done it
+		uint64_t traps = 0;
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		for (int k = 0; k < kMaxDevices; ++k)
+			if (t->devs[k].device >= 0 && t->devs[k].trapSignalHost)
+				traps += *t->devs[k].trapSignalHost;
+		if (traps == 0 || t->autoAdapts >= kMaxAutoAdapts)
+			return PIRE_HIP_OK;
+		t->autoAdapts++;
+	}
 	HostTable& h = t->host;
 	const uint32_t N = h.states, H = h.hot;
 	// what every device that ever ran this table saw, summed
@@ -1098,8 +1172,12 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 		int cur = -1;
 		(void)hipGetDevice(&cur);
 		for (int k = 0; k < kMaxDevices; ++k)
-			if (t->devs[k].device >= 0 && hipSetDevice(k) == hipSuccess)
-				(void)hipMemset(t->devs[k].visitHot, 0, 256 * 4);
+			if (t->devs[k].device >= 0 && hipSetDevice(k) == hipSuccess) {
+				(void)hipMemset(t->devs[k].visitHot, 0, 256 * 4);          // not the checked build's slot
+				(void)hipMemset(t->devs[k].visitHot + kTrapSlot, 0, 4);
+				if (t->devs[k].trapSignalHost)
+					*t->devs[k].trapSignalHost = 0;
+			}
 		(void)hipSetDevice(cur);
 		return PIRE_HIP_OK;   // nothing trapped: the current rows already cover the traffic
 	}
@@ -1114,7 +1192,10 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows)
 	// every image holds the old numbering: drop them all (synchronised above), each device re-uploads on its next run
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
-		FreeAllDeviceTables(t);
+		if (automatic)
+			RetireAllDeviceTables(t);
+		else
+			FreeAllDeviceTables(t);
 	}
 	DeviceTable d;
 	return UploadTable(t, &d);

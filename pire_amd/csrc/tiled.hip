@@ -317,9 +317,8 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	if (int rc = CheckCounts(p))
 		return rc;
 	// Variant knob for A/B measurements (DESIGN.md section 5 ladder); every variant returns the same results.
-	const char* variantEnv = getenv("PIRE_HIP_TILED_VARIANT");   // read per call: the tests switch it
-	const char* checkedEnv = getenv("PIRE_HIP_CHECKED");
-	const int variant = checkedEnv && checkedEnv[0] == '1' ? 4 : variantEnv ? atoi(variantEnv) : 0;
+	const pire_hip_config cfg = GetConfig();
+	const int variant = cfg.checked ? 4 : int(cfg.tiled_variant);
 	ScanParams q = p;
 #ifdef PIRE_HIP_TUNING
 	q.stamps = nullptr;

@@ -99,6 +99,28 @@ static void TestSuite()
 			CHECK(end[i] == want);
 		}
 	}
+	// Table::Adapt(): the dense-row ranking follows the data (explicitly here; the library also does it by itself),
+	// and the states that come back are the same row addresses before and after
+	{
+		Scanner sc = glued3;
+		Pire::Hip::Table<Scanner> table(sc);
+		std::vector<Pire::ystring> many;
+		for (int i = 0; i < 600; ++i)
+			many.push_back(text[size_t(i) % text.size()] + (i % 3 ? " hello   world" : "abcabc"));
+		Pire::Hip::BatchRunner<Scanner> before(table);
+		const std::vector<typename Scanner::State> a = before.Begin().Run(many).End().States();
+		const unsigned rows = table.Adapt();
+		CHECK(rows <= 255);
+		Pire::Hip::BatchRunner<Scanner> after(table);
+		const std::vector<typename Scanner::State>& b = after.Begin().Run(many).End().States();
+		CHECK(a.size() == b.size());
+		for (size_t i = 0; i < a.size(); ++i) {
+			CHECK(a[i] == b[i]);
+			CHECK(a[i] == Pire::Runner(sc).Begin().Run(many[i]).End().State());
+		}
+		Pire::Hip::Table<Scanner>::FreezeRanking(true);
+		Pire::Hip::Table<Scanner>::FreezeRanking(false);
+	}
 	// empty scanner never matches and must not crash -- pire_ut.cpp:760-830
 	{
 		Scanner empty;

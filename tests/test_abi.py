@@ -150,3 +150,64 @@ def test_run_without_gpu_fails_loudly():
         t.run_strings([b"abc"])
     assert e.value.code == -3
     assert "hip" in str(e.value).lower()
+
+
+def test_config_struct_round_trip_and_partial_sizes():
+    """pire_hip_config (runtime knobs through the ABI): get/set round trip, a caller compiled against
+    a SHORTER struct only touches the fields it knows, bad sizes are rejected."""
+    import ctypes as C
+
+    old = pb.get_config()
+    assert old.size == C.sizeof(pb.Config)
+    try:
+        pb.set_config(tiled_variant=22, segment_bytes=4096, segment_warmup=pb.NONE, auto_adapt=1)
+        c = pb.get_config()
+        assert (c.tiled_variant, c.segment_bytes, c.segment_warmup, c.auto_adapt) == (22, 4096, pb.NONE, 1)
+        short = pb.Config()
+        short.size = 12                      # size + tiled_variant + checked
+        short.tiled_variant, short.checked = 2, 1
+        short.segment_bytes = 999            # beyond `size`: must be ignored
+        assert pb.lib().pire_hip_config_set(C.byref(short)) == 0
+        c = pb.get_config()
+        assert (c.tiled_variant, c.checked, c.segment_bytes) == (2, 1, 4096)
+        part = pb.Config()
+        part.size = 8
+        assert pb.lib().pire_hip_config_get(C.byref(part)) == 0 and part.size == 8 and part.tiled_variant == 2
+        bad = pb.Config()
+        bad.size = 0
+        assert pb.lib().pire_hip_config_set(C.byref(bad)) < 0 and pb.lib().pire_hip_config_get(C.byref(bad)) < 0
+        assert pb.lib().pire_hip_config_set(None) < 0
+    finally:
+        assert pb.lib().pire_hip_config_set(C.byref(old)) == 0
+    assert pb.get_config().tiled_variant == old.tiled_variant
+
+
+def test_environment_only_seeds_the_config_once():
+    """The PIRE_HIP_* environment variables are read when the library is loaded, never per launch: a child process
+    started with them set sees them in pire_hip_config; changing os.environ afterwards changes nothing."""
+    import subprocess
+    import sys
+
+    code = ("import os; from pire_amd import binding as pb; c = pb.get_config(); "
+            "os.environ['PIRE_HIP_TILED_VARIANT'] = '2'; d = pb.get_config(); "
+            "print(c.tiled_variant, c.no_segments, c.segment_warmup == pb.NONE, c.segment_bytes, d.tiled_variant)")
+    env = dict(os.environ, PIRE_HIP_TILED_VARIANT="22", PIRE_HIP_NO_SEGMENTS="1", PIRE_HIP_SEGMENT_WARMUP="0",
+               PIRE_HIP_SEGMENT_BYTES="512", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-400:]
+    assert out.stdout.split() == ["22", "1", "True", "512", "22"]
+
+
+def test_no_launch_path_reads_the_environment():
+    """getenv() only where the configuration is seeded (api.cpp) and in -DPIRE_HIP_TUNING blocks."""
+    import re
+
+    src = os.path.join(ROOT, "pire_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if not name.endswith((".cpp", ".hip", ".h")):
+            continue
+        text = open(os.path.join(src, name)).read()
+        # drop the tuning-build blocks
+        text = re.sub(r"#ifdef PIRE_HIP_TUNING.*?#endif", "", text, flags=re.S)
+        for m in re.finditer(r"getenv\(([^)]*)\)", text):
+            assert name == "api.cpp" and ("name" in m.group(1) or "PIRE_HIP_SEGMENT_" in m.group(1)), (name, m.group(0))

@@ -348,7 +348,7 @@ def test_full_size_config_properties(pa, torch_cuda, name, length):
 
 
 @pytest.mark.parametrize("name", ["set_d", "set_b", "set_a"])
-def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name, monkeypatch):
+def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name, cfg):
     """pire_hip_table_adapt(): after one representative batch the rows the data really visits move into LDS.
     Results must be bit-identical before and after; the trap counter must collapse.  The table starts from a prior
     that knows nothing (PIRE_HIP_PRIOR_FLAT: dense rows = the first 255 states by index) so that there is something to
@@ -356,10 +356,10 @@ def test_adapt_promotes_visited_rows_and_keeps_results(pa, torch_cuda, name, mon
     torch = torch_cuda
     big = [b for b in H.big_sets() if b["name"] == name][0]
     blob = H.load_blob(big["blob"])
-    monkeypatch.setenv("PIRE_HIP_PRIOR_FLAT", "1")
+    cfg.set(prior_flat="1")
     t, o = pa.Table(blob), ob.OracleScanner(blob)
     t.layout()                                   # ranks the rows now, under the knob
-    monkeypatch.delenv("PIRE_HIP_PRIOR_FLAT")
+    cfg.unset("prior_flat")
     n, length = 8192, 2048
     data = ob.corpus_fill(77, 0, n, length, H.plants_for(big), threads=4)
     oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
@@ -432,6 +432,84 @@ def test_concurrent_host_threads_share_one_table(pa, torch_cuda):
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["set_d", "set_a"])
+def test_auto_adapt_reranks_at_a_launch_boundary(pa, torch_cuda, name, cfg):
+    """pire_hip_config.auto_adapt (the library's default): a table whose scans keep leaving the dense rows re-ranks
+    itself at the next launch -- no call by the user (a drop-in user of BatchRunner never makes one).  The
+    table starts from a prior that knows nothing; the first launch traps, the second notices (host-visible trap total),
+    adapts and runs on the new image; results identical throughout, traps collapse, and with the policy off nothing
+    changes by itself."""
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    n, length = 8192, 2048
+    data = ob.corpus_fill(78, 0, n, length, H.plants_for(big), threads=4)
+    o = ob.OracleScanner(blob)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    for policy, expect in ((1, False), (0, True)):
+        cfg.set(prior_flat=1, auto_adapt=policy)
+        t = pa.Table(blob)
+        t.layout()                                   # ranks the rows now, under the knob
+        cfg.set(prior_flat=0)
+        rows_before = set(t.layout()[0][:t.info.hot_states].tolist())
+        for launch in range(4):
+            gi, gf, cnt = dev_run_strided(torch, t, d)
+            assert (gi == oi).all() and (gf == of).all(), (policy, launch)
+        info = t.refresh_info()
+        rows_after = set(t.layout()[0][:info.hot_states].tolist())
+        if expect:
+            assert 1 <= info.adaptations <= 3, info.adaptations
+            assert rows_after != rows_before
+            t.adapt()                                # reads the counters of the launches since the last re-ranking
+            assert t.info.last_trap_samples * 20 < info.last_trap_samples + 20   # the traps have collapsed
+        else:
+            assert info.adaptations == 0 and rows_after == rows_before
+        gi, gf, cnt = dev_run_strided(torch, t, d)
+        assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.gpu
+def test_auto_adapt_under_concurrent_launches(pa, cfg):
+    """The automatic re-ranking replaces the device images while other host threads may hold their pointers: the
+    old images are retired, not freed (table.cpp RetireAllDeviceTables), and the host layout is copied under a shared
+    lock.  Six threads, one table that starts from the know-nothing prior, ragged and fixed-length calls: every result
+    equals the oracle's while the table adapts itself underneath."""
+    import threading
+
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    blob = H.load_blob(big["blob"])
+    cfg.set(prior_flat=1, auto_adapt=0, auto_adapt_min_traps=8)
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    t.layout()
+    cfg.set(prior_flat=0)
+    jobs = []
+    for k in range(6):
+        data = ob.corpus_fill(100 + k, 0, 2048, 512, H.plants_for(big), threads=2)
+        want = o.run(data.reshape(-1), np.arange(2049, dtype=np.uint64) * 512, threads=2)
+        jobs.append((data, want))
+    errors = []
+
+    def worker(k):
+        try:
+            data, want = jobs[k]
+            for rep in range(12):
+                gi, gf = t.run_strided_host(data)
+                if not ((gi == want[0]).all() and (gf == want[1]).all()):
+                    errors.append((k, rep))
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert t.refresh_info().adaptations >= 1
 
 
 @pytest.mark.gpu
@@ -556,13 +634,13 @@ def test_empty_fixed_length_records_in_host_mode(pa):
 
 
 @pytest.mark.gpu
-def test_concurrent_host_pointer_calls_share_the_staging_pool(pa, monkeypatch):
+def test_concurrent_host_pointer_calls_share_the_staging_pool(pa, cfg):
     """Host-pointer calls from several threads at once, ragged and fixed-length, small and cut into chunks
     (PIRE_HIP_HOST_CHUNK_BYTES): the pooled staging arenas of api.cpp are taken, grown and returned under contention;
     every result must equal the oracle's, repeatedly."""
     import threading
 
-    monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", str(256 * 1024))
+    cfg.set(host_chunk_bytes=str(256 * 1024))
     big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
     blob = H.load_blob(big["blob"])
     t, o = pa.Table(blob), ob.OracleScanner(blob)
@@ -601,7 +679,7 @@ def test_concurrent_host_pointer_calls_share_the_staging_pool(pa, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch):
+def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, cfg):
     """PIRE_HIP_CHECKED=1 (the analogue of the reference's ValidateSkip, multi.h:925-934): the wave-wide early-out is
     only noted, the text is walked to the end, and lanes whose state still moved are counted.  On a batch in which every
     wave does go absorbing (an unanchored pattern matched early in every string) the count must be 0 and the results
@@ -625,7 +703,7 @@ def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch
     from pire_amd import binding as pb
 
     assert pb.last_kernel_symbol().endswith("nt,5>")   # the default instantiation (tiled.hip LaunchTiled)
-    monkeypatch.setenv("PIRE_HIP_CHECKED", "1")
+    cfg.set(checked="1")
     ci, cf, ccnt = dev_run_strided(torch, t, d)
     assert "checked" in pb.last_kernel_symbol()
     assert (ci == oi).all() and (cf == of).all() and (ccnt == cnt).all()
@@ -634,7 +712,7 @@ def test_checked_kernel_build_confirms_the_early_out(pa, torch_cuda, monkeypatch
 
 
 @pytest.mark.gpu
-def test_host_pointer_mode_in_chunks_equals_one_shot(pa, torch_cuda, monkeypatch):
+def test_host_pointer_mode_in_chunks_equals_one_shot(pa, torch_cuda, cfg):
     """The host-pointer mode cuts big batches into chunks of whole strings that go H2D -> scan -> D2H on alternating
     streams of a pooled staging arena (api.cpp RunHostPipelined).  With a tiny chunk size (knob) a small batch takes
     dozens of chunks: ragged strings with empty ones, strings longer than most chunks' average, offsets that do not
@@ -655,11 +733,11 @@ def test_host_pointer_mode_in_chunks_equals_one_shot(pa, torch_cuda, monkeypatch
     want = {}
     for name, kw in (("plain", {}), ("resume", {"init_idx": init})):
         want[name] = o.run(text2, offs2, threads=4, **kw)
-    monkeypatch.setenv("PIRE_HIP_HOST_ONE_SHOT", "1")
+    cfg.set(host_one_shot="1")
     one = t.run(text2, offs2, counts=True)
-    monkeypatch.delenv("PIRE_HIP_HOST_ONE_SHOT")
+    cfg.unset("host_one_shot")
     for chunk in ("4096", "20000", "65536"):
-        monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", chunk)
+        cfg.set(host_chunk_bytes=chunk)
         gi, gf, cnt = t.run(text2, offs2, counts=True)
         assert (gi == want["plain"][0]).all() and (gf == want["plain"][1]).all(), chunk
         assert (gi == one[0]).all() and (cnt == one[2]).all()
@@ -668,6 +746,6 @@ def test_host_pointer_mode_in_chunks_equals_one_shot(pa, torch_cuda, monkeypatch
     # fixed-length records: 3 000 x 512 B in chunks of 64 KiB
     data = ob.corpus_fill(5, 0, 3000, 512, H.plants_for(big), threads=4)
     oi, of = o.run(data.reshape(-1), np.arange(3001, dtype=np.uint64) * 512, threads=4)
-    monkeypatch.setenv("PIRE_HIP_HOST_CHUNK_BYTES", "65536")
+    cfg.set(host_chunk_bytes="65536")
     si, sf = t.run_strided_host(data)
     assert (si == oi).all() and (sf == of).all()

@@ -62,11 +62,11 @@ def half_blobs():
 
 
 @pytest.mark.parametrize("name,blob", half_blobs(), ids=[b[0] for b in half_blobs()])
-def test_half_final_and_prefix_in_poisoned_memory(name, blob, monkeypatch):
+def test_half_final_and_prefix_in_poisoned_memory(name, blob, cfg):
     import torch
     import pire_amd
 
-    monkeypatch.setenv("PIRE_HIP_RAGGED_ACT_ALWAYS", "1")
+    cfg.set(ragged_act_always="1")
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
     t.upload()
     rng = np.random.RandomState(2024)

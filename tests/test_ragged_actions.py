@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True)
-def always_ragged(monkeypatch):
+def always_ragged(cfg):
     """The prefix searches pick the one-string-per-lane kernel for scanners whose searches end after a few bytes
     (a heuristic, exact.hip LaunchPrefix); these tests are about the ragged kernel, whatever the scanner."""
-    monkeypatch.setenv("PIRE_HIP_RAGGED_ACT_ALWAYS", "1")
+    cfg.set(ragged_act_always="1")
 
 
 def length_mix(rng, n, alphabet, long_every=97):
@@ -151,14 +151,14 @@ def test_ragged_actions_on_device_buffers_of_exact_size():
         assert (ln.cpu().numpy() == o.prefix(text, offs, True)).all()
 
 
-def test_prefix_kernel_choice_follows_the_scanner(monkeypatch):
+def test_prefix_kernel_choice_follows_the_scanner(cfg):
     """A lexer-like scanner (Dead right behind the token) keeps the exact kernel, a Surround()ed one takes the ragged."""
     if not ob.ref_available():
         pytest.skip("oracle/_ref/libpire_ref.so not built")
     import pire_amd
     from pire_amd import binding as pb
 
-    monkeypatch.delenv("PIRE_HIP_RAGGED_ACT_ALWAYS")
+    cfg.unset("ragged_act_always")
     rng = np.random.RandomState(5)
     strings = length_mix(rng, 600, b"abc 019")
     text, offs = H.pack(strings)

@@ -35,7 +35,7 @@ def pa():
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_scanner_all_kernels(pa, seed, monkeypatch):
+def test_random_scanner_all_kernels(pa, seed, cfg):
     if not ob.ref_available():
         pytest.skip("oracle/_ref not built")
     import torch
@@ -95,13 +95,13 @@ def test_random_scanner_all_kernels(pa, seed, monkeypatch):
     long_strings = [bytes(alphabet[rng.randint(0, len(alphabet), size=int(n))]) for n in rng.randint(0, 5000, size=40)]
     ltext, loffs = H.pack(long_strings)
     oi, of = o.run(ltext, loffs, threads=4)
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(int(rng.choice([48, 128, 400]))))
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", str(int(rng.choice([0, 8, 64]))))
+    cfg.set(segment_bytes=str(int(rng.choice([48, 128, 400]))))
+    cfg.set(segment_warmup=str(int(rng.choice([0, 8, 64]))))
     gi, gf, cnt = t.run(ltext, loffs, counts=True)
     assert pb.last_kernel().startswith("segmented")
     assert (gi == oi).all() and (gf == of).all(), (pats, opts)
     assert cnt[0] == int(of.sum()) and cnt[1] == len(long_strings)
-    monkeypatch.delenv("PIRE_HIP_SEGMENT_BYTES")
+    cfg.unset("segment_bytes")
     if t.RegexpsCount <= 8:
         hi, hf, hr = o.run_half_final(text, offs)
         gi, gf, gr = t.run_half_final(text, offs)

@@ -39,14 +39,14 @@ def strings_for(rng, name):
 @pytest.mark.parametrize("name,blob", tables(), ids=[n for n, _ in tables()])
 @pytest.mark.parametrize("seg,warm,modes,budget", [(64, 0, 6, 32), (100, 16, 1, 0), (256, 256, 6, 32), (128, 32, 2, 1),
                                                    (4096, 256, 3, 4)])
-def test_segmented_scan_is_exact(name, blob, seg, warm, modes, budget, monkeypatch):
+def test_segmented_scan_is_exact(name, blob, seg, warm, modes, budget, cfg):
     import pire_amd
     from pire_amd import binding as pb
 
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", str(warm))
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_MODES", str(modes))      # 1: nothing is learned
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BUDGET", str(budget))    # 0: every surprise ends in the plain walk
+    cfg.set(segment_bytes=str(seg))
+    cfg.set(segment_warmup=str(warm))
+    cfg.set(segment_modes=str(modes))      # 1: nothing is learned
+    cfg.set(segment_budget=str(budget))    # 0: every surprise ends in the plain walk
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
     rng = np.random.RandomState(seg * 7 + warm)
     strings = strings_for(rng, name)
@@ -68,13 +68,13 @@ def test_segmented_scan_is_exact(name, blob, seg, warm, modes, budget, monkeypat
     assert (gi == oi).all() and (gf == of).all()
 
 
-def test_segmented_fixed_length_records_host_and_device(monkeypatch):
+def test_segmented_fixed_length_records_host_and_device(cfg):
     import torch
     import pire_amd
     from pire_amd import binding as pb
 
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", "512")
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_WARMUP", "64")
+    cfg.set(segment_bytes="512")
+    cfg.set(segment_warmup="64")
     big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
     blob = H.load_blob(big["blob"])
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
@@ -125,13 +125,13 @@ def test_one_long_string_takes_the_segmented_path_by_itself():
 
 
 @pytest.mark.parametrize("length,seg", [((1 << 20) + 1000, 2048), ((1 << 20), 4096), (300000, 1024)])
-def test_single_string_grid_segments_through_the_tiled_kernel_plus_tail(length, seg, monkeypatch):
+def test_single_string_grid_segments_through_the_tiled_kernel_plus_tail(length, seg, cfg):
     """One string on the device: its full segments are fixed-length records (tiled kernel), the tail is not."""
     import torch
     import pire_amd
     from pire_amd import binding as pb
 
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
+    cfg.set(segment_bytes=str(seg))
     big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
     blob = H.load_blob(big["blob"])
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
@@ -142,7 +142,7 @@ def test_single_string_grid_segments_through_the_tiled_kernel_plus_tail(length, 
     fin = torch.empty(1, dtype=torch.uint8, device="cuda")
     for grid in (True, False):
         if not grid:
-            monkeypatch.setenv("PIRE_HIP_SEGMENT_NO_GRID", "1")
+            cfg.set(segment_no_grid="1")
         t.run_strided_device(d.data_ptr(), 1, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0,
                              torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
@@ -226,16 +226,16 @@ def test_concurrent_threads_segmented_scans_on_one_table():
 
 
 @pytest.mark.parametrize("seg,modes,budget", [(96, 6, 32), (256, 1, 0), (4096, 6, 32)])
-def test_segmented_half_final_counting(seg, modes, budget, monkeypatch):
+def test_segmented_half_final_counting(seg, modes, budget, cfg):
     """HalfFinalScanner counting of few long strings: the chain gives every segment its true start state, the segments
     are then counted in parallel; a chain that had to fall back to the plain walk hands the batch to the ordinary
     half-final kernel.  Either way Result(r), StateIndex and Final are the oracle's."""
     import pire_amd
     from pire_amd import binding as pb
 
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BYTES", str(seg))
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_MODES", str(modes))
-    monkeypatch.setenv("PIRE_HIP_SEGMENT_BUDGET", str(budget))
+    cfg.set(segment_bytes=str(seg))
+    cfg.set(segment_modes=str(modes))
+    cfg.set(segment_budget=str(budget))
     g = H.golden()
     tables = [(c["name"], H.load_blob(c["blob"]), b"abcde w") for c in g["half_final"] if c["regexps"] <= 8][:3]
     big = [b for b in H.big_sets() if b["name"] == "set_d"][0]

@@ -197,9 +197,10 @@ def test_slow_wide_gpu_matches_golden_and_oracle(case):
 @pytest.mark.skipif(not ob.ref_available(), reason="oracle/_ref/libpire_ref.so not built")
 def test_slow_wide_gpu_sets_in_device_memory():
     """x.{6000}$ has 12 007 states (two sets of 376 words per wave); the UTF-8 x.{1500}$ 7 507.  Both run with the sets
-    in LDS and -- forced with the PIRE_HIP_SLOW_SETS_IN_MEMORY knob -- with the sets in device memory, the form
+    in LDS and -- forced with pire_hip_config.slow_sets_in_memory -- with the sets in device memory, the form
     automata too large for the LDS take.  All against the oracle on strings around the gap length."""
     import pire_amd
+    from pire_amd import binding as pb
 
     for pat, opt, gap in (("x.{6000}$", "", 6000), ("x.{1500}$", "u", 1500)):
         r = ob.RefSlowScanner.compile(pat, opt)
@@ -210,12 +211,9 @@ def test_slow_wide_gpu_sets_in_device_memory():
         strings += [b"x" + bytes(rng.choice(np.frombuffer(b"xyz", dtype=np.uint8), size=k)) for k in (gap, 17)]
         strings += [bytes(rng.choice(np.frombuffer(b"xy", dtype=np.uint8), size=gap + 40)) for _ in range(6)] + [b""]
         of, obits = o.run_strings(strings)
-        for knob in ("0", "1"):
-            os.environ["PIRE_HIP_SLOW_SETS_IN_MEMORY"] = knob
-            try:
+        for knob in (0, 1):
+            with pb.config(slow_sets_in_memory=knob, slow_no_list=1):
                 t = pire_amd.SlowTable(blob)
                 gf, gb = t.run_strings(strings)
-            finally:
-                os.environ.pop("PIRE_HIP_SLOW_SETS_IN_MEMORY")
             assert (gf == of).all() and (gb == obits).all(), (pat, knob)
         assert of[1] == 1 and of[0] == 0 and of[2] == 0

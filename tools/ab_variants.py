@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of tiled-kernel variants (PIRE_HIP_TILED_VARIANT, read per launch) inside ONE process, alternating bursts, so
+"""A/B of tiled-kernel variants (pire_hip_config.tiled_variant) inside ONE process, alternating bursts, so
 that box, clocks and temperature are shared.  usage: ab_variants.py "0,22,21" [rounds] [set] [extra env k=v ...]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,12 +28,12 @@ def burst(k, timed=True):
     torch.cuda.synchronize()
     return np.array([a.elapsed_time(b) for a, b in ev]) if timed else None
 
-os.environ["PIRE_HIP_TILED_VARIANT"] = variants[0]
+pb.set_config(tiled_variant=int(variants[0]))
 burst(60, False); table.adapt(); burst(60, False)
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in (variants if r % 2 == 0 else variants[::-1]):
-        os.environ["PIRE_HIP_TILED_VARIANT"] = v
+        pb.set_config(tiled_variant=int(v))
         burst(10, False)
         ms = burst(60)
         res[v].append((ms.mean(), np.median(ms), ms.min()))
@@ -42,7 +42,7 @@ for v in variants:
     print("variant %-3s steady: mean %.4f (per round %s) median %.4f min %.4f" % (v, a[:, 0].mean(), " ".join("%.4f" % x for x in a[:, 0]), a[:, 1].mean(), a[:, 2].min()))
 # the driver's shape: idle, 5 warm-up launches, sync, 20 timed launches
 for v in variants:
-    os.environ["PIRE_HIP_TILED_VARIANT"] = v
+    pb.set_config(tiled_variant=int(v))
     outs = []
     for rep in range(3):
         time.sleep(0.3)

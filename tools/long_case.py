@@ -52,10 +52,10 @@ for n in [int(x) for x in os.environ.get('LONG_NS', '1,8,64,1024,16384').split('
     idx = torch.empty(n, dtype=torch.int32, device="cuda")
     fin = torch.empty(n, dtype=torch.uint8, device="cuda")
     run = lambda: t.run_strided_device(buf.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
-    os.environ["PIRE_HIP_SEGMENT_STATS"] = "1"
+    pb.set_config(segment_stats=1)
     run()
     torch.cuda.synchronize()
-    del os.environ["PIRE_HIP_SEGMENT_STATS"]
+    pb.set_config(segment_stats=0)
     ms0 = timeit(run)
     # long strings live in other states than 4 KiB ones (sticky modes): let the dense rows follow
     rows = t.adapt()
@@ -64,10 +64,10 @@ for n in [int(x) for x in os.environ.get('LONG_NS', '1,8,64,1024,16384').split('
     rows += t.adapt()
     ms = timeit(run)
     kernel = pb.last_kernel()
-    os.environ["PIRE_HIP_SEGMENT_STATS"] = "1"
+    pb.set_config(segment_stats=1)
     run()
     torch.cuda.synchronize()
-    del os.environ["PIRE_HIP_SEGMENT_STATS"]
+    pb.set_config(segment_stats=0)
     # parity: the oracle on the host over the same bytes (first strings only when there are many)
     k = min(n, 4)
     host = buf[:k * length].cpu().numpy()
@@ -76,8 +76,8 @@ for n in [int(x) for x in os.environ.get('LONG_NS', '1,8,64,1024,16384').split('
     line = "%6d x %10d B: %-9s %8.3f ms -> %7.1f GB/s (%.3f ms before adapt(), %d rows changed); parity(first %d) %s" % (
         n, length, kernel, ms, total / ms / 1e6, ms0, rows, k, ok)
     if length <= (1 << 20):
-        os.environ["PIRE_HIP_NO_SEGMENTS"] = "1"
+        pb.set_config(no_segments=1)
         ms2 = timeit(run, reps=2)
         line += "   | one string per lane (%s): %9.3f ms -> %7.1f GB/s" % (pb.last_kernel(), ms2, total / ms2 / 1e6)
-        del os.environ["PIRE_HIP_NO_SEGMENTS"]
+        pb.set_config(no_segments=0)
     print(line, flush=True)

@@ -8,6 +8,7 @@ import numpy as np
 
 import pire_amd
 from oracle import binding as ob
+from pire_amd import binding as pb
 from tests import helpers as H
 
 rng = np.random.RandomState(2026)
@@ -26,10 +27,9 @@ for it in range(120):
     name, blob = tables[it % len(tables)]
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
     seg = int(rng.choice([32, 48, 64, 100, 128, 256, 1000, 4096]))
-    os.environ["PIRE_HIP_SEGMENT_BYTES"] = str(seg)
-    os.environ["PIRE_HIP_SEGMENT_WARMUP"] = str(int(rng.choice([0, 4, 16, 64, 256])))
-    os.environ["PIRE_HIP_SEGMENT_MODES"] = str(int(rng.randint(1, 7)))
-    os.environ["PIRE_HIP_SEGMENT_BUDGET"] = str(int(rng.choice([0, 1, 3, 32])))
+    knobs = dict(segment_bytes=seg, segment_warmup=int(rng.choice([0, 4, 16, 64, 256])) or pb.NONE,
+                 segment_modes=int(rng.randint(1, 7)), segment_budget=int(rng.choice([0, 1, 3, 32])) or pb.NONE)
+    pb.set_config(**knobs)
     a = np.frombuffer(b"ab" if name == "parity" else b"abc" if name == "mod3" else ALPHA, dtype=np.uint8)
     strings = [a[rng.randint(0, len(a), size=int(k))].tobytes() for k in rng.randint(0, 6000, size=int(rng.randint(1, 30)))]
     text, offs = H.pack(strings)
@@ -38,11 +38,9 @@ for it in range(120):
     gi, gf, cnt = t.run(text, offs, flags=flags, counts=True)
     runs += 1
     if not ((gi == oi).all() and (gf == of).all() and cnt[0] == int(of.sum()) and cnt[1] == len(strings)):
-        print("SEGMENTED FAIL", name, dict((k, os.environ[k]) for k in os.environ if k.startswith("PIRE_HIP_SEG")), flags)
+        print("SEGMENTED FAIL", name, knobs, flags)
         fails += 1
-for k in list(os.environ):
-    if k.startswith("PIRE_HIP_SEG"):
-        del os.environ[k]
+pb.set_config(segment_bytes=0, segment_warmup=0, segment_modes=0, segment_budget=0)
 print("segmented runs:", runs, "fails:", fails)
 
 # ---- SlowScanner, random patterns
