@@ -193,16 +193,31 @@ def bench_slow(args):
     elapsed = time.perf_counter() - t0
     ms = [a.elapsed_time(b) for a, b in ev]
     value = float(n) * length * args.steps / elapsed / 1e9
+    kernel, symbol = pb.last_kernel(), pb.last_kernel_symbol()
+    # The bound of this scanner is the LDS gather, not HBM (work per byte is proportional to the active
+    # states).  Per input byte a lane does one letter lookup (u8) and, in the list forms, one table lookup per list
+    # slot: 4 slots of 8 bytes (SlowScanKernel, <= 256 states) or up to 16 slots of 4 bytes (SlowListKernel).  The LDS
+    # serves 64 banks x 4 bytes per clock and CU; conflict-free, a wave instruction of 64 lanes costs 64 * width / 256
+    # clocks (2 for a u8 / b32 read -- two half-waves --, 4 for a b64 read).  Roofline = bytes/s the chip could scan if
+    # every lookup were conflict-free and nothing else took time, at the 2.4 GHz peak clock, 256 CUs.
+    clocks_per_wave_byte = {"slow": 2 + 4 * 4, "slow_list": 2 + 16 * 2}.get(kernel)
+    if clocks_per_wave_byte:
+        peak = 256 * 2.4e9 / clocks_per_wave_byte * 64 / 1e9
+        bound, model = "lds", (f"{clocks_per_wave_byte} conflict-free LDS clocks per 64 input bytes of a wave "
+                               f"(1 letter lookup + {'4 slots x b64' if kernel == 'slow' else '16 slots x b32'}), 256 CUs x 2.4 GHz")
+    else:   # wave-per-string form: latency bound per step (fences + atomics), no closed-form throughput bound
+        peak, bound, model = None, "latency", "one wave per string: ~1 us per byte and wave (set clear, scatter, fence)"
+    achieved = n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9
     res = {"metric": "scanned GB/s, SlowScanner (config 5b)", "value": round(value, 2), "unit": "GB/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
            "config": {"workload": f"C5b: SlowScanner {case['pattern']!r} ({case['options'] or 'latin1'}), "
                                   f"{case['geometry']['states']} NFA states, {n} x {length} B strings",
                       "strings_per_gpu": n, "string_bytes": length},
-           "roofline": {"bound": "hbm", "achieved": round(n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "pirehip::SlowScanKernel", "kernel_avg_ms": round(float(np.mean(ms)), 4)},
+           "roofline": {"bound": bound, "achieved": round(achieved, 1), "peak": round(peak, 1) if peak else None,
+                        "unit": "GB/s", "frac": round(achieved / peak, 4) if peak else None, "model": model,
+                        "traffic": None, "hbm_frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "kernel": symbol, "kernel_avg_ms": round(float(np.mean(ms)), 4)},
            "match_counts": {"final": int(cnt[0].item()), "strings": int(cnt[1].item())}}
     if not args.no_cpu:
         from oracle import binding as ob   # the cpu_baseline leg: the checker, never the thing measured

@@ -92,7 +92,7 @@ typedef struct pire_hip_config {
 	uint32_t no_rccl;              /* 1: sum the per-device counters on the host                                        */
 	/* SlowScanner */
 	uint32_t slow_sets_in_memory;  /* 1: the wave-per-string form keeps its state sets in device memory                 */
-	uint32_t slow_no_list;         /* 1: automata of more than 256 states always take the wave-per-string form          */
+	uint32_t slow_no_list;         /* 1: never the 16-slot list kernel: bitset kernel (<= 256 states) / wave per string   */
 	/* adaptation of the dense-row ranking */
 	uint32_t auto_adapt;           /* 0 default (on), 1 off, 2 on: re-rank by itself when scans keep leaving the dense   */
 	                               /* rows, see pire_hip_table_adapt()                                                  */

@@ -38,6 +38,9 @@ struct SlowHost {
 	std::vector<uint32_t> jumpPos;     // [states*letters + 1]
 	std::vector<uint32_t> jumps;       // targets
 	bool wide = false;                 // more than 256 states: masks / single are not built
+	// wide automata of fewer than 2^15 (state, letter) rows: the list form's table, [(states + 1) * letters] words
+	// (first / second target as row offsets, layout at SlowListKernel); empty otherwise
+	std::vector<uint32_t> pair16;
 };
 
 struct SlowDevice {
@@ -48,6 +51,7 @@ struct SlowDevice {
 	uint32_t* finals = nullptr;
 	uint32_t* jumpPos = nullptr;
 	uint32_t* jumps = nullptr;
+	uint32_t* pair16 = nullptr;
 };
 
 constexpr uint32_t kSlowNone = 0xFFFFFFFFu;    // no target / empty list slot
@@ -70,6 +74,8 @@ struct SlowParams {
 	const uint32_t* finals;
 	const uint32_t* jumpPos;   // wide form
 	const uint32_t* jumps;
+	const uint32_t* pair16;    // wide form, list kernel
+	uint32_t* overflow;        // list kernel -> wide kernel: [0] = count, [1 ..] = the strings whose sets outgrew the list
 	uint32_t* scratch;         // wide form, sets that do not fit the LDS: [waves][2][words]
 	uint32_t states, letters, start, words, flags, masksInLds, singleInLds;
 	const uint8_t* text;
@@ -256,7 +262,10 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 
 	const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
 	unsigned long long finals = 0, strings = 0;
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += stride) {
+	// with an overflow list (the list kernel ran first on this stream): only the strings it names
+	const uint64_t todo = p.overflow ? p.overflow[0] : p.n;
+	for (uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < todo; k += stride) {
+		const uint64_t s = p.overflow ? p.overflow[1 + k] : k;
 		uint64_t b, e;
 		if (p.offsets) {
 			b = p.offsets[s];
@@ -305,6 +314,170 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 	}
 	if (p.outCounts) {
 		// wave reduce, one atomic pair per wave
+		for (int off = 32; off > 0; off >>= 1) {
+			finals += __shfl_down(finals, off);
+			strings += __shfl_down(strings, off);
+		}
+		if ((threadIdx.x & 63) == 0 && strings) {
+			atomicAdd(&p.outCounts[0], finals);
+			atomicAdd(&p.outCounts[1], strings);
+		}
+	}
+}
+
+// ---- more than 256 NFA states, list form (round 3) ----------------------------------------------------------------------
+// The automata this scanner exists for -- easy.h:155-161 falls back to it when determinisation explodes, the textbook
+// case being x.{300}$ -- have hundreds or thousands of states of which a handful is active: one thread per 'x' seen in
+// the last 300 bytes, 1 + 300/95 = 4.2 on printable text, and nearly every (state, letter) has ONE target.  So the set
+// stays what SlowLane keeps it as, a list of states that move to their first target IN PLACE, only longer: 16 slots in
+// registers.  Rows: row 0 is the EMPTY row (every letter leads back to it), state s has row s + 1; a row is `letters`
+// words, and the word of (row, letter) is
+//     bits  0..15  BYTE offset of the first target's row (0 = the empty row: the jump list is empty, the thread dies)
+//     bits 16..30  index (row * letters) of the second target's row
+//     bit  31      there is a second target   (second == kListMulti: there are three or more)
+// A slot simply holds the word of its last lookup: its low half is where the state's row starts (no multiply, no mask:
+// the address is one add with a 16-bit operand select), an empty slot is the word 0, and "four slots all empty" is one
+// OR.  Step (branch free but for wave-uniform tests): up to 16 independent lookups; the OR of the 16 words says whether
+// the lane spawned a thread; a spawned thread enters at slot 0 and everything else moves up one slot (16 selects, every
+// step, whether or not anyone spawned -- cheaper than looking for a free slot only when someone did, which on text
+// with one trigger letter in 95 is every other step of a wave).  When a state with a self loop spawns (the unanchored
+// start state meeting the pattern's first letter) the table makes the SELF LOOP the spawned one: the persistent state
+// stays at slot 0, the new thread takes over its old slot and drifts upwards as it ages, so threads of x.{n}, which die
+// in the order they were born, die at the top and the list stays packed; groups of four slots that are empty in every
+// lane of the wave are skipped.
+// What the list cannot hold marks the STRING as overflowed -- two spawns in one step, a row with three targets, a live
+// state pushed out of slot 15 -- and the string is walked again from its start by the wave-per-string kernel below,
+// which knows no limits (SlowParams::overflow carries the list from one launch to the next on the stream).  A list may
+// name a state twice (two threads that merged): that wastes a slot and changes nothing, as in SlowLane.
+constexpr int kListSlots = 16;
+constexpr uint32_t kListMulti = 0x7FFFu;
+constexpr uint32_t kListMaxRows = 16383;   // (states + 1) * letters: 16-bit byte offsets of 4-byte words
+
+typedef const __attribute__((address_space(3))) uint32_t* LdsWordPtr;
+
+__device__ __forceinline__ void ListStep(uint32_t tabBase, uint32_t letter4, uint32_t (&lst)[kListSlots], bool& ovf)
+{
+	uint32_t r[kListSlots];
+	uint32_t orAll = 0;
+#pragma unroll
+	for (int g = 0; g < kListSlots / 4; ++g) {
+		const uint32_t any4 = lst[4 * g] | lst[4 * g + 1] | lst[4 * g + 2] | lst[4 * g + 3];
+		if (g > 0 && !__any(any4 != 0)) {
+#pragma unroll
+			for (int i = 4 * g; i < 4 * g + 4; ++i)
+				r[i] = 0;        // the empty row leads to itself, nothing spawns
+			continue;
+		}
+#pragma unroll
+		for (int i = 4 * g; i < 4 * g + 4; ++i) {
+			r[i] = *reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>((lst[i] & 0xFFFFu) + letter4 + tabBase));
+			orAll |= r[i];
+		}
+	}
+	const bool spawn = int32_t(orAll) < 0;
+	const uint32_t extra = (orAll >> 16) & 0x7FFFu;   // the spawned thread's row -- if exactly one slot spawned
+	if (__any(spawn)) {
+		// somebody did: count exactly (two in one step do not fit this scheme: the OR mixes their rows)
+		uint32_t cnt = 0;
+#pragma unroll
+		for (int i = 0; i < kListSlots; ++i)
+			cnt += r[i] >> 31;
+		const bool over = cnt > 1 || (spawn && extra == kListMulti) || (spawn && (r[kListSlots - 1] & 0xFFFFu) != 0);
+		if (__any(over)) {   // rare: the string goes quiet (every slot empty from now on, so nothing spawns either)
+			ovf = ovf || over;
+#pragma unroll
+			for (int i = 0; i < kListSlots; ++i)
+				r[i] = over ? 0u : r[i];
+		}
+	}
+	const bool shift = spawn && !ovf;
+#pragma unroll
+	for (int i = kListSlots - 1; i > 0; --i)
+		lst[i] = shift ? r[i - 1] : r[i];
+	lst[0] = shift ? extra << 2 : r[0];
+}
+
+__global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint8_t* ldsLetter = lds;                                        // 264 bytes: 4 * letter of every Char
+	uint32_t* tab = reinterpret_cast<uint32_t*>(lds + 1056 + 16);
+	const uint32_t tabBase = 1056 + 16;                              // LDS byte address of the table (dynamic LDS starts at 0)
+	uint32_t* ldsLetter4 = reinterpret_cast<uint32_t*>(lds);         // [264] u32: 4 * letter, indexed by Char
+	const uint32_t entries = (p.states + 1) * p.letters;
+	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x)
+		ldsLetter4[i] = 4u * p.letterOf[i];
+	for (uint32_t i = threadIdx.x; i < entries; i += blockDim.x)
+		tab[i] = p.pair16[i];
+	__syncthreads();
+	(void)ldsLetter;
+	const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
+	unsigned long long finals = 0, strings = 0;
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += stride) {
+		uint64_t b, e;
+		if (p.offsets) {
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		} else {
+			b = s * p.stride;
+			e = b + p.len;
+		}
+		uint32_t lst[kListSlots];
+		lst[0] = (p.start + 1) * p.letters * 4;                          // Initialize, slow.h:89-95
+#pragma unroll
+		for (int i = 1; i < kListSlots; ++i)
+			lst[i] = 0;
+		bool ovf = false;
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			ListStep(tabBase, ldsLetter4[kBeginMark], lst, ovf);          // Begin(), run.h:375
+		const uint8_t* ptr = p.text + b;
+		const uint8_t* end = p.text + e;
+		for (; ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15); ++ptr)
+			ListStep(tabBase, ldsLetter4[*ptr], lst, ovf);
+		for (; ptr + 16 <= end; ptr += 16) {
+			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+#pragma unroll 1
+			for (int i = 0; i < 16; ++i) {
+				ListStep(tabBase, ldsLetter4[v.x & 0xFF], lst, ovf);
+				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+				v.w >>= 8;
+			}
+		}
+		for (; ptr < end; ++ptr)
+			ListStep(tabBase, ldsLetter4[*ptr], lst, ovf);
+		if (p.flags & PIRE_HIP_RUN_END)
+			ListStep(tabBase, ldsLetter4[kEndMark], lst, ovf);            // End(), run.h:376
+		if (ovf) {
+			// the wave-per-string kernel that follows on the stream walks this string from its start
+			const uint32_t k = atomicAdd(&p.overflow[0], 1u);
+			p.overflow[1 + k] = uint32_t(s);
+			continue;
+		}
+		bool fin = false;                                                // Final, slow.h:152-158
+#pragma unroll
+		for (int i = 0; i < kListSlots; ++i) {
+			const uint32_t row = (lst[i] & 0xFFFFu) >> 2;                 // rows back to state ids, once per string
+			lst[i] = row ? row / p.letters - 1 : p.states;
+			fin = fin || (lst[i] != p.states && ((p.finals[lst[i] >> 5] >> (lst[i] & 31)) & 1u));
+		}
+		if (p.outFinal)
+			p.outFinal[s] = fin ? 1 : 0;
+		if (p.outBits) {
+			uint32_t* row = p.outBits + s * p.words;
+			for (uint32_t w = 0; w < p.words; ++w) {
+				uint32_t v = 0;
+#pragma unroll
+				for (int i = 0; i < kListSlots; ++i)
+					v |= (lst[i] != p.states && (lst[i] >> 5) == w) ? 1u << (lst[i] & 31) : 0u;
+				row[w] = v;
+			}
+		}
+		finals += fin ? 1 : 0;
+		strings += 1;
+	}
+	if (p.outCounts) {
 		for (int off = 32; off > 0; off >>= 1) {
 			finals += __shfl_down(finals, off);
 			strings += __shfl_down(strings, off);
@@ -418,7 +591,10 @@ __global__ __launch_bounds__(1024) void SlowWideKernel(SlowParams p, uint32_t wa
 	uint32_t* setA = SETS_LDS ? ldsSets + size_t(wave) * 2 * p.words : p.scratch + gwave * 2 * p.words;
 	uint32_t* setB = setA + p.words;
 	unsigned long long finals = 0, strings = 0;
-	for (uint64_t s = gwave; s < p.n; s += uint64_t(gridDim.x) * wavesPerBlock) {
+	// with an overflow list (the list kernel ran first on this stream): only the strings it names
+	const uint64_t todo = p.overflow ? p.overflow[0] : p.n;
+	for (uint64_t k = gwave; k < todo; k += uint64_t(gridDim.x) * wavesPerBlock) {
+		const uint64_t s = p.overflow ? p.overflow[1 + k] : k;
 		uint64_t b, e;
 		if (p.offsets) {
 			b = p.offsets[s];
@@ -552,6 +728,37 @@ int BuildSlowHost(const void* blob, size_t len, SlowHost* out)
 		if (tgt >= states)
 			return BadSlow("Corrupt SlowScanner: jump target out of range");
 	}
+	// the list form's table (SlowListKernel; layout there): row 0 = the empty row, state s = row s + 1
+	if ((size_t(states) + 1) * letters <= kListMaxRows) {
+		h.pair16.assign((size_t(states) + 1) * letters, 0);   // "no target": the thread dies (slot -> empty row)
+		for (size_t i = 0; i + 1 < npos; ++i) {
+			const uint32_t self = uint32_t(i / letters);
+			uint32_t t0 = kSlowNone, t1 = kSlowNone;
+			bool multi = false;
+			for (uint64_t k = jumpPos[i]; k < jumpPos[i + 1]; ++k) {
+				uint32_t tgt;
+				memcpy(&tgt, p + pos + size_t(k) * 4, 4);
+				if (t0 == kSlowNone)
+					t0 = tgt;
+				else if (tgt == t0)
+					continue;
+				else if (t1 == kSlowNone)
+					t1 = tgt;
+				else if (tgt != t1)
+					multi = true;
+			}
+			if (t1 != kSlowNone && t0 == self)
+				std::swap(t0, t1);   // a self loop is the SPAWNED one: the persistent state re-enters at slot 0
+			const auto rowIndex = [&](uint32_t t) { return uint32_t((size_t(t) + 1) * letters); };
+			uint32_t& w = h.pair16[letters + i];
+			if (multi)
+				w = (1u << 31) | (kListMulti << 16);
+			else if (t1 != kSlowNone)
+				w = (1u << 31) | (rowIndex(t1) << 16) | (rowIndex(t0) * 4);
+			else if (t0 != kSlowNone)
+				w = rowIndex(t0) * 4;
+		}
+	}
 	h.wide = h.words > 8;
 	if (h.wide) {
 		// more than 256 states: the sparse form as it is (a dense (state, letter) -> set matrix would be quadratic)
@@ -621,6 +828,7 @@ void FreeSlowDevice(SlowDevice* d)
 	if (d->finals) (void)hipFree(d->finals);
 	if (d->jumpPos) (void)hipFree(d->jumpPos);
 	if (d->jumps) (void)hipFree(d->jumps);
+	if (d->pair16) (void)hipFree(d->pair16);
 	*d = SlowDevice();
 }
 
@@ -651,7 +859,8 @@ int UploadSlow(pire_hip_slow_table* t, SlowDevice* image)
 		SlowDevice d;
 		int rc;
 		if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.finals, h.finals)) ||
-		    (rc = PutSlow(&d.jumpPos, h.jumpPos)) || (rc = PutSlow(&d.jumps, h.jumps))) {
+		    (rc = PutSlow(&d.jumpPos, h.jumpPos)) || (rc = PutSlow(&d.jumps, h.jumps)) ||
+		    (!h.pair16.empty() && (rc = PutSlow(&d.pair16, h.pair16)))) {
 			d.device = dev;
 			FreeSlowDevice(&d);
 			return rc;
@@ -671,7 +880,7 @@ int UploadSlow(pire_hip_slow_table* t, SlowDevice* image)
 	SlowDevice d;
 	int rc;
 	if ((rc = PutSlow(&d.letterOf, h.letterOf)) || (rc = PutSlow(&d.masks, masks)) || (rc = PutSlow(&d.single, h.single)) ||
-	    (rc = PutSlow(&d.finals, finals))) {
+	    (rc = PutSlow(&d.finals, finals)) || (!h.pair16.empty() && (rc = PutSlow(&d.pair16, h.pair16)))) {
 		d.device = dev;
 		FreeSlowDevice(&d);
 		return rc;
@@ -761,6 +970,52 @@ int LaunchSlowWide(const SlowParams& p0, uint32_t njumps, hipStream_t stream)
 	return PIRE_HIP_OK;
 }
 
+// List form first: SlowListKernel over the whole batch, then `fallback` -- the bitset kernel (<= 256 states) or the
+// wave-per-string kernel (more) -- over the strings whose sets outgrew the list (usually none; the count stays on the
+// device, an empty second launch costs a few microseconds).  The overflow list lives in stream-ordered scratch.
+template <class Fallback>
+int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallback)
+{
+	SlowParams p = p0;
+	int dev = 0, cus = 0;
+	hipError_t e;
+	if ((e = hipGetDevice(&dev)) != hipSuccess ||
+	    (e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess)
+		return HipFail(e, "device query");
+	void* list = nullptr;
+	e = hipMallocAsync(&list, (size_t(p.n) + 1) * 4, stream);
+	if (e == hipSuccess)
+		e = hipMemsetAsync(list, 0, 4, stream);
+	if (e != hipSuccess) {
+		if (list)
+			(void)hipFreeAsync(list, stream);
+		return HipFail(e, "hipMallocAsync(slow scanner overflow list)");
+	}
+	p.overflow = static_cast<uint32_t*>(list);
+	const uint32_t ldsBytes = uint32_t(1056 + 16 + size_t(p.states + 1) * p.letters * 4);
+	e = hipFuncSetAttribute(reinterpret_cast<const void*>(SlowListKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                        int(ldsBytes));
+	int rc = PIRE_HIP_OK;
+	if (e != hipSuccess) {
+		rc = HipFail(e, "hipFuncSetAttribute(LDS)");
+	} else {
+		// one string per lane and ~100 VALU instructions per byte: spread the waves over every SIMD of the chip before
+		// stacking them (65 536 strings are 1 024 waves = one per SIMD: 256-thread blocks, one per CU)
+		const unsigned threads = p.n >= uint64_t(cus) * 2048 ? 1024 : p.n >= uint64_t(cus) * 512 ? 512 : 256;
+		const uint64_t perCu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / threads, (160 * 1024) / ldsBytes));
+		const uint64_t want = (p.n + threads - 1) / threads;
+		const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(want, uint64_t(cus) * perCu)));
+		hipLaunchKernelGGL(SlowListKernel, dim3(blocks), dim3(threads), ldsBytes, stream, p);
+		e = hipGetLastError();
+		if (e != hipSuccess)
+			rc = HipFail(e, "slow kernel launch");
+	}
+	if (rc == PIRE_HIP_OK)
+		rc = fallback(p);   // p.overflow set: only the strings on the list
+	(void)hipFreeAsync(list, stream);
+	return rc;
+}
+
 int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint64_t len, uint64_t stride,
             uint32_t flags, uint8_t* outFinal, uint32_t* outBits, uint64_t* outCounts, void* streamPtr)
 {
@@ -781,6 +1036,7 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 	p.finals = image.finals;
 	p.jumpPos = image.jumpPos;
 	p.jumps = image.jumps;
+	p.pair16 = image.pair16;
 	p.states = h.states;
 	p.letters = h.letters;
 	p.start = h.start;
@@ -792,7 +1048,8 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 	if (n == 0)
 		return PIRE_HIP_OK;
 	const int K = DeviceK(h.words);
-	auto launch = [&](const SlowParams& q) {
+	const bool listFirst = image.pair16 && n < (1ull << 32) - 1 && !GetConfig().slow_no_list;
+	auto plain = [&](const SlowParams& q) {
 		if (h.wide)
 			return LaunchSlowWide(q, uint32_t(h.jumps.size()), stream);
 		switch (K) {
@@ -801,6 +1058,18 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 		case 4: return LaunchSlowK<4>(q, stream);
 		default: return LaunchSlowK<8>(q, stream);
 		}
+	};
+	auto launch = [&](const SlowParams& q) {
+		if (listFirst) {
+			NoteKernel("slow_list", "pirehip::SlowListKernel");
+			return LaunchSlowListThen(q, stream, plain);
+		}
+		if (h.wide)
+			NoteKernel("slow_wide", "pirehip::SlowWideKernel");
+		else
+			NoteKernel("slow", K == 1 ? "pirehip::SlowScanKernel<1>" : K == 2 ? "pirehip::SlowScanKernel<2>" :
+			                    K == 4 ? "pirehip::SlowScanKernel<4>" : "pirehip::SlowScanKernel<8>");
+		return plain(q);
 	};
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);

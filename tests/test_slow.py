@@ -115,21 +115,28 @@ def test_slow_gpu_strided_device_batch():
     ("^a.{5}b", "", b"ab"),
     ("hello.{20}world", "", b"helowrd abcxyz0123456789"),   # sparse: the list form nearly all the time
 ])
-def test_slow_gpu_list_and_bitset_forms_agree_with_the_oracle(pat, opt, alphabet):
-    """The kernel keeps a lane's active set as a short list while it fits and as a bitset otherwise; dense and sparse
-    triggers push lanes through both forms and back.  Final and the full state set must be the oracle's."""
+def test_slow_gpu_list_and_bitset_forms_agree_with_the_oracle(pat, opt, alphabet, cfg):
+    """A lane's active set is a list of states while it fits -- 16 slots in the list kernel that every batch takes
+    first (round 3), 4 slots in the bitset kernel that takes the strings the list kernel gave up on (and every string
+    with pire_hip_config.slow_no_list) -- and a bitset otherwise; dense and sparse triggers push strings and lanes
+    through all forms.  Final and the full state set must be the oracle's, either way."""
     import pire_amd
+    from pire_amd import binding as pb
 
     r = ob.RefSlowScanner.compile(pat, opt)
     blob = r.save()
     t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
     rng = np.random.RandomState(31)
     strings = H.random_strings(rng, 3000, 200, alphabet) + [b"", b"a", alphabet * 40]
-    for flags in (BE, 0, ob.FLAG_BEGIN, ob.FLAG_END):
-        of, obits = o.run_strings(strings, flags=flags)
-        gf, gb = t.run_strings(strings, flags=flags)
-        assert (gf == of).all(), (pat, flags)
-        assert (gb == obits).all(), (pat, flags)
+    for no_list in (0, 1):
+        cfg.set(slow_no_list=no_list)
+        for flags in (BE, 0, ob.FLAG_BEGIN, ob.FLAG_END):
+            of, obits = o.run_strings(strings, flags=flags)
+            gf, gb, cnt = t.run_strings(strings, flags=flags, counts=True)
+            assert pb.last_kernel() == ("slow" if no_list else "slow_list")
+            assert (gf == of).all(), (pat, flags, no_list)
+            assert (gb == obits).all(), (pat, flags, no_list)
+            assert cnt.tolist() == [int(of.sum()), len(strings)]
 
 
 # ---- more than 256 NFA states: the wave-per-string form (slow.hip SlowWideKernel) ------------------------------------
@@ -174,14 +181,21 @@ def test_slow_wide_table_ingest_without_gpu(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("no_list", [0, 1], ids=["list_first", "wave_per_string"])
 @pytest.mark.parametrize("case", WIDE, ids=lambda c: c["name"])
-def test_slow_wide_gpu_matches_golden_and_oracle(case):
+def test_slow_wide_gpu_matches_golden_and_oracle(case, no_list, cfg):
+    """Both forms for automata of more than 256 states: the list kernel with the wave-per-string kernel behind it for
+    the strings whose sets outgrow 16 slots (the default), and the wave-per-string kernel alone
+    (pire_hip_config.slow_no_list)."""
     import pire_amd
+    from pire_amd import binding as pb
 
+    cfg.set(slow_no_list=no_list)
     blob = H.load_blob(case["blob"])
     t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
     strings = [bytes.fromhex(h) for h in case["strings_hex"]]
     fin, bits, cnt = t.run_strings(strings, counts=True)
+    assert pb.last_kernel() == ("slow_wide" if no_list else "slow_list")
     assert fin.tolist() == case["final"]
     assert [hashlib.sha256(bytes(np.ascontiguousarray(b))).hexdigest() for b in bits] == case["bits_sha256"]
     assert cnt.tolist() == [sum(case["final"]), len(strings)]
@@ -191,6 +205,33 @@ def test_slow_wide_gpu_matches_golden_and_oracle(case):
         of, obits = o.run_strings(more, flags=flags)
         gf, gbits = t.run_strings(more, flags=flags)
         assert (gf == of).all() and (gbits == obits).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", WIDE, ids=lambda c: c["name"])
+def test_slow_list_kernel_hands_crowded_strings_to_the_wide_kernel(case):
+    """The list kernel keeps a lane's set in 16 slots.  Text with one trigger letter in every few bytes has dozens of
+    threads alive (x.{300}: one per 'x' of the last 300 bytes), text with one in a hundred a handful: a batch of
+    both -- sparse strings stay in the list form, crowded ones are walked by the wave-per-string kernel from their
+    start -- must come out as the oracle says, string by string, counters included, with offsets that are not
+    multiples of 16."""
+    import pire_amd
+
+    blob = H.load_blob(case["blob"])
+    t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
+    rng = np.random.RandomState(23)
+    sparse = np.frombuffer(b"x" + b"abcdefghijklmnopqrstuvwyz ABCDEFGHIJKLMNOPQRSTUVWYZ0123456789.,;:-_" * 2, dtype=np.uint8)
+    crowded = np.frombuffer(b"xxxyab(cd)ef", dtype=np.uint8)
+    strings = []
+    for i in range(700):
+        alpha = crowded if i % 5 == 0 else sparse
+        strings.append(bytes(alpha[rng.randint(0, len(alpha), size=int(rng.randint(0, 1400)))]))
+    strings += [b"", b"x", b"x" * 700, b"zx" + b"y" * 299, b"zx" + b"y" * 300, b"zx" + b"y" * 301]
+    of, obits = o.run_strings(strings)
+    gf, gbits, cnt = t.run_strings(strings, counts=True)
+    assert (gf == of).all()
+    assert (gbits == obits).all()
+    assert cnt.tolist() == [int(of.sum()), len(strings)]
 
 
 @pytest.mark.gpu
