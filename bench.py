@@ -316,11 +316,12 @@ def main():
     counts_all = torch.zeros((total_steps, table.RegexpsCount + 2), dtype=torch.int64, device=dev)
     step_no = [0]
     pending = []   # outstanding all-reduces, oldest first
+    per_rank = []  # wall seconds of the timed leg, per rank
 
     def step(tbl, ev=None):
         counts = counts_all[step_no[0]]
         step_no[0] += 1
-        while len(pending) > 1:
+        while len(pending) > 2:
             pending.pop(0).wait()   # stream-level wait for the reduction issued two steps ago: long finished
         if ev:
             ev[0].record()
@@ -350,7 +351,9 @@ def main():
         for k in range(steps):
             step(tbl, events[k])
         fence()
-        elapsed = pd.max_over_ranks(time.perf_counter() - t0, dev)
+        mine = time.perf_counter() - t0
+        per_rank[:] = pd.gather_over_ranks(mine, dev)      # this leg's wall time of every rank (the last leg's is reported)
+        elapsed = pd.max_over_ranks(mine, dev)
         return elapsed, [a.elapsed_time(b) for a, b in events]
 
     # --- 1. the dense-row ranking is learned on a HELD-OUT corpus: same generator, another seed, a quarter of the size.
@@ -456,6 +459,8 @@ def main():
                           "ranking_learned_on": heldout},
                 "strings_per_gpu": run_n, "string_bytes": run_len, "string_stride": run_stride, "corpus_seed": SEED,
                 "parallelism": f"shard-by-string x{world}",
+                "reduce_backend": pd.backend_description(),
+                "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank],
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -415,6 +415,34 @@ int pire_hip_multi_run_strided_host(pire_hip_multi* m, pire_hip_table* t, const 
                                     uint64_t stride, uint32_t flags, const uint32_t* init_state_idx,
                                     uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts);
 
+/* One shard of an OFFSET batch (what the reference's callers have: ragged lines, samples/pigrep/pigrep.cpp:38-45):
+ * text and n + 1 byte offsets resident on ITS device, string i = text[offsets[i], offsets[i+1]). */
+typedef struct pire_hip_shard_offsets {
+	const void*     text;
+	const uint64_t* offsets;
+	uint64_t        n;
+	const uint32_t* init_state_idx;   /* nullable */
+	uint32_t*       out_state_idx;    /* nullable */
+	uint8_t*        out_final;        /* nullable */
+} pire_hip_shard_offsets;
+
+/* pire_hip_multi_run_strided for offset batches: shards[g] lives on device g of the runner, all devices scan
+ * concurrently (pire_hip_run on the runner's stream of each device), the counters are reduced as above. */
+int pire_hip_multi_run(pire_hip_multi* m, pire_hip_table* t, const pire_hip_shard_offsets* shards, uint32_t flags,
+                       uint64_t* out_counts);
+
+/* Host-resident offset batch: cut into one contiguous run of whole strings per device, balanced by BYTES (a shard
+ * boundary is the string boundary nearest to g / G of the text: ragged strings make string counts a poor measure of
+ * work), staged through per-device buffers the runner keeps between calls (no allocation per call once they have
+ * grown), scanned concurrently, results written back in string order.  offsets[0] need not be 0. */
+int pire_hip_multi_run_host(pire_hip_multi* m, pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n,
+                            uint32_t flags, const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final,
+                            uint64_t* out_counts);
+
+/* First string of every shard the last pire_hip_multi_run_host / _run_strided_host call made: out[0 .. devices], the
+ * last entry = n.  Diagnostics (tests, the per-device rates of a benchmark). */
+int pire_hip_multi_last_split(const pire_hip_multi* m, uint64_t* out, int capacity);
+
 /* ---- memory helpers ------------------------------------------------------------------------------- */
 /*
  * Thin wrappers over the HIP runtime so that a caller of this ABI (and the header-only C++ shim) need not link HIP

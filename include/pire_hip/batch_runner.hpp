@@ -422,6 +422,90 @@ std::vector<const char*> BatchShortestSuffix(const Table<Scanner>& t, const char
 }
 
 /*
+ * BatchRunner over every GPU of the node: the batch is cut into one run of whole strings per device,
+ * balanced by bytes, staged through buffers the runner keeps between calls, scanned on all devices at once; the match
+ * counters are summed with one all-reduce over RCCL (or on the host, Backend() says which).  Same fluent surface:
+ *     MultiBatchRunner<Pire::Scanner> gpus(sc);          // all devices; or (sc, {0, 1, 2, 3})
+ *     gpus.Begin().Run(lines).End().States()
+ */
+template <class Scanner>
+class MultiBatchRunner {
+public:
+	typedef typename Scanner::State State;
+
+	explicit MultiBatchRunner(const Scanner& sc, const std::vector<int>& devices = std::vector<int>())
+	    : m_table(sc), m_multi(nullptr), m_flags(0), m_text(nullptr), m_offsets(nullptr), m_n(0), m_ran(false)
+	{
+		Check(pire_hip_multi_create(devices.empty() ? nullptr : devices.data(), int(devices.size()), &m_multi));
+	}
+	~MultiBatchRunner() { pire_hip_multi_destroy(m_multi); }
+
+	MultiBatchRunner& Begin() { m_flags |= PIRE_HIP_RUN_BEGIN; return *this; }
+	MultiBatchRunner& End() { m_flags |= PIRE_HIP_RUN_END; return *this; }
+	MultiBatchRunner& Run(const char* text, const uint64_t* offsets, size_t n)
+	{
+		m_text = text;
+		m_offsets = offsets;
+		m_n = n;
+		m_ran = false;
+		return *this;
+	}
+	MultiBatchRunner& Run(const std::vector<ystring>& strings)
+	{
+		m_ownText.clear();
+		m_ownOffsets.assign(1, 0);
+		for (size_t i = 0; i < strings.size(); ++i) {
+			m_ownText.append(strings[i]);
+			m_ownOffsets.push_back(m_ownText.size());
+		}
+		return Run(m_ownText.data(), m_ownOffsets.data(), strings.size());
+	}
+	const std::vector<State>& States() { Execute(); return m_states; }
+	const std::vector<char>& Finals() { Execute(); return m_final; }
+	const std::vector<uint64_t>& MatchCounts() { Execute(); return m_counts; }
+	int Devices() const { return pire_hip_multi_device_count(m_multi); }
+	const char* Backend() const { return pire_hip_multi_reduce_backend(m_multi); }
+	Table<Scanner>& GetTable() { return m_table; }
+
+private:
+	MultiBatchRunner(const MultiBatchRunner&);
+	MultiBatchRunner& operator=(const MultiBatchRunner&);
+	void Execute()
+	{
+		if (m_ran)
+			return;
+		pire_hip_table_info info;
+		Check(pire_hip_table_get_info(m_table.Handle(), &info));
+		std::vector<uint32_t> idx(m_n);
+		std::vector<uint8_t> fin(m_n);
+		m_counts.assign(info.regexps + 2, 0);
+		static const uint64_t none[1] = {0};
+		Check(pire_hip_multi_run_host(m_multi, m_table.Handle(), m_text, m_n ? m_offsets : none, m_n, m_flags, nullptr,
+		                              idx.data(), fin.data(), m_counts.data()));
+		m_states.resize(m_n);
+		m_final.resize(m_n);
+		for (size_t i = 0; i < m_n; ++i) {
+			m_states[i] = m_table.ToState(idx[i]);
+			m_final[i] = char(fin[i]);
+		}
+		m_ran = true;
+	}
+
+	Table<Scanner> m_table;
+	pire_hip_multi* m_multi;
+	uint32_t m_flags;
+	const char* m_text;
+	const uint64_t* m_offsets;
+	size_t m_n;
+	bool m_ran;
+	std::string m_ownText;
+	std::vector<uint64_t> m_ownOffsets;
+	std::vector<State> m_states;
+	std::vector<char> m_final;
+	std::vector<uint64_t> m_counts;
+};
+
+/*
  * Batched twin of Pire::ScannerPair<Scanner1, Scanner2> (scanners/pair.h:33-94) and of
  * Pire::Run(scanner1, scanner2, state1, state2, begin, end) (run.h:229-241): both scanners over the same strings, State =
  * pair of the two states (pair.h:35), Final = either (pair.h:69-72).  Host pointers: two passes (the walks are

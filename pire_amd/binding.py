@@ -159,6 +159,10 @@ ABI = [
     ("pire_hip_multi_device_count", C.c_int, [C.c_void_p]),
     ("pire_hip_multi_reduce_backend", C.c_char_p, [C.c_void_p]),
     ("pire_hip_multi_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("pire_hip_multi_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    ("pire_hip_multi_run_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_multi_last_split", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]),
     ("pire_hip_multi_run_strided_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                                   C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_last_kernel", C.c_char_p, []),
@@ -661,6 +665,12 @@ class Shard(C.Structure):
                 ("init_state_idx", C.c_void_p), ("out_state_idx", C.c_void_p), ("out_final", C.c_void_p)]
 
 
+class ShardOffsets(C.Structure):
+    """pire_hip_shard_offsets: one device's part of an offset batch (device pointers of that device)."""
+    _fields_ = [("text", C.c_void_p), ("offsets", C.c_void_p), ("n", C.c_uint64), ("init_state_idx", C.c_void_p),
+                ("out_state_idx", C.c_void_p), ("out_final", C.c_void_p)]
+
+
 class MultiRunner:
     """pire_hip_multi: one process, several GPUs, strings sharded by index, match counters reduced over RCCL."""
 
@@ -694,6 +704,37 @@ class MultiRunner:
         cnt = np.zeros(table.RegexpsCount + 2, dtype=np.uint64) if counts else None
         _check(lib().pire_hip_multi_run_strided(self._h, table._h, arr, flags, _np_ptr(cnt)))
         return cnt
+
+    def run_offset_shards(self, table: "Table", shards, flags=FLAG_BEGIN | FLAG_END, counts=True):
+        """shards: one (text_ptr, offsets_ptr, n, init_ptr, out_idx_ptr, out_final_ptr) per device (device pointers)."""
+        arr = (ShardOffsets * len(shards))()
+        for i, (text, offs, n, init, oi, of) in enumerate(shards):
+            arr[i] = ShardOffsets(text or None, offs or None, n, init or None, oi or None, of or None)
+        cnt = np.zeros(table.RegexpsCount + 2, dtype=np.uint64) if counts else None
+        _check(lib().pire_hip_multi_run(self._h, table._h, arr, flags, _np_ptr(cnt)))
+        return cnt
+
+    def run_host(self, table: "Table", text, offsets, flags=FLAG_BEGIN | FLAG_END, init_idx=None):
+        """A host batch of ragged strings sharded over the devices by BYTES; (idx, fin, counts) in string order."""
+        text = np.ascontiguousarray(np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray))
+                                    else text, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(offsets) - 1
+        idx = np.empty(n, dtype=np.uint32)
+        fin = np.empty(n, dtype=np.uint8)
+        init = None if init_idx is None else np.ascontiguousarray(init_idx, dtype=np.uint32)
+        cnt = np.zeros(table.RegexpsCount + 2, dtype=np.uint64)
+        _check(lib().pire_hip_multi_run_host(self._h, table._h, text.ctypes.data if text.size else None,
+                                             offsets.ctypes.data, n, flags, _np_ptr(init), idx.ctypes.data,
+                                             fin.ctypes.data, cnt.ctypes.data))
+        return idx, fin, cnt
+
+    def last_split(self):
+        """First string of every shard of the last host-pointer call, then n."""
+        out = (C.c_uint64 * (self.device_count + 1))()
+        k = lib().pire_hip_multi_last_split(self._h, out, self.device_count + 1)
+        _check(min(k, 0))
+        return [int(out[i]) for i in range(k)]
 
     def run_strided_host(self, table: "Table", text2d: np.ndarray, flags=FLAG_BEGIN | FLAG_END, init_idx=None):
         text2d = np.ascontiguousarray(text2d, dtype=np.uint8)

@@ -10,9 +10,11 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
 #include <memory>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "internal.h"
@@ -65,12 +67,22 @@ constexpr uint32_t kMaxCounters = kMaxLdsCountRegexps + 2;
 
 }  // namespace
 
+// Device-side staging of the host-pointer entry points, kept between calls (grown on demand, freed with the runner):
+// round 2 allocated and freed four buffers per device and call.
+struct StagePool {
+	void* buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // text, offsets, init, idx, fin
+	size_t cap[5] = {0, 0, 0, 0, 0};
+};
+enum { kStageText = 0, kStageOffs, kStageInit, kStageIdx, kStageFin };
+
 struct pire_hip_multi {
 	std::vector<int> devices;
 	std::vector<hipStream_t> streams;
 	std::vector<unsigned long long*> counters;   // [kMaxCounters] u64 on each device
 	std::vector<ncclComm_t> comms;               // empty: host reduce
 	std::vector<unsigned long long> hostCounters;
+	std::vector<StagePool> pools;                // one per device slot
+	std::vector<uint64_t> lastSplit;             // first string of every shard of the last host-pointer call, then n
 	std::string backend;
 };
 
@@ -98,6 +110,10 @@ void DestroyMulti(pire_hip_multi* m)
 			(void)hipStreamDestroy(m->streams[g]);
 		if (g < m->counters.size() && m->counters[g])
 			(void)hipFree(m->counters[g]);
+		if (g < m->pools.size())
+			for (void* q : m->pools[g].buf)
+				if (q)
+					(void)hipFree(q);
 	}
 	delete m;
 }
@@ -152,6 +168,80 @@ int ReduceCounters(pire_hip_multi* m, uint32_t count, uint64_t* out)
 	return PIRE_HIP_OK;
 }
 
+
+constexpr size_t kStageSlack = 4096;   // the kernels read whole 16-byte blocks around a string's ends (api.cpp kHostChunkSlack)
+
+// The current device must be device slot g's.  Grows buffer `which` of slot g to at least `bytes`.
+int ReserveStage(pire_hip_multi* m, size_t g, int which, size_t bytes, void** out)
+{
+	StagePool& p = m->pools[g];
+	if (p.cap[which] < bytes) {
+		if (p.buf[which]) {
+			// nothing of an earlier call is still in flight: every entry point drains its streams before it returns
+			(void)hipFree(p.buf[which]);
+			p.buf[which] = nullptr;
+			p.cap[which] = 0;
+		}
+		const size_t want = bytes + bytes / 4 + 4096;
+		hipError_t e = hipMalloc(&p.buf[which], want);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMalloc(multi-GPU staging)");
+		p.cap[which] = want;
+	}
+	*out = p.buf[which];
+	return PIRE_HIP_OK;
+}
+
+// After an error on one device: the devices launched before it keep writing the caller's shard outputs and the
+// runner's counters -- wait for them before the error is returned.
+void DrainAll(pire_hip_multi* m)
+{
+	for (size_t g = 0; g < m->devices.size(); ++g)
+		if (hipSetDevice(m->devices[g]) == hipSuccess)
+			(void)hipStreamSynchronize(m->streams[g]);
+	(void)hipGetLastError();
+}
+
+// Launch one scan per device (launch(g) enqueues device g's shard on m->streams[g]), then reduce the counters or drain.
+template <class Launch>
+int RunOnAllDevices(pire_hip_multi* m, pire_hip_table* t, uint64_t* out_counts, Launch launch)
+{
+	pire_hip_table_info info;
+	if (int rc = pire_hip_table_get_info(t, &info))
+		return rc;
+	const uint32_t count = info.regexps + 2;
+	if (out_counts && count > kMaxCounters) {
+		SetError("out_counts is supported for scanners with at most 1024 regexps");
+		return PIRE_HIP_EUNSUPPORTED;
+	}
+	const size_t G = m->devices.size();
+	// every device starts its shard before any is waited for: the launches are asynchronous
+	for (size_t g = 0; g < G; ++g) {
+		hipError_t e = hipSetDevice(m->devices[g]);
+		if (e == hipSuccess && out_counts)
+			e = hipMemsetAsync(m->counters[g], 0, size_t(count) * 8, m->streams[g]);
+		int rc = e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipSetDevice / counter reset");
+		if (rc == PIRE_HIP_OK)
+			rc = launch(g, out_counts ? reinterpret_cast<uint64_t*>(m->counters[g]) : nullptr);
+		if (rc != PIRE_HIP_OK) {
+			const std::string msg = pire_hip_last_error();   // DrainAll must not replace the message
+			DrainAll(m);
+			SetError(msg);
+			return rc;
+		}
+	}
+	if (out_counts)
+		return ReduceCounters(m, count, out_counts);
+	for (size_t g = 0; g < G; ++g) {
+		hipError_t e = hipSetDevice(m->devices[g]);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(m->streams[g]);
+		if (e != hipSuccess)
+			return HipFail(e, "hipStreamSynchronize");
+	}
+	return PIRE_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -197,6 +287,7 @@ try {
 	}
 	m->streams.assign(ndev, nullptr);
 	m->counters.assign(ndev, nullptr);
+	m->pools.assign(ndev, StagePool());
 	for (int g = 0; g < ndev; ++g) {
 		if ((e = hipSetDevice(m->devices[g])) != hipSuccess ||
 		    (e = hipStreamCreateWithFlags(&m->streams[g], hipStreamNonBlocking)) != hipSuccess ||
@@ -244,50 +335,146 @@ try {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
 	}
-	pire_hip_table_info info;
-	if (int rc = pire_hip_table_get_info(t, &info))
-		return rc;
-	const uint32_t count = info.regexps + 2;
-	if (out_counts && count > kMaxCounters) {
-		SetError("out_counts is supported for scanners with at most 1024 regexps");
-		return PIRE_HIP_EUNSUPPORTED;
-	}
 	DeviceGuard guard;
-	const size_t G = m->devices.size();
 	flags = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE;
-	// every device starts its shard before any is waited for: the launches are asynchronous
-	for (size_t g = 0; g < G; ++g) {
-		hipError_t e = hipSetDevice(m->devices[g]);
-		if (e == hipSuccess && out_counts)
-			e = hipMemsetAsync(m->counters[g], 0, size_t(count) * 8, m->streams[g]);
-		if (e != hipSuccess)
-			return HipFail(e, "hipSetDevice / counter reset");
+	return RunOnAllDevices(m, t, out_counts, [&](size_t g, uint64_t* counters) {
 		const pire_hip_shard& s = shards[g];
 		if (s.n == 0)
-			continue;
-		if (int rc = pire_hip_run_strided(t, s.text, s.n, s.len, s.stride, flags, s.init_state_idx, s.out_state_idx, s.out_final,
-		                                  out_counts ? reinterpret_cast<uint64_t*>(m->counters[g]) : nullptr, m->streams[g]))
-			return rc;
-	}
-	if (out_counts)
-		return ReduceCounters(m, count, out_counts);
-	for (size_t g = 0; g < G; ++g) {
-		hipError_t e = hipSetDevice(m->devices[g]);
-		if (e == hipSuccess)
-			e = hipStreamSynchronize(m->streams[g]);
-		if (e != hipSuccess)
-			return HipFail(e, "hipStreamSynchronize");
-	}
-	return PIRE_HIP_OK;
+			return int(PIRE_HIP_OK);
+		return pire_hip_run_strided(t, s.text, s.n, s.len, s.stride, flags, s.init_state_idx, s.out_state_idx, s.out_final,
+		                            counters, m->streams[g]);
+	});
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
+
+int pire_hip_multi_run(pire_hip_multi* m, pire_hip_table* t, const pire_hip_shard_offsets* shards, uint32_t flags,
+                       uint64_t* out_counts)
+try {
+	if (!m || !t || !shards) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	DeviceGuard guard;
+	flags = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE;
+	return RunOnAllDevices(m, t, out_counts, [&](size_t g, uint64_t* counters) {
+		const pire_hip_shard_offsets& s = shards[g];
+		if (s.n == 0)
+			return int(PIRE_HIP_OK);
+		return pire_hip_run(t, s.text, s.offsets, s.n, flags, s.init_state_idx, s.out_state_idx, s.out_final, counters,
+		                    m->streams[g]);
+	});
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
+}
+
+int pire_hip_multi_last_split(const pire_hip_multi* m, uint64_t* out, int capacity)
+{
+	if (!m || !out || capacity < int(m->lastSplit.size())) {
+		SetError("pire_hip_multi_last_split: null argument or too small an array (devices + 1 entries)");
+		return PIRE_HIP_EINVAL;
+	}
+	for (size_t i = 0; i < m->lastSplit.size(); ++i)
+		out[i] = m->lastSplit[i];
+	return int(m->lastSplit.size());
+}
+
+namespace {
+
+// The host-pointer entry points: shard g = strings [lo[g], lo[g+1]), staged into device slot g's pooled buffers,
+// scanned through the device-pointer entry point, results copied back in string order.  offsets == nullptr: records.
+int RunHostSharded(pire_hip_multi* m, pire_hip_table* t, const uint8_t* base, const uint64_t* offsets, uint64_t n,
+                   uint64_t len, uint64_t stride, const std::vector<uint64_t>& lo, uint32_t flags,
+                   const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts)
+{
+	const size_t G = m->devices.size();
+	m->lastSplit = lo;
+	std::vector<pire_hip_shard> rec(G);
+	std::vector<pire_hip_shard_offsets> rag(G);
+	int rc = PIRE_HIP_OK;
+	for (size_t g = 0; g < G && rc == PIRE_HIP_OK; ++g) {
+		const uint64_t cnt = lo[g + 1] - lo[g];
+		memset(&rec[g], 0, sizeof(rec[g]));
+		memset(&rag[g], 0, sizeof(rag[g]));
+		rec[g].len = len;
+		rec[g].stride = stride;
+		if (cnt == 0)
+			continue;
+		hipError_t e = hipSetDevice(m->devices[g]);
+		if (e != hipSuccess) {
+			rc = HipFail(e, "hipSetDevice");
+			break;
+		}
+		// the bytes of the shard; an offset shard keeps the caller's offsets and every string's alignment: the staged
+		// copy starts at a 256-byte boundary of the caller's buffer and is addressed through a virtual base
+		const uint64_t first = offsets ? offsets[lo[g]] & ~uint64_t(255) : lo[g] * stride;
+		const uint64_t last = offsets ? offsets[lo[g + 1]] : (lo[g + 1] - 1) * stride + len;
+		const size_t bytes = size_t(last - first);
+		void *dText = nullptr, *dOffs = nullptr, *dIdx = nullptr, *dFin = nullptr, *dInit = nullptr;
+		if ((rc = ReserveStage(m, g, kStageText, bytes + 2 * kStageSlack, &dText)) ||
+		    (offsets && (rc = ReserveStage(m, g, kStageOffs, (cnt + 1) * 8, &dOffs))) ||
+		    (out_state_idx && (rc = ReserveStage(m, g, kStageIdx, cnt * 4, &dIdx))) ||
+		    (out_final && (rc = ReserveStage(m, g, kStageFin, cnt, &dFin))) ||
+		    (init_state_idx && (rc = ReserveStage(m, g, kStageInit, cnt * 4, &dInit))))
+			break;
+		uint8_t* staged = static_cast<uint8_t*>(dText) + kStageSlack;
+		if (bytes)
+			e = hipMemcpyAsync(staged, base + first, bytes, hipMemcpyHostToDevice, m->streams[g]);
+		if (e == hipSuccess && offsets)
+			e = hipMemcpyAsync(dOffs, offsets + lo[g], (cnt + 1) * 8, hipMemcpyHostToDevice, m->streams[g]);
+		if (e == hipSuccess && dInit)
+			e = hipMemcpyAsync(dInit, init_state_idx + lo[g], cnt * 4, hipMemcpyHostToDevice, m->streams[g]);
+		if (e != hipSuccess) {
+			rc = HipFail(e, "hipMemcpy(H2D)");
+			break;
+		}
+		rec[g].text = staged;
+		rec[g].n = cnt;
+		rec[g].init_state_idx = static_cast<const uint32_t*>(dInit);
+		rec[g].out_state_idx = static_cast<uint32_t*>(dIdx);
+		rec[g].out_final = static_cast<uint8_t*>(dFin);
+		rag[g].text = staged - first;   // so that the caller's offsets address the staged copy
+		rag[g].offsets = static_cast<const uint64_t*>(dOffs);
+		rag[g].n = cnt;
+		rag[g].init_state_idx = rec[g].init_state_idx;
+		rag[g].out_state_idx = rec[g].out_state_idx;
+		rag[g].out_final = rec[g].out_final;
+	}
+	if (rc == PIRE_HIP_OK)
+		rc = offsets ? pire_hip_multi_run(m, t, rag.data(), flags, out_counts)
+		             : pire_hip_multi_run_strided(m, t, rec.data(), flags, out_counts);
+	for (size_t g = 0; g < G && rc == PIRE_HIP_OK; ++g) {
+		const uint64_t cnt = lo[g + 1] - lo[g];
+		if (cnt == 0)
+			continue;
+		hipError_t e = hipSetDevice(m->devices[g]);
+		if (e == hipSuccess && out_state_idx)
+			e = hipMemcpyAsync(out_state_idx + lo[g], rec[g].out_state_idx, cnt * 4, hipMemcpyDeviceToHost, m->streams[g]);
+		if (e == hipSuccess && out_final)
+			e = hipMemcpyAsync(out_final + lo[g], rec[g].out_final, cnt, hipMemcpyDeviceToHost, m->streams[g]);
+		if (e != hipSuccess)
+			rc = HipFail(e, "hipMemcpy(D2H)");
+	}
+	// every stream drained before the call returns, error or not: the pooled buffers are free for the next call
+	const std::string msg = rc != PIRE_HIP_OK ? pire_hip_last_error() : "";
+	for (size_t g = 0; g < G; ++g) {
+		(void)hipSetDevice(m->devices[g]);
+		hipError_t e = hipStreamSynchronize(m->streams[g]);
+		if (e != hipSuccess && rc == PIRE_HIP_OK)
+			rc = HipFail(e, "hipStreamSynchronize");
+	}
+	if (!msg.empty())
+		SetError(msg);
+	return rc;
+}
+
+}  // namespace
 
 int pire_hip_multi_run_strided_host(pire_hip_multi* m, pire_hip_table* t, const void* text, uint64_t n, uint64_t len,
                                     uint64_t stride, uint32_t flags, const uint32_t* init_state_idx,
                                     uint32_t* out_state_idx, uint8_t* out_final, uint64_t* out_counts)
 try {
-	if (!m || !t || (n && !text)) {
+	if (!m || !t || (n && len && !text)) {
 		SetError("null argument");
 		return PIRE_HIP_EINVAL;
 	}
@@ -297,83 +484,55 @@ try {
 	}
 	DeviceGuard guard;
 	const size_t G = m->devices.size();
-	std::vector<pire_hip_shard> shards(G);
-	std::vector<void*> owned;   // (device, pointer) pairs flattened: device buffers of this call
-	std::vector<int> ownedDev;
-	auto release = [&] {
-		for (size_t i = 0; i < owned.size(); ++i) {
-			(void)hipSetDevice(ownedDev[i]);
-			(void)hipFree(owned[i]);
-		}
-	};
-	auto alloc = [&](int dev, size_t bytes, void** p) -> int {
-		hipError_t e = hipMalloc(p, bytes ? bytes : 16);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMalloc(shard)");
-		owned.push_back(*p);
-		ownedDev.push_back(dev);
-		return PIRE_HIP_OK;
-	};
-	const uint8_t* base = static_cast<const uint8_t*>(text);
-	int rc = PIRE_HIP_OK;
-	// shard g owns strings [lo, hi): contiguous, balanced (sizes differ by at most one)
+	// shard g owns strings [lo, hi): contiguous, balanced (records are equal work: sizes differ by at most one)
 	std::vector<uint64_t> lo(G + 1);
 	for (size_t g = 0; g <= G; ++g)
 		lo[g] = n / G * g + std::min<uint64_t>(g, n % G);
-	for (size_t g = 0; g < G && rc == PIRE_HIP_OK; ++g) {
-		const uint64_t cnt = lo[g + 1] - lo[g];
-		const int dev = m->devices[g];
-		hipError_t e = hipSetDevice(dev);
-		if (e != hipSuccess) {
-			rc = HipFail(e, "hipSetDevice");
-			break;
+	return RunHostSharded(m, t, static_cast<const uint8_t*>(text), nullptr, n, len, stride, lo, flags, init_state_idx,
+	                      out_state_idx, out_final, out_counts);
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
+}
+
+int pire_hip_multi_run_host(pire_hip_multi* m, pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n,
+                            uint32_t flags, const uint32_t* init_state_idx, uint32_t* out_state_idx, uint8_t* out_final,
+                            uint64_t* out_counts)
+try {
+	if (!m || !t || (n && !offsets)) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	for (uint64_t i = 0; i < n; ++i)
+		if (offsets[i + 1] < offsets[i]) {
+			SetError("offsets must be non-decreasing");
+			return PIRE_HIP_EINVAL;
 		}
-		pire_hip_shard& s = shards[g];
-		memset(&s, 0, sizeof(s));
-		s.n = cnt;
-		s.len = len;
-		s.stride = stride;
-		if (cnt == 0)
+	if (n && offsets[n] > offsets[0] && !text) {
+		SetError("null text pointer with non-empty strings");
+		return PIRE_HIP_EINVAL;
+	}
+	DeviceGuard guard;
+	const size_t G = m->devices.size();
+	// balanced by BYTES: the boundary of shard g is the string boundary nearest to g / G of the text (whole strings
+	// only; empty strings at a boundary go with the shard in front).  Equal byte counts are equal work whatever the
+	// lengths; when all the text is empty strings the split falls back to string counts.
+	std::vector<uint64_t> lo(G + 1, 0);
+	lo[G] = n;
+	const uint64_t b0 = n ? offsets[0] : 0, total = n ? offsets[n] - b0 : 0;
+	for (size_t g = 1; g < G; ++g) {
+		if (total == 0) {
+			lo[g] = n / G * g + std::min<uint64_t>(g, n % G);
 			continue;
-		const size_t bytes = size_t(cnt - 1) * stride + len;
-		void *dText = nullptr, *dIdx = nullptr, *dFin = nullptr, *dInit = nullptr;
-		if ((rc = alloc(dev, bytes, &dText)) || (out_state_idx && (rc = alloc(dev, cnt * 4, &dIdx))) ||
-		    (out_final && (rc = alloc(dev, cnt, &dFin))) || (init_state_idx && (rc = alloc(dev, cnt * 4, &dInit))))
-			break;
-		e = hipMemcpyAsync(dText, base + lo[g] * stride, bytes, hipMemcpyHostToDevice, m->streams[g]);
-		if (e == hipSuccess && dInit)
-			e = hipMemcpyAsync(dInit, init_state_idx + lo[g], cnt * 4, hipMemcpyHostToDevice, m->streams[g]);
-		if (e != hipSuccess) {
-			rc = HipFail(e, "hipMemcpy(H2D)");
-			break;
 		}
-		s.text = dText;
-		s.init_state_idx = static_cast<const uint32_t*>(dInit);
-		s.out_state_idx = static_cast<uint32_t*>(dIdx);
-		s.out_final = static_cast<uint8_t*>(dFin);
+		const uint64_t want = b0 + total / G * g + std::min<uint64_t>(g, total % G);
+		const uint64_t* it = std::lower_bound(offsets, offsets + n + 1, want);   // first boundary at or behind `want`
+		uint64_t k = uint64_t(it - offsets);
+		if (k > 0 && want - offsets[k - 1] < offsets[k] - want)
+			--k;                                                                    // the one in front is nearer
+		lo[g] = std::max(lo[g - 1], std::min<uint64_t>(k, n));
 	}
-	if (rc == PIRE_HIP_OK)
-		rc = pire_hip_multi_run_strided(m, t, shards.data(), flags, out_counts);
-	for (size_t g = 0; g < G && rc == PIRE_HIP_OK; ++g) {
-		const uint64_t cnt = lo[g + 1] - lo[g];
-		if (cnt == 0)
-			continue;
-		hipError_t e = hipSetDevice(m->devices[g]);
-		if (e == hipSuccess && out_state_idx)
-			e = hipMemcpyAsync(out_state_idx + lo[g], shards[g].out_state_idx, cnt * 4, hipMemcpyDeviceToHost, m->streams[g]);
-		if (e == hipSuccess && out_final)
-			e = hipMemcpyAsync(out_final + lo[g], shards[g].out_final, cnt, hipMemcpyDeviceToHost, m->streams[g]);
-		if (e != hipSuccess)
-			rc = HipFail(e, "hipMemcpy(D2H)");
-	}
-	for (size_t g = 0; g < G; ++g) {
-		(void)hipSetDevice(m->devices[g]);
-		hipError_t e = hipStreamSynchronize(m->streams[g]);
-		if (e != hipSuccess && rc == PIRE_HIP_OK)
-			rc = HipFail(e, "hipStreamSynchronize");
-	}
-	release();
-	return rc;
+	return RunHostSharded(m, t, static_cast<const uint8_t*>(text), offsets, n, 0, 0, lo, flags, init_state_idx, out_state_idx,
+	                      out_final, out_counts);
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }

@@ -82,3 +82,35 @@ def barrier():
 
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()
+
+
+def gather_over_ranks(value: float, device=None):
+    """Every rank's `value`, in rank order, on every rank (one all-gather of a float64 each): the per-rank rates a
+    scaling line is read against."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [value]
+    on = device if device is not None and dist.get_backend() != "gloo" else "cpu"
+    mine = torch.tensor([value], dtype=torch.float64, device=on)
+    out = [torch.zeros(1, dtype=torch.float64, device=on) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def backend_description() -> str:
+    """What carries the counter all-reduce: "rccl <version> (torch.distributed backend nccl)", "gloo", or "none"."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return "none (one rank)"
+    name = dist.get_backend()
+    if name == "nccl":
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            ver = "?"
+        return f"rccl {ver} (torch.distributed backend nccl, HIP {torch.version.hip})"
+    return name

@@ -121,6 +121,20 @@ static void TestSuite()
 		Pire::Hip::Table<Scanner>::FreezeRanking(true);
 		Pire::Hip::Table<Scanner>::FreezeRanking(false);
 	}
+	// every GPU of the node behind the same surface (here: whatever devices there are; one is enough)
+	{
+		Pire::Hip::MultiBatchRunner<Scanner> gpus(glued3);
+		CHECK(gpus.Devices() >= 1);
+		const auto& st = gpus.Begin().Run(text).End().States();
+		CHECK(st.size() == text.size());
+		size_t finals = 0;
+		for (size_t i = 0; i < text.size(); ++i) {
+			typename Scanner::State want = Pire::Runner(glued3).Begin().Run(text[i]).End().State();
+			CHECK(st[i] == want);
+			finals += glued3.Final(want) ? 1 : 0;
+		}
+		CHECK(gpus.MatchCounts()[0] == finals && gpus.MatchCounts()[1] == text.size());
+	}
 	// empty scanner never matches and must not crash -- pire_ut.cpp:760-830
 	{
 		Scanner empty;

@@ -55,6 +55,90 @@ def test_host_batch_sharded_over_device_slots(slots, n, length):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slots", [1, 2, 4])
+@pytest.mark.parametrize("shape", ["urls", "skewed", "tiny", "empties", "resume"])
+def test_ragged_host_batch_sharded_by_bytes_over_device_slots(slots, shape):
+    """pire_hip_multi_run_host: what the reference's callers have is ragged lines (pigrep.cpp:38-45), so the batch is
+    cut by BYTES into one run of whole strings per device, staged through the runner's pooled per-device buffers
+    (the second call of each runner allocates nothing), scanned concurrently, results in string order, counters summed.
+    "skewed": a few long strings among many short ones -- equal string counts would give one device most of the text."""
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(len(shape) * 7 + slots)
+    alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCDEFGHIJKLMNOPQRSTUVWXYZ@Qnet"
+    if shape == "urls":
+        strings = H.random_strings(rng, 5000, 200, alphabet)
+    elif shape == "skewed":
+        strings = H.random_strings(rng, 3000, 60, alphabet)
+        for k in (5, 1500, 2990):
+            strings[k] = bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=60000))
+    elif shape == "tiny":
+        strings = H.random_strings(rng, 3, 40, alphabet)          # fewer strings than device slots (for 4)
+    elif shape == "empties":
+        strings = [b""] * 700
+    else:
+        strings = H.random_strings(rng, 2000, 300, alphabet)
+    text, offs = H.pack(strings)
+    # offsets that do not start at 0, text that does not start at a 256-byte boundary
+    lead = 77
+    text = np.concatenate([np.full(lead, ord("x"), np.uint8), text])
+    offs = offs + np.uint64(lead)
+    init = None
+    if shape == "resume":
+        init = rng.randint(0, o.size, size=len(strings)).astype(np.uint32)
+        oi, of = o.run(text, offs, threads=4, init_idx=init)
+    else:
+        oi, of = o.run(text, offs, threads=4)
+    m = pire_amd.MultiRunner(devices=[0] * slots)
+    for rep in range(2):
+        gi, gf, cnt = m.run_host(t, text, offs, init_idx=init)
+        assert (gi == oi).all() and (gf == of).all(), (shape, slots, rep)
+        assert (cnt == _expected_counts(o, oi, of)).all()
+    split = m.last_split()
+    assert split[0] == 0 and split[-1] == len(strings) and split == sorted(split) and len(split) == slots + 1
+    total = int(offs[-1] - offs[0])
+    if shape in ("urls", "skewed", "resume") and slots > 1:
+        longest = max(len(x) for x in strings)
+        for g in range(slots):   # every shard within one string of its fair share of the BYTES
+            got = int(offs[split[g + 1]] - offs[split[g]])
+            assert abs(got - total / slots) <= longest, (g, got, total / slots)
+
+
+@pytest.mark.gpu
+def test_device_resident_offset_shards():
+    """pire_hip_multi_run: offset shards already resident on their devices (here: three slots of device 0)."""
+    import torch
+
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(3)
+    m = pire_amd.MultiRunner(devices=[0, 0, 0])
+    shards, keep, want = [], [], []
+    for g, n in enumerate((900, 0, 2500)):
+        strings = H.random_strings(rng, n, 250, b"abcdehello w0123456789()- ABCXYZ@Qnet")
+        text, offs = H.pack(strings)
+        d = torch.as_tensor(np.array(text) if len(text) else np.zeros(16, np.uint8), device="cuda")
+        do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+        idx = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+        fin = torch.empty(max(n, 1), dtype=torch.uint8, device="cuda")
+        keep += [d, do, idx, fin]
+        shards.append((d.data_ptr(), do.data_ptr(), n, 0, idx.data_ptr(), fin.data_ptr()))
+        want.append((n, idx, fin) + tuple(o.run(text, offs, threads=2)))
+    cnt = m.run_offset_shards(t, shards)
+    total = np.zeros(o.regexps + 2, dtype=np.uint64)
+    for n, idx, fin, oi, of in want:
+        assert (idx[:n].cpu().numpy().astype(np.uint32) == oi).all() and (fin[:n].cpu().numpy() == of).all()
+        total += _expected_counts(o, oi, of)
+    assert (cnt == total).all()
+
+
+@pytest.mark.gpu
 def test_device_resident_shards_and_rccl_when_there_are_two_gpus():
     import torch
 
