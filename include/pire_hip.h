@@ -100,7 +100,10 @@ typedef struct pire_hip_config {
 	/* offset batches (pire_hip_run) */
 	uint32_t ragged_variant;       /* 0 chosen from the mean string length; 1 always the 16-wave prefetching kernel;    */
 	                               /* 2 always the 24-wave one-tile kernel                                              */
-	uint32_t reserved0;
+	uint32_t host_staging;         /* device staging of the host-pointer forms of the prefix / suffix / half-final /   */
+	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
+	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */
+	                               /* 2 the stream-ordered pool (hipMallocAsync): measurements                          */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)

@@ -103,7 +103,7 @@ class Config(C.Structure):
         ("auto_adapt", C.c_uint32),
         ("auto_adapt_min_traps", C.c_uint32),
         ("ragged_variant", C.c_uint32),
-        ("reserved0", C.c_uint32),
+        ("host_staging", C.c_uint32),
     ]
 
 
@@ -229,7 +229,7 @@ def set_config(**fields) -> Config:
     old = get_config()
     new = get_config()
     for k, v in fields.items():
-        if k not in dict(Config._fields_) or k in ("size", "reserved0"):
+        if k not in dict(Config._fields_) or k == "size":
             raise KeyError(k)
         setattr(new, k, int(v))
     _check(lib().pire_hip_config_set(C.byref(new)))

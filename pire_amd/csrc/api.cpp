@@ -33,6 +33,68 @@ thread_local float g_lastMs = -1.0f;
 
 void SetError(const std::string& msg) { g_error = msg; }
 
+// ---- device staging blocks cached between host-pointer calls (internal.h Staging) -------------------------------------
+// Round 2 allocated and freed four or five device buffers in every host-pointer call of the prefix / suffix /
+// half-final / counting / capture / slow entry points (77-110 us for 10 strings, most of it hipMalloc + hipFree, which
+// also synchronise the device).  Blocks now come from per-device free lists by power-of-two size class and go back when
+// the call returns (it has drained its stream by then); at most kStagingCacheBytes stay cached per device.
+namespace {
+constexpr size_t kStagingCacheBytes = size_t(1) << 30;
+struct StagingCache {
+	std::mutex mutex;
+	std::vector<void*> free[48];   // by log2 of the block size
+	size_t cached = 0;
+};
+StagingCache g_stagingCache[kMaxDevices];
+int SizeClass(size_t bytes)
+{
+	int c = 12;   // 4 KiB at least
+	while ((size_t(1) << c) < bytes)
+		++c;
+	return c;
+}
+}  // namespace
+
+int StagingAcquire(size_t bytes, void** out, size_t* blockBytes)
+{
+	*out = nullptr;
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+		return HipFail(e == hipSuccess ? hipErrorInvalidDevice : e, "hipGetDevice");
+	const int c = SizeClass(bytes);
+	*blockBytes = size_t(1) << c;
+	{
+		StagingCache& cache = g_stagingCache[dev];
+		std::lock_guard<std::mutex> lock(cache.mutex);
+		if (!cache.free[c].empty()) {
+			*out = cache.free[c].back();
+			cache.free[c].pop_back();
+			cache.cached -= *blockBytes;
+			return PIRE_HIP_OK;
+		}
+	}
+	e = hipMalloc(out, *blockBytes);
+	if (e != hipSuccess)
+		return HipFail(e, "hipMalloc(staging)");
+	return PIRE_HIP_OK;
+}
+
+void StagingRelease(void* p, size_t blockBytes)
+{
+	int dev = -1;
+	if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
+		StagingCache& cache = g_stagingCache[dev];
+		std::lock_guard<std::mutex> lock(cache.mutex);
+		if (cache.cached + blockBytes <= kStagingCacheBytes) {
+			cache.free[SizeClass(blockBytes)].push_back(p);
+			cache.cached += blockBytes;
+			return;
+		}
+	}
+	(void)hipFree(p);
+}
+
 int HandleException() noexcept
 {
 	try {
@@ -157,6 +219,7 @@ pire_hip_config SeedFromEnvironment()
 	c.auto_adapt = uint32_t(EnvU64("PIRE_HIP_AUTO_ADAPT"));
 	c.auto_adapt_min_traps = uint32_t(EnvU64("PIRE_HIP_AUTO_ADAPT_MIN_TRAPS"));
 	c.ragged_variant = uint32_t(EnvU64("PIRE_HIP_RAGGED_VARIANT"));
+	c.host_staging = uint32_t(EnvU64("PIRE_HIP_HOST_STAGING"));
 	return c;
 }
 
@@ -1094,7 +1157,7 @@ try {
 		}
 		return rc;
 	}
-	Staging st;
+	Staging st(stream);
 	for (uint64_t i = 0; i < n; ++i)
 		if (offsets[i] > offsets[i + 1]) {
 			SetError("offsets must be non-decreasing");
@@ -1166,7 +1229,7 @@ try {
 		return LaunchPrefix(p, longest != 0, through_end != 0, reinterpret_cast<long long*>(out_len), stream,
 		                    (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t, p));
 	}
-	Staging st;
+	Staging st(stream);
 	for (uint64_t i = 0; i < n; ++i)
 		if (offsets[i] > offsets[i + 1]) {
 			SetError("offsets must be non-decreasing");
@@ -1313,7 +1376,7 @@ try {
 		p.offsets = offsets;
 		return LaunchSuffix(p, longest != 0, through_begin != 0, reinterpret_cast<long long*>(out_len), stream);
 	}
-	Staging st;
+	Staging st(stream);
 	for (uint64_t i = 0; i < n; ++i)
 		if (offsets[i] > offsets[i + 1]) {
 			SetError("offsets must be non-decreasing");

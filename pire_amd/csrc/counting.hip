@@ -666,21 +666,20 @@ try {
 	p.actions = image.actions;
 	// more than 16 regexps: per-string `current` rows in a temporary device array (freed after the stream is drained)
 	void* scratch = nullptr;
+	// stream-ordered: allocated and freed on the call's stream (the free is ordered after the kernel that uses it)
 	struct ScratchGuard {
 		void*& q;
 		hipStream_t s;
 		~ScratchGuard()
 		{
-			if (q) {
-				(void)hipStreamSynchronize(s);
-				(void)hipFree(q);
-			}
+			if (q)
+				(void)hipFreeAsync(q, s);
 		}
 	} scratchGuard{scratch, stream};
 	if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT && t->host.regexps > kMaxReCount) {
-		hipError_t se = hipMalloc(&scratch, size_t(n) * t->host.regexps * 4);
+		hipError_t se = hipMallocAsync(&scratch, size_t(n) * t->host.regexps * 4, stream);
 		if (se != hipSuccess)
-			return HipFail(se, "hipMalloc(counting scratch)");
+			return HipFail(se, "hipMallocAsync(counting scratch)");
 		p.scratch = static_cast<uint32_t*>(scratch);
 	}
 	p.letterOf = image.letterOf;
@@ -709,7 +708,7 @@ try {
 		SetError("null text pointer with non-empty strings");
 		return PIRE_HIP_EINVAL;
 	}
-	Staging stage;
+	Staging stage(stream);
 	const uint8_t* dText = nullptr;
 	const uint64_t* dOffs = nullptr;
 	void *dIdx = nullptr, *dRes = nullptr;
@@ -801,7 +800,7 @@ try {
 		SetError("null text pointer with non-empty strings");
 		return PIRE_HIP_EINVAL;
 	}
-	Staging stage;
+	Staging stage(stream);
 	const uint8_t* dText = nullptr;
 	const uint64_t* dOffs = nullptr;
 	void *dIdx = nullptr, *dFin = nullptr, *dB = nullptr, *dE = nullptr;

@@ -270,28 +270,55 @@ __host__ __device__ inline uint32_t CompactBytes(const ScanParams& p)
 	return p.compact ? (p.compact + 1) * CompactPitch(p.letters) : 0;
 }
 
+// The library configuration (include/pire_hip.h pire_hip_config): a snapshot by value, taken once per call.
+pire_hip_config GetConfig();
 void SetError(const std::string& msg);
 // Inside a catch (...) of an extern "C" entry point: std::bad_alloc / std::length_error (blob fields that ask for
 // absurd sizes) -> PIRE_HIP_ENOMEM, anything else -> PIRE_HIP_EINVAL; the message goes to pire_hip_last_error().
 int HandleException() noexcept;
 int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_HIP_ENODEVICE / ENOMEM
 
-// Owns the temporary device buffers of a host-pointer call (PCIe-inclusive convenience mode): everything is freed when
-// the call returns, after it has synchronised its stream.
+// Owns the temporary device buffers of a host-pointer call (PCIe-inclusive convenience mode).  Default: blocks from the
+// per-device cache of api.cpp (StagingAcquire / StagingRelease: no allocation in steady state); they go back when the
+// call returns -- after its stream has been drained, which the destructor sees to itself: an error path may leave
+// copies or kernels in flight.  pire_hip_config.host_staging: 1 = hipMalloc + hipFree per call (round 2), 2 = the
+// stream-ordered pool.
+int StagingAcquire(size_t bytes, void** out, size_t* blockBytes);
+void StagingRelease(void* p, size_t blockBytes);
 struct Staging {
 	std::vector<void*> ptrs;
+	std::vector<size_t> sizes;
+	hipStream_t stream = nullptr;
+	uint32_t mode = 1;   // a default-constructed Staging is round 2's
+	Staging() {}
+	explicit Staging(hipStream_t s) : stream(s), mode(GetConfig().host_staging) {}
 	~Staging()
 	{
-		for (void* p : ptrs)
-			(void)hipFree(p);
+		if (mode == 0 && !ptrs.empty())
+			(void)hipStreamSynchronize(stream);
+		for (size_t i = 0; i < ptrs.size(); ++i) {
+			if (mode == 0)
+				StagingRelease(ptrs[i], sizes[i]);
+			else if (mode == 2)
+				(void)hipFreeAsync(ptrs[i], stream);
+			else
+				(void)hipFree(ptrs[i]);
+		}
 	}
 	int Alloc(void** out, size_t bytes)
 	{
 		*out = nullptr;
-		hipError_t e = hipMalloc(out, bytes ? bytes : 16);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMalloc(staging)");
+		size_t block = bytes ? bytes : 16;
+		if (mode == 0) {
+			if (int rc = StagingAcquire(block, out, &block))
+				return rc;
+		} else {
+			const hipError_t e = mode == 2 ? hipMallocAsync(out, block, stream) : hipMalloc(out, block);
+			if (e != hipSuccess)
+				return HipFail(e, "hipMalloc(staging)");
+		}
 		ptrs.push_back(*out);
+		sizes.push_back(block);
 		return PIRE_HIP_OK;
 	}
 	template <class T>
@@ -363,10 +390,5 @@ int LaunchSuffix(const ScanParams& p, bool longest, bool throughBegin, long long
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,
                      const void* plantsHost, hipStream_t stream);
 
-}  // namespace pirehip
-
-namespace pirehip {
-// The library configuration (include/pire_hip.h pire_hip_config): a snapshot by value, taken once per call.
-pire_hip_config GetConfig();
 }  // namespace pirehip
 

@@ -1080,15 +1080,9 @@ int RunSlow(pire_hip_slow_table* t, const void* text, const uint64_t* offsets, u
 		return launch(p);
 	}
 	// host-pointer mode: stage through HBM
-	std::vector<void*> tmp;
-	auto alloc = [&](void** d, size_t bytes) {
-		hipError_t e = hipMalloc(d, bytes ? bytes : 16);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMalloc(staging)");
-		tmp.push_back(*d);
-		return int(PIRE_HIP_OK);
-	};
-	auto cleanup = [&] { for (void* q : tmp) (void)hipFree(q); };
+	Staging stage(stream);
+	auto alloc = [&](void** d, size_t bytes) { return stage.Alloc(d, bytes); };
+	auto cleanup = [] {};   // the staging frees itself when the call returns
 	uint64_t textBytes = offsets ? offsets[n] : (n - 1) * stride + len;
 	if (!text && textBytes) {
 		SetError("null text pointer with non-empty strings");

@@ -23,3 +23,25 @@ for n, ln in ((10, 100), (1000, 100), (10000, 100), (1000, 4096), (100000, 100))
         t.run(text, offs)
         ts.append(time.perf_counter() - t0)
     print("%7d strings x ~%4d B (%8.1f KiB): median %.0f us, min %.0f us per call" % (n, ln, offs[-1] / 1024, 1e6 * np.median(ts), 1e6 * min(ts)))
+
+# the other host-pointer entry points (prefix, half-final): pire_hip_config.host_staging = 0 device blocks cached between
+# calls (the default), 1 hipMalloc + hipFree per call (round 2), 2 the stream-ordered pool (hipMallocAsync)
+from pire_amd import binding as pb
+
+n, ln = 10, 100
+lens = rng.randint(ln // 2, ln + 1, size=n)
+offs = np.zeros(n + 1, dtype=np.uint64)
+offs[1:] = np.cumsum(lens)
+text = rng.randint(32, 127, size=int(offs[-1])).astype(np.uint8)
+for mode in (0, 1, 2):
+    pb.set_config(host_staging=mode)
+    for name, fn in (("prefix", lambda: t.prefix(text, offs, True)), ("half_final", lambda: t.run_half_final(text, offs))):
+        fn()
+        ts = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        print("%-10s %d strings x ~%d B: median %.0f us, min %.0f us per call (host_staging=%d)" % (
+            name, n, ln, 1e6 * np.median(ts), 1e6 * min(ts), mode))
+pb.set_config(host_staging=0)
