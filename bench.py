@@ -409,7 +409,7 @@ def main():
         info = table.refresh_info()
         # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3 requires)
         traffic = traffic_src = lds = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
