@@ -249,6 +249,11 @@ unsigned long long* NextWorkSlot(pire_hip_table* t, const ScanParams& p)
 	return WorkSlotOf(p.workBase, t->workSlot[p.workDevice].fetch_add(1));
 }
 
+}  // namespace
+int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags) { return FillParams(t, p, flags); }
+unsigned long long* TakeWorkSlot(pire_hip_table* t, const ScanParams& p) { return NextWorkSlot(t, p); }
+namespace {
+
 int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,
              uint64_t totalBytesHint = 0)
 {

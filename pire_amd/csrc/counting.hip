@@ -52,6 +52,12 @@ struct pire_hip_counting_table {
 	pirehip::CountingHost host;
 	pirehip::CountingDevice devs[pirehip::kMaxDevices];   // one image per HIP device, as in pire_hip_table
 	std::mutex uploadMutex;
+	// CapturingScanner on the ragged kernel with actions (BuildCaptureTable): the expanded automaton as an ordinary
+	// table (dense rows, adaptation and all), built when first needed, and its per-state info word on every device
+	std::unique_ptr<pire_hip_table> captureTable;
+	std::vector<uint32_t> captureInfo;                    // [expanded states] original state << 8 | Final tag << 2 | action
+	uint32_t* captureInfoDev[pirehip::kMaxDevices] = {};
+	bool captureTried = false;
 };
 
 namespace pirehip {
@@ -616,6 +622,13 @@ void pire_hip_counting_table_destroy(pire_hip_counting_table* t)
 			(void)hipSetDevice(k);
 			FreeCountingDevice(&t->devs[k]);
 		}
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->captureInfoDev[k]) {
+			(void)hipSetDevice(k);
+			(void)hipFree(t->captureInfoDev[k]);
+		}
+	if (t->captureTable)
+		pire_hip_table_destroy(t->captureTable.release());
 	if (cur >= 0)
 		(void)hipSetDevice(cur);
 	delete t;
@@ -737,6 +750,103 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+}  // extern "C"
+
+namespace pirehip {
+namespace {
+
+// The capture scanner as a table the scan kernels understand: actions move from the transitions to the states.
+// Expanded state = (state, action of the transition that entered it); the walk of the expanded automaton visits
+// (state_i, action_i) exactly where the reference's walk is in state_i having just returned action_i from Next().
+// Breadth-first from (initial, 0) over the letters, so only reachable pairs exist (<= 4 x the states).  States entered
+// with an action carry kFinal -- the flag the ragged kernel with actions looks for -- the real Final tag travels in
+// the info word.  Returns false when the expansion is not worth it / not possible (then the one-string-per-lane kernel
+// stays): more than 60 000 expanded states.
+bool BuildCaptureTable(const CountingHost& h, HostTable* out, std::vector<uint32_t>* info)
+{
+	const uint32_t C = h.letters;
+	std::vector<uint32_t> idOf(size_t(h.states) * 4, UINT32_MAX), queue;
+	auto get = [&](uint32_t st, uint32_t a) {
+		uint32_t& id = idOf[size_t(st) * 4 + (a & 3u)];
+		if (id == UINT32_MAX) {
+			id = uint32_t(queue.size());
+			queue.push_back(st * 4 + (a & 3u));
+		}
+		return id;
+	};
+	(void)get(h.initial, 0);
+	std::vector<uint32_t> next;
+	for (size_t head = 0; head < queue.size(); ++head) {
+		if (queue.size() > 60000)
+			return false;
+		const uint32_t st = queue[head] >> 2;
+		for (uint32_t c = 0; c < C; ++c) {
+			const uint64_t x = h.trans[size_t(st) * C + c];
+			next.push_back(get(uint32_t(x), uint32_t(x >> 32)));
+		}
+	}
+	HostTable& t = *out;
+	t = HostTable();
+	t.states = uint32_t(queue.size());
+	t.letters = C;
+	t.regexps = 1;
+	t.initial = 0;
+	t.scannerType = 4;
+	t.cls.assign(kMaxChar, 0);
+	for (uint32_t c = 0; c < kMaxChar; ++c)
+		t.cls[c] = h.letterOf[c];
+	t.next = next;
+	t.flags.assign(t.states, 0);
+	info->assign(t.states, 0);
+	for (uint32_t e = 0; e < t.states; ++e) {
+		const uint32_t st = queue[e] >> 2, a = queue[e] & 3u;
+		bool absorbing = true;
+		for (uint32_t c = 0; c < C; ++c)
+			absorbing = absorbing && t.next[size_t(e) * C + c] == e;
+		t.flags[e] = uint8_t((a ? kFinal : 0) | (absorbing ? kAbsorbing : 0));
+		(*info)[e] = (st << 8) | ((h.tags[st] & 1u) << 2) | a;
+	}
+	t.acceptOff.assign(size_t(t.states) + 1, 0);   // no AcceptedRegexps lists: the counters of pire_hip_run are not used
+	ChooseHotAndPermuteExported(t);
+	return true;
+}
+
+// The capture table and its info array on the current device (built / uploaded when first needed).
+int EnsureCaptureTable(pire_hip_counting_table* t, pire_hip_table** table, const uint32_t** infoDev)
+{
+	std::lock_guard<std::mutex> lock(t->uploadMutex);
+	*table = nullptr;
+	if (!t->captureTried) {
+		t->captureTried = true;
+		if (t->host.states < (1u << 22) && t->host.letters <= 127) {
+			std::unique_ptr<pire_hip_table> ct(new pire_hip_table);
+			if (BuildCaptureTable(t->host, &ct->host, &t->captureInfo))
+				t->captureTable = std::move(ct);
+		}
+	}
+	if (!t->captureTable)
+		return PIRE_HIP_OK;
+	int dev = -1;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess || dev < 0 || dev >= kMaxDevices)
+		return HipFail(e == hipSuccess ? hipErrorInvalidDevice : e, "hipGetDevice");
+	if (!t->captureInfoDev[dev]) {
+		e = hipMalloc(reinterpret_cast<void**>(&t->captureInfoDev[dev]), t->captureInfo.size() * 4);
+		if (e == hipSuccess)
+			e = hipMemcpy(t->captureInfoDev[dev], t->captureInfo.data(), t->captureInfo.size() * 4, hipMemcpyHostToDevice);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMalloc(capture info)");
+	}
+	*table = t->captureTable.get();
+	*infoDev = t->captureInfoDev[dev];
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+}  // namespace pirehip
+
+extern "C" {
+
 int pire_hip_capture_run(pire_hip_counting_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                          uint32_t* out_state_idx, uint8_t* out_final, int64_t* out_begin, int64_t* out_end, void* streamPtr)
 try {
@@ -779,6 +889,41 @@ try {
 	                        int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	// Batches of >= 256 strings ride the ragged kernel with actions (the expanded table of BuildCaptureTable):
+	// 2-3 x the one-string-per-lane kernel below, which keeps the small batches and PIRE_HIP_RUN_GENERIC.
+	auto ragged = [&](const uint8_t* dText, const uint64_t* dOffs, uint32_t* dIdx, uint8_t* dFin, long long* dB,
+	                  long long* dE, bool* done) -> int {
+		*done = false;
+		if ((flags & PIRE_HIP_RUN_GENERIC) || n < 256 || n >= (1ull << 32) - (1ull << 16) || GetConfig().no_ragged_act)
+			return PIRE_HIP_OK;
+		pire_hip_table* ct = nullptr;
+		const uint32_t* infoDev = nullptr;
+		if (int rc = EnsureCaptureTable(t, &ct, &infoDev))
+			return rc;
+		if (!ct)
+			return PIRE_HIP_OK;
+		ScanParams sp;
+		if (int rc = PrepareScanParams(ct, &sp, flags & PIRE_HIP_RUN_BEGIN))   // startPerm = Initialize [+ BeginMark]
+			return rc;
+		// Scanners whose walk is in an action state most of the time gain nothing from looking for the chunks that have
+		// one: =(\d+)[^\d] re-arms BeginCapture on every byte in front of the match (99.5 % of the steps on the benchmark
+		// text, measured), (/to-match-with) on 2 %, google_id\s*=... on none.  The share of the byte model's visits that
+		// fall on action states (the expanded table's "Final" share, table.cpp) decides; either kernel is exact.
+		if (sp.finalShare > 0.01f && !GetConfig().ragged_act_always)
+			return PIRE_HIP_OK;
+		sp.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+		sp.n = n;
+		sp.text = dText;
+		sp.offsets = dOffs;
+		sp.outIdx = dIdx;
+		sp.outFinal = dFin;
+		const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
+		if (int rc = EnsureActDist(ct, &distFinal, &distFlagged))
+			return rc;
+		sp.actDist = distFinal;
+		*done = true;
+		return LaunchRaggedCapture(sp, TakeWorkSlot(ct, sp), infoDev, dB, dE, stream);
+	};
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
@@ -786,6 +931,12 @@ try {
 		p.outFinal = out_final;
 		p.outBegin = reinterpret_cast<long long*>(out_begin);
 		p.outEnd = reinterpret_cast<long long*>(out_end);
+		bool done = false;
+		if (int rc = ragged(p.text, p.offsets, p.outIdx, p.outFinal, p.outBegin, p.outEnd, &done))
+			return rc;
+		if (done)
+			return PIRE_HIP_OK;
+		NoteKernel("capture");
 		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
 		e = hipGetLastError();
 		return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "capture kernel launch");
@@ -815,7 +966,13 @@ try {
 	p.outFinal = static_cast<uint8_t*>(dFin);
 	p.outBegin = static_cast<long long*>(dB);
 	p.outEnd = static_cast<long long*>(dE);
-	hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+	bool done = false;
+	if ((rc = ragged(p.text, p.offsets, p.outIdx, p.outFinal, p.outBegin, p.outEnd, &done)))
+		return rc;
+	if (!done) {
+		NoteKernel("capture");
+		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+	}
 	e = hipGetLastError();
 	if (e == hipSuccess && out_state_idx)
 		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);

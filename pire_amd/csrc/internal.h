@@ -376,6 +376,15 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 void NoteKernel(const char* name, const char* symbol = nullptr);   // what pire_hip_last_kernel[_symbol]() report (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);
+// CapturingScanner on the ragged kernel with actions (counting.hip builds the table): `info` = per state of the
+// EXPANDED automaton (reference numbering of that table): original state << 8 | Final tag << 2 | action that entered it
+int LaunchRaggedCapture(const ScanParams& p, unsigned long long* workCounter, const uint32_t* info, long long* outBegin,
+                        long long* outEnd, hipStream_t stream);
+// api.cpp, for the other translation units: the scan parameters of a table on the current device (uploads the image,
+// auto-adapts at the launch boundary), one ragged work slot of it, a table handle around a host table built elsewhere
+int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags);
+unsigned long long* TakeWorkSlot(pire_hip_table* t, const ScanParams& p);
+void ChooseHotAndPermuteExported(HostTable& t);
 int LaunchRaggedPrefix(const ScanParams& p, unsigned long long* workCounter, bool longest, bool throughEnd,
                        long long* outLen, hipStream_t stream);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);

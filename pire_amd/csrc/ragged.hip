@@ -429,6 +429,93 @@ struct PrefixAct {
 	}
 };
 
+// Pire::CapturingScanner (extra/capture.h:49-162) on this kernel.  Its table is a LoadedScanner whose TRANSITIONS carry
+// the actions (BeginCapture / EndCapture); counting.hip expands it so that an action becomes a property of the STATE
+// entered -- expanded state = (state, action of the transition that entered it), at most 4 x the states, which are
+// few -- and flags those with an action as the states this walk cares about (they take the place Final states have for
+// the half-final counting: ordered last among the dense rows, one compare per chunk on the largest id seen).  On text
+// the capture's brackets are met in a few chunks per string, so nearly every chunk takes the plain fast path.
+// info[e] for expanded state e (reference numbering of the expanded table): original state << 8 | Final tag << 2 | action.
+struct CaptureAct {
+	static constexpr bool kActive = true;
+	static constexpr bool kGroupLoads = kRaggedGroupLoads;
+	const uint32_t* info;
+	long long* outBegin;
+	long long* outEnd;
+	uint32_t beginStep;   // 1 when Begin() is a counted step of the string (PIRE_HIP_RUN_BEGIN)
+	static constexpr uint32_t npos = ~uint32_t(0);
+	struct Lane {
+		uint64_t start;
+		uint32_t begin, end;
+	};
+	__device__ __forceinline__ bool Wants(const Lane&) const { return true; }   // Final needs the whole string anyway
+	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotFinalLo; }
+	// next to the table in LDS: the info word of every dense-row state (1 KiB), and of the state its end of string
+	// leads to (Step(EndMark) when asked for; 1 KiB at +2048) -- no load from memory on the common path
+	__device__ __forceinline__ void LoadLds(const ScanParams& p, uint8_t* area) const
+	{
+		uint32_t* infoHot = reinterpret_cast<uint32_t*>(area);
+		uint32_t* endHot = reinterpret_cast<uint32_t*>(area + 2048);
+		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x) {
+			infoHot[i] = info[p.origOfPerm[i]];
+			endHot[i] = info[recs[i].orig];
+		}
+	}
+	// TakeAction, capture.h:96-102, at value `at` = m_counter - 1
+	__device__ __forceinline__ void Apply(Lane& al, uint32_t a, uint32_t at) const
+	{
+		const bool open = !(al.begin != npos && al.end != npos);
+		const bool setBegin = (a & 1u) && open;
+		const bool setEnd = !(a & 1u) && (a & 2u) && open;
+		al.begin = setBegin ? at : al.begin;
+		al.end = setEnd ? at : al.end;
+	}
+	// `after` = address behind the byte just consumed: that byte was step (after - start) + beginStep, counted from 1
+	__device__ __forceinline__ void HotStep(const ScanParams&, const uint8_t*, const LdsLayout&, const uint8_t* area, Lane& al,
+	                                        uint32_t h, uint64_t after) const
+	{
+		Apply(al, reinterpret_cast<const uint32_t*>(area)[h] & 3u, uint32_t(after - al.start) + beginStep - 1u);
+	}
+	__device__ __forceinline__ void Step(const ScanParams& p, const uint8_t*, const LdsLayout&, Lane& al, uint32_t st,
+	                                     uint64_t after) const
+	{
+		if (IsFinalState(p, st))   // "Final" = entered by a transition with an action (counting.hip BuildCaptureTable)
+			Apply(al, info[p.origOfPerm[st]] & 3u, uint32_t(after - al.start) + beginStep - 1u);
+	}
+	__device__ __forceinline__ uint32_t Start(const ScanParams& p, const uint8_t*, const LdsLayout&, Lane& al, uint32_t,
+	                                          uint64_t addr) const
+	{
+		al.start = addr;
+		al.begin = al.end = npos;                          // Initialize, capture.h:89-94
+		const uint32_t st = p.startPerm;                   // ... [+ Step(BeginMark): m_counter = 1, its action at 0]
+		if (beginStep && IsFinalState(p, st))
+			Apply(al, info[p.origOfPerm[st]] & 3u, 0u);
+		return st;
+	}
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t*, const LdsLayout&, const uint8_t* area, Lane& al,
+	                                       uint32_t s, uint32_t st, uint64_t end) const
+	{
+		const bool cold = st >= p.hot;
+		uint32_t e = cold ? 0u : reinterpret_cast<const uint32_t*>(area + 2048)[st];
+		if (__any(cold)) {
+			if (cold) {
+				const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+				e = info[recs[st].orig];
+				asm volatile("" : "+v"(e));   // the wait belongs in here
+			}
+		}
+		if (p.flags & PIRE_HIP_RUN_END)   // the End() step is a counted step with an action of its own
+			Apply(al, e & 3u, uint32_t(end - al.start) + beginStep);
+		if (p.outIdx)
+			p.outIdx[s] = e >> 8;
+		if (p.outFinal)
+			p.outFinal[s] = (e >> 2) & 1u;
+		outBegin[s] = al.begin == npos ? -1ll : (long long)al.begin;
+		outEnd[s] = al.end == npos ? -1ll : (long long)al.end;
+	}
+};
+
 // Exact walk of the first `count` (<= 16) bytes of v with the action after every step; `addr` is the address of
 // byte 0.  Rolled: this is the cold path.
 template <class Act>
@@ -1076,6 +1163,22 @@ int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter,
 	HalfFinalAct act;
 	act.results = outResults;
 	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);
+}
+
+int LaunchRaggedCapture(const ScanParams& p0, unsigned long long* workCounter, const uint32_t* info, long long* outBegin,
+                        long long* outEnd, hipStream_t stream)
+{
+	ScanParams p = p0;
+	if (!p.actDist)
+		p.compact = 0;
+	p.outCounts = nullptr;
+	CaptureAct act;
+	act.info = info;
+	act.outBegin = outBegin;
+	act.outEnd = outEnd;
+	act.beginStep = (p0.flags & PIRE_HIP_RUN_BEGIN) ? 1u : 0u;
+	NoteKernel("ragged_capture");
+	return LaunchRaggedT<CaptureAct, false>(p, workCounter, act, stream);
 }
 
 int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bool longest, bool throughEnd,

@@ -444,6 +444,8 @@ int BuildSimpleHostTable(const uint8_t* p, size_t len, size_t pos, HostTable* ou
 
 }  // namespace
 
+void ChooseHotAndPermuteExported(HostTable& t) { ChooseHotAndPermute(t); }
+
 int BuildHostTable(const void* blob, size_t len, HostTable* out)
 {
 	const uint8_t* p = static_cast<const uint8_t*>(blob);

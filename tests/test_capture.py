@@ -52,7 +52,7 @@ def test_oracle_matches_golden_and_reference(case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", cases(), ids=lambda c: c["name"])
-def test_gpu_capture_parity(case, pa):
+def test_gpu_capture_parity(case, pa, cfg):
     assert pa.device_count() > 0
     blob = H.load_blob(case["blob"])
     t, o = pa.CountingTable(blob, 0), ob.OracleCountingScanner(blob, 0)
@@ -66,7 +66,26 @@ def test_gpu_capture_parity(case, pa):
                  bytes(rng.choice(np.frombuffer(b"google_id ='\";x1/", dtype=np.uint8), size=rng.randint(0, 40)))
                  for _ in range(rng.randint(0, 6))]
         many.append(b"".join(parts))
+    from pire_amd import binding as pb
+
+    # long strings among the short ones, the brackets in every position relative to the 16-byte chunks and 128-byte
+    # windows of the ragged kernel, strings that are nothing but brackets
+    for k in range(0, 300, 7):
+        many.append(b"x" * k + pool[k % len(pool)] + b"y" * (300 - k))
+    many += [pool[0] * 40, pool[1] * 3 + b"z" * 5000 + pool[2], b""]
+    cfg.set(ragged_act_always=1)   # whatever the scanner's share of action states (the library's own choice: below)
     for flags in (3, 0, 1, 2):
-        a, b = o.capture(*ob.pack_strings(many), flags=flags), t.capture(*H.pack(many), flags=flags)
-        assert all((x == y).all() for x, y in zip(a, b))
+        a = o.capture(*ob.pack_strings(many), flags=flags)
+        b = t.capture(*H.pack(many), flags=flags)                       # >= 256 strings: the ragged kernel with actions
+        assert pb.last_kernel() == "ragged_capture"
+        assert all((x == y).all() for x, y in zip(a, b)), flags
+        c = t.capture(*H.pack(many), flags=flags | pb.FLAG_GENERIC)     # the one-string-per-lane kernel
+        assert pb.last_kernel() == "capture"
+        assert all((x == y).all() for x, y in zip(a, c)), flags
     assert a[2].sum() > 0
+    # left to itself the library keeps the one-string-per-lane kernel for scanners that are in an action state on most
+    # bytes of text (=(\d+)[^\d] re-arms BeginCapture all the time), and takes the ragged one for the others
+    cfg.set(ragged_act_always=0)
+    b = t.capture(*H.pack(many))
+    assert pb.last_kernel() == ("capture" if case["name"] == "capture_digits" else "ragged_capture") or case["name"] == "capture_path"
+    assert all((x == y).all() for x, y in zip(o.capture(*ob.pack_strings(many)), b))
