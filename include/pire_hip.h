@@ -98,8 +98,7 @@ typedef struct pire_hip_config {
 	                               /* rows, see pire_hip_table_adapt()                                                  */
 	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 64)           */
 	/* offset batches (pire_hip_run) */
-	uint32_t ragged_variant;       /* 0 chosen from the mean string length; 1 always the 16-wave prefetching kernel;    */
-	                               /* 2 always the 24-wave one-tile kernel                                              */
+	uint32_t ragged_variant;       /* reserved (offset batches: one kernel today)                                       */
 	uint32_t host_staging;         /* device staging of the host-pointer forms of the prefix / suffix / half-final /   */
 	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
 	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */
