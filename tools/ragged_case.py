@@ -16,7 +16,6 @@ CASES = {  # name: (lo, hi, log2 strings, multiplier)
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 flags = 3 | (pb.FLAG_GENERIC if len(sys.argv) > 3 and sys.argv[3] == "generic" else 0)
-flags |= getattr(pb, "FLAG_SHORT", 0) if len(sys.argv) > 3 and sys.argv[3] == "short" else 0   # tools/experiments/stream.hip
 lo, hi, lg, mul = CASES[case]
 big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
 t = pire_amd.Table(H.load_blob(big["blob"]))
@@ -34,20 +33,28 @@ assert total <= n * L
 doffs = torch.as_tensor(offs.astype(np.int64), device="cuda")
 idx = torch.empty(m, dtype=torch.int32, device="cuda")
 fin = torch.empty(m, dtype=torch.uint8, device="cuda")
-ts = []
-for r in range(reps + 2):
-    if r in (1, 2):
-        torch.cuda.synchronize()
-        print("adapt: rows changed", t.adapt(), "hot", t.info.hot_states)
-    a = torch.cuda.Event(enable_timing=True)
-    b = torch.cuda.Event(enable_timing=True)
-    a.record()
+def launch():
     t.run_device(buf.data_ptr(), doffs.data_ptr(), m, flags, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
-    b.record()
+
+
+# two adaptation rounds from the batch itself (the estimates are remembered and settle), then the GPU's
+# clocks settled by ~40 ms of back-to-back launches, then `reps` x 10 timed launches back to back
+for r in range(2):
+    launch()
     torch.cuda.synchronize()
-    if r >= 2:
-        ts.append(a.elapsed_time(b))
+    print("adapt: rows changed", t.adapt(), "hot", t.info.hot_states)
+settle = max(20, int(40.0 / max(total / 2.5e9, 0.05)))
+for _ in range(settle):
+    launch()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps * 10)]
+for a, b in ev:
+    a.record()
+    launch()
+    b.record()
 torch.cuda.synchronize()
+ts = [a.elapsed_time(b) for a, b in ev]
 ch = t.adapt()
 print("after the timed runs: adapt changed", ch, "rows; trap samples seen", t.refresh_info().last_trap_samples)
-print("%s %s: %d strings, %.3f GiB, min %.3f ms -> %.1f GB/s" % (pb.last_kernel(), case, m, total / 2**30, min(ts), total / min(ts) / 1e6))
+print("%s %s: %d strings, %.3f GiB, %d launches at settled clocks: mean %.3f ms -> %.1f GB/s (min %.3f ms -> %.1f GB/s)" % (
+    pb.last_kernel(), case, m, total / 2**30, len(ts), float(np.mean(ts)), total / float(np.mean(ts)) / 1e6, min(ts),
+    total / min(ts) / 1e6))
