@@ -36,6 +36,11 @@ struct CountingHost {
 	uint32_t type = 4;                 // ScannerIOTypes: 4 LoadedScanner, 5 NoGlueLimitCountingScanner
 	std::vector<uint8_t> tags;         // [states] m_tags (CapturingScanner: bit 0 = Final, capture.h:56, 134)
 	std::vector<uint32_t> actions;     // type 5: [0] = length; per action: resets count, ids, increments count, ids
+	// the dense form of CountingPackedKernel (BASIC / ADVANCED, <= 255 states, <= 255 distinct actions); empty otherwise
+	std::vector<uint16_t> dense;       // [states][256] next state | action id << 8, indexed by the input BYTE
+	std::vector<uint16_t> denseMarks;  // [states][2] the same for BeginMark / EndMark
+	std::vector<uint32_t> actWords;    // [256][2 * NREG]: per action id NREG packed increment words, then NREG reset masks
+	uint32_t nreg = 0;                 // 32-bit words of packed 16-bit counters: ceil(regexps / 2) rounded up to 1, 2, 4, 8
 };
 
 struct CountingDevice {
@@ -44,6 +49,9 @@ struct CountingDevice {
 	uint64_t* trans = nullptr;
 	uint32_t* actions = nullptr;
 	uint8_t* tags = nullptr;
+	uint16_t* dense = nullptr;
+	uint16_t* denseMarks = nullptr;
+	uint32_t* actWords = nullptr;
 };
 
 }  // namespace pirehip
@@ -73,6 +81,11 @@ struct CountingParams {
 	uint32_t* outResults;
 	const uint32_t* actions;   // NoGlueLimitCountingScanner action lists, or null (single regexp: raw action bits)
 	uint32_t* scratch;         // NoGlueLimit with more than 16 regexps: current[n][regexps]
+	// CountingPackedKernel
+	const uint16_t* dense;
+	const uint16_t* denseMarks;
+	const uint32_t* actWords;
+	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
 	// CapturingScanner run
 	const uint8_t* tags;
 	uint8_t* outFinal;
@@ -165,6 +178,117 @@ struct Counters {
 	}
 };
 
+// ---- CountingScanner / AdvancedCountingScanner, dense rows and packed counters (round 3) -----------------------------
+// On text 22-46 % of a counting scanner's steps carry an action, so -- unlike HalfFinal counting or capturing -- there
+// is no skipping the chunks without one; what can shrink is the step itself.  The kernel above pays, per byte, two
+// dependent LDS lookups (letter, then the 8-byte transition) and, whenever any lane of the wave has an action (always),
+// ~30 VALU instructions of per-regexp bit tests (PerformIncrement / PerformReset over RMAX counters).  Here:
+//   * ONE lookup per byte: dense rows indexed by the input byte, entry = next state | action id << 8 (<= 255 states,
+//     <= 255 distinct actions: counting tables have tens of states);
+//   * counters PACKED two to a register as 16-bit halves: an action is NREG packed increment words and NREG reset
+//     masks from LDS, applied with v_pk_add_u16 / v_pk_max_u16 and two ANDs per register.  PerformReset's
+//     "mask &= m_updatedMask" needs no mask: a counter is non-zero exactly when its updated bit is set (an increment
+//     sets both, only a reset clears both), and resetting a zero counter changes nothing (count.h:87-99, 175-192).
+// 16 bits hold any count of a string shorter than 65 000 bytes (a step bumps a counter by at most one); longer strings
+// go onto the overflow list and the 32-bit kernel above walks them (CountingKernel with CountingParams::overflow).
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+template <int NREG, bool ADVANCED>
+__global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint16_t* dense = reinterpret_cast<uint16_t*>(lds);                               // [states][256]
+	uint32_t* act = reinterpret_cast<uint32_t*>(lds + size_t(p.states) * 512);        // [256][2 * NREG]
+	for (uint32_t i = threadIdx.x; i < p.states * 128; i += blockDim.x)
+		reinterpret_cast<uint32_t*>(dense)[i] = reinterpret_cast<const uint32_t*>(p.dense)[i];
+	for (uint32_t i = threadIdx.x; i < 256 * 2 * NREG; i += blockDim.x)
+		act[i] = p.actWords[i];
+	__syncthreads();
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		const uint64_t b = p.offsets[s], e = p.offsets[s + 1];
+		if (e - b > 65000) {
+			const uint32_t k = atomicAdd(&p.overflow[0], 1u);
+			p.overflow[1 + k] = uint32_t(s);
+			continue;
+		}
+		u16x2 cur[NREG], tot[NREG];
+#pragma unroll
+		for (int r = 0; r < NREG; ++r)
+			cur[r] = tot[r] = u16x2{0, 0};
+		uint32_t st = p.initial;
+		auto take = [&](uint32_t id) {   // TakeActionImpl: count.h:251-257 (increment, reset) / 287-295 (reset, increment)
+			const uint32_t* w = act + id * (2 * NREG);
+#pragma unroll
+			for (int r = 0; r < NREG; ++r) {
+				const uint32_t incBits = w[r], rstBits = w[NREG + r];
+				u16x2 inc, rst;
+				__builtin_memcpy(&inc, &incBits, 4);
+				__builtin_memcpy(&rst, &rstBits, 4);
+				if (!ADVANCED)
+					cur[r] += inc;
+				tot[r] = __builtin_elementwise_max(tot[r], cur[r] & rst);
+				cur[r] &= ~rst;
+				if (ADVANCED)
+					cur[r] += inc;
+			}
+		};
+		// Software pipeline: the lookup of step i+1 needs only the STATE of step i, so it is issued first and the
+		// action of step i (another LDS read + eight packed instructions) is applied while it is on its way -- one LDS
+		// round trip per byte on the dependent chain instead of two.  `pend` = the action id not applied yet.
+		uint32_t pend = 0;
+		auto step = [&](uint32_t entry) {
+			if (pend)
+				take(pend);
+			st = entry & 0xFFu;
+			pend = entry >> 8;
+		};
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			step(p.denseMarks[st * 2]);
+		const uint8_t* ptr = p.text + b;
+		const uint8_t* end = p.text + e;
+		while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+			step(dense[st * 256 + *ptr]);
+			++ptr;
+		}
+		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
+		uint4 ahead = ptr + 16 <= end ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
+		for (; ptr + 16 <= end; ptr += 16) {
+			uint4 v = ahead;
+			if (ptr + 32 <= end)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
+#pragma unroll 1
+			for (int i = 0; i < 4; ++i) {
+				const uint32_t x = v.x;
+				step(dense[st * 256 + (x & 0xFF)]);
+				step(dense[st * 256 + ((x >> 8) & 0xFF)]);
+				step(dense[st * 256 + ((x >> 16) & 0xFF)]);
+				step(dense[st * 256 + (x >> 24)]);
+				v.x = v.y;
+				v.y = v.z;
+				v.z = v.w;
+			}
+		}
+		for (; ptr < end; ++ptr)
+			step(dense[st * 256 + *ptr]);
+		if (p.flags & PIRE_HIP_RUN_END)
+			step(p.denseMarks[st * 2 + 1]);
+		if (pend)
+			take(pend);
+		if (p.outIdx)
+			p.outIdx[s] = st;
+		for (uint32_t r = 0; r < p.regexps; ++r) {
+			uint32_t c = 0, t = 0;
+#pragma unroll
+			for (int k = 0; k < NREG; ++k)
+				if (uint32_t(k) == (r >> 1)) {
+					c = (r & 1) ? cur[k].y : cur[k].x;
+					t = (r & 1) ? tot[k].y : tot[k].x;
+				}
+			p.outResults[s * p.regexps + r] = c > t ? c : t;   // Result(r), count.h:206
+		}
+	}
+}
+
 // KIND: PIRE_HIP_COUNTING_BASIC / _ADVANCED / _NOGLUELIMIT (the latter with at most RMAX regexps: counters in registers)
 template <int RMAX, int KIND>
 __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
@@ -180,7 +304,10 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 	__syncthreads();
 	const uint64_t* trans = p.transInLds ? transLds : p.trans;
 
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+	// with an overflow list (the packed kernel ran first on this stream): only the strings it names
+	const uint64_t todo = p.overflow ? p.overflow[0] : p.n;
+	for (uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < todo; k += uint64_t(gridDim.x) * blockDim.x) {
+		const uint64_t s = p.overflow ? p.overflow[1 + k] : k;
 		Counters<RMAX> c;
 		c.Init();                                                       // Initialize, count.h:127-133
 		uint32_t st = p.initial;
@@ -203,8 +330,12 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 			step(*ptr);
 			++ptr;
 		}
+		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
+		uint4 ahead = ptr + 16 <= end ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
 		for (; ptr + 16 <= end; ptr += 16) {
-			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+			uint4 v = ahead;
+			if (ptr + 32 <= end)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
 #pragma unroll 1
 			for (int i = 0; i < 16; ++i) {
 				step(v.x & 0xFF);
@@ -326,8 +457,12 @@ __global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
 			step(*ptr);
 			++ptr;
 		}
+		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
+		uint4 ahead = ptr + 16 <= stop ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
 		for (; ptr + 16 <= stop; ptr += 16) {
-			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+			uint4 v = ahead;
+			if (ptr + 32 <= stop)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
 #pragma unroll 1
 			for (int i = 0; i < 16; ++i) {
 				step(v.x & 0xFF);
@@ -364,6 +499,58 @@ int Bad(const char* msg)
 {
 	SetError(msg);
 	return PIRE_HIP_EFORMAT;
+}
+
+// The dense, packed form of CountingPackedKernel for LoadedScanner tables (CountingScanner / AdvancedCountingScanner:
+// the action word is increment bits 0..15 | reset bits 16..31, loaded.h:223-224).  Left empty -- the 32-bit kernel
+// stays -- for more than 255 states or distinct actions, or a table that would not leave room for several blocks per CU.
+void BuildDenseCounting(CountingHost& t)
+{
+	t.dense.clear();
+	t.nreg = 0;
+	if (t.type != 4 || t.states == 0 || t.states > 255 || t.regexps == 0 || t.regexps > kMaxReCount)
+		return;
+	const uint32_t nreg = t.regexps <= 2 ? 1 : t.regexps <= 4 ? 2 : t.regexps <= 8 ? 4 : 8;
+	if (size_t(t.states) * 512 + 256 * 2 * nreg * 4 > 60 * 1024)
+		return;
+	std::vector<uint32_t> ids;   // distinct non-zero action words, id = index + 1
+	auto idOf = [&](uint32_t a) -> uint32_t {
+		if (!a)
+			return 0;
+		for (size_t i = 0; i < ids.size(); ++i)
+			if (ids[i] == a)
+				return uint32_t(i + 1);
+		ids.push_back(a);
+		return uint32_t(ids.size());
+	};
+	std::vector<uint16_t> dense(size_t(t.states) * 256), marks(size_t(t.states) * 2);
+	for (uint32_t st = 0; st < t.states; ++st) {
+		for (uint32_t ch = 0; ch < 256 + 2; ++ch) {
+			const uint32_t c = ch < 256 ? ch : ch == 256 ? kBeginMark : kEndMark;
+			const uint64_t x = t.trans[size_t(st) * t.letters + t.letterOf[c]];
+			const uint32_t id = idOf(uint32_t(x >> 32));
+			if (id > 255 || uint32_t(x) > 255)
+				return;
+			const uint16_t e = uint16_t(uint32_t(x) | (id << 8));
+			if (ch < 256)
+				dense[size_t(st) * 256 + ch] = e;
+			else
+				marks[size_t(st) * 2 + (ch - 256)] = e;
+		}
+	}
+	t.actWords.assign(size_t(256) * 2 * nreg, 0);
+	for (size_t i = 0; i < ids.size(); ++i) {
+		uint32_t* w = &t.actWords[(i + 1) * 2 * nreg];
+		for (uint32_t r = 0; r < t.regexps; ++r) {
+			if ((ids[i] >> r) & 1u)
+				w[r >> 1] |= 1u << (16 * (r & 1));                    // +1 in the counter's 16-bit half
+			if ((ids[i] >> (kMaxReCount + r)) & 1u)
+				w[nreg + (r >> 1)] |= 0xFFFFu << (16 * (r & 1));      // the counter's reset mask
+		}
+	}
+	t.dense.swap(dense);
+	t.denseMarks.swap(marks);
+	t.nreg = nreg;
 }
 
 int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
@@ -463,6 +650,7 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 			return Bad("Corrupt scanner: several regexps without an action table");
 		}
 	}
+	BuildDenseCounting(t);
 	return PIRE_HIP_OK;
 }
 
@@ -478,6 +666,12 @@ void FreeCountingDevice(CountingDevice* d)
 		(void)hipFree(d->actions);
 	if (d->tags)
 		(void)hipFree(d->tags);
+	if (d->dense)
+		(void)hipFree(d->dense);
+	if (d->denseMarks)
+		(void)hipFree(d->denseMarks);
+	if (d->actWords)
+		(void)hipFree(d->actWords);
 	*d = CountingDevice();
 }
 
@@ -515,6 +709,20 @@ int UploadCounting(pire_hip_counting_table* t, CountingDevice* image)
 		if (e == hipSuccess)
 			e = hipMemcpy(d.tags, t->host.tags.data(), t->host.tags.size(), hipMemcpyHostToDevice);
 	}
+	if (e == hipSuccess && !t->host.dense.empty()) {
+		const CountingHost& h = t->host;
+		e = hipMalloc(reinterpret_cast<void**>(&d.dense), h.dense.size() * 2);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&d.denseMarks), h.denseMarks.size() * 2);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&d.actWords), h.actWords.size() * 4);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.dense, h.dense.data(), h.dense.size() * 2, hipMemcpyHostToDevice);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.denseMarks, h.denseMarks.data(), h.denseMarks.size() * 2, hipMemcpyHostToDevice);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.actWords, h.actWords.data(), h.actWords.size() * 4, hipMemcpyHostToDevice);
+	}
 	d.device = dev;
 	if (e != hipSuccess) {
 		FreeCountingDevice(&d);
@@ -536,7 +744,22 @@ void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipS
 	*err = hipGetLastError();
 }
 
-int LaunchCounting(CountingParams p, int kind, hipStream_t stream)
+template <int NREG>
+void LaunchPacked(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+{
+	const void* fn = advanced ? reinterpret_cast<const void*>(CountingPackedKernel<NREG, true>)
+	                          : reinterpret_cast<const void*>(CountingPackedKernel<NREG, false>);
+	*err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (*err != hipSuccess)
+		return;
+	if (advanced)
+		hipLaunchKernelGGL((CountingPackedKernel<NREG, true>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+	else
+		hipLaunchKernelGGL((CountingPackedKernel<NREG, false>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+	*err = hipGetLastError();
+}
+
+int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg = 0)
 {
 	if (p.n == 0)
 		return PIRE_HIP_OK;
@@ -546,6 +769,40 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream)
 		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	if (e != hipSuccess)
 		return HipFail(e, "device query");
+	// Dense rows + packed 16-bit counters first (CountingPackedKernel); the strings it leaves on the overflow list
+	// (longer than 65 000 bytes) go through the 32-bit kernel below on the same stream.
+	void* list = nullptr;
+	struct ListGuard {
+		void*& q;
+		hipStream_t s;
+		~ListGuard()
+		{
+			if (q)
+				(void)hipFreeAsync(q, s);
+		}
+	} listGuard{list, stream};
+	if (nreg && p.dense && kind != PIRE_HIP_COUNTING_NOGLUELIMIT && p.n < (1ull << 32) - 1) {
+		e = hipMallocAsync(&list, (size_t(p.n) + 1) * 4, stream);
+		if (e == hipSuccess)
+			e = hipMemsetAsync(list, 0, 4, stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(counting overflow list)");
+		p.overflow = static_cast<uint32_t*>(list);
+		const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
+		const unsigned pblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
+		const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
+		switch (nreg) {
+		case 1: LaunchPacked<1>(p, adv, pblocks, packedLds, stream, &e); break;
+		case 2: LaunchPacked<2>(p, adv, pblocks, packedLds, stream, &e); break;
+		case 4: LaunchPacked<4>(p, adv, pblocks, packedLds, stream, &e); break;
+		default: LaunchPacked<8>(p, adv, pblocks, packedLds, stream, &e); break;
+		}
+		if (e != hipSuccess)
+			return HipFail(e, "counting kernel launch");
+		NoteKernel("counting_packed");
+	} else {
+		NoteKernel("counting");
+	}
 	const uint64_t tableBytes = uint64_t(p.states) * p.letters * 8;
 	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;   // several 256-thread blocks per CU stay resident
 	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
@@ -697,19 +954,24 @@ try {
 	}
 	p.letterOf = image.letterOf;
 	p.trans = image.trans;
+	p.dense = image.dense;
+	p.denseMarks = image.denseMarks;
+	p.actWords = image.actWords;
 	p.states = t->host.states;
 	p.letters = t->host.letters;
 	p.regexps = t->host.regexps;
 	p.initial = t->host.initial;
 	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
 	p.n = n;
+	// PIRE_HIP_RUN_GENERIC keeps the 32-bit kernel alone (the tests compare the two)
+	const uint32_t nreg = (flags & PIRE_HIP_RUN_GENERIC) ? 0 : t->host.nreg;
 	const uint32_t R = std::max<uint32_t>(t->host.regexps, 1);
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
 		p.outIdx = out_state_idx;
 		p.outResults = out_results;
-		return LaunchCounting(p, kind, stream);
+		return LaunchCounting(p, kind, stream, nreg);
 	}
 	for (uint64_t i = 0; i < n; ++i)
 		if (offsets[i] > offsets[i + 1]) {
@@ -734,7 +996,7 @@ try {
 	p.offsets = dOffs;
 	p.outIdx = static_cast<uint32_t*>(dIdx);
 	p.outResults = static_cast<uint32_t*>(dRes);
-	if ((rc = LaunchCounting(p, kind, stream)))
+	if ((rc = LaunchCounting(p, kind, stream, nreg)))
 		return rc;
 	hipError_t e = hipSuccess;
 	if (out_state_idx)

@@ -283,8 +283,12 @@ __global__ __launch_bounds__(1024) void SlowScanKernel(SlowParams p)
 		// Run<SlowScanner>, slow.h:436-451 -- byte by byte; 16-byte vector loads where the pointer allows
 		for (; ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15); ++ptr)
 			lane.Step(masks, single, p.letters, ldsLetter[*ptr]);
+		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
+		uint4 ahead = ptr + 16 <= end ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
 		for (; ptr + 16 <= end; ptr += 16) {
-			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+			uint4 v = ahead;
+			if (ptr + 32 <= end)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
 #pragma unroll 1
 			for (int i = 0; i < 16; ++i) {
 				lane.Step(masks, single, p.letters, ldsLetter[v.x & 0xFF]);
@@ -434,8 +438,12 @@ __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
 		const uint8_t* end = p.text + e;
 		for (; ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15); ++ptr)
 			ListStep(tabBase, ldsLetter4[*ptr], lst, ovf);
+		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
+		uint4 ahead = ptr + 16 <= end ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
 		for (; ptr + 16 <= end; ptr += 16) {
-			uint4 v = *reinterpret_cast<const uint4*>(ptr);
+			uint4 v = ahead;
+			if (ptr + 32 <= end)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
 #pragma unroll 1
 			for (int i = 0; i < 16; ++i) {
 				ListStep(tabBase, ldsLetter4[v.x & 0xFF], lst, ovf);

@@ -142,3 +142,37 @@ def test_gpu_counting_big_batches(pa, name):
         gi, gr = t.run_strings(many, flags=flags)
         assert (gi == oi).all() and (gr == orr).all(), (name, flags)
     assert orr.sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 3, 4, 7, 16])
+def test_gpu_counting_packed_kernel_and_its_overflow_list(pa, k):
+    """CountingScanner / AdvancedCountingScanner take the dense-row kernel with packed 16-bit counters first
+    (CountingPackedKernel: 1, 2, 4 or 8 registers of counter pairs); strings longer than 65 000 bytes -- a count could
+    outgrow 16 bits -- go onto its overflow list and through the 32-bit kernel.  Both kernels (PIRE_HIP_RUN_GENERIC
+    keeps the 32-bit one alone) against the oracle, with counts beyond 65 535 in the batch."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from pire_amd import binding as pb
+
+    res_ = (["a", "b", "ab", "[ab]+", "c", "bc", "d", "abc", "ca"] + ["[a-c]%d" % i for i in range(7)])[:k]
+    seps = ([".*", "\\s", ".*", "c", ".*", ".*", "\\s", ".*", ".*"] + [".*"] * 7)[:k]
+    rng = np.random.RandomState(50 + k)
+    many = H.random_strings(rng, 1500, 300, b"abcd \n012") + [b"", b"a"]
+    many += [b"a " * 40000, bytes(rng.choice(np.frombuffer(b"abcd \n", dtype=np.uint8), size=70001)), b"ab" * 32499]
+    for kind in (0, 1):
+        try:
+            blob = ob.RefCountingScanner.compile(kind, res_, seps).save()
+        except ValueError:
+            continue            # this class cannot glue that many
+        t, o = pa.CountingTable(blob, kind), ob.OracleCountingScanner(blob, kind)
+        for flags in (3, 0):
+            oi, orr = o.run_strings(many, flags=flags)
+            gi, gr = t.run_strings(many, flags=flags)
+            packed = pb.last_kernel() == "counting_packed"
+            assert (gi == oi).all() and (gr == orr).all(), (k, kind, flags, pb.last_kernel())
+            hi, hr = t.run_strings(many, flags=flags | pb.FLAG_GENERIC)
+            assert pb.last_kernel() == "counting"
+            assert (hi == oi).all() and (hr == orr).all(), (k, kind, flags)
+        assert packed or t.Size * 512 > 56 * 1024, "a table of %d states should have taken the packed kernel" % t.Size
+        assert orr.max() > 20000

@@ -29,17 +29,25 @@ R = t.RegexpsCount
 idx = torch.empty(m, dtype=torch.int32, device="cuda")
 res = torch.empty((m, R), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-ts = []
-for _ in range(4):
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+generic = pire_amd.binding.FLAG_GENERIC if len(sys.argv) > 2 and sys.argv[2] == "generic" else 0   # the 32-bit kernel alone
+
+
+def launch():
+    t.run_device(d.data_ptr(), do.data_ptr(), m, 3 | generic, idx.data_ptr(), res.data_ptr(), stream)
+
+
+# settled clocks: ~40 ms of back-to-back launches, then 20 timed ones back to back
+for _ in range(50):
+    launch()
+ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+for a, b in ev:
     a.record()
-    t.run_device(d.data_ptr(), do.data_ptr(), m, 3, idx.data_ptr(), res.data_ptr(), stream)
+    launch()
     b.record()
-    torch.cuda.synchronize()
-    ts.append(a.elapsed_time(b))
-ms = min(ts[1:])
-print("counting %s (re %s sep %s, %d states x %d letters, %d regexps): %d strings, %.3f GiB: %.3f ms -> %.1f GB/s; totals %s"
-      % (name, case["re"], case["sep"], t.Size, t.LettersCount, R, m, total / 2**30, ms, total / ms / 1e6, res.sum(dim=0).tolist()))
+torch.cuda.synchronize()
+ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+print("counting[%s] %s (re %s sep %s, %d states x %d letters, %d regexps): %d strings, %.3f GiB: %.3f ms -> %.1f GB/s; totals %s"
+      % (pire_amd.binding.last_kernel(), name, case["re"], case["sep"], t.Size, t.LettersCount, R, m, total / 2**30, ms, total / ms / 1e6, res.sum(dim=0).tolist()))
 if ob.ref_available():
     r = ob.RefCountingScanner.load(case["kind"], blob)
     k = 1 << 17
