@@ -485,6 +485,75 @@ __global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
 	}
 }
 
+// The same walk with ONE lookup per byte: dense rows indexed by the input byte, entry = next state | action << 8
+// (BuildDenseCounting: <= 255 states; the action is the raw 2-bit capture action, not an id), the action applied while
+// the next lookup is on its way, the text requested 16 bytes ahead -- the recipe of CountingPackedKernel.  For the
+// capture scanners that are in an action state on most bytes and therefore stay off the ragged kernel.
+__global__ __launch_bounds__(256) void CaptureDenseKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint16_t* dense = reinterpret_cast<uint16_t*>(lds);
+	for (uint32_t i = threadIdx.x; i < p.states * 128; i += blockDim.x)
+		reinterpret_cast<uint32_t*>(dense)[i] = reinterpret_cast<const uint32_t*>(p.dense)[i];
+	__syncthreads();
+	constexpr uint32_t npos = ~uint32_t(0);
+	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+		uint32_t st = p.initial;
+		uint32_t begin = npos, end = npos, counter = 0, pend = 0, pendAt = 0;
+		auto take = [&]() {   // TakeAction, capture.h:96-102, for the step that set `pend`, at m_counter - 1 = pendAt
+			const bool open = !(begin != npos && end != npos);
+			const bool setBegin = (pend & 1u) && open;
+			const bool setEnd = !(pend & 1u) && (pend & 2u) && open;
+			begin = setBegin ? pendAt : begin;
+			end = setEnd ? pendAt : end;
+		};
+		auto step = [&](uint32_t entry) {
+			if (pend)
+				take();
+			st = entry & 0xFFu;
+			pend = entry >> 8;
+			pendAt = counter++;
+		};
+		if (p.flags & PIRE_HIP_RUN_BEGIN)
+			step(p.denseMarks[st * 2]);
+		const uint8_t* ptr = p.text + p.offsets[s];
+		const uint8_t* stop = p.text + p.offsets[s + 1];
+		while (ptr < stop && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
+			step(dense[st * 256 + *ptr]);
+			++ptr;
+		}
+		uint4 ahead = ptr + 16 <= stop ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
+		for (; ptr + 16 <= stop; ptr += 16) {
+			uint4 v = ahead;
+			if (ptr + 32 <= stop)
+				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
+#pragma unroll 1
+			for (int i = 0; i < 4; ++i) {
+				const uint32_t x = v.x;
+				step(dense[st * 256 + (x & 0xFF)]);
+				step(dense[st * 256 + ((x >> 8) & 0xFF)]);
+				step(dense[st * 256 + ((x >> 16) & 0xFF)]);
+				step(dense[st * 256 + (x >> 24)]);
+				v.x = v.y;
+				v.y = v.z;
+				v.z = v.w;
+			}
+		}
+		for (; ptr < stop; ++ptr)
+			step(dense[st * 256 + *ptr]);
+		if (p.flags & PIRE_HIP_RUN_END)
+			step(p.denseMarks[st * 2 + 1]);
+		if (pend)
+			take();
+		if (p.outIdx)
+			p.outIdx[s] = st;
+		if (p.outFinal)
+			p.outFinal[s] = p.tags[st] & 1u;                  // Final, capture.h:134 (FinalFlag = 1)
+		p.outBegin[s] = begin == npos ? -1ll : (long long)begin;
+		p.outEnd[s] = end == npos ? -1ll : (long long)end;
+	}
+}
+
 namespace {
 
 struct RefHeader {
@@ -514,6 +583,14 @@ void BuildDenseCounting(CountingHost& t)
 	if (size_t(t.states) * 512 + 256 * 2 * nreg * 4 > 60 * 1024)
 		return;
 	std::vector<uint32_t> ids;   // distinct non-zero action words, id = index + 1
+	// tables whose action words all fit a byte (CapturingScanner: 1 = BeginCapture, 2 = EndCapture) keep them as ids:
+	// CaptureDenseKernel reads the action itself out of the entry
+	uint32_t maxAction = 0;
+	for (uint64_t x : t.trans)
+		maxAction = std::max(maxAction, uint32_t(x >> 32));
+	if (maxAction <= 255)
+		for (uint32_t a = 1; a <= maxAction; ++a)
+			ids.push_back(a);
 	auto idOf = [&](uint32_t a) -> uint32_t {
 		if (!a)
 			return 0;
@@ -1151,6 +1228,26 @@ try {
 	                        int(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	// one string per lane: the dense-row kernel when the table has the dense form (<= 255 states), else letter + transition
+	p.dense = image.dense;
+	p.denseMarks = image.denseMarks;
+	auto launchPerLane = [&]() -> int {
+		hipError_t le;
+		if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
+			const uint32_t denseLds = p.states * 512;
+			le = hipFuncSetAttribute(reinterpret_cast<const void*>(CaptureDenseKernel),
+			                         hipFuncAttributeMaxDynamicSharedMemorySize, int(denseLds));
+			if (le != hipSuccess)
+				return HipFail(le, "hipFuncSetAttribute(LDS)");
+			NoteKernel("capture_dense");
+			hipLaunchKernelGGL(CaptureDenseKernel, dim3(blocks), dim3(256), denseLds, stream, p);
+		} else {
+			NoteKernel("capture");
+			hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
+		}
+		le = hipGetLastError();
+		return le == hipSuccess ? PIRE_HIP_OK : HipFail(le, "capture kernel launch");
+	};
 	// Batches of >= 256 strings ride the ragged kernel with actions (the expanded table of BuildCaptureTable):
 	// 2-3 x the one-string-per-lane kernel below, which keeps the small batches and PIRE_HIP_RUN_GENERIC.
 	auto ragged = [&](const uint8_t* dText, const uint64_t* dOffs, uint32_t* dIdx, uint8_t* dFin, long long* dB,
@@ -1171,7 +1268,7 @@ try {
 		// one: =(\d+)[^\d] re-arms BeginCapture on every byte in front of the match (99.5 % of the steps on the benchmark
 		// text, measured), (/to-match-with) on 2 %, google_id\s*=... on none.  The share of the byte model's visits that
 		// fall on action states (the expanded table's "Final" share, table.cpp) decides; either kernel is exact.
-		if (sp.finalShare > 0.01f && !GetConfig().ragged_act_always)
+		if (sp.finalShare > 0.002f && !GetConfig().ragged_act_always)   // (2 % of the steps = a third of the chunks re-walked: 740 GB/s, the dense-row kernel does 1 000)
 			return PIRE_HIP_OK;
 		sp.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
 		sp.n = n;
@@ -1198,10 +1295,7 @@ try {
 			return rc;
 		if (done)
 			return PIRE_HIP_OK;
-		NoteKernel("capture");
-		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
-		e = hipGetLastError();
-		return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "capture kernel launch");
+		return launchPerLane();
 	}
 	for (uint64_t i = 0; i < n; ++i)
 		if (offsets[i] > offsets[i + 1]) {
@@ -1231,11 +1325,9 @@ try {
 	bool done = false;
 	if ((rc = ragged(p.text, p.offsets, p.outIdx, p.outFinal, p.outBegin, p.outEnd, &done)))
 		return rc;
-	if (!done) {
-		NoteKernel("capture");
-		hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
-	}
-	e = hipGetLastError();
+	if (!done && (rc = launchPerLane()))
+		return rc;
+	e = hipSuccess;
 	if (e == hipSuccess && out_state_idx)
 		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
 	if (e == hipSuccess && out_final)

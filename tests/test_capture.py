@@ -79,13 +79,18 @@ def test_gpu_capture_parity(case, pa, cfg):
         b = t.capture(*H.pack(many), flags=flags)                       # >= 256 strings: the ragged kernel with actions
         assert pb.last_kernel() == "ragged_capture"
         assert all((x == y).all() for x, y in zip(a, b)), flags
-        c = t.capture(*H.pack(many), flags=flags | pb.FLAG_GENERIC)     # the one-string-per-lane kernel
+        c = t.capture(*H.pack(many), flags=flags | pb.FLAG_GENERIC)     # the plain one-string-per-lane kernel
         assert pb.last_kernel() == "capture"
         assert all((x == y).all() for x, y in zip(a, c)), flags
+        cfg.set(ragged_act_always=0, no_ragged_act=1)                   # ... and its dense-row form
+        d = t.capture(*H.pack(many), flags=flags)
+        assert pb.last_kernel() == "capture_dense"
+        assert all((x == y).all() for x, y in zip(a, d)), flags
+        cfg.set(ragged_act_always=1, no_ragged_act=0)
     assert a[2].sum() > 0
     # left to itself the library keeps the one-string-per-lane kernel for scanners that are in an action state on most
     # bytes of text (=(\d+)[^\d] re-arms BeginCapture all the time), and takes the ragged one for the others
     cfg.set(ragged_act_always=0)
     b = t.capture(*H.pack(many))
-    assert pb.last_kernel() == ("capture" if case["name"] == "capture_digits" else "ragged_capture") or case["name"] == "capture_path"
+    assert pb.last_kernel() == {"capture_digits": "capture_dense", "capture_google": "ragged_capture"}.get(case["name"], pb.last_kernel())
     assert all((x == y).all() for x, y in zip(o.capture(*ob.pack_strings(many)), b))
