@@ -103,6 +103,9 @@ typedef struct pire_hip_config {
 	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
 	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */
 	                               /* 2 the stream-ordered pool (hipMallocAsync): measurements                          */
+	uint32_t no_offsets_peek;      /* 1: pire_hip_run with device offsets never reads offsets back (enqueue-only even for */
+	                               /* small batches; few long strings then walk one per lane)                            */
+	uint32_t reserved1;
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -244,12 +247,15 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
  * scanner are valid (tests/pire_ut.cpp:760-837).  Offsets are byte offsets into text, non-decreasing.
  * `stream` is a hipStream_t (NULL = default stream).
  *
- * Few long strings (strings of 8 KiB or more on average, too few of them to keep the lanes busy; lengths known to
- * the host: host pointers, or pire_hip_run_strided) are cut into segments that are scanned in parallel from guessed
- * start states; the chain of segments is then composed on the device and only results computed from the true state
- * are accepted, so the answers are the same (pire_amd/csrc/segmented.hip: one 1 GiB string in 0.54 ms instead of
- * 45 s).  Such a call synchronises `stream` even with PIRE_HIP_RUN_ON_DEVICE.
- * PIRE_HIP_RUN_GENERIC (or the environment variable PIRE_HIP_NO_SEGMENTS) keeps one string per lane.
+ * Few long strings (strings of 8 KiB or more on average, too few of them to keep the lanes busy) are cut into
+ * segments that are scanned in parallel from guessed start states; the chain of segments is then composed on the
+ * device and only results computed from the true state are accepted, so the answers are the same
+ * (pire_amd/csrc/segmented.hip: one 1 GiB string in 0.54 ms instead of 45 s).  The host has to know the lengths for
+ * that: host pointers, pire_hip_run_strided, PIRE_HIP_RUN_HOST_OFFSETS -- and, for offsets that live on the device, a
+ * batch of fewer than 65 536 strings is PEEKED at: its first and last offset are read back (which synchronises
+ * `stream`), and all of them only if the segmented scan is then chosen (pire_hip_config.no_offsets_peek = 1 keeps such
+ * calls enqueue-only).  A segmented call synchronises `stream` even with PIRE_HIP_RUN_ON_DEVICE.
+ * PIRE_HIP_RUN_GENERIC (or pire_hip_config.no_segments) keeps one string per lane.
  */
 int pire_hip_run(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n,
                  uint32_t flags, const uint32_t* init_state_idx,

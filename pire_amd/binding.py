@@ -104,6 +104,8 @@ class Config(C.Structure):
         ("auto_adapt_min_traps", C.c_uint32),
         ("ragged_variant", C.c_uint32),
         ("host_staging", C.c_uint32),
+        ("no_offsets_peek", C.c_uint32),
+        ("reserved1", C.c_uint32),
     ]
 
 
@@ -229,7 +231,7 @@ def set_config(**fields) -> Config:
     old = get_config()
     new = get_config()
     for k, v in fields.items():
-        if k not in dict(Config._fields_) or k == "size":
+        if k not in dict(Config._fields_) or k in ("size", "reserved1"):
             raise KeyError(k)
         setattr(new, k, int(v))
     _check(lib().pire_hip_config_set(C.byref(new)))

@@ -220,6 +220,7 @@ pire_hip_config SeedFromEnvironment()
 	c.auto_adapt_min_traps = uint32_t(EnvU64("PIRE_HIP_AUTO_ADAPT_MIN_TRAPS"));
 	c.ragged_variant = uint32_t(EnvU64("PIRE_HIP_RAGGED_VARIANT"));
 	c.host_staging = uint32_t(EnvU64("PIRE_HIP_HOST_STAGING"));
+	c.no_offsets_peek = EnvU64("PIRE_HIP_NO_OFFSETS_PEEK") != 0;
 	return c;
 }
 
@@ -617,6 +618,37 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		// device offsets the host does not know the lengths, so only fixed-length records qualify here.
 		if (!offsets && !(flags & PIRE_HIP_RUN_GENERIC) && n && SegmentedEligible(n, n * len))
 			return RunSegmented(t, p, nullptr, stream);
+		// Offsets on the device: the host does not know the lengths, and a handful of long strings would walk one per
+		// lane at 25 MB/s each (a single 1 GiB string: 45 s against 0.5 ms segmented).  A batch small enough to leave
+		// lanes idle (n < 65 536) is therefore PEEKED at: two words (first and last offset) come back -- which
+		// synchronises `stream` -- and only if the cost model then asks for the segmented scan are all n + 1 offsets
+		// fetched (<= 512 KB).  pire_hip_config.no_offsets_peek keeps such calls enqueue-only.
+		if (offsets && n && n < 65536 && !(flags & PIRE_HIP_RUN_GENERIC) && !GetConfig().no_offsets_peek) {
+			uint64_t ends[2] = {0, 0};
+			hipError_t e = hipMemcpyAsync(&ends[0], offsets, 8, hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess)
+				e = hipMemcpyAsync(&ends[1], offsets + n, 8, hipMemcpyDeviceToHost, stream);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(stream);
+			if (e != hipSuccess)
+				return HipFail(e, "reading the first and last offset back");
+			const uint64_t total = ends[1] >= ends[0] ? ends[1] - ends[0] : 0;
+			if (SegmentedEligible(n, total)) {
+				std::vector<uint64_t> hostOffsets(size_t(n) + 1);
+				e = hipMemcpyAsync(hostOffsets.data(), offsets, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, stream);
+				if (e == hipSuccess)
+					e = hipStreamSynchronize(stream);
+				if (e != hipSuccess)
+					return HipFail(e, "reading the offsets back");
+				for (uint64_t i = 0; i < n; ++i)
+					if (hostOffsets[i] > hostOffsets[i + 1]) {
+						SetError("offsets must be non-decreasing");
+						return PIRE_HIP_EINVAL;
+					}
+				return RunSegmented(t, p, hostOffsets.data(), stream);
+			}
+			return Dispatch(p, stream, NextWorkSlot(t, p), total);
+		}
 		return Dispatch(p, stream, NextWorkSlot(t, p), offsets ? ~0ull : 0);
 	}
 

@@ -181,6 +181,41 @@ def test_resident_text_with_host_offsets():
         t.run_device_host_offsets(d.data_ptr(), np.array([0, 10, 5], dtype=np.uint64), 3, 0, 0, 0, 0, stream)
 
 
+def test_device_offsets_are_peeked_at_so_that_few_long_strings_take_the_segmented_scan(cfg):
+    """Offsets on the DEVICE: the host does not know the lengths, and round 2 left such batches one string per lane
+    whatever their shape.  A batch of fewer than 65 536 strings is now peeked at (first and last offset read back): few
+    long documents take the segmented scan, many short ones the ragged kernel, and pire_hip_config.no_offsets_peek
+    keeps the call enqueue-only (one string per lane).  Same results every way."""
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    total = 6 << 20
+    data = ob.corpus_fill(big["corpus"]["seed"], 0, total // 4096, 4096, H.plants_for(big)).reshape(-1)
+    d = torch.as_tensor(np.array(data), device="cuda")
+    rng = np.random.RandomState(13)
+    stream = torch.cuda.current_stream().cuda_stream
+    for n, lead, kernel in ((5, 0, "segmented"), (3, 4097, "segmented"), (20000, 0, "ragged")):
+        cuts = np.sort(rng.choice(np.arange(lead + 1, total), size=n - 1, replace=False)).astype(np.uint64)
+        offs = np.concatenate([[lead], cuts, [total]]).astype(np.uint64)        # offsets[0] need not be 0
+        oi, of = o.run(data, offs, threads=4)
+        do = torch.as_tensor(offs.astype(np.int64), device="cuda")
+        for peek in (True, False):
+            cfg.set(no_offsets_peek=0 if peek else 1)
+            idx = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            fin = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+            cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+            t.run_device(d.data_ptr(), do.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), cnt.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            assert pb.last_kernel().startswith(kernel if peek else ("generic" if n < 256 else "ragged")), (n, peek, pb.last_kernel())
+            assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all(), (n, peek)
+            assert int(cnt[1]) == n and int(cnt[0]) == int(of.sum())
+
+
+
 def test_concurrent_threads_segmented_scans_on_one_table():
     """Four host threads, each on its own stream, run segmented scans of different texts on ONE table (learning and
     sharing its modes) at the same time; every result must equal the oracle's."""
