@@ -80,6 +80,42 @@ int StagingAcquire(size_t bytes, void** out, size_t* blockBytes)
 	return PIRE_HIP_OK;
 }
 
+namespace {
+StagingCache g_pinnedCache;   // host blocks are not per device
+}
+int StagingAcquireHost(size_t bytes, void** out, size_t* blockBytes)
+{
+	*out = nullptr;
+	const int c = SizeClass(bytes);
+	*blockBytes = size_t(1) << c;
+	{
+		std::lock_guard<std::mutex> lock(g_pinnedCache.mutex);
+		if (!g_pinnedCache.free[c].empty()) {
+			*out = g_pinnedCache.free[c].back();
+			g_pinnedCache.free[c].pop_back();
+			g_pinnedCache.cached -= *blockBytes;
+			return PIRE_HIP_OK;
+		}
+	}
+	const hipError_t e = hipHostMalloc(out, *blockBytes, hipHostMallocDefault);
+	if (e != hipSuccess)
+		return HipFail(e, "hipHostMalloc(staging)");
+	return PIRE_HIP_OK;
+}
+
+void StagingReleaseHost(void* p, size_t blockBytes)
+{
+	{
+		std::lock_guard<std::mutex> lock(g_pinnedCache.mutex);
+		if (g_pinnedCache.cached + blockBytes <= (size_t(64) << 20)) {
+			g_pinnedCache.free[SizeClass(blockBytes)].push_back(p);
+			g_pinnedCache.cached += blockBytes;
+			return;
+		}
+	}
+	(void)hipHostFree(p);
+}
+
 void StagingRelease(void* p, size_t blockBytes)
 {
 	int dev = -1;
@@ -1226,18 +1262,12 @@ try {
 	if (!counted)
 		if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t, p)))
 			return rc;
-	hipError_t e = hipSuccess;
-	if (out_state_idx)
-		e = hipMemcpyAsync(out_state_idx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && out_final)
-		e = hipMemcpyAsync(out_final, dFin, size_t(n), hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && R)
-		e = hipMemcpyAsync(out_results, dRes, size_t(n) * R * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "copy back / synchronize");
-	return PIRE_HIP_OK;
+	int rc = st.Out(out_state_idx, dIdx, size_t(n) * 4);
+	if (!rc)
+		rc = st.Out(out_final, dFin, size_t(n));
+	if (!rc && R)
+		rc = st.Out(out_results, dRes, size_t(n) * R * 4);
+	return rc ? rc : st.Finish();
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
@@ -1289,12 +1319,9 @@ try {
 	if (int rc = LaunchPrefix(p, longest != 0, through_end != 0, static_cast<long long*>(dOut), stream,
 	                          (flags & PIRE_HIP_RUN_GENERIC) ? nullptr : NextWorkSlot(t, p)))
 		return rc;
-	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "copy back / synchronize");
-	return PIRE_HIP_OK;
+	if (int rc = st.Out(out_len, dOut, size_t(n) * 8))
+		return rc;
+	return st.Finish();
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
@@ -1435,12 +1462,9 @@ try {
 		return rc;
 	if (int rc = LaunchSuffix(p, longest != 0, through_begin != 0, static_cast<long long*>(dOut), stream))
 		return rc;
-	hipError_t e = hipMemcpyAsync(out_len, dOut, size_t(n) * 8, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "copy back / synchronize");
-	return PIRE_HIP_OK;
+	if (int rc = st.Out(out_len, dOut, size_t(n) * 8))
+		return rc;
+	return st.Finish();
 } catch (...) {
 	return pirehip::HandleException();
 }

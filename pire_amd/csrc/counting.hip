@@ -1075,16 +1075,10 @@ try {
 	p.outResults = static_cast<uint32_t*>(dRes);
 	if ((rc = LaunchCounting(p, kind, stream, nreg)))
 		return rc;
-	hipError_t e = hipSuccess;
-	if (out_state_idx)
-		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && t->host.regexps)
-		e = hipMemcpyAsync(out_results, dRes, n * t->host.regexps * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "counting run (copy back / synchronize)");
-	return PIRE_HIP_OK;
+	rc = stage.Out(out_state_idx, dIdx, n * 4);
+	if (!rc && t->host.regexps)
+		rc = stage.Out(out_results, dRes, n * t->host.regexps * 4);
+	return rc ? rc : stage.Finish();
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
@@ -1327,20 +1321,14 @@ try {
 		return rc;
 	if (!done && (rc = launchPerLane()))
 		return rc;
-	e = hipSuccess;
-	if (e == hipSuccess && out_state_idx)
-		e = hipMemcpyAsync(out_state_idx, dIdx, n * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && out_final)
-		e = hipMemcpyAsync(out_final, dFin, n, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(out_begin, dB, n * 8, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipMemcpyAsync(out_end, dE, n * 8, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "capture run");
-	return PIRE_HIP_OK;
+	rc = stage.Out(out_state_idx, dIdx, n * 4);
+	if (!rc)
+		rc = stage.Out(out_final, dFin, n);
+	if (!rc)
+		rc = stage.Out(out_begin, dB, n * 8);
+	if (!rc)
+		rc = stage.Out(out_end, dE, n * 8);
+	return rc ? rc : stage.Finish();
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }

@@ -5,6 +5,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <atomic>
 #include <mutex>
 #include <shared_mutex>
@@ -285,16 +286,29 @@ int HipFail(hipError_t e, const char* what);   // sets the error, returns PIRE_H
 // stream-ordered pool.
 int StagingAcquire(size_t bytes, void** out, size_t* blockBytes);
 void StagingRelease(void* p, size_t blockBytes);
+// the same for PINNED host blocks: small inputs and results cross PCIe from / into pinned memory (a copy between
+// pageable memory and the device goes through the runtime's own staging and costs 10-15 us a piece, which is most of
+// a 10-string call), and the caller's pageable arrays are touched with plain memcpy
+int StagingAcquireHost(size_t bytes, void** out, size_t* blockBytes);
+void StagingReleaseHost(void* p, size_t blockBytes);
 struct Staging {
-	std::vector<void*> ptrs;
-	std::vector<size_t> sizes;
+	std::vector<void*> ptrs, hostPtrs;
+	std::vector<size_t> sizes, hostSizes;
+	struct Deferred {
+		void* dst;
+		const void* pinned;
+		size_t bytes;
+	};
+	std::vector<Deferred> deferred;   // results waiting in pinned blocks for Finish()
 	hipStream_t stream = nullptr;
 	uint32_t mode = 1;   // a default-constructed Staging is round 2's
+	bool drained = false;
+	static constexpr size_t kPinnedMax = size_t(1) << 20;   // larger pieces go straight from / to the caller's memory
 	Staging() {}
 	explicit Staging(hipStream_t s) : stream(s), mode(GetConfig().host_staging) {}
 	~Staging()
 	{
-		if (mode == 0 && !ptrs.empty())
+		if (mode == 0 && !drained && (!ptrs.empty() || !hostPtrs.empty()))
 			(void)hipStreamSynchronize(stream);
 		for (size_t i = 0; i < ptrs.size(); ++i) {
 			if (mode == 0)
@@ -304,6 +318,8 @@ struct Staging {
 			else
 				(void)hipFree(ptrs[i]);
 		}
+		for (size_t i = 0; i < hostPtrs.size(); ++i)
+			StagingReleaseHost(hostPtrs[i], hostSizes[i]);
 	}
 	int Alloc(void** out, size_t bytes)
 	{
@@ -321,18 +337,64 @@ struct Staging {
 		sizes.push_back(block);
 		return PIRE_HIP_OK;
 	}
+	int Pinned(void** out, size_t bytes)
+	{
+		size_t block = 0;
+		if (int rc = StagingAcquireHost(bytes, out, &block))
+			return rc;
+		hostPtrs.push_back(*out);
+		hostSizes.push_back(block);
+		return PIRE_HIP_OK;
+	}
 	template <class T>
 	int In(const T* host, size_t count, const T** dev, hipStream_t s)
 	{
 		void* d;
-		if (int rc = Alloc(&d, count * sizeof(T)))
+		const size_t bytes = count * sizeof(T);
+		if (int rc = Alloc(&d, bytes))
 			return rc;
 		if (count) {
-			hipError_t e = hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, s);
+			const void* src = host;
+			if (mode == 0 && bytes <= kPinnedMax) {
+				void* pin = nullptr;
+				if (int rc = Pinned(&pin, bytes))
+					return rc;
+				memcpy(pin, host, bytes);
+				src = pin;
+			}
+			hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, s);
 			if (e != hipSuccess)
 				return HipFail(e, "hipMemcpy(H2D)");
 		}
 		*dev = static_cast<const T*>(d);
+		return PIRE_HIP_OK;
+	}
+	// Result `bytes` from device memory into the caller's array: enqueued now, in the caller's array after Finish()
+	int Out(void* hostDst, const void* dev, size_t bytes)
+	{
+		if (!bytes || !hostDst)
+			return PIRE_HIP_OK;
+		void* dst = hostDst;
+		if (mode == 0 && bytes <= kPinnedMax) {
+			void* pin = nullptr;
+			if (int rc = Pinned(&pin, bytes))
+				return rc;
+			deferred.push_back(Deferred{hostDst, pin, bytes});
+			dst = pin;
+		}
+		const hipError_t e = hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, stream);
+		return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipMemcpy(D2H)");
+	}
+	// Drain the stream, then hand the results that waited in pinned blocks to the caller's arrays
+	int Finish()
+	{
+		const hipError_t e = hipStreamSynchronize(stream);
+		if (e != hipSuccess)
+			return HipFail(e, "copy back / synchronize");
+		drained = true;
+		for (const Deferred& d : deferred)
+			memcpy(d.dst, d.pinned, d.bytes);
+		deferred.clear();
 		return PIRE_HIP_OK;
 	}
 };
