@@ -105,7 +105,7 @@ typedef struct pire_hip_config {
 	                               /* 2 the stream-ordered pool (hipMallocAsync): measurements                          */
 	uint32_t no_offsets_peek;      /* 1: pire_hip_run with device offsets never reads offsets back (enqueue-only even for */
 	                               /* small batches; few long strings then walk one per lane)                            */
-	uint32_t reserved1;
+	uint32_t segment_no_pair;      /* 1: the segmented scan never fuses two modes into one pass of the pair kernel       */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)

@@ -105,7 +105,7 @@ class Config(C.Structure):
         ("ragged_variant", C.c_uint32),
         ("host_staging", C.c_uint32),
         ("no_offsets_peek", C.c_uint32),
-        ("reserved1", C.c_uint32),
+        ("segment_no_pair", C.c_uint32),
     ]
 
 
@@ -231,7 +231,7 @@ def set_config(**fields) -> Config:
     old = get_config()
     new = get_config()
     for k, v in fields.items():
-        if k not in dict(Config._fields_) or k in ("size", "reserved1"):
+        if k not in dict(Config._fields_) or k == "size":
             raise KeyError(k)
         setattr(new, k, int(v))
     _check(lib().pire_hip_config_set(C.byref(new)))

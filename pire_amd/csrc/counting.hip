@@ -813,8 +813,7 @@ int UploadCounting(pire_hip_counting_table* t, CountingDevice* image)
 template <int RMAX, int KIND>
 void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
-	*err = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingKernel<RMAX, KIND>),
-	                           hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	*err = SetDynamicLds(reinterpret_cast<const void*>(CountingKernel<RMAX, KIND>), uint32_t(ldsBytes));
 	if (*err != hipSuccess)
 		return;
 	hipLaunchKernelGGL((CountingKernel<RMAX, KIND>), dim3(blocks), dim3(256), ldsBytes, stream, p);
@@ -826,7 +825,7 @@ void LaunchPacked(const CountingParams& p, bool advanced, unsigned blocks, uint3
 {
 	const void* fn = advanced ? reinterpret_cast<const void*>(CountingPackedKernel<NREG, true>)
 	                          : reinterpret_cast<const void*>(CountingPackedKernel<NREG, false>);
-	*err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	*err = SetDynamicLds(fn, uint32_t(ldsBytes));
 	if (*err != hipSuccess)
 		return;
 	if (advanced)
@@ -885,8 +884,7 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
 	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
 	if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT && p.regexps > kMaxReCount) {
-		e = hipFuncSetAttribute(reinterpret_cast<const void*>(CountingWideKernel),
-		                        hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+		e = SetDynamicLds(reinterpret_cast<const void*>(CountingWideKernel), uint32_t(ldsBytes));
 		if (e == hipSuccess) {
 			hipLaunchKernelGGL(CountingWideKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
 			e = hipGetLastError();
@@ -1218,8 +1216,7 @@ try {
 	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;
 	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
 	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, uint64_t(cus) * 8)));
-	e = hipFuncSetAttribute(reinterpret_cast<const void*>(CaptureKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        int(ldsBytes));
+	e = SetDynamicLds(reinterpret_cast<const void*>(CaptureKernel), uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	// one string per lane: the dense-row kernel when the table has the dense form (<= 255 states), else letter + transition
@@ -1229,8 +1226,7 @@ try {
 		hipError_t le;
 		if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
 			const uint32_t denseLds = p.states * 512;
-			le = hipFuncSetAttribute(reinterpret_cast<const void*>(CaptureDenseKernel),
-			                         hipFuncAttributeMaxDynamicSharedMemorySize, int(denseLds));
+			le = SetDynamicLds(reinterpret_cast<const void*>(CaptureDenseKernel), uint32_t(denseLds));
 			if (le != hipSuccess)
 				return HipFail(le, "hipFuncSetAttribute(LDS)");
 			NoteKernel("capture_dense");

@@ -592,18 +592,43 @@ inline int DeviceCUs(int* cus)
 }
 
 template <class K>
+hipError_t CachedOccupancy(int* perCu, K kernel, int threads, uint32_t ldsBytes)
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return e;
+	const LaunchCache::Key key = {dev, reinterpret_cast<const void*>(kernel), threads, ldsBytes};
+	LaunchCache& c = LaunchCache::Get();
+	{
+		std::lock_guard<std::mutex> lock(c.mutex);
+		for (auto& x : c.occupancy)
+			if (x.key == key) {
+				*perCu = x.value;
+				return hipSuccess;
+			}
+	}
+	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(perCu, kernel, threads, ldsBytes);
+	if (e != hipSuccess)
+		return e;
+	std::lock_guard<std::mutex> lock(c.mutex);
+	if (c.occupancy.size() < 4096)
+		c.occupancy.push_back({key, *perCu});
+	return hipSuccess;
+}
+
+template <class K>
 int LaunchScan(K kernel, const ScanParams& p, int threads, uint32_t ldsBytes, hipStream_t stream, int tasksPerBlock = 0)
 {
 	int cus = 0;
 	int rc = DeviceCUs(&cus);
 	if (rc)
 		return rc;
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(kernel), uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	int perCu = 0;
-	e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, threads, ldsBytes);
+	e = CachedOccupancy(&perCu, kernel, threads, ldsBytes);
 	if (e != hipSuccess)
 		return HipFail(e, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
 #ifdef PIRE_HIP_TUNING

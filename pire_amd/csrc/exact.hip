@@ -377,8 +377,7 @@ int LaunchPrefix(const ScanParams& p0, bool longest, bool throughEnd, long long*
 	if (int rc = DeviceCUs(&cus))
 		return rc;
 	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(PrefixKernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
+	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(PrefixKernel), uint32_t(L.total));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	PrefixParams q;
@@ -406,8 +405,7 @@ int LaunchSuffix(const ScanParams& p0, bool longest, bool throughBegin, long lon
 	if (int rc = DeviceCUs(&cus))
 		return rc;
 	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SuffixKernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total));
+	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(SuffixKernel), uint32_t(L.total));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	SuffixParams q;
@@ -442,7 +440,7 @@ int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stre
 	const uint32_t ldsBytes = L.total + 256 * 8;
 	const bool packed = p.incPerm != nullptr;
 	const void* fn = packed ? reinterpret_cast<const void*>(HalfFinalKernel<true>) : reinterpret_cast<const void*>(HalfFinalKernel<false>);
-	hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	hipError_t e = SetDynamicLds(fn, uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	const unsigned threads = unsigned(ExactBlockThreads(p.n));

@@ -435,6 +435,53 @@ bool SegmentedEligible(uint64_t n, uint64_t totalBytes);
 int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOffsets, hipStream_t stream,
                  uint32_t* halfFinalResults = nullptr,    // non-null: also HalfFinalScanner counts, [n][regexps] ...
                  bool* halfFinalIncomplete = nullptr);    // ... unless some string ended in the plain walk (then true)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the occupancy query cost the host several microseconds per
+// launch; what they say does not change: remembered per device and kernel (the LDS limit as a high-water mark).
+struct LaunchCache {
+	struct Key {
+		int dev;
+		const void* fn;
+		int threads;
+		uint32_t lds;
+		bool operator==(const Key& o) const { return dev == o.dev && fn == o.fn && threads == o.threads && lds == o.lds; }
+	};
+	struct Entry {
+		Key key;
+		int value;
+	};
+	std::mutex mutex;
+	std::vector<Entry> ldsMax, occupancy;
+	static LaunchCache& Get()
+	{
+		static LaunchCache c;
+		return c;
+	}
+};
+
+inline hipError_t SetDynamicLds(const void* fn, uint32_t ldsBytes)
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return e;
+	LaunchCache& c = LaunchCache::Get();
+	std::lock_guard<std::mutex> lock(c.mutex);
+	LaunchCache::Entry* found = nullptr;
+	for (auto& x : c.ldsMax)
+		if (x.key.dev == dev && x.key.fn == fn)
+			found = &x;
+	if (found && uint32_t(found->value) >= ldsBytes)
+		return hipSuccess;
+	e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	if (e != hipSuccess)
+		return e;
+	if (found)
+		found->value = int(ldsBytes);
+	else
+		c.ldsMax.push_back({{dev, fn, 0, 0}, int(ldsBytes)});
+	return hipSuccess;
+}
+
 void NoteKernel(const char* name, const char* symbol = nullptr);   // what pire_hip_last_kernel[_symbol]() report (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);
@@ -455,7 +502,9 @@ int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* 
                  unsigned long long* workCounter);
 // pair.hip: two scanners in one pass over fixed-length records (run.h:229-241)
 bool PairTiledEligible(const ScanParams& a, const ScanParams& b);
-int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream);
+// guessA != nullptr: the segmented scan's form (pair.hip, PairParams): warm-up inside the pass, the guesses written out
+int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream, uint64_t warmBytes = 0,
+                    const uint32_t* segJ = nullptr, uint32_t* guessA = nullptr, uint32_t* guessB = nullptr);
 int LaunchOrFinal(uint8_t* fin, const uint8_t* other, uint64_t n, hipStream_t stream);
 int LaunchSuffix(const ScanParams& p, bool longest, bool throughBegin, long long* outLen, hipStream_t stream);
 int LaunchCorpusFill(uint8_t* out, uint64_t seed, uint64_t first, uint64_t count, uint64_t len, uint64_t stride,

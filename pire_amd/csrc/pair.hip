@@ -27,6 +27,15 @@ struct PairSide {
 struct PairParams {
 	ScanParams a, b;
 	uint32_t* outIdxB;
+	// the segmented scan's use (SEG, segmented.hip): the same table twice, every record a segment walked under two
+	// guessed modes.  The warm-up that MAKES the guesses is part of the pass: a lane starts `warmTiles` 128-byte tiles
+	// before its segment in the two representatives' states, notes the two states it is in at the segment's first byte
+	// (guessA / guessB, device ids) and walks on.  A string's first segment (segJ == 0) has no warm-up: its guesses are
+	// the start states themselves and the bytes before it are somebody else's.
+	uint32_t warmTiles;
+	const uint32_t* segJ;
+	uint32_t* guessA;
+	uint32_t* guessB;
 };
 
 __device__ __forceinline__ uint32_t PairSlowStep(const ScanParams& p, const PairSide& S, uint32_t st, uint32_t byte)
@@ -58,6 +67,8 @@ __device__ __forceinline__ uint32_t HotLookupB(uint32_t addr)
 }
 
 // 16 bytes through both tables; a side that leaves its dense rows is re-walked exactly for that chunk.
+// SAME: both walks are in table A's rows (the segmented scan's two modes of one table).
+template <bool SAME>
 __device__ __forceinline__ void PairStepChunk(const PairParams& q, const PairSide& A, const PairSide& B, const u32x4 v,
                                               uint32_t& ha, uint32_t& ca, uint32_t& hb, uint32_t& cb)
 {
@@ -66,13 +77,13 @@ __device__ __forceinline__ void PairStepChunk(const PairParams& q, const PairSid
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t x = v[w];
 		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0400u));
-		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0400u));
+		hb = SAME ? HotLookup(__builtin_amdgcn_perm(hb, x, 0x0c0c0400u)) : HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0400u));
 		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0401u));
-		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0401u));
+		hb = SAME ? HotLookup(__builtin_amdgcn_perm(hb, x, 0x0c0c0401u)) : HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0401u));
 		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0402u));
-		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0402u));
+		hb = SAME ? HotLookup(__builtin_amdgcn_perm(hb, x, 0x0c0c0402u)) : HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0402u));
 		ha = HotLookup(__builtin_amdgcn_perm(ha, x, 0x0c0c0403u));
-		hb = HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0403u));
+		hb = SAME ? HotLookup(__builtin_amdgcn_perm(hb, x, 0x0c0c0403u)) : HotLookupB(__builtin_amdgcn_perm(hb, x, 0x0c0c0403u));
 	}
 	if (ha == A.hot) {
 		const uint32_t f = PairSlowChunk(q.a, A, v, ha0 != A.hot ? ha0 : ca);
@@ -80,19 +91,24 @@ __device__ __forceinline__ void PairStepChunk(const PairParams& q, const PairSid
 		ca = f;
 	}
 	if (hb == B.hot) {
-		const uint32_t f = PairSlowChunk(q.b, B, v, hb0 != B.hot ? hb0 : cb);
+		const uint32_t f = PairSlowChunk(SAME ? q.a : q.b, B, v, hb0 != B.hot ? hb0 : cb);
 		hb = f < B.hot ? f : B.hot;
 		cb = f;
 	}
 }
 
 template <bool NT>
-__device__ __forceinline__ void PairIssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride)
+__device__ __forceinline__ void PairIssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride, uint64_t low = 0)
 {
-	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	// `low`: the first byte of the text.  Only the warm-up tiles of the very first record (the first load's lanes 0..7)
+	// lie below it (SEG); those lanes read from the record itself instead, and what they read is never used.
+	uint32_t voff0 = voff;
+	if (tileBase < low)
+		voff0 += (threadIdx.x & 63) < 8 ? uint32_t(low - tileBase + 127) & ~127u : 0u;
+	const uint64_t b0 = tileBase, b1 = tileBase + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
 	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
 	asm volatile(
-		"global_load_dwordx4 %0, %8, %9 nt\n\t"
+		"global_load_dwordx4 %0, %17, %9 nt\n\t"
 		"global_load_dwordx4 %1, %8, %10 nt\n\t"
 		"global_load_dwordx4 %2, %8, %11 nt\n\t"
 		"global_load_dwordx4 %3, %8, %12 nt\n\t"
@@ -101,7 +117,7 @@ __device__ __forceinline__ void PairIssueTile(u32x4 (&r)[8], uint32_t voff, uint
 		"global_load_dwordx4 %6, %8, %15 nt\n\t"
 		"global_load_dwordx4 %7, %8, %16 nt"
 		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7), "v"(voff0));
 }
 
 template <int BEHIND>
@@ -134,29 +150,36 @@ __device__ inline void PairLoadRows(uint8_t* dst, const uint8_t* src, uint32_t s
 		d[hot * 64 + i] = hot * 0x01010101u;
 }
 
+template <bool SEG>
 __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const ScanParams& pa = q.a;
-	const ScanParams& pb = q.b;
+	const ScanParams& pb = SEG ? q.a : q.b;   // SEG: one table, walked twice (q.b only carries the second start state)
 	PairSide A, B;
-	A.hot = pa.hot < kPairHotA ? pa.hot : kPairHotA;
-	B.hot = pb.hot;
+	A.hot = SEG ? pa.hot : (pa.hot < kPairHotA ? pa.hot : kPairHotA);
 	A.rows = lds;
-	B.rows = lds + kPairBaseB;
-	uint8_t* tail = lds + kPairBaseB + (B.hot + 1) * 256;
+	uint8_t* tail = SEG ? lds + (A.hot + 1) * 256 : lds + kPairBaseB + (pb.hot + 1) * 256;
 	A.flags = tail;
-	B.flags = tail + 256;
 	A.cls = reinterpret_cast<const uint16_t*>(tail + 512);
-	B.cls = reinterpret_cast<const uint16_t*>(tail + 512 + 528);
+	if (SEG) {
+		B = A;
+	} else {
+		B.hot = pb.hot;
+		B.rows = lds + kPairBaseB;
+		B.flags = tail + 256;
+		B.cls = reinterpret_cast<const uint16_t*>(tail + 512 + 528);
+	}
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint64_t ntasks = pa.n / 64;
-	const uint32_t ntiles = uint32_t(pa.len / 128);   // even, >= 2 (the launcher checks)
+	const uint32_t warm = SEG ? q.warmTiles : 0;      // even (the launcher checks)
+	const uint32_t ntiles = uint32_t(pa.len / 128) + warm;   // even, >= 2 (the launcher checks)
 	const uint32_t lastTile = ntiles - 1;
 	const uint32_t voff = (lane & ~7u) * uint32_t(pa.stride) + (lane & 7u) * 16;
-	const uint64_t text = reinterpret_cast<uint64_t>(pa.text);
+	const uint64_t low = SEG ? reinterpret_cast<uint64_t>(pa.text) : 0;
+	const uint64_t text = reinterpret_cast<uint64_t>(pa.text) - uint64_t(warm) * 128;
 	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
 	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
 
@@ -165,19 +188,22 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 	ZeroTile(b);
 	bool primed = firstTask < ntasks;
 	if (primed)
-		PairIssueTile<true>(a, voff, Uniform64(text + firstTask * 64 * pa.stride), pa.stride);
+		PairIssueTile<true>(a, voff, Uniform64(text + firstTask * 64 * pa.stride), pa.stride, low);
 	PairLoadRows(lds, pa.hotRows, pa.hot, A.hot);
-	PairLoadRows(lds + kPairBaseB, pb.hotRows, pb.hot, B.hot);
+	if (!SEG)
+		PairLoadRows(lds + kPairBaseB, pb.hotRows, pb.hot, B.hot);
 	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) {
 		tail[i] = i < A.hot ? pa.hotFlags[i] : 0;
-		tail[256 + i] = pb.hotFlags[i];
+		if (!SEG)
+			tail[256 + i] = pb.hotFlags[i];
 	}
 	for (uint32_t i = threadIdx.x; i < 264; i += blockDim.x) {
 		reinterpret_cast<uint16_t*>(tail + 512)[i] = pa.cls[i];
-		reinterpret_cast<uint16_t*>(tail + 512 + 528)[i] = pb.cls[i];
+		if (!SEG)
+			reinterpret_cast<uint16_t*>(tail + 512 + 528)[i] = pb.cls[i];
 	}
 	// block-wide progress counter: the waves of a block are kept in step by issue priority, as in the tiled kernel
-	uint32_t* prog = reinterpret_cast<uint32_t*>(tail + 512 + 2 * 528);
+	uint32_t* prog = reinterpret_cast<uint32_t*>(tail + 512 + 2 * 528);   // (SEG leaves the B halves of the tail unused)
 	if (threadIdx.x == 0)
 		*prog = 0;
 	uint32_t myTiles = 0;
@@ -189,12 +215,27 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 		const uint64_t rowBase = Uniform64(text + s0 * pa.stride);
 		const bool hasNext = task + taskStep < ntasks;
 		const uint64_t chainBase = hasNext ? Uniform64(text + (s0 + taskStep * 64) * pa.stride) : rowBase + uint64_t(lastTile) * 128;
-		uint32_t ca = pa.startPerm, cb = pb.startPerm;   // Initialize() (+ Begin()) of both, folded by the host
+		// Initialize() (+ Begin()) of both, folded by the host.  SEG: the two modes' representatives (device ids), mode 0's
+		// being the string's own start state
+		uint32_t ca = SEG && pa.initIdx ? StartStateFrom(pa, pa.initIdx[s]) : pa.startPerm;
+		uint32_t cb = q.b.startPerm;
 		uint32_t ha = ca < A.hot ? ca : A.hot, hb = cb < B.hot ? cb : B.hot;
 		bool done = false;
 		if (!primed)
-			PairIssueTile<true>(a, voff, rowBase, pa.stride);
+			PairIssueTile<true>(a, voff, rowBase, pa.stride, low);
 		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+			if (SEG && t == warm) {   // the segment's first byte: these two states are the guesses
+				ca = ha != A.hot ? ha : ca;
+				cb = hb != B.hot ? hb : cb;
+				if (q.segJ[s] == 0) {
+					ca = pa.initIdx ? StartStateFrom(pa, pa.initIdx[s]) : pa.startPerm;
+					cb = q.b.startPerm;
+				}
+				ha = ca < A.hot ? ca : A.hot;
+				hb = cb < B.hot ? cb : B.hot;
+				q.guessA[s] = ca;
+				q.guessB[s] = cb;
+			}
 			{
 				uint32_t sum = 0;
 				if (lane == 0)
@@ -208,22 +249,22 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 				else
 					__builtin_amdgcn_s_setprio(1);
 			}
-			PairIssueTile<true>(b, voff, rowBase + uint64_t(t + 1) * 128, pa.stride);
+			PairIssueTile<true>(b, voff, rowBase + uint64_t(t + 1) * 128, pa.stride, low);
 			PairWaitTile<1>(a);
 			TransposeTile(a, lane);
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				PairStepChunk(q, A, B, a[k], ha, ca, hb, cb);
-			PairIssueTile<true>(a, voff, t + 2 < ntiles ? rowBase + uint64_t(t + 2) * 128 : chainBase, pa.stride);
+				PairStepChunk<SEG>(q, A, B, a[k], ha, ca, hb, cb);
+			PairIssueTile<true>(a, voff, t + 2 < ntiles ? rowBase + uint64_t(t + 2) * 128 : chainBase, pa.stride, low);
 			PairWaitTile<1>(b);
 			TransposeTile(b, lane);
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				PairStepChunk(q, A, B, b[k], ha, ca, hb, cb);
+				PairStepChunk<SEG>(q, A, B, b[k], ha, ca, hb, cb);
 			// ScannerPair is absorbing when both sides are (the early-out of the single kernels, for the pair)
 			const bool absA = ha != A.hot && (A.flags[ha] & kAbsorbing);
 			const bool absB = hb != B.hot && (B.flags[hb] & kAbsorbing);
-			done = __all(absA && absB) && t + 2 < ntiles;
+			done = __all(absA && absB) && t + 2 < ntiles && (!SEG || t >= warm);
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (done)
@@ -231,21 +272,21 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 		uint32_t sa = ha != A.hot ? ha : ca, sb = hb != B.hot ? hb : cb;
 		if (!done) {
 			const uint8_t* base = pa.text + s * pa.stride;
-			for (uint64_t i = uint64_t(ntiles) * 128; i < pa.len; ++i) {
+			for (uint64_t i = uint64_t(ntiles - warm) * 128; i < pa.len; ++i) {
 				sa = PairSlowStep(pa, A, sa, base[i]);
 				sb = PairSlowStep(pb, B, sb, base[i]);
 			}
 		}
 		// End(), StateIndex of both, Final = either (pair.h:69-72, 79-82)
-		const FinRec* ra = (pa.flags & PIRE_HIP_RUN_END) ? pa.finEnd : pa.finSelf;
-		const FinRec* rb = (pb.flags & PIRE_HIP_RUN_END) ? pb.finEnd : pb.finSelf;
+		const FinRec* ra = SEG ? pa.finSelf : (pa.flags & PIRE_HIP_RUN_END) ? pa.finEnd : pa.finSelf;
+		const FinRec* rb = SEG ? pa.finSelf : (pb.flags & PIRE_HIP_RUN_END) ? pb.finEnd : pb.finSelf;
 		const u32x4 rawA = *reinterpret_cast<const u32x4*>(&ra[sa]);
 		const u32x4 rawB = *reinterpret_cast<const u32x4*>(&rb[sb]);
 		if (pa.outIdx)
-			pa.outIdx[s] = rawA.x;
+			pa.outIdx[s] = SEG ? (rawA.y & 0x0FFFFFFFu) : rawA.x;   // SEG: device ids out as well as in
 		if (q.outIdxB)
-			q.outIdxB[s] = rawB.x;
-		if (pa.outFinal)
+			q.outIdxB[s] = SEG ? (rawB.y & 0x0FFFFFFFu) : rawB.x;
+		if (!SEG && pa.outFinal)
 			pa.outFinal[s] = ((rawA.y | rawB.y) >> 28) & kFinal;
 	}
 	PairWaitTile<0>(a);
@@ -258,27 +299,40 @@ bool PairTiledEligible(const ScanParams& a, const ScanParams& b)
 	return TiledEligible(a) && a.len >= 256 && (a.len / 128) % 2 == 0 && need <= kLdsPerBlock;
 }
 
-int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream)
+int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream, uint64_t warmBytes,
+                    const uint32_t* segJ, uint32_t* guessA, uint32_t* guessB)
 {
-	PairParams q;
+	PairParams q = {};
 	q.a = a;
 	q.b = b;
 	q.outIdxB = outIdxB;
+	const bool seg = guessA != nullptr;
+	if (seg && (warmBytes % 256 != 0 || warmBytes > a.stride || !segJ || !guessB || a.hotRows != b.hotRows)) {
+		SetError("pair kernel: a segment's warm-up is whole pairs of 128-byte tiles, no longer than the segment");
+		return PIRE_HIP_EINVAL;
+	}
+	q.warmTiles = uint32_t(warmBytes / 128);
+	q.segJ = segJ;
+	q.guessA = guessA;
+	q.guessB = guessB;
 	q.a.n = a.n & ~uint64_t(63);   // whole 64-string tasks; the caller runs the remainder as two ordinary passes
 	if (q.a.n == 0)
 		return PIRE_HIP_OK;
-	const uint32_t ldsBytes = kPairBaseB + (b.hot + 1) * 256 + 512 + 2 * 528 + 64;
+	const uint32_t ldsBytes = (seg ? (a.hot + 1) * 256 : kPairBaseB + (b.hot + 1) * 256) + 512 + 2 * 528 + 64;
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanPairTiledKernel),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	const void* kernel = seg ? reinterpret_cast<const void*>(ScanPairTiledKernel<true>) : reinterpret_cast<const void*>(ScanPairTiledKernel<false>);
+	hipError_t e = SetDynamicLds(kernel, uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	const uint64_t ntasks = q.a.n / 64;
 	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + 15) / 16, uint64_t(cus)));
 	NoteKernel("pair_tiled", "pirehip::ScanPairTiledKernel");
-	hipLaunchKernelGGL(ScanPairTiledKernel, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
+	if (seg)
+		hipLaunchKernelGGL(ScanPairTiledKernel<true>, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
+	else
+		hipLaunchKernelGGL(ScanPairTiledKernel<false>, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "pair kernel launch");

@@ -1068,8 +1068,7 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	e = hipFuncSetAttribute(reinterpret_cast<const void*>(ScanRaggedKernel<Act, EXT>),
-	                        hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	e = SetDynamicLds(reinterpret_cast<const void*>(ScanRaggedKernel<Act, EXT>), uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	// one string per lane: spread the waves over every CU before stacking them (4..16 waves per block, 1 block per CU)

@@ -74,14 +74,18 @@ struct SlotArrays {
 };
 
 struct ChainArrays {
-	uint64_t* maps;                // [nSeg] slot at k -> slot at k+1, 7 x u8 (+ kResetMap)
-	uint64_t* prefix;              // [nSeg] inclusive composition
+	uint64_t* prefix;              // [nSeg] maps (slot at k -> slot at k+1, 7 x u8 + kResetMap), composed inclusively
 	uint32_t* trueStart;           // nullable, [nSeg]: the state every segment is really entered in
 	uint32_t* finalState;          // [nStrings]
 	uint32_t* strDone;             // [nStrings] 1: finalState set by the plain walk
 	uint32_t* breakSeg;            // [nStrings] first segment no slot predicted (kNoState: none)
 	uint32_t* breakState;          // [nStrings] the state the chain is in there
 	uint32_t* broken;              // [1]
+	// the scan of the maps, two levels (SegmentMapScanKernel): `prefix` is inclusive inside blocks of kChainBlock
+	// segments, blockPrefix[b] the inclusive composition of blocks 0..b
+	uint64_t* blockAgg;            // [chain blocks]
+	uint64_t* blockPrefix;         // [chain blocks]
+	uint32_t* brokenHost;          // mapped host word: the kernel behind the resolve kernel copies *broken there
 };
 
 __device__ __forceinline__ void StringOfSegment(const SegGeometry& g, uint64_t seg, uint64_t* str, uint64_t* j)
@@ -103,11 +107,22 @@ __device__ __forceinline__ void StringOfSegment(const SegGeometry& g, uint64_t s
 	*j = seg - g.strFirst[lo];
 }
 
-__global__ void SegmentPrepKernel(ScanParams p, SegGeometry g, SegArrays a)
+__global__ void SegmentPrepKernel(ScanParams p, SegGeometry g, SegArrays a, uint32_t* patchGuess, uint32_t* patchEnd,
+                                  uint32_t* strDone, uint32_t* breakSeg, uint32_t* broken)
 {
 	const uint64_t seg = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (seg >= g.nSeg)
 		return;
+	// what used to be five fills of their own (every launch costs ~6 us of a call that takes 400): the patch slot is
+	// empty, no string is done or broken (every string has a segment: seg < nStrings covers them)
+	patchGuess[seg] = kNoState;
+	patchEnd[seg] = kNoState;
+	if (seg < g.nStrings) {
+		strDone[seg] = 0;
+		breakSeg[seg] = kNoState;
+	}
+	if (seg == 0)
+		*broken = 0;
 	uint64_t s, j;
 	StringOfSegment(g, seg, &s, &j);
 	uint64_t B, E;
@@ -140,11 +155,8 @@ __global__ void SegmentFillKernel(uint32_t* dst, uint32_t value, uint64_t n)
 // The map of segment k: entered in slot i (i.e. in state guess[i][k]) it ends in end[i][k]; which slot of k+1 has
 // that state as its guess?  The first segment of a string is entered in slot 0 whatever came before it, so its map
 // is constant -- which also restarts the composition at every string.
-__global__ void SegmentMapKernel(SegGeometry g, SegArrays a, SlotArrays sl, ChainArrays c)
+__device__ __forceinline__ uint64_t MapOfSegment(const SegGeometry& g, const SegArrays& a, const SlotArrays& sl, uint64_t k)
 {
-	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-	if (k >= g.nSeg)
-		return;
 	const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
 	uint64_t map = 0;
 	if (!last) {
@@ -171,7 +183,7 @@ __global__ void SegmentMapKernel(SegGeometry g, SegArrays a, SlotArrays sl, Chai
 		const uint64_t to0 = map & 0xFF;
 		map = to0 * 0x0001010101010101ull | kResetMap;
 	}
-	c.maps[k] = map;
+	return map;
 }
 
 struct ComposeMaps {
@@ -190,6 +202,62 @@ struct ComposeMaps {
 	}
 };
 
+constexpr uint32_t kChainBlock = 1024;
+constexpr uint64_t kIdentityMap = 0x0006050403020100ull;
+
+// The maps and their inclusive scan in two small launches (round 3; before: a map kernel and hipcub's two): a block
+// composes its kChainBlock maps, one block then composes the blocks' aggregates, and the resolve kernel puts the two
+// levels together for the one byte of the composition it needs.  (No "last block done" tricks: a release fence per
+// block costs an L2 write-back on this chip -- eight L2s -- and made these kernels 25 us each.)
+__global__ __launch_bounds__(kChainBlock) void SegmentMapScanKernel(SegGeometry g, SegArrays a, SlotArrays sl, ChainArrays c)
+{
+	using Scan = hipcub::BlockScan<uint64_t, kChainBlock>;
+	__shared__ typename Scan::TempStorage temp;
+	const uint64_t k = uint64_t(blockIdx.x) * kChainBlock + threadIdx.x;
+	uint64_t map = kIdentityMap;
+	if (k < g.nSeg)
+		map = MapOfSegment(g, a, sl, k);
+	uint64_t incl;
+	Scan(temp).InclusiveScan(map, incl, ComposeMaps());
+	if (k < g.nSeg)
+		c.prefix[k] = incl;
+	if (threadIdx.x == kChainBlock - 1)
+		c.blockAgg[blockIdx.x] = incl;
+}
+
+__global__ __launch_bounds__(kChainBlock) void SegmentBlockScanKernel(ChainArrays c, uint32_t nblocks)
+{
+	using Scan = hipcub::BlockScan<uint64_t, kChainBlock>;
+	__shared__ typename Scan::TempStorage temp;
+	__shared__ uint64_t next;
+	uint64_t carry = kIdentityMap;
+	for (uint32_t base = 0; base < nblocks; base += kChainBlock) {
+		const uint32_t b = base + threadIdx.x;
+		const uint64_t agg = b < nblocks ? c.blockAgg[b] : kIdentityMap;
+		uint64_t in;
+		Scan(temp).InclusiveScan(agg, in, ComposeMaps());
+		const uint64_t out = ComposeMaps()(carry, in);
+		if (b < nblocks)
+			c.blockPrefix[b] = out;
+		if (threadIdx.x == kChainBlock - 1)
+			next = out;
+		__syncthreads();
+		carry = next;
+		__syncthreads();   // temp and next are reused
+	}
+}
+
+// byte 0 of the inclusive composition up to and including segment k: the slot segment k+1 is entered in
+__device__ __forceinline__ uint32_t ChainSlotAfter(const ChainArrays& c, uint64_t k)
+{
+	const uint64_t local = c.prefix[k];
+	const uint64_t b = k / kChainBlock;
+	if (b == 0 || (local & kResetMap))
+		return uint32_t(local) & 0xFF;
+	const uint32_t mid = uint32_t(c.blockPrefix[b - 1]) & 0xFF;
+	return mid == kNoSlot ? kNoSlot : uint32_t(local >> (8 * mid)) & 0xFF;
+}
+
 // Every segment reads the slot it is really entered in; the first segment of a string nobody predicted reports
 // itself; the last segment of a resolved string delivers the string's end state.
 __global__ void SegmentResolveKernel(SegGeometry g, SegArrays a, SlotArrays sl, ChainArrays c)
@@ -201,9 +269,9 @@ __global__ void SegmentResolveKernel(SegGeometry g, SegArrays a, SlotArrays sl, 
 	if (c.strDone[str])
 		return;
 	const uint32_t j = a.segJ[k];
-	const uint32_t slot = j == 0 ? 0u : uint32_t(c.prefix[k - 1]) & 0xFF;
+	const uint32_t slot = j == 0 ? 0u : ChainSlotAfter(c, k - 1);
 	if (slot == kNoSlot) {
-		const uint32_t before = j == 1 ? 0u : uint32_t(c.prefix[k - 2]) & 0xFF;
+		const uint32_t before = j == 1 ? 0u : ChainSlotAfter(c, k - 2);
 		if (before != kNoSlot) {   // the chain was intact up to segment k-1: this is where it breaks
 			c.breakSeg[str] = uint32_t(k);
 			c.breakState[str] = sl.end[before][k - 1];
@@ -216,6 +284,24 @@ __global__ void SegmentResolveKernel(SegGeometry g, SegArrays a, SlotArrays sl, 
 	const bool last = k + 1 == g.nSeg || a.segJ[k + 1] == 0;
 	if (last)
 		c.finalState[str] = sl.end[slot][k];
+}
+
+// How many chains broke, for the host: a mapped host word instead of a copy to enqueue.  The finish kernels are
+// launched behind the resolve kernel WITHOUT waiting for the host (round 3: one round trip less per call): they report
+// the number and do their work only if it is zero -- the usual case; otherwise the host repairs and launches them again.
+__device__ __forceinline__ bool ChainsIntact(const uint32_t* broken, uint32_t* brokenHost)
+{
+	if (!broken)
+		return true;   // the host has already looked
+	const uint32_t n = *broken;
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		__hip_atomic_store(brokenHost, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	return n == 0;
+}
+
+__global__ void SegmentReportKernel(const uint32_t* broken, uint32_t* brokenHost)
+{
+	(void)ChainsIntact(broken, brokenHost);
 }
 
 // Patch: segment breakSeg[i] of broken string i was scanned from breakState[i]; enter it as that segment's patch
@@ -238,9 +324,12 @@ __global__ void SegmentPatchKernel(const uint32_t* strings, const uint32_t* resu
 }
 
 // finish: one lane per string; endIdx[s] = the device state id string s ended in, before End().
-__global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const uint32_t* endIdx)
+__global__ __launch_bounds__(1024) void SegmentFinishKernel(ScanParams p, const uint32_t* endIdx, const uint32_t* broken,
+                                                           uint32_t* brokenHost)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	if (!ChainsIntact(broken, brokenHost))
+		return;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, kRotPitch, 0);
 	LoadTableToLds(p, lds, L);
 	const uint64_t rounds = (p.n + 63) / 64;
@@ -365,8 +454,11 @@ __global__ __launch_bounds__(1024) void SegmentHalfFinalKernel(ScanParams p, Seg
 
 // The same for a handful of strings without the 66 KB table fill: the end-of-string record straight from memory, the
 // counters straight to the caller's array (one atomic per wave and counter).
-__global__ __launch_bounds__(256) void SegmentFinishSmallKernel(ScanParams p, const uint32_t* endIdx)
+__global__ __launch_bounds__(256) void SegmentFinishSmallKernel(ScanParams p, const uint32_t* endIdx, const uint32_t* broken,
+                                                               uint32_t* brokenHost)
 {
+	if (!ChainsIntact(broken, brokenHost))
+		return;
 	const uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	const bool active = s < p.n;
 	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
@@ -412,6 +504,29 @@ uint64_t Knob(uint64_t v, uint64_t fallback)
 // Stream-ordered scratch: ONE allocation per call, made while the stream is still idle (allocating from the pool
 // with kernels in flight cost about a millisecond per call), carved up as the call goes, freed on the stream when
 // the call returns, i.e. after everything enqueued before.
+// One mapped host word out of the pinned staging cache (api.cpp), for the duration of a call.
+struct HostWord {
+	void* host = nullptr;
+	uint32_t* dev = nullptr;
+	size_t block = 0;
+	int Acquire()
+	{
+		if (int rc = StagingAcquireHost(64, &host, &block))
+			return rc;
+		void* d = nullptr;
+		const hipError_t e = hipHostGetDevicePointer(&d, host, 0);
+		if (e != hipSuccess)
+			return HipFail(e, "hipHostGetDevicePointer");
+		dev = static_cast<uint32_t*>(d);
+		return PIRE_HIP_OK;
+	}
+	~HostWord()
+	{
+		if (host)
+			StagingReleaseHost(host, block);
+	}
+};
+
 struct StreamScratch {
 	hipStream_t stream;
 	uint8_t* base = nullptr;
@@ -553,16 +668,14 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	}
 	const uint64_t S = g.nSeg;
 	StreamScratch scratch(stream);
-	size_t tempBytes = 0;
-	PIRE_TRY(HipOk(hipcub::DeviceScan::InclusiveScan(nullptr, tempBytes, static_cast<uint64_t*>(nullptr),
-	                                                 static_cast<uint64_t*>(nullptr), ComposeMaps(), int(S), stream), "hipcub::DeviceScan"));
+	const uint64_t chainBlocks = (S + kChainBlock - 1) / kChainBlock;
 	{
 		const size_t perSeg = 3 * 8 + 3 * 4            // the cut
 		                      + (size_t(maxModes) + 1) * 8 + 4   // guess + end per slot, the constant init array
-		                      + 2 * 8                  // maps, prefix
+		                      + 8                      // prefix
 		                      + 4;                     // true start states (half-final counting)
 		const size_t perString = 5 * 4 + 2 * 8 + 3 * 4 + 4;
-		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + tempBytes + 64 * 256));
+		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + chainBlocks * 16 + 64 * 256));
 	}
 	if (hostOffsets) {
 		uint32_t* d = nullptr;
@@ -581,7 +694,23 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	if (p.initIdx)
 		PIRE_TRY(scratch.Alloc(&a.initSeg, S));
 	const unsigned blocks = unsigned((S + 255) / 256);
-	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a);
+	SlotArrays sl = {};
+	PIRE_TRY(scratch.Alloc(&sl.guess[kMaxModes], S));   // the patch slot: empty
+	PIRE_TRY(scratch.Alloc(&sl.end[kMaxModes], S));
+	ChainArrays c = {};
+	PIRE_TRY(scratch.Alloc(&c.prefix, S));
+	PIRE_TRY(scratch.Alloc(&c.blockAgg, chainBlocks));
+	PIRE_TRY(scratch.Alloc(&c.blockPrefix, chainBlocks));
+	if (halfFinalResults)
+		PIRE_TRY(scratch.Alloc(&c.trueStart, S));
+	PIRE_TRY(scratch.Alloc(&c.finalState, n));
+	PIRE_TRY(scratch.Alloc(&c.strDone, n));
+	PIRE_TRY(scratch.Alloc(&c.breakSeg, n));
+	PIRE_TRY(scratch.Alloc(&c.breakState, n));
+	PIRE_TRY(scratch.Alloc(&c.broken, 1));
+	// the cut, and the initial values of the patch slot and of the chain's per-string arrays, in one launch
+	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a, sl.guess[kMaxModes], sl.end[kMaxModes],
+	                   c.strDone, c.breakSeg, c.broken);
 	// the host's copy of the cut (same arithmetic), for the batches of broken chains
 	auto segBeginOf = [&](uint64_t i, uint32_t k) {
 		const uint64_t B = hostOffsets ? hostOffsets[i] : i * p.stride;
@@ -611,11 +740,6 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	}
 
 	// ---- slots
-	SlotArrays sl = {};
-	PIRE_TRY(scratch.Alloc(&sl.guess[kMaxModes], S));   // the patch slot: empty
-	PIRE_TRY(scratch.Alloc(&sl.end[kMaxModes], S));
-	hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, sl.guess[kMaxModes], kNoState, S);
-	hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, sl.end[kMaxModes], kNoState, S);
 	uint32_t* dConst = nullptr;
 	// one mode: warm-up from its representative (mode 0: the string's own start state, and the first segment's
 	// warm-up is empty, so its guess is the true start state), then the scan proper from the guesses
@@ -663,54 +787,138 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		sl.count = m + 1;
 		return PIRE_HIP_OK;
 	};
-	mark("setup");
-	PIRE_TRY(addMode(true, 0));
-	mark("mode 0");
-	// the modes earlier calls on this table learned: the automaton is the same, the text probably similar
-	{
-		std::vector<uint32_t> known;
-		{
-			std::lock_guard<std::mutex> lock(t->segMutex);
-			known = t->segModes;
+	// Two modes at once (round 3): the scan proper of mode 0 and of the first known mode read the same bytes, so the
+	// grid segments take ONE pass of the fused pair kernel (pair.hip: the tiled load path, two lookups per byte -- here
+	// the same table twice) instead of two tiled passes, and the two warm-ups that make the guesses are the first tiles
+	// of that same pass (a lane starts `warmBytes` before its segment in the two representatives' states): one launch
+	// instead of four, the text read 1.06 times instead of 2.12.  Segments beyond the last whole 64 (and tails) take the
+	// separate warm-up and scan batches as before.
+	auto addModePair = [&](uint32_t representativeB) -> int {
+		const uint32_t m = sl.count;
+		for (uint32_t k = m; k < m + 2; ++k) {
+			PIRE_TRY(scratch.Alloc(&sl.guess[k], S));
+			PIRE_TRY(scratch.Alloc(&sl.end[k], S));
 		}
-		for (uint32_t r : known)   // kept as reference state indices: adapt() renumbers the device ids
-			if (sl.count < maxModes && r < t->host.states)
-				PIRE_TRY(addMode(false, t->host.permOfOrig[r]));
+		const uint64_t paired = gridSegs & ~uint64_t(63);
+		const uint64_t separate = paired;   // segments from here on: warm-up batches of their own
+		if (separate < S) {
+			if (!dConst)
+				PIRE_TRY(scratch.Alloc(&dConst, S));
+			hipLaunchKernelGGL(SegmentFillKernel, dim3(blocks), dim3(256), 0, stream, dConst, representativeB, S);
+		}
+		for (uint32_t k = 0; k < 2 && separate < S; ++k) {   // mode 0 from the strings' own start states, the other from its representative
+			q.n = S - separate;
+			q.offsets = a.warmBegin + separate;
+			q.ends = a.segBegin + separate;
+			q.initIdx = k == 0 ? (a.initSeg ? a.initSeg + separate : nullptr) : dConst;
+			q.flags = (k == 0 ? (p.flags & PIRE_HIP_RUN_BEGIN) : 0u) | kPermIds;
+			q.outIdx = sl.guess[m + k] + separate;
+			PIRE_TRY(ScanBatch(q, t, stream));
+		}
+		q.flags = kPermIds;
+		ScanParams ra = q;
+		ra.offsets = nullptr;
+		ra.ends = nullptr;
+		ra.n = paired;
+		ra.len = ra.stride = segBytes;
+		ra.outIdx = sl.end[m];
+		ScanParams rb = ra;
+		ra.initIdx = a.initSeg;   // nullable: then startPerm (Initialize + Begin folded)
+		ra.flags = (p.flags & PIRE_HIP_RUN_BEGIN) | kPermIds;
+		rb.initIdx = nullptr;
+		rb.startPerm = representativeB;
+		PIRE_TRY(LaunchPairTiled(ra, rb, sl.end[m + 1], stream, warmBytes, a.segJ, sl.guess[m], sl.guess[m + 1]));
+		for (uint32_t k = 0; k < 2 && paired < S; ++k) {
+			q.n = S - paired;
+			q.offsets = a.segBegin + paired;
+			q.ends = a.segEnd + paired;
+			q.initIdx = sl.guess[m + k] + paired;
+			q.outIdx = sl.end[m + k] + paired;
+			PIRE_TRY(ScanBatch(q, t, stream));
+		}
+		sl.count = m + 2;
+		return PIRE_HIP_OK;
+	};
+	mark("setup");
+	// the modes earlier calls on this table learned: the automaton is the same, the text probably similar
+	std::vector<uint32_t> known;
+	{
+		std::lock_guard<std::mutex> lock(t->segMutex);
+		for (uint32_t r : t->segModes)   // kept as reference state indices: adapt() renumbers the device ids
+			if (r < t->host.states)
+				known.push_back(r);
 	}
+	size_t nextKnown = 0;
+	bool pairedFirst = false;
+	if (!known.empty() && maxModes >= 2 && gridSegs >= 64 && !cfg.segment_no_pair && warmBytes % 256 == 0 && warmBytes <= segBytes) {
+		ScanParams probe = q;
+		probe.offsets = nullptr;
+		probe.n = gridSegs & ~uint64_t(63);
+		probe.len = probe.stride = segBytes;
+		pairedFirst = TiledEligible(probe) && segBytes % 256 == 0;
+	}
+	if (pairedFirst) {
+		PIRE_TRY(addModePair(t->host.permOfOrig[known[0]]));
+		nextKnown = 1;
+		mark("modes 0+1 (fused)");
+	} else {
+		PIRE_TRY(addMode(true, 0));
+		mark("mode 0");
+	}
+	for (; nextKnown < known.size(); ++nextKnown)
+		if (sl.count < maxModes)
+			PIRE_TRY(addMode(false, t->host.permOfOrig[known[nextKnown]]));
 
 	mark("known modes");
 	// ---- the chain
-	ChainArrays c = {};
-	PIRE_TRY(scratch.Alloc(&c.maps, S));
-	PIRE_TRY(scratch.Alloc(&c.prefix, S));
-	if (halfFinalResults)
-		PIRE_TRY(scratch.Alloc(&c.trueStart, S));
-	PIRE_TRY(scratch.Alloc(&c.finalState, n));
-	PIRE_TRY(scratch.Alloc(&c.strDone, n));
-	PIRE_TRY(scratch.Alloc(&c.breakSeg, n));
-	PIRE_TRY(scratch.Alloc(&c.breakState, n));
-	PIRE_TRY(scratch.Alloc(&c.broken, 1));
-	PIRE_TRY(HipOk(hipMemsetAsync(c.strDone, 0, n * 4, stream), "hipMemset"));
-	PIRE_TRY(HipOk(hipMemsetAsync(c.breakSeg, 0xFF, n * 4, stream), "hipMemset"));   // kNoState: not broken
-	uint8_t* dTemp = nullptr;
-	PIRE_TRY(scratch.Alloc(&dTemp, tempBytes));
+	// how many chains broke: a mapped host word the resolve kernel's last block writes (no copy to enqueue per round)
+	HostWord brokenWord;
+	PIRE_TRY(brokenWord.Acquire());
+	c.brokenHost = brokenWord.dev;
 	uint32_t *dExStr = nullptr, *dExInit = nullptr, *dExOut = nullptr;
 	uint64_t *dExB = nullptr, *dExE = nullptr;
 	std::vector<uint32_t> breakSeg(n), breakState(n), exStr, exInit;
 	std::vector<uint64_t> exB, exE;
 	std::unordered_map<uint32_t, uint32_t> surprises;
 	uint64_t nWalked = 0, nPlain = 0, rounds = 0;
+	// finish: End(), outputs and match counters.  With `broken` it runs only if no chain broke (see ChainsIntact).
+	auto launchFinish = [&](const uint32_t* broken) -> int {
+		if (n <= 4096) {
+			hipLaunchKernelGGL(SegmentFinishSmallKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, p, c.finalState, broken,
+			                   c.brokenHost);
+		} else {
+			ScanParams f = p;
+			f.compact = 0;
+			const LdsLayout L = MakeLayout(f.hot, f.outCounts ? f.regexps : 0, kRotPitch, 0);
+			PIRE_TRY(HipOk(SetDynamicLds(reinterpret_cast<const void*>(SegmentFinishKernel), uint32_t(L.total)), "hipFuncSetAttribute(LDS)"));
+			const unsigned threads = 1024;
+			const uint64_t tasks = (n + 63) / 64;
+			const unsigned cblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((tasks * 64 + threads - 1) / threads, uint64_t(cus))));
+			hipLaunchKernelGGL(SegmentFinishKernel, dim3(cblocks), dim3(threads), L.total, stream, f, c.finalState, broken, c.brokenHost);
+		}
+		return PIRE_HIP_OK;
+	};
 	for (;;) {
 		++rounds;
-		PIRE_TRY(HipOk(hipMemsetAsync(c.broken, 0, 4, stream), "hipMemset"));
-		hipLaunchKernelGGL(SegmentMapKernel, dim3(blocks), dim3(256), 0, stream, g, a, sl, c);
-		PIRE_TRY(HipOk(hipcub::DeviceScan::InclusiveScan(dTemp, tempBytes, c.maps, c.prefix, ComposeMaps(), int(S), stream), "hipcub::DeviceScan"));
+		*static_cast<volatile uint32_t*>(brokenWord.host) = kNoState;
+		hipLaunchKernelGGL(SegmentMapScanKernel, dim3(unsigned(chainBlocks)), dim3(kChainBlock), 0, stream, g, a, sl, c);
+		if (chainBlocks > 1)
+			hipLaunchKernelGGL(SegmentBlockScanKernel, dim3(1), dim3(kChainBlock), 0, stream, c, uint32_t(chainBlocks));
 		hipLaunchKernelGGL(SegmentResolveKernel, dim3(blocks), dim3(256), 0, stream, g, a, sl, c);
-		uint32_t broken = 0;
-		PIRE_TRY(HipOk(hipMemcpyAsync(&broken, c.broken, 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
+		if (halfFinalResults)   // the counting needs the host's decision first
+			hipLaunchKernelGGL(SegmentReportKernel, dim3(1), dim3(64), 0, stream, c.broken, c.brokenHost);
+		else
+			PIRE_TRY(launchFinish(c.broken));
+		PIRE_TRY(HipOk(hipGetLastError(), "segmented scan: chain kernels"));
 		PIRE_TRY(HipOk(hipStreamSynchronize(stream), "hipStreamSynchronize"));
+		const uint32_t broken = *static_cast<volatile uint32_t*>(brokenWord.host);
+		if (broken == kNoState) {
+			SetError("segmented scan: the chain kernels did not report");
+			return PIRE_HIP_EUNSUPPORTED;
+		}
 		if (!broken)
 			break;
+		PIRE_TRY(HipOk(hipMemsetAsync(c.broken, 0, 4, stream), "hipMemset"));
 		// where and in which state: the host only orchestrates, the states stay on the device
 		PIRE_TRY(HipOk(hipMemcpyAsync(breakSeg.data(), c.breakSeg, n * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
 		PIRE_TRY(HipOk(hipMemcpyAsync(breakState.data(), c.breakState, n * 4, hipMemcpyDeviceToHost, stream), "hipMemcpy(D2H)"));
@@ -806,30 +1014,19 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		hp.compact = 0;
 		const LdsLayout L = MakeLayout(hp.hot, 0, 256u, 0);
 		const uint32_t ldsBytes = L.total + 64;
-		PIRE_TRY(HipOk(hipFuncSetAttribute(reinterpret_cast<const void*>(SegmentHalfFinalKernel),
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes)), "hipFuncSetAttribute(LDS)"));
+		PIRE_TRY(HipOk(SetDynamicLds(reinterpret_cast<const void*>(SegmentHalfFinalKernel), uint32_t(ldsBytes)), "hipFuncSetAttribute(LDS)"));
 		const uint32_t initialPerm = t->host.permOfOrig[t->host.initial];
 		// 1024-thread blocks: the dense rows take 66 KB of LDS, so this is 16 waves per CU instead of 8
 		hipLaunchKernelGGL(SegmentHalfFinalKernel, dim3(unsigned((S + 1023) / 1024)), dim3(1024), ldsBytes, stream, hp, g, a,
 		                   c.trueStart, c.strDone, initialPerm, halfFinalResults);
 		mark("half-final counts");
 	}
-	// ---- finish
-	if (n <= 4096) {
-		hipLaunchKernelGGL(SegmentFinishSmallKernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, stream, p, c.finalState);
-	} else {
-		ScanParams f = p;
-		f.compact = 0;
-		const LdsLayout L = MakeLayout(f.hot, f.outCounts ? f.regexps : 0, kRotPitch, 0);
-		PIRE_TRY(HipOk(hipFuncSetAttribute(reinterpret_cast<const void*>(SegmentFinishKernel),
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(L.total)), "hipFuncSetAttribute(LDS)"));
-		const unsigned threads = 1024;
-		const uint64_t tasks = (n + 63) / 64;
-		const unsigned cblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((tasks * 64 + threads - 1) / threads, uint64_t(cus))));
-		hipLaunchKernelGGL(SegmentFinishKernel, dim3(cblocks), dim3(threads), L.total, stream, f, c.finalState);
-	}
+	// ---- finish: already done behind the last resolve kernel, except after the half-final counting
+	if (halfFinalResults)
+		PIRE_TRY(launchFinish(nullptr));
 	PIRE_TRY(HipOk(hipGetLastError(), "segmented scan launch"));
-	NoteKernel(nPlain ? "segmented+plain" : "segmented");   // "+plain": some strings ended in the sequential walk
+	// "+plain": some strings ended in the sequential walk; the symbol says whether two modes shared one pass
+	NoteKernel(nPlain ? "segmented+plain" : "segmented", pairedFirst ? "pirehip::ScanPairTiledKernel" : "");
 	if (wantStats) {
 		mark("finish");
 		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %u modes, %llu chain "

@@ -908,8 +908,7 @@ int LaunchSlowK(const SlowParams& p0, hipStream_t stream)
 	p.singleInLds = singleBytes <= 64 * 1024 ? 1 : 0;
 	p.masksInLds = maskBytes + (p.singleInLds ? singleBytes : 0) <= 150 * 1024 ? 1 : 0;
 	const uint32_t ldsBytes = uint32_t(272 + (p.singleInLds ? singleBytes : 0) + (p.masksInLds ? maskBytes : 0));
-	hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(SlowScanKernel<K>),
-	                                   hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(SlowScanKernel<K>), uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	int dev = 0, cus = 0;
@@ -961,7 +960,7 @@ int LaunchSlowWide(const SlowParams& p0, uint32_t njumps, hipStream_t stream)
 	}
 	const uint32_t ldsBytes = uint32_t(272 + (inLds ? waves * setBytes : 0) + (posInLds ? posBytes : 0) + (jumpsInLds ? jumpBytes : 0));
 	const void* fn = inLds ? reinterpret_cast<const void*>(SlowWideKernel<true>) : reinterpret_cast<const void*>(SlowWideKernel<false>);
-	e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(ldsBytes));
+	e = SetDynamicLds(fn, uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	if (inLds)
@@ -1001,8 +1000,7 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 	}
 	p.overflow = static_cast<uint32_t*>(list);
 	const uint32_t ldsBytes = uint32_t(1056 + 16 + size_t(p.states + 1) * p.letters * 4);
-	e = hipFuncSetAttribute(reinterpret_cast<const void*>(SlowListKernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                        int(ldsBytes));
+	e = SetDynamicLds(reinterpret_cast<const void*>(SlowListKernel), uint32_t(ldsBytes));
 	int rc = PIRE_HIP_OK;
 	if (e != hipSuccess) {
 		rc = HipFail(e, "hipFuncSetAttribute(LDS)");

@@ -289,3 +289,45 @@ def test_segmented_half_final_counting(seg, modes, budget, cfg):
             assert (gi == oi).all() and (gf == of).all(), (name, flags)
             assert (gr == orr).all(), (name, flags, gr.tolist(), orr.tolist())
         assert orr.sum() > 0
+
+
+@pytest.mark.parametrize("name", ["set_a", "set_d", "parity"])
+@pytest.mark.parametrize("n,length,seg", [(1, (1 << 21) + 777, 2048), (3, 1 << 19, 4096), (1, 100 * 1024 + 5, 1024)])
+def test_two_modes_share_one_pass_of_the_pair_kernel(name, n, length, seg, cfg):
+    """Once a table knows a second mode, the scan proper of mode 0 and of that mode is ONE pass of the fused pair kernel
+    over the grid segments (the same table twice, the two guesses as start states): the same answers as with
+    pire_hip_config.segment_no_pair, and as the reference's."""
+    import torch
+    import pire_amd
+    from pire_amd import binding as pb
+
+    tabs = dict(tables())
+    if name not in tabs:
+        pytest.skip("needs oracle/_ref to compile the parity scanner")
+    cfg.set(segment_bytes=str(seg))   # the warm-up stays the default 256 B: whole pairs of tiles, so it can be fused
+    t, o = pire_amd.Table(tabs[name]), ob.OracleScanner(tabs[name])
+    rng = np.random.RandomState(n * 1000 + seg)
+    if name == "parity":
+        data = np.frombuffer(b"ab", dtype=np.uint8)[rng.randint(0, 2, size=n * length)]
+    else:
+        big = [b for b in H.big_sets() if b["name"] == name][0]
+        data = ob.corpus_fill(big["corpus"]["seed"], 0, (n * length + 4095) // 4096, 4096, H.plants_for(big)).reshape(-1)[:n * length]
+    data = np.ascontiguousarray(data)
+    oi, of = o.run(data, np.arange(n + 1, dtype=np.uint64) * length)
+    d = torch.as_tensor(data, device="cuda")
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    fused = 0
+    for rep in range(4):
+        if rep == 3:
+            cfg.set(segment_no_pair="1")
+        idx.fill_(-1)
+        t.run_strided_device(d.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        assert pb.last_kernel().startswith("segmented")
+        fused += pb.last_kernel_symbol() == "pirehip::ScanPairTiledKernel"
+        assert rep < 3 or pb.last_kernel_symbol() != "pirehip::ScanPairTiledKernel"
+        assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()
+    if name != "parity":       # (surrounded patterns over {a, b} forget at once: one mode, nothing to fuse)
+        assert fused == 2      # the first call learned the second mode from the planted matches; calls two and three used it
