@@ -694,7 +694,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	// piece.
 	if (n == 0)
 		return PIRE_HIP_OK;
-	Staging st;
+	Staging st(stream);
 	uint64_t textBytes;
 	if (offsets) {
 		for (uint64_t i = 0; i < n; ++i)
@@ -720,8 +720,12 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 				return PIRE_HIP_EINVAL;
 			}
 	const bool segmented = !(flags & PIRE_HIP_RUN_GENERIC) && SegmentedEligible(n, textBytes);
-	// every size: the pooled staging also wins on small calls (10 strings 58 -> 36 us, 3 MB 563 -> 308 us per call)
-	if (!segmented && !g_timing && !GetConfig().host_one_shot) {
+	const size_t cntBytes = (size_t(t->host.regexps) + 2) * 8;
+	// The pooled, chunked staging wins from a few hundred KiB on (3 MB 563 -> 308 us per call); a call whose inputs and
+	// results all fit the one-piece staging's arena (internal.h, Staging: one copy in, one copy out) is faster there
+	// (round 3: 10 strings 36 -> 30 us)
+	const bool small = st.mode == 0 && textBytes + (n + 1) * 8 + n * 9 + cntBytes + 8 * 256 <= Staging::kArenaBytes;
+	if (!segmented && !small && !g_timing && !GetConfig().host_one_shot) {
 		bool done = false;
 		const int rc = RunHostPipelined(t, p, static_cast<const uint8_t*>(text), offsets, n, len, stride, init, outIdx,
 		                                outFinal, outCounts, &done);
@@ -740,7 +744,12 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return rc;
 	void* dIdx = nullptr;
 	void* dFin = nullptr;
-	void* dCnt = nullptr;
+	const unsigned long long* dCnt = nullptr;
+	if (outCounts) {   // accumulated into: an input as well as a result
+		if (int rc = st.In(reinterpret_cast<const unsigned long long*>(outCounts), cntBytes / 8, &dCnt, stream))
+			return rc;
+		p.outCounts = const_cast<unsigned long long*>(dCnt);
+	}
 	if (outIdx) {
 		if (int rc = st.Alloc(&dIdx, size_t(n) * 4))
 			return rc;
@@ -751,33 +760,21 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 			return rc;
 		p.outFinal = static_cast<uint8_t*>(dFin);
 	}
-	const size_t cntBytes = (size_t(t->host.regexps) + 2) * 8;
-	if (outCounts) {
-		if (int rc = st.Alloc(&dCnt, cntBytes))
-			return rc;
-		hipError_t e = hipMemcpyAsync(dCnt, outCounts, cntBytes, hipMemcpyHostToDevice, stream);
-		if (e != hipSuccess)
-			return HipFail(e, "hipMemcpy(counts)");
-		p.outCounts = static_cast<unsigned long long*>(dCnt);
-	}
+	if (int rc = st.Flush())
+		return rc;
 	if (segmented) {
 		if (int rc = RunSegmented(t, p, offsets, stream))
 			return rc;
 	} else if (int rc = Dispatch(p, stream, NextWorkSlot(t, p), textBytes)) {
 		return rc;
 	}
-	hipError_t e = hipSuccess;
-	if (outIdx)
-		e = hipMemcpyAsync(outIdx, dIdx, size_t(n) * 4, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && outFinal)
-		e = hipMemcpyAsync(outFinal, dFin, size_t(n), hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess && outCounts)
-		e = hipMemcpyAsync(outCounts, dCnt, cntBytes, hipMemcpyDeviceToHost, stream);
-	if (e == hipSuccess)
-		e = hipStreamSynchronize(stream);
-	if (e != hipSuccess)
-		return HipFail(e, "copy back / synchronize");
-	return PIRE_HIP_OK;
+	if (int rc = st.Out(outIdx, dIdx, size_t(n) * 4))
+		return rc;
+	if (int rc = st.Out(outFinal, dFin, size_t(n)))
+		return rc;
+	if (int rc = st.Out(outCounts, dCnt, cntBytes))
+		return rc;
+	return st.Finish();
 }
 
 }  // namespace

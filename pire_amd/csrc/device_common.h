@@ -95,12 +95,31 @@ __device__ inline void LoadTableToLds(const ScanParams& p, uint8_t* lds, const L
 	if (L.pitch == 256) {
 		CopyToLds16<8>(lds, p.hotRows, (p.hot + 1) * 16);
 	} else {
-		// 260-byte pitch (bank-rotated variant): 256-byte rows in HBM, dword copies
-		const uint32_t* src = reinterpret_cast<const uint32_t*>(p.hotRows);
+		// 260-byte pitch (bank-rotated variant): 256-byte rows in HBM; 16-byte loads, four in flight per thread, dword
+		// stores (the rows are only 4-byte aligned in LDS).  Rounds 1-2 copied dword by dword, one load in flight: 25-45 us
+		// for a 256-thread block, most of the time of a small call (kernel trace, round 3).
+		const u32x4* src = reinterpret_cast<const u32x4*>(p.hotRows);
 		uint32_t* dst = reinterpret_cast<uint32_t*>(lds);
 		const uint32_t pitchDw = L.pitch / 4;
-		for (uint32_t i = tid; i < (p.hot + 1) * 64; i += nthr)
-			dst[(i >> 6) * pitchDw + (i & 63)] = src[i];
+		const uint32_t nvec = (p.hot + 1) * 16;
+		for (uint32_t base = tid; base < nvec; base += nthr * 4) {
+			u32x4 v[4];
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k)
+				if (base + k * nthr < nvec)
+					v[k] = src[base + k * nthr];
+#pragma unroll
+			for (uint32_t k = 0; k < 4; ++k) {
+				const uint32_t i = base + k * nthr;
+				if (i < nvec) {
+					uint32_t* d = dst + (i >> 4) * pitchDw + (i & 15) * 4;
+					d[0] = v[k].x;
+					d[1] = v[k].y;
+					d[2] = v[k].z;
+					d[3] = v[k].w;
+				}
+			}
+		}
 	}
 	if (p.compact)
 		CopyToLds16<8>(lds + L.compactOff, p.compactRows, L.compactBytes / 16);
@@ -139,6 +158,48 @@ __device__ __forceinline__ uint32_t SlowStepWord(const ScanParams& p, const uint
 	st = SlowStep(p, lds, L, st, (w >> 16) & 0xFF);
 	st = SlowStep(p, lds, L, st, w >> 24);
 	return st;
+}
+
+// Sixteen bytes through the dense rows alone, from a state that has one: the state after them and the largest id on
+// the way (the trap id p.hot, if the walk left the dense rows -- its row is absorbing).  The one-string-per-lane exact
+// kernels use it the way the ragged kernel's walks with actions do: the dense rows are ordered plain,
+// Dead, Final, so "largest id < threshold" says that none of the 16 steps needs a closer look.
+__device__ __forceinline__ uint32_t DenseChunk(const uint8_t* lds, const LdsLayout& L, const u32x4 v, uint32_t& st)
+{
+	uint32_t mx = 0;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			st = lds[st * L.pitch + ((x >> (8 * b)) & 0xFFu)];
+			mx = mx > st ? mx : st;
+		}
+	}
+	return mx;
+}
+
+// The same for bytes [skip, skip + count) of a block (a string's ragged first or last block).
+__device__ __forceinline__ uint32_t DenseBytes(const uint8_t* lds, const LdsLayout& L, u32x4 v, uint32_t skip, uint32_t count,
+                                               uint32_t& st)
+{
+	for (uint32_t i = 0; i < skip; ++i) {
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	uint32_t mx = 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < count; ++i) {
+		st = lds[st * L.pitch + (v.x & 0xFFu)];
+		mx = mx > st ? mx : st;
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return mx;
 }
 
 // Final(state) on a perm id: the hot set is ordered non-final first, so a hot state is Final iff id >= hotFinalLo.

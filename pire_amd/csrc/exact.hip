@@ -142,24 +142,23 @@ __global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* 
 			st = SlowStep(p, lds, L, st, byte);
 			if (IsFinalState(p, st))
 				cnt.Take(p, incHot, st);
+			return true;
 		};
-		while (ptr < end && (reinterpret_cast<uintptr_t>(ptr) & 15)) {
-			step(*ptr);
-			++ptr;
-		}
-		for (; ptr + 16 <= end; ptr += 16) {
-			u32x4 v = *reinterpret_cast<const u32x4*>(ptr);
-#pragma unroll 1
-			for (int i = 0; i < 16; ++i) {
-				step(v.x & 0xFF);
-				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-				v.w >>= 8;
+		// whole blocks first through the dense rows alone: no Final state among the 16 (largest id below the first
+		// Final one, which also says the walk stayed in the dense rows) -> nothing to count, take the state; otherwise
+		// the block again, step by step.  Line-aligned tile loads (walk.h) instead of a block per iteration and byte
+		// loads at the ragged ends: round 3, from the kernel trace of 10-string calls (0.14 us per byte before).
+		WalkBlocks(ptr, end, [&](walk_u32x4 v, uint32_t skip, uint32_t count) {
+			if (st < p.hot) {
+				uint32_t h = st;
+				const uint32_t mx = count == 16 ? DenseChunk(lds, L, v, h) : DenseBytes(lds, L, v, skip, count, h);
+				if (mx < p.hotFinalLo) {
+					st = h;
+					return true;
+				}
 			}
-		}
-		for (; ptr < end; ++ptr)
-			step(*ptr);
+			return BlockBytes(v, skip, count, step);
+		});
 		if (p.flags & PIRE_HIP_RUN_END) {
 			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
 			if (IsFinalState(p, st))
@@ -212,7 +211,7 @@ __global__ __launch_bounds__(1024) void PrefixKernel(PrefixParams q)
 		const bool foundAtStart = stop;
 		if (!stop) {
 			uint64_t i = 0;
-			WalkBytes(text, text + len, [&](uint32_t byte) {   // line-aligned vector loads instead of byte loads
+			auto step = [&](uint32_t byte) {
 				st = SlowStep(p, lds, L, st, byte);
 				f = StateFlags(p, lds, L, st);
 				++i;
@@ -224,6 +223,21 @@ __global__ __launch_bounds__(1024) void PrefixKernel(PrefixParams q)
 				if (f & kDead)
 					stop = true;                         // both predicates stop on a dead state
 				return !stop;
+			};
+			// line-aligned vector loads instead of byte loads (walk.h); whole blocks first through the dense rows alone:
+			// neither a Dead nor a Final state among the 16 (the rows are ordered plain, Dead, Final) -> nothing to record,
+			// take the state; otherwise the block again, step by step (round 3: 0.25 us per byte before, one wave alone)
+			WalkBlocks(text, text + len, [&](walk_u32x4 v, uint32_t skip, uint32_t count) {
+				if (st < p.hot) {
+					uint32_t h = st;
+					const uint32_t mx = count == 16 ? DenseChunk(lds, L, v, h) : DenseBytes(lds, L, v, skip, count, h);
+					if (mx < p.hotDeadLo) {
+						st = h;
+						i += count;
+						return true;
+					}
+				}
+				return BlockBytes(v, skip, count, step);
 			});
 		}
 		if (q.throughEnd && !foundAtStart) {
@@ -335,12 +349,16 @@ __global__ __launch_bounds__(256) void StepKernel(ScanParams p, uint32_t* stateI
 
 namespace {
 
-// The dense rows take 66 KB of LDS, so at most two blocks share a CU: big batches get 1024-thread blocks (16-32 waves
-// per CU to hide the per-byte lookup latency), small ones 256-thread blocks (more CUs busy).
-int ExactBlockThreads(uint64_t n)
+// The dense rows take 66 KB of LDS (130 KB with the compact tier), and every block copies them in before it walks a
+// byte: 1024-thread blocks throughout.  Rounds 1-2 gave batches below 128 Ki strings 256-thread blocks ("more CUs
+// busy"); the kernel trace of 10-string calls (round 3) showed what that costs: the copy by four waves took 25-45 us
+// of a call whose walk takes 3.  Sixteen waves copy it in ~5 us, and 16 waves per CU hide the lookup latency as well
+// as 4 waves on each of four times as many CUs.
+int ExactBlockThreads(uint64_t)
 {
-	return n >= 128 * 1024 ? 1024 : 256;
+	return 1024;
 }
+
 
 }  // namespace
 

@@ -17,8 +17,11 @@ namespace pirehip {
 
 typedef uint32_t walk_u32x4 __attribute__((ext_vector_type(4)));
 
-template <class Step>
-__device__ __forceinline__ void WalkBytes(const uint8_t* ptr, const uint8_t* end, Step&& step)
+// Block feeder: hands the 16-byte blocks that hold [ptr, end) to `block(v, skip, count)` in order -- bytes
+// [skip, skip + count) of v belong to the string (only the first block can have skip > 0, only the last count < 16 -
+// skip) -- reading line-aligned tiles as described above.  `block` returns false to stop early.
+template <class Block>
+__device__ __forceinline__ void WalkBlocks(const uint8_t* ptr, const uint8_t* end, Block&& block)
 {
 	if (ptr >= end)
 		return;
@@ -39,28 +42,14 @@ __device__ __forceinline__ void WalkBytes(const uint8_t* ptr, const uint8_t* end
 		uint64_t left = span;   // bytes from the start of block k to the end of the string
 #pragma unroll 1
 		for (uint32_t k = 0; k < nch; ++k) {
-			walk_u32x4 v = t[0];
+			const walk_u32x4 v = t[0];
 #pragma unroll
 			for (int j = 0; j < 7; ++j)   // static indices only: the tile is a shift register
 				t[j] = t[j + 1];
 			const uint32_t hi = left < 16 ? uint32_t(left) : 16u;
-			uint32_t i = 0;
-			if (k == 0)
-				for (; i < skip; ++i) {   // only the first block of a string starts in the middle
-					v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-					v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-					v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-					v.w >>= 8;
-				}
-#pragma unroll 1
-			for (; i < hi; ++i) {
-				if (!step(v.x & 0xFFu))
-					return;
-				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-				v.w >>= 8;
-			}
+			const uint32_t sk = k == 0 ? skip : 0u;
+			if (!block(v, sk, hi - sk))
+				return;
 			left -= hi;
 		}
 		const uint64_t consumed = uint64_t(nch) * 16 - skip;
@@ -68,6 +57,34 @@ __device__ __forceinline__ void WalkBytes(const uint8_t* ptr, const uint8_t* end
 		base += uint64_t(nch) * 16;
 		skip = 0;
 	}
+}
+
+// bytes [skip, skip + count) of a block, one at a time; false as soon as `step` says stop
+template <class Step>
+__device__ __forceinline__ bool BlockBytes(walk_u32x4 v, uint32_t skip, uint32_t count, Step&& step)
+{
+	for (uint32_t i = 0; i < skip; ++i) {
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+#pragma unroll 1
+	for (uint32_t i = 0; i < count; ++i) {
+		if (!step(v.x & 0xFFu))
+			return false;
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return true;
+}
+
+template <class Step>
+__device__ __forceinline__ void WalkBytes(const uint8_t* ptr, const uint8_t* end, Step&& step)
+{
+	WalkBlocks(ptr, end, [&](walk_u32x4 v, uint32_t skip, uint32_t count) { return BlockBytes(v, skip, count, step); });
 }
 
 }  // namespace pirehip
