@@ -38,3 +38,33 @@ def test_staging_modes_interleaved_against_the_oracle(cfg):
             assert (t.suffix(text, offs, True) == ls).all(), (rep, k)
             gi, gf, gr = t.run_half_final(text, offs)
             assert (gi == hf[0]).all() and (gf == hf[1]).all() and (gr == hf[2]).all(), (rep, k)
+
+
+@pytest.mark.parametrize("text_bytes", [200 * 1024, 256 * 1024 - 9000, 256 * 1024 - 300, 256 * 1024 + 4096])
+def test_calls_around_the_size_of_the_staging_arena(text_bytes, cfg):
+    """Round 3: the inputs and results of a small call are carved out of one 256 KiB device block and its pinned twin
+    (one copy in, one out).  Calls whose pieces only partly fit take the arena for the first pieces and separate blocks
+    for the rest; calls that do not fit at all take the pipelined path (pire_hip_run) or separate blocks: every answer
+    against the oracle, counters included, and again with recycled blocks."""
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_d"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(text_bytes % 9973)
+    alphabet = b"abcdeaxHeadInnerTailhello wd0123456789 xxx"
+    for n in (3, 900, 7000):
+        lens = rng.multinomial(text_bytes - n, np.ones(n) / n) + 1          # n strings, text_bytes in all
+        strings = [bytes(bytearray(alphabet[i] for i in rng.randint(0, len(alphabet), size=int(k)))) for k in lens]
+        text, offs = H.pack(strings)
+        assert len(text) == text_bytes
+        oi, of = o.run(text, offs)
+        lp, hf = o.prefix(text, offs, True), o.run_half_final(text, offs)
+        for rep in range(2):
+            cfg.set(host_staging=0)
+            gi, gf, counts = t.run(text, offs, counts=True)
+            assert (gi == oi).all() and (gf == of).all()
+            assert int(counts[0]) == int(of.sum()) and int(counts[1]) == n
+            assert (t.prefix(text, offs, True) == lp).all()
+            hi, hfin, hr = t.run_half_final(text, offs)
+            assert (hi == hf[0]).all() and (hfin == hf[1]).all() and (hr == hf[2]).all()
