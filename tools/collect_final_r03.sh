@@ -16,3 +16,5 @@ for f in c2 c5a c5b set_d c4_shard cxx_records cxx_one_string 2ranks_gloo; do cp
 cp $S/bench_slow_wide.jsonl $P/r03_bench_slow_wide.jsonl
 cp $S/ragged_cases.log $P/r03_final_ragged_cases.log
 for f in prefix half_final counting actions long_strings long_half_final capture pair host_mode host_call_latency shim warmup_curve; do cp $S/$f.log $P/r03_final_$f.log; done
+cp $S/micro_smallcall.log $P/r03_micro_smallcall.log
+cp $S/small_call_timeline.log $P/r03_small_call_timeline.log

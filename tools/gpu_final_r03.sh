@@ -69,6 +69,8 @@ for n,L in ((1<<16,4096),(1<<18,4096),(1<<19,4096)):
         t0=time.perf_counter(); idx,fin=t.run_strided_host(data); dt=time.perf_counter()-t0; best=min(best,dt)
     print("host-pointer mode: %d x %d B (%.0f MiB pageable): %.1f ms -> %.2f GB/s" % (n,L,n*L/2**20,best*1e3,n*L/best/1e9))
 PY
+hipcc --offload-arch=gfx950 -O3 -o /tmp/micro_smallcall tools/micro_smallcall.hip && /tmp/micro_smallcall | tee $OUT/micro_smallcall.log | cut -c1-200
+bash tools/gpu_scripts/r03_smalltrace.sh > /dev/null 2>&1; cp gpurun_out/small_call_timeline.log $OUT/small_call_timeline.log; rm -rf gpurun_out/smalltrace
 echo "== C++ shim (host pointers, pinned, device-resident) and the pigrep example"
 tests/cpp/bin/shim_test 2>&1 | tail -2 | tee $OUT/shim.log
 examples/bin/pigrep_hip -i "lds.*bytes" DESIGN.md | head -2
