@@ -86,6 +86,7 @@ struct CountingParams {
 	const uint16_t* denseMarks;
 	const uint32_t* actWords;
 	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
+	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class, longest first)
 	// CapturingScanner run
 	const uint8_t* tags;
 	uint8_t* outFinal;
@@ -204,7 +205,12 @@ __global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
 	for (uint32_t i = threadIdx.x; i < 256 * 2 * NREG; i += blockDim.x)
 		act[i] = p.actWords[i];
 	__syncthreads();
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		if (k >= p.n)
+			continue;
+		const uint64_t s = p.order ? p.order[k] : k;
 		const uint64_t b = p.offsets[s], e = p.offsets[s + 1];
 		if (e - b > 65000) {
 			const uint32_t k = atomicAdd(&p.overflow[0], 1u);
@@ -306,8 +312,12 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 
 	// with an overflow list (the packed kernel ran first on this stream): only the strings it names
 	const uint64_t todo = p.overflow ? p.overflow[0] : p.n;
-	for (uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; k < todo; k += uint64_t(gridDim.x) * blockDim.x) {
-		const uint64_t s = p.overflow ? p.overflow[1 + k] : k;
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < todo; ++pass) {
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x,
+		                                !p.overflow && p.order);
+		if (k >= todo)
+			continue;
+		const uint64_t s = p.overflow ? p.overflow[1 + k] : p.order ? p.order[k] : k;
 		Counters<RMAX> c;
 		c.Init();                                                       // Initialize, count.h:127-133
 		uint32_t st = p.initial;
@@ -380,7 +390,12 @@ __global__ __launch_bounds__(256) void CountingWideKernel(CountingParams p)
 	__syncthreads();
 	const uint64_t* trans = p.transInLds ? transLds : p.trans;
 	const uint32_t R = p.regexps;
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		if (k >= p.n)
+			continue;
+		const uint64_t s = p.order ? p.order[k] : k;
 		uint32_t* current = p.scratch + s * R;
 		uint32_t* total = p.outResults + s * R;
 		for (uint32_t r = 0; r < R; ++r)
@@ -433,7 +448,12 @@ __global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
 	const uint64_t* trans = p.transInLds ? transLds : p.trans;
 	// 32-bit positions (a string is shorter than 4 GiB); widened to the reference's size_t / npos on output
 	constexpr uint32_t npos = ~uint32_t(0);
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		if (k >= p.n)
+			continue;
+		const uint64_t s = p.order ? p.order[k] : k;
 		uint32_t st = p.initial;
 		uint32_t begin = npos, end = npos, counter = 0;     // Initialize, capture.h:89-94
 		auto step = [&](uint32_t ch) {
@@ -497,7 +517,12 @@ __global__ __launch_bounds__(256) void CaptureDenseKernel(CountingParams p)
 		reinterpret_cast<uint32_t*>(dense)[i] = reinterpret_cast<const uint32_t*>(p.dense)[i];
 	__syncthreads();
 	constexpr uint32_t npos = ~uint32_t(0);
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += uint64_t(gridDim.x) * blockDim.x) {
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		if (k >= p.n)
+			continue;
+		const uint64_t s = p.order ? p.order[k] : k;
 		uint32_t st = p.initial;
 		uint32_t begin = npos, end = npos, counter = 0, pend = 0, pendAt = 0;
 		auto take = [&]() {   // TakeAction, capture.h:96-102, for the step that set `pend`, at m_counter - 1 = pendAt
@@ -845,6 +870,25 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
 	if (e != hipSuccess)
 		return HipFail(e, "device query");
+	// the strings by length class (order.hip), so that a wave's 64 lanes finish together
+	void* orderScratch = nullptr;
+	struct OrderGuard {
+		void*& q;
+		hipStream_t s;
+		~OrderGuard()
+		{
+			if (q)
+				(void)hipFreeAsync(q, s);
+		}
+	} orderGuard{orderScratch, stream};
+	p.order = nullptr;
+	if (p.offsets && LengthOrderWanted(p.n)) {
+		e = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(length order)");
+		if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order))
+			return rc;
+	}
 	// Dense rows + packed 16-bit counters first (CountingPackedKernel); the strings it leaves on the overflow list
 	// (longer than 65 000 bytes) go through the 32-bit kernel below on the same stream.
 	void* list = nullptr;
@@ -1222,8 +1266,27 @@ try {
 	// one string per lane: the dense-row kernel when the table has the dense form (<= 255 states), else letter + transition
 	p.dense = image.dense;
 	p.denseMarks = image.denseMarks;
+	void* orderScratch = nullptr;   // freed on the stream, behind the kernel that reads it
+	struct OrderGuard {
+		void*& q;
+		hipStream_t s;
+		~OrderGuard()
+		{
+			if (q)
+				(void)hipFreeAsync(q, s);
+		}
+	} orderGuard{orderScratch, stream};
 	auto launchPerLane = [&]() -> int {
 		hipError_t le;
+		// (order.hip, measured on the capture walks: 1 025-1 045 GB/s in the caller's order, 941-977 by length -- the walk
+		// has little to win, its text reads lose their neighbours; `capture_by_length` keeps the A/B)
+		if (p.offsets && LengthOrderWanted(p.n) && GetConfig().capture_by_length) {
+			le = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
+			if (le != hipSuccess)
+				return HipFail(le, "hipMallocAsync(length order)");
+			if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order))
+				return rc;
+		}
 		if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
 			const uint32_t denseLds = p.states * 512;
 			le = SetDynamicLds(reinterpret_cast<const void*>(CaptureDenseKernel), uint32_t(denseLds));

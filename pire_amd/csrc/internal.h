@@ -567,6 +567,18 @@ inline hipError_t SetDynamicLds(const void* fn, uint32_t ldsBytes)
 	return hipSuccess;
 }
 
+// order.hip: the strings of an offset batch ordered by length class (longest first), built on the device, for the
+// one-string-per-lane kernels with per-byte actions.  `scratch`: LengthOrderScratchBytes(n) of device memory that stays
+// valid until the kernels that read *perm have run.
+// The k of pass `pass` (k = pass * lanes + t, or the same range backwards in odd passes when `serpentine`), for the
+// grid-stride loops of those kernels; >= n: nothing for this lane in this pass.
+__host__ __device__ inline uint64_t OrderedIndex(uint64_t pass, uint64_t t, uint64_t lanes, bool serpentine)
+{
+	return pass * lanes + ((serpentine && (pass & 1)) ? lanes - 1 - t : t);
+}
+bool LengthOrderWanted(uint64_t n);
+size_t LengthOrderScratchBytes(uint64_t n);
+int BuildLengthOrder(const uint64_t* offsets, uint64_t n, void* scratch, hipStream_t stream, const uint32_t** perm);
 void NoteKernel(const char* name, const char* symbol = nullptr);   // what pire_hip_last_kernel[_symbol]() report (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);

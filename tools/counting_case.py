@@ -17,7 +17,10 @@ blob = H.load_blob(case["blob"])
 t = pire_amd.CountingTable(blob, case["kind"])
 m = 1 << 20
 rng = np.random.RandomState(3)
+# COUNTING_FIXED_LEN=544: every string that long (how much of the time is lanes waiting for the longest string of their wave)
 lens = rng.randint(64, 1024, size=m).astype(np.uint64)
+if os.environ.get("COUNTING_FIXED_LEN"):
+    lens[:] = int(os.environ["COUNTING_FIXED_LEN"])
 offs = np.zeros(m + 1, dtype=np.uint64)
 offs[1:] = np.cumsum(lens)
 total = int(offs[-1])
@@ -29,6 +32,8 @@ R = t.RegexpsCount
 idx = torch.empty(m, dtype=torch.int32, device="cuda")
 res = torch.empty((m, R), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
+if os.environ.get("NO_LENGTH_ORDER"):
+    pire_amd.binding.set_config(no_length_order=1)
 generic = pire_amd.binding.FLAG_GENERIC if len(sys.argv) > 2 and sys.argv[2] == "generic" else 0   # the 32-bit kernel alone
 
 
