@@ -76,6 +76,7 @@ struct SlowParams {
 	const uint32_t* jumps;
 	const uint32_t* pair16;    // wide form, list kernel
 	uint32_t* overflow;        // list kernel -> wide kernel: [0] = count, [1 ..] = the strings whose sets outgrew the list
+	const uint32_t* order;     // list kernel, nullable: string k of the launch is order[k] (order.hip: by length class)
 	uint32_t* scratch;         // wide form, sets that do not fit the LDS: [waves][2][words]
 	uint32_t states, letters, start, words, flags, masksInLds, singleInLds;
 	const uint8_t* text;
@@ -417,7 +418,12 @@ __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
 	(void)ldsLetter;
 	const uint64_t stride = uint64_t(gridDim.x) * blockDim.x;
 	unsigned long long finals = 0, strings = 0;
-	for (uint64_t s = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x; s < p.n; s += stride) {
+	for (uint64_t pass = 0; pass * stride < p.n; ++pass) {
+		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride, p.order != nullptr);
+		if (k >= p.n)
+			continue;
+		const uint64_t s = p.order ? p.order[k] : k;
 		uint64_t b, e;
 		if (p.offsets) {
 			b = p.offsets[s];
@@ -999,6 +1005,22 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 		return HipFail(e, "hipMallocAsync(slow scanner overflow list)");
 	}
 	p.overflow = static_cast<uint32_t*>(list);
+	// ragged batches: the strings by length class (order.hip) -- this kernel is all VALU, a wave waiting for its longest
+	// string is its one avoidable cost
+	void* orderScratch = nullptr;
+	p.order = nullptr;
+	if (p.offsets && LengthOrderWanted(p.n)) {
+		e = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
+		if (e != hipSuccess) {
+			(void)hipFreeAsync(list, stream);
+			return HipFail(e, "hipMallocAsync(length order)");
+		}
+		if (int orc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order)) {
+			(void)hipFreeAsync(orderScratch, stream);
+			(void)hipFreeAsync(list, stream);
+			return orc;
+		}
+	}
 	const uint32_t ldsBytes = uint32_t(1056 + 16 + size_t(p.states + 1) * p.letters * 4);
 	e = SetDynamicLds(reinterpret_cast<const void*>(SlowListKernel), uint32_t(ldsBytes));
 	int rc = PIRE_HIP_OK;
@@ -1018,6 +1040,8 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 	}
 	if (rc == PIRE_HIP_OK)
 		rc = fallback(p);   // p.overflow set: only the strings on the list
+	if (orderScratch)
+		(void)hipFreeAsync(orderScratch, stream);
 	(void)hipFreeAsync(list, stream);
 	return rc;
 }

@@ -61,3 +61,26 @@ def test_capture_kernels_do_not_depend_on_the_order(name, cfg):
             assert pb.last_kernel() in ("capture_dense", "capture")
             assert all((x == y).all() for x, y in zip(want, got)), (name, off, flags)
     assert want[2].sum() > 0
+
+
+@pytest.mark.parametrize("name", ["slow_x40_utf8", "slow_alt"])
+def test_slow_list_kernel_does_not_depend_on_the_order(name, cfg):
+    """The SlowScanner list kernel takes ragged batches by length class too (it is all VALU: a wave waiting for its
+    longest string is its one avoidable cost)."""
+    import pire_amd
+    from pire_amd import binding as pb
+
+    case = [c for c in H.golden().get("slow", []) if c["name"] == name]
+    if not case:
+        pytest.skip("fixture not present")
+    blob = H.load_blob(case[0]["blob"])
+    t, o = pire_amd.SlowTable(blob), ob.OracleSlowScanner(blob)
+    rng = np.random.RandomState(12)
+    many = [s for s in batch(rng, b"ax.yd e\xd0\xb6bcx")]
+    of, obits = o.run_strings(many)
+    for off in (0, 1):
+        cfg.set(no_length_order=off)
+        gf, gbits, cnt = t.run_strings(many, counts=True)
+        assert pb.last_kernel().startswith("slow")
+        assert (gf == of).all() and (gbits == obits).all(), (name, off)
+        assert cnt.tolist() == [int(of.sum()), len(many)]
