@@ -86,7 +86,8 @@ struct CountingParams {
 	const uint16_t* denseMarks;
 	const uint32_t* actWords;
 	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
-	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class, longest first)
+	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class)
+	uint32_t serpentine;       // walk the order forwards and backwards in turn (the global order)
 	// CapturingScanner run
 	const uint8_t* tags;
 	uint8_t* outFinal;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
 	__syncthreads();
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		if (k >= p.n)
 			continue;
 		const uint64_t s = p.order ? p.order[k] : k;
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
 	const uint64_t todo = p.overflow ? p.overflow[0] : p.n;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < todo; ++pass) {
 		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x,
-		                                !p.overflow && p.order);
+		                                !p.overflow && p.serpentine);
 		if (k >= todo)
 			continue;
 		const uint64_t s = p.overflow ? p.overflow[1 + k] : p.order ? p.order[k] : k;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void CountingWideKernel(CountingParams p)
 	const uint32_t R = p.regexps;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		if (k >= p.n)
 			continue;
 		const uint64_t s = p.order ? p.order[k] : k;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
 	constexpr uint32_t npos = ~uint32_t(0);
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		if (k >= p.n)
 			continue;
 		const uint64_t s = p.order ? p.order[k] : k;
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(256) void CaptureDenseKernel(CountingParams p)
 	constexpr uint32_t npos = ~uint32_t(0);
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.order != nullptr);
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		if (k >= p.n)
 			continue;
 		const uint64_t s = p.order ? p.order[k] : k;
@@ -886,8 +887,10 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		e = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
 		if (e != hipSuccess)
 			return HipFail(e, "hipMallocAsync(length order)");
-		if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order))
+		bool serp = false;
+		if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order, &serp))
 			return rc;
+		p.serpentine = serp ? 1u : 0u;
 	}
 	// Dense rows + packed 16-bit counters first (CountingPackedKernel); the strings it leaves on the overflow list
 	// (longer than 65 000 bytes) go through the 32-bit kernel below on the same stream.
@@ -1284,8 +1287,10 @@ try {
 			le = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
 			if (le != hipSuccess)
 				return HipFail(le, "hipMallocAsync(length order)");
-			if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order))
+			bool serp = false;
+			if (int rc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order, &serp))
 				return rc;
+			p.serpentine = serp ? 1u : 0u;
 		}
 		if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
 			const uint32_t denseLds = p.states * 512;

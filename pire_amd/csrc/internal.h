@@ -578,7 +578,8 @@ __host__ __device__ inline uint64_t OrderedIndex(uint64_t pass, uint64_t t, uint
 }
 bool LengthOrderWanted(uint64_t n);
 size_t LengthOrderScratchBytes(uint64_t n);
-int BuildLengthOrder(const uint64_t* offsets, uint64_t n, void* scratch, hipStream_t stream, const uint32_t** perm);
+// *serpentine: whether the kernels should walk the order with OrderedIndex's serpentine (the global order) or plainly
+int BuildLengthOrder(const uint64_t* offsets, uint64_t n, void* scratch, hipStream_t stream, const uint32_t** perm, bool* serpentine);
 void NoteKernel(const char* name, const char* symbol = nullptr);   // what pire_hip_last_kernel[_symbol]() report (thread local)
 bool RaggedActEligible(const ScanParams& p);
 int LaunchRaggedHalfFinal(const ScanParams& p, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream);

@@ -12,6 +12,9 @@
 //
 // Length classes: 32-byte steps below 1 KiB, quarter octaves above (a class spans at most 32 bytes or 19 %); longest
 // class first, so that what runs at the end of the launch -- when CUs go idle one by one -- is the short strings.
+// (Tried: every run of 4 096 consecutive strings sorted on its own -- one launch, and a wave's strings from one stretch of
+// the text -- 719 GB/s against 1 042 for the one order over the whole batch, 948 without: the blocks of a grid-stride
+// loop then meet the same rank of every run, i.e. some only long strings.  profiles/r03_length_order.log.)
 // Results do not depend on the order (every string is walked by one lane from its first byte to its last, as before).
 //
 // The kernels take string k of the order in a SERPENTINE over their passes (OrderedIndex below): a lane that took the
@@ -134,9 +137,10 @@ size_t LengthOrderScratchBytes(uint64_t n)
 	return ((size_t(n) * 4 + 255) & ~size_t(255)) + size_t(OrderBlocks(n)) * kOrderClasses * 4;
 }
 
-int BuildLengthOrder(const uint64_t* offsets, uint64_t n, void* scratch, hipStream_t stream, const uint32_t** perm)
+int BuildLengthOrder(const uint64_t* offsets, uint64_t n, void* scratch, hipStream_t stream, const uint32_t** perm, bool* serpentine)
 {
 	uint32_t* p = static_cast<uint32_t*>(scratch);
+	*serpentine = true;
 	uint32_t* hist = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + ((size_t(n) * 4 + 255) & ~size_t(255)));
 	const uint32_t blocks = OrderBlocks(n);
 	const uint64_t perBlock = (n + blocks - 1) / blocks;

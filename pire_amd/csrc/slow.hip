@@ -77,6 +77,7 @@ struct SlowParams {
 	const uint32_t* pair16;    // wide form, list kernel
 	uint32_t* overflow;        // list kernel -> wide kernel: [0] = count, [1 ..] = the strings whose sets outgrew the list
 	const uint32_t* order;     // list kernel, nullable: string k of the launch is order[k] (order.hip: by length class)
+	uint32_t serpentine;
 	uint32_t* scratch;         // wide form, sets that do not fit the LDS: [waves][2][words]
 	uint32_t states, letters, start, words, flags, masksInLds, singleInLds;
 	const uint8_t* text;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
 	unsigned long long finals = 0, strings = 0;
 	for (uint64_t pass = 0; pass * stride < p.n; ++pass) {
 		// order.hip: a wave takes 64 strings of about the same length, a lane long and short ones in turn
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride, p.order != nullptr);
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, stride, p.serpentine != 0);
 		if (k >= p.n)
 			continue;
 		const uint64_t s = p.order ? p.order[k] : k;
@@ -1015,7 +1016,10 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 			(void)hipFreeAsync(list, stream);
 			return HipFail(e, "hipMallocAsync(length order)");
 		}
-		if (int orc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order)) {
+		bool serp = false;
+		const int orc = BuildLengthOrder(p.offsets, p.n, orderScratch, stream, &p.order, &serp);
+		p.serpentine = serp ? 1u : 0u;
+		if (orc) {
 			(void)hipFreeAsync(orderScratch, stream);
 			(void)hipFreeAsync(list, stream);
 			return orc;
