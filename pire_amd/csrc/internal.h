@@ -600,6 +600,8 @@ int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* 
                  unsigned long long* workCounter);
 // pair.hip: two scanners in one pass over fixed-length records (run.h:229-241)
 bool PairTiledEligible(const ScanParams& a, const ScanParams& b);
+// the tiled kernel for the segmented scan's grid segments, warm-up inside the pass (tiled.hip, TiledSegParams)
+int LaunchTiledSeg(const ScanParams& p, uint64_t warmBytes, const uint32_t* segJ, uint32_t* guess, hipStream_t stream);
 // guessA != nullptr: the segmented scan's form (pair.hip, PairParams): warm-up inside the pass, the guesses written out
 int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB, hipStream_t stream, uint64_t warmBytes = 0,
                     const uint32_t* segJ = nullptr, uint32_t* guessA = nullptr, uint32_t* guessB = nullptr);

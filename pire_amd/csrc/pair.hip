@@ -180,8 +180,9 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 	const uint32_t voff = (lane & ~7u) * uint32_t(pa.stride) + (lane & 7u) * 16;
 	const uint64_t low = SEG ? reinterpret_cast<uint64_t>(pa.text) : 0;
 	const uint64_t text = reinterpret_cast<uint64_t>(pa.text) - uint64_t(warm) * 128;
-	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
-	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+	const uint32_t wavesPerBlock = blockDim.x >> 6;   // 16, or fewer when the batch has fewer tasks than 16 per CU
+	const uint64_t taskStep = uint64_t(gridDim.x) * wavesPerBlock;
+	const uint64_t firstTask = uint64_t(blockIdx.x) * wavesPerBlock + wave;
 
 	u32x4 a[8], b[8];
 	ZeroTile(a);
@@ -242,9 +243,9 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 					sum = atomicAdd(prog, 2u) + 2;
 				sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
 				myTiles += 2;
-				if (myTiles * 16 > sum + 8)
+				if (myTiles * wavesPerBlock > sum + 8)
 					__builtin_amdgcn_s_setprio(0);
-				else if (myTiles * 16 + 8 < sum)
+				else if (myTiles * wavesPerBlock + 8 < sum)
 					__builtin_amdgcn_s_setprio(3);
 				else
 					__builtin_amdgcn_s_setprio(1);
@@ -326,13 +327,16 @@ int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB,
 	hipError_t e = SetDynamicLds(kernel, uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	// one block per CU (the tables fill its LDS); a batch of fewer than 16 tasks per CU gets smaller blocks on more CUs
+	// (the segmented scan of 64-256 MiB: 1 024-4 096 tasks)
 	const uint64_t ntasks = q.a.n / 64;
-	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + 15) / 16, uint64_t(cus)));
+	const uint64_t waves = std::max<uint64_t>(4, std::min<uint64_t>(16, (ntasks + cus - 1) / cus));
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + waves - 1) / waves, uint64_t(cus)));
 	NoteKernel("pair_tiled", "pirehip::ScanPairTiledKernel");
 	if (seg)
-		hipLaunchKernelGGL(ScanPairTiledKernel<true>, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
+		hipLaunchKernelGGL(ScanPairTiledKernel<true>, dim3(unsigned(blocks)), dim3(unsigned(waves * 64)), ldsBytes, stream, q);
 	else
-		hipLaunchKernelGGL(ScanPairTiledKernel<false>, dim3(unsigned(blocks)), dim3(1024), ldsBytes, stream, q);
+		hipLaunchKernelGGL(ScanPairTiledKernel<false>, dim3(unsigned(blocks)), dim3(unsigned(waves * 64)), ldsBytes, stream, q);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "pair kernel launch");

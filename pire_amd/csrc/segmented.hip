@@ -603,7 +603,7 @@ bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 		return false;
 	const double lanes = 256.0 * 1024.0;
 	const double plain = std::ceil(double(n) / lanes) * mean / 25e6;
-	const double segmented = double(totalBytes) / 1.1e12 + 150e-6;
+	const double segmented = double(totalBytes) / 2.0e12 + 80e-6;   // (round 3's numbers; rounds 1-2: 1.1e12, 150e-6)
 	return plain > 1.5 * segmented;
 }
 
@@ -636,7 +636,9 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	PIRE_TRY(DeviceCUs(&cus));
 	// segments: as many as there are lanes, a multiple of the 128-byte window, long against the warm-up
 	const uint64_t wanted = uint64_t(cus) * 1024;
-	uint64_t segBytes = std::min<uint64_t>(1u << 20, std::max<uint64_t>(4096, (total / wanted + 127) / 128 * 128));
+	// (floor 1 KiB since round 3 -- four times the warm-up: below 1 GiB of text 4 KiB segments left most lanes without
+	// one, and a lane walks 25 MB/s however few are busy: 256 MiB took 0.23 ms, as long as 1 GiB)
+	uint64_t segBytes = std::min<uint64_t>(1u << 20, std::max<uint64_t>(1024, (total / wanted + 255) / 256 * 256));
 	segBytes = Knob(cfg.segment_bytes, segBytes);
 	const uint64_t warmBytes = Knob(cfg.segment_warmup, 256);
 	const uint32_t maxModes = uint32_t(std::min<uint64_t>(kMaxModes, std::max<uint64_t>(1, Knob(cfg.segment_modes, 6))));
@@ -743,10 +745,56 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	uint32_t* dConst = nullptr;
 	// one mode: warm-up from its representative (mode 0: the string's own start state, and the first segment's
 	// warm-up is empty, so its guess is the true start state), then the scan proper from the guesses
+	// the grid segments of ONE mode with the warm-up inside the tiled pass (tiled.hip, ScanTiledSegKernel): whole
+	// 64-segment tasks, whole pairs of tiles
+	const uint64_t fusedSegs = (warmBytes % 256 == 0 && warmBytes <= segBytes && segBytes % 256 == 0 && !cfg.segment_no_pair)
+	                               ? gridSegs & ~uint64_t(63) : 0;
 	auto addMode = [&](bool first, uint32_t representative) -> int {
 		const uint32_t m = sl.count;
 		PIRE_TRY(scratch.Alloc(&sl.guess[m], S));
 		PIRE_TRY(scratch.Alloc(&sl.end[m], S));
+		if (fusedSegs) {
+			// one launch for warm-up and scan of the grid's whole tasks; whatever is left (the segments beyond the
+			// last whole 64, tails) gets a warm-up batch and a scan batch of its own
+			ScanParams r = q;
+			r.offsets = nullptr;
+			r.ends = nullptr;
+			r.n = fusedSegs;
+			r.len = r.stride = segBytes;
+			r.outIdx = sl.end[m];
+			if (first) {
+				r.initIdx = a.initSeg;                   // nullable: then startPerm (Initialize + Begin folded)
+				r.flags = (p.flags & PIRE_HIP_RUN_BEGIN) | kPermIds;
+			} else {
+				r.initIdx = nullptr;
+				r.startPerm = representative;
+				r.flags = kPermIds;
+			}
+			PIRE_TRY(LaunchTiledSeg(r, warmBytes, a.segJ, sl.guess[m], stream));
+			if (fusedSegs < S) {
+				const uint64_t rest = S - fusedSegs;
+				if (!first) {
+					if (!dConst)
+						PIRE_TRY(scratch.Alloc(&dConst, S));
+					hipLaunchKernelGGL(SegmentFillKernel, dim3(unsigned((rest + 255) / 256)), dim3(256), 0, stream, dConst, representative, rest);
+				}
+				q.n = rest;
+				q.offsets = a.warmBegin + fusedSegs;
+				q.ends = a.segBegin + fusedSegs;
+				q.initIdx = first ? (a.initSeg ? a.initSeg + fusedSegs : nullptr) : dConst;
+				q.flags = (first ? (p.flags & PIRE_HIP_RUN_BEGIN) : 0u) | kPermIds;
+				q.outIdx = sl.guess[m] + fusedSegs;
+				PIRE_TRY(ScanBatch(q, t, stream));
+				q.flags = kPermIds;
+				q.offsets = a.segBegin + fusedSegs;
+				q.ends = a.segEnd + fusedSegs;
+				q.initIdx = sl.guess[m] + fusedSegs;
+				q.outIdx = sl.end[m] + fusedSegs;
+				PIRE_TRY(ScanBatch(q, t, stream));
+			}
+			sl.count = m + 1;
+			return PIRE_HIP_OK;
+		}
 		q.n = S;
 		q.offsets = a.warmBegin;
 		q.ends = a.segBegin;
@@ -1025,8 +1073,10 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	if (halfFinalResults)
 		PIRE_TRY(launchFinish(nullptr));
 	PIRE_TRY(HipOk(hipGetLastError(), "segmented scan launch"));
-	// "+plain": some strings ended in the sequential walk; the symbol says whether two modes shared one pass
-	NoteKernel(nPlain ? "segmented+plain" : "segmented", pairedFirst ? "pirehip::ScanPairTiledKernel" : "");
+	// "+plain": some strings ended in the sequential walk; the symbol says whether two modes shared one pass, or one
+	// mode had its warm-up inside the tiled pass
+	NoteKernel(nPlain ? "segmented+plain" : "segmented",
+	           pairedFirst ? "pirehip::ScanPairTiledKernel" : fusedSegs ? "pirehip::ScanTiledSegKernel" : "");
 	if (wantStats) {
 		mark("finish");
 		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %u modes, %llu chain "

@@ -304,6 +304,140 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 }
 
 
+// ------------------------------------------------------------------------------------------ segmented scan, one mode
+// The tiled kernel for the segmented scan's grid segments (segmented.hip) with the WARM-UP INSIDE THE PASS, as the pair
+// kernel has it for two modes (pair.hip, SEG): a lane starts `warmTiles` 128-byte tiles before its segment in the
+// mode's representative state (mode 0: the string's own start state), writes the state it is in at the segment's first
+// byte to `guess` (device ids; what the chain compares) and walks on; a string's first segment (segJ == 0) keeps its
+// start state, and the one record whose warm-up would lie in front of the text reads its own bytes for those tiles.
+// One launch instead of a ragged warm-up batch plus the tiled pass: what a table with ONE mode -- e.g. the reference's
+// benchmark corpus as one string -- still paid in round 3's first version of the fused scan.
+// A kernel of its own (a trimmed copy of ScanTiledKernel's loop: shipped variant only, even tile counts only) so that
+// the headline kernel's code is what it was.
+struct TiledSegParams {
+	ScanParams p;
+	uint32_t warmTiles;
+	const uint32_t* segJ;
+	uint32_t* guess;
+};
+
+__device__ __forceinline__ void IssueTileLow(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride, uint64_t low)
+{
+	// only the warm-up tiles of the very first record (the first load's lanes 0..7) lie below `low`, the first byte of
+	// the text: those lanes read from the record itself instead, and what they read is never used
+	uint32_t voff0 = voff;
+	if (tileBase < low)
+		voff0 += (threadIdx.x & 63) < 8 ? uint32_t(low - tileBase + 127) & ~127u : 0u;
+	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
+	asm volatile(
+		"global_load_dwordx4 %0, %17, %9 nt\n\t"
+		"global_load_dwordx4 %1, %8, %10 nt\n\t"
+		"global_load_dwordx4 %2, %8, %11 nt\n\t"
+		"global_load_dwordx4 %3, %8, %12 nt\n\t"
+		"global_load_dwordx4 %4, %8, %13 nt\n\t"
+		"global_load_dwordx4 %5, %8, %14 nt\n\t"
+		"global_load_dwordx4 %6, %8, %15 nt\n\t"
+		"global_load_dwordx4 %7, %8, %16 nt"
+		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7), "v"(voff0));
+}
+
+__device__ __forceinline__ void PhaseSeg(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, uint64_t rowBase,
+                                         uint64_t chainBase, uint32_t voff, uint64_t istride, uint64_t low, uint32_t lane,
+                                         uint32_t t, uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& hs,
+                                         uint32_t& cold, uint32_t* prog, uint32_t& myTiles)
+{
+	{   // the waves of a block kept in step (EQ, above)
+		uint32_t sum = 0;
+		if (lane == 0)
+			sum = atomicAdd(prog, 1u) + 1;
+		sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+		const uint32_t mine = ++myTiles;
+		constexpr uint32_t margin = 4;
+		if (mine * (blockDim.x >> 6) > sum + margin)
+			__builtin_amdgcn_s_setprio(0);
+		else if (mine * (blockDim.x >> 6) + margin < sum)
+			__builtin_amdgcn_s_setprio(3);
+		else
+			__builtin_amdgcn_s_setprio(1);
+	}
+	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
+	IssueTileLow(refill, voff, ahead, istride, low);
+	WaitTile<1>(cur);
+	TransposeTile(cur, lane);
+	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating
+		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + hs, 1u);
+	StepTile<0>(p, lds, L, cur, hs, cold, t);
+}
+
+__global__ __launch_bounds__(1024, 4) void ScanTiledSegKernel(TiledSegParams q)
+{
+	const ScanParams& p = q.p;
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const LdsLayout L = MakeLayout(p.hot, 0, 256u, CompactBytes(p));
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = p.n / 64;                          // whole tasks only
+	const uint32_t warm = q.warmTiles;                         // even (the launcher checks)
+	const uint32_t ntiles = uint32_t(p.len / 128) + warm;      // even (the launcher checks)
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
+	const uint64_t istride = p.stride;
+	const uint64_t low = reinterpret_cast<uint64_t>(p.text);
+	const uint64_t text = low - uint64_t(warm) * 128;
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + L.progOff);
+	uint32_t myTiles = 0;
+	const uint32_t wavesPerBlock = blockDim.x >> 6;   // 16, or fewer when the batch has fewer tasks than 16 per CU
+	const uint64_t taskStep = uint64_t(gridDim.x) * wavesPerBlock;
+	const uint64_t firstTask = uint64_t(blockIdx.x) * wavesPerBlock + wave;
+	bool primed = firstTask < ntasks;
+	if (primed)
+		IssueTileLow(a, voff, Uniform64(text + firstTask * 64 * p.stride), istride, low);
+	LoadTableToLds(p, lds, L);
+	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
+		const uint64_t s0 = task * 64;
+		const uint64_t s = s0 + lane;
+		const uint64_t rowBase = Uniform64(text + s0 * p.stride);
+		const bool hasNext = task + taskStep < ntasks;
+		const uint64_t chainBase = hasNext ? Uniform64(text + (s0 + taskStep * 64) * p.stride) : rowBase + uint64_t(lastTile) * 128;
+		uint32_t cold = StartState(p, s);   // the mode's representative (mode 0: the string's start state)
+		uint32_t hs = cold < p.hot ? cold : p.hot;
+		bool done = false;
+		if (!primed)
+			IssueTileLow(a, voff, rowBase, istride, low);
+		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+			if (t == warm) {   // the segment's first byte: this state is the guess
+				uint32_t st = hs != p.hot ? hs : cold;
+				if (q.segJ[s] == 0)
+					st = StartState(p, s);
+				q.guess[s] = st;
+				cold = st;
+				hs = st < p.hot ? st : p.hot;
+			}
+			PhaseSeg(p, lds, L, rowBase, chainBase, voff, istride, low, lane, t, lastTile, a, b, hs, cold, prog, myTiles);
+			PhaseSeg(p, lds, L, rowBase, chainBase, voff, istride, low, lane, t + 1, lastTile, b, a, hs, cold, prog, myTiles);
+			done = t >= warm && AllAbsorbing(p, lds, L, hs);
+		}
+		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
+		if (done)
+			WaitTile<0>(a);
+		uint32_t st = hs != p.hot ? hs : cold;
+		if (!done) {   // tail shorter than a tile: exact steps straight from memory
+			const uint8_t* base = p.text + s * p.stride;
+			for (uint64_t i = uint64_t(ntiles - warm) * 128; i < p.len; ++i)
+				st = SlowStep(p, lds, L, st, base[i]);
+		}
+		Finish(p, lds, L, s, true, st);
+	}
+	WaitTile<0>(a);
+	WaitTile<0>(b);
+	FlushCounts(p, lds, L);
+}
+
 // ------------------------------------------------------------------------------------------ launcher
 
 bool TiledEligible(const ScanParams& p)
@@ -432,5 +566,40 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	return LaunchGeneric(tail, stream);
 }
 
+
+
+int LaunchTiledSeg(const ScanParams& p, uint64_t warmBytes, const uint32_t* segJ, uint32_t* guess, hipStream_t stream)
+{
+	if (warmBytes % 256 != 0 || warmBytes > p.stride || (p.len / 128) % 2 != 0 || p.len < 256 || !segJ || !guess || !TiledEligible(p)) {
+		SetError("tiled segment kernel: whole pairs of 128-byte tiles, a warm-up no longer than the segment");
+		return PIRE_HIP_EINVAL;
+	}
+	TiledSegParams q = {};
+	q.p = p;
+	q.p.n = p.n & ~uint64_t(63);   // whole 64-segment tasks; the caller runs the rest as batches of their own
+	q.p.outCounts = nullptr;
+	q.p.outFinal = nullptr;
+	q.warmTiles = uint32_t(warmBytes / 128);
+	q.segJ = segJ;
+	q.guess = guess;
+	if (q.p.n == 0)
+		return PIRE_HIP_OK;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const LdsLayout L = MakeLayout(p.hot, 0, 256u, CompactBytes(p));
+	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(ScanTiledSegKernel), L.total);
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	// one block per CU (the table fills its LDS); fewer than 16 tasks per CU: smaller blocks on more CUs
+	const uint64_t ntasks = q.p.n / 64;
+	// (at least 4 waves: LoadTableToLds hands its small pieces to the first 256 threads)
+	const uint64_t waves = std::max<uint64_t>(4, std::min<uint64_t>(16, (ntasks + cus - 1) / cus));
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + waves - 1) / waves, uint64_t(cus)));
+	NoteKernel("tiled_seg", "pirehip::ScanTiledSegKernel");
+	hipLaunchKernelGGL(ScanTiledSegKernel, dim3(unsigned(blocks)), dim3(unsigned(waves * 64)), L.total, stream, q);
+	e = hipGetLastError();
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "tiled segment kernel launch");
+}
 
 }  // namespace pirehip
