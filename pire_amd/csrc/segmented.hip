@@ -710,9 +710,9 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	PIRE_TRY(scratch.Alloc(&c.breakSeg, n));
 	PIRE_TRY(scratch.Alloc(&c.breakState, n));
 	PIRE_TRY(scratch.Alloc(&c.broken, 1));
-	// the cut, and the initial values of the patch slot and of the chain's per-string arrays, in one launch
-	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a, sl.guess[kMaxModes], sl.end[kMaxModes],
-	                   c.strDone, c.breakSeg, c.broken);
+	// (the kernel that fills these -- the cut, the patch slot, the chain's per-string arrays -- is launched further down,
+	// right in front of the first mode's pass: everything the host does in between would otherwise be a gap on the
+	// stream between that 5 us kernel and the pass, 10-20 us in the kernel trace of a call)
 	// the host's copy of the cut (same arithmetic), for the batches of broken chains
 	auto segBeginOf = [&](uint64_t i, uint32_t k) {
 		const uint64_t B = hostOffsets ? hostOffsets[i] : i * p.stride;
@@ -905,6 +905,8 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		probe.len = probe.stride = segBytes;
 		pairedFirst = TiledEligible(probe) && segBytes % 256 == 0;
 	}
+	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a, sl.guess[kMaxModes], sl.end[kMaxModes],
+	                   c.strDone, c.breakSeg, c.broken);
 	if (pairedFirst) {
 		PIRE_TRY(addModePair(t->host.permOfOrig[known[0]]));
 		nextKnown = 1;
