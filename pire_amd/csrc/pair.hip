@@ -180,7 +180,9 @@ __global__ __launch_bounds__(1024, 4) void ScanPairTiledKernel(PairParams q)
 	const uint32_t voff = (lane & ~7u) * uint32_t(pa.stride) + (lane & 7u) * 16;
 	const uint64_t low = SEG ? reinterpret_cast<uint64_t>(pa.text) : 0;
 	const uint64_t text = reinterpret_cast<uint64_t>(pa.text) - uint64_t(warm) * 128;
-	const uint32_t wavesPerBlock = blockDim.x >> 6;   // 16, or fewer when the batch has fewer tasks than 16 per CU
+	// 16; the segmented scan's form: fewer when the batch has fewer tasks than 16 per CU (a compile-time 16 for the plain
+	// pair: the run-time value cost it 28 bytes of scratch, tests/test_build_audit.py)
+	const uint32_t wavesPerBlock = SEG ? blockDim.x >> 6 : 16u;
 	const uint64_t taskStep = uint64_t(gridDim.x) * wavesPerBlock;
 	const uint64_t firstTask = uint64_t(blockIdx.x) * wavesPerBlock + wave;
 
@@ -330,7 +332,7 @@ int LaunchPairTiled(const ScanParams& a, const ScanParams& b, uint32_t* outIdxB,
 	// one block per CU (the tables fill its LDS); a batch of fewer than 16 tasks per CU gets smaller blocks on more CUs
 	// (the segmented scan of 64-256 MiB: 1 024-4 096 tasks)
 	const uint64_t ntasks = q.a.n / 64;
-	const uint64_t waves = std::max<uint64_t>(4, std::min<uint64_t>(16, (ntasks + cus - 1) / cus));
+	const uint64_t waves = seg ? std::max<uint64_t>(4, std::min<uint64_t>(16, (ntasks + cus - 1) / cus)) : 16;
 	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>((ntasks + waves - 1) / waves, uint64_t(cus)));
 	NoteKernel("pair_tiled", "pirehip::ScanPairTiledKernel");
 	if (seg)

@@ -36,8 +36,9 @@ def resources(unit):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_scan_kernels_have_no_scratch_and_no_spills():
-    tiled = {k: v for k, v in resources("tiled.hip").items() if "ScanTiledKernel" in k}
-    assert tiled, "no tiled kernel instantiation found"
+    tiled = {k: v for k, v in resources("tiled.hip").items() if "ScanTiledKernel" in k or "ScanTiledSegKernel" in k}
+    assert any("ScanTiledKernel" in k for k in tiled), "no tiled kernel instantiation found"
+    assert any("ScanTiledSegKernel" in k for k in tiled), "no segment form of the tiled kernel found"
     ragged = {k: v for k, v in resources("ragged.hip").items() if "ScanRaggedKernel" in k}
     assert ragged, "no ragged kernel found"
     pair = {k: v for k, v in resources("pair.hip").items() if "ScanPairTiledKernel" in k}
