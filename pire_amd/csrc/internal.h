@@ -202,6 +202,13 @@ struct pire_hip_table {
 	std::atomic<uint32_t> workSlot[pirehip::kMaxDevices] = {};   // per device image: round-robin over its counter pairs
 	std::mutex segMutex;
 	std::vector<uint32_t> segModes;      // segmented.hip: mode representatives (state indices) earlier calls learned
+	// segmented.hip, ModeFunction: for a pair (start state, mode representative), reference numbering, the function f
+	// with "mode's state = f(mode 0's state)" after any text -- or an empty vector when there is none
+	struct SegModeFn {
+		uint32_t a0, b0, minSteps;
+		std::vector<uint32_t> f;
+	};
+	std::vector<SegModeFn> segModeFns;
 	// Adaptation (table.cpp AdaptTable) rewrites host.{hot, origOfPerm, permOfOrig, hotRows, ...} and swaps the images.
 	// Run entry points hold adaptMutex SHARED while they copy what they need (api.cpp FillParams); an adaptation holds
 	// it exclusively.  Images an AUTOMATIC adaptation replaces are not freed but retired: a call on another host thread

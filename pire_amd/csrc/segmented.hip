@@ -591,6 +591,106 @@ int HipOk(hipError_t e, const char* what)
 // Worth it when the lanes would starve.  One string per lane walks ~25 MB/s per lane however many lanes are busy
 // (measured: 1 024 x 1 MiB 40 ms, 16 384 x 64 KiB 2.6 ms); the segmented scan does ~1.1 TB/s plus ~0.15 ms of fixed
 // cost (profiles/r01_long_strings.log).  Either is exact; PIRE_HIP_SEGMENT_BYTES forces this one (tests).
+// A mode DERIVED from mode 0 (round 3).  Walk a text from the start state a0 and from a mode's representative b0 at the
+// same time: the pair of states moves through the product automaton.  If among ALL pairs reachable from (a0, b0) every
+// first component comes with exactly one second component -- b = f(a) -- then the mode's walk is redundant: its guess
+// and its end state of every segment are f of mode 0's, whatever the bytes.  That is the case for the sticky modes of
+// the benchmark tables ("pattern 3 was seen": the same walk with one more bit set, until mode 0's walk sets it too),
+// and then two modes cost ONE pass over the text instead of the pair kernel's two lookups per byte.  The search is a
+// BFS over at most `states` pairs (it stops at the first state that turns up with two partners) on the host, once per
+// (a0, b0), remembered in the table in reference numbering; the letters are those the 256 byte values map to (the
+// marks of Begin() / End() never occur inside a segment).  Exact by construction: the BFS covers every text.
+__global__ void SegmentDeriveKernel(const uint32_t* guess0, const uint32_t* end0, const uint32_t* f, uint32_t states,
+                                    uint32_t* guess, uint32_t* end, uint64_t n)
+{
+	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (k >= n)
+		return;
+	const uint32_t g = guess0[k], e = end0[k];
+	guess[k] = g < states ? f[g] : kNoState;
+	end[k] = e < states ? f[e] : kNoState;
+}
+
+// f in reference numbering (kNoState where mode 0's walk never gets); false: no such function.  Only pairs reached by
+// texts of at least `minSteps` bytes count -- a segment's guess is taken after its whole warm-up, its end state later
+// still -- because on the first bytes the two walks have not forgotten where they started (the same mode-0 state then
+// comes with several partners).  Levels of pairs up to minSteps (stopping early where a level repeats), then the closure.
+bool ModeFunction(const HostTable& h, uint32_t a0, uint32_t b0, uint32_t minSteps, std::vector<uint32_t>* f)
+{
+	std::vector<uint32_t> letters;
+	{
+		std::vector<uint8_t> seen(h.letters, 0);
+		for (uint32_t c = 0; c < 256; ++c)
+			if (h.cls[c] < h.letters && !seen[h.cls[c]]) {
+				seen[h.cls[c]] = 1;
+				letters.push_back(h.cls[c]);
+			}
+	}
+	const size_t cap = std::max<size_t>(size_t(h.states) * 8, 4096);   // pairs per level we are willing to follow
+	std::vector<uint64_t> level{(uint64_t(a0) << 32) | b0}, next;
+	for (uint32_t step = 0; step < minSteps; ++step) {
+		next.clear();
+		for (uint64_t pr : level) {
+			const uint32_t a = uint32_t(pr >> 32), b = uint32_t(pr);
+			for (uint32_t l : letters)
+				next.push_back((uint64_t(h.next[size_t(a) * h.letters + l]) << 32) | h.next[size_t(b) * h.letters + l]);
+		}
+		std::sort(next.begin(), next.end());
+		next.erase(std::unique(next.begin(), next.end()), next.end());
+		if (next.size() > cap)
+			return false;
+		if (next == level)
+			break;   // a fixed point: every later level is this one
+		level.swap(next);
+	}
+	f->assign(h.states, kNoState);
+	std::vector<uint32_t> todo;
+	for (uint64_t pr : level) {
+		const uint32_t a = uint32_t(pr >> 32), b = uint32_t(pr);
+		if ((*f)[a] == kNoState) {
+			(*f)[a] = b;
+			todo.push_back(a);
+		} else if ((*f)[a] != b) {
+			return false;
+		}
+	}
+	while (!todo.empty()) {
+		const uint32_t a = todo.back();
+		todo.pop_back();
+		const uint32_t b = (*f)[a];
+		for (uint32_t l : letters) {
+			const uint32_t na = h.next[size_t(a) * h.letters + l], nb = h.next[size_t(b) * h.letters + l];
+			if ((*f)[na] == kNoState) {
+				(*f)[na] = nb;
+				todo.push_back(na);
+			} else if ((*f)[na] != nb) {
+				return false;
+			}
+		}
+	}
+	return true;
+}
+
+// the same through the table's memory of earlier answers; *f stays valid while the caller holds nothing (a copy)
+bool ModeFunctionCached(pire_hip_table* t, uint32_t a0, uint32_t b0, uint32_t minSteps, std::vector<uint32_t>* f)
+{
+	{
+		std::lock_guard<std::mutex> lock(t->segMutex);
+		for (const auto& e : t->segModeFns)
+			if (e.a0 == a0 && e.b0 == b0 && e.minSteps == minSteps) {
+				*f = e.f;
+				return !f->empty();
+			}
+	}
+	const bool ok = ModeFunction(t->host, a0, b0, minSteps, f);
+	if (!ok)
+		f->clear();
+	std::lock_guard<std::mutex> lock(t->segMutex);
+	if (t->segModeFns.size() < 64)
+		t->segModeFns.push_back({a0, b0, minSteps, *f});
+	return ok;
+}
+
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 {
 	const pire_hip_config cfg = GetConfig();
@@ -677,7 +777,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		                      + 8                      // prefix
 		                      + 4;                     // true start states (half-final counting)
 		const size_t perString = 5 * 4 + 2 * 8 + 3 * 4 + 4;
-		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + chainBlocks * 16 + 64 * 256));
+		PIRE_TRY(scratch.Reserve(S * perSeg + n * perString + chainBlocks * 16 + size_t(t->host.states) * 4 * kMaxModes + 64 * 256));
 	}
 	if (hostOffsets) {
 		uint32_t* d = nullptr;
@@ -907,17 +1007,71 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	}
 	hipLaunchKernelGGL(SegmentPrepKernel, dim3(blocks), dim3(256), 0, stream, p, g, a, sl.guess[kMaxModes], sl.end[kMaxModes],
 	                   c.strDone, c.breakSeg, c.broken);
-	if (pairedFirst) {
-		PIRE_TRY(addModePair(t->host.permOfOrig[known[0]]));
+	// Modes that are a function of mode 0 (ModeFunction above) are not walked: their slots are filled from mode 0's by a
+	// table lookup per segment.  Only with one start state for every string (no caller's resume states): mode 0 is then
+	// the walk from q.startPerm, slot 0.
+	// ... and with segments no shorter than the warm-up: every segment but a string's first then has ALL of it behind it
+	const bool derive = !p.initIdx && !cfg.segment_no_derive && segBytes >= warmBytes && warmBytes < (1u << 20);
+	const uint32_t minSteps = uint32_t(warmBytes);
+	const uint32_t a0 = t->host.origOfPerm[q.startPerm];
+	uint32_t* dModeFn = nullptr;
+	void* pinnedFn = nullptr;
+	size_t pinnedFnBytes = 0;
+	struct PinnedGuard {
+		void*& q;
+		size_t& bytes;
+		~PinnedGuard()
+		{
+			if (q)
+				StagingReleaseHost(q, bytes);   // the call has synchronised its stream by the time it returns
+		}
+	} pinnedGuard{pinnedFn, pinnedFnBytes};
+	uint32_t derivedModes = 0;
+	auto addDerived = [&](const std::vector<uint32_t>& fOrig) -> int {
+		const uint32_t m = sl.count;
+		const uint32_t N = t->host.states;
+		PIRE_TRY(scratch.Alloc(&sl.guess[m], S));
+		PIRE_TRY(scratch.Alloc(&sl.end[m], S));
+		if (!pinnedFn) {
+			PIRE_TRY(StagingAcquireHost(size_t(N) * 4 * kMaxModes, &pinnedFn, &pinnedFnBytes));
+			PIRE_TRY(scratch.Alloc(&dModeFn, size_t(N) * kMaxModes));
+		}
+		uint32_t* host = static_cast<uint32_t*>(pinnedFn) + size_t(derivedModes) * N;
+		uint32_t* dev = dModeFn + size_t(derivedModes) * N;
+		for (uint32_t perm = 0; perm < N; ++perm) {   // device ids in, device ids out
+			const uint32_t to = fOrig[t->host.origOfPerm[perm]];
+			host[perm] = to == kNoState ? kNoState : t->host.permOfOrig[to];
+		}
+		PIRE_TRY(HipOk(hipMemcpyAsync(dev, host, size_t(N) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(mode function)"));
+		hipLaunchKernelGGL(SegmentDeriveKernel, dim3(blocks), dim3(256), 0, stream, sl.guess[0], sl.end[0], dev, N, sl.guess[m], sl.end[m], S);
+		++derivedModes;
+		sl.count = m + 1;
+		return PIRE_HIP_OK;
+	};
+	std::vector<std::vector<uint32_t>> derivable;
+	std::vector<uint32_t> walked;   // known modes that need a walk of their own
+	for (uint32_t r : known) {
+		std::vector<uint32_t> f;
+		if (derive && derivable.size() + 1 < kMaxModes && ModeFunctionCached(t, a0, r, minSteps, &f))
+			derivable.push_back(std::move(f));
+		else
+			walked.push_back(r);
+	}
+	if (pairedFirst && !walked.empty()) {
+		PIRE_TRY(addModePair(t->host.permOfOrig[walked[0]]));
 		nextKnown = 1;
 		mark("modes 0+1 (fused)");
 	} else {
+		pairedFirst = false;
 		PIRE_TRY(addMode(true, 0));
 		mark("mode 0");
 	}
-	for (; nextKnown < known.size(); ++nextKnown)
+	for (const auto& f : derivable)
 		if (sl.count < maxModes)
-			PIRE_TRY(addMode(false, t->host.permOfOrig[known[nextKnown]]));
+			PIRE_TRY(addDerived(f));
+	for (; nextKnown < walked.size(); ++nextKnown)
+		if (sl.count < maxModes)
+			PIRE_TRY(addMode(false, t->host.permOfOrig[walked[nextKnown]]));
 
 	mark("known modes");
 	// ---- the chain
@@ -1001,7 +1155,11 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 			}
 		}
 		if (sl.count < maxModes && (bestCount >= 2 || budget == 0)) {
-			PIRE_TRY(addMode(false, best));
+			std::vector<uint32_t> f;
+			if (derive && derivedModes + 1 < kMaxModes && ModeFunctionCached(t, a0, t->host.origOfPerm[best], minSteps, &f))
+				PIRE_TRY(addDerived(f));
+			else
+				PIRE_TRY(addMode(false, best));
 			{
 				std::lock_guard<std::mutex> lock(t->segMutex);
 				const uint32_t orig = t->host.origOfPerm[best];
@@ -1078,7 +1236,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	// "+plain": some strings ended in the sequential walk; the symbol says whether two modes shared one pass, or one
 	// mode had its warm-up inside the tiled pass
 	NoteKernel(nPlain ? "segmented+plain" : "segmented",
-	           pairedFirst ? "pirehip::ScanPairTiledKernel" : fusedSegs ? "pirehip::ScanTiledSegKernel" : "");
+	           pairedFirst ? "pirehip::ScanPairTiledKernel" : fusedSegs ? (derivedModes ? "pirehip::ScanTiledSegKernel+derived" : "pirehip::ScanTiledSegKernel") : "");
 	if (wantStats) {
 		mark("finish");
 		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %u modes, %llu chain "
