@@ -626,7 +626,9 @@ bool ModeFunction(const HostTable& h, uint32_t a0, uint32_t b0, uint32_t minStep
 				letters.push_back(h.cls[c]);
 			}
 	}
-	const size_t cap = std::max<size_t>(size_t(h.states) * 8, 4096);   // pairs per level we are willing to follow
+	// pairs per level we are willing to follow (a function has at most `states` of them in the end; the bound keeps the
+	// search under ~0.2 s for the tables of this repository even when it fails late)
+	const size_t cap = size_t(h.states) * 2 + 1024;
 	std::vector<uint64_t> level{(uint64_t(a0) << 32) | b0}, next;
 	for (uint32_t step = 0; step < minSteps; ++step) {
 		next.clear();
