@@ -106,6 +106,7 @@ typedef struct pire_hip_config {
 	uint32_t no_offsets_peek;      /* 1: pire_hip_run with device offsets never reads offsets back (enqueue-only even for */
 	                               /* small batches; few long strings then walk one per lane)                            */
 	uint32_t segment_no_pair;      /* 1: the segmented scan never fuses two modes into one pass of the pair kernel       */
+	uint32_t segment_no_product;   /* 1: two modes that are not functions of each other take the pair kernel, not a product */
 	uint32_t segment_no_derive;    /* 1: the segmented scan walks every mode (none derived from mode 0's walk)           */
 	uint32_t no_length_order;      /* 1: counting / SlowScanner kernels take strings in the caller's order, not by length */
 	uint32_t capture_by_length;    /* 1: the one-string-per-lane capture kernels too take them by length (A/B: slower)   */

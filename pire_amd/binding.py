@@ -106,6 +106,7 @@ class Config(C.Structure):
         ("host_staging", C.c_uint32),
         ("no_offsets_peek", C.c_uint32),
         ("segment_no_pair", C.c_uint32),
+        ("segment_no_product", C.c_uint32),
         ("segment_no_derive", C.c_uint32),
         ("no_length_order", C.c_uint32),
         ("capture_by_length", C.c_uint32),

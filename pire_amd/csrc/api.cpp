@@ -258,6 +258,7 @@ pire_hip_config SeedFromEnvironment()
 	c.host_staging = uint32_t(EnvU64("PIRE_HIP_HOST_STAGING"));
 	c.no_offsets_peek = EnvU64("PIRE_HIP_NO_OFFSETS_PEEK") != 0;
 	c.segment_no_pair = EnvU64("PIRE_HIP_SEGMENT_NO_PAIR") != 0;
+	c.segment_no_product = EnvU64("PIRE_HIP_SEGMENT_NO_PRODUCT") != 0;
 	c.segment_no_derive = EnvU64("PIRE_HIP_SEGMENT_NO_DERIVE") != 0;
 	c.no_length_order = EnvU64("PIRE_HIP_NO_LENGTH_ORDER") != 0;
 	c.capture_by_length = EnvU64("PIRE_HIP_CAPTURE_BY_LENGTH") != 0;
@@ -980,6 +981,8 @@ void pire_hip_table_destroy(pire_hip_table* t)
 	if (!t)
 		return;
 	FreeAllDeviceTables(t);   // the retired images of automatic adaptations too
+	if (t->segProduct)
+		FreeAllDeviceTables(t->segProduct.get());   // the product automaton of the segmented scan's two modes
 	delete t;
 }
 

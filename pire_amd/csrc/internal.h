@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -209,6 +210,12 @@ struct pire_hip_table {
 		std::vector<uint32_t> f;
 	};
 	std::vector<SegModeFn> segModeFns;
+	// segmented.hip, EnsureModeProduct: the product automaton of this table started in (a0, b0) -- the walk of two
+	// modes as ONE walk -- with the two components of every product state (reference numbering, both)
+	std::unique_ptr<pire_hip_table> segProduct;
+	uint32_t segProductA0 = 0, segProductB0 = 0;
+	bool segProductTried = false;
+	std::vector<uint32_t> segProductA, segProductB;
 	// Adaptation (table.cpp AdaptTable) rewrites host.{hot, origOfPerm, permOfOrig, hotRows, ...} and swaps the images.
 	// Run entry points hold adaptMutex SHARED while they copy what they need (api.cpp FillParams); an adaptation holds
 	// it exclusively.  Images an AUTOMATIC adaptation replaces are not freed but retired: a call on another host thread

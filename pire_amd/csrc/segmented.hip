@@ -693,6 +693,117 @@ bool ModeFunctionCached(pire_hip_table* t, uint32_t a0, uint32_t b0, uint32_t mi
 	return ok;
 }
 
+// Two modes that are NOT functions of each other, as ONE walk all the same: the product automaton of the table with
+// itself, started in (a0, b0) -- Scanner::Glue's construction on two copies of the table that differ in their start
+// states -- has one state per pair the two walks can be in together.  One
+// lookup per byte in ITS dense rows instead of two in the table's (the pair kernel), and both modes' guess and end state
+// are the two components of the product's.  Built once per table and (a0, b0), a table object of its own (ranked,
+// uploaded and adapted like any other); none when the product outgrows 6 x the table.
+struct ModeProduct {
+	pire_hip_table* table = nullptr;
+	const std::vector<uint32_t>* compA = nullptr;   // [product states, reference numbering] -> the table's state
+	const std::vector<uint32_t>* compB = nullptr;
+};
+
+int EnsureModeProduct(pire_hip_table* t, uint32_t a0, uint32_t b0, ModeProduct* out)
+{
+	*out = ModeProduct();
+	std::lock_guard<std::mutex> lock(t->segMutex);
+	if (!t->segProductTried || t->segProductA0 != a0 || t->segProductB0 != b0) {
+		if (t->segProductTried && t->segProduct)
+			return PIRE_HIP_OK;   // one product per table: the first pair of modes it met (replacing it would free
+			                      // device memory another thread's launch may still read)
+		t->segProductTried = true;
+		t->segProductA0 = a0;
+		t->segProductB0 = b0;
+		if (t->host.scannerType != 1 || t->host.empty)
+			return PIRE_HIP_OK;
+		// Glue's construction, restricted to what a segment can contain: the pairs reachable over the letters of the 256
+		// byte values (the marks of Begin() / End() never occur inside a segment; their columns are self loops here).
+		// For set_a that is 162 pairs -- every one of them gets a dense row.
+		const HostTable& h = t->host;
+		const uint32_t LC = h.letters;
+		std::vector<uint8_t> isByteLetter(LC, 0);
+		for (uint32_t c = 0; c < 256; ++c)
+			if (h.cls[c] < LC)
+				isByteLetter[h.cls[c]] = 1;
+		const size_t cap = size_t(h.states) * 6 + 1024;
+		std::vector<std::pair<uint32_t, uint32_t>> pairs{{a0, b0}};
+		std::unordered_map<uint64_t, uint32_t> index{{(uint64_t(a0) << 32) | b0, 0u}};
+		std::vector<uint32_t> next;
+		for (size_t i = 0; i < pairs.size(); ++i) {
+			const auto pr = pairs[i];   // (a copy: the vector grows)
+			next.resize((i + 1) * size_t(LC));
+			for (uint32_t l = 0; l < LC; ++l) {
+				if (!isByteLetter[l]) {
+					next[i * LC + l] = uint32_t(i);
+					continue;
+				}
+				const uint32_t na = h.next[size_t(pr.first) * LC + l], nb = h.next[size_t(pr.second) * LC + l];
+				const uint64_t key = (uint64_t(na) << 32) | nb;
+				auto it = index.find(key);
+				if (it == index.end()) {
+					if (pairs.size() >= cap)
+						return PIRE_HIP_OK;   // too large: the pair kernel it is
+					it = index.emplace(key, uint32_t(pairs.size())).first;
+					pairs.emplace_back(na, nb);
+				}
+				next[i * LC + l] = it->second;
+			}
+		}
+		const uint32_t PN = uint32_t(pairs.size());
+		HostTable prod;
+		prod.scannerType = 1;
+		prod.headerSize = h.headerSize;
+		prod.rowStride = h.rowStride;
+		prod.states = PN;
+		prod.letters = LC;
+		prod.regexps = 0;   // nobody asks the product what it accepts: its states are only ever taken apart
+		prod.initial = 0;
+		prod.cls = h.cls;
+		prod.next.swap(next);
+		prod.flags.assign(PN, 0);
+		for (uint32_t i = 0; i < PN; ++i) {
+			bool absorbing = true;
+			for (uint32_t l = 0; l < LC; ++l)
+				absorbing = absorbing && prod.next[size_t(i) * LC + l] == i;
+			prod.flags[i] = absorbing ? uint8_t(kAbsorbing) : 0;
+		}
+		prod.acceptOff.assign(size_t(PN) + 1, 0);
+		prod.refBufSize = 0;
+		prod.blobBytes = 0;
+		prod.ranked = false;
+		t->segProductA.resize(PN);
+		t->segProductB.resize(PN);
+		for (uint32_t i = 0; i < PN; ++i) {
+			t->segProductA[i] = pairs[i].first;
+			t->segProductB[i] = pairs[i].second;
+		}
+		t->segProduct.reset(new pire_hip_table);
+		t->segProduct->host = std::move(prod);
+	}
+	if (t->segProduct && t->segProductA0 == a0 && t->segProductB0 == b0) {
+		out->table = t->segProduct.get();
+		out->compA = &t->segProductA;
+		out->compB = &t->segProductB;
+	}
+	return PIRE_HIP_OK;
+}
+
+// the product's states taken apart: slot A and slot B of every segment from the product walk's guess and end state
+__global__ void SegmentSplitKernel(const uint32_t* guessP, const uint32_t* endP, const uint32_t* compA, const uint32_t* compB,
+                                   uint32_t states, uint32_t* guessA, uint32_t* endA, uint32_t* guessB, uint32_t* endB, uint64_t n)
+{
+	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+	if (k >= n)
+		return;
+	const uint32_t g = guessP[k], e = endP[k];
+	guessA[k] = g < states ? compA[g] : kNoState;
+	guessB[k] = g < states ? compB[g] : kNoState;
+	endA[k] = e < states ? compA[e] : kNoState;
+	endB[k] = e < states ? compB[e] : kNoState;
+}
+
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
 {
 	const pire_hip_config cfg = GetConfig();
@@ -989,6 +1100,100 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		sl.count = m + 2;
 		return PIRE_HIP_OK;
 	};
+	// Modes 0 and B as one walk of their product automaton (EnsureModeProduct) over the grid's whole tasks; the rest as
+	// in addModePair.
+	void* productScratch = nullptr;   // the product walk's own arrays: freed on the stream behind the kernels that use them
+	struct ProductGuard {
+		void*& q;
+		hipStream_t s;
+		~ProductGuard()
+		{
+			if (q)
+				(void)hipFreeAsync(q, s);
+		}
+	} productGuard{productScratch, stream};
+	void* pinnedComp = nullptr;
+	size_t pinnedCompBytes = 0;
+	struct PinnedCompGuard {
+		void*& q;
+		size_t& bytes;
+		~PinnedCompGuard()
+		{
+			if (q)
+				StagingReleaseHost(q, bytes);   // the call has synchronised its stream by the time it returns
+		}
+	} pinnedCompGuard{pinnedComp, pinnedCompBytes};
+	bool productUsed = false;
+	auto addModeProduct = [&](const ModeProduct& mp, uint32_t representativeB) -> int {
+		const uint32_t m = sl.count;
+		for (uint32_t k = m; k < m + 2; ++k) {
+			PIRE_TRY(scratch.Alloc(&sl.guess[k], S));
+			PIRE_TRY(scratch.Alloc(&sl.end[k], S));
+		}
+		ScanParams pp;
+		PIRE_TRY(PrepareScanParams(mp.table, &pp, 0));   // the product on this device; startPerm = its initial state (a0, b0)
+		const HostTable& ph = mp.table->host;
+		const uint32_t PN = ph.states;
+		const size_t bytes = ((fusedSegs * 4 + 255) & ~size_t(255)) * 2 + ((size_t(PN) * 4 + 255) & ~size_t(255)) * 2;
+		PIRE_TRY(HipOk(hipMallocAsync(&productScratch, bytes, stream), "hipMallocAsync(product walk)"));
+		uint8_t* base = static_cast<uint8_t*>(productScratch);
+		uint32_t* guessP = reinterpret_cast<uint32_t*>(base);
+		uint32_t* endP = reinterpret_cast<uint32_t*>(base + ((fusedSegs * 4 + 255) & ~size_t(255)));
+		uint32_t* dCompA = reinterpret_cast<uint32_t*>(base + ((fusedSegs * 4 + 255) & ~size_t(255)) * 2);
+		uint32_t* dCompB = dCompA + ((size_t(PN) + 63) & ~size_t(63));
+		ScanParams r = pp;
+		r.text = q.text;
+		r.textEnd = q.textEnd;
+		r.offsets = nullptr;
+		r.ends = nullptr;
+		r.n = fusedSegs;
+		r.len = r.stride = segBytes;
+		r.initIdx = nullptr;
+		r.flags = kPermIds;
+		r.outIdx = endP;
+		r.outFinal = nullptr;
+		r.outCounts = nullptr;
+		PIRE_TRY(LaunchTiledSeg(r, warmBytes, a.segJ, guessP, stream));
+		// (behind the launch: the host fills these while the pass runs)
+		// the components by the PRODUCT's device ids, in the TABLE's device ids (both numberings move with adapt())
+		PIRE_TRY(StagingAcquireHost(size_t(PN) * 8, &pinnedComp, &pinnedCompBytes));
+		uint32_t* hA = static_cast<uint32_t*>(pinnedComp);
+		uint32_t* hB = hA + PN;
+		for (uint32_t perm = 0; perm < PN; ++perm) {
+			const uint32_t o = ph.origOfPerm[perm];
+			hA[perm] = t->host.permOfOrig[(*mp.compA)[o]];
+			hB[perm] = t->host.permOfOrig[(*mp.compB)[o]];
+		}
+		PIRE_TRY(HipOk(hipMemcpyAsync(dCompA, hA, size_t(PN) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(product components)"));
+		PIRE_TRY(HipOk(hipMemcpyAsync(dCompB, hB, size_t(PN) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(product components)"));
+		hipLaunchKernelGGL(SegmentSplitKernel, dim3(unsigned((fusedSegs + 255) / 256)), dim3(256), 0, stream, guessP, endP, dCompA, dCompB,
+		                   PN, sl.guess[m], sl.end[m], sl.guess[m + 1], sl.end[m + 1], fusedSegs);
+		if (fusedSegs < S) {
+			const uint64_t rest = S - fusedSegs;
+			if (!dConst)
+				PIRE_TRY(scratch.Alloc(&dConst, S));
+			hipLaunchKernelGGL(SegmentFillKernel, dim3(unsigned((rest + 255) / 256)), dim3(256), 0, stream, dConst, representativeB, rest);
+			for (uint32_t k = 0; k < 2; ++k) {
+				q.n = rest;
+				q.offsets = a.warmBegin + fusedSegs;
+				q.ends = a.segBegin + fusedSegs;
+				q.initIdx = k == 0 ? nullptr : dConst;
+				q.flags = (k == 0 ? (p.flags & PIRE_HIP_RUN_BEGIN) : 0u) | kPermIds;
+				q.outIdx = sl.guess[m + k] + fusedSegs;
+				PIRE_TRY(ScanBatch(q, t, stream));
+				q.flags = kPermIds;
+				q.offsets = a.segBegin + fusedSegs;
+				q.ends = a.segEnd + fusedSegs;
+				q.initIdx = sl.guess[m + k] + fusedSegs;
+				q.outIdx = sl.end[m + k] + fusedSegs;
+				PIRE_TRY(ScanBatch(q, t, stream));
+			}
+			q.flags = kPermIds;
+		}
+		productUsed = true;
+		sl.count = m + 2;
+		return PIRE_HIP_OK;
+	};
 	mark("setup");
 	// the modes earlier calls on this table learned: the automaton is the same, the text probably similar
 	std::vector<uint32_t> known;
@@ -1059,7 +1264,15 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		else
 			walked.push_back(r);
 	}
-	if (pairedFirst && !walked.empty()) {
+	ModeProduct product;
+	if (pairedFirst && !walked.empty() && fusedSegs && !p.initIdx && !cfg.segment_no_product)
+		PIRE_TRY(EnsureModeProduct(t, a0, walked[0], &product));
+	if (product.table) {
+		PIRE_TRY(addModeProduct(product, t->host.permOfOrig[walked[0]]));
+		nextKnown = 1;
+		pairedFirst = false;
+		mark("modes 0+1 (product)");
+	} else if (pairedFirst && !walked.empty()) {
 		PIRE_TRY(addModePair(t->host.permOfOrig[walked[0]]));
 		nextKnown = 1;
 		mark("modes 0+1 (fused)");
@@ -1238,7 +1451,10 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	// "+plain": some strings ended in the sequential walk; the symbol says whether two modes shared one pass, or one
 	// mode had its warm-up inside the tiled pass
 	NoteKernel(nPlain ? "segmented+plain" : "segmented",
-	           pairedFirst ? "pirehip::ScanPairTiledKernel" : fusedSegs ? (derivedModes ? "pirehip::ScanTiledSegKernel+derived" : "pirehip::ScanTiledSegKernel") : "");
+	           pairedFirst ? "pirehip::ScanPairTiledKernel"
+	           : productUsed ? "pirehip::ScanTiledSegKernel+product"
+	           : fusedSegs   ? (derivedModes ? "pirehip::ScanTiledSegKernel+derived" : "pirehip::ScanTiledSegKernel")
+	                         : "");
 	if (wantStats) {
 		mark("finish");
 		fprintf(stderr, "pire_hip segmented: %llu strings, %llu segments of %llu B (+%llu B warm-up), %u modes, %llu chain "

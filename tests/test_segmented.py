@@ -318,9 +318,10 @@ def test_two_modes_share_one_pass_of_the_pair_kernel(name, n, length, seg, cfg):
     idx = torch.empty(n, dtype=torch.int32, device="cuda")
     fin = torch.empty(n, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    fused = one_mode = derived = 0
+    fused = one_mode = derived = product = 0
     for rep in range(6):
-        cfg.set(segment_no_derive=1 if rep >= 4 else 0)   # the last two: every mode walked (the pair kernel for 0 + 1)
+        # the last two: every mode walked, and by the pair kernel (no derived modes, no product automaton)
+        cfg.set(segment_no_derive=1 if rep >= 4 else 0, segment_no_product=1 if rep >= 4 else 0)
         cfg.set(segment_no_pair=1 if rep == 3 else 0)
         idx.fill_(-1)
         t.run_strided_device(d.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
@@ -329,16 +330,17 @@ def test_two_modes_share_one_pass_of_the_pair_kernel(name, n, length, seg, cfg):
         fused += pb.last_kernel_symbol() == "pirehip::ScanPairTiledKernel"
         one_mode += pb.last_kernel_symbol() == "pirehip::ScanTiledSegKernel"
         derived += pb.last_kernel_symbol() == "pirehip::ScanTiledSegKernel+derived"
+        product += pb.last_kernel_symbol() == "pirehip::ScanTiledSegKernel+product"
         assert rep != 3 or pb.last_kernel_symbol() not in ("pirehip::ScanPairTiledKernel", "pirehip::ScanTiledSegKernel")
         assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (fin.cpu().numpy() == of).all()
     if name != "parity":
-        # the first call learned the second mode from the planted matches; the others (but the fourth) either walked both
-        # in one pass of the pair kernel or -- where the learned mode is a function of mode 0 (ModeFunction; with `$`-anchored
-        # patterns it mostly is not) -- walked one and derived the other; the last two walked both
-        # (the learning call itself may already derive a mode it has just learned)
-        assert derived + fused >= 4 and fused >= 2, (derived, fused, one_mode)
+        # the first call learned the second mode from the planted matches; calls two and three walked the two modes as one
+        # walk of their product automaton -- or, where the learned mode is a function of mode 0 (ModeFunction; with
+        # `$`-anchored patterns it mostly is not), walked one and derived the other; the last two walked both in one pass of
+        # the pair kernel (the learning call itself may already derive a mode it has just learned)
+        assert derived + product >= 2 and fused == 2, (derived, product, fused, one_mode)
     else:                      # surrounded patterns over {a, b} forget at once: ONE mode, its warm-up inside the tiled pass
-        assert fused == 0 and derived == 0 and one_mode == 5
+        assert fused == 0 and derived == 0 and product == 0 and one_mode == 5
 
 
 def test_a_mode_that_is_a_function_of_mode_zero_is_not_walked(cfg):

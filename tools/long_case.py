@@ -64,10 +64,11 @@ for n in [int(x) for x in os.environ.get('LONG_NS', '1,8,64,1024,16384').split('
     rows += t.adapt()
     ms = timeit(run)
     kernel = pb.last_kernel() + {"pirehip::ScanPairTiledKernel": "(2 modes fused)", "pirehip::ScanTiledSegKernel": "(1 mode)",
-                                 "pirehip::ScanTiledSegKernel+derived": "(modes derived)"}.get(pb.last_kernel_symbol(), "")
-    pb.set_config(segment_no_derive=1)
+                                 "pirehip::ScanTiledSegKernel+derived": "(modes derived)",
+                                 "pirehip::ScanTiledSegKernel+product": "(2 modes, product walk)"}.get(pb.last_kernel_symbol(), "")
+    pb.set_config(segment_no_derive=1, segment_no_product=1)
     ms_noderive = timeit(run)
-    pb.set_config(segment_no_derive=0)
+    pb.set_config(segment_no_derive=0, segment_no_product=0)
     pb.set_config(segment_no_pair=1, segment_no_derive=1)
     ms_nopair = timeit(run)
     pb.set_config(segment_no_pair=0, segment_no_derive=0)
@@ -80,7 +81,7 @@ for n in [int(x) for x in os.environ.get('LONG_NS', '1,8,64,1024,16384').split('
     host = buf[:k * length].cpu().numpy()
     oi, of = o.run(host, np.arange(k + 1, dtype=np.uint64) * length, threads=min(k, 4))
     ok = bool((idx[:k].cpu().numpy().astype(np.uint32) == oi).all() and (fin[:k].cpu().numpy() == of).all())
-    line = "%6d x %10d B: %-9s %8.3f ms -> %7.1f GB/s (%.3f ms with segment_no_derive, %.3f with segment_no_pair too, %.3f before adapt(), %d rows changed); parity(first %d) %s" % (
+    line = "%6d x %10d B: %-9s %8.3f ms -> %7.1f GB/s (%.3f ms with segment_no_derive / _no_product, %.3f with segment_no_pair too, %.3f before adapt(), %d rows changed); parity(first %d) %s" % (
         n, length, kernel, ms, total / ms / 1e6, ms_noderive, ms_nopair, ms0, rows, k, ok)
     if length <= (1 << 20):
         pb.set_config(no_segments=1)
