@@ -600,15 +600,22 @@ int HipOk(hipError_t e, const char* what)
 // BFS over at most `states` pairs (it stops at the first state that turns up with two partners) on the host, once per
 // (a0, b0), remembered in the table in reference numbering; the letters are those the 256 byte values map to (the
 // marks of Begin() / End() never occur inside a segment).  Exact by construction: the BFS covers every text.
+// (f in reference numbering; the device ids go through the arrays of the very image the walk used -- the host's copies
+// may have been renumbered by an adaptation on another thread since this call took its parameters)
 __global__ void SegmentDeriveKernel(const uint32_t* guess0, const uint32_t* end0, const uint32_t* f, uint32_t states,
-                                    uint32_t* guess, uint32_t* end, uint64_t n)
+                                    const uint32_t* origOfPerm, const uint32_t* permOfOrig, uint32_t* guess, uint32_t* end, uint64_t n)
 {
 	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (k >= n)
 		return;
-	const uint32_t g = guess0[k], e = end0[k];
-	guess[k] = g < states ? f[g] : kNoState;
-	end[k] = e < states ? f[e] : kNoState;
+	auto through = [&](uint32_t perm) {
+		if (perm >= states)
+			return kNoState;
+		const uint32_t to = f[origOfPerm[perm]];
+		return to < states ? permOfOrig[to] : kNoState;
+	};
+	guess[k] = through(guess0[k]);
+	end[k] = through(end0[k]);
 }
 
 // f in reference numbering (kNoState where mode 0's walk never gets); false: no such function.  Only pairs reached by
@@ -791,17 +798,21 @@ int EnsureModeProduct(pire_hip_table* t, uint32_t a0, uint32_t b0, ModeProduct* 
 }
 
 // the product's states taken apart: slot A and slot B of every segment from the product walk's guess and end state
+// (components in reference numbering, by the product's reference numbering; device ids go through the arrays of the two
+// images the launches used -- either table may have been renumbered on the host by an adaptation since)
 __global__ void SegmentSplitKernel(const uint32_t* guessP, const uint32_t* endP, const uint32_t* compA, const uint32_t* compB,
-                                   uint32_t states, uint32_t* guessA, uint32_t* endA, uint32_t* guessB, uint32_t* endB, uint64_t n)
+                                   uint32_t productStates, const uint32_t* productOrigOfPerm, const uint32_t* permOfOrig,
+                                   uint32_t* guessA, uint32_t* endA, uint32_t* guessB, uint32_t* endB, uint64_t n)
 {
 	const uint64_t k = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
 	if (k >= n)
 		return;
 	const uint32_t g = guessP[k], e = endP[k];
-	guessA[k] = g < states ? compA[g] : kNoState;
-	guessB[k] = g < states ? compB[g] : kNoState;
-	endA[k] = e < states ? compA[e] : kNoState;
-	endB[k] = e < states ? compB[e] : kNoState;
+	const uint32_t go = g < productStates ? productOrigOfPerm[g] : kNoState, eo = e < productStates ? productOrigOfPerm[e] : kNoState;
+	guessA[k] = go != kNoState ? permOfOrig[compA[go]] : kNoState;
+	guessB[k] = go != kNoState ? permOfOrig[compB[go]] : kNoState;
+	endA[k] = eo != kNoState ? permOfOrig[compA[eo]] : kNoState;
+	endB[k] = eo != kNoState ? permOfOrig[compB[eo]] : kNoState;
 }
 
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes)
@@ -1155,19 +1166,16 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		r.outCounts = nullptr;
 		PIRE_TRY(LaunchTiledSeg(r, warmBytes, a.segJ, guessP, stream));
 		// (behind the launch: the host fills these while the pass runs)
-		// the components by the PRODUCT's device ids, in the TABLE's device ids (both numberings move with adapt())
+		// the components of the product's states (the split kernel takes them through both images' own numberings)
 		PIRE_TRY(StagingAcquireHost(size_t(PN) * 8, &pinnedComp, &pinnedCompBytes));
 		uint32_t* hA = static_cast<uint32_t*>(pinnedComp);
 		uint32_t* hB = hA + PN;
-		for (uint32_t perm = 0; perm < PN; ++perm) {
-			const uint32_t o = ph.origOfPerm[perm];
-			hA[perm] = t->host.permOfOrig[(*mp.compA)[o]];
-			hB[perm] = t->host.permOfOrig[(*mp.compB)[o]];
-		}
+		memcpy(hA, mp.compA->data(), size_t(PN) * 4);   // reference numbering both: the kernel translates on the device
+		memcpy(hB, mp.compB->data(), size_t(PN) * 4);
 		PIRE_TRY(HipOk(hipMemcpyAsync(dCompA, hA, size_t(PN) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(product components)"));
 		PIRE_TRY(HipOk(hipMemcpyAsync(dCompB, hB, size_t(PN) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(product components)"));
 		hipLaunchKernelGGL(SegmentSplitKernel, dim3(unsigned((fusedSegs + 255) / 256)), dim3(256), 0, stream, guessP, endP, dCompA, dCompB,
-		                   PN, sl.guess[m], sl.end[m], sl.guess[m + 1], sl.end[m + 1], fusedSegs);
+		                   PN, pp.origOfPerm, p.permOfOrig, sl.guess[m], sl.end[m], sl.guess[m + 1], sl.end[m + 1], fusedSegs);
 		if (fusedSegs < S) {
 			const uint64_t rest = S - fusedSegs;
 			if (!dConst)
@@ -1220,7 +1228,11 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	// ... and with segments no shorter than the warm-up: every segment but a string's first then has ALL of it behind it
 	const bool derive = !p.initIdx && !cfg.segment_no_derive && segBytes >= warmBytes && warmBytes < (1u << 20);
 	const uint32_t minSteps = uint32_t(warmBytes);
-	const uint32_t a0 = t->host.origOfPerm[q.startPerm];
+	// (the start state in reference numbering, from the table itself: Initialize(), then Begin() if asked -- not through
+	// the host's copy of the device numbering, which another thread's adaptation may have moved on)
+	uint32_t a0 = t->host.initial;
+	if (p.flags & PIRE_HIP_RUN_BEGIN)
+		a0 = t->host.next[size_t(a0) * t->host.letters + t->host.cls[kBeginMark]];
 	uint32_t* dModeFn = nullptr;
 	void* pinnedFn = nullptr;
 	size_t pinnedFnBytes = 0;
@@ -1245,12 +1257,10 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		}
 		uint32_t* host = static_cast<uint32_t*>(pinnedFn) + size_t(derivedModes) * N;
 		uint32_t* dev = dModeFn + size_t(derivedModes) * N;
-		for (uint32_t perm = 0; perm < N; ++perm) {   // device ids in, device ids out
-			const uint32_t to = fOrig[t->host.origOfPerm[perm]];
-			host[perm] = to == kNoState ? kNoState : t->host.permOfOrig[to];
-		}
+		memcpy(host, fOrig.data(), size_t(N) * 4);   // reference numbering: the kernel translates with the image's own arrays
 		PIRE_TRY(HipOk(hipMemcpyAsync(dev, host, size_t(N) * 4, hipMemcpyHostToDevice, stream), "hipMemcpy(mode function)"));
-		hipLaunchKernelGGL(SegmentDeriveKernel, dim3(blocks), dim3(256), 0, stream, sl.guess[0], sl.end[0], dev, N, sl.guess[m], sl.end[m], S);
+		hipLaunchKernelGGL(SegmentDeriveKernel, dim3(blocks), dim3(256), 0, stream, sl.guess[0], sl.end[0], dev, N, p.origOfPerm,
+		                   p.permOfOrig, sl.guess[m], sl.end[m], S);
 		++derivedModes;
 		sl.count = m + 1;
 		return PIRE_HIP_OK;
