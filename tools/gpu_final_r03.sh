@@ -48,7 +48,7 @@ timeout 200 python tools/half_final_case.py half_5 2>&1 | grep "half_final\|refe
 timeout 200 python tools/counting_case.py count_glued3_advanced 2>&1 | grep "counting\|reference" | tee $OUT/counting.log
 { echo "== strings in the caller's order (pire_hip_config.no_length_order), the same batch:"; NO_LENGTH_ORDER=1 timeout 200 python tools/counting_case.py count_glued3_advanced 2>&1 | grep "^counting"; echo "== the 32-bit kernel alone, by length / in the caller's order:"; timeout 200 python tools/counting_case.py count_glued3_advanced generic 2>&1 | grep "^counting"; NO_LENGTH_ORDER=1 timeout 200 python tools/counting_case.py count_glued3_advanced generic 2>&1 | grep "^counting"; echo "== SlowScanner list kernel on a ragged batch:"; timeout 100 python tools/slow_ragged_case.py 2>&1 | grep "^slow"; } | tee -a $OUT/counting.log | cut -c1-200
 timeout 200 python tools/actions_case.py 2>&1 | grep -v amdgpu.ids > $OUT/actions.log; tail -4 $OUT/actions.log | cut -c1-200
-LONG_TOTAL_LOG2=30 timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm" | tee $OUT/long_strings.log | cut -c1-200
+{ LONG_TOTAL_LOG2=30 timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm"; timeout 120 python tools/long_grep_case.py 2>&1 | grep "^grep"; } | tee $OUT/long_strings.log | cut -c1-200
 timeout 200 python tools/long_half_final.py 2>&1 | grep -v amdgpu.ids | tee $OUT/long_half_final.log | cut -c1-200
 timeout 200 python tools/capture_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/capture.log | cut -c1-200
 timeout 200 python tools/pair_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pair.log | cut -c1-200
