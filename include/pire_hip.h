@@ -49,7 +49,21 @@ enum {
 	PIRE_HIP_RUN_ON_DEVICE = 1u << 2,   /* text/offsets/init/out pointers are DEVICE pointers; the call only */
 	                                    /* enqueues work on `stream`. Without it they are HOST pointers and  */
 	                                    /* the call copies in, runs, copies out and synchronises.            */
+	                                    /* What can still make an ON_DEVICE call wait, and how to switch it   */
+	                                    /* off (pire_hip_config): (1) pire_hip_run with DEVICE offsets and    */
+	                                    /* n < 65 536 reads the first and last offset back (synchronises      */
+	                                    /* `stream`) to spot few long strings -- no_offsets_peek = 1; (2) a   */
+	                                    /* call that ends up in the segmented scan (few long strings of known */
+	                                    /* length: strided records, HOST_OFFSETS, or the peek) synchronises   */
+	                                    /* `stream` while it follows the chain -- no_segments = 1; (3) the    */
+	                                    /* first call on a device uploads the table (hipMalloc + copies):     */
+	                                    /* pire_hip_table_upload() beforehand.  With those three an ON_DEVICE */
+	                                    /* call enqueues kernels and nothing else (it is then legal inside a  */
+	                                    /* stream capture).  Automatic adaptation (auto_adapt) never runs     */
+	                                    /* inside an ON_DEVICE call unless auto_adapt = 2.                    */
 	PIRE_HIP_RUN_GENERIC   = 1u << 3,   /* force the generic (offset-driven) kernel; testing/diagnostics     */
+	PIRE_HIP_RUN_NO_PEEK   = 1u << 5,   /* with ON_DEVICE, pire_hip_run: this call never reads device offsets  */
+	                                    /* back (what pire_hip_config.no_offsets_peek is for every call)       */
 	PIRE_HIP_RUN_HOST_OFFSETS = 1u << 4 /* with ON_DEVICE, pire_hip_run only: `offsets` is a HOST pointer (the  */
 	                                    /* text stays resident on the device, the caller knows where its        */
 	                                    /* documents start).  The call copies the offsets and synchronises      */
@@ -94,11 +108,17 @@ typedef struct pire_hip_config {
 	uint32_t slow_sets_in_memory;  /* 1: the wave-per-string form keeps its state sets in device memory                 */
 	uint32_t slow_no_list;         /* 1: never the 16-slot list kernel: bitset kernel (<= 256 states) / wave per string   */
 	/* adaptation of the dense-row ranking */
-	uint32_t auto_adapt;           /* 0 default (on), 1 off, 2 on: re-rank by itself when scans keep leaving the dense   */
-	                               /* rows, see pire_hip_table_adapt()                                                  */
-	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 64)           */
+	uint32_t auto_adapt;           /* re-rank the dense rows by itself when scans keep leaving them (see                 */
+	                               /* pire_hip_table_adapt()): 0 default = at the start of calls that synchronise anyway */
+	                               /* (host-pointer forms, HOST_OFFSETS) -- an adaptation drains the device              */
+	                               /* (hipDeviceSynchronize), so it never runs inside a call that only enqueues;         */
+	                               /* 1 never; 2 at every launch boundary, ON_DEVICE calls included (such a call may     */
+	                               /* then block and is not capturable)                                                  */
+	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 256)          */
 	/* offset batches (pire_hip_run) */
-	uint32_t ragged_variant;       /* reserved (offset batches: one kernel today)                                       */
+	uint32_t ragged_variant;       /* 0 default: batches of >= 16 384 strings take the stream kernel (every lane walks a  */
+	                               /* run of consecutive strings), smaller ones the ragged kernel (one string per lane at */
+	                               /* a time); 1 always the ragged kernel; 2 the stream kernel from 256 strings (tests)  */
 	uint32_t host_staging;         /* device staging of the host-pointer forms of the prefix / suffix / half-final /   */
 	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
 	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */
@@ -110,6 +130,8 @@ typedef struct pire_hip_config {
 	uint32_t segment_no_derive;    /* 1: the segmented scan walks every mode (none derived from mode 0's walk)           */
 	uint32_t no_length_order;      /* 1: counting / SlowScanner kernels take strings in the caller's order, not by length */
 	uint32_t capture_by_length;    /* 1: the one-string-per-lane capture kernels too take them by length (A/B: slower)   */
+	uint32_t force_rccl;           /* 1: pire_hip_multi_create builds an RCCL communicator for ONE device as well (a       */
+	                               /* one-rank all-reduce: exercises the RCCL path on a one-GPU box; default: host sum)   */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)

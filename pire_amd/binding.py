@@ -18,6 +18,7 @@ FLAG_END = 2
 FLAG_ON_DEVICE = 4
 FLAG_GENERIC = 8
 FLAG_HOST_OFFSETS = 16
+FLAG_NO_PEEK = 32
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
@@ -110,6 +111,7 @@ class Config(C.Structure):
         ("segment_no_derive", C.c_uint32),
         ("no_length_order", C.c_uint32),
         ("capture_by_length", C.c_uint32),
+        ("force_rccl", C.c_uint32),
     ]
 
 

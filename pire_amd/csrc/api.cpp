@@ -164,10 +164,10 @@ int HipFail(hipError_t e, const char* what)
 namespace {
 
 
-int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
+// The caller holds the table's TableUse (internal.h): no adaptation between here and the caller's return.
+// wantDist: also the image's per-state distance tables (EnsureActDist).
+int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist = false)
 {
-	MaybeAutoAdapt(t);   // a launch boundary: re-rank the dense rows first if the scans so far kept leaving them
-	std::shared_lock<std::shared_mutex> stable(t->adaptMutex);   // no adaptation while the layout is copied
 	DeviceTable d;   // a copy of the current device's image (pointers), taken under the table's lock
 	if (int rc = UploadTable(t, &d))
 		return rc;
@@ -208,6 +208,11 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags)
 	if (flags & PIRE_HIP_RUN_BEGIN)
 		start = h.next[size_t(start) * h.letters + h.cls[kBeginMark]];  // Begin(), run.h:375
 	p->startPerm = h.permOfOrig[start];
+	p->hostPermOfOrig = h.permOfOrig.data();
+	p->hostOrigOfPerm = h.origOfPerm.data();
+	if (wantDist)
+		if (int rc = EnsureActDist(t, &p->distFinalPerm, &p->distFlaggedPerm))
+			return rc;
 	return PIRE_HIP_OK;
 }
 
@@ -262,6 +267,7 @@ pire_hip_config SeedFromEnvironment()
 	c.segment_no_derive = EnvU64("PIRE_HIP_SEGMENT_NO_DERIVE") != 0;
 	c.no_length_order = EnvU64("PIRE_HIP_NO_LENGTH_ORDER") != 0;
 	c.capture_by_length = EnvU64("PIRE_HIP_CAPTURE_BY_LENGTH") != 0;
+	c.force_rccl = EnvU64("PIRE_HIP_FORCE_RCCL") != 0;
 	return c;
 }
 
@@ -292,7 +298,11 @@ unsigned long long* NextWorkSlot(pire_hip_table* t, const ScanParams& p)
 }
 
 }  // namespace
-int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags) { return FillParams(t, p, flags); }
+int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags, TableUse* use, bool wantDist, bool enqueueOnly)
+{
+	use->Acquire(t, enqueueOnly);
+	return FillParams(t, p, flags, wantDist);
+}
 unsigned long long* TakeWorkSlot(pire_hip_table* t, const ScanParams& p) { return NextWorkSlot(t, p); }
 namespace {
 
@@ -309,8 +319,9 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 			return HipFail(hipGetLastError(), "hipEventCreate");
 		(void)hipEventRecord(ev0, stream);
 	}
+	const bool streamed = ragged && StreamEligible(p, totalBytesHint);
 	NoteKernel(tiled ? "tiled" : ragged ? "ragged" : "generic");
-	int rc = tiled ? LaunchTiled(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
+	int rc = tiled ? LaunchTiled(p, stream) : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
 		if (rc == PIRE_HIP_OK) {
@@ -607,8 +618,11 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	// only the public bits: the upper ones are the kernels' internal switches (device_common.h)
-	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC | PIRE_HIP_RUN_HOST_OFFSETS;
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC | PIRE_HIP_RUN_HOST_OFFSETS |
+	         PIRE_HIP_RUN_NO_PEEK;
 	ScanParams p;
+	// (an automatic adaptation drains the device: only in calls that synchronise anyway, pire_hip_config.auto_adapt)
+	TableUse use(t, (flags & PIRE_HIP_RUN_ON_DEVICE) && !(flags & PIRE_HIP_RUN_HOST_OFFSETS));
 	if (int rc = FillParams(t, &p, flags))
 		return rc;
 	p.n = n;
@@ -664,7 +678,7 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 		// lanes idle (n < 65 536) is therefore PEEKED at: two words (first and last offset) come back -- which
 		// synchronises `stream` -- and only if the cost model then asks for the segmented scan are all n + 1 offsets
 		// fetched (<= 512 KB).  pire_hip_config.no_offsets_peek keeps such calls enqueue-only.
-		if (offsets && n && n < 65536 && !(flags & PIRE_HIP_RUN_GENERIC) && !GetConfig().no_offsets_peek) {
+		if (offsets && n && n < 65536 && !(flags & (PIRE_HIP_RUN_GENERIC | PIRE_HIP_RUN_NO_PEEK)) && !GetConfig().no_offsets_peek) {
 			uint64_t ends[2] = {0, 0};
 			hipError_t e = hipMemcpyAsync(&ends[0], offsets, 8, hipMemcpyDeviceToHost, stream);
 			if (e == hipSuccess)
@@ -980,7 +994,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)
 		return;
-	FreeAllDeviceTables(t);   // the retired images of automatic adaptations too
+	FreeAllDeviceTables(t);
 	if (t->segProduct)
 		FreeAllDeviceTables(t->segProduct.get());   // the product automaton of the segmented scan's two modes
 	delete t;
@@ -1153,17 +1167,16 @@ try {
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	ScanParams p;
-	if (int rc = FillParams(t, &p, 0))   // startPerm = Initialize(); Begin() is a counted step in the kernel
+	const bool enqueueOnly = (flags & PIRE_HIP_RUN_ON_DEVICE) && !(flags & PIRE_HIP_RUN_HOST_OFFSETS);
+	TableUse use(t, enqueueOnly);
+	if (int rc = FillParams(t, &p, 0, /*wantDist=*/true))   // startPerm = Initialize(); Begin() is a counted step in the kernel
 		return rc;
 	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
 	p.n = n;
 	if (n == 0)
 		return PIRE_HIP_OK;
 	const uint32_t R = t->host.regexps;
-	const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
-	if (int rc = EnsureActDist(t, &distFinal, &distFlagged))
-		return rc;
-	p.actDist = distFinal;
+	p.actDist = p.distFinalPerm;
 	{   // Initialize() and Begin() of a HalfFinalScanner end with TakeAction: walked once here (ScanParams::hfStart)
 		const HostTable& h = t->host;
 		uint32_t o = h.initial;
@@ -1177,7 +1190,7 @@ try {
 			o = h.next[size_t(o) * h.letters + h.cls[kBeginMark]];
 			take(o);
 		}
-		p.hfStart = h.permOfOrig[o];
+		p.hfStart = p.hostPermOfOrig[o];   // the numbering of the image in p (FillParams), not whatever t->host holds by now
 	}
 	// PIRE_HIP_RUN_GENERIC keeps the one-string-per-lane kernel (tests compare the two)
 	const bool exactOnly = (flags & PIRE_HIP_RUN_GENERIC) != 0;
@@ -1188,7 +1201,7 @@ try {
 		if (exactOnly || !p.incPerm || !SegmentedEligible(n, hostOffsets[n] - hostOffsets[0]))
 			return PIRE_HIP_OK;
 		ScanParams ps;
-		if (int rc = FillParams(t, &ps, flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END)))   // Begin() folded into the start
+		if (int rc = FillParams(t, &ps, flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END)))   // Begin() folded into the start; the same image as p (`use`)
 			return rc;
 		ps.n = n;
 		ps.text = p.text;
@@ -1285,15 +1298,13 @@ try {
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	ScanParams p;
-	if (int rc = FillParams(t, &p, through_begin ? PIRE_HIP_RUN_BEGIN : 0))   // startPerm = Initialize [+ BeginMark]
+	TableUse use(t, (flags & PIRE_HIP_RUN_ON_DEVICE) != 0);
+	if (int rc = FillParams(t, &p, through_begin ? PIRE_HIP_RUN_BEGIN : 0, /*wantDist=*/true))   // startPerm = Initialize [+ BeginMark]
 		return rc;
 	p.n = n;
 	if (n == 0)
 		return PIRE_HIP_OK;
-	const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
-	if (int rc = EnsureActDist(t, &distFinal, &distFlagged))
-		return rc;
-	p.actDist = distFlagged;
+	p.actDist = p.distFlaggedPerm;
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
@@ -1346,6 +1357,10 @@ static int RunPairImpl(pire_hip_table* t1, pire_hip_table* t2, const void* text,
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_GENERIC;
 	ScanParams a, b;
+	TableUse use1, use2;   // in address order: two calls with the tables swapped must not wait for each other
+	use1.Acquire(t1 < t2 ? t1 : t2, true);
+	if (t1 != t2)
+		use2.Acquire(t1 < t2 ? t2 : t1, true);
 	if (int rc = FillParams(t1, &a, flags))
 		return rc;
 	if (int rc = FillParams(t2, &b, flags))
@@ -1430,11 +1445,12 @@ try {
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
 	ScanParams p;
+	TableUse use(t, (flags & PIRE_HIP_RUN_ON_DEVICE) != 0);
 	if (int rc = FillParams(t, &p, 0))
 		return rc;
 	if (through_end) {   // Initialize, then Step(EndMark): run.h:319-320 / 349-350
 		const HostTable& h = t->host;
-		p.startPerm = h.permOfOrig[h.next[size_t(h.initial) * h.letters + h.cls[kEndMark]]];
+		p.startPerm = p.hostPermOfOrig[h.next[size_t(h.initial) * h.letters + h.cls[kEndMark]]];
 	}
 	p.n = n;
 	if (n == 0)
@@ -1480,6 +1496,7 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	ScanParams p;
+	TableUse use(t, /*enqueueOnly=*/true);   // device arrays: the call only enqueues
 	if (int rc = FillParams(t, &p, 0))
 		return rc;
 	return LaunchStep(p, state_idx, n, t->host.cls[ch], static_cast<hipStream_t>(stream));

@@ -1308,6 +1308,7 @@ try {
 	};
 	// Batches of >= 256 strings ride the ragged kernel with actions (the expanded table of BuildCaptureTable):
 	// 2-3 x the one-string-per-lane kernel below, which keeps the small batches and PIRE_HIP_RUN_GENERIC.
+	TableUse ctUse;   // the expanded capture table's numbering stays put until this call returns
 	auto ragged = [&](const uint8_t* dText, const uint64_t* dOffs, uint32_t* dIdx, uint8_t* dFin, long long* dB,
 	                  long long* dE, bool* done) -> int {
 		*done = false;
@@ -1320,7 +1321,7 @@ try {
 		if (!ct)
 			return PIRE_HIP_OK;
 		ScanParams sp;
-		if (int rc = PrepareScanParams(ct, &sp, flags & PIRE_HIP_RUN_BEGIN))   // startPerm = Initialize [+ BeginMark]
+		if (int rc = PrepareScanParams(ct, &sp, flags & PIRE_HIP_RUN_BEGIN, &ctUse, /*wantDist=*/true, (flags & PIRE_HIP_RUN_ON_DEVICE) != 0))   // startPerm = Initialize [+ BeginMark]
 			return rc;
 		// Scanners whose walk is in an action state most of the time gain nothing from looking for the chunks that have
 		// one: =(\d+)[^\d] re-arms BeginCapture on every byte in front of the match (99.5 % of the steps on the benchmark
@@ -1334,10 +1335,7 @@ try {
 		sp.offsets = dOffs;
 		sp.outIdx = dIdx;
 		sp.outFinal = dFin;
-		const uint8_t *distFinal = nullptr, *distFlagged = nullptr;
-		if (int rc = EnsureActDist(ct, &distFinal, &distFlagged))
-			return rc;
-		sp.actDist = distFinal;
+		sp.actDist = sp.distFinalPerm;   // of the image in sp, taken under the table's lock
 		*done = true;
 		return LaunchRaggedCapture(sp, TakeWorkSlot(ct, sp), infoDev, dB, dE, stream);
 	};

@@ -216,14 +216,12 @@ struct pire_hip_table {
 	uint32_t segProductA0 = 0, segProductB0 = 0;
 	bool segProductTried = false;
 	std::vector<uint32_t> segProductA, segProductB;
-	// Adaptation (table.cpp AdaptTable) rewrites host.{hot, origOfPerm, permOfOrig, hotRows, ...} and swaps the images.
-	// Run entry points hold adaptMutex SHARED while they copy what they need (api.cpp FillParams); an adaptation holds
-	// it exclusively.  Images an AUTOMATIC adaptation replaces are not freed but retired: a call on another host thread
-	// may already have copied their pointers and not have launched yet.  They go with the table (a table adapts itself
-	// at most kMaxAutoAdapts times, ~1 MB per image).
+	// Adaptation (table.cpp AdaptTable) rewrites host.{hot, origOfPerm, permOfOrig, hotRows, ...} and replaces the images.
+	// Run entry points hold adaptMutex SHARED from their first look at the table until they return (internal.h TableUse);
+	// an adaptation -- the caller's or the automatic one -- holds it exclusively, drains the devices and frees the old
+	// images: no call can be between "copied the pointers" and "enqueued its kernels" at that moment.
 	std::shared_mutex adaptMutex;
-	std::vector<pirehip::DeviceTable> retired;
-	uint32_t autoAdapts = 0;
+	std::atomic<uint32_t> autoAdapts{0};
 };
 namespace pirehip { constexpr uint32_t kMaxAutoAdapts = 6; }
 
@@ -276,6 +274,14 @@ struct ScanParams {
 	// host walks those two steps once instead of every lane doing them (two dependent loads) for every string
 	uint32_t hfStart;
 	uint32_t hfStartC[8];
+	// host side only, filled by FillParams under the entry point's TableUse (below) and valid while it is held: the
+	// numbering of the image the pointers above belong to, and that image's distance tables when the entry point asked
+	// for them.  What an entry point derives after FillParams (start states of the half-final / suffix / segmented
+	// scans, mode representatives) goes through these.
+	const uint32_t* hostPermOfOrig;
+	const uint32_t* hostOrigOfPerm;
+	const uint8_t* distFinalPerm;
+	const uint8_t* distFlaggedPerm;
 #ifdef PIRE_HIP_TUNING
 	unsigned long long* stamps;     // timing experiments: [blocks][4] wall-clock stamps (start, table loaded, walk done, end)
 #endif
@@ -518,7 +524,7 @@ int GlueBfsDevice(const HostTable& a, const HostTable& b, const std::vector<uint
 int GlueHostTables(const HostTable& a, const HostTable& b, size_t maxSize, HostTable* out, bool onDevice = false);
 int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic = false);
 // the auto-adaptation policy (pire_hip_config.auto_adapt): called at every launch boundary, cheap when nothing is due
-void MaybeAutoAdapt(pire_hip_table* t);
+void MaybeAutoAdapt(pire_hip_table* t, bool enqueueOnly = false);
 int CheckFailures(pire_hip_table* t, uint64_t* out);
 void FreeDeviceTable(DeviceTable* d);
 
@@ -528,6 +534,9 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
+// stream.hip: offset batches of many short strings, every lane a run of consecutive strings
+bool StreamEligible(const ScanParams& p, uint64_t totalBytesHint);
+int LaunchStream(const ScanParams& p, hipStream_t stream);
 // segmented.hip: few long strings, cut into segments that are scanned in parallel (speculatively; the chain of
 // segments is then followed on the host, so the call synchronises its stream)
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes);
@@ -603,7 +612,26 @@ int LaunchRaggedCapture(const ScanParams& p, unsigned long long* workCounter, co
                         long long* outEnd, hipStream_t stream);
 // api.cpp, for the other translation units: the scan parameters of a table on the current device (uploads the image,
 // auto-adapts at the launch boundary), one ragged work slot of it, a table handle around a host table built elsewhere
-int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags);
+// Holds a table still for ONE entry point: the automatic adaptation's turn first (no lock held), then the table's
+// adaptMutex SHARED until the entry point returns, i.e. until its kernels are enqueued (host-pointer forms: until they
+// have run).  pire_hip_table_adapt() and the automatic adaptation take the mutex exclusively, drain the devices and only
+// then replace numbering and images -- so whatever an entry point derives from t->host after FillParams belongs to the
+// image its ScanParams point at, and an adaptation may run concurrently with scans on other host threads (ADVICE r3:
+// round 3 dropped the lock when FillParams returned).  Two tables (pire_hip_run_pair): acquire in address order.
+struct TableUse {
+	std::shared_lock<std::shared_mutex> lock;
+	TableUse() {}
+	TableUse(pire_hip_table* t, bool enqueueOnly) { Acquire(t, enqueueOnly); }
+	void Acquire(pire_hip_table* t, bool enqueueOnly)
+	{
+		if (lock.owns_lock())
+			return;   // a second look at the same table inside one entry point (an adaptation would wait for this very lock)
+		MaybeAutoAdapt(t, enqueueOnly);
+		lock = std::shared_lock<std::shared_mutex>(t->adaptMutex);
+	}
+};
+// for the other translation units: TableUse::Acquire(t) + FillParams
+int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags, TableUse* use, bool wantDist = false, bool enqueueOnly = false);
 unsigned long long* TakeWorkSlot(pire_hip_table* t, const ScanParams& p);
 void ChooseHotAndPermuteExported(HostTable& t);
 int LaunchRaggedPrefix(const ScanParams& p, unsigned long long* workCounter, bool longest, bool throughEnd,

