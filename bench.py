@@ -37,6 +37,8 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+import hashlib  # noqa: E402
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 SEED = 0x5EED5EED
 SEED_HELDOUT = 0x0DDBA11   # the corpus the dense-row ranking is learned on (never the timed one)
@@ -44,6 +46,17 @@ WORKLOADS = {"set_a": "C3: 8 regexps glued via Scanner::Glue, LDS-resident dense
              "c2_single": "C2: single Scanner hello\\s+w.+d$",
              "set_b": "C5a: 8 glued regexps, 8952-state table with HBM-resident transitions",
              "set_d": "8 glued unanchored regexps (pire_ut.cpp patterns)"}
+
+
+def kernel_sources_sha16() -> str:
+    """sha256 (16 hex digits) over the sources the headline kernel is compiled from: a committed PMC file
+    (profiles/*_pmc_traffic.json, written by tools/make_pmc_json.py) carries the hash of the sources it was measured
+    with, and a file whose hash is not this one is refused -- its traffic figure describes another kernel."""
+    h = hashlib.sha256()
+    for name in ("tiled.hip", "device_common.h", "internal.h"):
+        with open(os.path.join(ROOT, "pire_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -66,6 +79,13 @@ def parse():
     ap.add_argument("--settle", type=int, default=60,
                     help="untimed passes in front of the warm-up passes of every timed leg, so that the GPU's clocks "
                          "have settled (an idle MI355X needs 20-30 launches, profiles/r03_warmup_curve.log); 0 = none")
+    ap.add_argument("--cold-launches", type=int, default=20,
+                    help="launches of the from-idle leg (`cold_start` in the line): after the timed region the GPU is "
+                         "left idle for --cold-idle-ms, then this many passes are timed; 0 = no such leg")
+    ap.add_argument("--cold-idle-ms", type=int, default=300)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for ONE rank (world-1 process group): the counters then go "
+                         "through dist.all_reduce of the chosen backend -- with nccl, through RCCL -- on a one-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -244,12 +264,70 @@ def bench_slow(args):
     print(json.dumps(res))
 
 
+def bench_c1(args):
+    """BASELINE config C1 (informational, `--set c1_nonreloc`): ONE NonrelocScanner, pattern hello\\s+w.+d$, 10 000 x 256 B
+    ASCII strings on the reference's own CPU Run() -- "plumbing, no GPU".  The measured thing here IS the reference
+    (oracle/_ref, the unmodified library): `value` = its all-core rate, n_gpus 0.  When a GPU is present the same batch
+    also goes through pire_hip_run_strided and every result is compared (`gpu_parity`)."""
+    from oracle import binding as ob   # this config is the CPU baseline itself
+    from pire_amd import workloads as W
+
+    big = W.pattern_set("c2_single")
+    blob = W.load_blob(big["blob"])
+    n, length = args.strings or 10000, 256 if args.len == 4096 else args.len
+    host = ob.corpus_fill(SEED, 0, n, length, W.plants_for(big), threads=min(os.cpu_count() or 1, 16))
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    ref = ob.RefScanner.load(blob) if ob.ref_available() else None
+    runs, want = {}, None
+    cores = min(os.cpu_count() or 1, 256)
+    legs = (("nonreloc_1t", 1, 1), ("nonreloc_all", 1, cores), ("scanner_1t", 0, 1)) if ref else (("port_1t", 0, 1),)
+    for label, kind, thr in legs:
+        best = None
+        for _ in range(max(3, args.steps // 10)):
+            t0 = time.perf_counter()
+            if ref:
+                idx, fin = ref.run(host.reshape(-1), offs, kind=kind, threads=thr)
+            else:
+                idx, fin = ob.OracleScanner(blob).run(host.reshape(-1), offs, threads=thr)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        runs[label] = {"GBps": round(n * length / best / 1e9, 4), "seconds": round(best, 6), "threads": thr}
+        if want is None:
+            want = (idx, fin)
+        assert (idx == want[0]).all() and (fin == want[1]).all()
+    # a 2.5 MB batch: one thread is often faster than spawning all of them; the line reports the better of the two
+    top = max((k for k in runs if not k.startswith("scanner")), key=lambda k: runs[k]["GBps"])
+    res = {"metric": "scanned GB/s, config C1 (plumbing): NonrelocScanner hello\\s+w.+d$ on the reference CPU Run()",
+           "value": runs[top]["GBps"], "unit": "GB/s", "n_gpus": 0, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(runs[top]["seconds"] * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": {"workload": f"C1: single NonrelocScanner {big['patterns'][0]!r}, {n} x {length} B ASCII strings, "
+                                  "reference CPU Run() (Begin().Run().End() per string)", "corpus_seed": SEED},
+           "cpu_baseline": {"value": runs[top]["GBps"], "unit": "GB/s", "cores": runs[top]["threads"],
+                            "kind": "reference" if ref else "port", "sample": f"the whole batch, {n} x {length} B", "runs": runs},
+           "match_counts": {"final": int(want[1].sum()), "strings": n, "distinct_end_states": int(len(np.unique(want[0])))}}
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            import pire_amd
+
+            t = pire_amd.Table(blob)
+            gi, gf = t.run_strided_host(host)
+            res["gpu_parity"] = bool((gi == want[0]).all() and (gf == want[1]).all())
+    except ImportError:
+        pass
+    print(json.dumps(res))
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.set.startswith("slow_"):
         return bench_slow(args)
+    if args.set == "c1_nonreloc":
+        return bench_c1(args)
     import torch
     import torch.distributed as dist
 
@@ -268,8 +346,9 @@ def main():
     local_dev = local % max(ndev, 1)
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if world > 1:
+    if world > 1 or args.force_dist:
         pd.init(args.backend, dev)   # "nccl" is RCCL on ROCm
+        pd.FORCE_SINGLE_RANK_COLLECTIVES = bool(args.force_dist)
 
     # The library re-ranks a table's dense rows by itself when scans keep leaving them (pire_hip_config.auto_adapt).
     # Here the ranking is learned explicitly, on a held-out corpus (step 1 below), and must not move afterwards: off.
@@ -312,7 +391,11 @@ def main():
     # every scan (3.6 us + its gap in round 2) is not part of the path.  The all-reduce of step k (RCCL runs it on its
     # own stream) overlaps the scan of step k+1.
     settle = max(0, args.settle)
-    total_steps = 2 * settle + args.warmup + args.steps + 40
+    cold_steps = max(1, min(args.steps, 10))
+    cold_launches = max(0, args.cold_launches)
+    # every pass of every leg has a row of its own: two legs of (settle + warm-up) untimed passes, the never-adapted
+    # table's timed passes, the timed region, the from-idle leg (round 3 sized this by a constant)
+    total_steps = 2 * (settle + args.warmup) + cold_steps + args.steps + cold_launches + 8
     counts_all = torch.zeros((total_steps, table.RegexpsCount + 2), dtype=torch.int64, device=dev)
     step_no = [0]
     pending = []   # outstanding all-reduces, oldest first
@@ -389,14 +472,24 @@ def main():
     # scanning) issued back to back with the W warm-up passes: the metric is the throughput of sustained scanning.
     cold_table = pire_amd.Table(blob)
     cold_table.upload()
-    cold_steps = max(1, min(args.steps, 10))
     cold_elapsed, cold_ms = timed(cold_table, cold_steps, settle + args.warmup)
     del cold_table
     # --- 3. the timed region: settle + W warm-up passes, fence, exactly K passes, fence
     elapsed, kernel_ms = timed(table, args.steps, settle + args.warmup)
+    per_rank_timed = list(per_rank)   # of THIS leg (the from-idle leg below overwrites per_rank)
     kernel_name = pb.last_kernel_symbol()   # the instantiation the library actually launched
 
     total_counts = counts_all[step_no[0] - 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
+    # --- 4. from idle: what a caller gets who scans one batch on a GPU that was doing nothing.  Behind the
+    # timed region and outside it: the device is drained, left idle for 0.3 s (its clocks drop), then `cold_launches`
+    # passes are timed back to back with no warm-up at all (the first ones run in the power management's transient,
+    # profiles/r03_warmup_curve.log).  Reported beside the sustained `value`, never instead of it.
+    from_idle = None
+    if cold_launches:
+        fence()
+        time.sleep(args.cold_idle_ms / 1e3)
+        cold_el, cold_start_ms = timed(table, cold_launches, 0)
+        from_idle = (cold_el, cold_start_ms)
     gpu_idx = out_idx.cpu().numpy().astype(np.uint32)
     gpu_fin = out_fin.cpu().numpy()
 
@@ -408,22 +501,28 @@ def main():
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
         info = table.refresh_info()
         # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3 requires)
-        traffic = traffic_src = lds = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        traffic = traffic_src = lds = traffic_note = None
+        sources = kernel_sources_sha16()
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
-                if pmc.get("workload") == f"{args.set} 2^{args.log2_strings} x {length}" and not args.strings \
-                        and args.corpus == "synthetic":
-                    traffic, traffic_src = pmc["hbm_bytes_per_launch"], name
-                    if "lds_idx_active_cycles_per_launch" in pmc:
-                        # the secondary bound SURVEY 8(d) asks for: the dependent LDS gather (one ds_read_u8 per byte)
-                        lds = {"bank_conflict_over_idx_active": round(pmc["lds_bank_conflict_cycles_per_launch"] /
-                                                                      pmc["lds_idx_active_cycles_per_launch"], 3),
-                               "lds_cycles_per_lookup": round(pmc["lds_idx_active_cycles_per_launch"] /
-                                                              pmc["lds_instructions_per_launch"], 2),
-                               "source": f"profiles/{name} (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)"}
-                    break
+                if pmc.get("workload") != f"{args.set} 2^{args.log2_strings} x {length}" or args.strings or args.corpus != "synthetic":
+                    continue
+                if pmc.get("kernel_sources_sha16") != sources:
+                    # counters of another build of the kernel say nothing about this one
+                    traffic_note = (f"profiles/{name} was collected with kernel sources {pmc.get('kernel_sources_sha16', 'unknown')}, "
+                                    f"these are {sources}: refused (re-run the --pmc passes, tools/make_pmc_json.py)")
+                    continue
+                traffic, traffic_src = pmc["hbm_bytes_per_launch"], name
+                if "lds_idx_active_cycles_per_launch" in pmc:
+                    # the secondary bound SURVEY 8(d) asks for: the dependent LDS gather (one ds_read_u8 per byte)
+                    lds = {"bank_conflict_over_idx_active": round(pmc["lds_bank_conflict_cycles_per_launch"] /
+                                                                  pmc["lds_idx_active_cycles_per_launch"], 3),
+                           "lds_cycles_per_lookup": round(pmc["lds_idx_active_cycles_per_launch"] /
+                                                          pmc["lds_instructions_per_launch"], 2),
+                           "source": f"profiles/{name} (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS)"}
+                break
             except (OSError, ValueError, KeyError):
                 pass
         if args.corpus == "cxx":
@@ -460,13 +559,13 @@ def main():
                 "strings_per_gpu": run_n, "string_bytes": run_len, "string_stride": run_stride, "corpus_seed": SEED,
                 "parallelism": f"shard-by-string x{world}",
                 "reduce_backend": pd.backend_description(),
-                "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank],
+                "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank_timed],
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
-                                  if traffic else None,
+                "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same kernel sources "
+                                  f"{sources})" if traffic else traffic_note,
                 "lds_gather": lds,
                 "kernel": kernel_name, "kernel_avg_ms": round(avg_ms, 4),
                 "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
@@ -477,6 +576,17 @@ def main():
             "match_counts": {"final": int(total_counts[0]), "strings": int(total_counts[1]),
                              "per_regexp": [int(c) for c in total_counts[2:]]},
         }
+        if from_idle:
+            cel, cms = from_idle
+            cold_achieved = algo_bytes / (float(np.mean(cms)) * 1e-3) / 1e9
+            res["cold_start"] = {
+                "what": f"{cold_launches} passes back to back after {args.cold_idle_ms} ms of idle GPU, no warm-up, adapted table; "
+                        "outside the timed region",
+                "value": round(float(n) * length * cold_launches * world / cel / 1e9, 2), "unit": "GB/s",
+                "ms_per_step": round(cel / cold_launches * 1e3, 4),
+                "kernel_avg_ms": round(float(np.mean(cms)), 4), "kernel_first_ms": round(float(cms[0]), 4),
+                "kernel_max_ms": round(float(np.max(cms)), 4),
+                "frac": round(cold_achieved / HBM_PEAK_GBS, 4)}
         assert int(total_counts[1]) == run_n * world, "match-count reduce lost strings"
         if not args.no_cpu and world == 1 and not args.one_string:   # the reported CPU baseline belongs to the N=1 line
             sample = min(n, 1 << args.cpu_sample_log2)
@@ -490,7 +600,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(blob, host, length, gpu_idx, gpu_fin)
         print(json.dumps(res))
         sys.stdout.flush()
-    if world > 1:
+    if world > 1 or args.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -131,7 +131,8 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 	TransposeTile(cur, lane);
 	const bool more = S.laneEnd > S.wpos + 128u;   // boundaries of this lane lie behind this window
 	// unconditional (lanes without a further line fetch a harmless valid one), see ragged.hip
-	IssueTileGroup(nxt, S.dataEnd > S.wpos + 128u ? lineBase + S.wpos + 128u : reinterpret_cast<uint64_t>(p.hotRows), lane);
+	// (the sum modulo 2^32 FIRST: in a sub-task's first phase wpos is -128 mod 2^32 for the lanes whose first line is line 0)
+	IssueTileGroup(nxt, S.dataEnd > S.wpos + 128u ? lineBase + uint64_t(uint32_t(S.wpos + 128u)) : reinterpret_cast<uint64_t>(p.hotRows), lane);
 	if (lane == (iter & 63) && S.live)   // visit sample, as in the tiled kernel
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
 	// (`walk` is false in a sub-task's first phase only: its window is the line in FRONT of the lanes' first lines, there

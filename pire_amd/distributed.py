@@ -10,6 +10,17 @@ import os
 from typing import Tuple
 
 
+# bench.py --force-dist: a world of ONE rank still sends its counters through the backend's all-reduce (with nccl: RCCL),
+# so that a one-GPU box executes the collective path the 8-GPU run takes
+FORCE_SINGLE_RANK_COLLECTIVES = False
+
+
+def _collectives_on() -> bool:
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_SINGLE_RANK_COLLECTIVES)
+
+
 def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced [lo, hi) of global string indices owned by `rank` (sizes differ by at most 1)."""
     if not (0 <= rank < world):
@@ -31,6 +42,8 @@ def init(backend: str, device=None):
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")          # a world of one rank without a launcher (bench.py --force-dist)
+    os.environ.setdefault("WORLD_SIZE", "1")
     if dist.is_initialized():
         return
     if device is not None and backend == "nccl":
@@ -54,7 +67,7 @@ def allreduce_counts(counts, async_op: bool = False):
     through the host, synchronously."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         if _gloo_with_device_tensor(counts):
             host = counts.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -69,7 +82,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return seconds
     on = device if device is not None and dist.get_backend() != "gloo" else "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=on)
@@ -80,7 +93,7 @@ def max_over_ranks(seconds: float, device=None) -> float:
 def barrier():
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.barrier()
 
 
@@ -90,7 +103,7 @@ def gather_over_ranks(value: float, device=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return [value]
     on = device if device is not None and dist.get_backend() != "gloo" else "cpu"
     mine = torch.tensor([value], dtype=torch.float64, device=on)
@@ -104,7 +117,7 @@ def backend_description() -> str:
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return "none (one rank)"
     name = dist.get_backend()
     if name == "nccl":

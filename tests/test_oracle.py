@@ -155,3 +155,30 @@ def test_reference_own_unit_tests_pass_with_standin_parser():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "OK(50 tests)" in r.stdout          # pire_ut + easy_ut (26) + count_ut (13) + capture_ut (11)
+
+
+@needs_ref
+def test_baseline_config_c1_nonreloc_scanner_10k_x_256_on_the_reference_cpu_run():
+    """BASELINE.json configs[0], at its stated shape: a single NonrelocScanner, pattern hello\\s+w.+d$, 10 000 x 256 B
+    ASCII strings, the reference's own CPU Run() -- the plumbing case, no GPU.  The unmodified reference
+    (oracle/_ref: Pire::NonrelocScanner, Runner(sc).Begin().Run(p, 256).End() per string) over the seeded corpus; the
+    relocatable Scanner and the C restatement must return the same StateIndex / Final for every string, the planted
+    witnesses must be found, and SURVEY 8(c)'s known answers hold for this very scanner object."""
+    big = [b for b in H.big_sets() if b["name"] == "c2_single"][0]
+    assert big["patterns"] == ["hello\\s+w.+d$"]
+    blob = H.load_blob(big["blob"])
+    r, o = ob.RefScanner.load(blob), ob.OracleScanner(blob)
+    assert (r.size, r.letters, r.initial) == (11, 10, 8)          # SURVEY 8(c): 11 states x 10 letter classes, initial 8
+    n, length = 10000, 256
+    data = ob.corpus_fill(0x5EED5EED, 0, n, length, H.plants_for(big), threads=4)
+    assert data.max() <= 0x7E                                     # ASCII (printable text, tabs in the whitespace runs)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    ni, nf = r.run(data.reshape(-1), offs, kind=ob.RefScanner.NONRELOC, threads=1)   # the config: NonrelocScanner, CPU Run()
+    si, sf = r.run(data.reshape(-1), offs, kind=0, threads=2)
+    oi, of = o.run(data.reshape(-1), offs, threads=2)
+    assert (ni == si).all() and (nf == sf).all() and (ni == oi).all() and (nf == of).all()
+    assert 0 < int(nf.sum()) < n and len(np.unique(ni)) >= 2      # planted matches: parity is not vacuous
+    known = [(b"hello world", 1, 1), (b"Hello world", 8, 0), (b"say hello   wod", 1, 1), (b"hello world!", 8, 0),
+             (b"hello wd", 8, 0), (b"", 8, 0), (b"xxhello\tw--d", 1, 1)]
+    ki, kf = r.run_strings([k[0] for k in known], kind=ob.RefScanner.NONRELOC)
+    assert ki.tolist() == [k[1] for k in known] and kf.tolist() == [k[2] for k in known]
