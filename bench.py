@@ -576,6 +576,15 @@ def main():
             "match_counts": {"final": int(total_counts[0]), "strings": int(total_counts[1]),
                              "per_regexp": [int(c) for c in total_counts[2:]]},
         }
+        # how often the timed corpus left the dense rows: the table's cold-state samples since the ranking was frozen (one
+        # rotating lane of 64 per chunk that ended outside the dense rows), read by an adapt() AFTER every
+        # timed leg -- it re-ranks a table nobody uses any more
+        launches_since_ranking = settle + args.warmup + args.steps + (cold_launches if from_idle else 0)
+        table.adapt()
+        samples = int(table.refresh_info().last_trap_samples)
+        res["traps"] = {"cold_samples": samples, "launches": launches_since_ranking,
+                        "cold_lane_chunk_share": round(samples * 64.0 / max(1.0, launches_since_ranking * float(n) * length / 16.0), 8),
+                        "what": "share of (lane, 16-byte chunk) pairs of the timed corpus that ended in a state without a dense row"}
         if from_idle:
             cel, cms = from_idle
             cold_achieved = algo_bytes / (float(np.mean(cms)) * 1e-3) / 1e9

@@ -51,6 +51,7 @@ typedef __attribute__((address_space(3))) uint32_t* LdsWordPtr;
 struct StreamLane {
 	uint32_t wpos;      // start of the current window, relative to the sub-task's line base (multiple of 128)
 	uint32_t E;         // end of the current string (relative); kStreamInf once the lane's strings are over
+	uint32_t En;        // end of the string that starts at the next boundary, read one boundary ahead (LDS latency off the walk)
 	uint32_t laneEnd;   // end of the lane's last string: windows up to the one that holds it are walked
 	uint32_t dataEnd;   // the same, or 0 when all the lane's strings are empty: lines that hold none of its bytes are not fetched
 	uint32_t nxt;       // the string that starts at the next boundary (index inside the sub-task)
@@ -66,9 +67,10 @@ __device__ __forceinline__ void StreamBoundary(LdsWordPtr eo, StreamLane& S, uin
 	if (S.live)
 		eo[S.nxt] = state;
 	if (S.nxt < S.sEnd) {
-		S.E = eo[S.nxt + 1];
+		S.E = S.En;
 		S.nxt += 1;
 		S.live = true;
+		S.En = eo[S.nxt + 1];   // of the string after this one (a word of the padding / a neighbour's when there is none: unused)
 	} else {
 		S.E = kStreamInf;
 		S.live = false;
@@ -77,18 +79,29 @@ __device__ __forceinline__ void StreamBoundary(LdsWordPtr eo, StreamLane& S, uin
 
 // Sixteen bytes through the dense rows with a string boundary in front of byte c (c >= 16: none): `snap` = the state the
 // walk was in when it reached byte c, and the walk goes on from `start`.
+// What a step costs on top of the plain kernel's v_perm + ds_read_u8 is the select that restarts the walk (on the
+// dependent chain) and the select that keeps the end state (issued behind the lookup, in its shadow).  The sixteen lane
+// masks "c == j" are NOT sixteen vector compares: five ballots (c < 16 and the four bits of c) and the scalar unit's
+// and / andn2 give all of them, and the scalar unit has nothing else to do here (the first version spent a quarter of
+// its vector instructions on those compares; 60 % VALU-busy, the walk's steps 150 cycles apart against 90 in the tiled
+// kernel: profiles/r04_stream_pmc_*).
 __device__ __forceinline__ void StepChunkB(const u32x4 v, uint32_t c, uint32_t start, uint32_t& hs, uint32_t& snap)
 {
+	const unsigned long long any = __ballot(c < 16u), b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0),
+	                         b2 = __ballot((c & 4u) != 0), b3 = __ballot((c & 8u) != 0);
 	uint32_t h = hs, sn = hs;
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t x = v[w];
 #pragma unroll
 		for (int b = 0; b < 4; ++b) {
-			const bool at = c == uint32_t(4 * w + b);
-			sn = at ? h : sn;
-			h = at ? start : h;
-			h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u + uint32_t(b)));
+			const int j = 4 * w + b;
+			const unsigned long long m = any & ((j & 1) ? b0 : ~b0) & ((j & 2) ? b1 : ~b1) & ((j & 4) ? b2 : ~b2) & ((j & 8) ? b3 : ~b3);
+			const bool at = __builtin_amdgcn_inverse_ballot_w64(m);
+			const uint32_t from = at ? start : h;
+			const uint32_t next = HotLookup(__builtin_amdgcn_perm(from, x, 0x0c0c0400u + uint32_t(b)));
+			sn = at ? h : sn;   // behind the lookup: it needs the state in front of the step, not the lookup's result
+			h = next;
 		}
 	}
 	hs = h;
@@ -253,7 +266,10 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 	uint64_t K = totalKey / g.minTaskUnits;
 	K = K < 1 ? 1 : K > W ? W : K;
 	const uint64_t perTask = (totalKey + K - 1) / K;
-	const uint64_t gw = uint64_t(blockIdx.x) * wavesPerBlock + wave;
+	// fewer tasks than waves: every block takes its share of them (ceil(K / blocks) of its waves work), so that a batch
+	// that does not fill the chip still uses every CU's LDS bandwidth instead of the first K / 16 CUs'
+	const uint64_t perBlock = (K + gridDim.x - 1) / gridDim.x;
+	const uint64_t gw = wave < perBlock ? uint64_t(blockIdx.x) * perBlock + wave : K;
 	uint64_t i0 = 0, i1 = 0;
 	if (gw < K) {
 		const uint64_t T0 = gw * perTask, T1 = (gw + 1) * perTask;
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		S.live = false;
 		const bool has = s0 < s1;
 		S.E = has ? eo[s0] : kStreamInf;
+		S.En = eo[s0 + 1];
 		S.laneEnd = has ? eo[s1] : 0u;
 		S.dataEnd = S.E < S.laneEnd ? S.laneEnd : 0u;
 		// the window in front of the lane's first line (modulo 2^32; lanes without strings stay at 0, where "no boundary
@@ -398,9 +415,11 @@ int LaunchStream(const ScanParams& p0, hipStream_t stream)
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	StreamGeom g;
-	g.lambda = 16;
+	g.lambda = 4;   // a boundary costs the wave a few lane-steps' worth of instructions; what matters is that keys stay distinct among empty strings
 	g.minTaskUnits = 64 * 256;
-	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), p.n / 2048));
+	// every CU (the kernel starts as many of a block's waves as the batch has work for, see perBlock there); the host
+	// cannot size the grid by bytes: with device offsets it does not know them
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), p.n / 64));
 	NoteKernel("stream", "pirehip::ScanStreamKernel");
 	hipLaunchKernelGGL(ScanStreamKernel, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
 	e = hipGetLastError();
