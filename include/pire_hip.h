@@ -116,9 +116,11 @@ typedef struct pire_hip_config {
 	                               /* then block and is not capturable)                                                  */
 	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 256)          */
 	/* offset batches (pire_hip_run) */
-	uint32_t ragged_variant;       /* 0 default: batches of >= 16 384 strings take the stream kernel (every lane walks a  */
-	                               /* run of consecutive strings), smaller ones the ragged kernel (one string per lane at */
-	                               /* a time); 1 always the ragged kernel; 2 the stream kernel from 256 strings (tests)  */
+	uint32_t ragged_variant;       /* 0 default: large offset batches (>= 160 MiB of text when the host knows the lengths, */
+	                               /* >= 2^20 strings when the offsets are on the device) take the stream kernel (every    */
+	                               /* lane walks a run of consecutive strings), smaller ones the ragged kernel (one string */
+	                               /* per lane at a time); 1 always the ragged kernel; 2 the stream kernel from 256        */
+	                               /* strings (tests).  Same results either way.                                            */
 	uint32_t host_staging;         /* device staging of the host-pointer forms of the prefix / suffix / half-final /   */
 	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
 	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */

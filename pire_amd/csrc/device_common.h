@@ -601,9 +601,8 @@ __device__ __forceinline__ void WaitAllLoads(u32x4 (&r)[8])
 
 
 // ---- end of a string for the offset-batch kernels -------------------------------------------------------------------
-template <bool EXT>
-__device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
-                                             uint32_t s, bool active, uint32_t st)
+// The end-of-string record of state `st`: LDS for a dense-row state, memory for any other.
+__device__ __forceinline__ u32x4 FinRecordOf(const ScanParams& p, const FinRec* finHot, bool active, uint32_t st)
 {
 	// The record of a dense-row state comes from LDS, the record of any other state from memory -- under a wave-uniform
 	// branch of its own, and waited for inside it.  Written as one if/else per lane the compiler merges the two into a
@@ -620,6 +619,25 @@ __device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, 
 			asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));   // the wait belongs in here
 		}
 	}
+	return raw;
+}
+
+template <bool EXT>
+__device__ __forceinline__ void FinishWith(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint32_t s, bool active,
+                                           const u32x4 raw);
+
+template <bool EXT>
+__device__ __forceinline__ void FinishRagged(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
+                                             uint32_t s, bool active, uint32_t st)
+{
+	FinishWith<EXT>(p, lds, L, s, active, FinRecordOf(p, finHot, active, st));
+}
+
+// outputs and block-local counters of one finished string per lane, from its end-of-string record
+template <bool EXT>
+__device__ __forceinline__ void FinishWith(const ScanParams& p, uint8_t* lds, const LdsLayout& L, uint32_t s, bool active,
+                                           const u32x4 raw)
+{
 	const uint32_t orig = raw.x, endPerm = raw.y & 0x0FFFFFFFu, fl = raw.y >> 28;
 	if (active) {
 		if (p.outIdx)

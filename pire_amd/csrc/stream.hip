@@ -36,7 +36,7 @@
 
 namespace pirehip {
 
-constexpr uint32_t kStreamMaxStrings = 1024;                    // strings of one sub-task
+constexpr uint32_t kStreamMaxStrings = 1280;                    // strings of one sub-task (20 x 64; with the dense rows 155 of the 160 KiB)
 constexpr uint32_t kStreamStageWords = kStreamMaxStrings + 16;  // their positions (m + 1 words) per wave, padded
 constexpr uint32_t kStreamInf = 0xFFFFFFFFu;                    // "no boundary ahead": the lane's strings are over
 constexpr uint32_t kStreamWaves = 16;
@@ -85,6 +85,12 @@ __device__ __forceinline__ void StreamBoundary(LdsWordPtr eo, StreamLane& S, uin
 // and / andn2 give all of them, and the scalar unit has nothing else to do here (the first version spent a quarter of
 // its vector instructions on those compares; 60 % VALU-busy, the walk's steps 150 cycles apart against 90 in the tiled
 // kernel: profiles/r04_stream_pmc_*).
+// START0 (the start state has dense id 0: table.cpp puts Begin()'s there when it can): the restart is not a select of the
+// state in front of the lookup but a select of the v_perm SELECTOR -- the row byte of the address comes from the state
+// register (0x04) or is the constant 0 (0x0c) -- which depends on nothing the chain computes: the dependent chain of a
+// boundary chunk is the plain kernel's v_perm -> ds_read_u8 again (the first version's select in the chain cost every
+// step ~50 cycles: 174 per step against the tiled kernel's 96, profiles/r04_stream_ablation.log).
+template <bool START0>
 __device__ __forceinline__ void StepChunkB(const u32x4 v, uint32_t c, uint32_t start, uint32_t& hs, uint32_t& snap)
 {
 	const unsigned long long any = __ballot(c < 16u), b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0),
@@ -98,8 +104,14 @@ __device__ __forceinline__ void StepChunkB(const u32x4 v, uint32_t c, uint32_t s
 			const int j = 4 * w + b;
 			const unsigned long long m = any & ((j & 1) ? b0 : ~b0) & ((j & 2) ? b1 : ~b1) & ((j & 4) ? b2 : ~b2) & ((j & 8) ? b3 : ~b3);
 			const bool at = __builtin_amdgcn_inverse_ballot_w64(m);
-			const uint32_t from = at ? start : h;
-			const uint32_t next = HotLookup(__builtin_amdgcn_perm(from, x, 0x0c0c0400u + uint32_t(b)));
+			uint32_t next;
+			if constexpr (START0) {
+				const uint32_t sel = at ? 0x0c0c0c00u + uint32_t(b) : 0x0c0c0400u + uint32_t(b);
+				next = HotLookup(__builtin_amdgcn_perm(h, x, sel));
+			} else {
+				const uint32_t from = at ? start : h;
+				next = HotLookup(__builtin_amdgcn_perm(from, x, 0x0c0c0400u + uint32_t(b)));
+			}
 			sn = at ? h : sn;   // behind the lookup: it needs the state in front of the step, not the lookup's result
 			h = next;
 		}
@@ -135,28 +147,44 @@ __device__ __forceinline__ void ExactRest(const ScanParams& p, const uint8_t* ld
 
 // One window: start fetching the next line into `nxt`, walk the line held in `cur`.  Returns whether any lane of the wave
 // has a further line.
+template <bool START0>
 __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, LdsWordPtr eo,
                                             uint64_t lineBase, StreamLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter,
                                             bool walk)
 {
 	const uint32_t lane = threadIdx.x & 63;
-	WaitAllLoads(cur);
-	TransposeTile(cur, lane);
 	const bool more = S.laneEnd > S.wpos + 128u;   // boundaries of this lane lie behind this window
+	// The NEXT line is requested before this one is waited for (its address depends on nothing but the window counter),
+	// as the tiled kernel does: its latency then runs behind the wait, the transpose and the walk of this line.  With the
+	// wait first a wave had nothing on its way during the transpose, and the kernel without any walk still took 122 us on
+	// the URL batch (3.75 TB/s, profiles/r04_stream_ablation.log).
 	// unconditional (lanes without a further line fetch a harmless valid one), see ragged.hip
 	// (the sum modulo 2^32 FIRST: in a sub-task's first phase wpos is -128 mod 2^32 for the lanes whose first line is line 0)
 	IssueTileGroup(nxt, S.dataEnd > S.wpos + 128u ? lineBase + uint64_t(uint32_t(S.wpos + 128u)) : reinterpret_cast<uint64_t>(p.hotRows), lane);
+	// at most the 8 loads just issued may still be out: loads return in order, whatever else is in the queue only makes
+	// the wait stricter (tiled.hip)
+	asm volatile("s_waitcnt vmcnt(8)"
+	             : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+	TransposeTile(cur, lane);
 	if (lane == (iter & 63) && S.live)   // visit sample, as in the tiled kernel
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
 	// (`walk` is false in a sub-task's first phase only: its window is the line in FRONT of the lanes' first lines, there
 	// to get the first lines requested from inside the loop -- asynchronous asm loads issued in front of the loop end up
 	// in registers the loop does not use, and the compiler copies them over while they are in flight)
+#if defined(PIRE_EXP) && PIRE_EXP == 3   // timing experiment: no walk at all (loads, transposes, bookkeeping only)
+	if (false)
+#else
 	if (walk)
+#endif
 #pragma unroll
 	for (int k = 0; k < 8; ++k) {
 		const uint32_t c = (S.E - S.wpos) - 16u * uint32_t(k);   // bytes of this chunk in front of the boundary (>= 16: none)
 		const uint32_t hs0 = S.hs;
+#if defined(PIRE_EXP) && PIRE_EXP == 5   // timing experiment: every chunk takes the plain step (boundaries ignored)
+		if (true) {
+#else
 		if (!__any(c < 16u)) {
+#endif
 			// no string of the wave ends in this chunk: the tiled kernel's step
 			uint32_t h = S.hs;
 #pragma unroll
@@ -168,11 +196,20 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 				h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
 			}
 			S.hs = h;
-			if (h == p.hot && S.live)
-				TrapChunk(p, lds, L, cur[k], hs0, S.hs, S.cold, (iter * 8 + k) & 63);
+			if (h == p.hot && S.live) {
+				// TrapChunk without the compact tier (its LDS holds the string positions here): the chunk again through the
+				// full table, the cold end state sampled for pire_hip_table_adapt()
+				const uint32_t f = SlowChunk(p, lds, L, cur[k], hs0 != p.hot ? hs0 : S.cold);
+				S.hs = f < p.hot ? f : p.hot;
+				S.cold = f;
+				if (f >= p.hot && lane == ((iter * 8 + k) & 63)) {
+					atomicAdd(&p.visitCold[f], 1u);
+					atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + kLdsTrapSlot, 1u);
+				}
+			}
 		} else {
 			uint32_t snap;
-			StepChunkB(cur[k], c, p.startPerm, S.hs, snap);
+			StepChunkB<START0>(cur[k], c, p.startPerm, S.hs, snap);
 			const bool isB = c < 16u;
 			// the part of the chunk that belongs to the current string left the dense rows (or was outside them all along),
 			// or the part that belongs to the string starting here did: this lane's chunk again, exactly
@@ -180,7 +217,11 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 			const bool trapAfter = isB && S.hs == p.hot && S.nxt < S.sEnd;
 			bool exact = trapBefore || trapAfter;
 			uint32_t from = 0, st = hs0 != p.hot ? hs0 : S.cold;
+#if defined(PIRE_EXP) && PIRE_EXP == 4   // timing experiment: boundary chunks walked, boundaries not processed
+			if (false) {
+#else
 			if (!exact && isB) {
+#endif
 				StreamBoundary(eo, S, snap);
 				if ((S.E - S.wpos) - 16u * uint32_t(k) < 16u) {   // the string that started here ends in this chunk as well
 					exact = true;
@@ -247,12 +288,32 @@ __device__ __forceinline__ void StreamSearch2(const uint64_t* off, uint64_t off0
 	r1 = lo[1];
 }
 
+#ifdef PIRE_HIP_TUNING
+// timing experiments (PIRE_HIP_DEBUG_STREAM_CLOCKS): wall-clock (100 MHz) time of a wave per stage, summed over the waves
+// into ScanParams::stamps: 0 search, 1 table copy, 2 positions into LDS + lane search, 3 window loop, 4 flush; 5 = waves,
+// 6 = windows, 7 = the latest end of any wave, 8 = the earliest start (both against the kernel's first stamp)
+#define PIRE_SCLK(k)                                                       \
+	do {                                                                   \
+		if (p.stamps) {                                                    \
+			const unsigned long long n_ = wall_clock64();                  \
+			sclk[k] += n_ - sclkT;                                         \
+			sclkT = n_;                                                    \
+		}                                                                  \
+	} while (0)
+#else
+#define PIRE_SCLK(k) do { } while (0)
+#endif
+
+template <bool START0>
 __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeom g)
 {
+#ifdef PIRE_HIP_TUNING
+	unsigned long long sclk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sclkT = p.stamps ? wall_clock64() : 0;
+	const unsigned long long sclkStart = sclkT;
+#endif
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
-	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
 	const uint32_t wavesPerBlock = blockDim.x >> 6;
 	LdsWordPtr eo = reinterpret_cast<LdsWordPtr>(
@@ -277,19 +338,43 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		if (gw == K - 1)
 			i1 = p.n;
 	}
+	i0 = Uniform64(i0);   // wave-uniform by construction: keep them (and what is derived from them) in scalar registers
+	i1 = Uniform64(i1);
+	PIRE_SCLK(0);
 	{
 		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
 		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
 			finHot[i] = recs[i];
 	}
 	LoadTableToLds(p, lds, L);   // ends with a barrier
+	PIRE_SCLK(1);
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
 	uint32_t iter = 0;
-	for (uint64_t sub = i0; sub < i1; sub += kStreamMaxStrings) {
-		const uint32_t m = uint32_t(i1 - sub < kStreamMaxStrings ? i1 - sub : kStreamMaxStrings);
-		// ---- the sub-task's string positions into LDS, relative to the line that holds its first byte
+	// sub-tasks of equal size (a task of 1 030 strings is not one of 1 024 and one of 6: the second would pay a whole
+	// pipeline start for six strings, and the launch ends with its slowest wave)
+	const uint64_t taskStrings = i1 - i0;
+	const uint64_t subTasks = (taskStrings + kStreamMaxStrings - 1) / kStreamMaxStrings;
+	const uint32_t subStrings = subTasks ? uint32_t((taskStrings + subTasks - 1) / subTasks) : 0;
+	for (uint64_t sub = i0; sub < i1; sub += subStrings) {
+		// (what the set-up derives from the lane number -- a dozen addresses and positions -- is cheap to compute and was
+		// hoisted out of this loop and carried across the window loop through scratch: opaque here, so it stays inside)
+		uint32_t lane = threadIdx.x & 63;
+		asm volatile("" : "+v"(lane));
+		const uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(i1 - sub < subStrings ? i1 - sub : subStrings)));
+		// ---- the sub-task's string positions into LDS, relative to the line that holds its first byte.  ONE round trip:
+		// the m + 1 offsets and the two the conversion needs are all requested before any is looked at (at kernel start
+		// every wave asks at once and a round trip is 4 us: six of them in a row were a sixth of the URL batch's time,
+		// profiles/r04_stream_stage_clocks.log)
+		constexpr int kLoads = 11;   // per batch: two batches cover kStreamMaxStrings + 1 positions (all 21 at once: 42 registers)
+		uint64_t v[kLoads];
+#pragma unroll
+		for (int j = 0; j < kLoads; ++j) {
+			const uint32_t q = uint32_t(j) * 64 + lane;
+			v[j] = p.offsets[sub + (q <= m ? q : m)];   // (clamped, not skipped: an unconditional load can be issued at once)
+		}
 		const uint64_t offA = p.offsets[sub], offZ = p.offsets[sub + m];
+		PIRE_SCLK(5);   // (tuning) the offsets of the sub-task
 		const uint64_t firstByte = textBase + offA;
 		const uint64_t lineBase = Uniform64(firstByte & ~uint64_t(127));
 		const uint32_t lead = uint32_t(firstByte) & 127u;
@@ -306,20 +391,26 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 			}
 			continue;
 		}
-		for (uint32_t base = 0; base <= m; base += 64 * 8) {
-			uint64_t v[8];
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const uint32_t q = base + uint32_t(j) * 64 + lane;
-				v[j] = q <= m ? p.offsets[sub + q] : 0;
+		for (int j = 0; j < kLoads; ++j) {
+			const uint32_t q = uint32_t(j) * 64 + lane;
+			if (q <= m)
+				eo[q] = lead + uint32_t(v[j] - offA);
+		}
+		if (m >= kLoads * 64) {   // the second batch (sub-tasks of more than 703 strings)
+#pragma unroll
+			for (int j = 0; j < kLoads; ++j) {
+				const uint32_t q = uint32_t(kLoads + j) * 64 + lane;
+				v[j] = p.offsets[sub + (q <= m ? q : m)];
 			}
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
-				const uint32_t q = base + uint32_t(j) * 64 + lane;
+			for (int j = 0; j < kLoads; ++j) {
+				const uint32_t q = uint32_t(kLoads + j) * 64 + lane;
 				if (q <= m)
 					eo[q] = lead + uint32_t(v[j] - offA);
 			}
 		}
+		PIRE_SCLK(6);   // (tuning) positions into LDS
 		// ---- the lane's strings: equal steps of the key over the 64 lanes
 		const uint32_t keyAll = uint32_t(offZ - offA) + g.lambda * m;   // < 2^32: m <= 1024, the span is checked above
 		const uint32_t perLane = (keyAll + 63) / 64;                    // >= 1: m >= 1
@@ -337,6 +428,7 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 			}
 			s0 = lo;
 		}
+		PIRE_SCLK(7);   // (tuning) lane search
 		uint32_t s1 = uint32_t(__shfl_down(int(s0), 1));
 		if (lane == 63)
 			s1 = m;
@@ -360,21 +452,55 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		ZeroTile(a);
 		ZeroTile(b);
 		bool walk = false;
+		PIRE_SCLK(2);
 		for (;; iter += 2) {
-			if (!StreamPhase(p, lds, L, eo, lineBase, S, a, b, iter, walk))
+			if (!StreamPhase<START0>(p, lds, L, eo, lineBase, S, a, b, iter, walk))
 				break;
 			walk = true;
-			if (!StreamPhase(p, lds, L, eo, lineBase, S, b, a, iter + 1, true))
+			if (!StreamPhase<START0>(p, lds, L, eo, lineBase, S, b, a, iter + 1, true))
 				break;
 		}
-		// ---- the sub-task's results: End(), StateIndex, Final and the counters, 64 strings at a time
-		for (uint32_t base = 0; base < m; base += 64) {
-			const uint32_t q = base + lane;
-			const bool act = q < m;
-			const uint32_t st = act ? eo[q + 1] : 0u;
-			FinishRagged<false>(p, lds, L, finHot, uint32_t(sub + q), act, st);
+		PIRE_SCLK(3);
+		// ---- the sub-task's results: End(), StateIndex, Final and the counters, 4 x 64 strings at a time (the slots and the
+		// end-of-string records of four strings per lane are read before any is used: two dependent LDS reads per string
+		// cost a microsecond per 64 strings one after the other)
+#if defined(PIRE_EXP) && PIRE_EXP == 1   // timing experiment: no flush
+		for (uint32_t base = m; base < m; base += 256) {
+#elif defined(PIRE_EXP) && PIRE_EXP == 2   // timing experiment: the flush 64 strings at a time
+		for (uint32_t base = 0; base < m; base += 64)
+			FinishRagged<false>(p, lds, L, finHot, uint32_t(sub + base + lane), base + lane < m, base + lane < m ? eo[base + lane + 1] : 0u);
+		for (uint32_t base = m; base < m; base += 256) {
+#else
+		for (uint32_t base = 0; base < m; base += 256) {
+#endif
+			u32x4 rec[4];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t q = base + uint32_t(j) * 64 + lane;
+				rec[j] = FinRecordOf(p, finHot, q < m, q < m ? eo[q + 1] : 0u);
+			}
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const uint32_t q = base + uint32_t(j) * 64 + lane;
+				if (base + uint32_t(j) * 64 < m)
+					FinishWith<false>(p, lds, L, uint32_t(sub + q), q < m, rec[j]);
+			}
 		}
 	}
+#ifdef PIRE_HIP_TUNING
+	if (p.stamps && gw < K) {
+		PIRE_SCLK(4);
+		if ((threadIdx.x & 63) == 0) {
+			for (int k = 0; k < 5; ++k)
+				atomicAdd(&p.stamps[k], sclk[k]);
+			atomicAdd(&p.stamps[5], 1ull);
+			atomicAdd(&p.stamps[6], (unsigned long long)(iter));
+			atomicAdd(&p.stamps[7], wall_clock64() - sclkStart);
+			for (int k = 5; k < 8; ++k)
+				atomicAdd(&p.stamps[4 + k], sclk[k]);
+		}
+	}
+#endif
 	FlushCounts(p, lds, L);
 }
 
@@ -393,12 +519,18 @@ bool StreamEligible(const ScanParams& p, uint64_t totalBytesHint)
 		return false;
 	if (variant == 2)
 		return true;
-	// strings much longer than a lane's share of the batch leave most lanes without one: the ragged kernel, which deals
-	// single strings out, is the better one there.  With device offsets the host does not know the lengths (hint ~0).
-	if (totalBytesHint != ~0ull && totalBytesHint / p.n > 1024)
-		return false;
-	return p.n >= 16384;
+	// The stream kernel's fixed part (two searches, the table, the first lines: ~75 us from launch to the first byte
+	// walked, against ~50 for the ragged kernel) pays from ~190 MB of URL-sized text on (T = 75 us + bytes / 4.5 TB/s
+	// against 50 us + bytes / 2.8 TB/s, profiles/r04_ragged_cases.log); on long strings the two are even.  With device
+	// offsets the host does not know the bytes (hint ~0): a million strings stand for them.
+	if (totalBytesHint != ~0ull)
+		return totalBytesHint >= (160ull << 20);
+	return p.n >= (1ull << 20);
 }
+
+#ifdef PIRE_HIP_TUNING
+static unsigned long long* g_streamClockBuf = nullptr;
+#endif
 
 int LaunchStream(const ScanParams& p0, hipStream_t stream)
 {
@@ -411,19 +543,63 @@ int LaunchStream(const ScanParams& p0, hipStream_t stream)
 		return rc;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
 	const uint32_t ldsBytes = L.total + kRaggedFinBytes + kStreamWaves * kStreamStageWords * 4;
-	hipError_t e = SetDynamicLds(reinterpret_cast<const void*>(ScanStreamKernel), ldsBytes);
+	const bool start0 = p.startPerm == 0;
+	hipError_t e = SetDynamicLds(start0 ? reinterpret_cast<const void*>(ScanStreamKernel<true>) : reinterpret_cast<const void*>(ScanStreamKernel<false>),
+	                             ldsBytes);
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	StreamGeom g;
-	g.lambda = 4;   // a boundary costs the wave a few lane-steps' worth of instructions; what matters is that keys stay distinct among empty strings
+	g.lambda = 16;   // a boundary costs the wave a few lane-steps' worth of instructions (1 / 16 / 64 measured: 16 by a hair); what matters is that keys stay distinct among empty strings
 	g.minTaskUnits = 64 * 256;
 	// every CU (the kernel starts as many of a block's waves as the batch has work for, see perBlock there); the host
 	// cannot size the grid by bytes: with device offsets it does not know them
 	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), p.n / 64));
-	NoteKernel("stream", "pirehip::ScanStreamKernel");
-	hipLaunchKernelGGL(ScanStreamKernel, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+	NoteKernel("stream", start0 ? "pirehip::ScanStreamKernel<start0>" : "pirehip::ScanStreamKernel<any start>");
+#ifdef PIRE_HIP_TUNING
+	// stage clocks: accumulated over launches (no synchronisation here: a drained GPU drops its clocks and the stamps
+	// would describe another machine); pire_hip_debug_stream_clocks() reads and clears them
+	p.stamps = nullptr;
+	if (getenv("PIRE_HIP_DEBUG_STREAM_CLOCKS")) {
+		if (!g_streamClockBuf) {
+			(void)hipMalloc(reinterpret_cast<void**>(&g_streamClockBuf), 16 * 8);
+			(void)hipMemset(g_streamClockBuf, 0, 16 * 8);
+		}
+		p.stamps = g_streamClockBuf;
+	}
+	if (const char* lam = getenv("PIRE_HIP_STREAM_LAMBDA"))
+		g.lambda = uint32_t(std::max(1, atoi(lam)));
+#endif
+	if (start0)
+		hipLaunchKernelGGL(ScanStreamKernel<true>, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+	else
+		hipLaunchKernelGGL(ScanStreamKernel<false>, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
 	e = hipGetLastError();
 	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "stream kernel launch");
 }
 
 }  // namespace pirehip
+
+#ifdef PIRE_HIP_TUNING
+// tuning build only: the stage clocks accumulated since the last call -- us per wave: search, table copy, positions + lane
+// search, window loop, flush, whole wave; then phases per wave and the number of waves.  Drains the device.
+extern "C" int pire_hip_debug_stream_clocks(double* out8)
+{
+	using namespace pirehip;
+	if (!g_streamClockBuf)
+		return -1;
+	(void)hipDeviceSynchronize();
+	unsigned long long c[16];
+	(void)hipMemcpy(c, g_streamClockBuf, sizeof c, hipMemcpyDeviceToHost);
+	(void)hipMemset(g_streamClockBuf, 0, 16 * 8);
+	const double w = double(c[5] ? c[5] : 1);
+	for (int k = 0; k < 5; ++k)
+		out8[k] = c[k] / w / 100.0;
+	out8[5] = c[7] / w / 100.0;
+	out8[6] = double(c[6]) / w;
+	out8[7] = w;
+	fprintf(stderr, "pire_hip stream clocks, inside 'positions + lane search' (us per wave): [flush of the previous sub-task +] the two end "
+	        "offsets %.2f | positions into LDS %.2f | lane search %.2f | (rest: shuffles, zeroing the line registers)\n", c[9] / w / 100.0,
+	        c[10] / w / 100.0, c[11] / w / 100.0);
+	return 0;
+}
+#endif

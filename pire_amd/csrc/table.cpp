@@ -262,6 +262,18 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	t.hotFinalLo = t.hotDeadLo;
 	while (t.hotFinalLo < t.hot && rankOf(order[t.hotFinalLo]) == 1)
 		++t.hotFinalLo;
+	// Dense id 0 = the state strings start in with Begin() (Initialize(), then Step(BeginMark): run.h:375) whenever that
+	// state is among the plain dense rows -- any order inside the group is as good as any other, and the stream kernel
+	// restarts a lane's walk at a string boundary by selecting the CONSTANT 0 as the row byte of the lookup address
+	// (v_perm_b32 selector 0x0c), which takes the restart off the dependent chain (stream.hip StepChunkB).
+	{
+		const uint32_t begin = t.next[size_t(t.initial) * C + t.cls[kBeginMark]];
+		for (uint32_t i = 0; i < t.hotDeadLo; ++i)
+			if (order[i] == begin) {
+				std::swap(order[0], order[i]);
+				break;
+			}
+	}
 	t.compact = GetConfig().no_compact ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
 	t.origOfPerm = order;
 	t.permOfOrig.assign(N, 0);

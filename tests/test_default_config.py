@@ -16,6 +16,14 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(scope="module")
+def pa():
+    import pire_amd
+
+    assert pire_amd.device_count() > 0, "GPU tests need a HIP device; the library has no CPU fallback"
+    return pire_amd
+
+
 def _table(pa, cfg, name, min_traps=8):
     big = [b for b in H.big_sets() if b["name"] == name][0]
     blob = H.load_blob(big["blob"])
@@ -57,7 +65,8 @@ def test_host_entry_points_under_the_default_policy(pa, cfg, name):
         assert (t.suffix(text, offs, True, True, False) == o.suffix(text, offs, True, True, False)).all()
         hi, hf, hr = t.run_half_final(text, offs)
         assert (hi == want_hf[0]).all() and (hf == want_hf[1]).all() and (hr == want_hf[2]).all(), rep
-    assert t.refresh_info().adaptations >= 1   # it did adapt along the way
+    if name == "set_a":   # (set_d's walks stay inside the know-nothing prior's rows on this text: nothing to adapt to)
+        assert t.refresh_info().adaptations >= 1   # it did adapt along the way
 
 
 def test_every_host_entry_point_while_the_table_adapts_on_other_threads(pa, cfg):
@@ -128,3 +137,63 @@ def test_every_host_entry_point_while_the_table_adapts_on_other_threads(pa, cfg)
         th.join()
     assert not errors, errors[:5]
     assert t.refresh_info().adaptations >= 1
+
+
+def test_scans_while_another_thread_calls_adapt(pa, cfg):
+    """pire_hip_table_adapt() itself, called from a fifth thread while four threads scan.  Rounds 1-3
+    documented that as "must not run concurrently": an adaptation frees the images, and a scan could be between copying
+    their pointers and launching.  Now every entry point holds the table's lock shared until its kernels are enqueued
+    (internal.h TableUse) and adapt() takes it exclusively and drains the devices before it frees anything: legal, and
+    every result must still equal the oracle's."""
+    big, t, o = _table(pa, cfg, "set_a", min_traps=1 << 30)   # no automatic adaptation: the fifth thread does it
+    rng = np.random.RandomState(21)
+    alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet"
+    witnesses = [bytes.fromhex(h) for h in big["witnesses_hex"]]
+    jobs = []
+    for k in range(4):
+        strings = H.random_strings(rng, 1500, 220, alphabet)
+        for w in witnesses:
+            for j in rng.randint(0, len(strings), size=20):
+                strings[j] = strings[j][: len(strings[j]) // 2] + w
+        tx, ofs = H.pack(strings)
+        jobs.append((k, tx, ofs, o.run(tx, ofs, threads=2), o.prefix(tx, ofs, True, True, True), o.run_half_final(tx, ofs)))
+    errors, stop = [], threading.Event()
+
+    def scanner(job):
+        k, tx, ofs, want, want_p, want_hf = job
+        try:
+            for rep in range(12):
+                if k % 2 == 0:
+                    got = t.run(tx, ofs)
+                    ok = (got[0] == want[0]).all() and (got[1] == want[1]).all()
+                elif k == 1:
+                    ok = (t.prefix(tx, ofs, True, True, True) == want_p).all()
+                else:
+                    got = t.run_half_final(tx, ofs)
+                    ok = all((g == w).all() for g, w in zip(got, want_hf))
+                if not ok:
+                    errors.append((k, rep))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    adapts = [0]
+
+    def adapter():
+        try:
+            while not stop.is_set():
+                t.adapt()
+                adapts[0] += 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(("adapt", repr(e)))
+
+    threads = [threading.Thread(target=scanner, args=(j,)) for j in jobs]
+    ad = threading.Thread(target=adapter)
+    ad.start()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    stop.set()
+    ad.join()
+    assert not errors, errors[:5]
+    assert adapts[0] >= 3

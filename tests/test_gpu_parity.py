@@ -259,7 +259,8 @@ def test_stream_kernel_vs_oracle(pa, torch_cuda, name, kind, n, lead, cfg):
 
 
 def test_stream_kernel_is_the_default_for_large_offset_batches(pa, torch_cuda, cfg):
-    """Routing: offsets on the device, many strings -> stream; few -> ragged; pire_hip_config.ragged_variant = 1 -> ragged."""
+    """Routing: offsets on the device and a million strings -> stream; fewer -> ragged; pire_hip_config.ragged_variant = 1
+    -> ragged; host offsets: by the bytes the host then knows."""
     from pire_amd import binding as pb
 
     torch = torch_cuda
@@ -267,8 +268,8 @@ def test_stream_kernel_is_the_default_for_large_offset_batches(pa, torch_cuda, c
     blob = H.load_blob(big["blob"])
     t, o = pa.Table(blob), ob.OracleScanner(blob)
     rng = np.random.RandomState(11)
-    for n, want in ((20000, "stream"), (3000, "ragged")):
-        ln = rng.randint(10, 300, size=n).astype(np.uint64)
+    for n, want in (((1 << 20) + 5, "stream"), (3000, "ragged")):
+        ln = rng.randint(0, 40, size=n).astype(np.uint64)
         offs = np.zeros(n + 1, dtype=np.uint64)
         offs[1:] = np.cumsum(ln)
         text = rng.randint(32, 127, size=int(offs[-1])).astype(np.uint8)
@@ -282,6 +283,10 @@ def test_stream_kernel_is_the_default_for_large_offset_batches(pa, torch_cuda, c
         assert pb.last_kernel() == "ragged"
         assert (gi == oi).all() and (gf == of).all()
         cfg.set(ragged_variant=0)
+        # the host-pointer form knows the bytes: 20 MB of text is the ragged kernel's whatever the string count
+        gi, gf = t.run(text, offs)
+        assert pb.last_kernel() == "ragged"
+        assert (gi == oi).all() and (gf == of).all()
 
 
 def test_ragged_kernel_offsets_not_from_zero(pa, torch_cuda):

@@ -17,6 +17,7 @@ CASES = {  # name: (lo, hi, log2 strings, multiplier)
 }
 case = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+no_out = bool(__import__("os").environ.get("NO_OUT"))
 flags = 3 | (pb.FLAG_GENERIC if len(sys.argv) > 3 and sys.argv[3] == "generic" else 0)
 lo, hi, lg, mul = CASES[case]
 big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
@@ -36,7 +37,7 @@ doffs = torch.as_tensor(offs.astype(np.int64), device="cuda")
 idx = torch.empty(m, dtype=torch.int32, device="cuda")
 fin = torch.empty(m, dtype=torch.uint8, device="cuda")
 def launch():
-    t.run_device(buf.data_ptr(), doffs.data_ptr(), m, flags, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
+    t.run_device(buf.data_ptr(), doffs.data_ptr(), m, flags, 0 if no_out else idx.data_ptr(), 0 if no_out else fin.data_ptr(), 0, 0, stream)
 
 
 # two adaptation rounds from the batch itself (the estimates are remembered and settle), then the GPU's
@@ -54,6 +55,14 @@ for a, b in ev:
     launch()
     b.record()
 torch.cuda.synchronize()
+try:   # tuning build (PIRE_HIP_LIB=tools/ab/libpire_hip_tuning.so PIRE_HIP_DEBUG_STREAM_CLOCKS=1): the stream kernel's stage clocks
+    import ctypes as C
+    out = (C.c_double * 8)()
+    if pb.lib().pire_hip_debug_stream_clocks(out) == 0:
+        print("stream clocks over the settled launches, us per wave: search %.2f | table copy %.2f | positions + lane search %.2f | "
+              "window loop %.2f | flush %.2f | whole wave %.2f ; %.1f phases per wave, %d wave-launches" % (*out[:7], int(out[7])))
+except AttributeError:
+    pass
 ts = [a.elapsed_time(b) for a, b in ev]
 ch = t.adapt()
 print("after the timed runs: adapt changed", ch, "rows; trap samples seen", t.refresh_info().last_trap_samples)

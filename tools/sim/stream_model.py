@@ -14,7 +14,7 @@ import numpy as np
 
 M32 = 0xFFFFFFFF
 INF = 0xFFFFFFFF
-MAXS = 1024
+MAXS = 1280
 
 
 def u32(x):
@@ -60,7 +60,7 @@ class Lane:
     __slots__ = ("wpos", "E", "laneEnd", "dataEnd", "nxt", "sEnd", "hs", "cold", "live")
 
 
-def run_model(tab, text, offs, text_base=0, lam=16, min_task_units=64 * 256, total_waves=8, check_reads=True):
+def run_model(tab, text, offs, text_base=0, lam=4, min_task_units=64 * 256, total_waves=8, check_reads=True):
     """offs: uint64 array [n+1]; text: the bytes at absolute addresses text_base + offset.  Returns end states."""
     n = len(offs) - 1
     out = np.full(n, -1, dtype=np.int64)
@@ -102,8 +102,11 @@ def run_model(tab, text, offs, text_base=0, lam=16, min_task_units=64 * 256, tot
         if gw == K - 1:
             i1 = n
         sub = i0
+        task_strings = i1 - i0
+        sub_tasks = (task_strings + MAXS - 1) // MAXS
+        sub_strings = (task_strings + sub_tasks - 1) // sub_tasks if sub_tasks else 0
         while sub < i1:
-            m = min(MAXS, i1 - sub)
+            m = min(sub_strings, i1 - sub)
             offA, offZ = int(offs[sub]), int(offs[sub + m])
             first_byte = text_base + offA
             line_base = first_byte & ~127
@@ -238,7 +241,7 @@ def run_model(tab, text, offs, text_base=0, lam=16, min_task_units=64 * 256, tot
             for q in range(m):
                 assert out[sub + q] == -1, "a string was finished twice"
                 out[sub + q] = eo[q + 1]
-            sub += MAXS
+            sub += sub_strings
     return out, fetched, (line_lo, line_hi)
 
 
