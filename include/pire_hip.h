@@ -82,8 +82,10 @@ typedef struct pire_hip_table pire_hip_table;
 typedef struct pire_hip_config {
 	uint32_t size;
 	/* fixed-length records (pire_hip_run_strided) */
-	uint32_t tiled_variant;        /* 0 the shipped kernel; 2 without `nt`; 20 waves not kept in step; 22 the transpose */
-	                               /* of the next tile hidden in the walk; 1 bank-rotated rows: A/B measurements, same results */
+	uint32_t tiled_variant;        /* 0 the shipped kernel; 23 dense rows with rotated columns (LDS bank = byte & 63; no  */
+	                               /* gain measured, round 4); 2 without `nt`; 20 waves not kept in step; 22 the transpose */
+	                               /* of the next tile hidden in the walk; 1 rows 260 bytes apart: A/B measurements, same  */
+	                               /* results                                                                               */
 	uint32_t checked;              /* 1: the checked kernel build, see pire_hip_table_check_failures()                 */
 	/* tables (applies to tables created / glued afterwards) */
 	uint32_t no_compact;           /* 1: no compact LDS tier behind the dense rows                                      */

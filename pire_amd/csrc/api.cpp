@@ -176,6 +176,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->workBase = d.workCounter;
 	p->workDevice = d.device >= 0 && d.device < kMaxDevices ? d.device : 0;
 	p->hotRows = d.hotRows;
+	p->hotRowsRot = d.hotRowsRot;
+	p->topShare = h.topShare;
 	p->hotFlags = d.hotFlags;
 	p->cls = d.cls;
 	p->nextPerm = d.nextPerm;

@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t SlowStep(const ScanParams& p, const uint8_t*
                                              uint32_t st, uint32_t byte)
 {
 	if (st < p.hot) {
-		const uint32_t e = lds[st * L.pitch + byte];
+		const uint32_t e = lds[st * L.pitch + (L.rot2 ? RotColumn(byte) : byte)];
 		if (e != p.hot)
 			return e;
 	}
@@ -412,7 +412,9 @@ __device__ __forceinline__ void StepChunk(const ScanParams& p, const uint8_t* ld
 	const uint32_t hs0 = hs;
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
-		const uint32_t x = v[w];
+		uint32_t x = v[w];
+		if (ROT == 2)   // rotated columns: every byte of the word rotated left by 2 bits (3 VALU per 4 bytes, off the chain)
+			x = ((x << 2) & 0xFCFCFCFCu) | ((x >> 6) & 0x03030303u);
 		if (ROT == 1) {
 			// rows are 65 dwords apart, so row r is rotated by r banks: lanes in different states reading the same
 			// byte>>2 no longer hit the same bank.  The byte is extracted off the dependent chain; the chain

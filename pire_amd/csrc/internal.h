@@ -49,7 +49,12 @@ struct LdsLayout {
 	uint32_t histOff;      // 256 u32: sampled visits of hot ids (feeds pire_hip_table_adapt)
 	uint32_t progOff;      // u32: tiles walked by the waves of the block (tiled kernel: keeps them in step)
 	uint32_t total;
+	uint32_t rot2;         // the dense rows' columns are in ROTATED byte order (column of byte b = rotl8(b, 2)): tiled kernel variant
 };
+
+// Column of input byte b in a dense row whose columns are rotated (LdsLayout::rot2): the LDS bank of a lookup is then
+// b & 63 instead of (b >> 2) & 63 -- printable text spreads over all 64 banks instead of 24.
+__host__ __device__ inline uint32_t RotColumn(uint32_t b) { return ((b << 2) | (b >> 6)) & 0xFFu; }
 
 constexpr uint32_t kRotPitch = 260;
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
@@ -78,6 +83,7 @@ __host__ __device__ inline LdsLayout MakeLayout(uint32_t hot, uint32_t regexps, 
 	l.histOff = l.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
 	l.progOff = l.histOff + 1024;   // 16 B: the tiled kernel's block-wide progress counter
 	l.total = l.progOff + 16;
+	l.rot2 = 0;
 	return l;
 }
 
@@ -121,6 +127,7 @@ struct HostTable {
 	uint32_t hotFinalLo = 0;          // hot perm ids >= this are Final (the hot set is ordered non-final first)
 	uint32_t hotDeadLo = 0;           // hot perm ids in [hotDeadLo, hotFinalLo) are Dead (ordered plain, Dead, Final)
 	float deadShare = 0, finalShare = 0;   // share of the byte model's visits that fall on Dead / Final states
+	float topShare = 1;               // share of the ranking's mass on its most visited state (1 = all lanes in one row)
 	// steps (text bytes only, capped at 255) from every state to the nearest Final / Final-or-Dead state: the ragged
 	// kernel with actions skips the exact re-walk of a trapped chunk that cannot reach one (table.cpp EnsureActDist)
 	std::vector<uint8_t> distFinal, distFlagged;   // [states], reference numbering; empty until first needed
@@ -146,6 +153,7 @@ struct FinRec {
 struct DeviceTable {
 	int device = -1;
 	uint8_t* hotRows = nullptr;       // [(hot+1)*256]
+	uint8_t* hotRowsRot = nullptr;    // the same rows with their columns in rotated byte order (RotColumn)
 	uint8_t* hotFlags = nullptr;      // [256]
 	uint16_t* cls = nullptr;          // [264]
 	uint32_t* nextPerm = nullptr;     // [states*letters], perm ids in, perm ids out
@@ -231,6 +239,8 @@ namespace pirehip {
 struct ScanParams {
 	// table
 	const uint8_t* hotRows;
+	const uint8_t* hotRowsRot;   // host side only (LaunchTiled swaps it in for the rotated-column kernel)
+	float topShare;              // host side only: share of the walk's steps the most visited state carries (ranking's estimate)
 	const uint8_t* hotFlags;
 	const uint16_t* cls;
 	const uint32_t* nextPerm;

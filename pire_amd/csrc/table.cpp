@@ -245,6 +245,14 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	std::vector<uint32_t> order(N);
 	std::iota(order.begin(), order.end(), 0u);
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return score[a] > score[b]; });
+	{
+		// how concentrated the traffic is: lanes in the SAME state that read the same dword of its row are served together
+		// by the LDS, lanes in different states collide in the bank (byte >> 2) & 63
+		double total = 0;
+		for (uint32_t i = 0; i < N; ++i)
+			total += score[i] > 0 ? score[i] : 0;
+		t.topShare = total > 0 && N ? float((score[order[0]] > 0 ? score[order[0]] : 0) / total) : 1.0f;
+	}
 
 	t.hot = std::min<uint32_t>(N, kMaxHotRows - 1);
 #ifdef PIRE_HIP_TUNING
@@ -643,7 +651,7 @@ void FreeDeviceTable(DeviceTable* d)
 {
 	if (d->device < 0)
 		return;
-	void* ptrs[] = {d->hotRows, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
+	void* ptrs[] = {d->hotRows, d->hotRowsRot, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
 	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm,
 	                d->distFinalPerm, d->distFlaggedPerm};
@@ -697,7 +705,12 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 	}
 	DeviceTable d;
 	int rc;
-	if ((rc = Put(&d.hotRows, h.hotRows, &d.bytes)) || (rc = Put(&d.hotFlags, h.hotFlags, &d.bytes)) ||
+	std::vector<uint8_t> rowsRot(h.hotRows.size());
+	for (size_t r = 0; r < h.hotRows.size() / 256; ++r)
+		for (uint32_t b = 0; b < 256; ++b)
+			rowsRot[r * 256 + RotColumn(b)] = h.hotRows[r * 256 + b];
+	if ((rc = Put(&d.hotRows, h.hotRows, &d.bytes)) || (rc = Put(&d.hotRowsRot, rowsRot, &d.bytes)) ||
+	    (rc = Put(&d.hotFlags, h.hotFlags, &d.bytes)) ||
 	    (rc = Put(&d.cls, h.cls, &d.bytes)) || (rc = Put(&d.nextPerm, nextPerm, &d.bytes)) ||
 	    (rc = Put(&d.flagsPerm, flagsPerm, &d.bytes)) || (rc = Put(&d.origOfPerm, h.origOfPerm, &d.bytes)) ||
 	    (rc = Put(&d.permOfOrig, h.permOfOrig, &d.bytes))) {

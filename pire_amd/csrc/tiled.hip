@@ -182,11 +182,13 @@ template <int WAVES, int NBUF, bool NT, int MINW, int ROT, bool CHECKED = false,
 __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p)
 {
 	static_assert(!SHADOW || (ROT == 0 && !CHECKED), "the shadowed transpose exists for the shipped layout only");
+	static_assert(ROT != 2 || !CHECKED, "rotated columns: shipped form only");
 	// Depth 2 only: with three slots hipcc (ROCm 7.2) spills tile registers to scratch WHILE their loads are in
 	// flight (profiles/ + DESIGN.md section 6) -- silently wrong data.  tests/test_build_audit.py pins "no scratch".
 	static_assert(NBUF == 2, "ring depth");
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT == 1 ? kRotPitch : 256u, CompactBytes(p));
+	LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, ROT == 1 ? kRotPitch : 256u, CompactBytes(p));
+	L.rot2 = ROT == 2 ? 1u : 0u;   // the launcher handed over the rows with rotated columns (ScanParams::hotRowsRot)
 
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -452,7 +454,18 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		return rc;
 	// Variant knob for A/B measurements (DESIGN.md section 5 ladder); every variant returns the same results.
 	const pire_hip_config cfg = GetConfig();
-	const int variant = cfg.checked ? 4 : int(cfg.tiled_variant);
+	int variant = cfg.checked ? 4 : int(cfg.tiled_variant);
+	// Tables whose traffic is spread over many states (no state carries 60 % of the steps: set_d 0.55 against set_a's 0.76,
+	// set_b's 0.68, a single pattern's 0.87) are bound by LDS bank conflicts, not by the loads (PMC: the LDS is busy 98 % of
+	// set_d's kernel, 5.6 cycles per lookup against 4.8, profiles/r04_set_d_pmc.txt).  Variant 23 gives them rows with
+	// ROTATED columns -- bank = byte & 63 instead of (byte >> 2) & 63, simulated 5.9 -> 4.65 cycles -- at 3 more VALU per 4
+	// bytes.  Measured (profiles/r04_rotated_columns_ab.log, two alternating rounds on one box): set_d 0.7367 / 0.7273 ms
+	// against 0.7325 / 0.7240 with the plain rows, every other table 3-5 % slower -- the walk is as sensitive to VALU
+	// issue as to the LDS, what round 1 found for set_a holds for the spread-out table too.  NOT selected by itself; kept
+	// as an A/B variant (23).  With its lanes in ~11 different rows a half-wave's 32 lookups are 32 balls in 64 banks
+	// (expected fullest bank ~3 -> ~6 cycles per wave lookup): set_d already sits at that floor of a 64-lane byte gather.
+	if (variant == 24)
+		variant = 0;
 	ScanParams q = p;
 #ifdef PIRE_HIP_TUNING
 	q.stamps = nullptr;
@@ -504,6 +517,15 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	case 4:   // also chosen by PIRE_HIP_CHECKED=1
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,checked>");
 		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream);
+		break;
+	case 23:
+		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,rotated columns>");
+		q.hotRows = p.hotRowsRot ? p.hotRowsRot : p.hotRows;
+		if (!p.hotRowsRot) {
+			rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream);
+			break;
+		}
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 2, false, true>, q, 1024, L256.total, stream);
 		break;
 	case 22:
 		// The transpose of tile t+1 in the shadows of the last 24 lookups of tile t (PhaseShadow).  Measured in round 3

@@ -326,6 +326,35 @@ def test_tiled_kernel_shapes_vs_oracle(pa, torch_cuda, name, n, length):
     assert (cnt == expected_counts(o, oi, of)).all()
 
 
+@pytest.mark.parametrize("name", ["set_a", "set_d", "set_b", "c2_single"])
+def test_tiled_kernel_with_rotated_columns(pa, torch_cuda, name, cfg):
+    """pire_hip_config.tiled_variant = 23: the dense rows with their columns in rotated byte order (bank = byte & 63, the
+    variant tables with spread-out traffic take by themselves) -- fast path, traps through the compact tier
+    and the full table (text that leaves the dense rows), tails shorter than a tile -- against the oracle and against the
+    plain rows (24)."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    big = [b for b in H.big_sets() if b["name"] == name][0]
+    blob = H.load_blob(big["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(23)
+    for n, length in ((64 * 9 + 3, 1024), (256, 128 * 3 + 16), (64, 4096 + 48)):
+        data = ob.corpus_fill(n + length, 0, n, length, H.plants_for(big), threads=4)
+        # raw bytes into a third of the strings: the walk leaves the dense rows
+        k = rng.randint(0, n, size=n // 3)
+        data[k, : length // 2] = rng.randint(0, 256, size=(len(k), length // 2), dtype=np.uint8)
+        offs = np.arange(n + 1, dtype=np.uint64) * length
+        oi, of = o.run(data.reshape(-1), offs, threads=4)
+        d = torch.as_tensor(data, device="cuda")
+        for variant, symbol in ((23, "rotated columns"), (24, "16,2,nt,5>")):
+            cfg.set(tiled_variant=variant)
+            gi, gf, cnt = dev_run_strided(torch, t, d)
+            assert symbol in pb.last_kernel_symbol(), pb.last_kernel_symbol()
+            assert (gi == oi).all() and (gf == of).all(), (variant, n, length)
+            assert (cnt == expected_counts(o, oi, of)).all()
+
+
 def test_cold_states_are_exact(pa, torch_cuda):
     """Text that drives set_d far outside its 255 dense rows: the trap / exact re-walk path must stay bit-exact."""
     torch = torch_cuda
