@@ -1026,8 +1026,13 @@ try {
 	out->scanner_type = h.scannerType;
 	out->reserved = 0;
 	out->device_bytes = 0;   // all images (one per device the table has run on)
-	for (int k = 0; k < kMaxDevices; ++k)
-		out->device_bytes += t->devs[k].device >= 0 ? t->devs[k].bytes : 0;
+	{
+		// devs[] is written by the first run on a device, under uploadMutex (found by ThreadSanitizer, round 4: this loop
+		// read it under the adaptation lock alone)
+		std::lock_guard<std::mutex> images(const_cast<pire_hip_table*>(t)->uploadMutex);
+		for (int k = 0; k < kMaxDevices; ++k)
+			out->device_bytes += t->devs[k].device >= 0 ? t->devs[k].bytes : 0;
+	}
 	out->adaptations = h.adaptations;
 	out->last_trap_samples = h.lastTrapSamples;
 	out->ref_buf_size = h.refBufSize;

@@ -439,7 +439,8 @@ struct Staging {
 		const size_t bytes = count * sizeof(T);
 		if (s == stream && arenaInputs == arenaUsed)   // inputs only in front of everything else of the arena
 			if (uint8_t* p = Carve(bytes)) {
-				memcpy(arenaPin + (p - arenaDev), host, bytes);
+				if (bytes)   // (an empty input may come with a null pointer: memcpy's arguments are declared non-null, UBSan r4)
+					memcpy(arenaPin + (p - arenaDev), host, bytes);
 				arenaInputs = arenaUsed;
 				*dev = reinterpret_cast<const T*>(p);
 				return PIRE_HIP_OK;

@@ -29,7 +29,7 @@ PY
 echo "== bench, defaults (50 steps after 20)"
 timeout 900 python bench.py --no-cpu 2>&1 | tail -1 > $OUT/bench_n1_defaults.json; cut -c1-200 $OUT/bench_n1_defaults.json
 echo "== rocprofv3 kernel trace + stats of the bench command"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 20 --warmup 5 --no-cpu > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python bench.py --steps 20 --warmup 5 --no-cpu --cold-launches 0 > $OUT/stats.log 2>&1   # (no from-idle leg: the LAST 20 launches of the process are the timed region)
 head -3 $OUT/stats/stats_kernel_stats.csv
 python tools/summarize_trace.py $OUT/stats 20 | tee $OUT/trace_timed_region.txt
 echo "== world of one rank over RCCL; 8 ranks over gloo (launch path)"
