@@ -32,21 +32,9 @@
 //     shorter than 16 bytes, empty strings), is walked again for that lane byte by byte with the exact step
 //     (ExactRest).  Results never depend on which rows are dense, on lambda or on how the batch was cut.
 
-#include "device_common.h"
+#include "stream_common.h"
 
 namespace pirehip {
-
-constexpr uint32_t kStreamMaxStrings = 1280;                    // strings of one sub-task (20 x 64; with the dense rows 155 of the 160 KiB)
-constexpr uint32_t kStreamStageWords = kStreamMaxStrings + 16;  // their positions (m + 1 words) per wave, padded
-constexpr uint32_t kStreamInf = 0xFFFFFFFFu;                    // "no boundary ahead": the lane's strings are over
-constexpr uint32_t kStreamWaves = 16;
-
-struct StreamGeom {
-	uint32_t lambda;         // cost of a string boundary in bytes of walk
-	uint32_t minTaskUnits;   // a wave is not started for less than this much key
-};
-
-typedef __attribute__((address_space(3))) uint32_t* LdsWordPtr;
 
 struct StreamLane {
 	uint32_t wpos;      // start of the current window, relative to the sub-task's line base (multiple of 128)
@@ -249,45 +237,6 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 	return false;
 }
 
-// smallest i in [0, n] with key(i) >= T for two targets at once; key(i) = offsets[i] - off0 + lambda * i is strictly
-// increasing and key(n) >= T (the caller clamps T).  64 probes per round and target: the interval shrinks 64-fold.
-__device__ __forceinline__ void StreamSearch2(const uint64_t* off, uint64_t off0, uint64_t n, uint32_t lambda, uint64_t T0,
-                                              uint64_t T1, uint64_t& r0, uint64_t& r1)
-{
-	const uint32_t lane = threadIdx.x & 63;
-	uint64_t lo[2] = {0, 0}, hi[2] = {n, n};
-	const uint64_t T[2] = {T0, T1};
-	while (lo[0] < hi[0] || lo[1] < hi[1]) {
-		uint64_t pos[2], key[2], step[2];
-#pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			step[j] = (hi[j] - lo[j]) / 64 + 1;
-			pos[j] = lo[j] + uint64_t(lane) * step[j];
-			key[j] = ~0ull;
-			if (pos[j] <= hi[j])
-				key[j] = off[pos[j]] - off0 + uint64_t(lambda) * pos[j];
-		}
-#pragma unroll
-		for (int j = 0; j < 2; ++j) {
-			const unsigned long long ge = __ballot(key[j] >= T[j]);   // monotone: 0...01...1
-			const uint32_t f = ge ? uint32_t(__builtin_ctzll(ge)) : 64u;   // number of probes below the target
-			if (f == 0) {
-				hi[j] = lo[j];
-			} else {
-				const uint64_t lastBelow = lo[j] + uint64_t(f - 1) * step[j];
-				const uint64_t firstAt = lo[j] + uint64_t(f) * step[j];
-				lo[j] = lastBelow + 1;
-				if (f < 64 && firstAt < hi[j])
-					hi[j] = firstAt;
-			}
-			lo[j] = Uniform64(lo[j]);
-			hi[j] = Uniform64(hi[j]);
-		}
-	}
-	r0 = lo[0];
-	r1 = lo[1];
-}
-
 #ifdef PIRE_HIP_TUNING
 // timing experiments (PIRE_HIP_DEBUG_STREAM_CLOCKS): wall-clock (100 MHz) time of a wave per stage, summed over the waves
 // into ScanParams::stamps: 0 search, 1 table copy, 2 positions into LDS + lane search, 3 window loop, 4 flush; 5 = waves,
@@ -315,31 +264,14 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
 	const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-	const uint32_t wavesPerBlock = blockDim.x >> 6;
 	LdsWordPtr eo = reinterpret_cast<LdsWordPtr>(
 		static_cast<uintptr_t>(L.total + kRaggedFinBytes + wave * kStreamStageWords * 4u));
 
 	// ---- this wave's task: strings [i0, i1), found before the table is copied (the searches' round trips overlap the
 	// other waves' part of the copy)
-	const uint64_t off0 = p.offsets[0], offN = p.offsets[p.n];
-	const uint64_t totalKey = (offN - off0) + uint64_t(g.lambda) * p.n;
-	const uint64_t W = uint64_t(gridDim.x) * wavesPerBlock;
-	uint64_t K = totalKey / g.minTaskUnits;
-	K = K < 1 ? 1 : K > W ? W : K;
-	const uint64_t perTask = (totalKey + K - 1) / K;
-	// fewer tasks than waves: every block takes its share of them (ceil(K / blocks) of its waves work), so that a batch
-	// that does not fill the chip still uses every CU's LDS bandwidth instead of the first K / 16 CUs'
-	const uint64_t perBlock = (K + gridDim.x - 1) / gridDim.x;
-	const uint64_t gw = wave < perBlock ? uint64_t(blockIdx.x) * perBlock + wave : K;
-	uint64_t i0 = 0, i1 = 0;
-	if (gw < K) {
-		const uint64_t T0 = gw * perTask, T1 = (gw + 1) * perTask;
-		StreamSearch2(p.offsets, off0, p.n, g.lambda, T0 < totalKey ? T0 : totalKey, T1 < totalKey ? T1 : totalKey, i0, i1);
-		if (gw == K - 1)
-			i1 = p.n;
-	}
-	i0 = Uniform64(i0);   // wave-uniform by construction: keep them (and what is derived from them) in scalar registers
-	i1 = Uniform64(i1);
+	uint64_t i0, i1;
+	const bool hasTask = StreamTaskOfWave(p.offsets, p.n, g, i0, i1);
+	(void)hasTask;
 	PIRE_SCLK(0);
 	{
 		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
@@ -351,34 +283,18 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
 	uint32_t iter = 0;
-	// sub-tasks of equal size (a task of 1 030 strings is not one of 1 024 and one of 6: the second would pay a whole
-	// pipeline start for six strings, and the launch ends with its slowest wave)
-	const uint64_t taskStrings = i1 - i0;
-	const uint64_t subTasks = (taskStrings + kStreamMaxStrings - 1) / kStreamMaxStrings;
-	const uint32_t subStrings = subTasks ? uint32_t((taskStrings + subTasks - 1) / subTasks) : 0;
+	const uint32_t subStrings = StreamSubStrings(i1 - i0);
 	for (uint64_t sub = i0; sub < i1; sub += subStrings) {
 		// (what the set-up derives from the lane number -- a dozen addresses and positions -- is cheap to compute and was
 		// hoisted out of this loop and carried across the window loop through scratch: opaque here, so it stays inside)
 		uint32_t lane = threadIdx.x & 63;
 		asm volatile("" : "+v"(lane));
 		const uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(i1 - sub < subStrings ? i1 - sub : subStrings)));
-		// ---- the sub-task's string positions into LDS, relative to the line that holds its first byte.  ONE round trip:
-		// the m + 1 offsets and the two the conversion needs are all requested before any is looked at (at kernel start
-		// every wave asks at once and a round trip is 4 us: six of them in a row were a sixth of the URL batch's time,
-		// profiles/r04_stream_stage_clocks.log)
-		constexpr int kLoads = 11;   // per batch: two batches cover kStreamMaxStrings + 1 positions (all 21 at once: 42 registers)
-		uint64_t v[kLoads];
-#pragma unroll
-		for (int j = 0; j < kLoads; ++j) {
-			const uint32_t q = uint32_t(j) * 64 + lane;
-			v[j] = p.offsets[sub + (q <= m ? q : m)];   // (clamped, not skipped: an unconditional load can be issued at once)
-		}
-		const uint64_t offA = p.offsets[sub], offZ = p.offsets[sub + m];
-		PIRE_SCLK(5);   // (tuning) the offsets of the sub-task
-		const uint64_t firstByte = textBase + offA;
-		const uint64_t lineBase = Uniform64(firstByte & ~uint64_t(127));
-		const uint32_t lead = uint32_t(firstByte) & 127u;
-		if (offZ - offA >= 0xFFFF0000ull) {
+		uint64_t lineBase;
+		uint32_t lead, spanBytes;
+		const bool staged = StreamStage(p.offsets, sub, m, textBase, eo, lane, lineBase, lead, spanBytes);
+		PIRE_SCLK(5);   // (tuning) positions into LDS
+		if (!staged) {
 			// positions that do not fit 32 bits (a string of 4 GiB among short ones): every lane takes whole strings and
 			// walks them byte by byte from memory
 			for (uint32_t base = 0; base < m; base += 64) {
@@ -391,47 +307,9 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 			}
 			continue;
 		}
-#pragma unroll
-		for (int j = 0; j < kLoads; ++j) {
-			const uint32_t q = uint32_t(j) * 64 + lane;
-			if (q <= m)
-				eo[q] = lead + uint32_t(v[j] - offA);
-		}
-		if (m >= kLoads * 64) {   // the second batch (sub-tasks of more than 703 strings)
-#pragma unroll
-			for (int j = 0; j < kLoads; ++j) {
-				const uint32_t q = uint32_t(kLoads + j) * 64 + lane;
-				v[j] = p.offsets[sub + (q <= m ? q : m)];
-			}
-#pragma unroll
-			for (int j = 0; j < kLoads; ++j) {
-				const uint32_t q = uint32_t(kLoads + j) * 64 + lane;
-				if (q <= m)
-					eo[q] = lead + uint32_t(v[j] - offA);
-			}
-		}
-		PIRE_SCLK(6);   // (tuning) positions into LDS
-		// ---- the lane's strings: equal steps of the key over the 64 lanes
-		const uint32_t keyAll = uint32_t(offZ - offA) + g.lambda * m;   // < 2^32: m <= 1024, the span is checked above
-		const uint32_t perLane = (keyAll + 63) / 64;                    // >= 1: m >= 1
-		uint32_t s0;
-		{
-			const uint32_t target = lane * perLane;
-			uint32_t lo = 0, hi = m;
-#pragma unroll 1
-			for (int it = 0; it < 11; ++it) {   // 2^11 > kStreamMaxStrings + 1 candidates
-				const uint32_t mid = (lo + hi) >> 1;
-				const bool below = lo < hi && (eo[mid] - lead) + g.lambda * mid < target;
-				const bool shrink = lo < hi && !below;
-				lo = below ? mid + 1 : lo;
-				hi = shrink ? mid : hi;
-			}
-			s0 = lo;
-		}
+		uint32_t s0, s1;
+		StreamLaneSplit(eo, m, lead, spanBytes, g.lambda, lane, s0, s1);
 		PIRE_SCLK(7);   // (tuning) lane search
-		uint32_t s1 = uint32_t(__shfl_down(int(s0), 1));
-		if (lane == 63)
-			s1 = m;
 		StreamLane S;
 		S.nxt = s0;
 		S.sEnd = s1;
@@ -488,7 +366,7 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		}
 	}
 #ifdef PIRE_HIP_TUNING
-	if (p.stamps && gw < K) {
+	if (p.stamps && hasTask) {
 		PIRE_SCLK(4);
 		if ((threadIdx.x & 63) == 0) {
 			for (int k = 0; k < 5; ++k)

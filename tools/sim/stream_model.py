@@ -60,7 +60,7 @@ class Lane:
     __slots__ = ("wpos", "E", "laneEnd", "dataEnd", "nxt", "sEnd", "hs", "cold", "live")
 
 
-def run_model(tab, text, offs, text_base=0, lam=4, min_task_units=64 * 256, total_waves=8, check_reads=True):
+def run_model(tab, text, offs, text_base=0, lam=16, min_task_units=64 * 256, total_waves=8, check_reads=True):
     """offs: uint64 array [n+1]; text: the bytes at absolute addresses text_base + offset.  Returns end states."""
     n = len(offs) - 1
     out = np.full(n, -1, dtype=np.int64)
