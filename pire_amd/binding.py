@@ -112,6 +112,7 @@ class Config(C.Structure):
         ("no_length_order", C.c_uint32),
         ("capture_by_length", C.c_uint32),
         ("force_rccl", C.c_uint32),
+        ("counting_variant", C.c_uint32),
     ]
 
 

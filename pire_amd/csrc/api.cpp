@@ -270,6 +270,7 @@ pire_hip_config SeedFromEnvironment()
 	c.no_length_order = EnvU64("PIRE_HIP_NO_LENGTH_ORDER") != 0;
 	c.capture_by_length = EnvU64("PIRE_HIP_CAPTURE_BY_LENGTH") != 0;
 	c.force_rccl = EnvU64("PIRE_HIP_FORCE_RCCL") != 0;
+	c.counting_variant = uint32_t(EnvU64("PIRE_HIP_COUNTING_VARIANT"));
 	return c;
 }
 

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "device_common.h"
 
 namespace pirehip {
 
@@ -293,6 +294,279 @@ __global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
 				}
 			p.outResults[s * p.regexps + r] = c > t ? c : t;   // Result(r), count.h:206
 		}
+	}
+}
+
+// ---- the same walk on whole cache lines, with the step cut to its data flow (round 4) --------------------------------
+// The kernel above runs at 1.05 TB/s whatever the table (one regexp or three, 4 states or 45): it waits for its text.  A
+// lane asks for 16 bytes of its own string at a time, one block ahead of its walk -- 64 lines touched per instruction,
+// each of them eight times, and a round trip to memory that sixteen steps do not cover.  Making the step cheaper alone
+// (entries that are LDS addresses, below) bought 6-10 % (profiles/r04_counting_rows.log).  So:
+//   * the text arrives as in the offset-batch kernels of the Scanner path: per lane one 128-byte LINE per window, fetched by
+//     groups of 8 lanes (IssueTileGroup's pattern: an instruction touches 8 lines, every line once) while the previous
+//     line is walked, transposed in registers (TransposeTile);
+//   * an entry IS the two addresses a step needs: 8 bytes per (state, byte) = { LDS offset of the next state's row,
+//     LDS offset of the action's words }, expanded from the u16 rows while the block copies them.  A step is one v_bfe,
+//     one v_lshl_add (row + byte * 8), one ds_read_b64, one ds_read_b128 of the pending action's words and the eight
+//     packed counter operations: no unpacking, and no branch around the action -- action 0 is a row of zeroes;
+//   * the bytes of a line in front of the string's first or behind its last take a 257th entry of the row, { the row
+//     itself, action 0 }: a step that changes nothing, chosen by an add, a compare and a select.  Windows that lie
+//     inside the strings of all the lanes still at work take a copy of the walk without the three.
+// 2 KB of LDS per state, so one block of 16 waves per CU and tables of up to kCountingRowStates states (counting tables
+// have tens); larger ones keep the kernel above, and so do scanners of more than four regexps (eight and sixteen counter
+// registers: not built).  Same counters, same overflow list, same length order.
+// The line on its way lands in ACCUMULATION registers a0..a31 -- by name: the load instructions write a[4j:4j+3] and
+// LandTile() reads a0..a31, whatever the compiler thinks.  To the compiler they are eight values that the loads define
+// in exactly those registers and LandTile() consumes from exactly those registers ("{a[0:3]}" constraints), alive
+// during the walk: so it keeps its own spills out of them (it uses free accumulation registers as spill space: with
+// clobber lists alone it parked values of the walk in a0..a22, under the loads), and it has no reason to move them --
+// nothing else wants an accumulation register here; tests/test_build_audit.py checks that no instruction but these
+// touches a0..a31.  The first form of this kernel kept the line on its way in a second tile of ordinary registers, as
+// stream.hip and tiled.hip do: a live-range split copied that tile in front of its s_waitcnt, and 57 of 4 096 strings
+// came out wrong, all in the lanes whose loads are issued last (profiles/r04_counting_rows_vmcnt.log).
+// LandTile() waits for the line and reads it into the one ordinary tile: 32 v_accvgpr_read per 128 steps.
+struct AccTile {
+	u32x4 r[8];
+};
+#define PIRE_ACC_LOAD(J, RANGE)                                                                                        \
+	if constexpr (J_ == J)                                                                                            \
+		asm volatile("global_load_dwordx4 " RANGE ", %1, off" : "={" RANGE "}"(acc.r[J]) : "v"(a))
+template <int J_>
+__device__ __forceinline__ void IssueAccGroupOne(AccTile& acc, uint32_t lo, uint32_t hi, uint32_t mine)
+{
+	const uint32_t l = GroupBroadcast<J_>(lo);
+	const uint32_t h = GroupBroadcast<J_>(hi);
+	const uint64_t a = ((uint64_t(h) << 32) | l) + mine;
+	PIRE_ACC_LOAD(0, "a[0:3]");
+	PIRE_ACC_LOAD(1, "a[4:7]");
+	PIRE_ACC_LOAD(2, "a[8:11]");
+	PIRE_ACC_LOAD(3, "a[12:15]");
+	PIRE_ACC_LOAD(4, "a[16:19]");
+	PIRE_ACC_LOAD(5, "a[20:23]");
+	PIRE_ACC_LOAD(6, "a[24:27]");
+	PIRE_ACC_LOAD(7, "a[28:31]");
+}
+#undef PIRE_ACC_LOAD
+
+// IssueTileGroup() (device_common.h) with a0..a31 as the destination: instruction j loads, in every group of 8 lanes, the
+// line of lane 8g+j, lane 8g+c its bytes [16c, 16c+16).
+__device__ __forceinline__ void IssueAccGroup(AccTile& acc, uint64_t src, uint32_t lane)
+{
+	const uint32_t lo = uint32_t(src), hi = uint32_t(src >> 32);
+	const uint32_t mine = (lane & 7u) << 4;
+	IssueAccGroupOne<0>(acc, lo, hi, mine);
+	IssueAccGroupOne<1>(acc, lo, hi, mine);
+	IssueAccGroupOne<2>(acc, lo, hi, mine);
+	IssueAccGroupOne<3>(acc, lo, hi, mine);
+	IssueAccGroupOne<4>(acc, lo, hi, mine);
+	IssueAccGroupOne<5>(acc, lo, hi, mine);
+	IssueAccGroupOne<6>(acc, lo, hi, mine);
+	IssueAccGroupOne<7>(acc, lo, hi, mine);
+}
+
+#define PIRE_ACC_IN                                                                                                    \
+	"{a[0:3]}"(acc.r[0]), "{a[4:7]}"(acc.r[1]), "{a[8:11]}"(acc.r[2]), "{a[12:15]}"(acc.r[3]), "{a[16:19]}"(acc.r[4]),   \
+		"{a[20:23]}"(acc.r[5]), "{a[24:27]}"(acc.r[6]), "{a[28:31]}"(acc.r[7])
+__device__ __forceinline__ void LandTile(const AccTile& acc, u32x4 (&r)[8])
+{
+	uint32_t w[32];
+	asm volatile("s_waitcnt vmcnt(0)\n\t"
+	             "v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\t"
+	             "v_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\t"
+	             "v_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\t"
+	             "v_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15"
+	             : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7]), "=&v"(w[8]),
+	               "=&v"(w[9]), "=&v"(w[10]), "=&v"(w[11]), "=&v"(w[12]), "=&v"(w[13]), "=&v"(w[14]), "=&v"(w[15])
+	             : PIRE_ACC_IN);
+	asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\t"
+	             "v_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\t"
+	             "v_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\t"
+	             "v_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31"
+	             : "=&v"(w[16]), "=&v"(w[17]), "=&v"(w[18]), "=&v"(w[19]), "=&v"(w[20]), "=&v"(w[21]), "=&v"(w[22]), "=&v"(w[23]),
+	               "=&v"(w[24]), "=&v"(w[25]), "=&v"(w[26]), "=&v"(w[27]), "=&v"(w[28]), "=&v"(w[29]), "=&v"(w[30]), "=&v"(w[31])
+	             : PIRE_ACC_IN);
+#pragma unroll
+	for (int q = 0; q < 8; ++q)
+		r[q] = u32x4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+}
+#undef PIRE_ACC_IN
+
+constexpr uint32_t kCountingRowStates = 64;
+constexpr uint32_t kCountingRowPitch = 257 * 8;
+
+template <int NREG, bool ADVANCED>
+__global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+	typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+	// (LDS by absolute address: the dynamic segment starts at 0, this kernel has no static LDS)
+	typedef const __attribute__((address_space(3))) Pair* LdsPair;
+	typedef const __attribute__((address_space(3))) Quad* LdsQuad;
+	const uint32_t sinkRow = p.states * kCountingRowPitch;   // every entry: { the sink row, no action }
+	const uint32_t actBase = ((p.states + 1) * kCountingRowPitch + 15u) & ~15u;
+	for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x)
+		*reinterpret_cast<uint2*>(lds + sinkRow + i * 8u) = uint2{sinkRow, actBase};
+	for (uint32_t i = threadIdx.x; i < p.states * 256; i += blockDim.x) {
+		const uint32_t e = p.dense[i];
+		*reinterpret_cast<uint2*>(lds + (i >> 8) * kCountingRowPitch + (i & 255u) * 8u) =
+			uint2{(e & 0xFFu) * kCountingRowPitch, actBase + (e >> 8) * (8u * NREG)};
+	}
+	for (uint32_t i = threadIdx.x; i < p.states; i += blockDim.x)
+		*reinterpret_cast<uint2*>(lds + i * kCountingRowPitch + 2048u) = uint2{i * kCountingRowPitch, actBase};
+	for (uint32_t i = threadIdx.x; i < 256 * 2 * NREG; i += blockDim.x)
+		reinterpret_cast<uint32_t*>(lds + actBase)[i] = p.actWords[i];
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
+		uint64_t s = 0, b = 0, e = 0;
+		if (k < p.n) {
+			s = p.order ? p.order[k] : k;
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		}
+		const bool ok = k < p.n && e - b <= 65000;
+		if (k < p.n && !ok) {
+			const uint32_t slot = atomicAdd(&p.overflow[0], 1u);
+			p.overflow[1 + slot] = uint32_t(s);
+		}
+		const uint32_t len = ok ? uint32_t(e - b) : 0u;
+		const uint64_t first = reinterpret_cast<uint64_t>(p.text) + b;
+		const uint64_t line0 = first & ~uint64_t(127);
+		const uint32_t lead = uint32_t(first - line0);
+		const uint32_t windows = len ? (lead + len + 127u) >> 7 : 0u;
+		u16x2 cur[NREG], tot[NREG];
+#pragma unroll
+		for (int r = 0; r < NREG; ++r)
+			cur[r] = tot[r] = u16x2{0, 0};
+		uint32_t row = p.initial * kCountingRowPitch, pend = actBase;   // pend: LDS offset of the words of the action not applied yet
+		auto take = [&]() __attribute__((always_inline)) {   // TakeActionImpl: count.h:251-257 (increment, reset) / 287-295 (reset, increment)
+			uint32_t w[2 * NREG];
+			if (NREG == 1) {
+				const Pair q = *reinterpret_cast<LdsPair>(static_cast<uintptr_t>(pend));
+				w[0] = q.x;
+				w[1] = q.y;
+			} else {
+#pragma unroll
+				for (int q4 = 0; q4 < NREG / 2; ++q4) {
+					const Quad q = *reinterpret_cast<LdsQuad>(static_cast<uintptr_t>(pend + 16u * q4));
+					w[4 * q4] = q.x;
+					w[4 * q4 + 1] = q.y;
+					w[4 * q4 + 2] = q.z;
+					w[4 * q4 + 3] = q.w;
+				}
+			}
+			// Between two resets a counter only grows, and the result is max(current, total) (count.h:206): so the largest
+			// value `current` ever has IS the result, and the maximum can be taken at every step instead of under the
+			// reset mask -- three packed operations per register (and-not, add, max) instead of four.  total then is
+			// max(total, current) of count.h plus values it would only have taken in at the next reset.
+#pragma unroll
+			for (int r = 0; r < NREG; ++r) {
+				const uint32_t incBits = w[r], rstBits = w[NREG + r];
+				u16x2 inc, rst;
+				__builtin_memcpy(&inc, &incBits, 4);
+				__builtin_memcpy(&rst, &rstBits, 4);
+				if (!ADVANCED)
+					cur[r] += inc;
+				tot[r] = __builtin_elementwise_max(tot[r], cur[r]);
+				// (the maxima stay a chain: left alone, hipcc reassociates the 128 of a window into a tree and spills
+				// its leaves -- 1.2-2.5 KB of scratch per lane)
+				uint32_t pin;
+				__builtin_memcpy(&pin, &tot[r], 4);
+				asm volatile("" : "+v"(pin));
+				__builtin_memcpy(&tot[r], &pin, 4);
+				cur[r] &= ~rst;
+				if (ADVANCED)
+					cur[r] += inc;
+			}
+		};
+		// as above: the lookup of step i+1 needs only the row of step i, the action of step i is applied under it
+		auto step = [&](uint32_t entryOffset) __attribute__((always_inline)) {
+			const Pair next = *reinterpret_cast<LdsPair>(static_cast<uintptr_t>(row + entryOffset));
+			take();
+			row = next.x;
+			pend = next.y;
+		};
+		auto mark = [&](uint32_t which) {   // BeginMark / EndMark: the u16 entry from global memory, twice per string
+			const uint32_t m = p.denseMarks[(row / kCountingRowPitch) * 2 + which];
+			take();
+			row = (m & 0xFFu) * kCountingRowPitch;
+			pend = actBase + (m >> 8) * (8u * NREG);
+		};
+		if (ok && (p.flags & PIRE_HIP_RUN_BEGIN))
+			mark(0);
+		// Window t of a lane = the line line0 + 128 t.  An iteration lands the line that was on its way (window t), asks
+		// for the next one and walks; the first iteration (t = -1) lands nothing of value and does not walk.
+		u32x4 tile[8];
+		AccTile acc;
+		// (whatever a0..a31 hold: the first iteration lands it and walks nothing)
+		asm volatile("" : "={a[0:3]}"(acc.r[0]), "={a[4:7]}"(acc.r[1]), "={a[8:11]}"(acc.r[2]), "={a[12:15]}"(acc.r[3]),
+		             "={a[16:19]}"(acc.r[4]), "={a[20:23]}"(acc.r[5]), "={a[24:27]}"(acc.r[6]), "={a[28:31]}"(acc.r[7]));
+		for (uint32_t t = ~0u;;) {
+			LandTile(acc, tile);
+			const uint32_t tn = t + 1u;
+			// (lanes without a further line fetch a harmless valid one: the table)
+			IssueAccGroup(acc, tn < windows ? line0 + uint64_t(tn) * 128u : reinterpret_cast<uint64_t>(p.dense), lane);
+			if (t != ~0u) {
+				TransposeTile(tile, lane);
+				const uint32_t at = t * 128u - lead;   // byte j of this window is byte at + j of the string (mod 2^32)
+				const bool inside = t * 128u >= lead && at + 128u <= len;
+				const bool idle = t >= windows;
+				if (__all(inside || idle)) {
+					// every lane's line lies inside its string, or behind it: the walk without the compares.  The lanes
+					// that are done spend it in the sink row (their pending action is applied by the first step).
+					const uint32_t keep = row;
+					row = idle ? sinkRow : row;
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+#pragma unroll
+						for (int w = 0; w < 4; ++w) {
+							const uint32_t x = tile[q][w];
+							step((x & 0xFFu) * 8u);
+							step(((x >> 8) & 0xFFu) * 8u);
+							step(((x >> 16) & 0xFFu) * 8u);
+							step((x >> 24) * 8u);
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					row = idle ? keep : row;
+				} else {
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+#pragma unroll
+						for (int w = 0; w < 4; ++w) {
+							const uint32_t x = tile[q][w];
+							const uint32_t j = 16u * q + 4u * w;
+							step(at + j < len ? (x & 0xFFu) * 8u : 2048u);
+							step(at + j + 1u < len ? ((x >> 8) & 0xFFu) * 8u : 2048u);
+							step(at + j + 2u < len ? ((x >> 16) & 0xFFu) * 8u : 2048u);
+							step(at + j + 3u < len ? (x >> 24) * 8u : 2048u);
+							__builtin_amdgcn_sched_barrier(0);   // a dword at a time: hipcc otherwise hoists the compares of the whole window
+						}
+				}
+			}
+			t = tn;
+			if (!__any(t < windows))
+				break;
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the line asked for last (nobody's) has landed before a0..a31 are asked again
+		if (ok && (p.flags & PIRE_HIP_RUN_END))
+			mark(1);
+		take();
+		if (ok && p.outIdx)
+			p.outIdx[s] = row / kCountingRowPitch;
+		if (ok)
+			for (uint32_t r = 0; r < p.regexps; ++r) {
+				uint32_t c = 0, m = 0;
+#pragma unroll
+				for (int q = 0; q < NREG; ++q)
+					if (uint32_t(q) == (r >> 1)) {
+						c = (r & 1) ? cur[q].y : cur[q].x;
+						m = (r & 1) ? tot[q].y : tot[q].x;
+					}
+				p.outResults[s * p.regexps + r] = c > m ? c : m;   // Result(r), count.h:206
+			}
 	}
 }
 
@@ -847,6 +1121,21 @@ void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipS
 }
 
 template <int NREG>
+void LaunchRow(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+{
+	const void* fn = advanced ? reinterpret_cast<const void*>(CountingRowKernel<NREG, true>)
+	                          : reinterpret_cast<const void*>(CountingRowKernel<NREG, false>);
+	*err = SetDynamicLds(fn, uint32_t(ldsBytes));
+	if (*err != hipSuccess)
+		return;
+	if (advanced)
+		hipLaunchKernelGGL((CountingRowKernel<NREG, true>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
+	else
+		hipLaunchKernelGGL((CountingRowKernel<NREG, false>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
+	*err = hipGetLastError();
+}
+
+template <int NREG>
 void LaunchPacked(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
 	const void* fn = advanced ? reinterpret_cast<const void*>(CountingPackedKernel<NREG, true>)
@@ -911,18 +1200,31 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		if (e != hipSuccess)
 			return HipFail(e, "hipMallocAsync(counting overflow list)");
 		p.overflow = static_cast<uint32_t*>(list);
-		const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
-		const unsigned pblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
 		const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
-		switch (nreg) {
-		case 1: LaunchPacked<1>(p, adv, pblocks, packedLds, stream, &e); break;
-		case 2: LaunchPacked<2>(p, adv, pblocks, packedLds, stream, &e); break;
-		case 4: LaunchPacked<4>(p, adv, pblocks, packedLds, stream, &e); break;
-		default: LaunchPacked<8>(p, adv, pblocks, packedLds, stream, &e); break;
+		// entries that are LDS addresses (CountingRowKernel) where the table leaves room for them and the batch fills the
+		// one block of 16 waves a CU then holds; pire_hip_config.counting_variant: 1 = never, 2 = whenever the table fits
+		const int variant = GetConfig().counting_variant;
+		const bool rows = nreg <= 2 && p.states <= kCountingRowStates && variant != 1 && (variant == 2 || p.n >= uint64_t(cus) * 256);
+		if (rows) {
+			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * nreg * 4);
+			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 1023) / 1024, uint64_t(cus))));
+			switch (nreg) {
+			case 1: LaunchRow<1>(p, adv, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<2>(p, adv, rblocks, rowLds, stream, &e); break;
+			}
+		} else {
+			const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
+			const unsigned pblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
+			switch (nreg) {
+			case 1: LaunchPacked<1>(p, adv, pblocks, packedLds, stream, &e); break;
+			case 2: LaunchPacked<2>(p, adv, pblocks, packedLds, stream, &e); break;
+			case 4: LaunchPacked<4>(p, adv, pblocks, packedLds, stream, &e); break;
+			default: LaunchPacked<8>(p, adv, pblocks, packedLds, stream, &e); break;
+			}
 		}
 		if (e != hipSuccess)
 			return HipFail(e, "counting kernel launch");
-		NoteKernel("counting_packed");
+		NoteKernel(rows ? "counting_rows" : "counting_packed");
 	} else {
 		NoteKernel("counting");
 	}

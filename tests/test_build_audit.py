@@ -69,3 +69,43 @@ def test_exact_kernels_have_no_scratch():
         for name, res in resources(unit).items():
             if "pirehip" in name:    # segmented.hip also instantiates library (rocprim) scan kernels
                 assert res.get("ScratchSize", -1) == 0, (unit, name, res)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_counting_row_kernel_owns_its_landing_registers():
+    """CountingRowKernel lands the text line that is on its way in a0..a31, named in its asm statements only.  The
+    compiler may use accumulation registers as spill space: never those (a register written by it while the memory
+    system still owes data to it, or the other way round, is a silently wrong count), and no scratch."""
+    src = os.path.join(ROOT, "pire_amd", "csrc", "counting.hip")
+    res = {k: v for k, v in resources("counting.hip").items() if "CountingRowKernel" in k}
+    assert len(res) == 4, sorted(res)
+    for name, r in res.items():
+        assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)   # 16 waves per CU
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--offload-device-only", "-S", src,
+                          "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=900).stdout
+    body, seen = None, 0
+    lines = asm.splitlines()
+    for n, line in enumerate(lines):
+        m = re.match(r"^(_ZN7pirehip17CountingRowKernel\S*):", line)
+        if m:
+            body, seen = m.group(1), seen + 1
+            # what hipcc spills per pass (a lane has 64 ordinary registers next to the 64 accumulation registers) goes
+            # to a32.. and a few bytes of scratch: not inside the window loop, where its s_waitcnt for a reload would
+            # wait for the line on its way as well
+            end = next(k for k in range(n, len(lines)) if lines[k].startswith(".Lfunc_end"))
+            land = next(k for k in range(n, end) if re.search(r"v_accvgpr_read_b32 v\d+, a0\b", lines[k]))
+            last = max(k for k in range(n, end) if "ds_read_b64" in lines[k])
+            assert not [lines[k] for k in range(land, last) if "scratch_" in lines[k]], body
+        elif line.startswith(".Lfunc_end"):
+            body = None
+        elif body:
+            # a0..a31: written by the eight loads, read by v_accvgpr_read_b32, touched by nothing else
+            for m in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]", line.split(";")[0]):
+                lo = int(m.group(1) if m.group(1) is not None else m.group(2))
+                if lo >= 32:
+                    continue
+                op = line.split()[0]
+                assert op in ("global_load_dwordx4", "v_accvgpr_read_b32"), (body, line)
+                if op == "global_load_dwordx4":
+                    assert re.search(r"global_load_dwordx4 a\[\d+:\d+\], v\[\d+:\d+\], off", line), (body, line)
+    assert seen == 4

@@ -176,3 +176,60 @@ def test_gpu_counting_packed_kernel_and_its_overflow_list(pa, k):
             assert (hi == oi).all() and (hr == orr).all(), (k, kind, flags)
         assert packed or t.Size * 512 > 56 * 1024, "a table of %d states should have taken the packed kernel" % t.Size
         assert orr.max() > 20000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 8])
+def test_gpu_counting_row_kernel(pa, k):
+    """CountingRowKernel (whole lines of text per lane, entries that are LDS addresses, no branch around the action;
+    tables of up to 64 states and four regexps): both counter-register instantiations, both scanner classes, all four
+    Begin/End combinations, the overflow list -- against the oracle and against the 16-bit-entry kernel (pire_hip_config.counting_variant 2 / 1)."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from pire_amd import binding as pb
+
+    res_ = ["a", "b", "ab", "[ab]+", "c", "bc", "d", "abc"][:k]
+    seps = [".*", "\\s", ".*", "c", ".*", ".*", "\\s", ".*"][:k]
+    rng = np.random.RandomState(70 + k)
+    many = H.random_strings(rng, 5000, 300, b"abcd \n012") + [b"", b"a", b"ab ab ab"] + [b""] * 70
+    many += [b"a " * 40000, b"ab" * 32499, b"abc " * 16250]
+    took_rows = 0
+    for kind in (0, 1):
+        try:
+            blob = ob.RefCountingScanner.compile(kind, res_, seps).save()
+        except ValueError:
+            continue            # this class cannot glue that many
+        t, o = pa.CountingTable(blob, kind), ob.OracleCountingScanner(blob, kind)
+        for flags in (3, 0, 1, 2):
+            oi, orr = o.run_strings(many, flags=flags)
+            with pb.config(counting_variant=2):
+                gi, gr = t.run_strings(many, flags=flags)
+                rows = pb.last_kernel() == "counting_rows"
+            assert rows == (t.Size <= 64 and k <= 4), (k, kind, t.Size, pb.last_kernel())
+            took_rows += rows
+            assert (gi == oi).all() and (gr == orr).all(), (k, kind, flags)
+            with pb.config(counting_variant=1):
+                hi, hr = t.run_strings(many, flags=flags)
+                assert pb.last_kernel() in ("counting_packed", "counting")
+            assert (hi == oi).all() and (hr == orr).all(), (k, kind, flags)
+        assert orr.max() > 20000
+    assert took_rows or k > 4, "no table of this size took the row kernel"
+
+
+@pytest.mark.gpu
+def test_gpu_counting_row_kernel_is_the_default_for_batches_that_fill_the_gpu(pa):
+    from pire_amd import binding as pb
+
+    case = [c for c in cases() if c["name"] == "count_glued3_advanced"][0]
+    blob = H.load_blob(case["blob"])
+    t, o = pa.CountingTable(blob, case["kind"]), ob.OracleCountingScanner(blob, case["kind"])
+    rng = np.random.RandomState(81)
+    many = H.random_strings(rng, 70000, 60, b"abc def,http:/\n")
+    oi, orr = o.run_strings(many)
+    gi, gr = t.run_strings(many)
+    assert pb.last_kernel() == "counting_rows"
+    assert (gi == oi).all() and (gr == orr).all()
+    few = many[:3000]
+    gi, gr = t.run_strings(few)
+    assert pb.last_kernel() == "counting_packed"
+    assert (gi == oi[:3000]).all() and (gr == orr[:3000]).all()
