@@ -421,17 +421,17 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
 		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
-		uint64_t s = 0, b = 0, e = 0;
+		uint64_t b = 0, e = 0;
 		if (k < p.n) {
-			s = p.order ? p.order[k] : k;
+			const uint64_t s = p.order ? p.order[k] : k;
 			b = p.offsets[s];
 			e = p.offsets[s + 1];
+			if (e - b > 65000) {
+				const uint32_t slot = atomicAdd(&p.overflow[0], 1u);
+				p.overflow[1 + slot] = uint32_t(s);
+			}
 		}
 		const bool ok = k < p.n && e - b <= 65000;
-		if (k < p.n && !ok) {
-			const uint32_t slot = atomicAdd(&p.overflow[0], 1u);
-			p.overflow[1 + slot] = uint32_t(s);
-		}
 		const uint32_t len = ok ? uint32_t(e - b) : 0u;
 		const uint64_t first = reinterpret_cast<uint64_t>(p.text) + b;
 		const uint64_t line0 = first & ~uint64_t(127);
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 		if (ok && (p.flags & PIRE_HIP_RUN_END))
 			mark(1);
 		take();
+		const uint64_t s = ok ? (p.order ? p.order[k] : k) : 0;   // read again: two registers less across the window loop
 		if (ok && p.outIdx)
 			p.outIdx[s] = row / kCountingRowPitch;
 		if (ok)
@@ -868,6 +869,147 @@ int Bad(const char* msg)
 {
 	SetError(msg);
 	return PIRE_HIP_EFORMAT;
+}
+
+// ---- CapturingScanner on whole text lines (round 4) --------------------------------------------------------------------
+// CaptureDenseKernel with the text path and the entries of CountingRowKernel: one 128-byte line per lane and window,
+// landing in a0..a31 while the previous one is walked; entries of 8 bytes = { LDS offset of the next state's row, what
+// the step's action does: 1 = BeginCapture, 2 = EndCapture alone (capture.h:96-102: Begin wins when both are set) }; a
+// 257th entry per row for the bytes outside the string, a sink row for lanes that are done.  The capture is kept as
+// masks: `sel` = the action's kind as an all-ones word, and-ed with "capture not complete yet"; begin / end take the
+// position through v_bfi.  Positions count steps (the BeginMark step included); a step's action is applied one step
+// later, so what is stored is the position of the step that applies it, corrected by one at the end.
+__global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	typedef uint32_t Pair __attribute__((ext_vector_type(2)));
+	typedef const __attribute__((address_space(3))) Pair* LdsPair;
+	const uint32_t sinkRow = p.states * kCountingRowPitch;
+	for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x)
+		*reinterpret_cast<uint2*>(lds + sinkRow + i * 8u) = uint2{sinkRow, 0u};
+	for (uint32_t i = threadIdx.x; i < p.states * 256; i += blockDim.x) {
+		const uint32_t e = p.dense[i], a = e >> 8;
+		*reinterpret_cast<uint2*>(lds + (i >> 8) * kCountingRowPitch + (i & 255u) * 8u) =
+			uint2{(e & 0xFFu) * kCountingRowPitch, (a & 1u) ? 1u : (a & 2u)};
+	}
+	for (uint32_t i = threadIdx.x; i < p.states; i += blockDim.x)
+		*reinterpret_cast<uint2*>(lds + i * kCountingRowPitch + 2048u) = uint2{i * kCountingRowPitch, 0u};
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
+	constexpr uint32_t npos = ~uint32_t(0);
+	const uint32_t beginStep = (p.flags & PIRE_HIP_RUN_BEGIN) ? 1u : 0u;
+	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
+		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
+		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
+		uint64_t b = 0, e = 0;
+		if (k < p.n) {
+			const uint64_t s = p.order ? p.order[k] : k;
+			b = p.offsets[s];
+			e = p.offsets[s + 1];
+		}
+		// (positions are 32-bit, as in the kernels above)
+		const bool ok = k < p.n;
+		const uint32_t len = ok ? uint32_t(e - b) : 0u;
+		const uint64_t first = reinterpret_cast<uint64_t>(p.text) + b;
+		const uint64_t line0 = first & ~uint64_t(127);
+		const uint32_t lead = uint32_t(first - line0);
+		const uint32_t windows = len ? (lead + len + 127u) >> 7 : 0u;
+		uint32_t row = p.initial * kCountingRowPitch, pend = 0;
+		uint32_t begin = npos, end = npos, hasBegin = 0, hasEnd = 0;
+		// TakeAction (capture.h:96-102) of the step before the one at position `at`
+		auto take = [&](uint32_t at) __attribute__((always_inline)) {
+			const uint32_t open = ~(hasBegin & hasEnd);
+			const uint32_t selB = uint32_t(int32_t(pend << 31) >> 31) & open;
+			const uint32_t selE = uint32_t(int32_t(pend << 30) >> 31) & open;
+			begin = (at & selB) | (begin & ~selB);
+			end = (at & selE) | (end & ~selE);
+			hasBegin |= selB;
+			hasEnd |= selE;
+		};
+		auto step = [&](uint32_t entryOffset, uint32_t at) __attribute__((always_inline)) {
+			const Pair next = *reinterpret_cast<LdsPair>(static_cast<uintptr_t>(row + entryOffset));
+			take(at);
+			row = next.x;
+			pend = next.y;
+		};
+		auto mark = [&](uint32_t which, uint32_t at) __attribute__((always_inline)) {
+			const uint32_t m = p.denseMarks[(row / kCountingRowPitch) * 2 + which];
+			take(at);
+			row = (m & 0xFFu) * kCountingRowPitch;
+			const uint32_t a = m >> 8;
+			pend = (a & 1u) ? 1u : (a & 2u);
+		};
+		// `at` of a step = the string's byte index it consumes (BeginMark: -1, EndMark: len); its own position in steps
+		// is at + beginStep, the position of the step whose action it applies one less
+		if (ok && beginStep)
+			mark(0, npos);
+		u32x4 tile[8];
+		AccTile acc;
+		asm volatile("" : "={a[0:3]}"(acc.r[0]), "={a[4:7]}"(acc.r[1]), "={a[8:11]}"(acc.r[2]), "={a[12:15]}"(acc.r[3]),
+		             "={a[16:19]}"(acc.r[4]), "={a[20:23]}"(acc.r[5]), "={a[24:27]}"(acc.r[6]), "={a[28:31]}"(acc.r[7]));
+		for (uint32_t t = ~0u;;) {
+			LandTile(acc, tile);
+			const uint32_t tn = t + 1u;
+			IssueAccGroup(acc, tn < windows ? line0 + uint64_t(tn) * 128u : reinterpret_cast<uint64_t>(p.dense), lane);
+			if (t != ~0u) {
+				TransposeTile(tile, lane);
+				const uint32_t at = t * 128u - lead;
+				const bool inside = t * 128u >= lead && at + 128u <= len;
+				const bool idle = t >= windows;
+				if (__all(inside || idle)) {
+					const uint32_t keep = row;
+					row = idle ? sinkRow : row;
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+#pragma unroll
+						for (int w = 0; w < 4; ++w) {
+							const uint32_t x = tile[q][w];
+							const uint32_t j = 16u * q + 4u * w;
+							step((x & 0xFFu) * 8u, at + j);
+							step(((x >> 8) & 0xFFu) * 8u, at + j + 1u);
+							step(((x >> 16) & 0xFFu) * 8u, at + j + 2u);
+							step((x >> 24) * 8u, at + j + 3u);
+							__builtin_amdgcn_sched_barrier(0);
+						}
+					row = idle ? keep : row;
+				} else {
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+#pragma unroll
+						for (int w = 0; w < 4; ++w) {
+							const uint32_t x = tile[q][w];
+							const uint32_t j = 16u * q + 4u * w;
+							step(at + j < len ? (x & 0xFFu) * 8u : 2048u, at + j);
+							step(at + j + 1u < len ? ((x >> 8) & 0xFFu) * 8u : 2048u, at + j + 1u);
+							step(at + j + 2u < len ? ((x >> 16) & 0xFFu) * 8u : 2048u, at + j + 2u);
+							step(at + j + 3u < len ? (x >> 24) * 8u : 2048u, at + j + 3u);
+							__builtin_amdgcn_sched_barrier(0);
+						}
+				}
+			}
+			t = tn;
+			if (!__any(t < windows))
+				break;
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		if (ok && (p.flags & PIRE_HIP_RUN_END)) {
+			mark(1, len);
+			take(len + 1u);
+		} else {
+			take(len);
+		}
+		if (ok) {
+			const uint64_t s = p.order ? p.order[k] : k;   // read again: two registers less across the window loop
+			const uint32_t st = row / kCountingRowPitch;
+			if (p.outIdx)
+				p.outIdx[s] = st;
+			if (p.outFinal)
+				p.outFinal[s] = p.tags[st] & 1u;                  // Final, capture.h:134 (FinalFlag = 1)
+			// stored: the byte index of the step that applied the action = the action's own byte index + 1
+			p.outBegin[s] = hasBegin ? (long long)(begin + beginStep - 1u) : -1ll;
+			p.outEnd[s] = hasEnd ? (long long)(end + beginStep - 1u) : -1ll;
+		}
+	}
 }
 
 // The dense, packed form of CountingPackedKernel for LoadedScanner tables (CountingScanner / AdvancedCountingScanner:
@@ -1585,7 +1727,13 @@ try {
 		hipError_t le;
 		// (order.hip, measured on the capture walks: 1 025-1 045 GB/s in the caller's order, 941-977 by length -- the walk
 		// has little to win, its text reads lose their neighbours; `capture_by_length` keeps the A/B)
-		if (p.offsets && LengthOrderWanted(p.n) && GetConfig().capture_by_length) {
+		// whole text lines per lane (CaptureRowKernel) where the table leaves room for 2 KB rows and the batch fills the one
+		// block of 16 waves a CU then holds; pire_hip_config.counting_variant as for the counting scanners.  That kernel
+		// does take its strings by length: a line is a line wherever the neighbouring lanes read.
+		const int variant = GetConfig().counting_variant;
+		const bool rows = p.dense && !(flags & PIRE_HIP_RUN_GENERIC) && p.states <= kCountingRowStates && variant != 1 &&
+		                  (variant == 2 || p.n >= uint64_t(cus) * 256);
+		if (p.offsets && LengthOrderWanted(p.n) && (GetConfig().capture_by_length || (rows && !GetConfig().no_length_order))) {
 			le = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
 			if (le != hipSuccess)
 				return HipFail(le, "hipMallocAsync(length order)");
@@ -1594,7 +1742,15 @@ try {
 				return rc;
 			p.serpentine = serp ? 1u : 0u;
 		}
-		if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
+		if (rows) {
+			const uint32_t rowLds = uint32_t(size_t(p.states + 1) * kCountingRowPitch);
+			le = SetDynamicLds(reinterpret_cast<const void*>(CaptureRowKernel), rowLds);
+			if (le != hipSuccess)
+				return HipFail(le, "hipFuncSetAttribute(LDS)");
+			NoteKernel("capture_rows");
+			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 1023) / 1024, uint64_t(cus))));
+			hipLaunchKernelGGL(CaptureRowKernel, dim3(rblocks), dim3(1024), rowLds, stream, p);
+		} else if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
 			const uint32_t denseLds = p.states * 512;
 			le = SetDynamicLds(reinterpret_cast<const void*>(CaptureDenseKernel), uint32_t(denseLds));
 			if (le != hipSuccess)

@@ -86,7 +86,11 @@ def test_gpu_capture_parity(case, pa, cfg):
         d = t.capture(*H.pack(many), flags=flags)
         assert pb.last_kernel() == "capture_dense"
         assert all((x == y).all() for x, y in zip(a, d)), flags
-        cfg.set(ragged_act_always=1, no_ragged_act=0)
+        cfg.set(counting_variant=2)                                     # ... and that on whole text lines (round 4)
+        r = t.capture(*H.pack(many), flags=flags)
+        assert pb.last_kernel() == ("capture_rows" if t.Size <= 64 else "capture_dense")
+        assert all((x == y).all() for x, y in zip(a, r)), flags
+        cfg.set(ragged_act_always=1, no_ragged_act=0, counting_variant=0)
     assert a[2].sum() > 0
     # left to itself the library keeps the one-string-per-lane kernel for scanners that are in an action state on most
     # bytes of text (=(\d+)[^\d] re-arms BeginCapture all the time), and takes the ragged one for the others
