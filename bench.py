@@ -220,11 +220,24 @@ def bench_slow(args):
     # serves 64 banks x 4 bytes per clock and CU; conflict-free, a wave instruction of 64 lanes costs 64 * width / 256
     # clocks (2 for a u8 / b32 read -- two half-waves --, 4 for a b64 read).  Roofline = bytes/s the chip could scan if
     # every lookup were conflict-free and nothing else took time, at the 2.4 GHz peak clock, 256 CUs.
-    clocks_per_wave_byte = {"slow": 2 + 4 * 4, "slow_list": 2 + 16 * 2}.get(kernel)
+    # Round 4: the list kernel walks only the groups of four slots in use (one, on this pattern), and what bounds it is
+    # not the LDS but VALU issue: 30.8 VALU instructions per wave and input byte (rocprofv3 PMC of this very workload,
+    # profiles/r04_slow_list_pmc.txt) x 4 clocks each on one of a CU's 4 SIMDs.  Both bounds are stated, `frac` is
+    # against the lower one.
+    valu_per_wave_byte = {"slow_list": 30.8}.get(kernel)
+    clocks_per_wave_byte = {"slow": 2 + 4 * 4, "slow_list": 2 + 4 * 2}.get(kernel)
     if clocks_per_wave_byte:
-        peak = 256 * 2.4e9 / clocks_per_wave_byte * 64 / 1e9
-        bound, model = "lds", (f"{clocks_per_wave_byte} conflict-free LDS clocks per 64 input bytes of a wave "
-                               f"(1 letter lookup + {'4 slots x b64' if kernel == 'slow' else '16 slots x b32'}), 256 CUs x 2.4 GHz")
+        lds_peak = 256 * 2.4e9 / clocks_per_wave_byte * 64 / 1e9
+        bound, peak = "lds", lds_peak
+        model = (f"{clocks_per_wave_byte} conflict-free LDS clocks per 64 input bytes of a wave "
+                 f"(1 letter lookup + {'4 slots x b64' if kernel == 'slow' else '4 slots in use x b32; all 16: 34 clocks'}), "
+                 f"256 CUs x 2.4 GHz = {lds_peak:.0f} GB/s")
+        if valu_per_wave_byte:
+            valu_peak = 256 * 4 * 2.4e9 / (valu_per_wave_byte * 4) * 64 / 1e9
+            model += (f"; VALU issue: {valu_per_wave_byte} instructions per wave and byte (measured, PMC) x 4 clocks, 1 024 SIMDs x "
+                      f"2.4 GHz = {valu_peak:.0f} GB/s")
+            if valu_peak < lds_peak:
+                bound, peak = "valu", valu_peak
     else:   # wave-per-string form: latency bound per step (fences + atomics), no closed-form throughput bound
         peak, bound, model = None, "latency", "one wave per string: ~1 us per byte and wave (set clear, scatter, fence)"
     achieved = n * (length + 1) / (np.mean(ms) * 1e-3) / 1e9

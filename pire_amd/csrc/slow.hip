@@ -361,46 +361,91 @@ constexpr uint32_t kListMaxRows = 16383;   // (states + 1) * letters: 16-bit byt
 
 typedef const __attribute__((address_space(3))) uint32_t* LdsWordPtr;
 
-__device__ __forceinline__ void ListStep(uint32_t tabBase, uint32_t letter4, uint32_t (&lst)[kListSlots], bool& ovf)
+// Round 4: a step costs what the slots in use cost.  `top` (wave-uniform) bounds the groups of four slots that hold a
+// thread in SOME lane of the wave: slots 4 * top .. 15 are empty in every lane.  ListStepT<T> walks the first T groups
+// in straight-line code -- lookups, spawn bookkeeping and shift alike -- and the window loop picks the instance by
+// `top` with one branch per step.  (Round 3 skipped the lookups of an empty group and still paid 16 selects, 16 ORs and,
+// in the 80 % of the steps in which some lane spawns, a 16-slot count: 65 VALU instructions per step on x.{40}$, which
+// bounded the kernel -- profiles/r04_slow_list_pmc.txt: 4.37 G instructions x 4 clocks on 1 024 SIMDs = 7.1 ms of the
+// 6.8 ms launch.  A first form with a branch per group and phase traded 20 of them for 26 scalar instructions and 7
+// branches per step, and was slower.)  The spawn words are SUMMED, not ORed: an entry's upper half is 0x8000 | the
+// spawned row for a spawning entry and 0 for any other, so the sum of the upper halves is 0 (nobody spawned), below
+// 0x10000 (exactly one did: the sum is its word) or not (two or more) -- one add per slot instead of an OR and a count.
+template <int T>
+__device__ __forceinline__ void ListStepT(uint32_t tabBase, uint32_t letter4, uint32_t (&lst)[kListSlots], bool& ovf)
 {
-	uint32_t r[kListSlots];
-	uint32_t orAll = 0;
+	constexpr int N = 4 * T;
+	uint32_t r[N];
+	uint32_t sumHi = 0;
+	const uint32_t base = letter4 + tabBase;
 #pragma unroll
-	for (int g = 0; g < kListSlots / 4; ++g) {
-		const uint32_t any4 = lst[4 * g] | lst[4 * g + 1] | lst[4 * g + 2] | lst[4 * g + 3];
-		if (g > 0 && !__any(any4 != 0)) {
-#pragma unroll
-			for (int i = 4 * g; i < 4 * g + 4; ++i)
-				r[i] = 0;        // the empty row leads to itself, nothing spawns
-			continue;
-		}
-#pragma unroll
-		for (int i = 4 * g; i < 4 * g + 4; ++i) {
-			r[i] = *reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>((lst[i] & 0xFFFFu) + letter4 + tabBase));
-			orAll |= r[i];
-		}
+	for (int i = 0; i < N; ++i) {
+		// the row is the slot's lower half (the upper one is what is left of a spawn word): mask and add in one instruction
+		uint32_t addr;
+		asm("v_mad_u32_u16 %0, %1, 1, %2" : "=v"(addr) : "v"(lst[i]), "v"(base));
+		r[i] = *reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(addr));
+		sumHi += r[i] >> 16;
 	}
-	const bool spawn = int32_t(orAll) < 0;
-	const uint32_t extra = (orAll >> 16) & 0x7FFFu;   // the spawned thread's row -- if exactly one slot spawned
-	if (__any(spawn)) {
-		// somebody did: count exactly (two in one step do not fit this scheme: the OR mixes their rows)
-		uint32_t cnt = 0;
+	const bool spawn = sumHi != 0;
+	const uint32_t extra = sumHi & 0x7FFFu;   // the spawned thread's row -- if exactly one slot spawned
+	// two spawns in one step do not fit this scheme (sum >= 0x10000), nor a row with three targets (its word is 0x8000 |
+	// kListMulti = 0xFFFF, the largest a single one can be), nor a live thread pushed out of the last slot
+	bool over = sumHi >= (0x8000u | kListMulti);
+	if (N == kListSlots)
+		over = over || (spawn && (r[N - 1] & 0xFFFFu) != 0);
+	if (__any(over)) {   // rare: the string goes quiet (every slot empty from now on, so nothing spawns either)
+		ovf = ovf || over;
 #pragma unroll
-		for (int i = 0; i < kListSlots; ++i)
-			cnt += r[i] >> 31;
-		const bool over = cnt > 1 || (spawn && extra == kListMulti) || (spawn && (r[kListSlots - 1] & 0xFFFFu) != 0);
-		if (__any(over)) {   // rare: the string goes quiet (every slot empty from now on, so nothing spawns either)
-			ovf = ovf || over;
-#pragma unroll
-			for (int i = 0; i < kListSlots; ++i)
-				r[i] = over ? 0u : r[i];
-		}
+		for (int i = 0; i < N; ++i)
+			r[i] = over ? 0u : r[i];
 	}
 	const bool shift = spawn && !ovf;
+	if (N < kListSlots)
+		lst[N] = shift ? r[N - 1] : 0u;      // the first slot above: empty before, takes the thread that shifts up
 #pragma unroll
-	for (int i = kListSlots - 1; i > 0; --i)
+	for (int i = N - 1; i > 0; --i)
 		lst[i] = shift ? r[i - 1] : r[i];
 	lst[0] = shift ? extra << 2 : r[0];
+}
+
+// the smallest `top` that holds for the wave (exact: used after the steps that do not keep it up to date)
+__device__ __forceinline__ uint32_t ListTop(const uint32_t (&lst)[kListSlots])
+{
+	uint32_t top = 1;
+#pragma unroll
+	for (int g = 1; g < kListSlots / 4; ++g)
+		top = __any((lst[4 * g] | lst[4 * g + 1] | lst[4 * g + 2] | lst[4 * g + 3]) != 0) ? uint32_t(g + 1) : top;
+	return top;
+}
+
+// One step with `top` kept up to date: at most one group more (the thread that shifted into its first slot), one less
+// when the highest group in use has emptied in every lane.
+__device__ __forceinline__ void ListStepTop(uint32_t tabBase, uint32_t letter4, uint32_t (&lst)[kListSlots], bool& ovf, uint32_t& top)
+{
+	switch (top) {
+	case 1:
+		ListStepT<1>(tabBase, letter4, lst, ovf);
+		top = __any(lst[4] != 0) ? 2u : 1u;
+		break;
+	case 2:
+		ListStepT<2>(tabBase, letter4, lst, ovf);
+		top = __any(lst[8] != 0) ? 3u : __any((lst[4] | lst[5] | lst[6] | lst[7]) != 0) ? 2u : 1u;
+		break;
+	case 3:
+		ListStepT<3>(tabBase, letter4, lst, ovf);
+		top = __any(lst[12] != 0) ? 4u : __any((lst[8] | lst[9] | lst[10] | lst[11]) != 0) ? 3u : 2u;
+		break;
+	default:
+		ListStepT<4>(tabBase, letter4, lst, ovf);
+		top = __any((lst[12] | lst[13] | lst[14] | lst[15]) != 0) ? 4u : 3u;
+		break;
+	}
+}
+
+// (the steps outside the window loop -- marks, the bytes in front of the first and behind the last whole block)
+__device__ __forceinline__ void ListStep(uint32_t tabBase, uint32_t letter4, uint32_t (&lst)[kListSlots], bool& ovf)
+{
+	ListStepT<kListSlots / 4>(tabBase, letter4, lst, ovf);
 }
 
 __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
@@ -430,7 +475,11 @@ __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
 			b = p.offsets[s];
 			e = p.offsets[s + 1];
 		} else {
+#if defined(PIRE_EXP) && PIRE_EXP == 21   // timing experiment: every lane reads one of 64 strings (the text stays in the caches)
+			b = (s & 63) * p.stride;
+#else
 			b = s * p.stride;
+#endif
 			e = b + p.len;
 		}
 		uint32_t lst[kListSlots];
@@ -447,17 +496,24 @@ __global__ __launch_bounds__(1024) void SlowListKernel(SlowParams p)
 			ListStep(tabBase, ldsLetter4[*ptr], lst, ovf);
 		// the next 16 bytes are requested before this block's 16 steps, not when they are needed
 		uint4 ahead = ptr + 16 <= end ? *reinterpret_cast<const uint4*>(ptr) : uint4{0, 0, 0, 0};
+		uint32_t top = ListTop(lst);
 		for (; ptr + 16 <= end; ptr += 16) {
+			// (`top` is the wave's: a lane that has left this loop no longer counts, and what is left of the wave is
+			// bounded by the same number or a smaller one)
+			top = __builtin_amdgcn_readfirstlane(top);
 			uint4 v = ahead;
 			if (ptr + 32 <= end)
 				ahead = *reinterpret_cast<const uint4*>(ptr + 16);
 #pragma unroll 1
-			for (int i = 0; i < 16; ++i) {
-				ListStep(tabBase, ldsLetter4[v.x & 0xFF], lst, ovf);
-				v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-				v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-				v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-				v.w >>= 8;
+			for (int i = 0; i < 4; ++i) {   // a dword at a time: the byte is one v_bfe away, not four funnel shifts
+				const uint32_t x = v.x;
+				ListStepTop(tabBase, ldsLetter4[x & 0xFF], lst, ovf, top);
+				ListStepTop(tabBase, ldsLetter4[(x >> 8) & 0xFF], lst, ovf, top);
+				ListStepTop(tabBase, ldsLetter4[(x >> 16) & 0xFF], lst, ovf, top);
+				ListStepTop(tabBase, ldsLetter4[x >> 24], lst, ovf, top);
+				v.x = v.y;
+				v.y = v.z;
+				v.z = v.w;
 			}
 		}
 		for (; ptr < end; ++ptr)

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            if "Scan" not in k and "Corpus" not in k:
+            if not any(w in k for w in ("Scan", "Corpus", "Slow", "Counting", "Capture")):
                 continue
             acc[k.split("(")[0][:60]][row["Counter_Name"]].append((row.get("Dispatch_Id"), float(row["Counter_Value"])))
 for k, ctrs in acc.items():
