@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -1097,6 +1099,12 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 		e = hipGetLastError();
 		if (e != hipSuccess)
 			rc = HipFail(e, "slow kernel launch");
+	}
+	if (rc == PIRE_HIP_OK && getenv("PIRE_HIP_SLOW_STATS")) {   // measurements: how many strings the 16-slot list could not hold
+		uint32_t over = 0;
+		if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(&over, list, 4, hipMemcpyDeviceToHost) == hipSuccess)
+			fprintf(stderr, "pire_hip slow: %u of %llu strings left the list kernel for the %s one\n", over,
+			        static_cast<unsigned long long>(p.n), p.words > 8 ? "wave-per-string" : "bitset");
 	}
 	if (rc == PIRE_HIP_OK)
 		rc = fallback(p);   // p.overflow set: only the strings on the list
