@@ -141,6 +141,8 @@ typedef struct pire_hip_config {
 	                               /* up to 64 states and 4 regexps and batches that fill the GPU, else 16 bytes of text   */
 	                               /* at a time and 16-bit entries; 1 always the latter; 2 the former whenever the table   */
 	                               /* fits.  Same results either way.                                                      */
+	uint32_t slow_stats;           /* 1: every SlowScanner call prints to stderr how many strings left the list kernel     */
+	                               /* (synchronises the stream: measurements)                                              */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)

@@ -113,6 +113,7 @@ class Config(C.Structure):
         ("capture_by_length", C.c_uint32),
         ("force_rccl", C.c_uint32),
         ("counting_variant", C.c_uint32),
+        ("slow_stats", C.c_uint32),
     ]
 
 

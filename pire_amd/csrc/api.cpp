@@ -271,6 +271,7 @@ pire_hip_config SeedFromEnvironment()
 	c.capture_by_length = EnvU64("PIRE_HIP_CAPTURE_BY_LENGTH") != 0;
 	c.force_rccl = EnvU64("PIRE_HIP_FORCE_RCCL") != 0;
 	c.counting_variant = uint32_t(EnvU64("PIRE_HIP_COUNTING_VARIANT"));
+	c.slow_stats = EnvU64("PIRE_HIP_SLOW_STATS") != 0;
 	return c;
 }
 

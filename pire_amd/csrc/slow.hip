@@ -1100,7 +1100,7 @@ int LaunchSlowListThen(const SlowParams& p0, hipStream_t stream, Fallback fallba
 		if (e != hipSuccess)
 			rc = HipFail(e, "slow kernel launch");
 	}
-	if (rc == PIRE_HIP_OK && getenv("PIRE_HIP_SLOW_STATS")) {   // measurements: how many strings the 16-slot list could not hold
+	if (rc == PIRE_HIP_OK && GetConfig().slow_stats) {   // measurements: how many strings the 16-slot list could not hold
 		uint32_t over = 0;
 		if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(&over, list, 4, hipMemcpyDeviceToHost) == hipSuccess)
 			fprintf(stderr, "pire_hip slow: %u of %llu strings left the list kernel for the %s one\n", over,

@@ -83,11 +83,14 @@ echo "== host-pointer mode"
 timeout 300 python tools/host_call_latency.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_call_latency.log | tail -8
 echo "== C++ shim and the pigrep example"
 tests/cpp/bin/shim_test 2>&1 | tail -2 | tee $OUT/shim.log
-echo "== host side under ASan + UBSan on the GPU box: the default-config / concurrency tests and the ABI tests"
-make -C pire_amd/csrc -j16 asan > $OUT/asan_build.log 2>&1
-RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | tail -1)
-LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 PIRE_HIP_LIB=pire_amd/libpire_hip_asan.so \
-  timeout 900 python -m pytest tests/test_default_config.py tests/test_abi.py tests/test_host_staging.py tests/test_multi_gpu.py -m gpu -x -q -p no:cacheprovider > $OUT/asan_gpu.log 2>&1
-tail -5 $OUT/asan_gpu.log; grep -c "AddressSanitizer\|runtime error:" $OUT/asan_gpu.log
+echo "== counting / capturing scanners: round 3's kernels (variant 1) against the row kernels (default), same box; SlowScanner on ragged strings"
+for name in count_glued3_advanced count0_advanced count0_basic; do
+  for v in 1 0; do
+    echo -n "variant=$v: "; PIRE_HIP_COUNTING_VARIANT=$v timeout 300 python tools/counting_case.py $name 2>&1 | grep "^counting\|parity" | tr '\n' ' ' | cut -c1-420; echo
+  done
+done | tee $OUT/counting_variants.log
+for v in 1 0; do PIRE_HIP_COUNTING_VARIANT=$v timeout 400 python tools/capture_case.py 2>&1 | grep "^capture" | sed "s/^/variant=$v: /"; done | tee $OUT/capture_variants.log | cut -c1-220
+PIRE_HIP_SLOW_STATS=1 timeout 300 python tools/slow_ragged_case.py 2>&1 | grep "^slow\|pire_hip slow" | tee $OUT/slow_ragged.log | cut -c1-220
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_counting -o stats -- python tools/counting_case.py count_glued3_advanced > /dev/null 2>&1; grep "Counting\|Order\|Length" $OUT/stats_counting/stats_kernel_stats.csv | cut -c1-200 | tee $OUT/counting_kernel_stats.txt
 find $OUT -name "*.csv" -size +1M -delete; find $OUT -name "*.db" -delete
 du -sh $OUT
