@@ -138,7 +138,7 @@ typedef struct pire_hip_config {
 	                               /* one-rank all-reduce: exercises the RCCL path on a one-GPU box; default: host sum)   */
 	uint32_t counting_variant;     /* counting scanners with dense rows: 0 default = whole text lines per lane and entries */
 	                               /* that are LDS addresses (2 KB per state, one block of 16 waves per CU) for tables of  */
-	                               /* up to 64 states and 4 regexps and batches that fill the GPU, else 16 bytes of text   */
+	                               /* up to 64 states and 8 regexps and batches that fill the GPU, else 16 bytes of text   */
 	                               /* at a time and 16-bit entries; 1 always the latter; 2 the former whenever the table   */
 	                               /* fits.  Same results either way.                                                      */
 	uint32_t slow_stats;           /* 1: every SlowScanner call prints to stderr how many strings left the list kernel     */

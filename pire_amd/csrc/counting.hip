@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
 //     itself, action 0 }: a step that changes nothing, chosen by an add, a compare and a select.  Windows that lie
 //     inside the strings of all the lanes still at work take a copy of the walk without the three.
 // 2 KB of LDS per state, so one block of 16 waves per CU and tables of up to kCountingRowStates states (counting tables
-// have tens); larger ones keep the kernel above, and so do scanners of more than four regexps (eight and sixteen counter
+// have tens); larger ones keep the kernel above, and so do scanners of more than eight regexps (eight counter
 // registers: not built).  Same counters, same overflow list, same length order.
 // The line on its way lands in ACCUMULATION registers a0..a31 -- by name: the load instructions write a[4j:4j+3] and
 // LandTile() reads a0..a31, whatever the compiler thinks.  To the compiler they are eight values that the loads define
@@ -1346,13 +1346,14 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		// entries that are LDS addresses (CountingRowKernel) where the table leaves room for them and the batch fills the
 		// one block of 16 waves a CU then holds; pire_hip_config.counting_variant: 1 = never, 2 = whenever the table fits
 		const int variant = GetConfig().counting_variant;
-		const bool rows = nreg <= 2 && p.states <= kCountingRowStates && variant != 1 && (variant == 2 || p.n >= uint64_t(cus) * 256);
+		const bool rows = nreg <= 4 && p.states <= kCountingRowStates && variant != 1 && (variant == 2 || p.n >= uint64_t(cus) * 256);
 		if (rows) {
 			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * nreg * 4);
 			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 1023) / 1024, uint64_t(cus))));
 			switch (nreg) {
 			case 1: LaunchRow<1>(p, adv, rblocks, rowLds, stream, &e); break;
-			default: LaunchRow<2>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 2: LaunchRow<2>(p, adv, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<4>(p, adv, rblocks, rowLds, stream, &e); break;
 			}
 		} else {
 			const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);

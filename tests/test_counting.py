@@ -182,7 +182,7 @@ def test_gpu_counting_packed_kernel_and_its_overflow_list(pa, k):
 @pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 8])
 def test_gpu_counting_row_kernel(pa, k):
     """CountingRowKernel (whole lines of text per lane, entries that are LDS addresses, no branch around the action;
-    tables of up to 64 states and four regexps): both counter-register instantiations, both scanner classes, all four
+    tables of up to 64 states and eight regexps): all three counter-register instantiations, both scanner classes, all four
     Begin/End combinations, the overflow list -- against the oracle and against the 16-bit-entry kernel (pire_hip_config.counting_variant 2 / 1)."""
     if not ob.ref_available():
         pytest.skip("oracle/_ref not built")
@@ -205,7 +205,7 @@ def test_gpu_counting_row_kernel(pa, k):
             with pb.config(counting_variant=2):
                 gi, gr = t.run_strings(many, flags=flags)
                 rows = pb.last_kernel() == "counting_rows"
-            assert rows == (t.Size <= 64 and k <= 4), (k, kind, t.Size, pb.last_kernel())
+            assert rows == (t.Size <= 64), (k, kind, t.Size, pb.last_kernel())
             took_rows += rows
             assert (gi == oi).all() and (gr == orr).all(), (k, kind, flags)
             with pb.config(counting_variant=1):
@@ -213,7 +213,7 @@ def test_gpu_counting_row_kernel(pa, k):
                 assert pb.last_kernel() in ("counting_packed", "counting")
             assert (hi == oi).all() and (hr == orr).all(), (k, kind, flags)
         assert orr.max() > 20000
-    assert took_rows or k > 4, "no table of this size took the row kernel"
+    assert took_rows or k > 4, "no table of this size took the row kernel"   # (glued tables of 7-8 regexps may exceed 64 states)
 
 
 @pytest.mark.gpu
