@@ -197,7 +197,7 @@ struct Counters {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 template <int NREG, bool ADVANCED>
-__global__ __launch_bounds__(256) void CountingPackedKernel(CountingParams p)
+__global__ __launch_bounds__(1024) void CountingPackedKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint16_t* dense = reinterpret_cast<uint16_t*>(lds);                               // [states][256]
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void CaptureKernel(CountingParams p)
 // (BuildDenseCounting: <= 255 states; the action is the raw 2-bit capture action, not an id), the action applied while
 // the next lookup is on its way, the text requested 16 bytes ahead -- the recipe of CountingPackedKernel.  For the
 // capture scanners that are in an action state on most bytes and therefore stay off the ragged kernel.
-__global__ __launch_bounds__(256) void CaptureDenseKernel(CountingParams p)
+__global__ __launch_bounds__(1024) void CaptureDenseKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint16_t* dense = reinterpret_cast<uint16_t*>(lds);
@@ -1022,7 +1022,7 @@ void BuildDenseCounting(CountingHost& t)
 	if (t.type != 4 || t.states == 0 || t.states > 255 || t.regexps == 0 || t.regexps > kMaxReCount)
 		return;
 	const uint32_t nreg = t.regexps <= 2 ? 1 : t.regexps <= 4 ? 2 : t.regexps <= 8 ? 4 : 8;
-	if (size_t(t.states) * 512 + 256 * 2 * nreg * 4 > 60 * 1024)
+	if (size_t(t.states) * 512 + 256 * 2 * nreg * 4 > 150 * 1024)   // (more than 40 KB: one block of 16 waves per CU, LaunchPacked)
 		return;
 	std::vector<uint32_t> ids;   // distinct non-zero action words, id = index + 1
 	// tables whose action words all fit a byte (CapturingScanner: 1 = BeginCapture, 2 = EndCapture) keep them as ids:
@@ -1278,17 +1278,23 @@ void LaunchRow(const CountingParams& p, bool advanced, unsigned blocks, uint32_t
 }
 
 template <int NREG>
-void LaunchPacked(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+void LaunchPacked(const CountingParams& p, bool advanced, unsigned cus, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
 	const void* fn = advanced ? reinterpret_cast<const void*>(CountingPackedKernel<NREG, true>)
 	                          : reinterpret_cast<const void*>(CountingPackedKernel<NREG, false>);
 	*err = SetDynamicLds(fn, uint32_t(ldsBytes));
 	if (*err != hipSuccess)
 		return;
+	// small tables: several 256-thread blocks per CU; a table of more than 40 KB (up to 255 states: 128 KB of rows) leaves
+	// room for one to three blocks, so these are blocks of 16 waves (round 4: such tables went to the 32-bit kernel, a
+	// 143-state scanner of 7 regexps at 0.45 TB/s)
+	const unsigned threads = ldsBytes > 40 * 1024 ? 1024 : 256;
+	const uint64_t perCu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / threads, (160 * 1024) / ldsBytes));
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + threads - 1) / threads, uint64_t(cus) * perCu)));
 	if (advanced)
-		hipLaunchKernelGGL((CountingPackedKernel<NREG, true>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+		hipLaunchKernelGGL((CountingPackedKernel<NREG, true>), dim3(blocks), dim3(threads), ldsBytes, stream, p);
 	else
-		hipLaunchKernelGGL((CountingPackedKernel<NREG, false>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+		hipLaunchKernelGGL((CountingPackedKernel<NREG, false>), dim3(blocks), dim3(threads), ldsBytes, stream, p);
 	*err = hipGetLastError();
 }
 
@@ -1357,12 +1363,11 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 			}
 		} else {
 			const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
-			const unsigned pblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
 			switch (nreg) {
-			case 1: LaunchPacked<1>(p, adv, pblocks, packedLds, stream, &e); break;
-			case 2: LaunchPacked<2>(p, adv, pblocks, packedLds, stream, &e); break;
-			case 4: LaunchPacked<4>(p, adv, pblocks, packedLds, stream, &e); break;
-			default: LaunchPacked<8>(p, adv, pblocks, packedLds, stream, &e); break;
+			case 1: LaunchPacked<1>(p, adv, unsigned(cus), packedLds, stream, &e); break;
+			case 2: LaunchPacked<2>(p, adv, unsigned(cus), packedLds, stream, &e); break;
+			case 4: LaunchPacked<4>(p, adv, unsigned(cus), packedLds, stream, &e); break;
+			default: LaunchPacked<8>(p, adv, unsigned(cus), packedLds, stream, &e); break;
 			}
 		}
 		if (e != hipSuccess)
@@ -1757,7 +1762,11 @@ try {
 			if (le != hipSuccess)
 				return HipFail(le, "hipFuncSetAttribute(LDS)");
 			NoteKernel("capture_dense");
-			hipLaunchKernelGGL(CaptureDenseKernel, dim3(blocks), dim3(256), denseLds, stream, p);
+			// (a table of more than 40 KB: blocks of 16 waves, as LaunchPacked)
+			const unsigned dthreads = denseLds > 40 * 1024 ? 1024 : 256;
+			const uint64_t perCu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / dthreads, (160 * 1024) / std::max<uint32_t>(denseLds, 1)));
+			const unsigned dblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + dthreads - 1) / dthreads, uint64_t(cus) * perCu)));
+			hipLaunchKernelGGL(CaptureDenseKernel, dim3(dblocks), dim3(dthreads), denseLds, stream, p);
 		} else {
 			NoteKernel("capture");
 			hipLaunchKernelGGL(CaptureKernel, dim3(blocks), dim3(256), ldsBytes, stream, p);
