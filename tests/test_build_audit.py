@@ -153,3 +153,24 @@ def test_no_instruction_touches_a_tile_that_is_on_its_way(unit, kernel):
             found += 1
             assert mod.check(body) == [], name
     assert found
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_sanitizer_builds_carry_the_products_device_code():
+    """The sanitizer libraries instrument the HOST side (-O1 -g); their kernels must be the product's, instruction for
+    instruction: the audits above hold for the product flags only (at -O1 hipcc spills the registers CaptureRowKernel
+    lands its text in -- found by the UBSan run of round 4).  counting.hip compiled with the flags of `make ubsan` and
+    with the product's, device side only."""
+    src = os.path.join(ROOT, "pire_amd", "csrc", "counting.hip")
+    mk = open(os.path.join(ROOT, "pire_amd", "csrc", "Makefile")).read()
+    assert mk.count("-O1 -g $(DEVOPT)") == 3 and "DEVOPT  := -Xarch_device -O3 -Xarch_device -g0" in mk
+
+    def isa(flags):
+        out = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-x", "hip", "--offload-device-only", "-S",
+                              src, "-o", "-"] + flags, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                             timeout=900).stdout
+        return [l for l in out.splitlines() if not l.lstrip().startswith(";") and "__hip_cuid" not in l and ".ident" not in l]
+
+    product = isa(["-O3"])
+    sanitized = isa(["-O1", "-g", "-Xarch_device", "-O3", "-Xarch_device", "-g0", "-fsanitize=undefined", "-fno-gpu-sanitize"])
+    assert len(product) > 10000 and product == sanitized

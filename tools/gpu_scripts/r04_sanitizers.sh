@@ -11,7 +11,7 @@ D=$(ls -d /opt/rocm/lib/llvm/lib/clang/*/lib/linux | tail -1)
 make -C pire_amd/csrc -j16 ubsan tsan > $OUT/san_build.log 2>&1; tail -1 $OUT/san_build.log | cut -c1-120
 echo "== UBSan"
 LD_PRELOAD=$D/libclang_rt.ubsan_standalone-x86_64.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=$OUT/ubsan_report PIRE_HIP_LIB=pire_amd/libpire_hip_ubsan.so \
-  timeout 900 python -m pytest tests/test_default_config.py tests/test_abi.py tests/test_host_staging.py tests/test_multi_gpu.py tests/test_segmented.py -m gpu -x -q -p no:cacheprovider > $OUT/ubsan_gpu.log 2>&1; echo "rc=$?"
+  timeout 900 python -m pytest tests/test_default_config.py tests/test_abi.py tests/test_host_staging.py tests/test_multi_gpu.py tests/test_segmented.py tests/test_counting.py tests/test_capture.py tests/test_slow.py -m gpu -x -q -p no:cacheprovider > $OUT/ubsan_gpu.log 2>&1; echo "rc=$?"
 tail -4 $OUT/ubsan_gpu.log; cat $OUT/ubsan_report.* 2>/dev/null | grep "runtime error" | sort | uniq -c | sort -rn | head -20; echo "UBSan reports: $(cat $OUT/ubsan_report.* 2>/dev/null | grep -c 'runtime error:')"
 echo "== ThreadSanitizer"
 LD_PRELOAD=$D/libclang_rt.tsan-x86_64.so TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 history_size=4 second_deadlock_stack=1 log_path=$OUT/tsan_report" PIRE_HIP_LIB=pire_amd/libpire_hip_tsan.so \
