@@ -61,6 +61,10 @@ enum {
 	                                    /* call enqueues kernels and nothing else (it is then legal inside a  */
 	                                    /* stream capture).  Automatic adaptation (auto_adapt) never runs     */
 	                                    /* inside an ON_DEVICE call unless auto_adapt = 2.                    */
+	                                    /* Device text is read in whole 128-byte aligned lines: the kernels   */
+	                                    /* may load (never use) up to 127 bytes in front of the first and     */
+	                                    /* behind the last byte of the text -- always inside the memory page  */
+	                                    /* that holds that byte, so any device allocation will do.            */
 	PIRE_HIP_RUN_GENERIC   = 1u << 3,   /* force the generic (offset-driven) kernel; testing/diagnostics     */
 	PIRE_HIP_RUN_NO_PEEK   = 1u << 5,   /* with ON_DEVICE, pire_hip_run: this call never reads device offsets  */
 	                                    /* back (what pire_hip_config.no_offsets_peek is for every call)       */
