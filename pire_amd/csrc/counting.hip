@@ -572,8 +572,10 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 }
 
 // KIND: PIRE_HIP_COUNTING_BASIC / _ADVANCED / _NOGLUELIMIT (the latter with at most RMAX regexps: counters in registers)
+// (blocks of up to 16 waves -- 8 for the sixteen-counter instantiations, whose counters need more than 128 registers --
+// so that a table of up to 150 KB can sit in LDS: LaunchOne)
 template <int RMAX, int KIND>
-__global__ __launch_bounds__(256) void CountingKernel(CountingParams p)
+__global__ __launch_bounds__(RMAX > 8 ? 512 : 1024) void CountingKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	uint8_t* letterOf = lds;                                            // 264 bytes
@@ -1253,12 +1255,17 @@ int UploadCounting(pire_hip_counting_table* t, CountingDevice* image)
 }
 
 template <int RMAX, int KIND>
-void LaunchOne(const CountingParams& p, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+void LaunchOne(const CountingParams& p, unsigned cus, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
 	*err = SetDynamicLds(reinterpret_cast<const void*>(CountingKernel<RMAX, KIND>), uint32_t(ldsBytes));
 	if (*err != hipSuccess)
 		return;
-	hipLaunchKernelGGL((CountingKernel<RMAX, KIND>), dim3(blocks), dim3(256), ldsBytes, stream, p);
+	// (a table of more than 40 KB: blocks of 16 waves, as LaunchPacked)
+	const unsigned threads = ldsBytes > 40 * 1024 ? (RMAX > 8 ? 512 : 1024) : 256;
+	const uint64_t perCu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / threads, (160 * 1024) / ldsBytes));
+	const uint64_t todo = p.n;   // (with an overflow list: at most this many)
+	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((todo + threads - 1) / threads, uint64_t(cus) * perCu)));
+	hipLaunchKernelGGL((CountingKernel<RMAX, KIND>), dim3(blocks), dim3(threads), ldsBytes, stream, p);
 	*err = hipGetLastError();
 }
 
@@ -1377,7 +1384,10 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		NoteKernel("counting");
 	}
 	const uint64_t tableBytes = uint64_t(p.states) * p.letters * 8;
-	p.transInLds = tableBytes <= 60 * 1024 ? 1 : 0;   // several 256-thread blocks per CU stay resident
+	// the transitions in LDS while they fit a CU's 160 KB (round 4: up to 60 KB only -- a 573-state scanner of 7 regexps
+	// read every transition from memory); above 40 KB the blocks are of 16 waves (LaunchOne)
+	const bool wideKernel = kind == PIRE_HIP_COUNTING_NOGLUELIMIT && p.regexps > kMaxReCount;
+	p.transInLds = tableBytes <= (wideKernel ? 60 : 150) * 1024 ? 1 : 0;
 	const uint32_t ldsBytes = 272 + (p.transInLds ? uint32_t(tableBytes) : 0);
 	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
 	if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT && p.regexps > kMaxReCount) {
@@ -1392,9 +1402,9 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		auto launch = [&](auto rmax) {
 			constexpr int R = decltype(rmax)::value;
 			switch (kind) {
-			case PIRE_HIP_COUNTING_BASIC: LaunchOne<R, PIRE_HIP_COUNTING_BASIC>(p, blocks, ldsBytes, stream, &e); break;
-			case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<R, PIRE_HIP_COUNTING_ADVANCED>(p, blocks, ldsBytes, stream, &e); break;
-			default: LaunchOne<R, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, blocks, ldsBytes, stream, &e); break;
+			case PIRE_HIP_COUNTING_BASIC: LaunchOne<R, PIRE_HIP_COUNTING_BASIC>(p, unsigned(cus), ldsBytes, stream, &e); break;
+			case PIRE_HIP_COUNTING_ADVANCED: LaunchOne<R, PIRE_HIP_COUNTING_ADVANCED>(p, unsigned(cus), ldsBytes, stream, &e); break;
+			default: LaunchOne<R, PIRE_HIP_COUNTING_NOGLUELIMIT>(p, unsigned(cus), ldsBytes, stream, &e); break;
 			}
 		};
 		if (p.regexps <= 1)
