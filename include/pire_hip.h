@@ -140,10 +140,11 @@ typedef struct pire_hip_config {
 	uint32_t capture_by_length;    /* 1: the one-string-per-lane capture kernels too take them by length (A/B: slower)   */
 	uint32_t force_rccl;           /* 1: pire_hip_multi_create builds an RCCL communicator for ONE device as well (a       */
 	                               /* one-rank all-reduce: exercises the RCCL path on a one-GPU box; default: host sum)   */
-	uint32_t counting_variant;     /* counting scanners with dense rows: 0 default = whole text lines per lane and entries */
-	                               /* that are LDS addresses (2 KB per state, one block of 16 waves per CU) for tables of  */
-	                               /* up to 64 states and 8 regexps and batches that fill the GPU, else 16 bytes of text   */
-	                               /* at a time and 16-bit entries; 1 always the latter; 2 the former whenever the table   */
+	uint32_t counting_variant;     /* counting / capturing scanners: 0 default = whole text lines per lane and entries     */
+	                               /* that are LDS addresses (CountingRowKernel: rows indexed by the byte for tables of up */
+	                               /* to 64 states, by the table's letters for any other whose rows fit the LDS; up to 8   */
+	                               /* regexps) for batches that fill the GPU, else 16 bytes of text at a time and 16-bit   */
+	                               /* entries / the 32-bit kernel; 1 always the latter; 2 the former whenever the table    */
 	                               /* fits.  Same results either way.                                                      */
 	uint32_t slow_stats;           /* 1: every SlowScanner call prints to stderr how many strings left the list kernel     */
 	                               /* (synchronises the stream: measurements)                                              */

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <unordered_map>
 
 #include <algorithm>
 #include <cstring>
@@ -42,6 +43,11 @@ struct CountingHost {
 	std::vector<uint16_t> denseMarks;  // [states][2] the same for BeginMark / EndMark
 	std::vector<uint32_t> actWords;    // [256][2 * NREG]: per action id NREG packed increment words, then NREG reset masks
 	uint32_t nreg = 0;                 // 32-bit words of packed 16-bit counters: ceil(regexps / 2) rounded up to 1, 2, 4, 8
+	// the letter-indexed form of CountingRowKernel (BASIC / ADVANCED, any number of states whose rows fit a CU's LDS,
+	// <= 255 distinct actions, <= 8 regexps); empty otherwise
+	std::vector<uint32_t> lrows;       // [states][letters] next state | action id << 16
+	std::vector<uint32_t> lactWords;   // [distinct actions + 1][2 * lnreg], as actWords
+	uint32_t lnreg = 0;
 };
 
 struct CountingDevice {
@@ -53,6 +59,8 @@ struct CountingDevice {
 	uint16_t* dense = nullptr;
 	uint16_t* denseMarks = nullptr;
 	uint32_t* actWords = nullptr;
+	uint32_t* lrows = nullptr;
+	uint32_t* lactWords = nullptr;
 };
 
 }  // namespace pirehip
@@ -86,6 +94,10 @@ struct CountingParams {
 	const uint16_t* dense;
 	const uint16_t* denseMarks;
 	const uint32_t* actWords;
+	const uint32_t* lrows;     // CountingRowKernel, letter-indexed rows: [states][letters] next | action id << 16
+	const uint32_t* lactWords;
+	uint32_t lnreg;            // 0: no letter-indexed rows (or PIRE_HIP_RUN_GENERIC)
+	uint32_t lactCount;        // rows of lactWords (distinct actions + 1)
 	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
 	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class)
 	uint32_t serpentine;       // walk the order forwards and backwards in turn (the global order)
@@ -394,7 +406,10 @@ __device__ __forceinline__ void LandTile(const AccTile& acc, u32x4 (&r)[8])
 constexpr uint32_t kCountingRowStates = 64;
 constexpr uint32_t kCountingRowPitch = 257 * 8;
 
-template <int NREG, bool ADVANCED>
+// LETTERS: rows indexed by the table's own letters (a byte is translated first: one more LDS read, off the dependent
+// chain) -- (states + 1) x (letters + 1) entries, so tables of hundreds of states fit; without it rows of 257 entries
+// indexed by the byte itself (<= 64 states).
+template <int NREG, bool ADVANCED, bool LETTERS>
 __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -403,19 +418,31 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 	// (LDS by absolute address: the dynamic segment starts at 0, this kernel has no static LDS)
 	typedef const __attribute__((address_space(3))) Pair* LdsPair;
 	typedef const __attribute__((address_space(3))) Quad* LdsQuad;
-	const uint32_t sinkRow = p.states * kCountingRowPitch;   // every entry: { the sink row, no action }
-	const uint32_t actBase = ((p.states + 1) * kCountingRowPitch + 15u) & ~15u;
-	for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x)
+	const uint32_t pitch = LETTERS ? (p.letters + 1u) * 8u : kCountingRowPitch;
+	const uint32_t idleOff = pitch - 8u;                     // the row's last entry: { this row, no action }
+	const uint32_t sinkRow = p.states * pitch;               // every entry: { the sink row, no action }
+	const uint32_t actBase = ((p.states + 1) * pitch + 15u) & ~15u;
+	const uint32_t actCount = LETTERS ? p.lactCount : 256u;
+	const uint32_t lettab = actBase + actCount * 8u * NREG;  // LETTERS: u16[256], 8 * letter of every byte
+	for (uint32_t i = threadIdx.x; i < pitch / 8u; i += blockDim.x)
 		*reinterpret_cast<uint2*>(lds + sinkRow + i * 8u) = uint2{sinkRow, actBase};
-	for (uint32_t i = threadIdx.x; i < p.states * 256; i += blockDim.x) {
-		const uint32_t e = p.dense[i];
-		*reinterpret_cast<uint2*>(lds + (i >> 8) * kCountingRowPitch + (i & 255u) * 8u) =
-			uint2{(e & 0xFFu) * kCountingRowPitch, actBase + (e >> 8) * (8u * NREG)};
+	if (LETTERS) {
+		for (uint32_t i = threadIdx.x; i < p.states * p.letters; i += blockDim.x) {
+			const uint32_t e = p.lrows[i], st = i / p.letters, l = i - st * p.letters;
+			*reinterpret_cast<uint2*>(lds + st * pitch + l * 8u) = uint2{(e & 0xFFFFu) * pitch, actBase + (e >> 16) * (8u * NREG)};
+		}
+		for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+			*reinterpret_cast<uint16_t*>(lds + lettab + i * 2u) = uint16_t(p.letterOf[i] * 8u);
+	} else {
+		for (uint32_t i = threadIdx.x; i < p.states * 256; i += blockDim.x) {
+			const uint32_t e = p.dense[i];
+			*reinterpret_cast<uint2*>(lds + (i >> 8) * pitch + (i & 255u) * 8u) = uint2{(e & 0xFFu) * pitch, actBase + (e >> 8) * (8u * NREG)};
+		}
 	}
 	for (uint32_t i = threadIdx.x; i < p.states; i += blockDim.x)
-		*reinterpret_cast<uint2*>(lds + i * kCountingRowPitch + 2048u) = uint2{i * kCountingRowPitch, actBase};
-	for (uint32_t i = threadIdx.x; i < 256 * 2 * NREG; i += blockDim.x)
-		reinterpret_cast<uint32_t*>(lds + actBase)[i] = p.actWords[i];
+		*reinterpret_cast<uint2*>(lds + i * pitch + idleOff) = uint2{i * pitch, actBase};
+	for (uint32_t i = threadIdx.x; i < actCount * 2 * NREG; i += blockDim.x)
+		reinterpret_cast<uint32_t*>(lds + actBase)[i] = (LETTERS ? p.lactWords : p.actWords)[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
@@ -441,7 +468,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 #pragma unroll
 		for (int r = 0; r < NREG; ++r)
 			cur[r] = tot[r] = u16x2{0, 0};
-		uint32_t row = p.initial * kCountingRowPitch, pend = actBase;   // pend: LDS offset of the words of the action not applied yet
+		uint32_t row = p.initial * pitch, pend = actBase;   // pend: LDS offset of the words of the action not applied yet
 		auto take = [&]() __attribute__((always_inline)) {   // TakeActionImpl: count.h:251-257 (increment, reset) / 287-295 (reset, increment)
 			uint32_t w[2 * NREG];
 			if (NREG == 1) {
@@ -489,11 +516,19 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 			row = next.x;
 			pend = next.y;
 		};
-		auto mark = [&](uint32_t which) {   // BeginMark / EndMark: the u16 entry from global memory, twice per string
-			const uint32_t m = p.denseMarks[(row / kCountingRowPitch) * 2 + which];
-			take();
-			row = (m & 0xFFu) * kCountingRowPitch;
-			pend = actBase + (m >> 8) * (8u * NREG);
+		auto mark = [&](uint32_t which) __attribute__((always_inline)) {   // BeginMark / EndMark, twice per string
+			if (LETTERS) {
+				step(p.letterOf[which ? kEndMark : kBeginMark] * 8u);
+			} else {
+				const uint32_t m = p.denseMarks[(row / kCountingRowPitch) * 2 + which];   // the u16 entry from global memory
+				take();
+				row = (m & 0xFFu) * kCountingRowPitch;
+				pend = actBase + (m >> 8) * (8u * NREG);
+			}
+		};
+		// the entry a byte selects within a row
+		auto at8 = [&](uint32_t byte) __attribute__((always_inline)) -> uint32_t {
+			return LETTERS ? LdsU16(lettab + byte * 2u) : byte * 8u;
 		};
 		if (ok && (p.flags & PIRE_HIP_RUN_BEGIN))
 			mark(0);
@@ -508,7 +543,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 			LandTile(acc, tile);
 			const uint32_t tn = t + 1u;
 			// (lanes without a further line fetch a harmless valid one: the table)
-			IssueAccGroup(acc, tn < windows ? line0 + uint64_t(tn) * 128u : reinterpret_cast<uint64_t>(p.dense), lane);
+			IssueAccGroup(acc, tn < windows ? line0 + uint64_t(tn) * 128u : reinterpret_cast<uint64_t>(LETTERS ? static_cast<const void*>(p.lrows) : static_cast<const void*>(p.dense)), lane);
 			if (t != ~0u) {
 				TransposeTile(tile, lane);
 				const uint32_t at = t * 128u - lead;   // byte j of this window is byte at + j of the string (mod 2^32)
@@ -524,10 +559,10 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 #pragma unroll
 						for (int w = 0; w < 4; ++w) {
 							const uint32_t x = tile[q][w];
-							step((x & 0xFFu) * 8u);
-							step(((x >> 8) & 0xFFu) * 8u);
-							step(((x >> 16) & 0xFFu) * 8u);
-							step((x >> 24) * 8u);
+							step(at8(x & 0xFFu));
+							step(at8((x >> 8) & 0xFFu));
+							step(at8((x >> 16) & 0xFFu));
+							step(at8(x >> 24));
 							__builtin_amdgcn_sched_barrier(0);
 						}
 					row = idle ? keep : row;
@@ -538,10 +573,10 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 						for (int w = 0; w < 4; ++w) {
 							const uint32_t x = tile[q][w];
 							const uint32_t j = 16u * q + 4u * w;
-							step(at + j < len ? (x & 0xFFu) * 8u : 2048u);
-							step(at + j + 1u < len ? ((x >> 8) & 0xFFu) * 8u : 2048u);
-							step(at + j + 2u < len ? ((x >> 16) & 0xFFu) * 8u : 2048u);
-							step(at + j + 3u < len ? (x >> 24) * 8u : 2048u);
+							step(at + j < len ? at8(x & 0xFFu) : idleOff);
+							step(at + j + 1u < len ? at8((x >> 8) & 0xFFu) : idleOff);
+							step(at + j + 2u < len ? at8((x >> 16) & 0xFFu) : idleOff);
+							step(at + j + 3u < len ? at8(x >> 24) : idleOff);
 							__builtin_amdgcn_sched_barrier(0);   // a dword at a time: hipcc otherwise hoists the compares of the whole window
 						}
 				}
@@ -556,7 +591,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 		take();
 		const uint64_t s = ok ? (p.order ? p.order[k] : k) : 0;   // read again: two registers less across the window loop
 		if (ok && p.outIdx)
-			p.outIdx[s] = row / kCountingRowPitch;
+			p.outIdx[s] = row / pitch;
 		if (ok)
 			for (uint32_t r = 0; r < p.regexps; ++r) {
 				uint32_t c = 0, m = 0;
@@ -1074,6 +1109,56 @@ void BuildDenseCounting(CountingHost& t)
 	t.nreg = nreg;
 }
 
+// The letter-indexed rows of CountingRowKernel: what BuildDenseCounting does for tables of up to 255 states, without the
+// expansion to 256 columns -- (states + 1) x (letters + 1) entries of 8 bytes in LDS, so hundreds of states fit.
+constexpr size_t kCountingRowLds = 150 * 1024;
+void BuildLetterRows(CountingHost& t)
+{
+	t.lrows.clear();
+	t.lnreg = 0;
+	if (t.type != 4 || t.states == 0 || t.states > 65535 || t.regexps == 0 || t.regexps > 8 || t.letters == 0 || t.letters > 255)
+		return;
+	const uint32_t nreg = t.regexps <= 2 ? 1 : t.regexps <= 4 ? 2 : 4;
+	const size_t rowBytes = (size_t(t.states) + 1) * (t.letters + 1) * 8 + 16 + 512;
+	if (rowBytes + 2 * 8 * nreg > kCountingRowLds)
+		return;
+	// as many distinct actions as fit behind the rows (8 * nreg bytes each), at most what 16 bits number
+	const size_t maxIds = std::min<size_t>(65535, (kCountingRowLds - rowBytes) / (8 * nreg) - 1);
+	std::vector<uint32_t> ids;   // distinct non-zero action words, id = index + 1
+	std::unordered_map<uint32_t, uint32_t> idOf;
+	std::vector<uint32_t> rows(size_t(t.states) * t.letters);
+	for (size_t i = 0; i < rows.size(); ++i) {
+		const uint64_t x = t.trans[i];
+		const uint32_t a = uint32_t(x >> 32);
+		uint32_t id = 0;
+		if (a) {
+			auto it = idOf.find(a);
+			if (it == idOf.end()) {
+				if (ids.size() == maxIds)
+					return;
+				ids.push_back(a);
+				it = idOf.emplace(a, uint32_t(ids.size())).first;
+			}
+			id = it->second;
+		}
+		if (uint32_t(x) >= t.states)
+			return;
+		rows[i] = uint32_t(x) | (id << 16);
+	}
+	t.lactWords.assign((ids.size() + 1) * 2 * nreg, 0);
+	for (size_t i = 0; i < ids.size(); ++i) {
+		uint32_t* w = &t.lactWords[(i + 1) * 2 * nreg];
+		for (uint32_t r = 0; r < t.regexps; ++r) {
+			if ((ids[i] >> r) & 1u)
+				w[r >> 1] |= 1u << (16 * (r & 1));                    // +1 in the counter's 16-bit half
+			if ((ids[i] >> (kMaxReCount + r)) & 1u)
+				w[nreg + (r >> 1)] |= 0xFFFFu << (16 * (r & 1));      // the counter's reset mask
+		}
+	}
+	t.lrows.swap(rows);
+	t.lnreg = nreg;
+}
+
 int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 {
 	const uint8_t* p = static_cast<const uint8_t*>(blob);
@@ -1172,6 +1257,7 @@ int BuildCountingHost(const void* blob, size_t len, CountingHost* out)
 		}
 	}
 	BuildDenseCounting(t);
+	BuildLetterRows(t);
 	return PIRE_HIP_OK;
 }
 
@@ -1193,6 +1279,10 @@ void FreeCountingDevice(CountingDevice* d)
 		(void)hipFree(d->denseMarks);
 	if (d->actWords)
 		(void)hipFree(d->actWords);
+	if (d->lrows)
+		(void)hipFree(d->lrows);
+	if (d->lactWords)
+		(void)hipFree(d->lactWords);
 	*d = CountingDevice();
 }
 
@@ -1244,6 +1334,16 @@ int UploadCounting(pire_hip_counting_table* t, CountingDevice* image)
 		if (e == hipSuccess)
 			e = hipMemcpy(d.actWords, h.actWords.data(), h.actWords.size() * 4, hipMemcpyHostToDevice);
 	}
+	if (e == hipSuccess && !t->host.lrows.empty()) {
+		const CountingHost& h = t->host;
+		e = hipMalloc(reinterpret_cast<void**>(&d.lrows), h.lrows.size() * 4);
+		if (e == hipSuccess)
+			e = hipMalloc(reinterpret_cast<void**>(&d.lactWords), h.lactWords.size() * 4);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.lrows, h.lrows.data(), h.lrows.size() * 4, hipMemcpyHostToDevice);
+		if (e == hipSuccess)
+			e = hipMemcpy(d.lactWords, h.lactWords.data(), h.lactWords.size() * 4, hipMemcpyHostToDevice);
+	}
 	d.device = dev;
 	if (e != hipSuccess) {
 		FreeCountingDevice(&d);
@@ -1269,18 +1369,18 @@ void LaunchOne(const CountingParams& p, unsigned cus, uint32_t ldsBytes, hipStre
 	*err = hipGetLastError();
 }
 
-template <int NREG>
+template <int NREG, bool LETTERS>
 void LaunchRow(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
-	const void* fn = advanced ? reinterpret_cast<const void*>(CountingRowKernel<NREG, true>)
-	                          : reinterpret_cast<const void*>(CountingRowKernel<NREG, false>);
+	const void* fn = advanced ? reinterpret_cast<const void*>(CountingRowKernel<NREG, true, LETTERS>)
+	                          : reinterpret_cast<const void*>(CountingRowKernel<NREG, false, LETTERS>);
 	*err = SetDynamicLds(fn, uint32_t(ldsBytes));
 	if (*err != hipSuccess)
 		return;
 	if (advanced)
-		hipLaunchKernelGGL((CountingRowKernel<NREG, true>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
+		hipLaunchKernelGGL((CountingRowKernel<NREG, true, LETTERS>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
 	else
-		hipLaunchKernelGGL((CountingRowKernel<NREG, false>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
+		hipLaunchKernelGGL((CountingRowKernel<NREG, false, LETTERS>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
 	*err = hipGetLastError();
 }
 
@@ -1348,7 +1448,13 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 				(void)hipFreeAsync(q, s);
 		}
 	} listGuard{list, stream};
-	if (nreg && p.dense && kind != PIRE_HIP_COUNTING_NOGLUELIMIT && p.n < (1ull << 32) - 1) {
+	// letter-indexed rows (CountingRowKernel<.., LETTERS>): any table whose (states + 1) x (letters + 1) entries fit
+	const uint32_t lnreg = p.lnreg;
+	const int variant = GetConfig().counting_variant;
+	const bool fills = variant == 2 || p.n >= uint64_t(cus) * 256;   // the one block of 16 waves a CU then holds
+	const bool byteRows = nreg && p.dense && nreg <= 4 && p.states <= kCountingRowStates && variant != 1 && fills;
+	const bool letterRows = !byteRows && lnreg && p.lrows && variant != 1 && fills;
+	if (((nreg && p.dense) || letterRows) && kind != PIRE_HIP_COUNTING_NOGLUELIMIT && p.n < (1ull << 32) - 1) {
 		e = hipMallocAsync(&list, (size_t(p.n) + 1) * 4, stream);
 		if (e == hipSuccess)
 			e = hipMemsetAsync(list, 0, 4, stream);
@@ -1357,16 +1463,21 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		p.overflow = static_cast<uint32_t*>(list);
 		const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
 		// entries that are LDS addresses (CountingRowKernel) where the table leaves room for them and the batch fills the
-		// one block of 16 waves a CU then holds; pire_hip_config.counting_variant: 1 = never, 2 = whenever the table fits
-		const int variant = GetConfig().counting_variant;
-		const bool rows = nreg <= 4 && p.states <= kCountingRowStates && variant != 1 && (variant == 2 || p.n >= uint64_t(cus) * 256);
-		if (rows) {
+		// GPU; pire_hip_config.counting_variant: 1 = never, 2 = whenever the table fits
+		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 1023) / 1024, uint64_t(cus))));
+		if (byteRows) {
 			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * nreg * 4);
-			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 1023) / 1024, uint64_t(cus))));
 			switch (nreg) {
-			case 1: LaunchRow<1>(p, adv, rblocks, rowLds, stream, &e); break;
-			case 2: LaunchRow<2>(p, adv, rblocks, rowLds, stream, &e); break;
-			default: LaunchRow<4>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 1: LaunchRow<1, false>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 2: LaunchRow<2, false>(p, adv, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<4, false>(p, adv, rblocks, rowLds, stream, &e); break;
+			}
+		} else if (letterRows) {
+			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * (p.letters + 1) * 8 + 15) & ~size_t(15)) + size_t(p.lactCount) * 2 * lnreg * 4 + 512);
+			switch (lnreg) {
+			case 1: LaunchRow<1, true>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 2: LaunchRow<2, true>(p, adv, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<4, true>(p, adv, rblocks, rowLds, stream, &e); break;
 			}
 		} else {
 			const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
@@ -1379,7 +1490,9 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		}
 		if (e != hipSuccess)
 			return HipFail(e, "counting kernel launch");
-		NoteKernel(rows ? "counting_rows" : "counting_packed");
+		const bool rows = byteRows || letterRows;
+		NoteKernel(byteRows ? "counting_rows" : letterRows ? "counting_letter_rows" : "counting_packed");
+		(void)rows;
 	} else {
 		NoteKernel("counting");
 	}
@@ -1539,6 +1652,10 @@ try {
 	p.dense = image.dense;
 	p.denseMarks = image.denseMarks;
 	p.actWords = image.actWords;
+	p.lrows = image.lrows;
+	p.lactWords = image.lactWords;
+	p.lnreg = (flags & PIRE_HIP_RUN_GENERIC) ? 0 : t->host.lnreg;
+	p.lactCount = t->host.lnreg ? uint32_t(t->host.lactWords.size() / (2 * t->host.lnreg)) : 0;
 	p.states = t->host.states;
 	p.letters = t->host.letters;
 	p.regexps = t->host.regexps;
