@@ -234,3 +234,33 @@ def test_gpu_counting_row_kernel_is_the_default_for_batches_that_fill_the_gpu(pa
     gi, gr = t.run_strings(few)
     assert pb.last_kernel() == "counting_packed"
     assert (gi == oi[:3000]).all() and (gr == orr[:3000]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_counting_letter_rows_on_large_tables(pa):
+    """CountingRowKernel with rows indexed by the table's letters: glued scanners of hundreds of states (7 regexps:
+    143 states as CountingScanner, 573 as AdvancedCountingScanner, more than 255 distinct actions), all four Begin/End
+    combinations, the overflow list -- against the oracle and the 32-bit kernel."""
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from pire_amd import binding as pb
+
+    res_ = ["[a-z]+", "http", "abc", "[0-9]+", "e", "th", "ing"]
+    seps = ["\\s", ".*", ".*", "\\s", ".*", ".*", ".*"]
+    rng = np.random.RandomState(91)
+    many = H.random_strings(rng, 6000, 400, b"abc the thing http://e 0123 \n") + [b"", b"e", b"thing 42"] + [b""] * 70
+    many += [b"the thing " * 7000, b"e" * 64999]
+    for kind in (0, 1):
+        blob = ob.RefCountingScanner.compile(kind, res_, seps).save()
+        t, o = pa.CountingTable(blob, kind), ob.OracleCountingScanner(blob, kind)
+        assert t.Size > 64
+        for flags in (3, 0, 1, 2):
+            oi, orr = o.run_strings(many, flags=flags)
+            with pb.config(counting_variant=2):
+                gi, gr = t.run_strings(many, flags=flags)
+                assert pb.last_kernel() == "counting_letter_rows", (kind, t.Size, pb.last_kernel())
+            assert (gi == oi).all() and (gr == orr).all(), (kind, flags)
+            hi, hr = t.run_strings(many, flags=flags | pb.FLAG_GENERIC)
+            assert pb.last_kernel() == "counting"
+            assert (hi == oi).all() and (hr == orr).all(), (kind, flags)
+        assert orr.max() > 20000
