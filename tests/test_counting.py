@@ -264,3 +264,50 @@ def test_gpu_counting_letter_rows_on_large_tables(pa):
             assert pb.last_kernel() == "counting"
             assert (hi == oi).all() and (hr == orr).all(), (kind, flags)
         assert orr.max() > 20000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [1, 17, 127])
+def test_gpu_row_kernels_with_text_at_any_alignment(pa, shift):
+    """The row kernels read whole 128-byte lines by ABSOLUTE address: device text that starts `shift` bytes into a line
+    (first line of the first string reaches in front of the text, last line behind it), offsets on the device --
+    counting (rows by byte and by letter) and capture against the oracle."""
+    import torch
+    from pire_amd import binding as pb
+
+    rng = np.random.RandomState(100 + shift)
+    many = H.random_strings(rng, 3000, 500, b"abc def,http:/\n=123 ") + [b"", b"a"] + H.random_strings(rng, 40, 3000, b"ab =12 \n")
+    text, offs = ob.pack_strings(many)
+    buf = torch.zeros(len(text) + 256, dtype=torch.uint8, device="cuda")
+    buf[shift:shift + len(text)] = torch.as_tensor(np.asarray(text, dtype=np.uint8).copy())
+    doffs = torch.as_tensor(np.asarray(offs, dtype=np.uint64).astype(np.int64), device="cuda")
+    n = len(many)
+    stream = torch.cuda.current_stream().cuda_stream
+    cases_ = [c for c in cases() if c["name"] in ("count_glued3_advanced", "count0_basic")]
+    assert cases_
+    with pb.config(counting_variant=2):
+        for case in cases_:
+            blob = H.load_blob(case["blob"])
+            t, o = pa.CountingTable(blob, case["kind"]), ob.OracleCountingScanner(blob, case["kind"])
+            oi, orr = o.run_strings(many)
+            idx = torch.empty(n, dtype=torch.int32, device="cuda")
+            res = torch.empty((n, t.RegexpsCount), dtype=torch.int32, device="cuda")
+            t.run_device(buf.data_ptr() + shift, doffs.data_ptr(), n, 3, idx.data_ptr(), res.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert pb.last_kernel() == "counting_rows"
+            assert (idx.cpu().numpy().astype(np.uint32) == oi).all() and (res.cpu().numpy().astype(np.uint32) == orr).all(), case["name"]
+        cap = [c for c in H.golden()["capturing"] if c["name"] == "capture_digits"][0]
+        blob = H.load_blob(cap["blob"])
+        t, o = pa.CountingTable(blob, 0), ob.OracleCountingScanner(blob, 0)
+        want = o.capture(*ob.pack_strings(many))
+        idx = torch.empty(n, dtype=torch.int32, device="cuda")
+        fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+        bg = torch.empty(n, dtype=torch.int64, device="cuda")
+        en = torch.empty(n, dtype=torch.int64, device="cuda")
+        with pb.config(no_ragged_act=1):
+            t.capture_device(buf.data_ptr() + shift, doffs.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), bg.data_ptr(), en.data_ptr(), stream)
+            torch.cuda.synchronize()
+            assert pb.last_kernel() == "capture_rows"
+        widx, wfin, _, wbeg, wend = want
+        assert (idx.cpu().numpy().astype(np.uint32) == widx).all() and (fin.cpu().numpy() == wfin).all()
+        assert (bg.cpu().numpy() == wbeg).all() and (en.cpu().numpy() == wend).all() and (wbeg >= 0).sum() > 0
