@@ -999,6 +999,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 	if (!t)
 		return;
 	FreeAllDeviceTables(t);
+	FreeHalfRows(t);
 	if (t->segProduct)
 		FreeAllDeviceTables(t->segProduct.get());   // the product automaton of the segmented scan's two modes
 	delete t;
@@ -1223,13 +1224,33 @@ try {
 		*done = !incomplete;
 		return PIRE_HIP_OK;
 	};
+	// Scanners whose walk is in a Final state most of the time gain nothing from the ragged kernel's look for the chunks
+	// that hold one: those take the row kernel of the counting scanners (counting.hip: whole text lines per lane, the
+	// increments of the target state as the step's action), and what its 16-bit counters cannot hold -- strings of more
+	// than 65 000 bytes -- the one-string-per-lane kernel, from the list the row kernel leaves.
+	auto launchCounting = [&](uint32_t* dResults) -> int {
+		// (the share of the byte model's visits that fall on Final states decides, as for the capturing scanners: at 0.2 %
+		// of the steps a third of the ragged kernel's chunks are walked again)
+		if (!exactOnly && (!RaggedActEligible(p) || p.finalShare > 0.002f)) {
+			bool done = false;
+			uint32_t* list = nullptr;
+			if (int rc = LaunchHalfFinalRows(t, p.text, p.offsets, n, flags, p.outIdx, p.outFinal, dResults, stream, &done, &list))
+				return rc;
+			if (done) {
+				const int rc = LaunchHalfFinal(p, dResults, stream, nullptr, list);
+				(void)hipFreeAsync(list, stream);
+				return rc;
+			}
+		}
+		return LaunchHalfFinal(p, dResults, stream, exactOnly ? nullptr : NextWorkSlot(t, p));
+	};
 	if (flags & PIRE_HIP_RUN_ON_DEVICE) {
 		p.text = static_cast<const uint8_t*>(text);
 		p.offsets = offsets;
 		p.outIdx = out_state_idx;
 		p.outFinal = out_final;
 		if (!(flags & PIRE_HIP_RUN_HOST_OFFSETS))
-			return LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t, p));
+			return launchCounting(out_results);
 		// resident text, offsets known to the host (see pire_hip_run)
 		for (uint64_t i = 0; i < n; ++i)
 			if (offsets[i] > offsets[i + 1]) {
@@ -1247,7 +1268,7 @@ try {
 		if (!rc)
 			rc = segmented(offsets, out_results, &counted);
 		if (!rc && !counted)
-			rc = LaunchHalfFinal(p, out_results, stream, exactOnly ? nullptr : NextWorkSlot(t, p));
+			rc = launchCounting(out_results);
 		(void)hipFreeAsync(d, stream);
 		if (!rc) {
 			e = hipStreamSynchronize(stream);   // the caller's offsets array was the source of an async copy
@@ -1286,7 +1307,7 @@ try {
 	if (int rc = segmented(offsets, static_cast<uint32_t*>(dRes), &counted))
 		return rc;
 	if (!counted)
-		if (int rc = LaunchHalfFinal(p, static_cast<uint32_t*>(dRes), stream, exactOnly ? nullptr : NextWorkSlot(t, p)))
+		if (int rc = launchCounting(static_cast<uint32_t*>(dRes)))
 			return rc;
 	int rc = st.Out(out_state_idx, dIdx, size_t(n) * 4);
 	if (!rc)

@@ -98,6 +98,8 @@ struct CountingParams {
 	const uint32_t* lactWords;
 	uint32_t lnreg;            // 0: no letter-indexed rows (or PIRE_HIP_RUN_GENERIC)
 	uint32_t lactCount;        // rows of lactWords (distinct actions + 1)
+	uint32_t initialAct;       // action id pending before the first step (HalfFinal: Initialize ends with TakeAction)
+	uint32_t maxLen;           // CountingRowKernel: longest string its 16-bit counters hold (0: 65 000); longer ones go on `overflow`
 	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
 	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class)
 	uint32_t serpentine;       // walk the order forwards and backwards in turn (the global order)
@@ -409,7 +411,9 @@ constexpr uint32_t kCountingRowPitch = 257 * 8;
 // LETTERS: rows indexed by the table's own letters (a byte is translated first: one more LDS read, off the dependent
 // chain) -- (states + 1) x (letters + 1) entries, so tables of hundreds of states fit; without it rows of 257 entries
 // indexed by the byte itself (<= 64 states).
-template <int NREG, bool ADVANCED, bool LETTERS>
+// MODE: 0 CountingScanner (increment, reset), 1 AdvancedCountingScanner (reset, increment), 2 counters that are only
+// ever added to (HalfFinalScanner's match counts: one packed add per register and step, no reset words read).
+template <int NREG, int MODE, bool LETTERS>
 __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 	// (LDS by absolute address: the dynamic segment starts at 0, this kernel has no static LDS)
 	typedef const __attribute__((address_space(3))) Pair* LdsPair;
 	typedef const __attribute__((address_space(3))) Quad* LdsQuad;
+	typedef const __attribute__((address_space(3))) uint32_t* LdsU32;
 	const uint32_t pitch = LETTERS ? (p.letters + 1u) * 8u : kCountingRowPitch;
 	const uint32_t idleOff = pitch - 8u;                     // the row's last entry: { this row, no action }
 	const uint32_t sinkRow = p.states * pitch;               // every entry: { the sink row, no action }
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 		reinterpret_cast<uint32_t*>(lds + actBase)[i] = (LETTERS ? p.lactWords : p.actWords)[i];
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
+	const uint64_t maxLen = p.maxLen ? p.maxLen : 65000u;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
 		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
@@ -453,12 +459,12 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 			const uint64_t s = p.order ? p.order[k] : k;
 			b = p.offsets[s];
 			e = p.offsets[s + 1];
-			if (e - b > 65000) {
+			if (e - b > maxLen) {
 				const uint32_t slot = atomicAdd(&p.overflow[0], 1u);
 				p.overflow[1 + slot] = uint32_t(s);
 			}
 		}
-		const bool ok = k < p.n && e - b <= 65000;
+		const bool ok = k < p.n && e - b <= maxLen;
 		const uint32_t len = ok ? uint32_t(e - b) : 0u;
 		const uint64_t first = reinterpret_cast<uint64_t>(p.text) + b;
 		const uint64_t line0 = first & ~uint64_t(127);
@@ -468,22 +474,38 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 #pragma unroll
 		for (int r = 0; r < NREG; ++r)
 			cur[r] = tot[r] = u16x2{0, 0};
-		uint32_t row = p.initial * pitch, pend = actBase;   // pend: LDS offset of the words of the action not applied yet
+		uint32_t row = p.initial * pitch, pend = actBase + p.initialAct * (8u * NREG);   // pend: LDS offset of the words of the action not applied yet
 		auto take = [&]() __attribute__((always_inline)) {   // TakeActionImpl: count.h:251-257 (increment, reset) / 287-295 (reset, increment)
+			constexpr bool ADVANCED = MODE == 1, SUM = MODE == 2;
 			uint32_t w[2 * NREG];
-			if (NREG == 1) {
+			if (SUM && NREG == 1) {
+				w[0] = *reinterpret_cast<LdsU32>(static_cast<uintptr_t>(pend));
+			} else if (NREG == 1 || (SUM && NREG == 2)) {
 				const Pair q = *reinterpret_cast<LdsPair>(static_cast<uintptr_t>(pend));
 				w[0] = q.x;
 				w[1] = q.y;
 			} else {
 #pragma unroll
-				for (int q4 = 0; q4 < NREG / 2; ++q4) {
+				for (int q4 = 0; q4 < (SUM ? NREG / 4 : NREG / 2); ++q4) {
 					const Quad q = *reinterpret_cast<LdsQuad>(static_cast<uintptr_t>(pend + 16u * q4));
 					w[4 * q4] = q.x;
 					w[4 * q4 + 1] = q.y;
 					w[4 * q4 + 2] = q.z;
 					w[4 * q4 + 3] = q.w;
 				}
+			}
+			if (SUM) {
+#pragma unroll
+				for (int r = 0; r < NREG; ++r) {
+					u16x2 inc;
+					__builtin_memcpy(&inc, &w[r], 4);
+					cur[r] += inc;
+					uint32_t pin;   // (a chain, as the maxima below: hipcc sums the increments of a window first, in a tree)
+					__builtin_memcpy(&pin, &cur[r], 4);
+					asm volatile("" : "+v"(pin));
+					__builtin_memcpy(&cur[r], &pin, 4);
+				}
+				return;
 			}
 			// Between two resets a counter only grows, and the result is max(current, total) (count.h:206): so the largest
 			// value `current` ever has IS the result, and the maximum can be taken at every step instead of under the
@@ -592,6 +614,8 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 		const uint64_t s = ok ? (p.order ? p.order[k] : k) : 0;   // read again: two registers less across the window loop
 		if (ok && p.outIdx)
 			p.outIdx[s] = row / pitch;
+		if (ok && p.outFinal)
+			p.outFinal[s] = p.tags[row / pitch] & 1u;   // (HalfFinal counting: Final of the end state)
 		if (ok)
 			for (uint32_t r = 0; r < p.regexps; ++r) {
 				uint32_t c = 0, m = 0;
@@ -1370,18 +1394,24 @@ void LaunchOne(const CountingParams& p, unsigned cus, uint32_t ldsBytes, hipStre
 }
 
 template <int NREG, bool LETTERS>
-void LaunchRow(const CountingParams& p, bool advanced, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
+void LaunchRow(const CountingParams& p, int mode, unsigned blocks, uint32_t ldsBytes, hipStream_t stream, hipError_t* err)
 {
-	const void* fn = advanced ? reinterpret_cast<const void*>(CountingRowKernel<NREG, true, LETTERS>)
-	                          : reinterpret_cast<const void*>(CountingRowKernel<NREG, false, LETTERS>);
-	*err = SetDynamicLds(fn, uint32_t(ldsBytes));
-	if (*err != hipSuccess)
-		return;
-	if (advanced)
-		hipLaunchKernelGGL((CountingRowKernel<NREG, true, LETTERS>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
-	else
-		hipLaunchKernelGGL((CountingRowKernel<NREG, false, LETTERS>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
-	*err = hipGetLastError();
+	auto go = [&](auto m) {
+		constexpr int MODE = decltype(m)::value;
+		*err = SetDynamicLds(reinterpret_cast<const void*>(CountingRowKernel<NREG, MODE, LETTERS>), uint32_t(ldsBytes));
+		if (*err != hipSuccess)
+			return;
+		hipLaunchKernelGGL((CountingRowKernel<NREG, MODE, LETTERS>), dim3(blocks), dim3(1024), ldsBytes, stream, p);
+		*err = hipGetLastError();
+	};
+	if (mode == 2) {
+		if constexpr (LETTERS)
+			go(std::integral_constant<int, 2>());
+	} else if (mode == 1) {
+		go(std::integral_constant<int, 1>());
+	} else {
+		go(std::integral_constant<int, 0>());
+	}
 }
 
 template <int NREG>
@@ -1468,16 +1498,16 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		if (byteRows) {
 			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * nreg * 4);
 			switch (nreg) {
-			case 1: LaunchRow<1, false>(p, adv, rblocks, rowLds, stream, &e); break;
-			case 2: LaunchRow<2, false>(p, adv, rblocks, rowLds, stream, &e); break;
-			default: LaunchRow<4, false>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 1: LaunchRow<1, false>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
+			case 2: LaunchRow<2, false>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<4, false>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
 			}
 		} else if (letterRows) {
 			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * (p.letters + 1) * 8 + 15) & ~size_t(15)) + size_t(p.lactCount) * 2 * lnreg * 4 + 512);
 			switch (lnreg) {
-			case 1: LaunchRow<1, true>(p, adv, rblocks, rowLds, stream, &e); break;
-			case 2: LaunchRow<2, true>(p, adv, rblocks, rowLds, stream, &e); break;
-			default: LaunchRow<4, true>(p, adv, rblocks, rowLds, stream, &e); break;
+			case 1: LaunchRow<1, true>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
+			case 2: LaunchRow<2, true>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
+			default: LaunchRow<4, true>(p, adv ? 1 : 0, rblocks, rowLds, stream, &e); break;
 			}
 		} else {
 			const uint32_t packedLds = uint32_t(size_t(p.states) * 512 + 256 * 2 * nreg * 4);
@@ -1537,6 +1567,209 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 }
 
 }  // namespace
+
+// ---- HalfFinalScanner counting on the row kernel (round 4) --------------------------------------------------------------
+// HalfFinalScanner::TakeAction (half_final.h:137-164) bumps the counter of every regexp in the final list of the state a
+// step ARRIVES in.  As a counting table: the action of (state, letter) = the increments of next(state, letter); Initialize
+// ends with TakeAction too, which is an action pending before the first step.  No resets, so Result = the count.  Needs
+// counters that pack (<= 8 regexps); a regexp that is m times in a state's final list bumps its 16-bit counter by m, so the
+// row kernel takes strings of up to 65 000 / m bytes and leaves longer ones on its list.
+namespace {
+void BuildHalfRows(const HostTable& h, HalfRowsHost& r)
+{
+	r.tried = true;
+	r.nreg = 0;
+	if (!h.incPacked || h.states == 0 || h.states > 65535 || h.letters == 0 || h.letters > 255 || h.regexps == 0 || h.regexps > 8)
+		return;
+	uint32_t maxMult = 1;   // how often a regexp is in one state's final list (a step bumps its counter by that much)
+	for (uint64_t inc : h.inc64)
+		for (int b = 0; b < 8; ++b)
+			maxMult = std::max(maxMult, uint32_t(inc >> (8 * b)) & 0xFFu);
+	const uint32_t nreg = h.regexps <= 2 ? 1 : h.regexps <= 4 ? 2 : 4;
+	const size_t rowBytes = (size_t(h.states) + 1) * (h.letters + 1) * 8 + 16 + 512;
+	if (rowBytes + 2 * 8 * nreg > kCountingRowLds)
+		return;
+	const size_t maxIds = std::min<size_t>(65535, (kCountingRowLds - rowBytes) / (8 * nreg) - 1);
+	std::vector<uint64_t> ids;   // distinct non-zero increment words, id = index + 1
+	std::unordered_map<uint64_t, uint32_t> idOf;
+	auto idFor = [&](uint32_t st, bool* ok) -> uint32_t {
+		const uint64_t inc = (h.flags[st] & kFinal) ? h.inc64[st] : 0;
+		if (!inc)
+			return 0;
+		auto it = idOf.find(inc);
+		if (it == idOf.end()) {
+			if (ids.size() == maxIds) {
+				*ok = false;
+				return 0;
+			}
+			ids.push_back(inc);
+			it = idOf.emplace(inc, uint32_t(ids.size())).first;
+		}
+		return it->second;
+	};
+	bool ok = true;
+	std::vector<uint32_t> rows(size_t(h.states) * h.letters);
+	for (size_t i = 0; i < rows.size() && ok; ++i)
+		rows[i] = h.next[i] | (idFor(h.next[i], &ok) << 16);
+	const uint32_t initialAct = idFor(h.initial, &ok);
+	if (!ok)
+		return;
+	r.lactWords.assign((ids.size() + 1) * 2 * nreg, 0);
+	for (size_t i = 0; i < ids.size(); ++i)
+		for (uint32_t q = 0; q < h.regexps; ++q)
+			r.lactWords[(i + 1) * 2 * nreg + (q >> 1)] |= (uint32_t(ids[i] >> (8 * q)) & 0xFFu) << (16 * (q & 1));   // the counter's 16-bit half
+	r.letterOf.resize(264);
+	for (size_t c = 0; c < 264; ++c)
+		r.letterOf[c] = uint8_t(h.cls[c]);
+	r.finalTag.resize(h.states);
+	for (uint32_t st = 0; st < h.states; ++st)
+		r.finalTag[st] = (h.flags[st] & kFinal) ? 1 : 0;
+	r.lrows.swap(rows);
+	r.initialAct = initialAct;
+	r.maxLen = 65000u / maxMult;   // (+ the two marks and Initialize: 65 002 x 1, 32 502 x 2, ... all below 65 536)
+	r.nreg = nreg;
+}
+
+void FreeHalfRowsDevice(HalfRowsDevice* d)
+{
+	if (d->lrows) (void)hipFree(d->lrows);
+	if (d->lactWords) (void)hipFree(d->lactWords);
+	if (d->letterOf) (void)hipFree(d->letterOf);
+	if (d->finalTag) (void)hipFree(d->finalTag);
+	*d = HalfRowsDevice();
+}
+
+template <class T>
+hipError_t PutHalf(T** dst, const std::vector<T>& v, size_t pad = 0)
+{
+	hipError_t e = hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(T) + pad);
+	if (e == hipSuccess)
+		e = hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+	return e;
+}
+}  // namespace
+
+void FreeHalfRows(pire_hip_table* t)
+{
+	int cur = -1;
+	(void)hipGetDevice(&cur);
+	for (int k = 0; k < kMaxDevices; ++k)
+		if (t->halfRowsDev[k].device >= 0) {
+			(void)hipSetDevice(k);
+			FreeHalfRowsDevice(&t->halfRowsDev[k]);
+		}
+	if (cur >= 0)
+		(void)hipSetDevice(cur);
+}
+
+int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                        uint32_t* outIdx, uint8_t* outFinal, uint32_t* outResults, hipStream_t stream, bool* done,
+                        uint32_t** overflow)
+{
+	*done = false;
+	*overflow = nullptr;
+	const int variant = GetConfig().counting_variant;
+	if (variant == 1 || n == 0 || n >= (1ull << 32) - 1 || !offsets)
+		return PIRE_HIP_OK;
+	int dev = 0, cus = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e == hipSuccess)
+		e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+	if (e != hipSuccess)
+		return HipFail(e, "device query");
+	if (dev < 0 || dev >= kMaxDevices || (variant != 2 && n < uint64_t(cus) * 256))
+		return PIRE_HIP_OK;
+	HalfRowsDevice image;
+	uint32_t nreg, initialAct, lactCount, maxLen;
+	{
+		std::lock_guard<std::mutex> lock(t->halfRowsMutex);
+		if (!t->halfRows.tried)
+			BuildHalfRows(t->host, t->halfRows);   // (reference numbering: nothing an adaptation changes)
+		const HalfRowsHost& h = t->halfRows;
+		if (!h.nreg)
+			return PIRE_HIP_OK;
+		HalfRowsDevice& d = t->halfRowsDev[dev];
+		if (d.device != dev) {
+			e = PutHalf(&d.lrows, h.lrows, 128);
+			if (e == hipSuccess)
+				e = PutHalf(&d.lactWords, h.lactWords);
+			if (e == hipSuccess)
+				e = PutHalf(&d.letterOf, h.letterOf, 8);
+			if (e == hipSuccess)
+				e = PutHalf(&d.finalTag, h.finalTag, 16);
+			if (e != hipSuccess) {
+				FreeHalfRowsDevice(&d);
+				return HipFail(e, "uploading the half-final rows");
+			}
+			d.device = dev;
+		}
+		image = d;
+		nreg = h.nreg;
+		initialAct = h.initialAct;
+		maxLen = h.maxLen;
+		lactCount = uint32_t(h.lactWords.size() / (2 * h.nreg));
+	}
+	CountingParams p;
+	memset(&p, 0, sizeof(p));
+	p.letterOf = image.letterOf;
+	p.lrows = image.lrows;
+	p.lactWords = image.lactWords;
+	p.lnreg = nreg;
+	p.lactCount = lactCount;
+	p.initialAct = initialAct;
+	p.maxLen = maxLen;
+	p.tags = image.finalTag;
+	p.states = t->host.states;
+	p.letters = t->host.letters;
+	p.regexps = t->host.regexps;
+	p.initial = t->host.initial;
+	p.flags = flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+	p.text = text;
+	p.offsets = offsets;
+	p.n = n;
+	p.outIdx = outIdx;
+	p.outFinal = outFinal;
+	p.outResults = outResults;
+	// strings by length class, as the counting scanners (order.hip)
+	void* orderScratch = nullptr;
+	if (LengthOrderWanted(n)) {
+		e = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(n), stream);
+		if (e != hipSuccess)
+			return HipFail(e, "hipMallocAsync(length order)");
+		bool serp = false;
+		if (int rc = BuildLengthOrder(offsets, n, orderScratch, stream, &p.order, &serp)) {
+			(void)hipFreeAsync(orderScratch, stream);
+			return rc;
+		}
+		p.serpentine = serp ? 1u : 0u;
+	}
+	void* list = nullptr;
+	e = hipMallocAsync(&list, (size_t(n) + 1) * 4, stream);
+	if (e == hipSuccess)
+		e = hipMemsetAsync(list, 0, 4, stream);
+	if (e == hipSuccess) {
+		p.overflow = static_cast<uint32_t*>(list);
+		const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * (p.letters + 1) * 8 + 15) & ~size_t(15)) + size_t(lactCount) * 2 * nreg * 4 + 512);
+		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 1023) / 1024, uint64_t(cus))));
+		switch (nreg) {
+		case 1: LaunchRow<1, true>(p, 2, rblocks, rowLds, stream, &e); break;
+		case 2: LaunchRow<2, true>(p, 2, rblocks, rowLds, stream, &e); break;
+		default: LaunchRow<4, true>(p, 2, rblocks, rowLds, stream, &e); break;
+		}
+	}
+	if (orderScratch)
+		(void)hipFreeAsync(orderScratch, stream);
+	if (e != hipSuccess) {
+		if (list)
+			(void)hipFreeAsync(list, stream);
+		return HipFail(e, "half-final row kernel");
+	}
+	NoteKernel("half_final_rows");
+	*overflow = static_cast<uint32_t*>(list);
+	*done = true;
+	return PIRE_HIP_OK;
+}
+
 }  // namespace pirehip
 
 using namespace pirehip;

@@ -107,7 +107,7 @@ struct HalfCounters<false> {
 };
 
 template <bool PACKED>
-__global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* outResults)
+__global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* outResults, const uint32_t* list)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const LdsLayout L = MakeLayout(p.hot, 0, kRotPitch, CompactBytes(p));
@@ -117,15 +117,18 @@ __global__ __launch_bounds__(1024) void HalfFinalKernel(ScanParams p, uint32_t* 
 			incHot[i] = p.incPerm[i];
 	LoadTableToLds(p, lds, L);
 
-	const uint64_t nrounds = (p.n + 63) / 64;
+	// with a list (the row kernel ran first on this stream and left the strings its 16-bit counters cannot hold): only those
+	const uint64_t todo = list ? list[0] : p.n;
+	const uint64_t nrounds = (todo + 63) / 64;
 	const uint32_t wavesPerBlock = blockDim.x >> 6;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t initial = p.startPerm;   // Initialize(): the launcher passes flags without BEGIN to FillParams
 	for (uint64_t task = uint64_t(blockIdx.x) * wavesPerBlock + (threadIdx.x >> 6); task < nrounds;
 	     task += uint64_t(gridDim.x) * wavesPerBlock) {
-		const uint64_t s = task * 64 + lane;
-		if (s >= p.n)
+		const uint64_t k = task * 64 + lane;
+		if (k >= todo)
 			continue;
+		const uint64_t s = list ? list[1 + k] : k;
 		HalfCounters<PACKED> cnt;
 		cnt.Init(p, outResults, s);
 		uint32_t st = initial;
@@ -440,15 +443,17 @@ int LaunchSuffix(const ScanParams& p0, bool longest, bool throughBegin, long lon
 	return PIRE_HIP_OK;
 }
 
-int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter)
+int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter,
+                    const uint32_t* list)
 {
 	if (p0.n == 0)
 		return PIRE_HIP_OK;
-	if (workCounter && RaggedActEligible(p0)) {
+	if (!list && workCounter && RaggedActEligible(p0)) {
 		NoteKernel("ragged_half_final");
 		return LaunchRaggedHalfFinal(p0, workCounter, outResults, stream);
 	}
-	NoteKernel("half_final");
+	if (!list)
+		NoteKernel("half_final");
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
@@ -464,9 +469,9 @@ int LaunchHalfFinal(const ScanParams& p0, uint32_t* outResults, hipStream_t stre
 	const unsigned threads = unsigned(ExactBlockThreads(p.n));
 	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + threads - 1) / threads, uint64_t(cus) * 2)));
 	if (packed)
-		hipLaunchKernelGGL(HalfFinalKernel<true>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults);
+		hipLaunchKernelGGL(HalfFinalKernel<true>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults, list);
 	else
-		hipLaunchKernelGGL(HalfFinalKernel<false>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults);
+		hipLaunchKernelGGL(HalfFinalKernel<false>, dim3(blocks), dim3(threads), ldsBytes, stream, p, outResults, list);
 	e = hipGetLastError();
 	if (e != hipSuccess)
 		return HipFail(e, "half-final kernel launch");

@@ -201,8 +201,29 @@ inline unsigned long long* WorkSlotOf(unsigned long long* base, uint32_t k)
 
 namespace pirehip { constexpr int kMaxDevices = 64; }
 
+namespace pirehip {
+// HalfFinalScanner counting on CountingRowKernel (counting.hip): the table as letter-indexed rows with the increments
+// of the TARGET state as the step's action, reference numbering (adaptation does not touch it); built when first needed.
+struct HalfRowsHost {
+	bool tried = false;
+	uint32_t nreg = 0, initialAct = 0, maxLen = 65000;
+	std::vector<uint32_t> lrows, lactWords;   // as CountingHost::lrows / lactWords
+	std::vector<uint8_t> letterOf, finalTag;  // [264] letter of every Char; [states] bit 0 = Final
+};
+struct HalfRowsDevice {
+	int device = -1;
+	uint32_t* lrows = nullptr;
+	uint32_t* lactWords = nullptr;
+	uint8_t* letterOf = nullptr;
+	uint8_t* finalTag = nullptr;
+};
+}  // namespace pirehip
+
 struct pire_hip_table {
 	pirehip::HostTable host;
+	pirehip::HalfRowsHost halfRows;
+	pirehip::HalfRowsDevice halfRowsDev[pirehip::kMaxDevices];
+	std::mutex halfRowsMutex;
 	// One image per HIP device (devs[d].device == d once uploaded), so that one handle serves every GPU of the node,
 	// from one host thread or from several.  Guarded by uploadMutex; the run entry points COPY the image's pointers
 	// while holding it (UploadTable) and never look at devs[] afterwards.
@@ -648,7 +669,15 @@ void ChooseHotAndPermuteExported(HostTable& t);
 int LaunchRaggedPrefix(const ScanParams& p, unsigned long long* workCounter, bool longest, bool throughEnd,
                        long long* outLen, hipStream_t stream);
 int LaunchStep(const ScanParams& p, uint32_t* stateIdx, uint64_t n, uint32_t cls, hipStream_t stream);
-int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter);
+int LaunchHalfFinal(const ScanParams& p, uint32_t* outResults, hipStream_t stream, unsigned long long* workCounter,
+                    const uint32_t* list = nullptr);
+// counting.hip: dense HalfFinal counting on the row kernel.  *done = false: not this table / batch.  Strings the 16-bit
+// counters cannot hold are left on `*overflow` (device: [0] = count, then string indices; stream-ordered memory the
+// caller frees) for LaunchHalfFinal(.., list).
+int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
+                        uint32_t* outIdx, uint8_t* outFinal, uint32_t* outResults, hipStream_t stream, bool* done,
+                        uint32_t** overflow);
+void FreeHalfRows(pire_hip_table* t);
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
                  unsigned long long* workCounter);
 // pair.hip: two scanners in one pass over fixed-length records (run.h:229-241)

@@ -78,7 +78,7 @@ def test_counting_row_kernel_owns_its_landing_registers():
     system still owes data to it, or the other way round, is a silently wrong count), and no scratch."""
     src = os.path.join(ROOT, "pire_amd", "csrc", "counting.hip")
     res = {k: v for k, v in resources("counting.hip").items() if "CountingRowKernel" in k or "CaptureRowKernel" in k}
-    assert len(res) == 13, sorted(res)
+    assert len(res) == 16, sorted(res)
     for name, r in res.items():
         assert r["VGPRs"] + r.get("AGPRs", 0) <= 128, (name, r)   # 16 waves per CU
         assert r.get("ScratchSize", -1) <= 64, (name, r)          # a few per-pass values, no array
@@ -110,7 +110,7 @@ def test_counting_row_kernel_owns_its_landing_registers():
                 assert op in ("global_load_dwordx4", "v_accvgpr_read_b32"), (body, line)
                 if op == "global_load_dwordx4":
                     assert re.search(r"global_load_dwordx4 a\[\d+:\d+\], v\[\d+:\d+\], off", line), (body, line)
-    assert seen == 13
+    assert seen == 16
 
 
 def _inflight():

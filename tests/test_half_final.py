@@ -120,3 +120,34 @@ def test_gpu_half_final_many_regexps_and_big_table(pa, tmp_path):
     oi, of, orr = o.run_half_final(data.reshape(-1), offs)
     gi, gf, gr = t.run_half_final(data.reshape(-1), offs)
     assert (gi == oi).all() and (gf == of).all() and (gr == orr).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", half_cases(), ids=lambda c: c["name"])
+def test_gpu_half_final_on_the_row_kernel(case, pa):
+    """Dense HalfFinal counting on the counting scanners' row kernel (round 4: whole text lines per lane, the increments
+    of the target state as the step's action): every Begin/End combination, strings longer than the 16-bit counters hold
+    (they go through the one-string-per-lane kernel, from the row kernel's list), empty strings -- against the oracle
+    and against the kernels of round 3."""
+    from pire_amd import binding as pb
+
+    blob = H.load_blob(case["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(23)
+    many = H.random_strings(rng, 5000, 400, b"abcde w") + [b""] * 70 + H.random_strings(rng, 300, 100)
+    many += [b"ab ab c " * 9000, b"b" * 65000, b"a" * 65001, b"abc" * 30000]
+    took = 0
+    for flags in (3, 0, 1, 2):
+        oi, of, orr = o.run_half_final(*ob.pack_strings(many), flags=flags)
+        with pb.config(counting_variant=2, no_ragged_act=1):
+            gi, gf, gr = t.run_half_final(*H.pack(many), flags=flags)
+            took += pb.last_kernel() == "half_final_rows"
+        assert (gi == oi).all() and (gf == of).all() and (gr == orr).all(), (flags, pb.last_kernel())
+        with pb.config(counting_variant=1, no_ragged_act=1):
+            hi, hf, hr = t.run_half_final(*H.pack(many), flags=flags)
+            assert pb.last_kernel() == "half_final"
+        assert (hi == oi).all() and (hf == of).all() and (hr == orr).all(), flags
+    info = t.info
+    if info.regexps <= 8 and info.letters <= 255:
+        assert took == 4, "a table of %d states x %d letters, %d regexps should have taken the row kernel" % (info.states, info.letters, info.regexps)
+    assert orr.sum() > 0

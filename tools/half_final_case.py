@@ -49,8 +49,8 @@ for _ in range(4):
     torch.cuda.synchronize()
     ts.append(a.elapsed_time(b))
 ms = min(ts[1:])
-print("half_final %s (pattern %s, %d states, %d regexps): %d strings, %.3f GiB: %.3f ms -> %.1f GB/s; matches counted: %s"
-      % (name, case["pattern"], t.Size, R, m, total / 2**30, ms, total / ms / 1e6, res.sum(dim=0).tolist()))
+print("half_final[%s] %s (pattern %s, %d states, %d regexps): %d strings, %.3f GiB: %.3f ms -> %.1f GB/s; matches counted: %s"
+      % (pb.last_kernel(), name, case["pattern"], t.Size, R, m, total / 2**30, ms, total / ms / 1e6, res.sum(dim=0).tolist()))
 # reference on the host (a sample), same bytes
 if ob.ref_available():
     r = ob.RefHalfFinalScanner.load(blob)
