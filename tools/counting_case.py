@@ -15,7 +15,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "count_glued3_advanced"
 case = [c for c in H.golden()["counting"] if c["name"] == name][0]
 blob = H.load_blob(case["blob"])
 t = pire_amd.CountingTable(blob, case["kind"])
-m = 1 << 20
+m = 1 << int(os.environ.get("COUNTING_LOG2_STRINGS", "20"))
 rng = np.random.RandomState(3)
 # COUNTING_FIXED_LEN=544: every string that long (how much of the time is lanes waiting for the longest string of their wave)
 lens = rng.randint(64, 1024, size=m).astype(np.uint64)
