@@ -16,5 +16,7 @@ cp $S/bench_slow_wide.jsonl $P/r04_bench_slow_wide.jsonl
 cp $S/ragged_cases.log $P/r04_ragged_cases.log
 for c in urls loglines; do cp $S/ragged_pmc_${c}_v1.txt $P/r04_ragged_pmc_${c}.txt; cp $S/ragged_pmc_${c}_v0.txt $P/r04_stream_pmc_${c}.txt; done
 for f in prefix half_final counting actions long_strings capture pair host_call_latency shim; do cp $S/$f.log $P/r04_final_$f.log; done
-for f in counting_variants capture_variants slow_ragged; do cp $S/$f.log $P/r04_final_$f.log; done
+for f in counting_variants capture_variants half_final_variants counting_many_regexps slow_ragged slow_ragged_nostats; do cp $S/$f.log $P/r04_final_$f.log; done
 cp $S/counting_kernel_stats.txt $P/r04_counting_kernel_stats.txt
+cp gpurun_out/final_r04.log $P/r04_final_run.log
+python tools/fill_design_tables.py

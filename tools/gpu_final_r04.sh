@@ -90,6 +90,9 @@ for name in count_glued3_advanced count0_advanced count0_basic; do
   done
 done | tee $OUT/counting_variants.log
 for v in 1 0; do PIRE_HIP_COUNTING_VARIANT=$v timeout 400 python tools/capture_case.py 2>&1 | grep "^capture" | sed "s/^/variant=$v: /"; done | tee $OUT/capture_variants.log | cut -c1-220
+for n in half_5 half_4 half_3 half_2; do for v in 1 0; do echo -n "variant=$v: "; PIRE_HIP_COUNTING_VARIANT=$v timeout 300 python tools/half_final_case.py $n 2>&1 | grep "^half_final\|parity" | tr '\n' ' ' | cut -c1-420; echo; done; done | tee $OUT/half_final_variants.log | cut -c1-200
+timeout 300 python tools/debug/counting_rows_wide.py 2>&1 | grep -v amdgpu.ids | tee $OUT/counting_many_regexps.log | cut -c1-200
+timeout 300 python tools/slow_ragged_case.py 2>&1 | grep "^slow" | tee $OUT/slow_ragged_nostats.log | cut -c1-220
 PIRE_HIP_SLOW_STATS=1 timeout 300 python tools/slow_ragged_case.py 2>&1 | grep "^slow\|pire_hip slow" | tee $OUT/slow_ragged.log | cut -c1-220
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_counting -o stats -- python tools/counting_case.py count_glued3_advanced > /dev/null 2>&1; grep "Counting\|Order\|Length" $OUT/stats_counting/stats_kernel_stats.csv | cut -c1-200 | tee $OUT/counting_kernel_stats.txt
 find $OUT -name "*.csv" -size +1M -delete; find $OUT -name "*.db" -delete
