@@ -562,6 +562,11 @@ typedef struct pire_hip_counting_info {
 int pire_hip_counting_table_create(const void* save_blob, size_t len, pire_hip_counting_table** out);
 void pire_hip_counting_table_destroy(pire_hip_counting_table* t);
 int pire_hip_counting_table_get_info(const pire_hip_counting_table* t, pire_hip_counting_info* out);
+/* Which device forms the table has (performance only; every form gives the same results): out[0] = counter registers of
+ * the 16-bit-entry form (0: none), out[1] = its LDS bytes; out[2] = 1 if the byte-indexed row form applies (<= 64 states),
+ * out[3] = its LDS bytes; out[4] = counter registers of the letter-indexed row form (0: none), out[5] = its LDS bytes,
+ * out[6] = its distinct actions; out[7] = 0. */
+int pire_hip_counting_table_forms(const pire_hip_counting_table* t, uint32_t out[8]);
 
 /*
  * Per string i: Initialize; Begin() if flags & BEGIN; Run; End() if flags & END (tests/count_ut.cpp:54-63), then

@@ -160,6 +160,7 @@ ABI = [
     ("pire_hip_counting_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     ("pire_hip_counting_table_destroy", None, [C.c_void_p]),
     ("pire_hip_counting_table_get_info", C.c_int, [C.c_void_p, C.POINTER(CountingInfo)]),
+    ("pire_hip_counting_table_forms", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32 * 8)]),
     ("pire_hip_counting_run", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     ("pire_hip_capture_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
@@ -583,6 +584,13 @@ class CountingTable:
     LettersCount = property(lambda s: s.info.letters)
     RegexpsCount = property(lambda s: s.info.regexps)
     initial = property(lambda s: s.info.initial)
+
+    def forms(self) -> dict:
+        """Which device forms the table has (pire_hip_counting_table_forms)."""
+        out = (C.c_uint32 * 8)()
+        _check(lib().pire_hip_counting_table_forms(self._h, C.byref(out)))
+        return {"packed_nreg": out[0], "packed_lds": out[1], "byte_rows": bool(out[2]), "byte_rows_lds": out[3],
+                "letter_rows_nreg": out[4], "letter_rows_lds": out[5], "letter_rows_actions": out[6]}
 
     def run(self, text, offsets, flags=FLAG_BEGIN | FLAG_END):
         """(StateIndex[n], Result[n, regexps]) for host strings."""

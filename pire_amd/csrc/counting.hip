@@ -1835,6 +1835,29 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+int pire_hip_counting_table_forms(const pire_hip_counting_table* t, uint32_t out[8])
+try {
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	const CountingHost& h = t->host;
+	memset(out, 0, 8 * sizeof(uint32_t));
+	out[0] = h.dense.empty() ? 0 : h.nreg;
+	out[1] = out[0] ? uint32_t(size_t(h.states) * 512 + 256 * 2 * h.nreg * 4) : 0;
+	out[2] = (out[0] && h.nreg <= 4 && h.states <= kCountingRowStates) ? 1 : 0;
+	out[3] = out[2] ? uint32_t(((size_t(h.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * h.nreg * 4) : 0;
+	out[4] = h.lrows.empty() ? 0 : h.lnreg;
+	if (out[4]) {
+		const uint32_t count = uint32_t(h.lactWords.size() / (2 * h.lnreg));
+		out[5] = uint32_t(((size_t(h.states + 1) * (h.letters + 1) * 8 + 15) & ~size_t(15)) + size_t(count) * 2 * h.lnreg * 4 + 512);
+		out[6] = count - 1;
+	}
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();
+}
+
 int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                           uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* streamPtr)
 try {

@@ -311,3 +311,34 @@ def test_gpu_row_kernels_with_text_at_any_alignment(pa, shift):
         widx, wfin, _, wbeg, wend = want
         assert (idx.cpu().numpy().astype(np.uint32) == widx).all() and (fin.cpu().numpy() == wfin).all()
         assert (bg.cpu().numpy() == wbeg).all() and (en.cpu().numpy() == wend).all() and (wbeg >= 0).sum() > 0
+
+
+def test_counting_table_forms_on_the_host(pa):
+    """Which device forms BuildDenseCounting / BuildLetterRows give a table (no GPU needed): the golden tables get the
+    16-bit-entry form, the byte-indexed rows (<= 64 states) and the letter-indexed rows; glued scanners of hundreds of
+    states keep the letter-indexed rows as long as (states + 1) x (letters + 1) entries and their actions fit 150 KB."""
+    for case in cases():
+        t = pa.CountingTable(H.load_blob(case["blob"]), case["kind"])
+        f = t.forms()
+        if case["kind"] == 2 or t.RegexpsCount > 8:      # NoGlueLimitCountingScanner: action lists, not bit words
+            assert f["packed_nreg"] == 0 and f["letter_rows_nreg"] == 0 and not f["byte_rows"], (case["name"], f)
+            continue
+        nreg = 1 if t.RegexpsCount <= 2 else 2 if t.RegexpsCount <= 4 else 4
+        assert f["packed_nreg"] == nreg and f["letter_rows_nreg"] == nreg, (case["name"], f)
+        assert f["byte_rows"] == (t.Size <= 64) and f["byte_rows_lds"] == (((t.Size + 1) * 2056 + 15) // 16 * 16 + 256 * 8 * nreg if t.Size <= 64 else 0)
+        assert f["letter_rows_lds"] <= 150 * 1024 and f["letter_rows_actions"] >= 1
+        assert f["letter_rows_lds"] == ((t.Size + 1) * (t.LettersCount + 1) * 8 + 15) // 16 * 16 + (f["letter_rows_actions"] + 1) * 8 * nreg + 512
+    if not ob.ref_available():
+        return
+    res_ = ["[a-z]+", "http", "abc", "[0-9]+", "e", "th", "ing"]
+    seps = ["\\s", ".*", ".*", "\\s", ".*", ".*", ".*"]
+    small = pa.CountingTable(ob.RefCountingScanner.compile(0, res_, seps).save(), 0)
+    big = pa.CountingTable(ob.RefCountingScanner.compile(1, res_, seps).save(), 1)
+    fs, fb = small.forms(), big.forms()
+    assert 64 < small.Size <= 255 and fs["packed_nreg"] == 4 and not fs["byte_rows"] and fs["letter_rows_nreg"] == 4
+    assert big.Size > 255 and fb["packed_nreg"] == 0 and fb["letter_rows_nreg"] == 4 and fb["letter_rows_actions"] > 255
+    assert fb["letter_rows_lds"] <= 150 * 1024
+    # a table whose rows do not fit: 16 glued regexps have no packed form at all
+    many = ["a", "b", "c", "ab", "bc", "ca", "[ab]+", "[bc]+", "d", "abc"]
+    wide = pa.CountingTable(ob.RefCountingScanner.compile(1, many, [".*"] * len(many)).save(), 1)
+    assert wide.forms()["letter_rows_nreg"] == 0
