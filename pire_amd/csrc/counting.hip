@@ -407,6 +407,8 @@ __device__ __forceinline__ void LandTile(const AccTile& acc, u32x4 (&r)[8])
 
 constexpr uint32_t kCountingRowStates = 64;
 constexpr uint32_t kCountingRowPitch = 257 * 8;
+constexpr uint32_t kCaptureRowPitch = 257 * 16;    // CaptureRowKernel: 16-byte entries
+constexpr uint32_t kCaptureRowStates = 34;         // (34 + 1) x 4 112 bytes = 141 KB
 
 // LETTERS: rows indexed by the table's own letters (a byte is translated first: one more LDS read, off the dependent
 // chain) -- (states + 1) x (letters + 1) entries, so tables of hundreds of states fit; without it rows of 257 entries
@@ -943,18 +945,20 @@ int Bad(const char* msg)
 __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	typedef uint32_t Pair __attribute__((ext_vector_type(2)));
-	typedef const __attribute__((address_space(3))) Pair* LdsPair;
-	const uint32_t sinkRow = p.states * kCountingRowPitch;
+	typedef uint32_t Quad __attribute__((ext_vector_type(4)));
+	typedef const __attribute__((address_space(3))) Quad* LdsQuad;
+	constexpr uint32_t kPitch = kCaptureRowPitch, kIdle = 256u * 16u;
+	const uint32_t sinkRow = p.states * kPitch;
 	for (uint32_t i = threadIdx.x; i < 257; i += blockDim.x)
-		*reinterpret_cast<uint2*>(lds + sinkRow + i * 8u) = uint2{sinkRow, 0u};
+		*reinterpret_cast<uint4*>(lds + sinkRow + i * 16u) = uint4{sinkRow, 0u, 0u, 0u};
 	for (uint32_t i = threadIdx.x; i < p.states * 256; i += blockDim.x) {
 		const uint32_t e = p.dense[i], a = e >> 8;
-		*reinterpret_cast<uint2*>(lds + (i >> 8) * kCountingRowPitch + (i & 255u) * 8u) =
-			uint2{(e & 0xFFu) * kCountingRowPitch, (a & 1u) ? 1u : (a & 2u)};
+		// the action as two masks: BeginCapture, EndCapture alone (capture.h:96-102: Begin wins when both are set)
+		*reinterpret_cast<uint4*>(lds + (i >> 8) * kPitch + (i & 255u) * 16u) =
+			uint4{(e & 0xFFu) * kPitch, (a & 1u) ? ~0u : 0u, (!(a & 1u) && (a & 2u)) ? ~0u : 0u, 0u};
 	}
 	for (uint32_t i = threadIdx.x; i < p.states; i += blockDim.x)
-		*reinterpret_cast<uint2*>(lds + i * kCountingRowPitch + 2048u) = uint2{i * kCountingRowPitch, 0u};
+		*reinterpret_cast<uint4*>(lds + i * kPitch + kIdle) = uint4{i * kPitch, 0u, 0u, 0u};
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	constexpr uint32_t npos = ~uint32_t(0);
@@ -975,30 +979,32 @@ __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 		const uint64_t line0 = first & ~uint64_t(127);
 		const uint32_t lead = uint32_t(first - line0);
 		const uint32_t windows = len ? (lead + len + 127u) >> 7 : 0u;
-		uint32_t row = p.initial * kCountingRowPitch, pend = 0;
+		uint32_t row = p.initial * kPitch, pendB = 0, pendE = 0;
 		uint32_t begin = npos, end = npos, hasBegin = 0, hasEnd = 0;
 		// TakeAction (capture.h:96-102) of the step before the one at position `at`
 		auto take = [&](uint32_t at) __attribute__((always_inline)) {
 			const uint32_t open = ~(hasBegin & hasEnd);
-			const uint32_t selB = uint32_t(int32_t(pend << 31) >> 31) & open;
-			const uint32_t selE = uint32_t(int32_t(pend << 30) >> 31) & open;
+			const uint32_t selB = pendB & open;
+			const uint32_t selE = pendE & open;
 			begin = (at & selB) | (begin & ~selB);
 			end = (at & selE) | (end & ~selE);
 			hasBegin |= selB;
 			hasEnd |= selE;
 		};
 		auto step = [&](uint32_t entryOffset, uint32_t at) __attribute__((always_inline)) {
-			const Pair next = *reinterpret_cast<LdsPair>(static_cast<uintptr_t>(row + entryOffset));
+			const Quad next = *reinterpret_cast<LdsQuad>(static_cast<uintptr_t>(row + entryOffset));
 			take(at);
 			row = next.x;
-			pend = next.y;
+			pendB = next.y;
+			pendE = next.z;
 		};
 		auto mark = [&](uint32_t which, uint32_t at) __attribute__((always_inline)) {
-			const uint32_t m = p.denseMarks[(row / kCountingRowPitch) * 2 + which];
+			const uint32_t m = p.denseMarks[(row / kPitch) * 2 + which];
 			take(at);
-			row = (m & 0xFFu) * kCountingRowPitch;
+			row = (m & 0xFFu) * kPitch;
 			const uint32_t a = m >> 8;
-			pend = (a & 1u) ? 1u : (a & 2u);
+			pendB = (a & 1u) ? ~0u : 0u;
+			pendE = (!(a & 1u) && (a & 2u)) ? ~0u : 0u;
 		};
 		// `at` of a step = the string's byte index it consumes (BeginMark: -1, EndMark: len); its own position in steps
 		// is at + beginStep, the position of the step whose action it applies one less
@@ -1026,10 +1032,10 @@ __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 						for (int w = 0; w < 4; ++w) {
 							const uint32_t x = tile[q][w];
 							const uint32_t j = 16u * q + 4u * w;
-							step((x & 0xFFu) * 8u, at + j);
-							step(((x >> 8) & 0xFFu) * 8u, at + j + 1u);
-							step(((x >> 16) & 0xFFu) * 8u, at + j + 2u);
-							step((x >> 24) * 8u, at + j + 3u);
+							step((x & 0xFFu) * 16u, at + j);
+							step(((x >> 8) & 0xFFu) * 16u, at + j + 1u);
+							step(((x >> 16) & 0xFFu) * 16u, at + j + 2u);
+							step((x >> 24) * 16u, at + j + 3u);
 							__builtin_amdgcn_sched_barrier(0);
 						}
 					row = idle ? keep : row;
@@ -1040,10 +1046,10 @@ __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 						for (int w = 0; w < 4; ++w) {
 							const uint32_t x = tile[q][w];
 							const uint32_t j = 16u * q + 4u * w;
-							step(at + j < len ? (x & 0xFFu) * 8u : 2048u, at + j);
-							step(at + j + 1u < len ? ((x >> 8) & 0xFFu) * 8u : 2048u, at + j + 1u);
-							step(at + j + 2u < len ? ((x >> 16) & 0xFFu) * 8u : 2048u, at + j + 2u);
-							step(at + j + 3u < len ? (x >> 24) * 8u : 2048u, at + j + 3u);
+							step(at + j < len ? (x & 0xFFu) * 16u : kIdle, at + j);
+							step(at + j + 1u < len ? ((x >> 8) & 0xFFu) * 16u : kIdle, at + j + 1u);
+							step(at + j + 2u < len ? ((x >> 16) & 0xFFu) * 16u : kIdle, at + j + 2u);
+							step(at + j + 3u < len ? (x >> 24) * 16u : kIdle, at + j + 3u);
 							__builtin_amdgcn_sched_barrier(0);
 						}
 				}
@@ -1061,7 +1067,7 @@ __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 		}
 		if (ok) {
 			const uint64_t s = p.order ? p.order[k] : k;   // read again: two registers less across the window loop
-			const uint32_t st = row / kCountingRowPitch;
+			const uint32_t st = row / kPitch;
 			if (p.outIdx)
 				p.outIdx[s] = st;
 			if (p.outFinal)
@@ -2120,7 +2126,7 @@ try {
 		// block of 16 waves a CU then holds; pire_hip_config.counting_variant as for the counting scanners.  That kernel
 		// does take its strings by length: a line is a line wherever the neighbouring lanes read.
 		const int variant = GetConfig().counting_variant;
-		const bool rows = p.dense && !(flags & PIRE_HIP_RUN_GENERIC) && p.states <= kCountingRowStates && variant != 1 &&
+		const bool rows = p.dense && !(flags & PIRE_HIP_RUN_GENERIC) && p.states <= kCaptureRowStates && variant != 1 &&
 		                  (variant == 2 || p.n >= uint64_t(cus) * 256);
 		if (p.offsets && LengthOrderWanted(p.n) && (GetConfig().capture_by_length || (rows && !GetConfig().no_length_order))) {
 			le = hipMallocAsync(&orderScratch, LengthOrderScratchBytes(p.n), stream);
@@ -2132,7 +2138,7 @@ try {
 			p.serpentine = serp ? 1u : 0u;
 		}
 		if (rows) {
-			const uint32_t rowLds = uint32_t(size_t(p.states + 1) * kCountingRowPitch);
+			const uint32_t rowLds = uint32_t(size_t(p.states + 1) * kCaptureRowPitch);
 			le = SetDynamicLds(reinterpret_cast<const void*>(CaptureRowKernel), rowLds);
 			if (le != hipSuccess)
 				return HipFail(le, "hipFuncSetAttribute(LDS)");

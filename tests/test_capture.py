@@ -88,7 +88,7 @@ def test_gpu_capture_parity(case, pa, cfg):
         assert all((x == y).all() for x, y in zip(a, d)), flags
         cfg.set(counting_variant=2)                                     # ... and that on whole text lines (round 4)
         r = t.capture(*H.pack(many), flags=flags)
-        assert pb.last_kernel() == ("capture_rows" if t.Size <= 64 else "capture_dense")
+        assert pb.last_kernel() == ("capture_rows" if t.Size <= 34 else "capture_dense")
         assert all((x == y).all() for x, y in zip(a, r)), flags
         cfg.set(ragged_act_always=1, no_ragged_act=0, counting_variant=0)
     assert a[2].sum() > 0
