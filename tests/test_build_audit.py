@@ -95,7 +95,7 @@ def test_counting_row_kernel_owns_its_landing_registers():
             # wait for the line on its way as well
             end = next(k for k in range(n, len(lines)) if lines[k].startswith(".Lfunc_end"))
             land = next(k for k in range(n, end) if re.search(r"v_accvgpr_read_b32 v\d+, a0\b", lines[k]))
-            last = max(k for k in range(n, end) if "ds_read_b64" in lines[k])
+            last = max(k for k in range(n, end) if "ds_read_b64" in lines[k] or "ds_read_b128" in lines[k])
             # (CaptureRowKernel reloads one value per window there -- 52 bytes of scratch per lane, measured with it)
             assert "Capture" in body or not [lines[k] for k in range(land, last) if "scratch_" in lines[k]], body
         elif line.startswith(".Lfunc_end"):
