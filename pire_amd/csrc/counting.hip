@@ -321,14 +321,19 @@ __global__ __launch_bounds__(1024) void CountingPackedKernel(CountingParams p)
 //     line is walked, transposed in registers (TransposeTile);
 //   * an entry IS the two addresses a step needs: 8 bytes per (state, byte) = { LDS offset of the next state's row,
 //     LDS offset of the action's words }, expanded from the u16 rows while the block copies them.  A step is one v_bfe,
-//     one v_lshl_add (row + byte * 8), one ds_read_b64, one ds_read_b128 of the pending action's words and the eight
-//     packed counter operations: no unpacking, and no branch around the action -- action 0 is a row of zeroes;
+//     one v_lshl_add (row + byte * 8), one ds_read_b64, one ds_read_b128 of the pending action's words and three packed
+//     operations per counter register (below): no unpacking, and no branch around the action -- action 0 is a row of
+//     zeroes;
 //   * the bytes of a line in front of the string's first or behind its last take a 257th entry of the row, { the row
 //     itself, action 0 }: a step that changes nothing, chosen by an add, a compare and a select.  Windows that lie
-//     inside the strings of all the lanes still at work take a copy of the walk without the three.
-// 2 KB of LDS per state, so one block of 16 waves per CU and tables of up to kCountingRowStates states (counting tables
-// have tens); larger ones keep the kernel above, and so do scanners of more than eight regexps (eight counter
-// registers: not built).  Same counters, same overflow list, same length order.
+//     inside the strings of all the lanes still at work take a copy of the walk without the three; lanes that are done
+//     sit in a sink row meanwhile.
+// Rows indexed by the byte cost 2 KB of LDS per state: tables of up to kCountingRowStates states (counting tables have
+// tens).  Larger ones take rows indexed by the table's own LETTERS -- the byte is translated first, one more LDS read off
+// the dependent chain -- and fit as long as (states + 1) x (letters + 1) entries and their distinct actions fit a CU's
+// LDS (template parameter LETTERS; 573 states x 21 letters with 7 regexps: 0.99 TB/s against 0.34).  One block of 16
+// waves per CU either way; up to eight regexps (four counter registers).  Same counters, same overflow list, same length
+// order.  HalfFinalScanner's match counting rides the same kernel (MODE 2: counters that are only added to).
 // The line on its way lands in ACCUMULATION registers a0..a31 -- by name: the load instructions write a[4j:4j+3] and
 // LandTile() reads a0..a31, whatever the compiler thinks.  To the compiler they are eight values that the loads define
 // in exactly those registers and LandTile() consumes from exactly those registers ("{a[0:3]}" constraints), alive
