@@ -16,6 +16,11 @@ Inputs are resident in HBM when the timed region starts.  Multi-GPU: one process
 by string index (rank r owns global strings [r*n, (r+1)*n)), no data-path collective; the only exchange is the
 all-reduce (RCCL) of the uint64[regexps+2] match counters per step.  Weak scaling.
 
+Wide working sets (BASELINE config 5 as north_star means it: transitions that do not fit the 255 dense rows):
+`--set dict_1k|dict_10k --corpus k32|k128|k512|k2048|k<words>` -- a dictionary scanner built the way the reference's
+samples/blacklist/blacklist.cpp builds one, over records of dictionary labels and filler words -- and `--set set_b_mix
+--corpus mix`; the line then carries `working_set` (distinct states visited, shares outside the dense / wide rows).
+
 Other workloads (informational lines of the same shape): `--set c2_single|set_b|set_d` (BASELINE configs 2 / 5a),
 `--set slow_x40_utf8` (config 5b, SlowScanner), `--corpus cxx` (the reference's own benchmark corpus,
 tools/bench/test_file, repeated as tools/bench/run-bench does, instead of the synthetic corpus; `--one-string` scans it
@@ -45,7 +50,10 @@ SEED_HELDOUT = 0x0DDBA11   # the corpus the dense-row ranking is learned on (nev
 WORKLOADS = {"set_a": "C3: 8 regexps glued via Scanner::Glue, LDS-resident dense rows",
              "c2_single": "C2: single Scanner hello\\s+w.+d$",
              "set_b": "C5a: 8 glued regexps, 8952-state table with HBM-resident transitions",
-             "set_d": "8 glued unanchored regexps (pire_ut.cpp patterns)"}
+             "set_d": "8 glued unanchored regexps (pire_ut.cpp patterns)",
+             "dict_1k": "C5 wide: dictionary Scanner of 1 000 domains (samples/blacklist construction, Surround()ed), 4 084 states",
+             "dict_10k": "C5 wide: dictionary Scanner of 10 000 domains (samples/blacklist construction, Surround()ed), 30 202 states",
+             "set_b_mix": "C5a table (8 glued regexps, 8 952 states) over fragments that keep its patterns half matched"}
 
 
 def kernel_sources_sha16() -> str:
@@ -69,9 +77,13 @@ def parse():
     ap.add_argument("--len", type=int, default=4096, help="bytes per string (headline: 4096)")
     ap.add_argument("--stride", type=int, default=0, help="bytes between strings in memory (default: --len, contiguous)")
     ap.add_argument("--set", default="set_a", help="golden pattern set (set_a = headline)")
-    ap.add_argument("--corpus", default="synthetic", choices=["synthetic", "cxx"],
+    ap.add_argument("--corpus", default="synthetic",
                     help="cxx: the reference's own benchmark corpus (tools/bench/test_file, C++ text) repeated to the "
-                         "batch size as run-bench:126-138 does, instead of the synthetic corpus")
+                         "batch size as run-bench:126-138 does, instead of the synthetic corpus; for the wide sets of "
+                         "tests/golden/wide.json (--set dict_1k|dict_10k|set_b_mix): one of their token corpora (k32 ... / mix)")
+    ap.add_argument("--walk", type=int, default=0, choices=[0, 1, 2],
+                    help="pire_hip_config.walk_variant: 0 the library's choice between the dense rows and the class-indexed "
+                         "walk, 1 always the dense rows, 2 always the class-indexed walk (same results)")
     ap.add_argument("--one-string", action="store_true", help="with --corpus cxx: the whole text as ONE string")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -365,12 +377,24 @@ def main():
 
     # The library re-ranks a table's dense rows by itself when scans keep leaving them (pire_hip_config.auto_adapt).
     # Here the ranking is learned explicitly, on a held-out corpus (step 1 below), and must not move afterwards: off.
-    pb.set_config(auto_adapt=1)
-    big = W.pattern_set(args.set)
+    pb.set_config(auto_adapt=1, walk_variant=args.walk)
+    wide_entry = None
+    try:
+        wide_entry = W.wide_set(args.set)   # tests/golden/wide.json: dictionary scanners, token-mixture corpora
+    except KeyError:
+        pass
+    if wide_entry:
+        if args.corpus == "synthetic":
+            args.corpus = sorted(wide_entry["samples"])[0]
+        big = {"blob": wide_entry["blob"],
+               "patterns": wide_entry.get("patterns") or [f"{wide_entry['words']} fixed strings joined with Fsm::operator|=, "
+                                                          f"{wide_entry['mode']} (samples/blacklist/blacklist.cpp:65-76)"]}
+    else:
+        big = W.pattern_set(args.set)
     blob = W.load_blob(big["blob"])
     table = pire_amd.Table(blob)
     table.upload()
-    plants = W.plants_for(big)
+    plants = None if wide_entry else W.plants_for(big)
     n = args.strings or (1 << args.log2_strings)
     length = args.len
     stride = args.stride or length
@@ -382,7 +406,15 @@ def main():
     first, last = pd.shard_range(n * world, rank, world)
     assert last - first == n
     base_text = None
-    if args.corpus == "cxx":
+    wide_base = None
+    if wide_entry:
+        # `nbase` distinct records of the token corpus (built on the host, numpy), repeated over the batch on the device:
+        # record i of rank r = base[(first + i) % nbase]
+        nbase = min(n, 16384)
+        assert n % nbase == 0
+        wide_base = W.wide_records(wide_entry, args.corpus, SEED, nbase, length)
+        text = torch.as_tensor(np.roll(wide_base, -(first % nbase), axis=0), device=dev).repeat(n // nbase, 1).contiguous()
+    elif args.corpus == "cxx":
         # the reference's benchmark text repeated over the whole (global) batch; this rank's shard starts at byte first*length
         base_text = cxx_corpus_bytes()
         f = len(base_text)
@@ -459,7 +491,11 @@ def main():
     heldout = None
     if not args.no_adapt:
         n2 = max(64, min(n, 1 << 18))
-        if args.corpus == "cxx":
+        if wide_entry:
+            n2 = min(n2, 16384)
+            text2 = torch.as_tensor(W.wide_records(wide_entry, args.corpus, SEED_HELDOUT, n2, length), device=dev)
+            heldout = f"token corpus {args.corpus!r}, seed {SEED_HELDOUT:#x}, {n2} records"
+        elif args.corpus == "cxx":
             # another cut of the same kind of text: the file reversed line by line would be another language; use the
             # text shifted by half a file and scanned as records of the same length
             f = len(base_text)
@@ -471,11 +507,14 @@ def main():
             pire_amd.corpus_fill_device(text2.data_ptr(), SEED_HELDOUT, 0, n2, length, stride, plants, stream)
             heldout = f"synthetic corpus, seed {SEED_HELDOUT:#x}, {n2} strings"
         n2r, l2r, s2r = (1, n2 * length, n2 * length) if args.one_string else (n2, length, stride)
-        for _ in range(3):
-            table.run_strided_device(text2.data_ptr(), n2r, l2r, s2r, flags, out_idx.data_ptr(), out_fin.data_ptr(), 0, 0,
-                                     stream)
-        torch.cuda.synchronize()
-        adapted_rows = table.adapt()
+        # (a wide table: a second round -- once adapt() has seen the scans leave the dense rows the library takes the
+        # class-indexed walk, whose own visit samples then rank the states beyond the dense rows)
+        for _ in range(2 if wide_entry else 1):
+            for _ in range(3):
+                table.run_strided_device(text2.data_ptr(), n2r, l2r, s2r, flags, out_idx.data_ptr(), out_fin.data_ptr(), 0, 0,
+                                         stream)
+            torch.cuda.synchronize()
+            adapted_rows += table.adapt()
         del text2
     # --- 2. the table as pire_hip_table_create ranks it (a-priori byte model, never adapted): a second handle, a short
     # timed leg on the timed corpus, reported as value_before_adapt.
@@ -538,7 +577,11 @@ def main():
                 break
             except (OSError, ValueError, KeyError):
                 pass
-        if args.corpus == "cxx":
+        if wide_entry:
+            data = (f"token corpus {args.corpus!r} of {args.set} (pire_amd/workloads.py wide_records, seed {SEED:#x}): "
+                    f"{wide_base.shape[0]} distinct records repeated over the batch")
+            shape = f"{'2^%d' % args.log2_strings if not args.strings else n} x {length} B records per GPU"
+        elif args.corpus == "cxx":
             data = (f"C++ source text: the reference's tools/bench/test_file ({len(base_text)} bytes) repeated to the batch size, "
                     "as tools/bench/run-bench:126-138 builds its big file")
             shape = f"ONE string of {n * length} B" if args.one_string else f"{n} x {length} B records"
@@ -565,6 +608,10 @@ def main():
                 "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), {shape}, "
                             f"Begin().Run().End() per string, match-count reduce",
                 "patterns": big["patterns"],
+                "walk": {"variant_asked": args.walk, "wide_rows": info.wide_states, "wide_lds_bytes": info.wide_lds_bytes,
+                         "measured_share_outside_dense_rows": round(float(info.outside_dense_share), 6),
+                         "measured_share_outside_wide_rows": round(float(info.outside_wide_share), 6),
+                         "shares_measured": bool(info.shares_measured)},
                 "table": {"states": info.states, "letters": info.letters, "regexps": info.regexps,
                           "ref_buf_bytes": int(info.ref_buf_size), "lds_dense_rows": info.hot_states,
                           "lds_table_bytes": info.lds_table_bytes, "rows_promoted_by_adapt": adapted_rows,
@@ -612,7 +659,14 @@ def main():
         assert int(total_counts[1]) == run_n * world, "match-count reduce lost strings"
         if not args.no_cpu and world == 1 and not args.one_string:   # the reported CPU baseline belongs to the N=1 line
             sample = min(n, 1 << args.cpu_sample_log2)
-            if args.corpus == "cxx":
+            if wide_entry:
+                sample = min(sample, wide_base.shape[0])
+                host = wide_base[:sample]
+                # every string of the batch: the repeats of a base record must all have ended where the first one did
+                nb = wide_base.shape[0]
+                res["parity_of_repeats"] = bool((gpu_idx.reshape(-1, nb) == gpu_idx[:nb][None, :]).all() and
+                                                (gpu_fin.reshape(-1, nb) == gpu_fin[:nb][None, :]).all())
+            elif args.corpus == "cxx":
                 f = len(base_text)
                 host = np.resize(base_text, sample * length + f)[:sample * length].reshape(sample, length)
             else:
@@ -620,6 +674,16 @@ def main():
 
                 host = ob.corpus_fill(SEED, 0, sample, length, plants, threads=min(os.cpu_count() or 1, 256))
             res["cpu_baseline"] = cpu_baseline(blob, host, length, gpu_idx, gpu_fin)
+            if wide_entry:
+                from oracle import binding as ob   # the checker's visit counts: how many states this corpus walks through
+
+                k = min(256, host.shape[0])
+                v = np.sort(ob.OracleScanner(blob).visit_counts(host[:k].reshape(-1), np.arange(k + 1, dtype=np.uint64) * length))[::-1]
+                cum = np.cumsum(v.astype(np.float64)) / max(float(v.sum()), 1.0)
+                res["working_set"] = {"distinct_states_visited": int((v > 0).sum()), "sample": f"first {k} records",
+                                      "share_of_steps_outside_the_255_most_visited": round(1.0 - float(cum[min(254, len(cum) - 1)]), 6),
+                                      "share_of_steps_outside_the_wide_rows_most_visited":
+                                          round(1.0 - float(cum[min(max(info.wide_states, 1) - 1, len(cum) - 1)]), 6)}
         print(json.dumps(res))
         sys.stdout.flush()
     if world > 1 or args.force_dist:

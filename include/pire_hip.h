@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PIRE_HIP_ABI_VERSION 4
+#define PIRE_HIP_ABI_VERSION 5
 
 enum {
 	PIRE_HIP_OK        =  0,
@@ -148,6 +148,12 @@ typedef struct pire_hip_config {
 	                               /* fits.  Same results either way.                                                      */
 	uint32_t slow_stats;           /* 1: every SlowScanner call prints to stderr how many strings left the list kernel     */
 	                               /* (synchronises the stream: measurements)                                              */
+	uint32_t walk_variant;         /* fixed-length records of tables with more states than dense rows: 0 default = the     */
+	                               /* class-indexed walk (every row of the first ~1 700 states of the ranking in LDS, the  */
+	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
+	                               /* outside the 255 dense rows passes 0.3 % (measured by adapt(); 5 % of the a-priori    */
+	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
+	                               /* class-indexed walk.  Same results either way.                                        */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -177,6 +183,12 @@ typedef struct pire_hip_table_info {
 	                             exact re-walk of a chunk that left the dense rows stays in LDS for them */
 	uint32_t scanner_type;    /* ScannerIOTypes of the ingested blob (scanners/common.h:34-40): 1 Scanner, 2 SimpleScanner */
 	uint32_t reserved;
+	uint32_t wide_states;     /* states with a class-indexed row in the wide walk's LDS image (0: table fits the dense rows) */
+	uint32_t wide_lds_bytes;  /* LDS bytes of that image per workgroup */
+	float outside_dense_share;   /* share of the ranking's mass (scans seen by adapt(), else the a-priori byte model) on   */
+	float outside_wide_share;    /* states without a dense row / without a wide row                                        */
+	uint32_t shares_measured;    /* 1: those shares come from visit counters                                               */
+	uint32_t reserved2;
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */
@@ -273,6 +285,15 @@ int64_t pire_hip_table_next(const pire_hip_table* t, uint32_t state_idx, uint32_
  * or hot_states (= trap: the lane leaves the LDS-resident set).  Either pointer may be NULL.
  */
 int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8_t* hot_rows);
+/*
+ * ... and of the class-indexed walk's LDS image (pire_hip_config.walk_variant; tables with more states than dense rows):
+ * *wide_states device ids [0, wide_states) have a row, *pitch bytes apart, the first at LDS byte address *rows_offset;
+ * rows[(wide_states + 1) * pitch / 2] (cap = its capacity in u16 entries; NULL: only the geometry): per row `letters`
+ * entries = LDS address / 4 of the target state's row (the last row, the escape row, for targets without one), then the
+ * row's device id, then its flags (1 Final, 2 Dead, 4 every transition a self loop).  wide_states == 0: no such image.
+ */
+int pire_hip_table_wide_layout(const pire_hip_table* t, uint16_t* rows, size_t cap, uint32_t* wide_states, uint32_t* pitch,
+                               uint32_t* rows_offset);
 
 /* ---- the hot path -------------------------------------------------------------------------------- */
 

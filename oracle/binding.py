@@ -98,6 +98,8 @@ def oracle_lib():
         L.oracle_run.restype = None
         L.oracle_run_shortcut.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u32p, u32p, u8p]
         L.oracle_run_shortcut.restype = None
+        L.oracle_visit_counts.argtypes = [C.c_void_p, C.c_void_p, u64p, C.c_uint64, C.c_uint32, u64p]
+        L.oracle_visit_counts.restype = None
         L.oracle_prefix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
         L.oracle_prefix.restype = None
         L.oracle_suffix.argtypes = [C.c_void_p, C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, i64p]
@@ -207,6 +209,15 @@ class OracleScanner:
             self._L.oracle_run(self._h, tp, _ptr(offsets, u64p), n, flags, _ptr(init, u32p),
                                _ptr(idx, u32p), _ptr(fin, u8p), threads)
         return idx, fin
+
+    def visit_counts(self, text, offsets, flags=FLAG_BEGIN | FLAG_END) -> np.ndarray:
+        """u64[states]: how many text bytes' steps ended in each state (working-set measurements)."""
+        text = _as_text(text)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        counts = np.zeros(self.size, dtype=np.uint64)
+        self._L.oracle_visit_counts(self._h, text.ctypes.data if text.size else None, _ptr(offsets, u64p), len(offsets) - 1,
+                                    flags, _ptr(counts, u64p))
+        return counts
 
     def run_strings(self, strings: Sequence[bytes], **kw):
         text, offs = pack_strings(strings)
@@ -417,6 +428,8 @@ def ref_lib():
         L.pire_ref_compile.restype = C.c_void_p
         L.pire_ref_load.argtypes = [C.c_void_p, C.c_size_t]
         L.pire_ref_load.restype = C.c_void_p
+        L.pire_ref_compile_dictionary.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.c_int]
+        L.pire_ref_compile_dictionary.restype = C.c_void_p
         L.pire_ref_free.argtypes = [C.c_void_p]
         L.pire_ref_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.pire_ref_save.restype = C.c_size_t
@@ -806,6 +819,14 @@ class RefScanner:
         pats = (C.c_char_p * n)(*[p.encode("latin-1") if isinstance(p, str) else p for p in patterns])
         opts = (C.c_char_p * n)(*[(o or "").encode() for o in (options or [""] * n)])
         return cls(L.pire_ref_compile(pats, opts, n, glue_max))
+
+    @classmethod
+    def compile_dictionary(cls, words: Sequence[bytes], surround: bool = False):
+        """samples/blacklist/blacklist.cpp:65-76: the words as fixed strings joined with |=, wrapped as the sample wraps
+        them (scheme, subdomains, path) or -- `surround` -- searched anywhere in the text (Fsm::Surround)."""
+        L = ref_lib()
+        arr = (C.c_char_p * len(words))(*[bytes(w) for w in words])
+        return cls(L.pire_ref_compile_dictionary(arr, len(words), 1 if surround else 0))
 
     @classmethod
     def load(cls, blob: bytes):

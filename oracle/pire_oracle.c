@@ -313,6 +313,27 @@ void oracle_run(const oracle_scanner* sc, const void* text, const uint64_t* offs
 	}
 }
 
+/* Where a batch's walks spend their steps: counts[StateIndex] += 1 for the state every text byte's step ENDS in
+ * (Step of run.h:50-57 on each byte of run.h:248-266's loop; the marks are not counted).  Measurement aid for the
+ * working-set figures of bench.py / DESIGN.md (how many distinct states a corpus visits); single-threaded. */
+void oracle_visit_counts(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
+                         uint32_t flags, uint64_t* counts)
+{
+	const uint8_t* t = (const uint8_t*)text;
+	uint64_t i;
+	for (i = 0; i < n; ++i) {
+		uint64_t st = sc->m.initial;
+		const uint8_t* p = t + offsets[i];
+		const uint8_t* e = t + offsets[i + 1];
+		if (flags & ORACLE_FLAG_BEGIN)
+			st = next_state(sc, st, ORACLE_BEGIN_MARK);
+		for (; p != e; ++p) {
+			st = next_state(sc, st, *p);
+			counts[state_index(sc, st)]++;
+		}
+	}
+}
+
 /* ------------------------------------------- HalfFinalScanner: the same table, counting TakeAction */
 
 /* HalfFinalScanner::TakeAction, half_final.h:156-164: if the state is Final, every entry of its final list

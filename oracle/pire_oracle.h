@@ -77,6 +77,10 @@ void oracle_run(const oracle_scanner* sc, const void* text, const uint64_t* offs
                 uint32_t flags, const uint32_t* init_idx, uint32_t* out_idx, uint8_t* out_final,
                 int threads);
 
+/* counts[StateIndex] += 1 for the state each text byte's step ends in (working-set measurements; single-threaded) */
+void oracle_visit_counts(const oracle_scanner* sc, const void* text, const uint64_t* offsets, uint64_t n,
+                         uint32_t flags, uint64_t* counts);
+
 /*
  * The same walk, but following the reference's production control flow: DoRun's head / aligned
  * body / tail split (run.h:187-226) and the ExitMasks shortcut skipping of multi.h:938-1000 using

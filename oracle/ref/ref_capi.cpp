@@ -162,6 +162,32 @@ void* pire_ref_compile(const char* const* patterns, const char* const* options, 
 	}
 }
 
+/* A dictionary scanner, built the way samples/blacklist/blacklist.cpp:65-76 (Generate) builds one: the words joined
+ * with Fsm::operator|= as fixed strings (Fsm().Append(word), no regexp syntax), then
+ *   mode 0: wrapped as the sample does -- "^([a-z]+://)?([A-Za-z0-9\\-]+\\.)*" + words + "(/.*)?$" -- and compiled with
+ *           Scanner(Fsm) (multi.h:123-131);
+ *   mode 1: the same words Surround()ed (fsm.cpp:1198-1203) like every pattern of tools/bench (bench.cpp:101-102): the
+ *           dictionary searched anywhere in a text. */
+void* pire_ref_compile_dictionary(const char* const* words, int n, int mode)
+{
+	try {
+		std::unique_ptr<RefScanner> h(new RefScanner);
+		Pire::Fsm re = Pire::Fsm::MakeFalse();
+		for (int i = 0; i < n; ++i)
+			re |= Pire::Fsm().Append(words[i]);
+		if (mode == 0)
+			re = Pire::Lexer("^([a-z]+://)?([A-Za-z0-9\\-]+\\.)*").Parse() + re + Pire::Lexer("(/.*)?$").Parse();
+		else
+			re.Surround();
+		Scanner(re).Swap(h->reloc);
+		h->nonreloc = NonrelocScanner(h->reloc);
+		return h.release();
+	} catch (const std::exception& e) {
+		SetErr(e.what());
+		return nullptr;
+	}
+}
+
 /* Load a Scanner::Save() blob -- multi.h:575-599. */
 void* pire_ref_load(const void* blob, size_t len)
 {

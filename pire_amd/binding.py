@@ -52,6 +52,12 @@ class TableInfo(C.Structure):
         ("compact_states", C.c_uint32),
         ("scanner_type", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("wide_states", C.c_uint32),
+        ("wide_lds_bytes", C.c_uint32),
+        ("outside_dense_share", C.c_float),
+        ("outside_wide_share", C.c_float),
+        ("shares_measured", C.c_uint32),
+        ("reserved2", C.c_uint32),
     ]
 
 
@@ -114,6 +120,7 @@ class Config(C.Structure):
         ("force_rccl", C.c_uint32),
         ("counting_variant", C.c_uint32),
         ("slow_stats", C.c_uint32),
+        ("walk_variant", C.c_uint32),
     ]
 
 
@@ -139,6 +146,8 @@ ABI = [
     ("pire_hip_table_letter_class", C.c_int, [C.c_void_p, C.c_uint32]),
     ("pire_hip_table_next", C.c_int64, [C.c_void_p, C.c_uint32, C.c_uint32]),
     ("pire_hip_table_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("pire_hip_table_wide_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                             C.POINTER(C.c_uint32)]),
     ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -367,6 +376,17 @@ class Table:
         h = np.empty((self.info.hot_states + 1, 256), dtype=np.uint8)
         _check(lib().pire_hip_table_layout(self._h, o.ctypes.data, h.ctypes.data))
         return o, h
+
+    def wide_layout(self):
+        """(rows u16[wide + 1, pitch / 2], wide_states, pitch, rows_offset): the class-indexed walk's LDS image (wide.hip);
+        rows is None for a table that fits the dense rows."""
+        w, pitch, off = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(lib().pire_hip_table_wide_layout(self._h, None, 0, C.byref(w), C.byref(pitch), C.byref(off)))
+        if not w.value:
+            return None, 0, pitch.value, off.value
+        rows = np.empty((w.value + 1, pitch.value // 2), dtype=np.uint16)
+        _check(lib().pire_hip_table_wide_layout(self._h, rows.ctypes.data, rows.size, C.byref(w), C.byref(pitch), C.byref(off)))
+        return rows, w.value, pitch.value, off.value
 
     def adapt(self) -> int:
         """Re-rank the LDS rows from the visit counters of earlier scans; returns the number of rows promoted."""

@@ -194,6 +194,13 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->trapSignal = d.trapSignalDev;
 	p->compactRows = d.compactRows;
 	p->compact = h.compact;
+	p->wideRows = d.wideRows;
+	p->next16 = d.next16;
+	p->visitWide = d.visitWide;
+	p->wide = d.wideRows ? h.wide : 0;
+	p->outsideDense = h.outsideDense;
+	p->outsideWide = h.outsideWide;
+	p->massMeasured = h.massMeasured;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
 	p->hotDeadLo = h.hotDeadLo;
@@ -272,6 +279,7 @@ pire_hip_config SeedFromEnvironment()
 	c.force_rccl = EnvU64("PIRE_HIP_FORCE_RCCL") != 0;
 	c.counting_variant = uint32_t(EnvU64("PIRE_HIP_COUNTING_VARIANT"));
 	c.slow_stats = EnvU64("PIRE_HIP_SLOW_STATS") != 0;
+	c.walk_variant = uint32_t(EnvU64("PIRE_HIP_WALK_VARIANT"));
 	return c;
 }
 
@@ -324,8 +332,10 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 		(void)hipEventRecord(ev0, stream);
 	}
 	const bool streamed = ragged && StreamEligible(p, totalBytesHint);
-	NoteKernel(tiled ? "tiled" : ragged ? "ragged" : "generic");
-	int rc = tiled ? LaunchTiled(p, stream) : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
+	// fixed-length records of a table whose scans keep leaving the dense rows: the class-indexed walk (wide.hip)
+	const bool wide = tiled && p.len >= 256 && WideWanted(p, GetConfig());
+	NoteKernel(wide ? "wide" : tiled ? "tiled" : streamed ? "stream" : ragged ? "ragged" : "generic");
+	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
 		if (rc == PIRE_HIP_OK) {
@@ -1028,6 +1038,11 @@ try {
 	out->compact_states = h.compact;
 	out->scanner_type = h.scannerType;
 	out->reserved = 0;
+	out->wide_states = h.wide;
+	out->wide_lds_bytes = h.wide ? MakeWideLayout(h.wide, h.letters, 0).total : 0;
+	out->outside_dense_share = h.outsideDense;
+	out->outside_wide_share = h.outsideWide;
+	out->shares_measured = h.massMeasured ? 1 : 0;
 	out->device_bytes = 0;   // all images (one per device the table has run on)
 	{
 		// devs[] is written by the first run on a device, under uploadMutex (found by ThreadSanitizer, round 4: this loop
@@ -1126,6 +1141,37 @@ try {
 		memcpy(orig_of_perm, h.origOfPerm.data(), h.origOfPerm.size() * sizeof(uint32_t));
 	if (hot_rows)
 		memcpy(hot_rows, h.hotRows.data(), h.hotRows.size());
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
+}
+
+int pire_hip_table_wide_layout(const pire_hip_table* t, uint16_t* rows, size_t cap, uint32_t* wide_states, uint32_t* pitch,
+                               uint32_t* rows_offset)
+try {
+	if (!t) {
+		SetError("null table");
+		return PIRE_HIP_EINVAL;
+	}
+	EnsureRanked(const_cast<pire_hip_table*>(t));
+	std::shared_lock<std::shared_mutex> stable(const_cast<pire_hip_table*>(t)->adaptMutex);
+	const HostTable& h = t->host;
+	const WideLayout wl = MakeWideLayout(h.wide, h.letters, 0);
+	if (wide_states)
+		*wide_states = h.wide;
+	if (pitch)
+		*pitch = wl.pitch;
+	if (rows_offset)
+		*rows_offset = wl.rowsOff;
+	if (rows && h.wide) {
+		const std::vector<uint16_t> img = BuildWideRows(h);
+		const size_t want = size_t(h.wide + 1) * wl.pitch / 2;
+		if (cap < want) {
+			SetError("wide layout: buffer too small");
+			return PIRE_HIP_EINVAL;
+		}
+		memcpy(rows, img.data(), want * sizeof(uint16_t));
+	}
 	return PIRE_HIP_OK;
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI

@@ -60,6 +60,7 @@ constexpr uint32_t kRotPitch = 260;
 constexpr uint32_t kMaxLdsCountRegexps = 1024;
 constexpr uint32_t kCheckSlot = 256;                     // visitHot[256]: failures seen by the checked kernel build
 constexpr uint32_t kTrapSlot = 257;                      // visitHot[257]: sampled traps since the image was uploaded (device total)
+constexpr uint32_t kWideTrapSlot = 258;                 // visitHot[258]: sampled chunks the WIDE walk left its rows in
 constexpr uint32_t kVisitHotSlots = 260;
 constexpr uint32_t kLdsTrapSlot = 257;                   // the same count inside a block: hist[257] in LDS (hist[256] = progress)
 constexpr uint32_t kLdsPerBlock = 160 * 1024;            // gfx950: 160 KiB per CU, one block per CU may have it all
@@ -104,6 +105,57 @@ inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps
 	return rows - 1 < states ? rows - 1 : states;
 }
 
+// ---- the wide walk (wide.hip, round 5) ---------------------------------------------------------------------------------
+// Tables whose scans keep leaving the 255 dense rows take a walk of their own: NO dense rows, the whole LDS of the CU
+// holds class-indexed u16 rows of the first `wide` states of the ranking (multi.h:169-192 as it stands: letter =
+// m_letters[ch], state = row[letter] -- with the row's LDS address as the state).  A row is
+//     u16 next[letters]   LDS byte address / 4 of the target state's row (the escape row for targets without one)
+//     u16 id              the row's own device state id (the escape row: `wide`)
+//     u16 flags           kFinal | kDead | kAbsorbing of the state
+// padded to a multiple of 4 bytes; cls8 (2 * letter class of every byte value) sits at LDS address 0, so that the byte
+// IS the address of its class.  Behind the rows: one u32 visit counter per row (what pire_hip_table_adapt() ranks from).
+struct WideLayout {
+	uint32_t pitch;      // bytes per row
+	uint32_t rowsOff;    // 256
+	uint32_t rows;       // wide + 1 (the last one is the escape row)
+	uint32_t histOff;    // u32[rows]
+	uint32_t countsOff;  // (regexps + 2) u32 block-local match counters
+	uint32_t progOff;    // u32 progress counter of the block's waves + u32 trap samples
+	uint32_t total;
+};
+
+__host__ __device__ inline uint32_t WidePitch(uint32_t letters) { return ((letters + 2) * 2 + 3) / 4 * 4; }
+
+__host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t letters, uint32_t regexps)
+{
+	WideLayout w;
+	w.pitch = WidePitch(letters);
+	w.rowsOff = 256;
+	w.rows = wide + 1;
+	w.histOff = (w.rowsOff + w.rows * w.pitch + 15) / 16 * 16;
+	w.countsOff = (w.histOff + w.rows * 4 + 15) / 16 * 16;
+	w.progOff = w.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
+	w.total = w.progOff + 16;
+	return w;
+}
+
+// LDS row address / 4 of device state id `pid` (pid <= wide; == wide: the escape row)
+__host__ __device__ inline uint32_t WideRow4(const WideLayout& w, uint32_t pid) { return (w.rowsOff + pid * w.pitch) >> 2; }
+
+// How many states get a wide row (0: the wide walk is not for this table).
+inline uint32_t WideCapacity(uint32_t letters, uint32_t regexps, uint32_t states)
+{
+	if (letters > 127 || states < 2)
+		return 0;   // cls8 holds 2 * class in a u8
+	const uint32_t fixed = MakeWideLayout(0, letters, regexps <= kMaxLdsCountRegexps ? regexps : 0).total + 64;
+	if (fixed >= kLdsPerBlock)
+		return 0;
+	const uint32_t rows = (kLdsPerBlock - fixed) / (WidePitch(letters) + 4);
+	if (rows < 2)
+		return 0;
+	return rows - 1 < states ? rows - 1 : states;
+}
+
 // Host-side, fully decoded scanner.  States are in the REFERENCE's numbering ("orig") unless a name says perm.
 struct HostTable {
 	// geometry (mirrors Scanner::Locals, multi.h:315-323)
@@ -134,6 +186,10 @@ struct HostTable {
 	bool incPacked = false;           // regexps <= 8 and every final-list multiplicity <= 255: inc64 is usable
 	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
+	uint32_t wide = 0;                // perm ids [0, wide) have a row in the wide walk's LDS image (wide.hip; 0 = no such image)
+	float outsideDense = 0;           // share of the ranking's mass on states WITHOUT a dense row / ...
+	float outsideWide = 0;            // ... without a wide row (from the byte model until adapt() has seen scans, then measured)
+	bool massMeasured = false;        // those shares come from visit counters, not from the a-priori byte model
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
 	std::vector<double> seenMass;     // [states] what the scans so far visited (lane-steps, halved at every adapt(); orig numbering)
@@ -169,6 +225,9 @@ struct DeviceTable {
 	uint8_t* distFinalPerm = nullptr;    // [states] HostTable::distFinal by device id (uploaded when first needed)
 	uint8_t* distFlaggedPerm = nullptr;
 	uint16_t* compactRows = nullptr;  // [(compact+1) rows] LDS address / 4 of the next state's row (last row = escape), padded
+	uint16_t* wideRows = nullptr;     // [(wide+1) rows] the wide walk's LDS image (WideLayout), or null
+	uint16_t* next16 = nullptr;       // [states*letters] nextPerm as u16 when states <= 65536 (half the L2 footprint), or null
+	uint32_t* visitWide = nullptr;    // [wide+1] sampled visits of the wide rows (one lane per wave per 128-byte tile)
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
 	unsigned long long* workCounter = nullptr;   // [kWorkSlots] ragged kernel: next string range to hand out;
@@ -229,6 +288,7 @@ struct pire_hip_table {
 	// while holding it (UploadTable) and never look at devs[] afterwards.
 	pirehip::DeviceTable devs[pirehip::kMaxDevices];
 	std::mutex uploadMutex;
+	std::vector<pirehip::DeviceTable> retired;   // images an AUTOMATIC adaptation replaced: alive until destroy (captured graphs)
 	std::atomic<uint32_t> workSlot[pirehip::kMaxDevices] = {};   // per device image: round-robin over its counter pairs
 	std::mutex segMutex;
 	std::vector<uint32_t> segModes;      // segmented.hip: mode representatives (state indices) earlier calls learned
@@ -278,6 +338,12 @@ struct ScanParams {
 	uint32_t* trapSignal;   // mapped host word (device address) for the auto-adaptation policy, or null
 	const uint16_t* compactRows;
 	uint32_t compact;        // 0 = tier off
+	const uint16_t* wideRows;   // nullable: the wide walk's LDS image
+	const uint16_t* next16;     // nullable
+	uint32_t* visitWide;
+	uint32_t wide;              // states with a wide row; 0 = no image
+	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
+	bool massMeasured;                 // host side only
 	const uint64_t* incPerm; // nullable
 	uint32_t hotFinalLo;
 	uint32_t hotDeadLo;
@@ -541,6 +607,7 @@ struct Staging {
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t, DeviceTable* image);   // image of the CURRENT device (built on first use), copied out
 void EnsureRanked(pire_hip_table* t);
+std::vector<uint16_t> BuildWideRows(const HostTable& h);   // the wide walk's LDS image (WideLayout), current numbering
 // after UploadTable, current device: the per-state distance tables (built on first use)
 int EnsureActDist(pire_hip_table* t, const uint8_t** distFinalPerm, const uint8_t** distFlaggedPerm);
 void FreeAllDeviceTables(pire_hip_table* t);
@@ -563,6 +630,9 @@ void FreeDeviceTable(DeviceTable* d);
 // tiled.hip / ragged.hip / exact.hip / corpus.hip
 int LaunchGeneric(const ScanParams& p, hipStream_t stream);
 int LaunchTiled(const ScanParams& p, hipStream_t stream);
+// wide.hip: fixed-length records through the class-indexed walk (tables whose scans keep leaving the dense rows)
+bool WideWanted(const ScanParams& p, const pire_hip_config& cfg);
+int LaunchWide(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);

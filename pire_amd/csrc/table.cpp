@@ -238,6 +238,23 @@ std::vector<double> VisitMass(const HostTable& t, uint32_t start)
 	return mass;
 }
 
+// How much of the ranking's mass (`score`, reference numbering) lies on states without a dense row / without a wide row in
+// the CURRENT numbering: what LaunchTiled chooses the walk by (any choice is correct).
+void MeasureShares(HostTable& t, const std::vector<double>& score)
+{
+	double total = 0, dense = 0, wide = 0;
+	for (uint32_t pid = 0; pid < t.states; ++pid) {
+		const double v = std::max(0.0, score[t.origOfPerm[pid]]);
+		total += v;
+		if (pid < t.hot)
+			dense += v;
+		if (pid < t.wide)
+			wide += v;
+	}
+	t.outsideDense = total > 0 ? float(std::max(0.0, 1.0 - dense / total)) : 0.0f;
+	t.outsideWide = total > 0 && t.wide ? float(std::max(0.0, 1.0 - wide / total)) : t.outsideDense;
+}
+
 // Renumber "hot first" by `score` (higher = hotter) and build the dense LDS rows.
 void PermuteByScore(HostTable& t, const std::vector<double>& score)
 {
@@ -283,7 +300,11 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 			}
 	}
 	t.compact = GetConfig().no_compact ? 0 : CompactCapacity(t.hot, C, t.regexps, N);   // knob: A/B measurements
+	// the wide walk's image (wide.hip): only for tables with more states than dense rows -- a table that fits the dense
+	// rows never leaves them
+	t.wide = N > t.hot ? WideCapacity(C, t.regexps, N) : 0;
 	t.origOfPerm = order;
+	MeasureShares(t, score);
 	t.permOfOrig.assign(N, 0);
 	for (uint32_t pid = 0; pid < N; ++pid)
 		t.permOfOrig[order[pid]] = pid;
@@ -654,7 +675,7 @@ void FreeDeviceTable(DeviceTable* d)
 	void* ptrs[] = {d->hotRows, d->hotRowsRot, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
 	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm,
-	                d->distFinalPerm, d->distFlaggedPerm};
+	                d->distFinalPerm, d->distFlaggedPerm, d->wideRows, d->next16, d->visitWide};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -667,6 +688,10 @@ void FreeAllDeviceTables(pire_hip_table* t)
 {
 	int cur = -1;
 	(void)hipGetDevice(&cur);
+	for (DeviceTable& r : t->retired)
+		if (r.device >= 0 && hipSetDevice(r.device) == hipSuccess)
+			FreeDeviceTable(&r);
+	t->retired.clear();
 	for (int k = 0; k < kMaxDevices; ++k)
 		if (t->devs[k].device >= 0) {
 			(void)hipSetDevice(k);
@@ -674,6 +699,24 @@ void FreeAllDeviceTables(pire_hip_table* t)
 		}
 	if (cur >= 0)
 		(void)hipSetDevice(cur);
+}
+
+// The wide walk's LDS image (internal.h WideLayout) in the table's current numbering: entry = LDS address / 4 of the
+// target's row, the escape row for targets without one; then the row's own id and its flags.
+std::vector<uint16_t> BuildWideRows(const HostTable& h)
+{
+	const uint32_t W = h.wide, C = h.letters, pitch2 = WidePitch(C) / 2;
+	const WideLayout wl = MakeWideLayout(W, C, 0);
+	std::vector<uint16_t> rows((size_t(W + 1) * pitch2 + 7) / 8 * 8, 0);
+	for (uint32_t pid = 0; pid <= W; ++pid) {
+		uint16_t* row = &rows[size_t(pid) * pitch2];
+		const uint32_t o = pid < W ? h.origOfPerm[pid] : 0;
+		for (uint32_t c = 0; c < C; ++c)
+			row[c] = uint16_t(WideRow4(wl, pid < W ? std::min(h.permOfOrig[h.next[size_t(o) * C + c]], W) : W));
+		row[C] = uint16_t(pid);
+		row[C + 1] = pid < W ? h.flags[o] : 0;
+	}
+	return rows;
 }
 
 int UploadTable(pire_hip_table* t, DeviceTable* image)
@@ -789,6 +832,18 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 			}
 		}
 		rc = Put(&d.compactRows, rows, &d.bytes);
+	}
+	if (!rc && h.wide) {
+		rc = Put(&d.wideRows, BuildWideRows(h), &d.bytes);
+		if (!rc)
+			rc = Put(&d.visitWide, std::vector<uint32_t>(h.wide + 1, 0), &d.bytes);
+	}
+	if (!rc && h.wide && N <= 65536) {
+		// the exact table once more as u16: what the wide walk reads for states without a row (half the cache footprint)
+		std::vector<uint16_t> n16(nextPerm.size());
+		for (size_t i = 0; i < nextPerm.size(); ++i)
+			n16[i] = uint16_t(nextPerm[i]);
+		rc = Put(&d.next16, n16, &d.bytes);
 	}
 	if (!rc)
 		rc = Put(&d.visitHot, std::vector<uint32_t>(kVisitHotSlots, 0), &d.bytes);
@@ -1130,7 +1185,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	HostTable& h = t->host;
 	const uint32_t N = h.states, H = h.hot;
 	// what every device that ever ran this table saw, summed
-	std::vector<uint64_t> hot(256, 0), cold(N, 0);
+	std::vector<uint64_t> hot(256, 0), cold(N, 0), wide(h.wide + 1, 0);
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
@@ -1138,7 +1193,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		if (e != hipSuccess)
 			return HipFail(e, "hipGetDevice");
 		bool any = false;
-		std::vector<uint32_t> bufHot(256), bufCold(N);
+		std::vector<uint32_t> bufHot(256), bufCold(N), bufWide(h.wide + 1, 0);
 		for (int k = 0; k < kMaxDevices; ++k) {
 			if (t->devs[k].device < 0)
 				continue;
@@ -1146,6 +1201,8 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 			if ((e = hipSetDevice(k)) == hipSuccess && (e = hipDeviceSynchronize()) == hipSuccess &&
 			    (e = hipMemcpy(bufHot.data(), t->devs[k].visitHot, 256 * 4, hipMemcpyDeviceToHost)) == hipSuccess)
 				e = hipMemcpy(bufCold.data(), t->devs[k].visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
+			if (e == hipSuccess && t->devs[k].visitWide && h.wide)
+				e = hipMemcpy(bufWide.data(), t->devs[k].visitWide, size_t(h.wide + 1) * 4, hipMemcpyDeviceToHost);
 			if (e != hipSuccess) {
 				(void)hipSetDevice(cur);
 				return HipFail(e, "visit counters");
@@ -1154,6 +1211,9 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 				hot[i] += bufHot[i];
 			for (uint32_t i = 0; i < N; ++i)
 				cold[i] += bufCold[i];
+			if (t->devs[k].visitWide)
+				for (uint32_t i = 0; i < h.wide; ++i)
+					wide[i] += bufWide[i];
 		}
 		(void)hipSetDevice(cur);
 		if (!any)
@@ -1174,15 +1234,19 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		double est = double(cold[pid]) * 1024.0;
 		if (pid < H)
 			est += double(hot[pid]) * 8192.0;
+		if (pid < h.wide)
+			est += double(wide[pid]) * 8192.0;   // the wide walk samples like the tiled kernel: one lane per wave per tile
 		if (pid >= H)
 			coldSamples += cold[pid];
 		h.seenMass[o] = 0.5 * h.seenMass[o] + est;
 		score[o] = h.seenMass[o] + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
 	}
 	h.lastTrapSamples = coldSamples;
+	h.massMeasured = true;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());
 	if (coldSamples == 0) {
+		MeasureShares(h, score);   // same numbering, measured masses
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
 		(void)hipGetDevice(&cur);
@@ -1190,6 +1254,9 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 			if (t->devs[k].device >= 0 && hipSetDevice(k) == hipSuccess) {
 				(void)hipMemset(t->devs[k].visitHot, 0, 256 * 4);          // not the checked build's slot
 				(void)hipMemset(t->devs[k].visitHot + kTrapSlot, 0, 4);
+				(void)hipMemset(t->devs[k].visitHot + kWideTrapSlot, 0, 4);
+				if (t->devs[k].visitWide)
+					(void)hipMemset(t->devs[k].visitWide, 0, size_t(h.wide + 1) * 4);
 				if (t->devs[k].trapSignalHost)
 					*t->devs[k].trapSignalHost = 0;
 			}
@@ -1207,7 +1274,19 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	// every image holds the old numbering: drop them all (synchronised above), each device re-uploads on its next run
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
-		FreeAllDeviceTables(t);   // drained above; every entry point that could hold their pointers has returned (TableUse)
+		if (automatic) {
+			// An AUTOMATIC adaptation keeps the replaced images until the table is destroyed: a graph captured
+			// from enqueue-only calls has their pointers baked in, and its owner never asked for a re-ranking -- a replay
+			// then walks the old image, which is as exact as the new one.  Bounded: kMaxAutoAdapts images per device.
+			// pire_hip_table_adapt() is the caller's own act: it frees them (include/pire_hip.h says re-capture).
+			for (int k = 0; k < kMaxDevices; ++k)
+				if (t->devs[k].device >= 0) {
+					t->retired.push_back(t->devs[k]);
+					t->devs[k] = DeviceTable();
+				}
+		} else {
+			FreeAllDeviceTables(t);   // drained above; every entry point that could hold their pointers has returned (TableUse)
+		}
 	}
 	DeviceTable d;
 	return UploadTable(t, &d);

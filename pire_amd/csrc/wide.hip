@@ -1,0 +1,305 @@
+// The wide walk (round 5): fixed-length records of tables whose scans keep leaving the 255 dense rows.  DESIGN.md 4.8.
+//
+// The reference's step costs the same in any state (multi.h:169-192: letter = m_letters[ch]; state = row[letter]).  The
+// dense rows of tiled.hip are that step with the letter lookup folded in -- one LDS gather per byte -- but only 255
+// states have one, and a 16-byte chunk in which a lane leaves them is walked a second time.  A dictionary automaton
+// (samples/blacklist/blacklist.cpp:65-76) or a glued table whose text keeps matches alive visits thousands of states;
+// nearly every wave-chunk then holds a lane outside the dense rows.  For such tables this kernel IS multi.h:169-192:
+//
+//     c    = cls8[byte]                      ds_read_u8, off the dependent chain (cls8 at LDS address 0: the byte is the address)
+//     row  = u16[(row << 2) + c]             v_lshl_add_u32 + ds_read_u16, the chain; a row's entries are row addresses / 4
+//
+// with class-indexed u16 rows of the first `wide` states of the ranking filling the CU's whole LDS (internal.h
+// WideLayout: 1 700 states at 44 letters, 2 150 at 34).  Targets without a row lead to an absorbing escape row; a lane
+// found there after a chunk is re-walked from the chunk's first byte, one load per byte -- LDS while its state has a row,
+// the exact table in memory (u16 entries when the ids fit: half the cache footprint) while it has none.  Bit-exact for
+// any table and any ranking, like every kernel of the path.  Text path, task numbering, wave levelling: tiled.hip's.
+
+#include "device_common.h"
+
+namespace pirehip {
+
+// Whole-line loads of one 128-byte tile of 64 strings (tiled.hip IssueTile; a copy of its own, like pair.hip's, so that
+// the headline kernel's translation unit stays what it was measured as)
+__device__ __forceinline__ void WideIssueTile(u32x4 (&r)[8], uint32_t voff, uint64_t tileBase, uint64_t stride)
+{
+	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride, b4 = b3 + stride,
+	               b5 = b4 + stride, b6 = b5 + stride, b7 = b6 + stride;
+	asm volatile(
+		"global_load_dwordx4 %0, %8, %9 nt\n\t"
+		"global_load_dwordx4 %1, %8, %10 nt\n\t"
+		"global_load_dwordx4 %2, %8, %11 nt\n\t"
+		"global_load_dwordx4 %3, %8, %12 nt\n\t"
+		"global_load_dwordx4 %4, %8, %13 nt\n\t"
+		"global_load_dwordx4 %5, %8, %14 nt\n\t"
+		"global_load_dwordx4 %6, %8, %15 nt\n\t"
+		"global_load_dwordx4 %7, %8, %16 nt"
+		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7));
+}
+
+template <int TILES_BEHIND>
+__device__ __forceinline__ void WideWaitTile(u32x4 (&r)[8])
+{
+	asm volatile("s_waitcnt vmcnt(%8)"
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+	             : "n"(TILES_BEHIND * 8));
+}
+
+// wave-uniform constants of a launch
+struct WideConst {
+	uint32_t esc4;     // LDS address / 4 of the escape row
+	uint32_t idOff;    // byte offset of a row's own id (2 * letters); its flags follow
+	uint32_t base4;    // LDS address / 4 of row 0
+	uint32_t pitch4;   // row pitch / 4
+};
+
+// The exact step for a state without a row (device ids in and out).
+template <bool N16>
+__device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, uint32_t cls)
+{
+	if (N16)
+		return p.next16[size_t(st) * p.letters + cls];
+	return p.nextPerm[size_t(st) * p.letters + cls];
+}
+
+// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly.
+// One dependent load per byte: the row entry in LDS while the state has a row, the table in memory while it has none
+// (cold = its device id).  Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
+template <bool N16>
+__device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
+                                              uint32_t row0, uint32_t& row, uint32_t& cold, uint32_t sampleLane)
+{
+	uint32_t r = row0, cd = cold;
+#pragma unroll 1
+	for (int i = 0; i < 16; ++i) {
+		const uint32_t c2 = HotLookup(v.x & 0xFFu);   // 2 * letter class
+		if (r != K.esc4) {
+			const uint32_t nr = LdsU16((r << 2) + c2);
+			if (nr == K.esc4)
+				cd = WideNext<N16>(p, LdsU16((r << 2) + K.idOff), c2 >> 1);
+			r = nr;
+		} else {
+			const uint32_t nx = WideNext<N16>(p, cd, c2 >> 1);
+			if (nx < p.wide)
+				r = K.base4 + nx * K.pitch4;
+			else
+				cd = nx;
+		}
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	row = r;
+	cold = cd;
+	// tell pire_hip_table_adapt() which states deserve a row: sampled like TrapChunk's (one rotating lane of 64)
+	if (r == K.esc4 && (threadIdx.x & 63) == sampleLane) {
+		atomicAdd(&p.visitCold[cd], 1u);
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+	}
+}
+
+// 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
+template <bool N16>
+__device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
+                                          uint32_t& row, uint32_t& cold, uint32_t sampleLane)
+{
+	const uint32_t row0 = row;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		// the four classes first: independent of the walk, the LDS serves them while the chain below waits for its rows
+		const uint32_t c0 = HotLookup(x & 0xFFu);
+		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
+		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
+		const uint32_t c3 = HotLookup(x >> 24);
+		row = LdsU16((row << 2) + c0);
+		row = LdsU16((row << 2) + c1);
+		row = LdsU16((row << 2) + c2);
+		row = LdsU16((row << 2) + c3);
+	}
+	if (row == K.esc4)
+		WideTrapChunk<N16>(p, lds, W, K, v, row0, row, cold, sampleLane);
+}
+
+template <bool N16>
+__device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, uint64_t rowBase,
+                                          uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
+                                          uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& row, uint32_t& cold,
+                                          uint32_t* prog, uint32_t& myTiles)
+{
+	{   // the waves of a block kept in step (tiled.hip, EQ)
+		uint32_t sum = 0;
+		if (lane == 0)
+			sum = atomicAdd(prog, 1u) + 1;
+		sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+		const uint32_t mine = ++myTiles;
+		constexpr uint32_t margin = 4;
+		if (mine * (blockDim.x >> 6) > sum + margin)
+			__builtin_amdgcn_s_setprio(0);
+		else if (mine * (blockDim.x >> 6) + margin < sum)
+			__builtin_amdgcn_s_setprio(3);
+		else
+			__builtin_amdgcn_s_setprio(1);
+	}
+	const uint64_t ahead = t < lastTile ? rowBase + uint64_t(t + 1) * 128 : chainBase;
+	WideIssueTile(refill, voff, ahead, istride);
+	WideWaitTile<1>(cur);
+	TransposeTile(cur, lane);
+	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating (the escape row counts into slot `wide`)
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + LdsU16((row << 2) + K.idOff), 1u);
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		WideChunk<N16>(p, lds, W, K, cur[k], row, cold, (t * 8 + k) & 63);
+}
+
+// Fixed-length records, 16-byte aligned, an EVEN number of 128-byte tiles per record (+ a tail shorter than a tile),
+// whole tasks of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries.
+template <bool N16>
+__global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
+	WideConst K;
+	K.esc4 = WideRow4(W, p.wide);
+	K.idOff = p.letters * 2;
+	K.base4 = W.rowsOff >> 2;
+	K.pitch4 = W.pitch >> 2;
+	LdsLayout L = {};           // what Finish() looks at: the block-local counters
+	L.countsOff = W.countsOff;
+
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = p.n / 64;
+	const uint32_t ntiles = uint32_t(p.len / 128) & ~1u;   // walked from the ring; an odd last tile and the tail: exact steps below
+	const uint32_t lastTile = ntiles - 1;
+	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
+	const uint64_t istride = p.stride;
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
+	uint32_t myTiles = 0;
+	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
+	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+	bool primed = firstTask < ntasks;
+	if (primed)   // the first tile is on its way while the table is copied
+		WideIssueTile(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), istride);
+	{
+		uint32_t cls8 = 0;
+		if (threadIdx.x < 256)
+			cls8 = p.cls[threadIdx.x];
+		CopyToLds16<4>(lds + W.rowsOff, p.wideRows, (W.rows * W.pitch + 15) / 16);
+		__syncthreads();   // the copy's last unit may reach past the rows
+		if (threadIdx.x < 256)
+			lds[threadIdx.x] = uint8_t(2 * cls8);
+		for (uint32_t i = threadIdx.x; i < W.rows; i += blockDim.x)
+			reinterpret_cast<uint32_t*>(lds + W.histOff)[i] = 0;
+		for (uint32_t i = threadIdx.x; i < (W.total - W.countsOff) / 4; i += blockDim.x)
+			reinterpret_cast<uint32_t*>(lds + W.countsOff)[i] = 0;
+		__syncthreads();
+	}
+	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
+		const uint64_t s0 = task * 64;
+		const uint64_t s = s0 + lane;
+		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
+		const bool hasNext = task + taskStep < ntasks;
+		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
+		                                   : rowBase + uint64_t(lastTile) * 128;
+		uint32_t cold = StartState(p, s);
+		uint32_t row = cold < p.wide ? K.base4 + cold * K.pitch4 : K.esc4;
+		bool done = false;
+		if (!primed)
+			WideIssueTile(a, voff, rowBase, istride);
+		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, row, cold, prog, myTiles);
+			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, row, cold, prog, myTiles);
+			// wave-wide early out (multi.h:955-958): every lane in a row whose every transition is a self loop
+			done = __all((LdsU16((row << 2) + K.idOff + 2) & kAbsorbing) != 0);
+		}
+		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
+		if (done)
+			WideWaitTile<0>(a);
+		const uint32_t id = LdsU16((row << 2) + K.idOff);
+		uint32_t st = id < p.wide ? id : cold;
+		if (!done) {   // an odd last tile and the tail shorter than a tile: exact steps straight from memory
+			const uint8_t* base = p.text + s * p.stride;
+			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
+				st = WideNext<N16>(p, st, uint32_t(lds[base[i]]) >> 1);
+		}
+		Finish(p, lds, L, s, true, st);
+	}
+	WideWaitTile<0>(a);
+	WideWaitTile<0>(b);
+	// visit samples, trap samples, match counters
+	__syncthreads();
+	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + W.histOff);
+	for (uint32_t i = threadIdx.x; i < p.wide; i += blockDim.x)
+		if (hist[i])
+			atomicAdd(&p.visitWide[i], hist[i]);
+	if (threadIdx.x == 0 && prog[1]) {
+		atomicAdd(&p.visitHot[kWideTrapSlot], prog[1]);
+		const uint32_t total = atomicAdd(&p.visitHot[kTrapSlot], prog[1]) + prog[1];
+		if (p.trapSignal)
+			__hip_atomic_store(p.trapSignal, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (p.outCounts) {
+		const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + W.countsOff);
+		for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
+			if (cnt[i])
+				atomicAdd(&p.outCounts[i], (unsigned long long)cnt[i]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------ launcher
+
+// The choice between the dense rows and the wide walk (any choice is correct).  pire_hip_config.walk_variant: 0 by the
+// share of the ranking's mass outside the dense rows -- measured by the scans so far once the table has adapted, the
+// byte model's estimate before (which only a table far outside the dense rows acts on) --, 1 never, 2 whenever the
+// table has states beyond the dense rows.
+bool WideWanted(const ScanParams& p, const pire_hip_config& cfg)
+{
+	if (!p.wide || !p.wideRows || cfg.checked || cfg.tiled_variant != 0 || cfg.walk_variant == 1)
+		return false;
+	if (p.initIdx && (p.flags & kPermIds))
+		return false;   // the segmented scan's passes stay on the kernels they were measured on
+	if (p.outCounts && p.regexps > kMaxLdsCountRegexps)
+		return false;
+	if (cfg.walk_variant == 2)
+		return true;
+	// a lane-step share of 0.3 % outside the dense rows puts a lane outside them in a fifth of all wave-chunks, each of
+	// which is then walked twice; the wide walk costs half as much again everywhere (measured: DESIGN.md 5.4)
+	return p.outsideDense > (p.massMeasured ? 0.003f : 0.05f);
+}
+
+int LaunchWide(const ScanParams& p, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	ScanParams q = p;
+	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
+	int rc;
+	if (p.next16) {
+		NoteKernel("wide", "pirehip::ScanWideKernel<u16 table>");
+		rc = LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
+	} else {
+		NoteKernel("wide", "pirehip::ScanWideKernel<u32 table>");
+		rc = LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
+	}
+	if (rc != PIRE_HIP_OK || q.n == p.n)
+		return rc;
+	ScanParams tail = p;
+	tail.n = p.n - q.n;
+	tail.text = p.text + q.n * p.stride;
+	if (p.initIdx)
+		tail.initIdx = p.initIdx + q.n;
+	if (p.outIdx)
+		tail.outIdx = p.outIdx + q.n;
+	if (p.outFinal)
+		tail.outFinal = p.outFinal + q.n;
+	return LaunchGeneric(tail, stream);
+}
+
+}  // namespace pirehip

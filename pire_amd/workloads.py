@@ -71,3 +71,150 @@ def ref_bench_corpus(total_bytes: int) -> bytes:
     while len(data) < total_bytes:
         data = data + data
     return data
+
+
+# ---- wide working sets (round 5): dictionary scanners and token-mixture corpora ---------------------------------------
+# The headline corpus (random printable text + planted witnesses) keeps a glued table inside ~100 states.  What the
+# reference's own deployment example scans with (samples/blacklist/blacklist.cpp: thousands of domains in one Scanner)
+# visits thousands.  tests/golden/make_golden_wide.py compiles such scanners with the unmodified reference and writes
+# tests/golden/wide.json; the corpora are defined HERE (numpy only, deterministic in their seed) so that bench.py, the
+# tests and the fixture generator build the same bytes.
+
+_wide = None
+
+
+def _wide_json():
+    global _wide
+    if _wide is None:
+        with open(os.path.join(GOLDEN, "wide.json")) as f:
+            _wide = json.load(f)
+    return _wide
+
+
+def wide_sets():
+    return _wide_json()["wide"]
+
+
+def wide_set(name: str) -> dict:
+    for w in wide_sets():
+        if w["name"] == name:
+            return w
+    raise KeyError(name)
+
+
+def dictionary_words(entry: dict):
+    """The words of a dictionary scanner, in the order the fixture generator drew them (bytes)."""
+    data = load_blob(entry["words_file"]).split(b"\n")
+    return [w for w in data if w][:entry["words"]]
+
+
+_SYL = ("ba be bi bo bu ca ce ci co cu da de di do du fa fe fi fo ga ge go ha he hi ho ja jo ka ke ki ko la le li lo lu ma me "
+        "mi mo mu na ne ni no nu pa pe pi po ra re ri ro ru sa se si so su ta te ti to tu va ve vi vo wa we wi xa ya yo za ze "
+        "zo an en in on un ar er or st tr ch sh th net web shop news mail blog soft tech data cloud game play free best top "
+        "my the e i x 24 365 1 2").split()
+_TLD = "com com com com net org ru ru de info biz co.uk io cn fr it nl com.br pl in".split()
+
+
+def synthetic_domains(n: int, seed: int = 1):
+    """n distinct made-up domain names (no network here for a real list): 2-4 syllables, sometimes a hyphen, a TLD; in
+    the order drawn."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    out, seen = [], set()
+    while len(out) < n:
+        k = rng.randint(2, 5)
+        w = "".join(_SYL[rng.randint(len(_SYL))] for _ in range(k))
+        if rng.rand() < 0.08:
+            w = w[:len(w) // 2] + "-" + w[len(w) // 2:]
+        w = w + "." + _TLD[rng.randint(len(_TLD))]
+        if w not in seen:
+            seen.add(w)
+            out.append(w.encode())
+    return out
+
+
+def token_stream(seed: int, tokens, weights, nbytes: int):
+    """`nbytes` bytes of text: tokens drawn independently with the given weights, back to back (vectorised)."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    lens = np.array([len(t) for t in tokens], dtype=np.int64)
+    flat = np.frombuffer(b"".join(tokens), dtype=np.uint8)
+    starts = np.concatenate(([0], np.cumsum(lens)[:-1]))
+    p = np.asarray(weights, dtype=np.float64)
+    p = p / p.sum()
+    mean = float((p * lens).sum())
+    out = np.empty(0, dtype=np.uint8)
+    while out.size < nbytes:
+        k = int((nbytes - out.size) / mean * 1.05) + 64
+        idx = rng.choice(len(tokens), size=k, p=p)
+        ln = lens[idx]
+        end = np.cumsum(ln)
+        src = np.repeat(starts[idx] - (end - ln), ln) + np.arange(int(end[-1]))
+        out = np.concatenate((out, flat[src]))
+    return out[:nbytes]
+
+
+def wide_tokens(entry: dict, corpus: str):
+    """(tokens, weights) of a named corpus of a wide set.
+    dictionary scanners -- corpus 'k<N>': the labels (word minus its TLD: never a whole dictionary word, so the Surround()ed
+    scanner is never absorbed in its accepting state) of the first N words, half of the items, the rest filler words of
+    the same syllables; every item followed by a separator.
+    set_b -- corpus 'mix': fragments that keep several of the 8 glued patterns half matched at once."""
+    import numpy as np
+
+    if entry["kind"] == "dictionary":
+        k = int(corpus[1:])
+        words = dictionary_words(entry)[:k]
+        labels = sorted({w.split(b".")[0] for w in words})
+        rng = np.random.RandomState(77)
+        filler = sorted({"".join(_SYL[rng.randint(len(_SYL))] for _ in range(rng.randint(1, 4))).encode() for _ in range(4096)})
+        seps = [b" ", b"/", b"\n", b"=", b"_"]
+        toks, wts = [], []
+        for group, share in ((labels, 0.5), (filler, 0.5)):
+            for t in group:
+                for s in seps:
+                    toks.append(t + s)
+                    wts.append(share / len(group) / len(seps))
+        return toks, wts
+    if entry["kind"] == "glued" and corpus == "mix":
+        alpha = b"ABCDEFGHIJKLMNOPQRSTUVWXYZ"
+        toks = [b"hello ", b"hello  w", b"w", b" ", b"  ", b"d", b"http://", b"http://ab.", b"cd.", b"xyz.", b"foo", b"bar", b"baz",
+                b"foobar", b"qu", b"abc@", b"def.co", b"(123) ", b"456-78", b"123-", b"-456", b"X", b"Y", b"Z", b"abc ", b"\n"]
+        toks += [alpha[:k] for k in range(1, 26)] + [b"X" + alpha[:k] for k in range(1, 20, 2)]
+        rng = np.random.RandomState(78)
+        toks += sorted({"".join(_SYL[rng.randint(len(_SYL))] for _ in range(rng.randint(1, 3))).encode() + b" " for _ in range(64)})
+        return toks, [1.0] * len(toks)
+    raise KeyError((entry["name"], corpus))
+
+
+def wide_records(entry: dict, corpus: str, seed: int, n: int, length: int):
+    """[n, length] u8: the token stream of the corpus cut into records."""
+    toks, wts = wide_tokens(entry, corpus)
+    return token_stream(seed, toks, wts, n * length).reshape(n, length)
+
+
+def wide_urls(entry: dict, seed: int, n: int, listed_share: float = 0.25):
+    """(text u8, offsets u64[n+1]): URLs for a blacklist scanner (samples/blacklist/blacklist.cpp:78-85 reads one per line):
+    scheme, 0-2 subdomain labels, a host -- a word of the dictionary with probability `listed_share`, else a made-up domain
+    of the same kind --, a path."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    words = dictionary_words(entry)
+    other = synthetic_domains(4096, seed=991)
+    subs = [b"", b"", b"www.", b"m.", b"shop.", b"mail.", b"a.b."]
+    paths = [b"", b"/", b"/index.html", b"/a/b/c?d=e", b"/news/2010/07/14/some-long-article-title.html", b"/img/logo.png",
+             b"/search?q=perl+incompatible+regular+expressions&lang=en", b"/~user/dir/"]
+    schemes = [b"http://", b"http://", b"https://", b"ftp://", b""]
+    parts = []
+    listed = rng.rand(n) < listed_share
+    wi = rng.randint(len(words), size=n)
+    oi = rng.randint(len(other), size=n)
+    si, pi, ci = rng.randint(len(subs), size=n), rng.randint(len(paths), size=n), rng.randint(len(schemes), size=n)
+    for i in range(n):
+        parts.append(schemes[ci[i]] + subs[si[i]] + (words[wi[i]] if listed[i] else other[oi[i]]) + paths[pi[i]])
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(u) for u in parts], dtype=np.uint64)
+    return np.frombuffer(b"".join(parts), dtype=np.uint8), offs

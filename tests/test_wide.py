@@ -1,0 +1,253 @@
+"""The class-indexed walk (pire_amd/csrc/wide.hip, round 5): tables whose scans visit thousands of states.
+
+CPU part: the fixtures of tests/golden/wide.json (dictionary scanners compiled by the unmodified reference the way
+samples/blacklist/blacklist.cpp:65-76 builds one) pin the oracle, and the walk's LDS image is walked on the host exactly
+as the kernel walks it -- rows for the first states of the ranking, the escape row, the exact table behind it.
+GPU part (-m gpu): the kernel against the oracle and the recorded reference results, through the C ABI."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pire_amd import workloads as W
+from tests import helpers as H
+from tests.test_gpu_parity import dev_run_strided, expected_counts, pa, torch_cuda  # noqa: F401  (fixtures)
+
+BE = ob.FLAG_BEGIN | ob.FLAG_END
+WIDE = [(w["name"], c) for w in W.wide_sets() for c in w["samples"]]
+
+
+def sample_of(name, corpus):
+    entry = W.wide_set(name)
+    s = entry["samples"][corpus]
+    if corpus == "urls":
+        text, offs = W.wide_urls(entry, s["seed"], s["n"])
+    else:
+        text = W.wide_records(entry, corpus, s["seed"], s["n"], s["len"]).reshape(-1)
+        offs = np.arange(s["n"] + 1, dtype=np.uint64) * s["len"]
+    assert hashlib.sha256(text.tobytes()).hexdigest() == s["sha256"], "the corpus generator no longer builds the recorded bytes"
+    return entry, s, text, offs
+
+
+@pytest.mark.parametrize("name,corpus", WIDE)
+def test_oracle_against_the_recorded_reference_results(name, corpus):
+    """oracle/pire_oracle.c on the wide corpora == what the compiled reference answered when the fixture was made."""
+    entry, s, text, offs = sample_of(name, corpus)
+    blob = W.load_blob(entry["blob"])
+    assert hashlib.sha256(blob).hexdigest() == entry["blob_sha256"]
+    o = ob.OracleScanner(blob)
+    assert (o.size, o.letters) == (entry["geometry"]["states"], entry["geometry"]["letters"])
+    idx, fin = o.run(text, offs, threads=4)
+    assert idx.tolist() == s["idx"] and fin.tolist() == s["final"]
+    visits = o.visit_counts(text, offs)
+    assert int((visits > 0).sum()) == s["distinct_states_visited"]
+    if ob.ref_available():
+        ri, rf = ob.RefScanner.load(blob).run(text, offs)
+        assert (ri == idx).all() and (rf == fin).all()
+
+
+def walk_image(t, strings):
+    """The kernel's walk on the host (wide.hip WideChunk / WideTrapChunk): the row's LDS address / 4 as the state while the
+    state has a row, the escape row + the device id otherwise; StateIndex of the end state per string."""
+    import pire_amd  # noqa: F401
+
+    rows, wide, pitch, off = t.wide_layout()
+    orig_of_perm, _ = t.layout()
+    perm_of_orig = np.empty_like(orig_of_perm)
+    perm_of_orig[orig_of_perm] = np.arange(len(orig_of_perm), dtype=np.uint32)
+    letters = t.info.letters
+    flat = rows.reshape(-1)
+    esc4 = (off + wide * pitch) // 4
+
+    def entry(row4, k):   # u16 at LDS byte address row4 * 4 + 2 k
+        return int(flat[(row4 * 4 - off) // 2 + k])
+
+    out = []
+    for s in strings:
+        st = perm_of_orig[t.Next(t.info.initial, 258)]     # Begin()
+        row = (off + st * pitch) // 4 if st < wide else esc4
+        cold = int(st)
+        for b in s:
+            c = t.letter_class(b)
+            if row != esc4:
+                nr = entry(row, c)
+                if nr == esc4:
+                    cold = int(perm_of_orig[t.Next(int(orig_of_perm[entry(row, letters)]), b)])
+                row = nr
+            else:
+                nx = int(perm_of_orig[t.Next(int(orig_of_perm[cold]), b)])
+                if nx < wide:
+                    row = (off + nx * pitch) // 4
+                else:
+                    cold = nx
+        st = entry(row, letters) if row != esc4 else cold
+        assert st != wide or row == esc4
+        out.append(int(t.Next(int(orig_of_perm[st]), 259)))   # End()
+    return out
+
+
+@pytest.mark.parametrize("name,corpus", [("dict_1k", "k512"), ("dict_10k", "k2048"), ("blacklist_1k", "urls"), ("set_b_mix", "mix")])
+def test_wide_image_walks_like_the_reference(name, corpus):
+    """The LDS image of the wide walk (pire_hip_table_wide_layout): walked the way the kernel walks it, a string ends in
+    the state the reference ends in -- rows, escape row, own-id field and the table behind them are consistent."""
+    import pire_amd
+
+    entry, s, text, offs = sample_of(name, corpus)
+    t = pire_amd.Table(W.load_blob(entry["blob"]))
+    info = t.info
+    assert info.wide_states > info.hot_states and info.wide_lds_bytes <= 160 * 1024
+    rows, wide, pitch, off = t.wide_layout()
+    assert wide == info.wide_states and rows.shape == (wide + 1, pitch // 2) and pitch % 4 == 0 and off == 256
+    assert (rows[:, info.letters] == np.arange(wide + 1)).all()                # every row knows its own id
+    assert (rows[wide, :info.letters] == (off + wide * pitch) // 4).all()      # the escape row is absorbing
+    k = min(24, len(offs) - 1)
+    strings = [bytes(text[int(offs[i]):int(offs[i + 1])])[:300] for i in range(k)]
+    o = ob.OracleScanner(W.load_blob(entry["blob"]))
+    want, _ = o.run_strings(strings)
+    assert walk_image(t, strings) == want.tolist()
+
+
+def test_walk_choice_follows_the_measured_share(cfg):
+    """pire_hip_config.walk_variant and the table's measured shares decide; tables that fit the dense rows have no image."""
+    import pire_amd
+
+    small = pire_amd.Table(H.load_blob([b for b in H.big_sets() if b["name"] == "c2_single"][0]["blob"]))
+    assert small.info.wide_states == 0 and small.wide_layout()[0] is None
+    t = pire_amd.Table(W.load_blob(W.wide_set("dict_1k")["blob"]))
+    i = t.info
+    assert i.wide_states >= 1700 and not i.shares_measured
+    assert 0.0 <= i.outside_wide_share <= i.outside_dense_share <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+
+
+def records_of(entry, corpus, seed, n, length):
+    return W.wide_records(entry, corpus, seed, n, length)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,corpus", [("dict_1k", "k32"), ("dict_1k", "k1000"), ("dict_10k", "k2048"), ("dict_10k", "k10000"),
+                                         ("set_b_mix", "mix")])
+@pytest.mark.parametrize("n,length", [(64, 256), (65, 4096), (1000, 1024), (333, 128 * 5 + 16), (4096 + 7, 512), (128, 4096 + 48)])
+def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
+    """pire_hip_run_strided with walk_variant = 2: partial waves, odd tile counts, tails shorter than a tile, counters."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    entry = W.wide_set(name)
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    data = records_of(entry, corpus, n * 7 + length, n, length)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    cfg.set(walk_variant=2)
+    gi, gf, cnt = dev_run_strided(torch, t, d)
+    assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the < 64-string remainder behind it
+    assert "ScanWideKernel" in pb.last_kernel_symbol() or n % 64
+    assert (gi == oi).all() and (gf == of).all()
+    assert (cnt == expected_counts(o, oi, of)).all()
+    cfg.set(walk_variant=1)
+    di, df, _ = dev_run_strided(torch, t, d)
+    assert pb.last_kernel() in ("tiled", "generic")
+    assert (di == oi).all() and (df == of).all()
+
+
+@pytest.mark.gpu
+def test_wide_kernel_on_the_recorded_samples(pa, torch_cuda, cfg):
+    """... and against what the compiled reference recorded in tests/golden/wide.json."""
+    torch = torch_cuda
+    cfg.set(walk_variant=2)
+    for w in W.wide_sets():
+        for corpus, s in w["samples"].items():
+            if corpus == "urls":
+                continue
+            t = pa.Table(W.load_blob(w["blob"]))
+            rec = W.wide_records(w, corpus, s["seed"], s["n"], s["len"])
+            gi, gf, _ = dev_run_strided(torch, t, torch.as_tensor(rec, device="cuda"))
+            assert gi.tolist() == s["idx"] and gf.tolist() == s["final"], (w["name"], corpus)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, ob.FLAG_BEGIN, ob.FLAG_END, BE])
+def test_wide_kernel_flags_and_resume_states(pa, torch_cuda, cfg, flags):
+    """Begin / End optional, resume states per string (also states WITHOUT a row), raw bytes of every value."""
+    torch = torch_cuda
+    entry = W.wide_set("dict_10k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    n, length = 640, 768
+    rng = np.random.RandomState(flags + 11)
+    data = records_of(entry, "k2048", 99 + flags, n, length).copy()
+    data[::5, 100:400] = rng.randint(0, 256, size=(len(data[::5]), 300), dtype=np.uint8)
+    init = rng.randint(0, o.size, size=n).astype(np.uint32)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    cfg.set(walk_variant=2)
+    d = torch.as_tensor(data, device="cuda")
+    for ini in (None, init):
+        oi, of = o.run(data.reshape(-1), offs, flags=flags, init_idx=ini, threads=4)
+        gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
+        assert (gi == oi).all() and (gf == of).all()
+        assert (cnt == expected_counts(o, oi, of)).all()
+
+
+@pytest.mark.gpu
+def test_wide_kernel_with_a_ranking_that_knows_nothing(pa, torch_cuda, cfg):
+    """prior_flat: rows for the first states BY INDEX -- most of the walk happens outside them, through the table in memory
+    (both widths of it: u16 for dict_1k, u32 for a table of more than 65 536 states is not in the fixtures)."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    cfg.set(prior_flat=1, walk_variant=2)
+    for name, corpus in (("dict_1k", "k1000"), ("dict_10k", "k10000")):
+        entry = W.wide_set(name)
+        blob = W.load_blob(entry["blob"])
+        t, o = pa.Table(blob), ob.OracleScanner(blob)
+        n, length = 512, 1024
+        data = records_of(entry, corpus, 4242, n, length)
+        offs = np.arange(n + 1, dtype=np.uint64) * length
+        oi, of = o.run(data.reshape(-1), offs, threads=4)
+        gi, gf, _ = dev_run_strided(torch, t, torch.as_tensor(data, device="cuda"))
+        assert pb.last_kernel() == "wide"
+        assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.gpu
+def test_wide_walk_is_chosen_once_the_scans_are_seen_leaving_the_dense_rows(pa, torch_cuda, cfg):
+    """Default configuration: the first passes take the dense rows (the a-priori ranking says little about a dictionary),
+    adapt() sees a third of the steps outside them, the next pass takes the wide walk -- same results; a table whose text
+    stays inside the dense rows (set_a, headline corpus) never does."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    cfg.set(walk_variant=0)
+    entry = W.wide_set("dict_1k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    n, length = 4096, 1024
+    data = records_of(entry, "k512", 5, n, length)
+    offs = np.arange(n + 1, dtype=np.uint64) * length
+    oi, of = o.run(data.reshape(-1), offs, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    kernels = []
+    for _ in range(3):
+        gi, gf, _c = dev_run_strided(torch, t, d)
+        kernels.append(pb.last_kernel())
+        assert (gi == oi).all() and (gf == of).all()
+        t.adapt()
+    info = t.refresh_info()
+    assert info.shares_measured and info.outside_dense_share > 0.05, (info.outside_dense_share, kernels)
+    assert kernels[-1] == "wide", kernels
+    # after the wide walk has run, its own visit counters keep the ranking: still wide, shares still measured
+    t.adapt()
+    gi, gf, _c = dev_run_strided(torch, t, d)
+    assert pb.last_kernel() == "wide" and (gi == oi).all()
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    ta = pa.Table(H.load_blob(big["blob"]))
+    da = torch.as_tensor(ob.corpus_fill(3, 0, 2048, 1024, H.plants_for(big), threads=4), device="cuda")
+    for _ in range(2):
+        dev_run_strided(torch, ta, da)
+        assert pb.last_kernel() == "tiled"
+        ta.adapt()
