@@ -509,7 +509,7 @@ def main():
         n2r, l2r, s2r = (1, n2 * length, n2 * length) if args.one_string else (n2, length, stride)
         # (a wide table: a second round -- once adapt() has seen the scans leave the dense rows the library takes the
         # class-indexed walk, whose own visit samples then rank the states beyond the dense rows)
-        for _ in range(2 if wide_entry else 1):
+        for _ in range(4 if wide_entry else 1):
             for _ in range(3):
                 table.run_strided_device(text2.data_ptr(), n2r, l2r, s2r, flags, out_idx.data_ptr(), out_fin.data_ptr(), 0, 0,
                                          stream)
@@ -642,7 +642,9 @@ def main():
         launches_since_ranking = settle + args.warmup + args.steps + (cold_launches if from_idle else 0)
         table.adapt()
         samples = int(table.refresh_info().last_trap_samples)
+        wide_chunks = int(table.info.last_wide_trap_chunks)
         res["traps"] = {"cold_samples": samples, "launches": launches_since_ranking,
+                        "wide_walk_wave_chunk_share_walked_twice": round(wide_chunks / max(1.0, launches_since_ranking * float(n) * length / 1024.0), 6),
                         "cold_lane_chunk_share": round(samples * 64.0 / max(1.0, launches_since_ranking * float(n) * length / 16.0), 8),
                         "what": "share of (lane, 16-byte chunk) pairs of the timed corpus that ended in a state without a dense row"}
         if from_idle:

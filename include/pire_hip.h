@@ -189,6 +189,9 @@ typedef struct pire_hip_table_info {
 	float outside_wide_share;    /* states without a dense row / without a wide row                                        */
 	uint32_t shares_measured;    /* 1: those shares come from visit counters                                               */
 	uint32_t reserved2;
+	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
+	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
+	                                /* (exact, all devices)                                                                 */
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */

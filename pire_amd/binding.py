@@ -58,6 +58,7 @@ class TableInfo(C.Structure):
         ("outside_wide_share", C.c_float),
         ("shares_measured", C.c_uint32),
         ("reserved2", C.c_uint32),
+        ("last_wide_trap_chunks", C.c_uint64),
     ]
 
 

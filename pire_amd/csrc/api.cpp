@@ -1043,6 +1043,7 @@ try {
 	out->outside_dense_share = h.outsideDense;
 	out->outside_wide_share = h.outsideWide;
 	out->shares_measured = h.massMeasured ? 1 : 0;
+	out->last_wide_trap_chunks = h.lastWideTrapChunks;
 	out->device_bytes = 0;   // all images (one per device the table has run on)
 	{
 		// devs[] is written by the first run on a device, under uploadMutex (found by ThreadSanitizer, round 4: this loop

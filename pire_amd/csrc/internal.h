@@ -112,7 +112,7 @@ inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps
 //     u16 next[letters]   LDS byte address / 4 of the target state's row (the escape row for targets without one)
 //     u16 id              the row's own device state id (the escape row: `wide`)
 //     u16 flags           kFinal | kDead | kAbsorbing of the state
-// padded to a multiple of 4 bytes; cls8 (2 * letter class of every byte value) sits at LDS address 0, so that the byte
+// padded to an odd number of dwords; cls8 (2 * letter class of every byte value) sits at LDS address 0, so that the byte
 // IS the address of its class.  Behind the rows: one u32 visit counter per row (what pire_hip_table_adapt() ranks from).
 struct WideLayout {
 	uint32_t pitch;      // bytes per row
@@ -124,7 +124,13 @@ struct WideLayout {
 	uint32_t total;
 };
 
-__host__ __device__ inline uint32_t WidePitch(uint32_t letters) { return ((letters + 2) * 2 + 3) / 4 * 4; }
+// (an ODD number of dwords per row: rows then start in every LDS bank in turn -- with 18 dwords, 34 letters, the lanes of a
+// wave that read the same letter's entry of different rows would share 16 of the 32 banks)
+__host__ __device__ inline uint32_t WidePitch(uint32_t letters)
+{
+	const uint32_t dwords = ((letters + 2) * 2 + 3) / 4;
+	return (dwords | 1u) * 4;
+}
 
 __host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t letters, uint32_t regexps)
 {
@@ -195,6 +201,7 @@ struct HostTable {
 	std::vector<double> seenMass;     // [states] what the scans so far visited (lane-steps, halved at every adapt(); orig numbering)
 	std::vector<double> priorMass;    // [states] expected visits under the byte model, max-normalised (orig numbering)
 	uint64_t lastTrapSamples = 0;     // cold-state samples seen by the most recent pire_hip_table_adapt()
+	uint64_t lastWideTrapChunks = 0;  // 16-byte wave-chunks the wide walk walked twice, as seen by the most recent adapt() (exact)
 	uint32_t adaptations = 0;
 };
 

@@ -1186,6 +1186,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	const uint32_t N = h.states, H = h.hot;
 	// what every device that ever ran this table saw, summed
 	std::vector<uint64_t> hot(256, 0), cold(N, 0), wide(h.wide + 1, 0);
+	uint64_t wideTrapChunks = 0;   // wave-chunks the wide walk walked twice since the last adapt() (exact)
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
@@ -1193,13 +1194,13 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		if (e != hipSuccess)
 			return HipFail(e, "hipGetDevice");
 		bool any = false;
-		std::vector<uint32_t> bufHot(256), bufCold(N), bufWide(h.wide + 1, 0);
+		std::vector<uint32_t> bufHot(kVisitHotSlots), bufCold(N), bufWide(h.wide + 1, 0);
 		for (int k = 0; k < kMaxDevices; ++k) {
 			if (t->devs[k].device < 0)
 				continue;
 			any = true;
 			if ((e = hipSetDevice(k)) == hipSuccess && (e = hipDeviceSynchronize()) == hipSuccess &&
-			    (e = hipMemcpy(bufHot.data(), t->devs[k].visitHot, 256 * 4, hipMemcpyDeviceToHost)) == hipSuccess)
+			    (e = hipMemcpy(bufHot.data(), t->devs[k].visitHot, kVisitHotSlots * 4, hipMemcpyDeviceToHost)) == hipSuccess)
 				e = hipMemcpy(bufCold.data(), t->devs[k].visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
 			if (e == hipSuccess && t->devs[k].visitWide && h.wide)
 				e = hipMemcpy(bufWide.data(), t->devs[k].visitWide, size_t(h.wide + 1) * 4, hipMemcpyDeviceToHost);
@@ -1209,6 +1210,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 			}
 			for (uint32_t i = 0; i < 256; ++i)
 				hot[i] += bufHot[i];
+			wideTrapChunks += bufHot[kWideTrapSlot];
 			for (uint32_t i = 0; i < N; ++i)
 				cold[i] += bufCold[i];
 			if (t->devs[k].visitWide)
@@ -1242,6 +1244,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		score[o] = h.seenMass[o] + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
 	}
 	h.lastTrapSamples = coldSamples;
+	h.lastWideTrapChunks = wideTrapChunks;
 	h.massMeasured = true;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());

@@ -65,15 +65,26 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 
 // A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly.
 // One dependent load per byte: the row entry in LDS while the state has a row, the table in memory while it has none
-// (cold = its device id).  Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
+// (cold = its device id); the class of the next byte is asked for before this byte's row.  Rolled on purpose
+// (instantiated once per unrolled chunk of the tile walk).
+// What pire_hip_table_adapt() ranks the states beyond the rows by: at ONE step of the 16 (rotating) the first lane of the
+// wave that is outside the rows adds 1 to its state's counter.  (Round 5's first form sampled one fixed lane of 64 at
+// the chunk's end, like TrapChunk: a state that carries 1e-6 of the steps was never seen, stayed outside the rows, and
+// although 2 148 rows were there for 1 530 visited states, 36 % of all wave-chunks were walked twice,
+// profiles/r05_pmc_wide_first.txt.)
 template <bool N16>
 __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
-                                              uint32_t row0, uint32_t& row, uint32_t& cold, uint32_t sampleLane)
+                                              uint32_t row0, uint32_t& row, uint32_t& cold, uint32_t sampleStep)
 {
 	uint32_t r = row0, cd = cold;
+	uint32_t c2 = HotLookup(v.x & 0xFFu);   // 2 * letter class
 #pragma unroll 1
-	for (int i = 0; i < 16; ++i) {
-		const uint32_t c2 = HotLookup(v.x & 0xFFu);   // 2 * letter class
+	for (uint32_t i = 0; i < 16; ++i) {
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
 		if (r != K.esc4) {
 			const uint32_t nr = LdsU16((r << 2) + c2);
 			if (nr == K.esc4)
@@ -86,18 +97,20 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 			else
 				cd = nx;
 		}
-		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-		v.w >>= 8;
+		if (i == sampleStep) {
+			const bool out = r == K.esc4;
+			const unsigned long long m = __ballot(out);
+			if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+				atomicAdd(&p.visitCold[cd], 1u);
+		}
+		c2 = c2n;
 	}
 	row = r;
 	cold = cd;
-	// tell pire_hip_table_adapt() which states deserve a row: sampled like TrapChunk's (one rotating lane of 64)
-	if (r == K.esc4 && (threadIdx.x & 63) == sampleLane) {
-		atomicAdd(&p.visitCold[cd], 1u);
+	// one more wave-chunk that was walked twice (exact count, block-local)
+	const unsigned long long lanes = __ballot(true);
+	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
-	}
 }
 
 // 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
@@ -120,7 +133,7 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 		row = LdsU16((row << 2) + c3);
 	}
 	if (row == K.esc4)
-		WideTrapChunk<N16>(p, lds, W, K, v, row0, row, cold, sampleLane);
+		WideTrapChunk<N16>(p, lds, W, K, v, row0, row, cold, sampleLane & 15u);
 }
 
 template <bool N16>

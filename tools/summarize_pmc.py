@@ -7,6 +7,9 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+# --last K: only the K most recent dispatches of each kernel (the timed region of a bench.py run: the launches before it
+# belong to the held-out corpus and to a never-adapted table, whose counters are another kernel's as far as traps go)
+last = int(sys.argv[sys.argv.index("--last") + 1]) if "--last" in sys.argv else 0
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:
@@ -21,5 +24,7 @@ for k, ctrs in acc.items():
         per = defaultdict(float)
         for d, v in vals:
             per[d] += v           # sum over XCDs / SEs of one dispatch
-        xs = list(per.values())
+        xs = [per[d] for d in sorted(per, key=lambda d: int(d))]
+        if last:
+            xs = xs[-last:]
         print("  %-32s dispatches %3d  avg/dispatch %.6g" % (c, len(xs), sum(xs) / len(xs)))

@@ -79,7 +79,7 @@ def point_records(entry, corpus, n, length, reps):
     total = n * length
     for variant, label in ((1, "dense"), (2, "wide"), (0, "auto")):
         pb.set_config(walk_variant=variant, auto_adapt=1)
-        for _ in range(2):   # the ranking learned from the batch itself, with the walk that is measured
+        for _ in range(4):   # the ranking learned from the batch itself, with the walk that is measured
             launch()
             torch.cuda.synchronize()
             t.adapt()
@@ -91,7 +91,8 @@ def point_records(entry, corpus, n, length, reps):
         launches = max(20, int(40.0 / max(total / 2.5e9, 0.05))) + reps
         res[label] = {"kernel": kernel, "GBps": round(total / mean / 1e6, 1), "GBps_best": round(total / best / 1e6, 1),
                       "ms": round(mean, 4), "parity_all_strings": ok,
-                      "lane_chunk_share_left_in_no_row": round(i2.last_trap_samples * 64.0 / max(1.0, launches * total / 16.0), 8),
+                      "trap_samples": int(i2.last_trap_samples),
+                      "wave_chunk_share_walked_twice_by_the_wide_walk": round(i2.last_wide_trap_chunks / max(1.0, launches * total / 1024.0), 6),
                       "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6),
                       "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6)}
     return res
