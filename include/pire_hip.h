@@ -153,7 +153,10 @@ typedef struct pire_hip_config {
 	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
 	                               /* outside the 255 dense rows passes 0.3 % (measured by adapt(); 5 % of the a-priori    */
 	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
-	                               /* class-indexed walk.  Same results either way.                                        */
+	                               /* class-indexed walk in the form that walks a chunk a second time when a lane left the */
+	                               /* rows (working sets that fit them); 3 always in the form that asks at every step      */
+	                               /* (working sets that do not; 0 picks between the two by the exact share of wave-chunks */
+	                               /* with a lane outside the rows).  Same results either way.                             */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -192,6 +195,9 @@ typedef struct pire_hip_table_info {
 	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
 	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
 	                                /* (exact, all devices)                                                                 */
+	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time: above 0.05 the   */
+	                                /* walk takes the form that asks at every step whether a lane is outside the rows       */
+	uint32_t reserved3;
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */

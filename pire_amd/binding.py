@@ -59,6 +59,8 @@ class TableInfo(C.Structure):
         ("shares_measured", C.c_uint32),
         ("reserved2", C.c_uint32),
         ("last_wide_trap_chunks", C.c_uint64),
+        ("wide_outside_chunk_share", C.c_float),
+        ("reserved3", C.c_uint32),
     ]
 
 

@@ -201,6 +201,8 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->outsideDense = h.outsideDense;
 	p->outsideWide = h.outsideWide;
 	p->massMeasured = h.massMeasured;
+	p->wideTwiceShare = h.wideTwiceShare;
+	p->wideLaunched = &t->wideLaunched;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
 	p->hotDeadLo = h.hotDeadLo;
@@ -1044,6 +1046,7 @@ try {
 	out->outside_wide_share = h.outsideWide;
 	out->shares_measured = h.massMeasured ? 1 : 0;
 	out->last_wide_trap_chunks = h.lastWideTrapChunks;
+	out->wide_outside_chunk_share = h.wideTwiceShare;
 	out->device_bytes = 0;   // all images (one per device the table has run on)
 	{
 		// devs[] is written by the first run on a device, under uploadMutex (found by ThreadSanitizer, round 4: this loop

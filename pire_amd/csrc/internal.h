@@ -196,6 +196,8 @@ struct HostTable {
 	float outsideDense = 0;           // share of the ranking's mass on states WITHOUT a dense row / ...
 	float outsideWide = 0;            // ... without a wide row (from the byte model until adapt() has seen scans, then measured)
 	bool massMeasured = false;        // those shares come from visit counters, not from the a-priori byte model
+	float wideTwiceShare = 0;         // share of the wide walk's 16-byte wave-chunks in which a lane was outside the rows (exact,
+	                                  // between the two most recent adapt() calls): chooses the form of the wide walk
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
 	std::vector<double> seenMass;     // [states] what the scans so far visited (lane-steps, halved at every adapt(); orig numbering)
@@ -318,6 +320,7 @@ struct pire_hip_table {
 	// images: no call can be between "copied the pointers" and "enqueued its kernels" at that moment.
 	std::shared_mutex adaptMutex;
 	std::atomic<uint32_t> autoAdapts{0};
+	std::atomic<uint64_t> wideLaunched{0};   // wave-chunks handed to the wide walk since the last adapt()
 };
 namespace pirehip { constexpr uint32_t kMaxAutoAdapts = 6; }
 
@@ -350,6 +353,8 @@ struct ScanParams {
 	uint32_t* visitWide;
 	uint32_t wide;              // states with a wide row; 0 = no image
 	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
+	float wideTwiceShare;              // host side only: share of the wide walk's wave-chunks with a lane outside the rows (last adapt())
+	std::atomic<uint64_t>* wideLaunched;   // host side only: wave-chunks handed to the wide walk since the last adapt()
 	bool massMeasured;                 // host side only
 	const uint64_t* incPerm; // nullable
 	uint32_t hotFinalLo;

@@ -1245,6 +1245,11 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	}
 	h.lastTrapSamples = coldSamples;
 	h.lastWideTrapChunks = wideTrapChunks;
+	{
+		const uint64_t launched = t->wideLaunched.exchange(0, std::memory_order_relaxed);
+		if (launched)   // (no wide launch since the last adapt(): the share stays what it was)
+			h.wideTwiceShare = float(std::min(1.0, double(wideTrapChunks) / double(launched)));
+	}
 	h.massMeasured = true;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());

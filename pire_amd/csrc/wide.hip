@@ -63,10 +63,12 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 	return p.nextPerm[size_t(st) * p.letters + cls];
 }
 
-// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly.
-// One dependent load per byte: the row entry in LDS while the state has a row, the table in memory while it has none
-// (cold = its device id); the class of the next byte is asked for before this byte's row.  Rolled on purpose
-// (instantiated once per unrolled chunk of the tile walk).
+// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly:
+// device ids through the exact table in memory, ONE dependent load per byte for every lane of the re-walk whether its
+// state has a row or not (the first form read the row in LDS where there was one, the row's id when it led out, and the
+// table otherwise -- three dependent round trips in every iteration as soon as the lanes of a wave disagreed: 1 000
+// clocks per step, profiles/r05b_wide_curve.jsonl); the class of the next byte is asked for before this byte's step.
+// Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
 // What pire_hip_table_adapt() ranks the states beyond the rows by: at ONE step of the 16 (rotating) the first lane of the
 // wave that is outside the rows adds 1 to its state's counter.  (Round 5's first form sampled one fixed lane of 64 at
 // the chunk's end, like TrapChunk: a state that carries 1e-6 of the steps was never seen, stayed outside the rows, and
@@ -76,8 +78,16 @@ template <bool N16>
 __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
                                               uint32_t row0, uint32_t& row, uint32_t& cold, uint32_t sampleStep)
 {
-	uint32_t r = row0, cd = cold;
+	// the device id of the state the chunk started in: the row's own id field, or (escape row: id == wide) the lane's
+	uint32_t sid = LdsU16((row0 << 2) + K.idOff);
+	sid = sid < p.wide ? sid : cold;
 	uint32_t c2 = HotLookup(v.x & 0xFFu);   // 2 * letter class
+	// one wave-chunk more that is walked twice (exact count, block-local); every 16th of them leaves a sample
+	const unsigned long long lanes = __ballot(true);
+	uint32_t nth = 0;
+	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
+		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 15u) == 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16; ++i) {
 		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
@@ -85,32 +95,17 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
 		v.w >>= 8;
 		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
-		if (r != K.esc4) {
-			const uint32_t nr = LdsU16((r << 2) + c2);
-			if (nr == K.esc4)
-				cd = WideNext<N16>(p, LdsU16((r << 2) + K.idOff), c2 >> 1);
-			r = nr;
-		} else {
-			const uint32_t nx = WideNext<N16>(p, cd, c2 >> 1);
-			if (nx < p.wide)
-				r = K.base4 + nx * K.pitch4;
-			else
-				cd = nx;
-		}
-		if (i == sampleStep) {
-			const bool out = r == K.esc4;
+		sid = WideNext<N16>(p, sid, c2 >> 1);           // ONE load per step for every lane of the re-walk, row or no row
+		if (sampled && i == sampleStep) {
+			const bool out = sid >= p.wide;
 			const unsigned long long m = __ballot(out);
 			if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-				atomicAdd(&p.visitCold[cd], 1u);
+				atomicAdd(&p.visitCold[sid], 1u);
 		}
 		c2 = c2n;
 	}
-	row = r;
-	cold = cd;
-	// one more wave-chunk that was walked twice (exact count, block-local)
-	const unsigned long long lanes = __ballot(true);
-	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+	row = sid < p.wide ? K.base4 + sid * K.pitch4 : K.esc4;
+	cold = sid;
 }
 
 // 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
@@ -136,11 +131,109 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 		WideTrapChunk<N16>(p, lds, W, K, v, row0, row, cold, sampleLane & 15u);
 }
 
+// ---- the same walk for tables whose scans leave the rows all the time (INL) ------------------------------------------
+// With 2 % of the steps outside the rows two of three wave-steps have a lane there, every chunk is walked twice, and the
+// re-walk sends EVERY lane of the chunk through the table in memory: the L1 serves about one scattered access per clock
+// and CU, so a 64-lane re-walk step costs what 64 accesses cost (profiles/r05c_wide_curve.jsonl: 450-1 250 clocks per
+// step).  This form has no re-walk.  Every step asks, wave-wide, whether a lane is outside the rows; only those lanes go
+// to memory, their load is issued BEFORE the row lookup of the others, and a lane that comes back to a state with a row
+// is back in LDS at once:
+//     row lanes:   nr = u16[(row << 2) + c]                                      (as ever)
+//     cold lanes:  g  = next[cd][class]   -> row = rowOf(g) if g has a row, else cd = g
+//     leaving now: cd = next[id(row)][class]                                      (nr == escape row)
+// Rolled over the four dwords of a chunk (the lane's chunk is shifted through one register): 16 copies of the step per
+// chunk would be 60 KB of code.
+// (Every load is issued and waited for inside ONE arm of a wave-uniform branch: with the cold lanes' load issued in front
+// of the row lookup and looked at behind it, hipcc put an s_waitcnt vmcnt(0) in front of every row lookup -- the register
+// the load lands in is written again in the next step -- and that wait is also a wait for the tile on its way.)
+// non-zero iff `x` holds in some lane: a value the compiler knows to be wave-uniform (a scalar branch, not an exec mask)
+__device__ __forceinline__ uint32_t WaveAny(bool x)
+{
+	const unsigned long long m = __builtin_amdgcn_ballot_w64(x);
+	return uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(m) | uint32_t(m >> 32))));
+}
+
 template <bool N16>
+__device__ __forceinline__ void WideStepInline(const ScanParams& p, const WideConst& K, uint32_t c2, uint32_t& row, uint32_t& cd,
+                                               uint32_t& anyCold)
+{
+	if (!anyCold) {
+		// nobody was outside the rows after the step before
+		const uint32_t nr = LdsU16((row << 2) + c2);
+		const bool out = nr == K.esc4;
+		anyCold = WaveAny(out);
+		if (anyCold) {
+			if (out) {   // leaves the rows with this step
+				cd = WideNext<N16>(p, LdsU16((row << 2) + K.idOff), c2 >> 1);
+				asm volatile("" : "+v"(cd));   // the wait for this load belongs in here, not at the join every step passes
+			}
+		}
+		row = nr;
+	} else {
+		const bool wasCold = row == K.esc4;
+		uint32_t nr = LdsU16((row << 2) + c2);   // asked for first, looked at behind the cold lanes' load
+		uint32_t g = 0;
+		if (wasCold) {
+			g = WideNext<N16>(p, cd, c2 >> 1);
+			asm volatile("" : "+v"(g));           // (the wait belongs in here, as above)
+		}
+		const bool out = nr == K.esc4;
+		if (out && !wasCold) {                   // leaves the rows with this step
+			g = WideNext<N16>(p, LdsU16((row << 2) + K.idOff), c2 >> 1);
+			asm volatile("" : "+v"(g));
+		}
+		if (out) {
+			if (wasCold && g < p.wide)
+				nr = K.base4 + g * K.pitch4;      // back in a state with a row
+			else
+				cd = g;
+		}
+		anyCold = WaveAny(nr == K.esc4);
+		row = nr;
+	}
+}
+
+template <bool N16>
+__device__ __forceinline__ void WideChunkInline(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
+                                                uint32_t& row, uint32_t& cd, uint32_t& anyCold, bool sample)
+{
+	uint32_t sawCold = anyCold;
+#pragma unroll 1
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v.x;
+		const uint32_t c0 = HotLookup(x & 0xFFu);
+		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
+		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
+		const uint32_t c3 = HotLookup(x >> 24);
+		WideStepInline<N16>(p, K, c0, row, cd, anyCold);
+		sawCold |= anyCold;
+		WideStepInline<N16>(p, K, c1, row, cd, anyCold);
+		sawCold |= anyCold;
+		WideStepInline<N16>(p, K, c2, row, cd, anyCold);
+		sawCold |= anyCold;
+		WideStepInline<N16>(p, K, c3, row, cd, anyCold);
+		sawCold |= anyCold;
+		v.x = v.y;
+		v.y = v.z;
+		v.z = v.w;
+	}
+	if (sawCold) {
+		// one more wave-chunk with a lane outside the rows (exact count, block-local: the same statistic the other form
+		// keeps of its re-walks); `sample`: the first lane that is outside them right now tells adapt() where it is
+		const bool out = row == K.esc4;
+		const unsigned long long m = __ballot(out);
+		if ((threadIdx.x & 63) == 0)
+			atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+		if (sample && out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+			atomicAdd(&p.visitCold[cd], 1u);
+	}
+}
+
+template <bool N16, bool INL>
 __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, uint64_t rowBase,
                                           uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
                                           uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& row, uint32_t& cold,
-                                          uint32_t* prog, uint32_t& myTiles)
+                                          uint32_t* prog, uint32_t& myTiles, uint32_t& anyCold)
 {
 	{   // the waves of a block kept in step (tiled.hip, EQ)
 		uint32_t sum = 0;
@@ -163,13 +256,17 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating (the escape row counts into slot `wide`)
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + LdsU16((row << 2) + K.idOff), 1u);
 #pragma unroll
-	for (int k = 0; k < 8; ++k)
-		WideChunk<N16>(p, lds, W, K, cur[k], row, cold, (t * 8 + k) & 63);
+	for (int k = 0; k < 8; ++k) {
+		if (INL)
+			WideChunkInline<N16>(p, lds, W, K, cur[k], row, cold, anyCold, ((t * 8 + k) & 15) == 0);
+		else
+			WideChunk<N16>(p, lds, W, K, cur[k], row, cold, (t * 8 + k) & 63);
+	}
 }
 
 // Fixed-length records, 16-byte aligned, an EVEN number of 128-byte tiles per record (+ a tail shorter than a tile),
 // whole tasks of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries.
-template <bool N16>
+template <bool N16, bool INL>
 __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -222,12 +319,13 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		                                   : rowBase + uint64_t(lastTile) * 128;
 		uint32_t cold = StartState(p, s);
 		uint32_t row = cold < p.wide ? K.base4 + cold * K.pitch4 : K.esc4;
+		uint32_t anyCold = INL ? WaveAny(row == K.esc4) : 0u;
 		bool done = false;
 		if (!primed)
 			WideIssueTile(a, voff, rowBase, istride);
 		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
-			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, row, cold, prog, myTiles);
-			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, row, cold, prog, myTiles);
+			WidePhase<N16, INL>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, row, cold, prog, myTiles, anyCold);
+			WidePhase<N16, INL>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, row, cold, prog, myTiles, anyCold);
 			// wave-wide early out (multi.h:955-958): every lane in a row whose every transition is a self loop
 			done = __all((LdsU16((row << 2) + K.idOff + 2) & kAbsorbing) != 0);
 		}
@@ -279,7 +377,7 @@ bool WideWanted(const ScanParams& p, const pire_hip_config& cfg)
 		return false;   // the segmented scan's passes stay on the kernels they were measured on
 	if (p.outCounts && p.regexps > kMaxLdsCountRegexps)
 		return false;
-	if (cfg.walk_variant == 2)
+	if (cfg.walk_variant >= 2)
 		return true;
 	// a lane-step share of 0.3 % outside the dense rows puts a lane outside them in a fifth of all wave-chunks, each of
 	// which is then walked twice; the wide walk costs half as much again everywhere (measured: DESIGN.md 5.4)
@@ -294,12 +392,20 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
+	// Two forms of the walk (same results): chunks in which a lane left the rows walked a second time -- nothing in the
+	// step but the two lookups, for working sets that fit the rows (4.3 TB/s) --, or every step asking whether a lane is
+	// outside them (INL), for working sets that do not.  By the share of wave-chunks the scans since the last adapt() had
+	// a lane outside the rows in (exact counters); walk_variant 2 / 3 force one.
+	const pire_hip_config cfg = GetConfig();
+	const bool inl = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.05f);
+	if (p.wideLaunched)
+		p.wideLaunched->fetch_add(q.n / 64 * (p.len / 16), std::memory_order_relaxed);
 	if (p.next16) {
-		NoteKernel("wide", "pirehip::ScanWideKernel<u16 table>");
-		rc = LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
+		NoteKernel("wide", inl ? "pirehip::ScanWideKernel<u16 table, every step asks>" : "pirehip::ScanWideKernel<u16 table>");
+		rc = inl ? LaunchScan(ScanWideKernel<true, true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true, false>, q, 1024, W.total, stream);
 	} else {
-		NoteKernel("wide", "pirehip::ScanWideKernel<u32 table>");
-		rc = LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
+		NoteKernel("wide", inl ? "pirehip::ScanWideKernel<u32 table, every step asks>" : "pirehip::ScanWideKernel<u32 table>");
+		rc = inl ? LaunchScan(ScanWideKernel<false, true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false, false>, q, 1024, W.total, stream);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

@@ -77,7 +77,7 @@ def point_records(entry, corpus, n, length, reps):
         return bool((gi == oi[None, :]).all() and (gf == of[None, :]).all())
 
     total = n * length
-    for variant, label in ((1, "dense"), (2, "wide"), (0, "auto")):
+    for variant, label in ((1, "dense"), (2, "wide"), (3, "wide_steps"), (0, "auto")):
         pb.set_config(walk_variant=variant, auto_adapt=1)
         for _ in range(4):   # the ranking learned from the batch itself, with the walk that is measured
             launch()
@@ -94,7 +94,8 @@ def point_records(entry, corpus, n, length, reps):
                       "trap_samples": int(i2.last_trap_samples),
                       "wave_chunk_share_walked_twice_by_the_wide_walk": round(i2.last_wide_trap_chunks / max(1.0, launches * total / 1024.0), 6),
                       "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6),
-                      "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6)}
+                      "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6),
+                      "symbol": pb.last_kernel_symbol()}
     return res
 
 
