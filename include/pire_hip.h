@@ -153,10 +153,7 @@ typedef struct pire_hip_config {
 	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
 	                               /* outside the 255 dense rows passes 0.3 % (measured by adapt(); 5 % of the a-priori    */
 	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
-	                               /* class-indexed walk in the form that walks a chunk a second time when a lane left the */
-	                               /* rows (working sets that fit them); 3 always in the form that asks at every step      */
-	                               /* (working sets that do not; 0 picks between the two by the exact share of wave-chunks */
-	                               /* with a lane outside the rows).  Same results either way.                             */
+	                               /* class-indexed walk.  Same results either way.                                        */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -195,8 +192,7 @@ typedef struct pire_hip_table_info {
 	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
 	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
 	                                /* (exact, all devices)                                                                 */
-	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time: above 0.05 the   */
-	                                /* walk takes the form that asks at every step whether a lane is outside the rows       */
+	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time                   */
 	uint32_t reserved3;
 } pire_hip_table_info;
 
@@ -298,8 +294,9 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
  * ... and of the class-indexed walk's LDS image (pire_hip_config.walk_variant; tables with more states than dense rows):
  * *wide_states device ids [0, wide_states) have a row, *pitch bytes apart, the first at LDS byte address *rows_offset;
  * rows[(wide_states + 1) * pitch / 2] (cap = its capacity in u16 entries; NULL: only the geometry): per row `letters`
- * entries = LDS address / 4 of the target state's row (the last row, the escape row, for targets without one), then the
- * row's device id, then its flags (1 Final, 2 Dead, 4 every transition a self loop).  wide_states == 0: no such image.
+ * entries = the device id of the target state (wide_states, the id of the last row -- the escape row, which leads to
+ * itself -- for targets without a row), then the row's flags (1 Final, 2 Dead, 4 every transition a self loop).
+ * wide_states == 0: no such image.
  */
 int pire_hip_table_wide_layout(const pire_hip_table* t, uint16_t* rows, size_t cap, uint32_t* wide_states, uint32_t* pitch,
                                uint32_t* rows_offset);

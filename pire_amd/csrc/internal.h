@@ -108,12 +108,12 @@ inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps
 // ---- the wide walk (wide.hip, round 5) ---------------------------------------------------------------------------------
 // Tables whose scans keep leaving the 255 dense rows take a walk of their own: NO dense rows, the whole LDS of the CU
 // holds class-indexed u16 rows of the first `wide` states of the ranking (multi.h:169-192 as it stands: letter =
-// m_letters[ch], state = row[letter] -- with the row's LDS address as the state).  A row is
-//     u16 next[letters]   LDS byte address / 4 of the target state's row (the escape row for targets without one)
-//     u16 id              the row's own device state id (the escape row: `wide`)
+// m_letters[ch], state = row[letter]).  A row is
+//     u16 next[letters]   device id of the target state; `wide` (the escape row's id) for targets without a row
 //     u16 flags           kFinal | kDead | kAbsorbing of the state
-// padded to an odd number of dwords; cls8 (2 * letter class of every byte value) sits at LDS address 0, so that the byte
-// IS the address of its class.  Behind the rows: one u32 visit counter per row (what pire_hip_table_adapt() ranks from).
+// padded to an odd number of dwords; row `wide`, the escape row, leads to itself.  cls8 (2 * letter class of every byte
+// value) sits at LDS address 0, so that the byte IS the address of its class.  Behind the rows: one u32 visit counter
+// per row (what pire_hip_table_adapt() ranks from).
 struct WideLayout {
 	uint32_t pitch;      // bytes per row
 	uint32_t rowsOff;    // 256
@@ -128,7 +128,7 @@ struct WideLayout {
 // wave that read the same letter's entry of different rows would share 16 of the 32 banks)
 __host__ __device__ inline uint32_t WidePitch(uint32_t letters)
 {
-	const uint32_t dwords = ((letters + 2) * 2 + 3) / 4;
+	const uint32_t dwords = ((letters + 1) * 2 + 3) / 4;
 	return (dwords | 1u) * 4;
 }
 
@@ -144,9 +144,6 @@ __host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t let
 	w.total = w.progOff + 16;
 	return w;
 }
-
-// LDS row address / 4 of device state id `pid` (pid <= wide; == wide: the escape row)
-__host__ __device__ inline uint32_t WideRow4(const WideLayout& w, uint32_t pid) { return (w.rowsOff + pid * w.pitch) >> 2; }
 
 // How many states get a wide row (0: the wide walk is not for this table).
 inline uint32_t WideCapacity(uint32_t letters, uint32_t regexps, uint32_t states)
@@ -196,8 +193,8 @@ struct HostTable {
 	float outsideDense = 0;           // share of the ranking's mass on states WITHOUT a dense row / ...
 	float outsideWide = 0;            // ... without a wide row (from the byte model until adapt() has seen scans, then measured)
 	bool massMeasured = false;        // those shares come from visit counters, not from the a-priori byte model
-	float wideTwiceShare = 0;         // share of the wide walk's 16-byte wave-chunks in which a lane was outside the rows (exact,
-	                                  // between the two most recent adapt() calls): chooses the form of the wide walk
+	float wideTwiceShare = 0;         // share of the wide walk's 16-byte wave-chunks it walked twice (exact, between the two most
+	                                  // recent adapt() calls)
 	std::vector<uint8_t> hotRows;     // [(hot + 1) * 256] u8: next perm id (< hot) or `hot` (= leaves the hot set)
 	std::vector<uint8_t> hotFlags;    // [256] flags of hot perm ids (kAbsorbing used for the early-out ballot)
 	std::vector<double> seenMass;     // [states] what the scans so far visited (lane-steps, halved at every adapt(); orig numbering)
@@ -353,7 +350,6 @@ struct ScanParams {
 	uint32_t* visitWide;
 	uint32_t wide;              // states with a wide row; 0 = no image
 	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
-	float wideTwiceShare;              // host side only: share of the wide walk's wave-chunks with a lane outside the rows (last adapt())
 	std::atomic<uint64_t>* wideLaunched;   // host side only: wave-chunks handed to the wide walk since the last adapt()
 	bool massMeasured;                 // host side only
 	const uint64_t* incPerm; // nullable

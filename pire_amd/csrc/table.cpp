@@ -701,20 +701,18 @@ void FreeAllDeviceTables(pire_hip_table* t)
 		(void)hipSetDevice(cur);
 }
 
-// The wide walk's LDS image (internal.h WideLayout) in the table's current numbering: entry = LDS address / 4 of the
-// target's row, the escape row for targets without one; then the row's own id and its flags.
+// The wide walk's LDS image (internal.h WideLayout) in the table's current numbering: entry = device id of the target,
+// `wide` (the escape row) for targets without a row; then the row's flags.
 std::vector<uint16_t> BuildWideRows(const HostTable& h)
 {
 	const uint32_t W = h.wide, C = h.letters, pitch2 = WidePitch(C) / 2;
-	const WideLayout wl = MakeWideLayout(W, C, 0);
 	std::vector<uint16_t> rows((size_t(W + 1) * pitch2 + 7) / 8 * 8, 0);
 	for (uint32_t pid = 0; pid <= W; ++pid) {
 		uint16_t* row = &rows[size_t(pid) * pitch2];
 		const uint32_t o = pid < W ? h.origOfPerm[pid] : 0;
 		for (uint32_t c = 0; c < C; ++c)
-			row[c] = uint16_t(WideRow4(wl, pid < W ? std::min(h.permOfOrig[h.next[size_t(o) * C + c]], W) : W));
-		row[C] = uint16_t(pid);
-		row[C + 1] = pid < W ? h.flags[o] : 0;
+			row[c] = uint16_t(pid < W ? std::min(h.permOfOrig[h.next[size_t(o) * C + c]], W) : W);
+		row[C] = pid < W ? h.flags[o] : 0;
 	}
 	return rows;
 }

@@ -6,14 +6,15 @@
 // (samples/blacklist/blacklist.cpp:65-76) or a glued table whose text keeps matches alive visits thousands of states;
 // nearly every wave-chunk then holds a lane outside the dense rows.  For such tables this kernel IS multi.h:169-192:
 //
-//     c    = cls8[byte]                      ds_read_u8, off the dependent chain (cls8 at LDS address 0: the byte is the address)
-//     row  = u16[(row << 2) + c]             v_lshl_add_u32 + ds_read_u16, the chain; a row's entries are row addresses / 4
+//     c   = cls8[byte]                       ds_read_u8, off the dependent chain (cls8 at LDS address 0: the byte is the address)
+//     st  = u16[rows + st * pitch + c]       v_mad_u32_u24 + ds_read_u16 (offset: rows), the chain; entries are state ids
 //
 // with class-indexed u16 rows of the first `wide` states of the ranking filling the CU's whole LDS (internal.h
-// WideLayout: 1 700 states at 44 letters, 2 150 at 34).  Targets without a row lead to an absorbing escape row; a lane
-// found there after a chunk is re-walked from the chunk's first byte, one load per byte -- LDS while its state has a row,
-// the exact table in memory (u16 entries when the ids fit: half the cache footprint) while it has none.  Bit-exact for
-// any table and any ranking, like every kernel of the path.  Text path, task numbering, wave levelling: tiled.hip's.
+// WideLayout: 1 700 states at 44 letters, 2 040 at 34).  Targets without a row lead to an absorbing escape row (id ==
+// wide); a lane found there after a chunk is re-walked from the chunk's first byte, one load per byte -- its row in LDS
+// while its state has one, the exact table in memory (u16 entries when the ids fit: half the cache footprint) while it
+// has none.  Bit-exact for any table and any ranking, like every kernel of the path.  Text path, task numbering, wave
+// levelling: tiled.hip's.
 
 #include "device_common.h"
 
@@ -48,11 +49,16 @@ __device__ __forceinline__ void WideWaitTile(u32x4 (&r)[8])
 
 // wave-uniform constants of a launch
 struct WideConst {
-	uint32_t esc4;     // LDS address / 4 of the escape row
-	uint32_t idOff;    // byte offset of a row's own id (2 * letters); its flags follow
-	uint32_t base4;    // LDS address / 4 of row 0
-	uint32_t pitch4;   // row pitch / 4
+	uint32_t pitch;    // bytes per row
+	uint32_t flagsOff; // byte offset of a row's flags (2 * letters)
 };
+
+// A row entry: the u16 at byte `c2` (2 * letter class) of state `st`'s row.  The rows start at LDS byte 256: the DS
+// instruction's immediate offset, so the address is ONE v_mad_u32_u24.
+__device__ __forceinline__ uint32_t WideEntry(uint32_t st, uint32_t pitch, uint32_t c2)
+{
+	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(st, pitch) + c2 + 256u));
+}
 
 // The exact step for a state without a row (device ids in and out).
 template <bool N16>
@@ -63,25 +69,28 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 	return p.nextPerm[size_t(st) * p.letters + cls];
 }
 
-// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly:
-// device ids through the exact table in memory, ONE dependent load per byte for every lane of the re-walk whether its
-// state has a row or not (the first form read the row in LDS where there was one, the row's id when it led out, and the
-// table otherwise -- three dependent round trips in every iteration as soon as the lanes of a wave disagreed: 1 000
-// clocks per step, profiles/r05b_wide_curve.jsonl); the class of the next byte is asked for before this byte's step.
-// Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
-// What pire_hip_table_adapt() ranks the states beyond the rows by: at ONE step of the 16 (rotating) the first lane of the
-// wave that is outside the rows adds 1 to its state's counter.  (Round 5's first form sampled one fixed lane of 64 at
-// the chunk's end, like TrapChunk: a state that carries 1e-6 of the steps was never seen, stayed outside the rows, and
-// although 2 148 rows were there for 1 530 visited states, 36 % of all wave-chunks were walked twice,
-// profiles/r05_pmc_wide_first.txt.)
+// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly.
+// One dependent load per byte: the row's entry in LDS while the state has a row -- and the table in memory behind it
+// only where that entry says "no row" --, the table in memory while it has none; both are asked for before either is
+// waited for, and every load is waited for inside the arm that issued it (a wait left to the join is a vmcnt(0) every
+// lane passes, and that one also waits for the tile on its way).  The class of the next byte is asked for before this
+// byte's step.  Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
+// History (profiles/r05b..r05d_wide_curve.jsonl, dict_1k / k512: 2 738 states visited, 2 041 rows, 1.7 % of the steps
+// outside them, EVERY wave-chunk with a lane outside): row / row's id / table as three dependent round trips per
+// iteration 464 GB/s; every lane of the re-walk through the table in memory, one round trip 887 GB/s -- but 64 scattered
+// accesses per step where all lanes re-walk (the L1 serves about one per clock and CU: dict_10k / k10000 454 GB/s); no
+// re-walk at all, every step asking whether a lane is outside the rows, 644 GB/s here and 2.4 instead of 4.25 TB/s where
+// the working set fits (a third form of the kernel, removed again).
+// What pire_hip_table_adapt() ranks the states beyond the rows by: every 16th re-walk leaves, at one rotating step, the
+// state of the first lane that is outside the rows.  (The first form sampled one fixed lane of 64 at the chunk's end,
+// like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
+// rows were there for 1 530 visited states 36 % of all wave-chunks were walked twice, profiles/r05_pmc_wide_first.txt.)
 template <bool N16>
 __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
-                                              uint32_t row0, uint32_t& row, uint32_t& cold, uint32_t sampleStep)
+                                              uint32_t st0, uint32_t& st, uint32_t& cold, uint32_t sampleStep)
 {
-	// the device id of the state the chunk started in: the row's own id field, or (escape row: id == wide) the lane's
-	uint32_t sid = LdsU16((row0 << 2) + K.idOff);
-	sid = sid < p.wide ? sid : cold;
-	uint32_t c2 = HotLookup(v.x & 0xFFu);   // 2 * letter class
+	uint32_t sid = st0 < p.wide ? st0 : cold;   // the device id of the state the chunk started in
+	uint32_t c2 = HotLookup(v.x & 0xFFu);       // 2 * letter class
 	// one wave-chunk more that is walked twice (exact count, block-local); every 16th of them leaves a sample
 	const unsigned long long lanes = __ballot(true);
 	uint32_t nth = 0;
@@ -95,7 +104,19 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
 		v.w >>= 8;
 		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
-		sid = WideNext<N16>(p, sid, c2 >> 1);           // ONE load per step for every lane of the re-walk, row or no row
+		const bool has = sid < p.wide;
+		uint32_t e = p.wide, g = 0;
+		if (has)
+			e = WideEntry(sid, K.pitch, c2);           // asked for first, looked at behind the other lanes' load
+		if (!has) {
+			g = WideNext<N16>(p, sid, c2 >> 1);
+			asm volatile("" : "+v"(g));                // (the wait belongs in here)
+		}
+		if (has && e == p.wide) {                      // leaves the rows with this step: which state is it?
+			g = WideNext<N16>(p, sid, c2 >> 1);
+			asm volatile("" : "+v"(g));
+		}
+		sid = e == p.wide ? g : e;
 		if (sampled && i == sampleStep) {
 			const bool out = sid >= p.wide;
 			const unsigned long long m = __ballot(out);
@@ -104,16 +125,16 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 		}
 		c2 = c2n;
 	}
-	row = sid < p.wide ? K.base4 + sid * K.pitch4 : K.esc4;
+	st = sid < p.wide ? sid : p.wide;
 	cold = sid;
 }
 
 // 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
 template <bool N16>
 __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
-                                          uint32_t& row, uint32_t& cold, uint32_t sampleLane)
+                                          uint32_t& st, uint32_t& cold, uint32_t sampleLane)
 {
-	const uint32_t row0 = row;
+	const uint32_t st0 = st;
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t x = v[w];
@@ -122,118 +143,20 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
 		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
 		const uint32_t c3 = HotLookup(x >> 24);
-		row = LdsU16((row << 2) + c0);
-		row = LdsU16((row << 2) + c1);
-		row = LdsU16((row << 2) + c2);
-		row = LdsU16((row << 2) + c3);
+		st = WideEntry(st, K.pitch, c0);
+		st = WideEntry(st, K.pitch, c1);
+		st = WideEntry(st, K.pitch, c2);
+		st = WideEntry(st, K.pitch, c3);
 	}
-	if (row == K.esc4)
-		WideTrapChunk<N16>(p, lds, W, K, v, row0, row, cold, sampleLane & 15u);
-}
-
-// ---- the same walk for tables whose scans leave the rows all the time (INL) ------------------------------------------
-// With 2 % of the steps outside the rows two of three wave-steps have a lane there, every chunk is walked twice, and the
-// re-walk sends EVERY lane of the chunk through the table in memory: the L1 serves about one scattered access per clock
-// and CU, so a 64-lane re-walk step costs what 64 accesses cost (profiles/r05c_wide_curve.jsonl: 450-1 250 clocks per
-// step).  This form has no re-walk.  Every step asks, wave-wide, whether a lane is outside the rows; only those lanes go
-// to memory, their load is issued BEFORE the row lookup of the others, and a lane that comes back to a state with a row
-// is back in LDS at once:
-//     row lanes:   nr = u16[(row << 2) + c]                                      (as ever)
-//     cold lanes:  g  = next[cd][class]   -> row = rowOf(g) if g has a row, else cd = g
-//     leaving now: cd = next[id(row)][class]                                      (nr == escape row)
-// Rolled over the four dwords of a chunk (the lane's chunk is shifted through one register): 16 copies of the step per
-// chunk would be 60 KB of code.
-// (Every load is issued and waited for inside ONE arm of a wave-uniform branch: with the cold lanes' load issued in front
-// of the row lookup and looked at behind it, hipcc put an s_waitcnt vmcnt(0) in front of every row lookup -- the register
-// the load lands in is written again in the next step -- and that wait is also a wait for the tile on its way.)
-// non-zero iff `x` holds in some lane: a value the compiler knows to be wave-uniform (a scalar branch, not an exec mask)
-__device__ __forceinline__ uint32_t WaveAny(bool x)
-{
-	const unsigned long long m = __builtin_amdgcn_ballot_w64(x);
-	return uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(m) | uint32_t(m >> 32))));
+	if (st == p.wide)
+		WideTrapChunk<N16>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
 }
 
 template <bool N16>
-__device__ __forceinline__ void WideStepInline(const ScanParams& p, const WideConst& K, uint32_t c2, uint32_t& row, uint32_t& cd,
-                                               uint32_t& anyCold)
-{
-	if (!anyCold) {
-		// nobody was outside the rows after the step before
-		const uint32_t nr = LdsU16((row << 2) + c2);
-		const bool out = nr == K.esc4;
-		anyCold = WaveAny(out);
-		if (anyCold) {
-			if (out) {   // leaves the rows with this step
-				cd = WideNext<N16>(p, LdsU16((row << 2) + K.idOff), c2 >> 1);
-				asm volatile("" : "+v"(cd));   // the wait for this load belongs in here, not at the join every step passes
-			}
-		}
-		row = nr;
-	} else {
-		const bool wasCold = row == K.esc4;
-		uint32_t nr = LdsU16((row << 2) + c2);   // asked for first, looked at behind the cold lanes' load
-		uint32_t g = 0;
-		if (wasCold) {
-			g = WideNext<N16>(p, cd, c2 >> 1);
-			asm volatile("" : "+v"(g));           // (the wait belongs in here, as above)
-		}
-		const bool out = nr == K.esc4;
-		if (out && !wasCold) {                   // leaves the rows with this step
-			g = WideNext<N16>(p, LdsU16((row << 2) + K.idOff), c2 >> 1);
-			asm volatile("" : "+v"(g));
-		}
-		if (out) {
-			if (wasCold && g < p.wide)
-				nr = K.base4 + g * K.pitch4;      // back in a state with a row
-			else
-				cd = g;
-		}
-		anyCold = WaveAny(nr == K.esc4);
-		row = nr;
-	}
-}
-
-template <bool N16>
-__device__ __forceinline__ void WideChunkInline(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
-                                                uint32_t& row, uint32_t& cd, uint32_t& anyCold, bool sample)
-{
-	uint32_t sawCold = anyCold;
-#pragma unroll 1
-	for (int w = 0; w < 4; ++w) {
-		const uint32_t x = v.x;
-		const uint32_t c0 = HotLookup(x & 0xFFu);
-		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
-		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
-		const uint32_t c3 = HotLookup(x >> 24);
-		WideStepInline<N16>(p, K, c0, row, cd, anyCold);
-		sawCold |= anyCold;
-		WideStepInline<N16>(p, K, c1, row, cd, anyCold);
-		sawCold |= anyCold;
-		WideStepInline<N16>(p, K, c2, row, cd, anyCold);
-		sawCold |= anyCold;
-		WideStepInline<N16>(p, K, c3, row, cd, anyCold);
-		sawCold |= anyCold;
-		v.x = v.y;
-		v.y = v.z;
-		v.z = v.w;
-	}
-	if (sawCold) {
-		// one more wave-chunk with a lane outside the rows (exact count, block-local: the same statistic the other form
-		// keeps of its re-walks); `sample`: the first lane that is outside them right now tells adapt() where it is
-		const bool out = row == K.esc4;
-		const unsigned long long m = __ballot(out);
-		if ((threadIdx.x & 63) == 0)
-			atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
-		if (sample && out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-			atomicAdd(&p.visitCold[cd], 1u);
-	}
-}
-
-template <bool N16, bool INL>
 __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, uint64_t rowBase,
                                           uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
-                                          uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& row, uint32_t& cold,
-                                          uint32_t* prog, uint32_t& myTiles, uint32_t& anyCold)
+                                          uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& st, uint32_t& cold,
+                                          uint32_t* prog, uint32_t& myTiles)
 {
 	{   // the waves of a block kept in step (tiled.hip, EQ)
 		uint32_t sum = 0;
@@ -254,28 +177,22 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 	WideWaitTile<1>(cur);
 	TransposeTile(cur, lane);
 	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating (the escape row counts into slot `wide`)
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + LdsU16((row << 2) + K.idOff), 1u);
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
 #pragma unroll
-	for (int k = 0; k < 8; ++k) {
-		if (INL)
-			WideChunkInline<N16>(p, lds, W, K, cur[k], row, cold, anyCold, ((t * 8 + k) & 15) == 0);
-		else
-			WideChunk<N16>(p, lds, W, K, cur[k], row, cold, (t * 8 + k) & 63);
-	}
+	for (int k = 0; k < 8; ++k)
+		WideChunk<N16>(p, lds, W, K, cur[k], st, cold, (t * 8 + k) & 63);
 }
 
 // Fixed-length records, 16-byte aligned, an EVEN number of 128-byte tiles per record (+ a tail shorter than a tile),
 // whole tasks of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries.
-template <bool N16, bool INL>
+template <bool N16>
 __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	WideConst K;
-	K.esc4 = WideRow4(W, p.wide);
-	K.idOff = p.letters * 2;
-	K.base4 = W.rowsOff >> 2;
-	K.pitch4 = W.pitch >> 2;
+	K.pitch = W.pitch;
+	K.flagsOff = p.letters * 2;
 	LdsLayout L = {};           // what Finish() looks at: the block-local counters
 	L.countsOff = W.countsOff;
 
@@ -318,28 +235,26 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
 		                                   : rowBase + uint64_t(lastTile) * 128;
 		uint32_t cold = StartState(p, s);
-		uint32_t row = cold < p.wide ? K.base4 + cold * K.pitch4 : K.esc4;
-		uint32_t anyCold = INL ? WaveAny(row == K.esc4) : 0u;
+		uint32_t st = cold < p.wide ? cold : p.wide;   // the walk's state: a device id with a row, or `wide` = the escape row
 		bool done = false;
 		if (!primed)
 			WideIssueTile(a, voff, rowBase, istride);
 		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
-			WidePhase<N16, INL>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, row, cold, prog, myTiles, anyCold);
-			WidePhase<N16, INL>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, row, cold, prog, myTiles, anyCold);
+			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, st, cold, prog, myTiles);
+			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, st, cold, prog, myTiles);
 			// wave-wide early out (multi.h:955-958): every lane in a row whose every transition is a self loop
-			done = __all((LdsU16((row << 2) + K.idOff + 2) & kAbsorbing) != 0);
+			done = __all((WideEntry(st, K.pitch, K.flagsOff) & kAbsorbing) != 0);
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (done)
 			WideWaitTile<0>(a);
-		const uint32_t id = LdsU16((row << 2) + K.idOff);
-		uint32_t st = id < p.wide ? id : cold;
+		uint32_t end = st < p.wide ? st : cold;
 		if (!done) {   // an odd last tile and the tail shorter than a tile: exact steps straight from memory
 			const uint8_t* base = p.text + s * p.stride;
 			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
-				st = WideNext<N16>(p, st, uint32_t(lds[base[i]]) >> 1);
+				end = WideNext<N16>(p, end, uint32_t(lds[base[i]]) >> 1);
 		}
-		Finish(p, lds, L, s, true, st);
+		Finish(p, lds, L, s, true, end);
 	}
 	WideWaitTile<0>(a);
 	WideWaitTile<0>(b);
@@ -392,20 +307,14 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
-	// Two forms of the walk (same results): chunks in which a lane left the rows walked a second time -- nothing in the
-	// step but the two lookups, for working sets that fit the rows (4.3 TB/s) --, or every step asking whether a lane is
-	// outside them (INL), for working sets that do not.  By the share of wave-chunks the scans since the last adapt() had
-	// a lane outside the rows in (exact counters); walk_variant 2 / 3 force one.
-	const pire_hip_config cfg = GetConfig();
-	const bool inl = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.05f);
 	if (p.wideLaunched)
 		p.wideLaunched->fetch_add(q.n / 64 * (p.len / 16), std::memory_order_relaxed);
 	if (p.next16) {
-		NoteKernel("wide", inl ? "pirehip::ScanWideKernel<u16 table, every step asks>" : "pirehip::ScanWideKernel<u16 table>");
-		rc = inl ? LaunchScan(ScanWideKernel<true, true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true, false>, q, 1024, W.total, stream);
+		NoteKernel("wide", "pirehip::ScanWideKernel<u16 table>");
+		rc = LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
 	} else {
-		NoteKernel("wide", inl ? "pirehip::ScanWideKernel<u32 table, every step asks>" : "pirehip::ScanWideKernel<u32 table>");
-		rc = inl ? LaunchScan(ScanWideKernel<false, true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false, false>, q, 1024, W.total, stream);
+		NoteKernel("wide", "pirehip::ScanWideKernel<u32 table>");
+		rc = LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

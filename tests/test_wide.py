@@ -48,41 +48,18 @@ def test_oracle_against_the_recorded_reference_results(name, corpus):
 
 
 def walk_image(t, strings):
-    """The kernel's walk on the host (wide.hip WideChunk / WideTrapChunk): the row's LDS address / 4 as the state while the
-    state has a row, the escape row + the device id otherwise; StateIndex of the end state per string."""
-    import pire_amd  # noqa: F401
-
+    """The kernel's walk on the host (wide.hip WideChunk / WideTrapChunk): device ids through the rows of the image while
+    the state has a row, through the exact table (the accessors) while it has none; StateIndex of the end state per string."""
     rows, wide, pitch, off = t.wide_layout()
     orig_of_perm, _ = t.layout()
     perm_of_orig = np.empty_like(orig_of_perm)
     perm_of_orig[orig_of_perm] = np.arange(len(orig_of_perm), dtype=np.uint32)
-    letters = t.info.letters
-    flat = rows.reshape(-1)
-    esc4 = (off + wide * pitch) // 4
-
-    def entry(row4, k):   # u16 at LDS byte address row4 * 4 + 2 k
-        return int(flat[(row4 * 4 - off) // 2 + k])
-
     out = []
     for s in strings:
-        st = perm_of_orig[t.Next(t.info.initial, 258)]     # Begin()
-        row = (off + st * pitch) // 4 if st < wide else esc4
-        cold = int(st)
+        st = int(perm_of_orig[t.Next(t.info.initial, 258)])     # Begin()
         for b in s:
-            c = t.letter_class(b)
-            if row != esc4:
-                nr = entry(row, c)
-                if nr == esc4:
-                    cold = int(perm_of_orig[t.Next(int(orig_of_perm[entry(row, letters)]), b)])
-                row = nr
-            else:
-                nx = int(perm_of_orig[t.Next(int(orig_of_perm[cold]), b)])
-                if nx < wide:
-                    row = (off + nx * pitch) // 4
-                else:
-                    cold = nx
-        st = entry(row, letters) if row != esc4 else cold
-        assert st != wide or row == esc4
+            e = int(rows[st, t.letter_class(b)]) if st < wide else wide
+            st = e if e != wide else int(perm_of_orig[t.Next(int(orig_of_perm[st]), b)])
         out.append(int(t.Next(int(orig_of_perm[st]), 259)))   # End()
     return out
 
@@ -99,8 +76,7 @@ def test_wide_image_walks_like_the_reference(name, corpus):
     assert info.wide_states > info.hot_states and info.wide_lds_bytes <= 160 * 1024
     rows, wide, pitch, off = t.wide_layout()
     assert wide == info.wide_states and rows.shape == (wide + 1, pitch // 2) and pitch % 4 == 0 and off == 256
-    assert (rows[:, info.letters] == np.arange(wide + 1)).all()                # every row knows its own id
-    assert (rows[wide, :info.letters] == (off + wide * pitch) // 4).all()      # the escape row is absorbing
+    assert (rows[wide, :info.letters] == wide).all() and (rows[:, :info.letters] <= wide).all()   # the escape row is absorbing
     k = min(24, len(offs) - 1)
     strings = [bytes(text[int(offs[i]):int(offs[i + 1])])[:300] for i in range(k)]
     o = ob.OracleScanner(W.load_blob(entry["blob"]))
@@ -143,13 +119,12 @@ def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     offs = np.arange(n + 1, dtype=np.uint64) * length
     oi, of = o.run(data.reshape(-1), offs, threads=4)
     d = torch.as_tensor(data, device="cuda")
-    for variant, form in ((2, ""), (3, "every step asks")):   # chunks walked twice / every step asks whether a lane left the rows
-        cfg.set(walk_variant=variant)
-        gi, gf, cnt = dev_run_strided(torch, t, d)
-        assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the < 64-string remainder behind it
-        assert ("ScanWideKernel" in pb.last_kernel_symbol() and form in pb.last_kernel_symbol()) or n % 64
-        assert (gi == oi).all() and (gf == of).all(), variant
-        assert (cnt == expected_counts(o, oi, of)).all()
+    cfg.set(walk_variant=2)
+    gi, gf, cnt = dev_run_strided(torch, t, d)
+    assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the < 64-string remainder behind it
+    assert "ScanWideKernel" in pb.last_kernel_symbol() or n % 64
+    assert (gi == oi).all() and (gf == of).all()
+    assert (cnt == expected_counts(o, oi, of)).all()
     cfg.set(walk_variant=1)
     di, df, _ = dev_run_strided(torch, t, d)
     assert pb.last_kernel() in ("tiled", "generic")
@@ -188,11 +163,10 @@ def test_wide_kernel_flags_and_resume_states(pa, torch_cuda, cfg, flags):
     d = torch.as_tensor(data, device="cuda")
     for ini in (None, init):
         oi, of = o.run(data.reshape(-1), offs, flags=flags, init_idx=ini, threads=4)
-        for variant in (2, 3):
-            cfg.set(walk_variant=variant)
-            gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
-            assert (gi == oi).all() and (gf == of).all(), variant
-            assert (cnt == expected_counts(o, oi, of)).all()
+        cfg.set(walk_variant=2)
+        gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
+        assert (gi == oi).all() and (gf == of).all()
+        assert (cnt == expected_counts(o, oi, of)).all()
 
 
 @pytest.mark.gpu
@@ -202,8 +176,8 @@ def test_wide_kernel_with_a_ranking_that_knows_nothing(pa, torch_cuda, cfg):
     from pire_amd import binding as pb
 
     torch = torch_cuda
-    for name, corpus, variant in (("dict_1k", "k1000", 2), ("dict_10k", "k10000", 2), ("dict_1k", "k1000", 3), ("dict_10k", "k10000", 3)):
-        cfg.set(prior_flat=1, walk_variant=variant)
+    cfg.set(prior_flat=1, walk_variant=2)
+    for name, corpus in (("dict_1k", "k1000"), ("dict_10k", "k10000")):
         entry = W.wide_set(name)
         blob = W.load_blob(entry["blob"])
         t, o = pa.Table(blob), ob.OracleScanner(blob)
