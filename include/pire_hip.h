@@ -151,7 +151,7 @@ typedef struct pire_hip_config {
 	uint32_t walk_variant;         /* fixed-length records of tables with more states than dense rows: 0 default = the     */
 	                               /* class-indexed walk (every row of the first ~1 700 states of the ranking in LDS, the  */
 	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
-	                               /* outside the 255 dense rows passes 0.3 % (measured by adapt(); 5 % of the a-priori    */
+	                               /* outside the 255 dense rows passes 0.05 % (measured by adapt(); 5 % of the a-priori   */
 	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
 	                               /* class-indexed walk.  Same results either way.                                        */
 } pire_hip_config;

@@ -69,18 +69,18 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 	return p.nextPerm[size_t(st) * p.letters + cls];
 }
 
-// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly.
-// One dependent load per byte: the row's entry in LDS while the state has a row -- and the table in memory behind it
-// only where that entry says "no row" --, the table in memory while it has none; both are asked for before either is
-// waited for, and every load is waited for inside the arm that issued it (a wait left to the join is a vmcnt(0) every
-// lane passes, and that one also waits for the tile on its way).  The class of the next byte is asked for before this
-// byte's step.  Rolled on purpose (instantiated once per unrolled chunk of the tile walk).
+// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly,
+// device ids all the way: the row's entry in LDS, and ONE load from the table in memory in the steps in which that entry
+// says "no row" -- for a lane that leaves the rows with this step and for one that is outside them already alike (the
+// table answers both from the state's id).  The class of the next byte is asked for before this byte's step.  Rolled on
+// purpose (instantiated once per unrolled chunk of the tile walk).
 // History (profiles/r05b..r05d_wide_curve.jsonl, dict_1k / k512: 2 738 states visited, 2 041 rows, 1.7 % of the steps
 // outside them, EVERY wave-chunk with a lane outside): row / row's id / table as three dependent round trips per
 // iteration 464 GB/s; every lane of the re-walk through the table in memory, one round trip 887 GB/s -- but 64 scattered
 // accesses per step where all lanes re-walk (the L1 serves about one per clock and CU: dict_10k / k10000 454 GB/s); no
 // re-walk at all, every step asking whether a lane is outside the rows, 644 GB/s here and 2.4 instead of 4.25 TB/s where
-// the working set fits (a third form of the kernel, removed again).
+// the working set fits (a third form of the kernel, removed again); rows for the lanes that have one, the table for the
+// others and -- in an arm of its own -- for those that leave with this step: 651 GB/s (two round trips in a row).
 // What pire_hip_table_adapt() ranks the states beyond the rows by: every 16th re-walk leaves, at one rotating step, the
 // state of the first lane that is outside the rows.  (The first form sampled one fixed lane of 64 at the chunk's end,
 // like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
@@ -104,19 +104,14 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
 		v.w >>= 8;
 		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
-		const bool has = sid < p.wide;
-		uint32_t e = p.wide, g = 0;
-		if (has)
-			e = WideEntry(sid, K.pitch, c2);           // asked for first, looked at behind the other lanes' load
-		if (!has) {
-			g = WideNext<N16>(p, sid, c2 >> 1);
-			asm volatile("" : "+v"(g));                // (the wait belongs in here)
+		// the row's entry (a state without a row reads the escape row: "no row") ...
+		const uint32_t e = WideEntry(sid < p.wide ? sid : p.wide, K.pitch, c2);
+		uint32_t next = e;
+		if (e == p.wide) {   // ... and, for the lanes it sends outside the rows or that are there already, the table in memory
+			next = WideNext<N16>(p, sid, c2 >> 1);
+			asm volatile("" : "+v"(next));   // (the wait belongs in here: left to the join it is a vmcnt(0) every lane passes)
 		}
-		if (has && e == p.wide) {                      // leaves the rows with this step: which state is it?
-			g = WideNext<N16>(p, sid, c2 >> 1);
-			asm volatile("" : "+v"(g));
-		}
-		sid = e == p.wide ? g : e;
+		sid = next;
 		if (sampled && i == sampleStep) {
 			const bool out = sid >= p.wide;
 			const unsigned long long m = __ballot(out);
@@ -294,9 +289,10 @@ bool WideWanted(const ScanParams& p, const pire_hip_config& cfg)
 		return false;
 	if (cfg.walk_variant >= 2)
 		return true;
-	// a lane-step share of 0.3 % outside the dense rows puts a lane outside them in a fifth of all wave-chunks, each of
-	// which is then walked twice; the wide walk costs half as much again everywhere (measured: DESIGN.md 5.4)
-	return p.outsideDense > (p.massMeasured ? 0.003f : 0.05f);
+	// Measured (profiles/r05_wide_curve.jsonl): with 0.1-0.2 % of the steps outside the dense rows 40 % of all wave-chunks
+	// hold a lane that left them and the dense walk runs at 1.1-1.8 TB/s, the wide walk at 3.1; with nothing outside them
+	// the dense walk's 6.5 TB/s against 4.3.  The wide walk wins from a few hundredths of a percent.
+	return p.outsideDense > (p.massMeasured ? 0.0005f : 0.05f);
 }
 
 int LaunchWide(const ScanParams& p, hipStream_t stream)
