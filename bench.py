@@ -98,6 +98,12 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even for ONE rank (world-1 process group): the counters then go "
                          "through dist.all_reduce of the chosen backend -- with nccl, through RCCL -- on a one-GPU box")
+    ap.add_argument("--c4", action="store_true",
+                    help="BASELINE configs[3] at its stated shape: 64 Mi x 4 KiB strings over 8 GPUs = 2^23 strings (32 GiB) per "
+                         "GPU (same as --log2-strings 23; the CPU baseline then checks the first 2^22 strings of rank 0)")
+    ap.add_argument("--reduce-every-step", action="store_true",
+                    help="all-reduce the match counters after every pass (round 4's form: 31-44 us per step on one rank, the "
+                         "all-reduce kernel waits for a CU of a GPU the persistent scan fills) instead of once per fence")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to "
                     "exercise the multi-rank control flow on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -347,6 +353,9 @@ def bench_c1(args):
 
 def main():
     args = parse()
+    if args.c4:
+        args.log2_strings = 23
+        args.cpu_sample_log2 = max(args.cpu_sample_log2, 22)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     if args.set.startswith("slow_"):
@@ -432,34 +441,44 @@ def main():
     out_idx = torch.empty(run_n, dtype=torch.int32, device=dev)
     out_fin = torch.empty(run_n, dtype=torch.uint8, device=dev)
     flags = pb.FLAG_BEGIN | pb.FLAG_END
-    # One row of match counters per step, zeroed once up front: out_counts accumulates, and a fill dispatch in front of
-    # every scan (3.6 us + its gap in round 2) is not part of the path.  The all-reduce of step k (RCCL runs it on its
-    # own stream) overlaps the scan of step k+1.
+    # The match counters ACCUMULATE on the device (out_counts is added to, never cleared by the library): one row per leg
+    # -- the untimed passes of a leg into a row of their own -- and ONE all-reduce of the leg's row per fence (RCCL over
+    # xGMI for N > 1).  The counters are sums, so the total over K passes reduced once is the sum of K reductions; a pass's
+    # own counts are total / K (checked: the batch is the same every pass).  Round 4 reduced after every pass: on one rank
+    # through RCCL that cost 31-44 us per 0.66 ms step (5-7 %), the all-reduce kernel waiting for a CU of a GPU whose every
+    # CU's LDS the persistent scan holds (`--reduce-every-step` restores it for comparison).
     settle = max(0, args.settle)
     cold_steps = max(1, min(args.steps, 10))
     cold_launches = max(0, args.cold_launches)
-    # every pass of every leg has a row of its own: two legs of (settle + warm-up) untimed passes, the never-adapted
-    # table's timed passes, the timed region, the from-idle leg (round 3 sized this by a constant)
     total_steps = 2 * (settle + args.warmup) + cold_steps + args.steps + cold_launches + 8
-    counts_all = torch.zeros((total_steps, table.RegexpsCount + 2), dtype=torch.int64, device=dev)
-    step_no = [0]
-    pending = []   # outstanding all-reduces, oldest first
+    counts_all = torch.zeros((total_steps + 16 if args.reduce_every_step else 16, table.RegexpsCount + 2), dtype=torch.int64,
+                             device=dev)
+    row_no = [0]
+    last_row = [None]
+    pending = []   # outstanding all-reduces, oldest first (--reduce-every-step)
     per_rank = []  # wall seconds of the timed leg, per rank
+    leg_stats = {}
 
-    def step(tbl, ev=None):
-        counts = counts_all[step_no[0]]
-        step_no[0] += 1
-        while len(pending) > 2:
-            pending.pop(0).wait()   # stream-level wait for the reduction issued two steps ago: long finished
+    def step(tbl, counts, ev=None):
+        last_row[0] = counts
         if ev:
             ev[0].record()
         tbl.run_strided_device(text.data_ptr(), run_n, run_len, run_stride, flags, out_idx.data_ptr(),
                                out_fin.data_ptr(), counts.data_ptr(), 0, stream)
         if ev:
             ev[1].record()
-        h = pd.allreduce_counts(counts, async_op=True)   # the path's only exchange: 80 B of counters
-        if h is not None:
-            pending.append(h)
+        if args.reduce_every_step:
+            while len(pending) > 2:
+                pending.pop(0).wait()   # stream-level wait for the reduction issued two steps ago: long finished
+            h = pd.allreduce_counts(counts, async_op=True)
+            if h is not None:
+                pending.append(h)
+
+    def next_row():
+        row_no[0] += 1
+        row = counts_all[row_no[0] % counts_all.shape[0]]
+        row.zero_()
+        return row
 
     def fence():
         while pending:
@@ -468,21 +487,37 @@ def main():
         torch.cuda.synchronize()
 
     def timed(tbl, steps, warm):
-        """`warm` untimed passes, then exactly `steps` timed ones between two fences.  The events are made before the
-        first fence: nothing but the fence itself (microseconds) separates the untimed passes from the timed ones, so
-        the GPU does not fall idle in between (see `settle` below)."""
+        """`warm` untimed passes, then exactly `steps` timed ones between two fences; the timed passes' counters are
+        all-reduced ONCE, inside the timed region, in front of its closing fence.  The events are made before the first
+        fence: nothing but the fence itself (microseconds) separates the untimed passes from the timed ones, so the GPU
+        does not fall idle in between (see `settle` below)."""
         events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        red = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        warm_row = next_row()
         for _ in range(warm):
-            step(tbl)
+            step(tbl, next_row() if args.reduce_every_step else warm_row)
         fence()
+        row = next_row()
+        rows = [next_row() for _ in range(steps)] if args.reduce_every_step else [row] * steps
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for k in range(steps):
-            step(tbl, events[k])
+            step(tbl, rows[k], events[k])
+        if not args.reduce_every_step:
+            red[0].record()
+            pd.allreduce_counts(row)          # the path's only exchange: 80 B of counters, once per fence
+            red[1].record()
         fence()
         mine = time.perf_counter() - t0
         per_rank[:] = pd.gather_over_ranks(mine, dev)      # this leg's wall time of every rank (the last leg's is reported)
         elapsed = pd.max_over_ranks(mine, dev)
-        return elapsed, [a.elapsed_time(b) for a, b in events]
+        kms = [a.elapsed_time(b) for a, b in events]
+        leg_stats.clear()
+        leg_stats.update({"counts_row": last_row[0],
+                          "passes_in_row": 1 if args.reduce_every_step else steps,
+                          "reduce_ms": None if args.reduce_every_step else round(red[0].elapsed_time(red[1]), 4),
+                          "kernel_ms_of_ranks": pd.gather_over_ranks(float(np.mean(kms)), dev)})
+        return elapsed, kms
 
     # --- 1. the dense-row ranking is learned on a HELD-OUT corpus: same generator, another seed, a quarter of the size.
     # pire_hip_table_adapt() (shim: Table<Scanner>::Adapt()) re-ranks the LDS-resident rows from the visit counters the
@@ -531,7 +566,10 @@ def main():
     per_rank_timed = list(per_rank)   # of THIS leg (the from-idle leg below overwrites per_rank)
     kernel_name = pb.last_kernel_symbol()   # the instantiation the library actually launched
 
-    total_counts = counts_all[step_no[0] - 1].cpu().numpy().astype(np.uint64)   # the last step's, reduced
+    timed_stats = dict(leg_stats)
+    total_counts = timed_stats["counts_row"].cpu().numpy().astype(np.uint64)   # the timed passes', reduced over the ranks
+    assert (total_counts % timed_stats["passes_in_row"] == 0).all(), "the same batch every pass: the totals are multiples of the pass count"
+    total_counts //= timed_stats["passes_in_row"]   # one pass's
     # --- 4. from idle: what a caller gets who scans one batch on a GPU that was doing nothing.  Behind the
     # timed region and outside it: the device is drained, left idle for 0.3 s (its clocks drop), then `cold_launches`
     # passes are timed back to back with no warm-up at all (the first ones run in the power management's transient,
@@ -620,6 +658,10 @@ def main():
                 "parallelism": f"shard-by-string x{world}",
                 "reduce_backend": pd.backend_description(),
                 "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank_timed],
+                "per_rank_kernel_ms": [round(x, 4) for x in timed_stats["kernel_ms_of_ranks"]],
+                "counter_reduce": ("after every pass, asynchronously (round 4's form)" if args.reduce_every_step else
+                                   "once per fence: the counters accumulate on the device over the timed passes"),
+                "counter_reduce_ms": timed_stats["reduce_ms"],
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

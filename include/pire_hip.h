@@ -158,6 +158,12 @@ typedef struct pire_hip_config {
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
 
+/* What this library is: the compiler its kernels' ISA audits passed with and the units they looked at -- or that it is
+ * not the audited product build.  The kernels that keep text on its way in registers rely on what hipcc emits for them
+ * (no spill, no copy of a register a load still owes data to); `make` checks that for every build and does not link a
+ * library that fails (pire_amd/csrc/Makefile, tools/audit/build_audit.py). */
+const char* pire_hip_build_info(void);
+
 /* Copies min(out->size, sizeof) bytes of the current configuration; out->size must be set by the caller. */
 int pire_hip_config_get(pire_hip_config* out);
 /* Replaces the configuration (fields beyond in->size keep their current values). */

@@ -132,6 +132,7 @@ NONE = (1 << 64) - 1   # PIRE_HIP_SEGMENT_WARMUP_NONE / PIRE_HIP_SEGMENT_BUDGET_
 
 # every symbol include/pire_hip.h declares: (name, restype, argtypes)
 ABI = [
+    ("pire_hip_build_info", C.c_char_p, []),
     ("pire_hip_config_get", C.c_int, [C.POINTER(Config)]),
     ("pire_hip_config_set", C.c_int, [C.POINTER(Config)]),
     ("pire_hip_table_create", C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
@@ -801,6 +802,10 @@ def run_pair_device(t1: "Table", t2: "Table", text_ptr, offsets_ptr, n, flags, o
                     out_final_ptr=0, stream=0):
     _check(lib().pire_hip_run_pair(t1._h, t2._h, text_ptr or None, offsets_ptr or None, n, flags | FLAG_ON_DEVICE,
                                    out_idx1_ptr or None, out_idx2_ptr or None, out_final_ptr or None, stream or None))
+
+
+def build_info() -> str:
+    return lib().pire_hip_build_info().decode()
 
 
 def last_kernel() -> str:
