@@ -61,6 +61,11 @@ enum {
 	                                    /* call enqueues kernels and nothing else (it is then legal inside a  */
 	                                    /* stream capture).  Automatic adaptation (auto_adapt) never runs     */
 	                                    /* inside an ON_DEVICE call unless auto_adapt = 2.                    */
+	                                    /* A graph captured from ON_DEVICE calls holds the pointers of the    */
+	                                    /* table's device image: an AUTOMATIC adaptation keeps the images it  */
+	                                    /* replaces alive until pire_hip_table_destroy() (a replay walks the  */
+	                                    /* old ranking: same results); after the caller's OWN                 */
+	                                    /* pire_hip_table_adapt() the old images are freed -- re-capture.     */
 	                                    /* Device text is read in whole 128-byte aligned lines: the kernels   */
 	                                    /* may load (never use) up to 127 bytes in front of the first and     */
 	                                    /* behind the last byte of the text -- always inside the memory page  */
@@ -363,6 +368,12 @@ int pire_hip_step(pire_hip_table* t, uint32_t* state_idx, uint64_t n, uint32_t c
  * re-walks exactly only the 16-byte chunks that touched a Final state).  PIRE_HIP_RUN_HOST_OFFSETS as for
  * pire_hip_run; few long strings of host-known length are counted segment-wise after the segmented scan has resolved
  * every segment's true start state.  Pinned by tests/count_ut.cpp:541-550, 575.
+ * ON_DEVICE calls: what is said at PIRE_HIP_RUN_ON_DEVICE holds, with two additions.  Tables that count on the row kernel
+ * (up to 8 regexps, rows that fit the LDS) keep a second image on the device: pire_hip_table_upload() uploads it with the
+ * table; without that call the first pire_hip_run_half_final on a device allocates and copies it synchronously.  And a
+ * call on the row kernel takes its per-call scratch (the length order of the strings, the list of strings whose counts
+ * outgrow 16 bits) from the stream-ordered allocator (hipMallocAsync / hipFreeAsync on `stream`): enqueue-only, but
+ * not something every capture mode accepts -- pire_hip_config.counting_variant = 1 keeps such calls off the row kernel.
  */
 int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                             uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* stream);

@@ -978,7 +978,13 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	DeviceTable image;
-	return UploadTable(t, &image);
+	if (int rc = UploadTable(t, &image))
+		return rc;
+	// ... and what the counting walk of the same table (pire_hip_run_half_final) keeps on the device, when the table
+	// qualifies for its row kernel: an ON_DEVICE call after this uploads nothing
+	if (!t->host.empty && t->host.regexps && t->host.regexps <= 8)
+		return UploadHalfRows(t);
+	return PIRE_HIP_OK;
 } catch (...) {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }

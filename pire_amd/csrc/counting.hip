@@ -1673,6 +1673,40 @@ void FreeHalfRows(pire_hip_table* t)
 		(void)hipSetDevice(cur);
 }
 
+// The letter-indexed rows of dense HalfFinal counting on the CURRENT device: built (host) and uploaded on first need.
+// pire_hip_table_upload() calls this, so that an ON_DEVICE call of pire_hip_run_half_final after it allocates and copies
+// nothing synchronously (the first such call on a device did, under halfRowsMutex).  A table that does not
+// qualify (more than 8 regexps, rows that do not fit the LDS) costs the host build once and uploads nothing.
+int UploadHalfRows(pire_hip_table* t)
+{
+	int dev = 0;
+	hipError_t e = hipGetDevice(&dev);
+	if (e != hipSuccess)
+		return HipFail(e, "hipGetDevice");
+	if (dev < 0 || dev >= kMaxDevices)
+		return PIRE_HIP_OK;
+	std::lock_guard<std::mutex> lock(t->halfRowsMutex);
+	if (!t->halfRows.tried)
+		BuildHalfRows(t->host, t->halfRows);   // (reference numbering: nothing an adaptation changes)
+	const HalfRowsHost& h = t->halfRows;
+	HalfRowsDevice& d = t->halfRowsDev[dev];
+	if (!h.nreg || d.device == dev)
+		return PIRE_HIP_OK;
+	e = PutHalf(&d.lrows, h.lrows, 128);
+	if (e == hipSuccess)
+		e = PutHalf(&d.lactWords, h.lactWords);
+	if (e == hipSuccess)
+		e = PutHalf(&d.letterOf, h.letterOf, 8);
+	if (e == hipSuccess)
+		e = PutHalf(&d.finalTag, h.finalTag, 16);
+	if (e != hipSuccess) {
+		FreeHalfRowsDevice(&d);
+		return HipFail(e, "uploading the half-final rows");
+	}
+	d.device = dev;
+	return PIRE_HIP_OK;
+}
+
 int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                         uint32_t* outIdx, uint8_t* outFinal, uint32_t* outResults, hipStream_t stream, bool* done,
                         uint32_t** overflow)
@@ -1693,28 +1727,14 @@ int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* 
 	HalfRowsDevice image;
 	uint32_t nreg, initialAct, lactCount, maxLen;
 	{
+		// (the image of this device: uploaded here on the first call unless pire_hip_table_upload() did it -- UploadHalfRows)
+		if (int rc = UploadHalfRows(t))
+			return rc;
 		std::lock_guard<std::mutex> lock(t->halfRowsMutex);
-		if (!t->halfRows.tried)
-			BuildHalfRows(t->host, t->halfRows);   // (reference numbering: nothing an adaptation changes)
 		const HalfRowsHost& h = t->halfRows;
-		if (!h.nreg)
+		if (!h.nreg || t->halfRowsDev[dev].device != dev)
 			return PIRE_HIP_OK;
-		HalfRowsDevice& d = t->halfRowsDev[dev];
-		if (d.device != dev) {
-			e = PutHalf(&d.lrows, h.lrows, 128);
-			if (e == hipSuccess)
-				e = PutHalf(&d.lactWords, h.lactWords);
-			if (e == hipSuccess)
-				e = PutHalf(&d.letterOf, h.letterOf, 8);
-			if (e == hipSuccess)
-				e = PutHalf(&d.finalTag, h.finalTag, 16);
-			if (e != hipSuccess) {
-				FreeHalfRowsDevice(&d);
-				return HipFail(e, "uploading the half-final rows");
-			}
-			d.device = dev;
-		}
-		image = d;
+		image = t->halfRowsDev[dev];
 		nreg = h.nreg;
 		initialAct = h.initialAct;
 		maxLen = h.maxLen;

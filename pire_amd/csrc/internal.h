@@ -756,6 +756,7 @@ int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* 
                         uint32_t* outIdx, uint8_t* outFinal, uint32_t* outResults, hipStream_t stream, bool* done,
                         uint32_t** overflow);
 void FreeHalfRows(pire_hip_table* t);
+int UploadHalfRows(pire_hip_table* t);   // counting.hip: the dense HalfFinal row image of the current device (first need / table_upload)
 int LaunchPrefix(const ScanParams& p, bool longest, bool throughEnd, long long* outLen, hipStream_t stream,
                  unsigned long long* workCounter);
 // pair.hip: two scanners in one pass over fixed-length records (run.h:229-241)

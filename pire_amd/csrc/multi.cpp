@@ -205,8 +205,15 @@ void DrainAll(pire_hip_multi* m)
 }
 
 // Launch one scan per device (launch(g) enqueues device g's shard on m->streams[g]), then reduce the counters or drain.
-template <class Launch>
-int RunOnAllDevices(pire_hip_multi* m, pire_hip_table* t, uint64_t* out_counts, Launch launch)
+// `late(g)`: true for a shard whose launch BLOCKS (the segmented scan of few long strings follows its chain on the host
+// and synchronises its stream): those run in a second round, after every other device has its shard enqueued (ADVICE r4:
+// launched in device order, device g + 1 did not start before such a shard g was over).
+struct NoLateShards {
+	bool operator()(size_t) const { return false; }
+};
+
+template <class Launch, class Late = NoLateShards>
+int RunOnAllDevices(pire_hip_multi* m, pire_hip_table* t, uint64_t* out_counts, Launch launch, Late late = Late())
 {
 	pire_hip_table_info info;
 	if (int rc = pire_hip_table_get_info(t, &info))
@@ -217,21 +224,25 @@ int RunOnAllDevices(pire_hip_multi* m, pire_hip_table* t, uint64_t* out_counts, 
 		return PIRE_HIP_EUNSUPPORTED;
 	}
 	const size_t G = m->devices.size();
-	// every device starts its shard before any is waited for: the launches are asynchronous
-	for (size_t g = 0; g < G; ++g) {
-		hipError_t e = hipSetDevice(m->devices[g]);
-		if (e == hipSuccess && out_counts)
-			e = hipMemsetAsync(m->counters[g], 0, size_t(count) * 8, m->streams[g]);
-		int rc = e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipSetDevice / counter reset");
-		if (rc == PIRE_HIP_OK)
-			rc = launch(g, out_counts ? reinterpret_cast<uint64_t*>(m->counters[g]) : nullptr);
-		if (rc != PIRE_HIP_OK) {
-			const std::string msg = pire_hip_last_error();   // DrainAll must not replace the message
-			DrainAll(m);
-			SetError(msg);
-			return rc;
+	// every device starts its shard before any is waited for: the launches are asynchronous; the shards whose launch
+	// blocks come last
+	for (int round = 0; round < 2; ++round)
+		for (size_t g = 0; g < G; ++g) {
+			if (late(g) != (round == 1))
+				continue;
+			hipError_t e = hipSetDevice(m->devices[g]);
+			if (e == hipSuccess && out_counts)
+				e = hipMemsetAsync(m->counters[g], 0, size_t(count) * 8, m->streams[g]);
+			int rc = e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "hipSetDevice / counter reset");
+			if (rc == PIRE_HIP_OK)
+				rc = launch(g, out_counts ? reinterpret_cast<uint64_t*>(m->counters[g]) : nullptr);
+			if (rc != PIRE_HIP_OK) {
+				const std::string msg = pire_hip_last_error();   // DrainAll must not replace the message
+				DrainAll(m);
+				SetError(msg);
+				return rc;
+			}
 		}
-	}
 	if (out_counts)
 		return ReduceCounters(m, count, out_counts);
 	for (size_t g = 0; g < G; ++g) {
@@ -455,17 +466,21 @@ int RunHostSharded(pire_hip_multi* m, pire_hip_table* t, const uint8_t* base, co
 		// the host knows the lengths: a shard of few long strings takes the segmented scan (pire_hip_run with the host's
 		// offsets; that call synchronises its stream), every other shard is enqueued without a look at its offsets
 		const uint32_t f = (flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END | PIRE_HIP_RUN_GENERIC)) | PIRE_HIP_RUN_ON_DEVICE;
+		auto segmented = [&](size_t g) {
+			const pire_hip_shard_offsets& s = rag[g];
+			return s.n != 0 && !(f & PIRE_HIP_RUN_GENERIC) && !s.init_state_idx &&
+			       pirehip::SegmentedEligible(s.n, offsets[lo[g + 1]] - offsets[lo[g]]);
+		};
 		rc = RunOnAllDevices(m, t, out_counts, [&](size_t g, uint64_t* counters) {
 			const pire_hip_shard_offsets& s = rag[g];
 			if (s.n == 0)
 				return int(PIRE_HIP_OK);
-			const uint64_t bytes = offsets[lo[g + 1]] - offsets[lo[g]];
-			if (!(f & PIRE_HIP_RUN_GENERIC) && !s.init_state_idx && pirehip::SegmentedEligible(s.n, bytes))
+			if (segmented(g))
 				return pire_hip_run(t, s.text, offsets + lo[g], s.n, f | PIRE_HIP_RUN_HOST_OFFSETS, nullptr, s.out_state_idx,
 				                    s.out_final, counters, m->streams[g]);
 			return pire_hip_run(t, s.text, s.offsets, s.n, f | PIRE_HIP_RUN_NO_PEEK, s.init_state_idx, s.out_state_idx, s.out_final,
 			                    counters, m->streams[g]);
-		});
+		}, segmented);
 	} else if (rc == PIRE_HIP_OK) {
 		rc = pire_hip_multi_run_strided(m, t, rec.data(), flags, out_counts);
 	}

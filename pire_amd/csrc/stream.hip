@@ -17,13 +17,13 @@
 //   * cost key: key(i) = (offsets[i] - offsets[0]) + lambda * i -- a byte costs 1, a string boundary `lambda` -- is
 //     strictly increasing, so "the first string at or behind key T" is well defined even among empty strings.  The
 //     batch is cut into one TASK per wave at equal steps of the key (two cooperative 64-ary searches per wave over the
-//     offsets: 4 rounds for 4 M strings), a task into SUB-TASKS of at most 1 024 strings, and a sub-task among the 64
+//     offsets: 4 rounds for 4 M strings), a task into SUB-TASKS of at most 1 280 strings (kStreamMaxStrings), and a sub-task among the 64
 //     lanes at equal steps of the key again.  Equal work per wave and per lane by construction, whatever the lengths:
 //     no work counters, no atomics, no tail of late long strings.
 //   * a sub-task's string positions sit in LDS as 32-bit offsets from the line that holds its first byte (4 KiB per
 //     wave: the compact tier's place, which this kernel does not use).  A lane finds its first string by a binary
 //     search there, reads the end of a string when it starts it, and leaves a string's end state in the slot of its
-//     end position (dead by then); when the sub-task is over the wave turns the 1 024 slots into StateIndex / Final /
+//     end position (dead by then); when the sub-task is over the wave turns the slots into StateIndex / Final /
 //     counters with coalesced stores (FinishRagged, 64 strings at a time).
 //   * windows: the lane's current line in registers, the next one in flight (group loads + DPP transpose, the ragged
 //     and tiled kernels' load path).  Nothing outside the 128-byte lines that hold the sub-task's text is read: a line

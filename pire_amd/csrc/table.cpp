@@ -746,11 +746,18 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 	}
 	DeviceTable d;
 	int rc;
-	std::vector<uint8_t> rowsRot(h.hotRows.size());
-	for (size_t r = 0; r < h.hotRows.size() / 256; ++r)
-		for (uint32_t b = 0; b < 256; ++b)
-			rowsRot[r * 256 + RotColumn(b)] = h.hotRows[r * 256 + b];
-	if ((rc = Put(&d.hotRows, h.hotRows, &d.bytes)) || (rc = Put(&d.hotRowsRot, rowsRot, &d.bytes)) ||
+	// the rows with rotated columns: read by the A/B variant tiled_variant = 23 alone, which is never chosen by the library
+	// (no gain measured, tiled.hip LaunchTiled) -- built and uploaded only for images made while that variant is asked
+	// for (every upload and every re-upload after an adaptation paid a host loop and 64 KB for it); a table
+	// uploaded earlier runs variant 23 with the plain rows (tiled.hip falls back when the pointer is null)
+	std::vector<uint8_t> rowsRot;
+	if (GetConfig().tiled_variant == 23) {
+		rowsRot.resize(h.hotRows.size());
+		for (size_t r = 0; r < h.hotRows.size() / 256; ++r)
+			for (uint32_t b = 0; b < 256; ++b)
+				rowsRot[r * 256 + RotColumn(b)] = h.hotRows[r * 256 + b];
+	}
+	if ((rc = Put(&d.hotRows, h.hotRows, &d.bytes)) || (!rowsRot.empty() && (rc = Put(&d.hotRowsRot, rowsRot, &d.bytes))) ||
 	    (rc = Put(&d.hotFlags, h.hotFlags, &d.bytes)) ||
 	    (rc = Put(&d.cls, h.cls, &d.bytes)) || (rc = Put(&d.nextPerm, nextPerm, &d.bytes)) ||
 	    (rc = Put(&d.flagsPerm, flagsPerm, &d.bytes)) || (rc = Put(&d.origOfPerm, h.origOfPerm, &d.bytes)) ||
