@@ -15,7 +15,10 @@ big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
 blob = H.load_blob(big["blob"])
 t = pire_amd.Table(blob)
 t.upload()
-m = 1 << 18
+import sys
+LOG2 = int(os.environ.get("PREFIX_LOG2_STRINGS", "18"))   # 18: the batch of profiles/r04_final_prefix.log (0.133 GiB); 21: 1.06 GiB
+SETTLE = int(os.environ.get("PREFIX_SETTLE", "0"))        # untimed launches in front of the timed ones (settled clocks)
+m = 1 << LOG2
 rng = np.random.RandomState(4)
 lens = rng.randint(64, 1024, size=m).astype(np.uint64)
 offs = np.zeros(m + 1, dtype=np.uint64)
@@ -37,7 +40,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "adapt":
         print("adapt: rows changed", t.adapt())
 for longest in (True, False):
     best = 1e9
-    for _ in range(4):
+    for _ in range(SETTLE):
+        t.prefix_device(d.data_ptr(), do.data_ptr(), m, longest, dout.data_ptr(), stream=stream)
+    for _ in range(4 if not SETTLE else 10):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         t.prefix_device(d.data_ptr(), do.data_ptr(), m, longest, dout.data_ptr(), stream=stream)
