@@ -302,7 +302,15 @@ struct PrefixAct {
 	};
 	__device__ __forceinline__ bool Wants(const Lane& al) const { return !(al.stop & 1u); }
 	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotDeadLo; }
-	__device__ __forceinline__ void LoadLds(const ScanParams&, uint8_t*) const {}
+	// next to the table in LDS: for every dense-row state, the flags of the state Step(EndMark) leads to -- what the end of
+	// a string asks when the search runs through End().  (Round 5: the end of a string read nextPerm and the flags from
+	// memory, two dependent loads whose wait also drained the window on its way; log lines end in every iteration of a
+	// wave, and the searches ran at two thirds of the plain scan, profiles/r05_prefix_sizes.log.)
+	__device__ __forceinline__ void LoadLds(const ScanParams& p, uint8_t* area) const
+	{
+		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
+			area[i] = uint8_t(p.finEnd[i].permFlags >> 28);
+	}
 	__device__ __forceinline__ void HotStep(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
 	                                        Lane& al, uint32_t h, uint64_t after) const
 	{
@@ -336,16 +344,22 @@ struct PrefixAct {
 		}
 		return st;
 	}
-	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const uint8_t*,
+	__device__ __forceinline__ void Finish(const ScanParams& p, const uint8_t*, const LdsLayout&, const uint8_t* area,
 	                                       Lane& al, uint32_t s, uint32_t st, uint64_t end) const
 	{
 		// a search that ended Dead stays not-Final through EndMark; one that was answered before the first byte
 		// does not look at EndMark at all; a shortest prefix already found is kept (run.h:286-290 / 305-309)
-		if (throughEnd && !(al.stop & 6u) && (longest || al.pos < 0)) {
-			st = p.nextPerm[size_t(st) * p.letters + p.endCls];
-			if (StateFlags(p, lds, L, st) & kFinal)
-				al.pos = (long long)(end - al.begin);
+		const bool asks = throughEnd && !(al.stop & 6u) && (longest || al.pos < 0);
+		const bool cold = asks && st >= p.hot;
+		uint32_t fl = asks && !cold ? area[st] : 0u;   // flags of the state End() leads to: LDS for a dense-row state
+		if (__any(cold)) {
+			if (cold) {
+				fl = p.finEnd[st].permFlags >> 28;
+				asm volatile("" : "+v"(fl));   // the wait belongs in here
+			}
 		}
+		if (asks && (fl & kFinal))
+			al.pos = (long long)(end - al.begin);
 		outLen[s] = al.pos;
 	}
 };

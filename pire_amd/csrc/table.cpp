@@ -375,6 +375,8 @@ void ChooseHotAndPermute(HostTable& t)
 	for (uint32_t s = 0; s < N; ++s)
 		t.priorMass[s] = top > 0 ? mass[s] / top : 0.0;
 	PermuteByScore(t, t.priorMass);
+	if (GetConfig().prior_flat)
+		t.outsideDense = t.outsideWide = 0;   // a prior that knows nothing makes no claim about where the walk will be
 }
 
 }  // namespace
