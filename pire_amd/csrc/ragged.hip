@@ -537,6 +537,13 @@ __device__ __forceinline__ void StepChunkAct(const ScanParams& p, const uint8_t*
 			}
 			hs = st < p.hot ? st : p.hot;
 			cold = st;
+			// tell pire_hip_table_adapt() which rows deserve LDS, sampled like TrapChunk's.  (Round 5: the walks with actions
+			// left no samples, so a caller of the prefix searches alone never saw its table adapt -- and 13 states of set_a
+			// without a dense row on log lines cost the searches 40 %: 1.65 against 2.35 TB/s, profiles/r05_prefix_sizes*.log.)
+			if (st >= p.hot && (threadIdx.x & 63) == ((uint32_t(addr) >> 4) & 63u)) {
+				atomicAdd(&p.visitCold[st], 1u);
+				atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + kLdsTrapSlot, 1u);
+			}
 		}
 	}
 }

@@ -75,3 +75,33 @@ def test_gpu_prefix_scan_boundaries_and_termination():
     t = pire_amd.Table(r.save())
     tx, offs = H.pack([b"aaab\x00"])
     assert t.prefix(tx, offs, True)[0] == 3
+
+
+@pytest.mark.gpu
+def test_prefix_calls_alone_feed_the_adaptation(cfg):
+    """A caller of pire_hip_prefix alone: the walks with actions leave visit samples of the states outside the dense rows
+    (round 5; before, only the plain scans did), adapt() promotes them, the same searches then leave them no more --
+    same answers before and after.  The table starts from a prior that knows nothing."""
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    blob = H.load_blob(big["blob"])
+    cfg.set(prior_flat=1, ragged_act_always=1)
+    t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    t.layout()
+    cfg.set(prior_flat=0)
+    rng = np.random.RandomState(3)
+    data = ob.corpus_fill(5, 0, 4096, 1024, H.plants_for(big), threads=4).reshape(-1)
+    lens = rng.randint(64, 700, size=6000).astype(np.uint64)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    text = data[:int(offs[-1])]
+    want = o.prefix(text, offs, True, False, True)
+    assert (t.prefix(text, offs, True, False, True) == want).all()
+    changed = t.adapt()
+    first = t.info.last_trap_samples
+    assert first > 0 and changed > 0, (first, changed)
+    assert (t.prefix(text, offs, True, False, True) == want).all()
+    t.adapt()
+    assert t.info.last_trap_samples * 10 < first, (t.info.last_trap_samples, first)
+    assert (t.prefix(text, offs, False, False, True) == o.prefix(text, offs, False, False, True)).all()

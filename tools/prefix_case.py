@@ -38,6 +38,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "adapt":
         t.run_device(d.data_ptr(), do.data_ptr(), m, 0, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
         torch.cuda.synchronize()
         print("adapt: rows changed", t.adapt())
+if len(sys.argv) > 1 and sys.argv[1] == "adapt_by_prefix":
+    # the searches' own visit samples: two prefix calls, then adapt() (what the automatic adaptation does for a caller of
+    # pire_hip_prefix alone)
+    for _ in range(2):
+        for _k in range(2):
+            t.prefix_device(d.data_ptr(), do.data_ptr(), m, True, dout.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        print("adapt after prefix calls only: rows changed", t.adapt())
 for longest in (True, False):
     best = 1e9
     for _ in range(SETTLE):
