@@ -332,11 +332,14 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 			return HipFail(hipGetLastError(), "hipEventCreate");
 		(void)hipEventRecord(ev0, stream);
 	}
-	const bool streamed = ragged && StreamEligible(p, totalBytesHint);
-	// fixed-length records of a table whose scans keep leaving the dense rows: the class-indexed walk (wide.hip)
-	const bool wide = tiled && p.len >= 256 && WideWanted(p, GetConfig());
-	NoteKernel(wide ? "wide" : tiled ? "tiled" : streamed ? "stream" : ragged ? "ragged" : "generic");
-	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
+	// a table whose scans keep leaving the dense rows: the class-indexed walk (wide.hip; offset batches: the ragged kernel on it)
+	const bool wideTable = (tiled || ragged) && WideWanted(p, GetConfig());
+	const bool wide = tiled && p.len >= 256 && wideTable;
+	const bool raggedWide = ragged && wideTable;
+	const bool streamed = ragged && !raggedWide && StreamEligible(p, totalBytesHint);
+	NoteKernel(wide ? "wide" : tiled ? "tiled" : raggedWide ? "ragged_wide" : streamed ? "stream" : ragged ? "ragged" : "generic");
+	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : raggedWide ? LaunchRaggedWide(p, workCounter, stream)
+	         : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
 		if (rc == PIRE_HIP_OK) {

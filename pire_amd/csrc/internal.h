@@ -644,6 +644,7 @@ int LaunchWide(const ScanParams& p, hipStream_t stream);
 bool TiledEligible(const ScanParams& p);
 bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);
+int LaunchRaggedWide(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream);   // ... on the class-indexed walk
 // stream.hip: offset batches of many short strings, every lane a run of consecutive strings
 bool StreamEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchStream(const ScanParams& p, hipStream_t stream);

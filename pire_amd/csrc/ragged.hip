@@ -1,6 +1,7 @@
 // The ragged kernel (offset batches, pire_hip_run).  DESIGN.md section 4.4.
 
 #include "device_common.h"
+#include "wide_common.h"
 
 namespace pirehip {
 
@@ -712,13 +713,18 @@ struct RaggedClock {};
 // EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
 // state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
 // A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
-template <class Act, bool EXT>
+// WIDE (round 5; 1: the exact table behind the rows has u32 entries, 2: u16): the class-indexed walk of wide.hip instead of
+// the dense rows -- S.hs is then a device id with a row or `wide` (the escape row), the state's end-of-string record comes
+// from memory (the LDS is the rows'), everything else of the kernel is what it was.  Plain scans only (NoAct).
+template <class Act, bool EXT, int WIDE = 0>
 __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const FinRec* finHot,
                                             volatile RaggedWork* work, unsigned long long* workCounter,
                                             RaggedGrab grab, uint64_t textBase, uint64_t safeEnd, RaggedRange& R,
                                             RaggedLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter,
-                                            const Act& act, typename Act::Lane& al, RaggedClock& clk)
+                                            const Act& act, typename Act::Lane& al, RaggedClock& clk,
+                                            const WideLayout& W = WideLayout(), const WideConst& K = WideConst())
 {
+	static_assert(!WIDE || !Act::kActive, "the wide walk has no actions");
 	WaitAllLoads(cur);
 	PIRE_RCLK(clk, 0);
 	if constexpr (Act::kGroupLoads)
@@ -776,7 +782,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	PIRE_RCLK(clk, 2);
 	// ---- walk the current window
 	if ((threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + (WIDE ? W.histOff : L.histOff)) + S.hs, 1u);
 	if (p.flags & kDebugNoStep) {
 		// timing experiments: no walk at all
 	} else if (__any(nb != 0)) {
@@ -789,6 +795,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 					if constexpr (Act::kActive)
 						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 						             S.pos + 16u * k);
+					else if constexpr (WIDE != 0)
+						WideChunk<WIDE == 2>(p, lds, W, K, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 					else
 						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 				}
@@ -802,20 +810,26 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 				if constexpr (Act::kActive)
 					StepPartialAct(p, lds, L, v, tail, S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 					               S.pos + 16u * full);
+				else if constexpr (WIDE != 0)
+					WidePartial<WIDE == 2>(p, K, v, tail, S.hs, S.cold);
 				else
 					StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
 			}
 		}
 		if (nb != 0 && !S.loaded) {
 			// the last bytes of the whole buffer: exact steps straight from memory
-			uint32_t st = S.hs != p.hot ? S.hs : S.cold;
+			const uint32_t lim = WIDE ? p.wide : p.hot;   // S.hs == lim: the state has no row, S.cold is its id
+			uint32_t st = S.hs != lim ? S.hs : S.cold;
 			const uint8_t* q = reinterpret_cast<const uint8_t*>(S.pos);
 			for (uint32_t i = 0; i < nb; ++i) {
-				st = SlowStep(p, lds, L, st, q[i]);
+				if constexpr (WIDE != 0)
+					st = WideNext<WIDE == 2>(p, st, uint32_t(lds[q[i]]) >> 1);
+				else
+					st = SlowStep(p, lds, L, st, q[i]);
 				if constexpr (Act::kActive)
 					act.Step(p, lds, L, al, st, S.pos + i + 1);
 			}
-			S.hs = st < p.hot ? st : p.hot;
+			S.hs = st < lim ? st : lim;
 			S.cold = st;
 		}
 	}
@@ -824,7 +838,19 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		if (ends)
 			act.Finish(p, lds, L, reinterpret_cast<const uint8_t*>(finHot), al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
-		FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
+		if constexpr (WIDE != 0) {
+			// the end-of-string record from memory, under a wave-uniform branch of its own and waited for inside it (FinRecordOf)
+			const uint32_t st = S.hs != p.wide ? S.hs : S.cold;
+			u32x4 raw = {0, 0, 0, 0};
+			if (ends) {
+				const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+				raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+				asm volatile("" : "+v"(raw.x), "+v"(raw.y), "+v"(raw.z), "+v"(raw.w));
+			}
+			FinishWith<EXT>(p, lds, L, S.sIdx, ends, raw);
+		} else {
+			FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
+		}
 	}
 	PIRE_RCLK(clk, 4);
 
@@ -846,7 +872,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			st = p.initIdx ? StartStateFrom(p, startInit) : p.startPerm;
 		else
 			st = p.startPerm;   // batches with resume states take the EXT instantiation
-		S.hs = st < p.hot ? st : p.hot;
+		const uint32_t lim = WIDE ? p.wide : p.hot;
+		S.hs = st < lim ? st : lim;
 		S.cold = st;
 	}
 	S.pos = nPos;
@@ -858,7 +885,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	return __any(nBusy || S.pend);
 }
 
-template <class Act, bool EXT>
+template <class Act, bool EXT, int WIDE = 0>
 __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned long long* workCounter,
                                                          RaggedGrab grab, Act act)
 {
@@ -870,10 +897,25 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 		clk.acc[k] = 0;
 	clk.t = clk.on ? __builtin_readcyclecounter() : 0;
 #endif
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
+	const WideLayout W = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0) : WideLayout();
+	WideConst K;
+	K.pitch = W.pitch;
+	K.flagsOff = p.letters * 2;
+	LdsLayout L = {};
+	if constexpr (WIDE != 0)
+		L.countsOff = W.countsOff;   // what FinishWith looks at
+	else
+		L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
-	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + L.total + kRaggedFinBytes);
-	{
+	volatile RaggedWork* work = reinterpret_cast<volatile RaggedWork*>(lds + (WIDE ? W.total : L.total + kRaggedFinBytes));
+	if constexpr (WIDE != 0) {
+		if (threadIdx.x == 0) {
+			work->range = 0;
+			work->lock = 0;
+			work->exhausted = 0;
+		}
+		LoadWideToLds(p, lds, W);   // ends with a barrier
+	} else {
 		if constexpr (!Act::kActive) {
 			const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
 			for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
@@ -886,8 +928,8 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 			work->lock = 0;
 			work->exhausted = 0;
 		}
+		LoadTableToLds(p, lds, L);   // ends with a barrier
 	}
-	LoadTableToLds(p, lds, L);   // ends with a barrier
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
 	const uint64_t safeEnd = (textBase + ((EXT && p.ends) ? p.textEnd : p.offsets[p.n]) + 15) & ~uint64_t(15);
@@ -915,9 +957,9 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	PIRE_RCLK(clk, 6);
 	uint32_t iter = 0;
 	for (;; iter += 2) {
-		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al, clk))
+		if (!RaggedPhase<Act, EXT, WIDE>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al, clk, W, K))
 			break;
-		if (!RaggedPhase<Act, EXT>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al, clk))
+		if (!RaggedPhase<Act, EXT, WIDE>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, b, a, iter + 1, act, al, clk, W, K))
 			break;
 	}
 #ifdef PIRE_HIP_TUNING
@@ -928,7 +970,10 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 		atomicAdd(&p.stamps[8], 1ull);
 	}
 #endif
-	FlushCounts(p, lds, L);
+	if constexpr (WIDE != 0)
+		FlushWide(p, lds, W);
+	else
+		FlushCounts(p, lds, L);
 	// the last block out leaves the launch's slot {next string, blocks done} zeroed for whoever uses it next
 	// (internal.h WorkSlotOf): every block is past its last grab when it counts itself done
 	if (threadIdx.x == 0) {
@@ -951,17 +996,18 @@ bool RaggedEligible(const ScanParams& p, uint64_t totalBytesHint)
 
 namespace {
 
-template <class Act, bool EXT>
+template <class Act, bool EXT, int WIDE = 0>
 int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Act& act, hipStream_t stream)
 {
 	// (the counter is zero: the last block of the launch that used the slot before put it back, internal.h WorkSlotOf)
 	hipError_t e;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
-	const uint32_t ldsBytes = L.total + kRaggedLdsExtra;
+	const uint32_t ldsBytes = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0).total + uint32_t(sizeof(RaggedWork))
+	                               : L.total + kRaggedLdsExtra;
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	e = SetDynamicLds(reinterpret_cast<const void*>(ScanRaggedKernel<Act, EXT>), uint32_t(ldsBytes));
+	e = SetDynamicLds(reinterpret_cast<const void*>(ScanRaggedKernel<Act, EXT, WIDE>), uint32_t(ldsBytes));
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	// one string per lane: spread the waves over every CU before stacking them (4..16 waves per block, 1 block per CU)
@@ -1003,7 +1049,7 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 		q.stamps = clockBuf;
 	}
 #endif
-	hipLaunchKernelGGL((ScanRaggedKernel<Act, EXT>), dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
+	hipLaunchKernelGGL((ScanRaggedKernel<Act, EXT, WIDE>), dim3(unsigned(blocks)), dim3(unsigned(wavesPerBlock * 64)), ldsBytes, stream,
 	                   q, workCounter, grab, act);
 	e = hipGetLastError();
 	if (e != hipSuccess)
@@ -1032,6 +1078,21 @@ int LaunchRagged(const ScanParams& p, unsigned long long* workCounter, hipStream
 	if (p.ends || p.initIdx || (p.flags & kPermIds))
 		return LaunchRaggedT<NoAct, true>(p, workCounter, NoAct(), stream);
 	return LaunchRaggedT<NoAct, false>(p, workCounter, NoAct(), stream);
+}
+
+// Offset batches of a table whose scans keep leaving the dense rows (WideWanted, wide.hip): the same kernel on the
+// class-indexed walk.
+int LaunchRaggedWide(const ScanParams& p, unsigned long long* workCounter, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p))
+		return rc;
+	const bool ext = p.ends || p.initIdx || (p.flags & kPermIds);
+	if (p.next16) {
+		NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u16 table>");
+		return ext ? LaunchRaggedT<NoAct, true, 2>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 2>(p, workCounter, NoAct(), stream);
+	}
+	NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u32 table>");
+	return ext ? LaunchRaggedT<NoAct, true, 1>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 1>(p, workCounter, NoAct(), stream);
 }
 
 // The walks with actions take the ragged kernel from a few waves' worth of strings (below that, and for tables

@@ -17,6 +17,7 @@
 // levelling: tiled.hip's.
 
 #include "device_common.h"
+#include "wide_common.h"
 
 namespace pirehip {
 
@@ -45,106 +46,6 @@ __device__ __forceinline__ void WideWaitTile(u32x4 (&r)[8])
 	asm volatile("s_waitcnt vmcnt(%8)"
 	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
 	             : "n"(TILES_BEHIND * 8));
-}
-
-// wave-uniform constants of a launch
-struct WideConst {
-	uint32_t pitch;    // bytes per row
-	uint32_t flagsOff; // byte offset of a row's flags (2 * letters)
-};
-
-// A row entry: the u16 at byte `c2` (2 * letter class) of state `st`'s row.  The rows start at LDS byte 256: the DS
-// instruction's immediate offset, so the address is ONE v_mad_u32_u24.
-__device__ __forceinline__ uint32_t WideEntry(uint32_t st, uint32_t pitch, uint32_t c2)
-{
-	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(st, pitch) + c2 + 256u));
-}
-
-// The exact step for a state without a row (device ids in and out).
-template <bool N16>
-__device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, uint32_t cls)
-{
-	if (N16)
-		return p.next16[size_t(st) * p.letters + cls];
-	return p.nextPerm[size_t(st) * p.letters + cls];
-}
-
-// A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly,
-// device ids all the way: the row's entry in LDS, and ONE load from the table in memory in the steps in which that entry
-// says "no row" -- for a lane that leaves the rows with this step and for one that is outside them already alike (the
-// table answers both from the state's id).  The class of the next byte is asked for before this byte's step.  Rolled on
-// purpose (instantiated once per unrolled chunk of the tile walk).
-// History (profiles/r05b..r05d_wide_curve.jsonl, dict_1k / k512: 2 738 states visited, 2 041 rows, 1.7 % of the steps
-// outside them, EVERY wave-chunk with a lane outside): row / row's id / table as three dependent round trips per
-// iteration 464 GB/s; every lane of the re-walk through the table in memory, one round trip 887 GB/s -- but 64 scattered
-// accesses per step where all lanes re-walk (the L1 serves about one per clock and CU: dict_10k / k10000 454 GB/s); no
-// re-walk at all, every step asking whether a lane is outside the rows, 644 GB/s here and 2.4 instead of 4.25 TB/s where
-// the working set fits (a third form of the kernel, removed again); rows for the lanes that have one, the table for the
-// others and -- in an arm of its own -- for those that leave with this step: 651 GB/s (two round trips in a row).
-// What pire_hip_table_adapt() ranks the states beyond the rows by: every 16th re-walk leaves, at one rotating step, the
-// state of the first lane that is outside the rows.  (The first form sampled one fixed lane of 64 at the chunk's end,
-// like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
-// rows were there for 1 530 visited states 36 % of all wave-chunks were walked twice, profiles/r05_pmc_wide_first.txt.)
-template <bool N16>
-__device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
-                                              uint32_t st0, uint32_t& st, uint32_t& cold, uint32_t sampleStep)
-{
-	uint32_t sid = st0 < p.wide ? st0 : cold;   // the device id of the state the chunk started in
-	uint32_t c2 = HotLookup(v.x & 0xFFu);       // 2 * letter class
-	// one wave-chunk more that is walked twice (exact count, block-local); every 16th of them leaves a sample
-	const unsigned long long lanes = __ballot(true);
-	uint32_t nth = 0;
-	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
-		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
-	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 15u) == 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16; ++i) {
-		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-		v.w >>= 8;
-		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
-		// the row's entry (a state without a row reads the escape row: "no row") ...
-		const uint32_t e = WideEntry(sid < p.wide ? sid : p.wide, K.pitch, c2);
-		uint32_t next = e;
-		if (e == p.wide) {   // ... and, for the lanes it sends outside the rows or that are there already, the table in memory
-			next = WideNext<N16>(p, sid, c2 >> 1);
-			asm volatile("" : "+v"(next));   // (the wait belongs in here: left to the join it is a vmcnt(0) every lane passes)
-		}
-		sid = next;
-		if (sampled && i == sampleStep) {
-			const bool out = sid >= p.wide;
-			const unsigned long long m = __ballot(out);
-			if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-				atomicAdd(&p.visitCold[sid], 1u);
-		}
-		c2 = c2n;
-	}
-	st = sid < p.wide ? sid : p.wide;
-	cold = sid;
-}
-
-// 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
-template <bool N16>
-__device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
-                                          uint32_t& st, uint32_t& cold, uint32_t sampleLane)
-{
-	const uint32_t st0 = st;
-#pragma unroll
-	for (int w = 0; w < 4; ++w) {
-		const uint32_t x = v[w];
-		// the four classes first: independent of the walk, the LDS serves them while the chain below waits for its rows
-		const uint32_t c0 = HotLookup(x & 0xFFu);
-		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
-		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
-		const uint32_t c3 = HotLookup(x >> 24);
-		st = WideEntry(st, K.pitch, c0);
-		st = WideEntry(st, K.pitch, c1);
-		st = WideEntry(st, K.pitch, c2);
-		st = WideEntry(st, K.pitch, c3);
-	}
-	if (st == p.wide)
-		WideTrapChunk<N16>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
 }
 
 template <bool N16>
@@ -208,20 +109,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	bool primed = firstTask < ntasks;
 	if (primed)   // the first tile is on its way while the table is copied
 		WideIssueTile(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), istride);
-	{
-		uint32_t cls8 = 0;
-		if (threadIdx.x < 256)
-			cls8 = p.cls[threadIdx.x];
-		CopyToLds16<4>(lds + W.rowsOff, p.wideRows, (W.rows * W.pitch + 15) / 16);
-		__syncthreads();   // the copy's last unit may reach past the rows
-		if (threadIdx.x < 256)
-			lds[threadIdx.x] = uint8_t(2 * cls8);
-		for (uint32_t i = threadIdx.x; i < W.rows; i += blockDim.x)
-			reinterpret_cast<uint32_t*>(lds + W.histOff)[i] = 0;
-		for (uint32_t i = threadIdx.x; i < (W.total - W.countsOff) / 4; i += blockDim.x)
-			reinterpret_cast<uint32_t*>(lds + W.countsOff)[i] = 0;
-		__syncthreads();
-	}
+	LoadWideToLds(p, lds, W);
 	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
 		const uint64_t s0 = task * 64;
 		const uint64_t s = s0 + lane;
@@ -253,24 +141,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	}
 	WideWaitTile<0>(a);
 	WideWaitTile<0>(b);
-	// visit samples, trap samples, match counters
-	__syncthreads();
-	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + W.histOff);
-	for (uint32_t i = threadIdx.x; i < p.wide; i += blockDim.x)
-		if (hist[i])
-			atomicAdd(&p.visitWide[i], hist[i]);
-	if (threadIdx.x == 0 && prog[1]) {
-		atomicAdd(&p.visitHot[kWideTrapSlot], prog[1]);
-		const uint32_t total = atomicAdd(&p.visitHot[kTrapSlot], prog[1]) + prog[1];
-		if (p.trapSignal)
-			__hip_atomic_store(p.trapSignal, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-	}
-	if (p.outCounts) {
-		const uint32_t* cnt = reinterpret_cast<const uint32_t*>(lds + W.countsOff);
-		for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
-			if (cnt[i])
-				atomicAdd(&p.outCounts[i], (unsigned long long)cnt[i]);
-	}
+	FlushWide(p, lds, W);
 }
 
 // ------------------------------------------------------------------------------------------ launcher

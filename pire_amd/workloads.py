@@ -206,7 +206,11 @@ def wide_urls(entry: dict, seed: int, n: int, listed_share: float = 0.25):
     other = synthetic_domains(4096, seed=991)
     subs = [b"", b"", b"www.", b"m.", b"shop.", b"mail.", b"a.b."]
     paths = [b"", b"/", b"/index.html", b"/a/b/c?d=e", b"/news/2010/07/14/some-long-article-title.html", b"/img/logo.png",
-             b"/search?q=perl+incompatible+regular+expressions&lang=en", b"/~user/dir/"]
+             b"/search?q=perl+incompatible+regular+expressions&lang=en", b"/~user/dir/",
+             b"/catalog/section/12/item/34567/reviews?page=3&sort=date&order=desc#comment-991",
+             b"/cgi-bin/view.pl?doc=/pub/docs/pire/README&format=text&session=4f2a91c07d55e38b",
+             b"/static/js/vendor/jquery-1.4.2.min.js?v=20100714", b"/forum/viewtopic.php?f=12&t=34567&start=40&hilit=regexp+scanner",
+             b"/download/releases/0.0.6/pire-0.0.6.tar.gz", b"/blog/2010/07/yet-another-post-about-finite-automata-and-their-tables/"]
     schemes = [b"http://", b"http://", b"https://", b"ftp://", b""]
     parts = []
     listed = rng.rand(n) < listed_share

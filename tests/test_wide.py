@@ -227,3 +227,86 @@ def test_wide_walk_is_chosen_once_the_scans_are_seen_leaving_the_dense_rows(pa, 
         dev_run_strided(torch, ta, da)
         assert pb.last_kernel() == "tiled"
         ta.adapt()
+
+
+# ---- offset batches of wide tables: the ragged kernel on the class-indexed walk ------------------------------------------
+
+
+def dev_run_offsets(torch, t, text, offs, flags=BE, init=None):
+    from pire_amd import binding as pb  # noqa: F401
+
+    n = len(offs) - 1
+    d = torch.as_tensor(np.ascontiguousarray(text), device="cuda")
+    doffs = torch.as_tensor(offs.astype(np.int64), device="cuda")
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    fin = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
+    init_t = None if init is None else torch.as_tensor(np.asarray(init, dtype=np.int32), device="cuda")
+    t.run_device(d.data_ptr(), doffs.data_ptr(), n, flags, idx.data_ptr(), fin.data_ptr(), cnt.data_ptr(),
+                 init_t.data_ptr() if init_t is not None else 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy().astype(np.uint32), fin.cpu().numpy(), cnt.cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["blacklist_1k", "blacklist_10k"])
+def test_ragged_kernel_on_the_wide_walk_urls(pa, torch_cuda, cfg, name):
+    """URL batches of a blacklist scanner (samples/blacklist/blacklist.cpp:78-85, one Runner per URL) through pire_hip_run:
+    walk_variant = 2 routes offset batches to the ragged kernel on the class-indexed walk; the recorded reference results,
+    the oracle on a larger batch with empty strings in it, resume states, counters; and the dense rows for comparison."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    entry = W.wide_set(name)
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    s = entry["samples"]["urls"]
+    text, offs = W.wide_urls(entry, s["seed"], s["n"])
+    cfg.set(walk_variant=2)
+    gi, gf, _ = dev_run_offsets(torch, t, text, offs)
+    assert pb.last_kernel() == "ragged_wide", pb.last_kernel()
+    assert gi.tolist() == s["idx"] and gf.tolist() == s["final"]
+    text, offs = W.wide_urls(entry, 77, 20000)
+    lens = np.diff(offs).astype(np.int64)
+    lens[::97] = 0                                   # empty strings
+    offs2 = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs2[1:] = np.cumsum(lens)
+    rng = np.random.RandomState(5)
+    init = rng.randint(0, o.size, size=len(lens)).astype(np.uint32)
+    for flags in (BE, 0):
+        for ini in (None, init):
+            oi, of = o.run(text, offs2, flags=flags, init_idx=ini, threads=4)
+            gi, gf, cnt = dev_run_offsets(torch, t, text, offs2, flags=flags, init=ini)
+            assert pb.last_kernel() == "ragged_wide"
+            assert (gi == oi).all() and (gf == of).all(), (flags, ini is not None)
+            assert (cnt == expected_counts(o, oi, of)).all()
+    cfg.set(walk_variant=1)
+    oi, of = o.run(text, offs2, threads=4)
+    gi, gf, _ = dev_run_offsets(torch, t, text, offs2)
+    assert pb.last_kernel() in ("ragged", "stream") and (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.gpu
+def test_ragged_kernel_on_the_wide_walk_records_cut_anywhere(pa, torch_cuda, cfg):
+    """Dictionary records cut into strings of 0..700 bytes at any alignment: windows that start anywhere in a line, partial
+    last chunks, strings shorter than a chunk, lanes that leave the rows (dict_10k, a corpus of 10 000 labels)."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    cfg.set(walk_variant=2)
+    for name, corpus in (("dict_1k", "k512"), ("dict_10k", "k10000")):
+        entry = W.wide_set(name)
+        blob = W.load_blob(entry["blob"])
+        t, o = pa.Table(blob), ob.OracleScanner(blob)
+        text = W.wide_records(entry, corpus, 31, 2048, 1024).reshape(-1)
+        rng = np.random.RandomState(8)
+        lens = rng.randint(0, 700, size=5000).astype(np.uint64)
+        lens[rng.randint(0, len(lens), size=300)] = rng.randint(0, 16, size=300)
+        offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens)
+        assert int(offs[-1]) <= text.size
+        oi, of = o.run(text, offs, threads=4)
+        gi, gf, cnt = dev_run_offsets(torch, t, text[:int(offs[-1])], offs)
+        assert pb.last_kernel() == "ragged_wide"
+        assert (gi == oi).all() and (gf == of).all(), name
+        assert (cnt == expected_counts(o, oi, of)).all()

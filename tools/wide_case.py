@@ -125,20 +125,23 @@ def point_urls(entry, n, reps):
     def launch():
         t.run_device(text.data_ptr(), doffs.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
 
-    pb.set_config(walk_variant=0, auto_adapt=1)
-    for _ in range(2):
-        launch()
-        torch.cuda.synchronize()
+    for variant, label in ((1, "dense"), (2, "wide"), (0, "auto")):
+        pb.set_config(walk_variant=variant, auto_adapt=1)
+        for _ in range(3):
+            launch()
+            torch.cuda.synchronize()
+            t.adapt()
+        mean, best = timed(launch, total, reps)
+        gi = idx.cpu().numpy().astype(np.uint32).reshape(rep, nbase)
+        gf = fin.cpu().numpy().reshape(rep, nbase)
+        kernel = pb.last_kernel()
         t.adapt()
-    mean, best = timed(launch, total, reps)
-    gi = idx.cpu().numpy().astype(np.uint32).reshape(rep, nbase)
-    gf = fin.cpu().numpy().reshape(rep, nbase)
-    t.adapt()
-    i2 = t.refresh_info()
-    res["default"] = {"kernel": pb.last_kernel(), "GBps": round(total / mean / 1e6, 1), "GBps_best": round(total / best / 1e6, 1),
+        i2 = t.refresh_info()
+        res[label] = {"kernel": kernel, "GBps": round(total / mean / 1e6, 1), "GBps_best": round(total / best / 1e6, 1),
                       "ms": round(mean, 4), "parity_all_strings": bool((gi == oi[None, :]).all() and (gf == of[None, :]).all()),
-                      "listed_share": round(float(of.mean()), 4),
-                      "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6)}
+                      "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6),
+                      "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6)}
+    res["listed_share"] = round(float(of.mean()), 4)
     return res
 
 
@@ -146,7 +149,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log2-strings", type=int, default=18)
     ap.add_argument("--len", type=int, default=4096)
-    ap.add_argument("--log2-urls", type=int, default=22)
+    ap.add_argument("--log2-urls", type=int, default=23)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--points", default=DEFAULT)
     ap.add_argument("--out", default="")
