@@ -232,7 +232,7 @@ def test_wide_walk_is_chosen_once_the_scans_are_seen_leaving_the_dense_rows(pa, 
 # ---- offset batches of wide tables: the ragged kernel on the class-indexed walk ------------------------------------------
 
 
-def dev_run_offsets(torch, t, text, offs, flags=BE, init=None):
+def dev_run_offsets(torch, t, text, offs, flags=BE, init=None, want_idx=True):
     from pire_amd import binding as pb  # noqa: F401
 
     n = len(offs) - 1
@@ -242,7 +242,7 @@ def dev_run_offsets(torch, t, text, offs, flags=BE, init=None):
     fin = torch.empty(n, dtype=torch.uint8, device="cuda")
     cnt = torch.zeros(t.RegexpsCount + 2, dtype=torch.int64, device="cuda")
     init_t = None if init is None else torch.as_tensor(np.asarray(init, dtype=np.int32), device="cuda")
-    t.run_device(d.data_ptr(), doffs.data_ptr(), n, flags, idx.data_ptr(), fin.data_ptr(), cnt.data_ptr(),
+    t.run_device(d.data_ptr(), doffs.data_ptr(), n, flags, idx.data_ptr() if want_idx else 0, fin.data_ptr(), cnt.data_ptr(),
                  init_t.data_ptr() if init_t is not None else 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     return idx.cpu().numpy().astype(np.uint32), fin.cpu().numpy(), cnt.cpu().numpy().astype(np.uint64)
@@ -280,6 +280,9 @@ def test_ragged_kernel_on_the_wide_walk_urls(pa, torch_cuda, cfg, name):
             assert pb.last_kernel() == "ragged_wide"
             assert (gi == oi).all() and (gf == of).all(), (flags, ini is not None)
             assert (cnt == expected_counts(o, oi, of)).all()
+            # without a StateIndex array the end states cannot be parked in it: the kernel finishes every string itself
+            _, gf, cnt = dev_run_offsets(torch, t, text, offs2, flags=flags, init=ini, want_idx=False)
+            assert (gf == of).all() and (cnt == expected_counts(o, oi, of)).all()
     cfg.set(walk_variant=1)
     oi, of = o.run(text, offs2, threads=4)
     gi, gf, _ = dev_run_offsets(torch, t, text, offs2)
