@@ -839,18 +839,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			act.Finish(p, lds, L, reinterpret_cast<const uint8_t*>(finHot), al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
 		if constexpr (WIDE != 0) {
+			// the end-of-string record from memory, under a wave-uniform branch of its own and waited for inside it (FinRecordOf)
 			const uint32_t st = S.hs != p.wide ? S.hs : S.cold;
-			if (p.outIdx) {
-				// DEFERRED: the end state's device id into the string's result slot -- a store, nothing to wait for -- and
-				// WideFinishKernel turns the slots into StateIndex / Final / counters behind this kernel.  The record of the
-				// end state lives in memory here (the LDS is the rows'), and a load under this branch is a vmcnt(0) in every
-				// iteration of a batch of short strings: it also waits for the window on its way (URLs: 0.95 -> 1.4 TB/s).
-				if (ends)
-					p.outIdx[S.sIdx] = st;
-				goto finished;
-			}
-			// no result array to park the state in: the end-of-string record from memory, under a wave-uniform branch of its
-			// own and waited for inside it (FinRecordOf)
 			u32x4 raw = {0, 0, 0, 0};
 			if (ends) {
 				const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
@@ -862,7 +852,6 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			FinishRagged<EXT>(p, lds, L, finHot, S.sIdx, ends, S.hs != p.hot ? S.hs : S.cold);
 		}
 	}
-finished:
 	PIRE_RCLK(clk, 4);
 
 	// ---- move on
@@ -894,32 +883,6 @@ finished:
 	S.loaded = nLoad;
 	PIRE_RCLK(clk, 5);
 	return __any(nBusy || S.pend);
-}
-
-// Behind a WIDE launch with a result array: out_state_idx[s] holds the device id of string s's end state; its record
-// (one coalesced 16-byte load per string) becomes StateIndex, Final and the match counters.
-template <bool EXT>
-__global__ __launch_bounds__(256) void WideFinishKernel(ScanParams p)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	LdsLayout L = {};   // the block-local counters at LDS byte 0
-	for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
-		reinterpret_cast<uint32_t*>(lds)[i] = 0;
-	__syncthreads();
-	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
-	for (uint64_t base = uint64_t(blockIdx.x) * blockDim.x; base < p.n; base += uint64_t(gridDim.x) * blockDim.x) {
-		const uint64_t s = base + threadIdx.x;
-		const bool active = s < p.n;
-		u32x4 raw = {0, 0, 0, 0};
-		if (active)
-			raw = *reinterpret_cast<const u32x4*>(&recs[p.outIdx[s]]);
-		FinishWith<EXT>(p, lds, L, uint32_t(s), active, raw);
-	}
-	__syncthreads();
-	if (p.outCounts)
-		for (uint32_t i = threadIdx.x; i < p.regexps + 2; i += blockDim.x)
-			if (reinterpret_cast<uint32_t*>(lds)[i])
-				atomicAdd(&p.outCounts[i], (unsigned long long)reinterpret_cast<uint32_t*>(lds)[i]);
 }
 
 template <class Act, bool EXT, int WIDE = 0>
@@ -1124,28 +1087,12 @@ int LaunchRaggedWide(const ScanParams& p, unsigned long long* workCounter, hipSt
 	if (int rc = CheckCounts(p))
 		return rc;
 	const bool ext = p.ends || p.initIdx || (p.flags & kPermIds);
-	int rc;
 	if (p.next16) {
 		NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u16 table>");
-		rc = ext ? LaunchRaggedT<NoAct, true, 2>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 2>(p, workCounter, NoAct(), stream);
-	} else {
-		NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u32 table>");
-		rc = ext ? LaunchRaggedT<NoAct, true, 1>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 1>(p, workCounter, NoAct(), stream);
+		return ext ? LaunchRaggedT<NoAct, true, 2>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 2>(p, workCounter, NoAct(), stream);
 	}
-	if (rc != PIRE_HIP_OK || !p.outIdx)
-		return rc;
-	// the scan parked every string's end state in its result slot: records -> StateIndex / Final / counters
-	int cus = 0;
-	if ((rc = DeviceCUs(&cus)))
-		return rc;
-	const unsigned blocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 255) / 256, uint64_t(cus) * 8)));
-	const uint32_t ldsBytes = (p.regexps + 2) * 4 + 16;
-	if (ext)
-		hipLaunchKernelGGL(WideFinishKernel<true>, dim3(blocks), dim3(256), ldsBytes, stream, p);
-	else
-		hipLaunchKernelGGL(WideFinishKernel<false>, dim3(blocks), dim3(256), ldsBytes, stream, p);
-	const hipError_t e = hipGetLastError();
-	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "wide finish kernel launch");
+	NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u32 table>");
+	return ext ? LaunchRaggedT<NoAct, true, 1>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 1>(p, workCounter, NoAct(), stream);
 }
 
 // The walks with actions take the ragged kernel from a few waves' worth of strings (below that, and for tables
