@@ -158,11 +158,14 @@ def test_scans_while_another_thread_calls_adapt(pa, cfg):
         tx, ofs = H.pack(strings)
         jobs.append((k, tx, ofs, o.run(tx, ofs, threads=2), o.prefix(tx, ofs, True, True, True), o.run_half_final(tx, ofs)))
     errors, stop = [], threading.Event()
+    adapts = [0]
 
     def scanner(job):
         k, tx, ofs, want, want_p, want_hf = job
         try:
-            for rep in range(12):
+            for rep in range(80):
+                if rep >= 12 and adapts[0] >= 3:   # (at least 12 rounds, and on until three adaptations ran underneath them:
+                    break                          #  an adaptation uploads more since round 5 -- the wide walk's image)
                 if k % 2 == 0:
                     got = t.run(tx, ofs)
                     ok = (got[0] == want[0]).all() and (got[1] == want[1]).all()
@@ -175,8 +178,6 @@ def test_scans_while_another_thread_calls_adapt(pa, cfg):
                     errors.append((k, rep))
         except Exception as e:   # noqa: BLE001
             errors.append((k, repr(e)))
-
-    adapts = [0]
 
     def adapter():
         try:
