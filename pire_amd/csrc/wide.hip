@@ -79,8 +79,8 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 		WideChunk<N16>(p, lds, W, K, cur[k], st, cold, (t * 8 + k) & 63);
 }
 
-// Fixed-length records, 16-byte aligned, an EVEN number of 128-byte tiles per record (+ a tail shorter than a tile),
-// whole tasks of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries.
+// Fixed-length records, 16-byte aligned, at least two 128-byte tiles per record (+ a tail shorter than a tile), whole tasks
+// of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries when the tile count is even.
 template <bool N16>
 __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 {
@@ -95,8 +95,11 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	const uint64_t ntasks = p.n / 64;
-	const uint32_t ntiles = uint32_t(p.len / 128) & ~1u;   // walked from the ring; an odd last tile and the tail: exact steps below
+	const uint32_t ntiles = uint32_t(p.len / 128);   // >= 2 (the dispatcher); a tail shorter than a tile: exact steps below
 	const uint32_t lastTile = ntiles - 1;
+	const uint32_t paired = ntiles & ~1u;            // tiles walked two by two out of the ring; an odd last one after them
+	// With an even tile count every task starts in slot a, so the ring runs straight through task boundaries (tiled.hip).
+	const bool chain = (ntiles & 1u) == 0;
 	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
 	const uint64_t istride = p.stride;
 	u32x4 a[8], b[8];
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		const uint64_t s0 = task * 64;
 		const uint64_t s = s0 + lane;
 		const uint64_t rowBase = Uniform64(reinterpret_cast<uint64_t>(p.text) + s0 * p.stride);
-		const bool hasNext = task + taskStep < ntasks;
+		const bool hasNext = chain && task + taskStep < ntasks;
 		const uint64_t chainBase = hasNext ? Uniform64(reinterpret_cast<uint64_t>(p.text) + (s0 + taskStep * 64) * p.stride)
 		                                   : rowBase + uint64_t(lastTile) * 128;
 		uint32_t cold = StartState(p, s);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		bool done = false;
 		if (!primed)
 			WideIssueTile(a, voff, rowBase, istride);
-		for (uint32_t t = 0; t < ntiles && !done; t += 2) {
+		for (uint32_t t = 0; t < paired && !done; t += 2) {
 			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, st, cold, prog, myTiles);
 			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, st, cold, prog, myTiles);
 			// wave-wide early out (multi.h:955-958): every lane in a row whose every transition is a self loop
@@ -131,8 +134,17 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (done)
 			WideWaitTile<0>(a);
+		if (!done && !chain) {
+			// the odd last tile (ntiles >= 3 here): requested into slot a by the last phase of the loop, walked with nothing
+			// on its way behind it
+			WideWaitTile<0>(a);
+			TransposeTile(a, lane);
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				WideChunk<N16>(p, lds, W, K, a[k], st, cold, (lastTile * 8 + k) & 63);
+		}
 		uint32_t end = st < p.wide ? st : cold;
-		if (!done) {   // an odd last tile and the tail shorter than a tile: exact steps straight from memory
+		if (!done) {   // the tail shorter than a tile: exact steps straight from memory
 			const uint8_t* base = p.text + s * p.stride;
 			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i)
 				end = WideNext<N16>(p, end, uint32_t(lds[base[i]]) >> 1);
