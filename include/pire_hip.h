@@ -158,7 +158,10 @@ typedef struct pire_hip_config {
 	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
 	                               /* outside the 255 dense rows passes 0.05 % (measured by adapt(); 5 % of the a-priori   */
 	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
-	                               /* class-indexed walk.  Same results either way.                                        */
+	                               /* class-indexed walk with one string per lane (working sets that fit its rows), 3      */
+	                               /* always with two strings per lane (working sets beyond them: twice the loads on their */
+	                               /* way; 0 picks between the two by the exact share of wave-chunks the walk had to walk  */
+	                               /* a second time).  Same results either way.                                            */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -203,7 +206,8 @@ typedef struct pire_hip_table_info {
 	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
 	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
 	                                /* (exact, all devices)                                                                 */
-	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time                   */
+	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time: above 0.3 it     */
+	                                /* walks two strings per lane                                                           */
 	uint32_t reserved3;
 } pire_hip_table_info;
 

@@ -201,6 +201,7 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->outsideDense = h.outsideDense;
 	p->outsideWide = h.outsideWide;
 	p->massMeasured = h.massMeasured;
+	p->wideTwiceShare = h.wideTwiceShare;
 	p->wideLaunched = &t->wideLaunched;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;

@@ -350,6 +350,7 @@ struct ScanParams {
 	uint32_t* visitWide;
 	uint32_t wide;              // states with a wide row; 0 = no image
 	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
+	float wideTwiceShare;              // host side only: share of the wide walk's wave-chunks walked twice (last adapt()): one or two strings per lane
 	std::atomic<uint64_t>* wideLaunched;   // host side only: wave-chunks handed to the wide walk since the last adapt()
 	bool massMeasured;                 // host side only
 	const uint64_t* incPerm; // nullable

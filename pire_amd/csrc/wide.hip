@@ -156,6 +156,87 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	FlushWide(p, lds, W);
 }
 
+// ---- two strings per lane: working sets beyond the rows (wide_common.h WideChunk2) --------------------------------------
+// A task = 128 strings, lane l walks strings l and l + 64 of it.  Both tiles live in the 64 tile registers the ring of
+// the kernel above uses for one string's two tiles, so there is no tile on its way during the walk: load, wait, walk
+// (the walk is 10 x the load here; and a load on its way would be waited for by the first vmcnt(0) of a re-walk anyway).
+template <bool N16>
+__global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
+	WideConst K;
+	K.pitch = W.pitch;
+	K.flagsOff = p.letters * 2;
+	LdsLayout L = {};
+	L.countsOff = W.countsOff;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t ntasks = p.n / 128;
+	const uint32_t ntiles = uint32_t(p.len / 128);
+	const uint32_t voff = (lane & ~7u) * uint32_t(p.stride) + (lane & 7u) * 16;
+	const uint64_t istride = p.stride;
+	u32x4 a[8], b[8];
+	ZeroTile(a);
+	ZeroTile(b);
+	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
+	uint32_t myTiles = 0;
+	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
+	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+	LoadWideToLds(p, lds, W);
+	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
+		const uint64_t sA = task * 128 + lane, sB = sA + 64;
+		const uint64_t baseA = Uniform64(reinterpret_cast<uint64_t>(p.text) + task * 128 * p.stride);
+		const uint64_t baseB = baseA + 64 * p.stride;
+		uint32_t colda = StartState(p, sA), coldb = StartState(p, sB);
+		uint32_t sa = colda < p.wide ? colda : p.wide, sb = coldb < p.wide ? coldb : p.wide;
+		bool done = false;
+		for (uint32_t t = 0; t < ntiles && !done; ++t) {
+			{   // the waves of a block kept in step (tiled.hip, EQ)
+				uint32_t sum = 0;
+				if (lane == 0)
+					sum = atomicAdd(prog, 1u) + 1;
+				sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
+				const uint32_t mine = ++myTiles;
+				constexpr uint32_t margin = 4;
+				if (mine * (blockDim.x >> 6) > sum + margin)
+					__builtin_amdgcn_s_setprio(0);
+				else if (mine * (blockDim.x >> 6) + margin < sum)
+					__builtin_amdgcn_s_setprio(3);
+				else
+					__builtin_amdgcn_s_setprio(1);
+			}
+			WideIssueTile(a, voff, baseA + uint64_t(t) * 128, istride);
+			WideIssueTile(b, voff, baseB + uint64_t(t) * 128, istride);
+			WideWaitTile<0>(a);
+			WideWaitTile<0>(b);
+			TransposeTile(a, lane);
+			TransposeTile(b, lane);
+			if (lane == (t & 63)) {   // visit samples: one lane per wave per tile, rotating
+				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sa, 1u);
+				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sb, 1u);
+			}
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				WideChunk2<N16>(p, lds, W, K, a[k], b[k], sa, sb, colda, coldb, (t * 8 + k) & 63);
+			if (t & 1)   // wave-wide early out (multi.h:955-958), every other tile
+				done = __all(((WideEntry(sa, K.pitch, K.flagsOff) & WideEntry(sb, K.pitch, K.flagsOff)) & kAbsorbing) != 0);
+		}
+		uint32_t enda = sa < p.wide ? sa : colda, endb = sb < p.wide ? sb : coldb;
+		if (!done) {   // the tail shorter than a tile: exact steps straight from memory
+			const uint8_t* ta = p.text + sA * p.stride;
+			const uint8_t* tb = p.text + sB * p.stride;
+			for (uint64_t i = uint64_t(ntiles) * 128; i < p.len; ++i) {
+				enda = WideNext<N16>(p, enda, uint32_t(lds[ta[i]]) >> 1);
+				endb = WideNext<N16>(p, endb, uint32_t(lds[tb[i]]) >> 1);
+			}
+		}
+		Finish(p, lds, L, sA, true, enda);
+		Finish(p, lds, L, sB, true, endb);
+	}
+	FlushWide(p, lds, W);
+}
+
 // ------------------------------------------------------------------------------------------ launcher
 
 // The choice between the dense rows and the wide walk (any choice is correct).  pire_hip_config.walk_variant: 0 by the
@@ -186,14 +267,24 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
+	// Two forms (same results): one string per lane and a ring of two tiles -- 4.2-4.3 TB/s while the working set fits the
+	// rows --, or two strings per lane (ScanWide2Kernel) once most wave-chunks are walked twice: the loads of the re-walk
+	// are then what the time goes into, and two chains per lane have two of them on their way.  By the exact share of
+	// wave-chunks the scans since the last adapt() walked twice; walk_variant 2 / 3 force one.
+	const pire_hip_config cfg = GetConfig();
+	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.3f);
+	if (two)
+		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
 	if (p.wideLaunched)
 		p.wideLaunched->fetch_add(q.n / 64 * (p.len / 16), std::memory_order_relaxed);
-	if (p.next16) {
-		NoteKernel("wide", "pirehip::ScanWideKernel<u16 table>");
-		rc = LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
+	if (q.n == 0) {
+		rc = PIRE_HIP_OK;
+	} else if (p.next16) {
+		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u16 table>" : "pirehip::ScanWideKernel<u16 table>");
+		rc = two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
 	} else {
-		NoteKernel("wide", "pirehip::ScanWideKernel<u32 table>");
-		rc = LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
+		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u32 table>" : "pirehip::ScanWideKernel<u32 table>");
+		rc = two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

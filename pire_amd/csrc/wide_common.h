@@ -107,6 +107,93 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 }
 
 
+// ---- two strings per lane (wide.hip ScanWide2Kernel) --------------------------------------------------------------------
+// Beyond the rows the walk is bound by the latency of its loads -- an L2 hit is ~500 clocks against ~150 for an LDS step --
+// and a CU holds 16 waves whatever happens (the image is its whole LDS).  What is left is more dependent chains per
+// wave: every lane walks TWO strings, step by step in turn, so that the two lookups -- and, in the re-walk, the two
+// loads from the table -- of a step are on their way together.
+
+// A lane of either string sits in the escape row after the chunk: both strings' 16 bytes again, exactly (WideTrapChunk
+// for two chains; a chain that did not leave the rows is walked again as well -- it costs nothing in lock step and ends
+// where it ended).  One round trip to the table per step serves both chains.
+template <bool N16>
+__device__ __forceinline__ void WideTrapChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 va,
+                                               u32x4 vb, uint32_t sa0, uint32_t sb0, uint32_t& sa, uint32_t& sb, uint32_t& colda,
+                                               uint32_t& coldb, uint32_t sampleStep)
+{
+	uint32_t ia = sa0 < p.wide ? sa0 : colda, ib = sb0 < p.wide ? sb0 : coldb;
+	uint32_t c2a = HotLookup(va.x & 0xFFu), c2b = HotLookup(vb.x & 0xFFu);
+	const unsigned long long lanes = __ballot(true);
+	uint32_t nth = 0;
+	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
+		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);   // wave-chunks walked twice (exact)
+	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 15u) == 0;
+#pragma unroll 1
+	for (uint32_t i = 0; i < 16; ++i) {
+		va.x = __builtin_amdgcn_alignbit(va.y, va.x, 8);
+		va.y = __builtin_amdgcn_alignbit(va.z, va.y, 8);
+		va.z = __builtin_amdgcn_alignbit(va.w, va.z, 8);
+		va.w >>= 8;
+		vb.x = __builtin_amdgcn_alignbit(vb.y, vb.x, 8);
+		vb.y = __builtin_amdgcn_alignbit(vb.z, vb.y, 8);
+		vb.z = __builtin_amdgcn_alignbit(vb.w, vb.z, 8);
+		vb.w >>= 8;
+		const uint32_t c2an = HotLookup(va.x & 0xFFu), c2bn = HotLookup(vb.x & 0xFFu);
+		const uint32_t ea = WideEntry(ia < p.wide ? ia : p.wide, K.pitch, c2a);
+		const uint32_t eb = WideEntry(ib < p.wide ? ib : p.wide, K.pitch, c2b);
+		uint32_t na = ea, nb = eb;
+		if (ea == p.wide || eb == p.wide) {
+			if (ea == p.wide)
+				na = WideNext<N16>(p, ia, c2a >> 1);
+			if (eb == p.wide)
+				nb = WideNext<N16>(p, ib, c2b >> 1);
+			asm volatile("" : "+v"(na), "+v"(nb));   // both loads on their way, ONE wait, inside this arm
+		}
+		ia = na;
+		ib = nb;
+		if (sampled && i == sampleStep) {
+			const uint32_t out = ia >= p.wide ? ia : ib;
+			const bool is = ia >= p.wide || ib >= p.wide;
+			const unsigned long long m = __ballot(is);
+			if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+				atomicAdd(&p.visitCold[out], 1u);
+		}
+		c2a = c2an;
+		c2b = c2bn;
+	}
+	sa = ia < p.wide ? ia : p.wide;
+	colda = ia;
+	sb = ib < p.wide ? ib : p.wide;
+	coldb = ib;
+}
+
+// 16 bytes of each of the lane's two strings through the rows, the two chains' lookups in turn.
+template <bool N16>
+__device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 va,
+                                           const u32x4 vb, uint32_t& sa, uint32_t& sb, uint32_t& colda, uint32_t& coldb,
+                                           uint32_t sampleLane)
+{
+	const uint32_t sa0 = sa, sb0 = sb;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t xa = va[w], xb = vb[w];
+		const uint32_t a0 = HotLookup(xa & 0xFFu), b0 = HotLookup(xb & 0xFFu);
+		const uint32_t a1 = HotLookup((xa >> 8) & 0xFFu), b1 = HotLookup((xb >> 8) & 0xFFu);
+		const uint32_t a2 = HotLookup((xa >> 16) & 0xFFu), b2 = HotLookup((xb >> 16) & 0xFFu);
+		const uint32_t a3 = HotLookup(xa >> 24), b3 = HotLookup(xb >> 24);
+		sa = WideEntry(sa, K.pitch, a0);
+		sb = WideEntry(sb, K.pitch, b0);
+		sa = WideEntry(sa, K.pitch, a1);
+		sb = WideEntry(sb, K.pitch, b1);
+		sa = WideEntry(sa, K.pitch, a2);
+		sb = WideEntry(sb, K.pitch, b2);
+		sa = WideEntry(sa, K.pitch, a3);
+		sb = WideEntry(sb, K.pitch, b3);
+	}
+	if (sa == p.wide || sb == p.wide)
+		WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u);
+}
+
 // The first `count` (0..15) bytes of v through the rows: the whole chunk is walked, unrolled like WideChunk, and the
 // state after byte `count` is kept; lanes with count == 0 keep their state (the ragged kernel's last, partial chunk of a
 // string: StepPartial of ragged.hip for this walk).  A lane that left the rows inside its bytes is re-walked exactly,

@@ -119,12 +119,13 @@ def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     offs = np.arange(n + 1, dtype=np.uint64) * length
     oi, of = o.run(data.reshape(-1), offs, threads=4)
     d = torch.as_tensor(data, device="cuda")
-    cfg.set(walk_variant=2)
-    gi, gf, cnt = dev_run_strided(torch, t, d)
-    assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the < 64-string remainder behind it
-    assert "ScanWideKernel" in pb.last_kernel_symbol() or n % 64
-    assert (gi == oi).all() and (gf == of).all()
-    assert (cnt == expected_counts(o, oi, of)).all()
+    for variant, symbol, task in ((2, "ScanWideKernel", 64), (3, "ScanWide2Kernel", 128)):   # one / two strings per lane
+        cfg.set(walk_variant=variant)
+        gi, gf, cnt = dev_run_strided(torch, t, d)
+        assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the remainder of a task behind it
+        assert symbol in pb.last_kernel_symbol() or n % task
+        assert (gi == oi).all() and (gf == of).all(), variant
+        assert (cnt == expected_counts(o, oi, of)).all()
     cfg.set(walk_variant=1)
     di, df, _ = dev_run_strided(torch, t, d)
     assert pb.last_kernel() in ("tiled", "generic")
@@ -163,10 +164,11 @@ def test_wide_kernel_flags_and_resume_states(pa, torch_cuda, cfg, flags):
     d = torch.as_tensor(data, device="cuda")
     for ini in (None, init):
         oi, of = o.run(data.reshape(-1), offs, flags=flags, init_idx=ini, threads=4)
-        cfg.set(walk_variant=2)
-        gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
-        assert (gi == oi).all() and (gf == of).all()
-        assert (cnt == expected_counts(o, oi, of)).all()
+        for variant in (2, 3):
+            cfg.set(walk_variant=variant)
+            gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
+            assert (gi == oi).all() and (gf == of).all(), variant
+            assert (cnt == expected_counts(o, oi, of)).all()
 
 
 @pytest.mark.gpu
@@ -176,8 +178,8 @@ def test_wide_kernel_with_a_ranking_that_knows_nothing(pa, torch_cuda, cfg):
     from pire_amd import binding as pb
 
     torch = torch_cuda
-    cfg.set(prior_flat=1, walk_variant=2)
-    for name, corpus in (("dict_1k", "k1000"), ("dict_10k", "k10000")):
+    for name, corpus, variant in (("dict_1k", "k1000", 2), ("dict_10k", "k10000", 2), ("dict_1k", "k1000", 3), ("dict_10k", "k10000", 3)):
+        cfg.set(prior_flat=1, walk_variant=variant)
         entry = W.wide_set(name)
         blob = W.load_blob(entry["blob"])
         t, o = pa.Table(blob), ob.OracleScanner(blob)
