@@ -126,8 +126,8 @@ __device__ __forceinline__ void WideTrapChunk2(const ScanParams& p, uint8_t* lds
 	const unsigned long long lanes = __ballot(true);
 	uint32_t nth = 0;
 	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
-		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);   // wave-chunks walked twice (exact)
-	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 15u) == 0;
+		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 2u);   // wave-chunks walked twice (exact): two here
+	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 30u) == 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < 16; ++i) {
 		va.x = __builtin_amdgcn_alignbit(va.y, va.x, 8);
