@@ -237,146 +237,6 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 	FlushWide(p, lds, W);
 }
 
-// ---- four strings per lane on half-line tiles ------------------------------------------------------------------------------
-// The same idea once more: a task = 256 strings, lane l walks strings l, l + 64, l + 128, l + 192 of it; a tile is HALF a
-// line (64 bytes) of each of a group's 64 strings -- four 16-byte registers per lane and group, the 64 tile registers in
-// all -- fetched by groups of FOUR lanes (4 x 16 bytes = a half line per instruction and group) and transposed inside
-// each quad.  Every line is fetched by two phases of the walk: twice the HBM traffic, which this regime has to spare
-// (the walk is at a sixth of the HBM rate there).
-__device__ __forceinline__ void WideIssueHalfTile(u32x4 (&r)[4], uint32_t voff, uint64_t tileBase, uint64_t stride)
-{
-	const uint64_t b0 = tileBase, b1 = b0 + stride, b2 = b1 + stride, b3 = b2 + stride;
-	asm volatile(
-		"global_load_dwordx4 %0, %4, %5\n\t"
-		"global_load_dwordx4 %1, %4, %6\n\t"
-		"global_load_dwordx4 %2, %4, %7\n\t"
-		"global_load_dwordx4 %3, %4, %8"
-		: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3])
-		: "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3));
-}
-
-__device__ __forceinline__ void WideWaitHalfTiles(u32x4 (&a)[4], u32x4 (&b)[4], u32x4 (&c)[4], u32x4 (&d)[4])
-{
-	asm volatile("s_waitcnt vmcnt(0)"
-	             : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(c[0]), "+v"(c[1]),
-	               "+v"(c[2]), "+v"(c[3]), "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
-}
-
-// 4x4 transpose inside every quad: before, lane 4g+c holds in register j chunk c of string 4g+j; after, lane 4g+j holds
-// chunks 0..3 of its own string in registers 0..3.  Two butterfly stages (lane bit 0, lane bit 1), two dword columns a call.
-__device__ __forceinline__ void TransposeHalfTile(u32x4 (&r)[4])
-{
-	const uint64_t lo1 = 0x5555555555555555ull, hi1 = 0xAAAAAAAAAAAAAAAAull;
-	const uint64_t lo2 = 0x3333333333333333ull, hi2 = 0xCCCCCCCCCCCCCCCCull;
-#pragma unroll
-	for (int w = 0; w < 4; w += 2) {
-		uint32_t d[4], e[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			d[k] = r[k][w];
-			e[k] = r[k][w + 1];
-		}
-		ButterflyQuad4<1>(d[0], d[1], d[2], d[3], e[0], e[1], e[2], e[3], lo1, hi1);
-		ButterflyQuad4<2>(d[0], d[2], d[1], d[3], e[0], e[2], e[1], e[3], lo2, hi2);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			r[k][w] = d[k];
-			r[k][w + 1] = e[k];
-		}
-		__builtin_amdgcn_sched_barrier(0);
-	}
-}
-
-template <bool N16>
-__global__ __launch_bounds__(1024, 4) void ScanWide4Kernel(ScanParams p)
-{
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
-	WideConst K;
-	K.pitch = W.pitch;
-	K.flagsOff = p.letters * 2;
-	LdsLayout L = {};
-	L.countsOff = W.countsOff;
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const uint64_t ntasks = p.n / 256;
-	const uint32_t nhalf = uint32_t(p.len / 64);   // half-line tiles per record; the tail behind them: exact steps below
-	const uint32_t voff = (lane & ~3u) * uint32_t(p.stride) + (lane & 3u) * 16;
-	const uint64_t istride = p.stride;
-	u32x4 ta[4], tb[4], tc[4], td[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k)
-		ta[k] = tb[k] = tc[k] = td[k] = u32x4{0, 0, 0, 0};
-	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
-	uint32_t myTiles = 0;
-	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
-	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
-	LoadWideToLds(p, lds, W);
-	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
-		const uint64_t s0 = task * 256 + lane;
-		const uint64_t base = Uniform64(reinterpret_cast<uint64_t>(p.text) + task * 256 * p.stride);
-		const uint64_t group = 64 * p.stride;
-		uint32_t st[4], cold[4];
-#pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			cold[c] = StartState(p, s0 + 64u * c);
-			st[c] = cold[c] < p.wide ? cold[c] : p.wide;
-		}
-		bool done = false;
-		for (uint32_t t = 0; t < nhalf && !done; ++t) {
-			if ((t & 1) == 0) {   // the waves of a block kept in step (tiled.hip, EQ), per whole line
-				uint32_t sum = 0;
-				if (lane == 0)
-					sum = atomicAdd(prog, 1u) + 1;
-				sum = uint32_t(__builtin_amdgcn_readfirstlane(int(sum)));
-				const uint32_t mine = ++myTiles;
-				constexpr uint32_t margin = 4;
-				if (mine * (blockDim.x >> 6) > sum + margin)
-					__builtin_amdgcn_s_setprio(0);
-				else if (mine * (blockDim.x >> 6) + margin < sum)
-					__builtin_amdgcn_s_setprio(3);
-				else
-					__builtin_amdgcn_s_setprio(1);
-			}
-			const uint64_t at = base + uint64_t(t) * 64;
-			WideIssueHalfTile(ta, voff, at, istride);
-			WideIssueHalfTile(tb, voff, at + group, istride);
-			WideIssueHalfTile(tc, voff, at + 2 * group, istride);
-			WideIssueHalfTile(td, voff, at + 3 * group, istride);
-			WideWaitHalfTiles(ta, tb, tc, td);
-			TransposeHalfTile(ta);
-			TransposeHalfTile(tb);
-			TransposeHalfTile(tc);
-			TransposeHalfTile(td);
-			if (lane == (t & 63))   // visit samples: one lane per wave per half tile, rotating (half the weight of a whole tile's)
-				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st[t & 3], 1u);
-#pragma unroll
-			for (int k = 0; k < 4; ++k) {
-				const u32x4 v[4] = {ta[k], tb[k], tc[k], td[k]};
-				WideChunkN<N16, 4>(p, lds, W, K, v, st, cold, (t * 4 + k) & 63);
-			}
-			if ((t & 3) == 3) {   // wave-wide early out (multi.h:955-958), every other line
-				uint32_t fl = kAbsorbing;
-#pragma unroll
-				for (int c = 0; c < 4; ++c)
-					fl &= WideEntry(st[c], K.pitch, K.flagsOff);
-				done = __all((fl & kAbsorbing) != 0);
-			}
-		}
-#pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			uint32_t end = st[c] < p.wide ? st[c] : cold[c];
-			if (!done) {   // the tail shorter than a half tile: exact steps straight from memory
-				const uint8_t* tx = p.text + (s0 + 64u * c) * p.stride;
-				for (uint64_t i = uint64_t(nhalf) * 64; i < p.len; ++i)
-					end = WideNext<N16>(p, end, uint32_t(lds[tx[i]]) >> 1);
-			}
-			Finish(p, lds, L, s0 + 64u * c, true, end);
-		}
-	}
-	FlushWide(p, lds, W);
-}
-
 // ------------------------------------------------------------------------------------------ launcher
 
 // The choice between the dense rows and the wide walk (any choice is correct).  pire_hip_config.walk_variant: 0 by the
@@ -412,24 +272,19 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	// are then what the time goes into, and two chains per lane have two of them on their way.  By the exact share of
 	// wave-chunks the scans since the last adapt() walked twice; walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
-	const bool four = cfg.walk_variant == 4;
-	const bool two = !four && (cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.3f));
+	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.3f);
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
-	if (four)
-		q.n = p.n & ~uint64_t(255);   // whole 256-string tasks
 	if (p.wideLaunched)
 		p.wideLaunched->fetch_add(q.n / 64 * (p.len / 16), std::memory_order_relaxed);
 	if (q.n == 0) {
 		rc = PIRE_HIP_OK;
 	} else if (p.next16) {
-		NoteKernel("wide", four ? "pirehip::ScanWide4Kernel<u16 table>" : two ? "pirehip::ScanWide2Kernel<u16 table>" : "pirehip::ScanWideKernel<u16 table>");
-		rc = four ? LaunchScan(ScanWide4Kernel<true>, q, 1024, W.total, stream)
-		     : two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
+		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u16 table>" : "pirehip::ScanWideKernel<u16 table>");
+		rc = two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
 	} else {
-		NoteKernel("wide", four ? "pirehip::ScanWide4Kernel<u32 table>" : two ? "pirehip::ScanWide2Kernel<u32 table>" : "pirehip::ScanWideKernel<u32 table>");
-		rc = four ? LaunchScan(ScanWide4Kernel<false>, q, 1024, W.total, stream)
-		     : two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
+		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u32 table>" : "pirehip::ScanWideKernel<u32 table>");
+		rc = two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

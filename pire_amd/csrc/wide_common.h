@@ -112,6 +112,11 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 // and a CU holds 16 waves whatever happens (the image is its whole LDS).  What is left is more dependent chains per
 // wave: every lane walks TWO strings, step by step in turn, so that the two lookups -- and, in the re-walk, the two
 // loads from the table -- of a step are on their way together.
+// (FOUR strings per lane on half-line tiles -- 64 bytes of each string per phase, fetched by groups of four lanes, 4 x 4
+// transposes inside the quads, every line read from HBM twice -- was built and measured, profiles/
+// r05j_wide_curve_four_chains.jsonl: 1.42 against 1.29 TB/s on dict_1k / k512, 1.40 against 1.30 on dict_10k / k32, no
+// gain from 6 % of the steps outside the rows on, 3.55 against 4.28 where the working set fits.  With more chains in
+// lock step every re-walk step has a lane outside the rows and more of them per load; not kept.)
 
 // A lane of either string sits in the escape row after the chunk: both strings' 16 bytes again, exactly (WideTrapChunk
 // for two chains; a chain that did not leave the rows is walked again as well -- it costs nothing in lock step and ends
@@ -192,117 +197,6 @@ __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, co
 	}
 	if (sa == p.wide || sb == p.wide)
 		WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u);
-}
-
-// ---- N strings per lane (wide.hip ScanWide4Kernel: four, on half-line tiles) ---------------------------------------------
-// WideTrapChunk2 / WideChunk2 for any number of chains: the lookups of a step in turn, ONE wait for all the table loads of
-// a re-walk step.
-template <bool N16, int NCH>
-__device__ __forceinline__ void WideTrapChunkN(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K,
-                                               u32x4 (&v)[NCH], const uint32_t (&st0)[NCH], uint32_t (&st)[NCH],
-                                               uint32_t (&cold)[NCH], uint32_t sampleStep)
-{
-	uint32_t id[NCH], c2[NCH];
-#pragma unroll
-	for (int c = 0; c < NCH; ++c) {
-		id[c] = st0[c] < p.wide ? st0[c] : cold[c];
-		c2[c] = HotLookup(v[c].x & 0xFFu);
-	}
-	const unsigned long long lanes = __ballot(true);
-	uint32_t nth = 0;
-	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
-		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, uint32_t(NCH));   // wave-chunks walked twice (exact)
-	const bool sampled = ((uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) / NCH) & 15u) == 0;
-#pragma unroll 1
-	for (uint32_t i = 0; i < 16; ++i) {
-		uint32_t c2n[NCH], e[NCH], nx[NCH];
-		bool any = false;
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			v[c].x = __builtin_amdgcn_alignbit(v[c].y, v[c].x, 8);
-			v[c].y = __builtin_amdgcn_alignbit(v[c].z, v[c].y, 8);
-			v[c].z = __builtin_amdgcn_alignbit(v[c].w, v[c].z, 8);
-			v[c].w >>= 8;
-			c2n[c] = HotLookup(v[c].x & 0xFFu);
-		}
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			e[c] = WideEntry(id[c] < p.wide ? id[c] : p.wide, K.pitch, c2[c]);
-			nx[c] = e[c];
-		}
-#pragma unroll
-		for (int c = 0; c < NCH; ++c)
-			any = any || e[c] == p.wide;
-		if (any) {
-#pragma unroll
-			for (int c = 0; c < NCH; ++c)
-				if (e[c] == p.wide)
-					nx[c] = WideNext<N16>(p, id[c], c2[c] >> 1);
-			if (NCH == 4)
-				asm volatile("" : "+v"(nx[0]), "+v"(nx[1]), "+v"(nx[NCH > 2 ? 2 : 0]), "+v"(nx[NCH > 3 ? 3 : 0]));   // all on their way, one wait
-			else
-				asm volatile("" : "+v"(nx[0]), "+v"(nx[NCH > 1 ? 1 : 0]));
-		}
-		uint32_t out = 0;
-		bool is = false;
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			id[c] = nx[c];
-			c2[c] = c2n[c];
-			if (id[c] >= p.wide) {
-				out = id[c];
-				is = true;
-			}
-		}
-		if (sampled && i == sampleStep) {
-			const unsigned long long m = __ballot(is);
-			if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-				atomicAdd(&p.visitCold[out], 1u);
-		}
-	}
-#pragma unroll
-	for (int c = 0; c < NCH; ++c) {
-		st[c] = id[c] < p.wide ? id[c] : p.wide;
-		cold[c] = id[c];
-	}
-}
-
-template <bool N16, int NCH>
-__device__ __forceinline__ void WideChunkN(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K,
-                                           const u32x4 (&v)[NCH], uint32_t (&st)[NCH], uint32_t (&cold)[NCH], uint32_t sampleLane)
-{
-	uint32_t st0[NCH];
-#pragma unroll
-	for (int c = 0; c < NCH; ++c)
-		st0[c] = st[c];
-#pragma unroll
-	for (int w = 0; w < 4; ++w) {
-		uint32_t cl[NCH][4];
-#pragma unroll
-		for (int c = 0; c < NCH; ++c) {
-			const uint32_t x = v[c][w];
-			cl[c][0] = HotLookup(x & 0xFFu);
-			cl[c][1] = HotLookup((x >> 8) & 0xFFu);
-			cl[c][2] = HotLookup((x >> 16) & 0xFFu);
-			cl[c][3] = HotLookup(x >> 24);
-		}
-#pragma unroll
-		for (int b = 0; b < 4; ++b)
-#pragma unroll
-			for (int c = 0; c < NCH; ++c)
-				st[c] = WideEntry(st[c], K.pitch, cl[c][b]);
-	}
-	bool trapped = false;
-#pragma unroll
-	for (int c = 0; c < NCH; ++c)
-		trapped = trapped || st[c] == p.wide;
-	if (trapped) {
-		u32x4 t[NCH];
-#pragma unroll
-		for (int c = 0; c < NCH; ++c)
-			t[c] = v[c];
-		WideTrapChunkN<N16, NCH>(p, lds, W, K, t, st0, st, cold, sampleLane & 15u);
-	}
 }
 
 // The first `count` (0..15) bytes of v through the rows: the whole chunk is walked, unrolled like WideChunk, and the

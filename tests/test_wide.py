@@ -119,7 +119,7 @@ def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     offs = np.arange(n + 1, dtype=np.uint64) * length
     oi, of = o.run(data.reshape(-1), offs, threads=4)
     d = torch.as_tensor(data, device="cuda")
-    for variant, symbol, task in ((2, "ScanWideKernel", 64), (3, "ScanWide2Kernel", 128), (4, "ScanWide4Kernel", 256)):   # 1 / 2 / 4 strings per lane
+    for variant, symbol, task in ((2, "ScanWideKernel", 64), (3, "ScanWide2Kernel", 128)):   # one / two strings per lane
         cfg.set(walk_variant=variant)
         gi, gf, cnt = dev_run_strided(torch, t, d)
         assert pb.last_kernel() in ("wide", "generic"), pb.last_kernel()   # "generic": the remainder of a task behind it
@@ -164,7 +164,7 @@ def test_wide_kernel_flags_and_resume_states(pa, torch_cuda, cfg, flags):
     d = torch.as_tensor(data, device="cuda")
     for ini in (None, init):
         oi, of = o.run(data.reshape(-1), offs, flags=flags, init_idx=ini, threads=4)
-        for variant in (2, 3, 4):
+        for variant in (2, 3):
             cfg.set(walk_variant=variant)
             gi, gf, cnt = dev_run_strided(torch, t, d, flags=flags, init=ini)
             assert (gi == oi).all() and (gf == of).all(), variant
@@ -178,8 +178,7 @@ def test_wide_kernel_with_a_ranking_that_knows_nothing(pa, torch_cuda, cfg):
     from pire_amd import binding as pb
 
     torch = torch_cuda
-    for name, corpus, variant in (("dict_1k", "k1000", 2), ("dict_10k", "k10000", 2), ("dict_1k", "k1000", 3), ("dict_10k", "k10000", 3),
-                                  ("dict_1k", "k1000", 4), ("dict_10k", "k10000", 4)):
+    for name, corpus, variant in (("dict_1k", "k1000", 2), ("dict_10k", "k10000", 2), ("dict_1k", "k1000", 3), ("dict_10k", "k10000", 3)):
         cfg.set(prior_flat=1, walk_variant=variant)
         entry = W.wide_set(name)
         blob = W.load_blob(entry["blob"])

@@ -9,5 +9,5 @@ python - <<PY
 import json
 for l in open("gpurun_out/${TAG}_wide_curve.jsonl"):
     d=json.loads(l)
-    print(d["set"], d["corpus"], d.get("GiB", ""), "visited", d["distinct_states_visited_in_sample"], "rows", d["wide_rows"], "| " + " | ".join("%s %s %.0f GB/s twice %.4f out_dense %.4f out_wide %.4f par %s" % (k, d[k]["kernel"], d[k]["GBps"], d[k].get("wave_chunk_share_walked_twice_by_the_wide_walk", -1), d[k]["measured_share_outside_dense_rows"], d[k]["measured_share_outside_wide_rows"], d[k]["parity_all_strings"]) for k in ("dense","wide","wide2","wide4","auto") if k in d))
+    print(d["set"], d["corpus"], d.get("GiB", ""), "visited", d["distinct_states_visited_in_sample"], "rows", d["wide_rows"], "| " + " | ".join("%s %s %.0f GB/s twice %.4f out_dense %.4f out_wide %.4f par %s" % (k, d[k]["kernel"], d[k]["GBps"], d[k].get("wave_chunk_share_walked_twice_by_the_wide_walk", -1), d[k]["measured_share_outside_dense_rows"], d[k]["measured_share_outside_wide_rows"], d[k]["parity_all_strings"]) for k in ("dense","wide","wide2","auto") if k in d))
 PY

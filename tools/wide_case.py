@@ -77,7 +77,7 @@ def point_records(entry, corpus, n, length, reps):
         return bool((gi == oi[None, :]).all() and (gf == of[None, :]).all())
 
     total = n * length
-    for variant, label in ((1, "dense"), (2, "wide"), (3, "wide2"), (4, "wide4"), (0, "auto")):
+    for variant, label in ((1, "dense"), (2, "wide"), (3, "wide2"), (0, "auto")):
         pb.set_config(walk_variant=variant, auto_adapt=1)
         for _ in range(4):   # the ranking learned from the batch itself, with the walk that is measured
             launch()
