@@ -39,7 +39,9 @@ enum {
 	                           /* and Scanner::Load, multi.h:575-599                                  */
 	PIRE_HIP_ENODEVICE = -3,   /* no HIP device / HIP runtime error (message has the hipError string) */
 	PIRE_HIP_ENOMEM    = -4,
-	PIRE_HIP_EUNSUPPORTED = -5
+	PIRE_HIP_EUNSUPPORTED = -5,
+	PIRE_HIP_ESELFTEST = -6    /* a kernel's first-use known-answer batch came back wrong (pire_hip_config.selftest):   */
+	                           /* this build of the library must not be used on this device; no results were written   */
 };
 
 /* run flags */
@@ -162,6 +164,17 @@ typedef struct pire_hip_config {
 	                               /* always with two strings per lane (working sets beyond them: twice the loads on their */
 	                               /* way; 0 picks between the two by the exact share of wave-chunks the walk had to walk  */
 	                               /* a second time).  Same results either way.                                            */
+	uint32_t selftest;             /* the first time a table takes one of the kernels of pire_hip_run[_strided] (dense     */
+	                               /* rows, class-indexed walk, one string per lane, stream) that kernel first scans a     */
+	                               /* known-answer batch of 256 x 512 bytes -- text that walks this table's own states --  */
+	                               /* and the library compares it with the host image's transitions (pire_hip_table_next): */
+	                               /* a mismatch returns PIRE_HIP_ESELFTEST and nothing is written.  The kernels keep text */
+	                               /* on its way in registers with hand-counted waits; this catches a build or a device    */
+	                               /* on which that goes wrong where the build-time ISA audit (pire_hip_build_info) only   */
+	                               /* argues that it cannot.  ~1-2 ms once per table and kernel, on a stream of its own    */
+	                               /* (an ON_DEVICE call blocks for that long, once); skipped while `stream` is being      */
+	                               /* captured.  0 default = on; 1 off; 2 on, with the expected answer of one string        */
+	                               /* altered (tests of the failure path)                                                  */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)

@@ -124,6 +124,7 @@ class Config(C.Structure):
         ("counting_variant", C.c_uint32),
         ("slow_stats", C.c_uint32),
         ("walk_variant", C.c_uint32),
+        ("selftest", C.c_uint32),
     ]
 
 

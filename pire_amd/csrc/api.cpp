@@ -221,6 +221,7 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->startPerm = h.permOfOrig[start];
 	p->hostPermOfOrig = h.permOfOrig.data();
 	p->hostOrigOfPerm = h.origOfPerm.data();
+	p->owner = t;
 	if (wantDist)
 		if (int rc = EnsureActDist(t, &p->distFinalPerm, &p->distFlaggedPerm))
 			return rc;
@@ -282,6 +283,7 @@ pire_hip_config SeedFromEnvironment()
 	c.counting_variant = uint32_t(EnvU64("PIRE_HIP_COUNTING_VARIANT"));
 	c.slow_stats = EnvU64("PIRE_HIP_SLOW_STATS") != 0;
 	c.walk_variant = uint32_t(EnvU64("PIRE_HIP_WALK_VARIANT"));
+	c.selftest = uint32_t(EnvU64("PIRE_HIP_SELFTEST"));
 	return c;
 }
 
@@ -320,6 +322,113 @@ int PrepareScanParams(pire_hip_table* t, ScanParams* p, uint32_t flags, TableUse
 unsigned long long* TakeWorkSlot(pire_hip_table* t, const ScanParams& p) { return NextWorkSlot(t, p); }
 namespace {
 
+// ---- first-use self-test (pire_hip_config.selftest) ---------------------------------------------------------------------
+// The kernels below keep text on its way in registers and count their own waits; the build argues from the ISA that this
+// is sound (tools/audit), this checks it where it runs: the first time a table takes one of Dispatch's kernels, that
+// kernel scans a batch whose answer the host image's transitions give (the accessor walk of pire_hip_table_next, 131 072
+// steps), on a stream and with visit counters of its own.  The text is a walk through the table's own states that
+// stays out of the dead ones where it can, so that the end state depends on every byte of the string.
+enum KernelKind : int { kKindGeneric, kKindTiled, kKindWide, kKindRagged, kKindRaggedWide, kKindStream };
+
+int SelfTest(const ScanParams& p, int kind, const char* name, uint32_t mode)
+{
+	constexpr uint32_t kStrings = 256, kLen = 512;
+	const HostTable& h = p.owner->host;
+	std::vector<uint8_t> text(size_t(kStrings) * kLen);
+	std::vector<uint32_t> want(kStrings);
+	std::vector<uint64_t> offsets(kStrings + 1);
+	uint64_t rng = 0x9E3779B97F4A7C15ull ^ (uint64_t(h.states) << 20) ^ h.letters;
+	auto next = [&](uint32_t st, uint32_t ch) { return h.next[size_t(st) * h.letters + h.cls[ch]]; };
+	const uint32_t start = p.hostOrigOfPerm[p.startPerm];
+	for (uint32_t i = 0; i < kStrings; ++i) {
+		uint32_t st = start;
+		offsets[i] = uint64_t(i) * kLen;
+		for (uint32_t j = 0; j < kLen; ++j) {
+			uint32_t ch = 0, to = st;
+			for (int attempt = 0; attempt < 4; ++attempt) {
+				rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+				// (printable text twice out of three times: what the tables here are mostly about)
+				ch = (rng >> 33) % 3 ? 32 + uint32_t(rng >> 40) % 95 : uint32_t(rng >> 40) & 255;
+				to = next(st, ch);
+				if (!(h.flags[to] & kDead))
+					break;
+			}
+			text[size_t(i) * kLen + j] = uint8_t(ch);
+			st = to;
+		}
+		if (p.flags & PIRE_HIP_RUN_END)
+			st = next(st, kEndMark);
+		want[i] = st;
+	}
+	offsets[kStrings] = uint64_t(kStrings) * kLen;
+	if (mode == 2)
+		want[kStrings / 2] ^= 1;   // tests of the failure path
+	// one block: text | offsets | end states | work counter | visit counters (dense rows, wide rows, every state)
+	const size_t offOffsets = text.size(), offOut = offOffsets + offsets.size() * 8, offWork = offOut + kStrings * 4;
+	const size_t offHot = offWork + 256, offWide = offHot + kVisitHotSlots * 4;
+	const size_t offCold = offWide + (size_t(p.wide) + 1) * 4, bytes = offCold + size_t(p.states) * 4;
+	void* block = nullptr;
+	size_t blockBytes = 0;
+	if (int rc = StagingAcquire(bytes, &block, &blockBytes))
+		return rc;
+	uint8_t* base = static_cast<uint8_t*>(block);
+	hipStream_t own = nullptr;
+	hipError_t e = hipStreamCreateWithFlags(&own, hipStreamNonBlocking);
+	std::vector<uint32_t> got(kStrings, ~0u);
+	int rc = PIRE_HIP_OK;
+	const int passes = kind == kKindWide ? 2 : 1;   // the class-indexed walk: with one and with two strings per lane
+	for (int pass = 0; pass < passes && e == hipSuccess && rc == PIRE_HIP_OK; ++pass) {
+		if ((e = hipMemsetAsync(base + offOut, 0xFF, bytes - offOut, own)) != hipSuccess ||
+		    (e = hipMemsetAsync(base + offWork, 0, bytes - offWork, own)) != hipSuccess ||
+		    (e = hipMemcpyAsync(base, text.data(), text.size(), hipMemcpyHostToDevice, own)) != hipSuccess ||
+		    (e = hipMemcpyAsync(base + offOffsets, offsets.data(), offsets.size() * 8, hipMemcpyHostToDevice, own)) != hipSuccess)
+			break;
+		std::atomic<uint64_t> launched{0};
+		ScanParams q = p;
+		q.text = base;
+		q.textEnd = text.size();
+		q.ends = nullptr;
+		q.initIdx = nullptr;
+		q.outIdx = reinterpret_cast<uint32_t*>(base + offOut);
+		q.outFinal = nullptr;
+		q.outCounts = nullptr;
+		q.flags = p.flags & (PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END);
+		q.n = kStrings;
+		q.len = kLen;
+		q.stride = kLen;
+		q.offsets = kind == kKindTiled || kind == kKindWide ? nullptr : reinterpret_cast<const uint64_t*>(base + offOffsets);
+		q.visitHot = reinterpret_cast<uint32_t*>(base + offHot);
+		q.visitWide = reinterpret_cast<uint32_t*>(base + offWide);
+		q.visitCold = reinterpret_cast<uint32_t*>(base + offCold);
+		q.trapSignal = nullptr;
+		q.wideLaunched = &launched;
+		q.wideTwiceShare = pass ? 1.0f : 0.0f;
+		unsigned long long* work = reinterpret_cast<unsigned long long*>(base + offWork);
+		rc = kind == kKindWide ? LaunchWide(q, own) : kind == kKindTiled ? LaunchTiled(q, own)
+		     : kind == kKindRaggedWide ? LaunchRaggedWide(q, work, own) : kind == kKindStream ? LaunchStream(q, own)
+		     : kind == kKindRagged ? LaunchRagged(q, work, own) : LaunchGeneric(q, own);
+		if (rc != PIRE_HIP_OK)
+			break;
+		if ((e = hipMemcpyAsync(got.data(), base + offOut, kStrings * 4, hipMemcpyDeviceToHost, own)) != hipSuccess ||
+		    (e = hipStreamSynchronize(own)) != hipSuccess)
+			break;
+		for (uint32_t i = 0; i < kStrings; ++i)
+			if (got[i] != want[i]) {
+				SetError(std::string("self-test of the ") + name + " kernel failed: string " + std::to_string(i) + " of the known-answer batch ended in state " +
+				         std::to_string(got[i]) + ", the table's transitions give " + std::to_string(want[i]) +
+				         " -- this build of libpire_hip.so (" + pire_hip_build_info() + ") must not be used on this device");
+				rc = PIRE_HIP_ESELFTEST;
+				break;
+			}
+	}
+	if (own)
+		(void)hipStreamDestroy(own);
+	StagingRelease(block, blockBytes);
+	if (rc == PIRE_HIP_OK && e != hipSuccess)
+		rc = HipFail(e, "self-test");
+	return rc;
+}
+
 int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCounter = nullptr,
              uint64_t totalBytesHint = 0)
 {
@@ -338,7 +447,19 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 	const bool wide = tiled && p.len >= 256 && wideTable;
 	const bool raggedWide = ragged && wideTable;
 	const bool streamed = ragged && !raggedWide && StreamEligible(p, totalBytesHint);
-	NoteKernel(wide ? "wide" : tiled ? "tiled" : raggedWide ? "ragged_wide" : streamed ? "stream" : ragged ? "ragged" : "generic");
+	const int kind = wide ? kKindWide : tiled ? kKindTiled : raggedWide ? kKindRaggedWide : streamed ? kKindStream : ragged ? kKindRagged : kKindGeneric;
+	static const char* const kNames[] = {"generic", "tiled", "wide", "ragged", "ragged_wide", "stream"};
+	if (p.owner && !(p.owner->selfTested[p.workDevice].load(std::memory_order_relaxed) & (1u << kind))) {
+		const uint32_t mode = GetConfig().selftest;
+		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+		if (mode != 1 && !(p.flags & (1u << 23)) &&   // (bit 23: device_common.h kPermIds, the segmented scan's internal passes)
+		     (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing == hipStreamCaptureStatusNone)) {
+			if (int rc = SelfTest(p, kind, kNames[kind], mode))
+				return rc;
+			p.owner->selfTested[p.workDevice].fetch_or(1u << kind);
+		}
+	}
+	NoteKernel(kNames[kind]);
 	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : raggedWide ? LaunchRaggedWide(p, workCounter, stream)
 	         : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {

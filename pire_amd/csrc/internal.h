@@ -318,6 +318,8 @@ struct pire_hip_table {
 	std::shared_mutex adaptMutex;
 	std::atomic<uint32_t> autoAdapts{0};
 	std::atomic<uint64_t> wideLaunched{0};   // wave-chunks handed to the wide walk since the last adapt()
+	std::atomic<uint32_t> selfTested[pirehip::kMaxDevices] = {};   // per device, bit k: Dispatch's kernel kind k passed its known-answer
+	                                                               // batch on this table there (api.cpp SelfTest)
 };
 namespace pirehip { constexpr uint32_t kMaxAutoAdapts = 6; }
 
@@ -386,6 +388,7 @@ struct ScanParams {
 	// scans, mode representatives) goes through these.
 	const uint32_t* hostPermOfOrig;
 	const uint32_t* hostOrigOfPerm;
+	pire_hip_table* owner;          // the table itself (the first-use self-test walks its host image)
 	const uint8_t* distFinalPerm;
 	const uint8_t* distFlaggedPerm;
 #ifdef PIRE_HIP_TUNING

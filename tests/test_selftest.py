@@ -1,0 +1,107 @@
+"""The first-use self-test of the kernels behind pire_hip_run / pire_hip_run_strided (pire_hip_config.selftest, api.cpp SelfTest):
+the first time a table takes one of them, that kernel scans a known-answer batch -- a walk through the table's own states --
+and the library compares it with the host image's transitions; a mismatch returns PIRE_HIP_ESELFTEST and writes nothing.
+
+The failure path is reached by altering the expected answer (selftest = 2); the library's own kernels pass (selftest = 0,
+the default: every other GPU test of this suite runs with it)."""
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from pire_amd import workloads as W
+from tests.test_gpu_parity import dev_run_strided, pa, torch_cuda  # noqa: F401  (fixtures)
+from tests.test_wide import dev_run_offsets
+
+ESELFTEST = -6
+
+
+def _strided(torch, t, data):
+    return dev_run_strided(torch, t, torch.as_tensor(data, device="cuda"))
+
+
+def _blob(name):
+    from tests import helpers as H
+
+    return H.load_blob([b for b in H.big_sets() if b["name"] == name][0]["blob"])
+
+
+KINDS = [
+    # kernel, config, scanner, batch: ("strided", strings, length) | ("offsets", strings)
+    ("tiled", dict(), "set_a", ("strided", 256, 1024)),
+    ("wide", dict(walk_variant=2), "dict_1k", ("strided", 256, 1024)),
+    ("ragged", dict(ragged_variant=1), "set_a", ("offsets", 3000)),
+    ("stream", dict(ragged_variant=2), "set_a", ("offsets", 3000)),
+    ("ragged_wide", dict(walk_variant=2), "dict_1k", ("offsets", 3000)),
+    ("generic", dict(), "set_a", ("strided", 8, 100)),
+]
+
+
+def _scanner(name):
+    if name.startswith("dict"):
+        return W.load_blob(W.wide_set(name)["blob"])
+    return _blob(name)
+
+
+def _batch(kind, seed):
+    rng = np.random.RandomState(seed)
+    if kind[0] == "strided":
+        return rng.randint(32, 127, size=(kind[1], kind[2])).astype(np.uint8), None
+    lens = rng.randint(0, 200, size=kind[1])
+    offs = np.zeros(kind[1] + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    return rng.randint(32, 127, size=int(offs[-1])).astype(np.uint8), offs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel,config,scanner,kind", KINDS, ids=[k[0] for k in KINDS])
+def test_first_use_runs_the_known_answer_batch_and_a_wrong_answer_refuses_the_call(pa, torch_cuda, cfg, kernel, config, scanner, kind):
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    blob = _scanner(scanner)
+    o = ob.OracleScanner(blob)
+    data, offs = _batch(kind, 11)
+
+    def call(t):
+        if offs is None:
+            gi, gf, _ = _strided(torch, t, data)
+            oi, of = o.run(data.reshape(-1), np.arange(data.shape[0] + 1, dtype=np.uint64) * data.shape[1], threads=2)
+        else:
+            gi, gf, _ = dev_run_offsets(torch, t, data, offs)
+            oi, of = o.run(data, offs, threads=2)
+        return (gi == oi).all() and (gf == of).all()
+
+    # 1. the expected answer altered: the call is refused, with the kernel's name in the message -- and keeps being refused
+    cfg.set(selftest=2, **config)
+    t = pa.Table(blob)
+    for _ in range(2):
+        with pytest.raises(pb.PireHipError) as err:
+            call(t)
+        assert err.value.code == ESELFTEST
+        assert f"self-test of the {kernel} kernel failed" in str(err.value), str(err.value)
+        assert pb.build_info().split(";")[0] in str(err.value)
+    # 2. the same table with the real expectation: passes once, results as the oracle's
+    cfg.set(selftest=0, **config)
+    assert call(t)
+    assert pb.last_kernel() == kernel
+    # 3. ... and is not asked again: with the fault switched back on the table's kernel stays trusted
+    cfg.set(selftest=2, **config)
+    assert call(t)
+    # 4. switched off, a fresh table is never tested
+    cfg.set(selftest=1, **config)
+    assert call(pa.Table(blob))
+
+
+@pytest.mark.gpu
+def test_self_test_leaves_the_visit_counters_alone(pa, torch_cuda, cfg):
+    """The batch walks states the caller's text may never see: its samples must not reach the ranking."""
+    torch = torch_cuda
+    t = pa.Table(_blob("set_b"))                  # thousands of states: the self-test's text leaves the dense rows
+    data, _ = _batch(("strided", 64, 256), 3)
+    data[:] = ord("a")
+    _strided(torch, t, data)                      # first use: self-test + a scan that stays in very few states
+    t.adapt()
+    info = t.info()
+    assert info.adaptations == 1
+    # the scan above is 64 x 256 steps: less than one sampling period of the self-test's 131 072 would have left
+    assert info.last_trap_samples == 0
