@@ -781,23 +781,30 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 
 	PIRE_RCLK(clk, 2);
 	// ---- walk the current window
-	if ((threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + (WIDE ? W.histOff : L.histOff)) + S.hs, 1u);
+	if (!WIDE && (threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
 	if (p.flags & kDebugNoStep) {
 		// timing experiments: no walk at all
 	} else if (__any(nb != 0)) {
 		if (__any(nb != 0 && S.loaded)) {
 			const uint32_t nbl = S.loaded ? nb : 0u;
 			const uint32_t full = nbl >> 4, tail = nbl & 15u;
+			// (the wide walk samples INSIDE the window, behind one of its chunks: a URL is one window, in front of it every lane
+			// is in the start state and behind it mostly in the dead one -- the samples said "nothing outside the rows" of
+			// batches that had 1.5 % of their steps there)
+			const uint32_t sampleHash = iter * 0x9E3779B1u;
+			const bool sampleLaneHere = WIDE && (threadIdx.x & 63) == (sampleHash >> 26) && !(p.flags & kDebugNoHist);
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) < full) {
 					if constexpr (Act::kActive)
 						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 						             S.pos + 16u * k);
-					else if constexpr (WIDE != 0)
+					else if constexpr (WIDE != 0) {
 						WideChunk<WIDE == 2>(p, lds, W, K, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
-					else
+						if (sampleLaneHere && uint32_t(k) == ((sampleHash >> 20) & 7u))
+							atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + S.hs, 1u);
+					} else
 						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 				}
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {

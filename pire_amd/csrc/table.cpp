@@ -1194,6 +1194,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	// what every device that ever ran this table saw, summed
 	std::vector<uint64_t> hot(256, 0), cold(N, 0), wide(h.wide + 1, 0);
 	uint64_t wideTrapChunks = 0;   // wave-chunks the wide walk walked twice since the last adapt() (exact)
+	uint64_t wideOutsideSamples = 0;   // of the wide walk's visit samples (one lane per wave and tile): lanes found outside the rows
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
@@ -1223,6 +1224,8 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 			if (t->devs[k].visitWide)
 				for (uint32_t i = 0; i < h.wide; ++i)
 					wide[i] += bufWide[i];
+			if (t->devs[k].visitWide)
+				wideOutsideSamples += bufWide[h.wide];
 		}
 		(void)hipSetDevice(cur);
 		if (!any)
@@ -1258,10 +1261,21 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 			h.wideTwiceShare = float(std::min(1.0, double(wideTrapChunks) / double(launched)));
 	}
 	h.massMeasured = true;
+	// The share of the steps outside the wide rows, as the scans since the last adapt() SAW it: of the wide walk's visit
+	// samples (one lane per wave and tile, whatever state it is in) those that found their lane outside the rows.  What
+	// the masses below give instead is the share the new ranking would leave outside -- of the states that were sampled:
+	// on long-tailed tables most states outside the rows never are, and the figure is an order of magnitude too low.
+	double wideSamples = double(wideOutsideSamples);
+	for (uint32_t i = 0; i < h.wide && i < wide.size(); ++i)
+		wideSamples += double(wide[i]);
+	const bool wideSeen = wideSamples >= 4096.0;
+	const float wideSeenOutside = wideSeen ? float(double(wideOutsideSamples) / wideSamples) : 0.0f;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());
 	if (coldSamples == 0) {
 		MeasureShares(h, score);   // same numbering, measured masses
+		if (wideSeen)
+			h.outsideWide = wideSeenOutside;
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
 		(void)hipGetDevice(&cur);
@@ -1279,6 +1293,8 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		return PIRE_HIP_OK;   // nothing trapped: the current rows already cover the traffic
 	}
 	PermuteByScore(h, score);
+	if (wideSeen)
+		h.outsideWide = wideSeenOutside;
 	std::vector<uint32_t> after(h.origOfPerm.begin(), h.origOfPerm.begin() + h.hot);
 	std::sort(after.begin(), after.end());
 	std::vector<uint32_t> diff;

@@ -72,7 +72,10 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 	WideIssueTile(refill, voff, ahead, istride);
 	WideWaitTile<1>(cur);
 	TransposeTile(cur, lane);
-	if (lane == (t & 63))   // visit sample: one lane per wave per tile, rotating (the escape row counts into slot `wide`)
+	// visit sample: one lane per wave per tile (the escape row counts into slot `wide`).  WHICH lane: a hash of the wave's
+	// tile count -- `t & 63` sampled lane l at tile l of its string and nowhere else, and a batch that repeats a base of a
+	// few thousand records (every benchmark here) was then seen at 2 048 places, over and over
+	if (lane == (myTiles * 0x9E3779B1u) >> 26)
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
@@ -181,6 +184,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 	ZeroTile(b);
 	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
 	uint32_t myTiles = 0;
+	uint32_t direct = 0;   // wave-uniform: the last chunk left the rows, the next ones skip the attempt on the rows alone (WideChunk2)
 	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
 	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
 	LoadWideToLds(p, lds, W);
@@ -212,13 +216,13 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 			WideWaitTile<0>(b);
 			TransposeTile(a, lane);
 			TransposeTile(b, lane);
-			if (lane == (t & 63)) {   // visit samples: one lane per wave per tile, rotating
+			if (lane == (myTiles * 0x9E3779B1u) >> 26) {   // visit samples: one lane per wave per tile (WidePhase)
 				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sa, 1u);
 				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sb, 1u);
 			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				WideChunk2<N16>(p, lds, W, K, a[k], b[k], sa, sb, colda, coldb, (t * 8 + k) & 63);
+				WideChunk2<N16>(p, lds, W, K, a[k], b[k], sa, sb, colda, coldb, (t * 8 + k) & 63, direct);
 			if (t & 1)   // wave-wide early out (multi.h:955-958), every other tile
 				done = __all(((WideEntry(sa, K.pitch, K.flagsOff) & WideEntry(sb, K.pitch, K.flagsOff)) & kAbsorbing) != 0);
 		}
@@ -267,12 +271,19 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
-	// Two forms (same results): one string per lane and a ring of two tiles -- 4.2-4.3 TB/s while the working set fits the
-	// rows --, or two strings per lane (ScanWide2Kernel) once most wave-chunks are walked twice: the loads of the re-walk
-	// are then what the time goes into, and two chains per lane have two of them on their way.  By the exact share of
-	// wave-chunks the scans since the last adapt() walked twice; walk_variant 2 / 3 force one.
+	// Two forms (same results): one string per lane and a ring of two tiles, or two strings per lane (ScanWide2Kernel).
+	// The second is never slower where both were measured with a batch that fills the chip (profiles/
+	// r05k_wide_curve.jsonl: 4.24 against 4.22 TB/s where the working set fits the rows, 4.34 against 3.26 on set_b_mix,
+	// 1.70 against 1.05 with 5 % of the steps outside the rows) bar the heaviest corpora (0.71 against 0.80 with 19 %), so it takes
+	// every batch that gives all 16 waves of every CU a task of 128 strings -- and smaller ones once most wave-chunks leave
+	// the rows (the exact share since the last adapt()): the loads of the re-walk are then what the time goes into, and
+	// two chains per lane have two of them on their way.  walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
-	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.wideTwiceShare > 0.3f);
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const bool heavy = p.massMeasured && p.outsideWide > 0.16f;   // (13 % of the steps outside the rows: 1.05 against 0.98 TB/s; 19 %: 0.71 against 0.80)
+	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && !heavy && (p.wideTwiceShare > 0.3f || p.n >= uint64_t(cus) * 16 * 128));
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
 	if (p.wideLaunched)

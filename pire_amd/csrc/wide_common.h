@@ -28,6 +28,19 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 	return p.nextPerm[size_t(st) * p.letters + cls];
 }
 
+// ... with the byte's doubled class as the caller has it (cls8 holds 2 * class).  The u16 table's entry is a 32-bit byte
+// offset from a wave-uniform base (65 536 states x 127 letters x 2 bytes < 2^24): one v_mad_u32_u24 and a load that adds
+// the base itself, instead of 64-bit address arithmetic in every step of the re-walk.
+template <bool N16>
+__device__ __forceinline__ uint32_t WideNextC2(const ScanParams& p, uint32_t st, uint32_t c2)
+{
+	if (N16) {
+		const uint32_t off = __umul24(st, p.letters * 2u) + c2;
+		return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(p.next16) + off);
+	}
+	return p.nextPerm[size_t(st) * p.letters + (c2 >> 1)];
+}
+
 // A lane sits in the escape row after the 16 bytes `v`: walk them again from the state it was in before them, exactly,
 // device ids all the way: the row's entry in LDS, and ONE load from the table in memory in the steps in which that entry
 // says "no row" -- for a lane that leaves the rows with this step and for one that is outside them already alike (the
@@ -40,8 +53,10 @@ __device__ __forceinline__ uint32_t WideNext(const ScanParams& p, uint32_t st, u
 // re-walk at all, every step asking whether a lane is outside the rows, 644 GB/s here and 2.4 instead of 4.25 TB/s where
 // the working set fits (a third form of the kernel, removed again); rows for the lanes that have one, the table for the
 // others and -- in an arm of its own -- for those that leave with this step: 651 GB/s (two round trips in a row).
-// What pire_hip_table_adapt() ranks the states beyond the rows by: every 16th re-walk leaves, at one rotating step, the
-// state of the first lane that is outside the rows.  (The first form sampled one fixed lane of 64 at the chunk's end,
+// What pire_hip_table_adapt() ranks the states beyond the rows by: every 64th re-walk leaves, at one rotating step, the
+// state of the first lane that is outside the rows, counted once per lane that is outside them in that step -- 64 chunks x
+// 16 steps per sample and lane: the 1 024 lane-steps a sample of the dense walk's trap path stands for (table.cpp
+// AdaptTable), so that the measured share of the steps outside the rows is a share.  (The first form sampled one fixed lane of 64 at the chunk's end,
 // like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
 // rows were there for 1 530 visited states 36 % of all wave-chunks were walked twice, profiles/r05_pmc_wide_first.txt.)
 template <bool N16>
@@ -50,34 +65,38 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 {
 	uint32_t sid = st0 < p.wide ? st0 : cold;   // the device id of the state the chunk started in
 	uint32_t c2 = HotLookup(v.x & 0xFFu);       // 2 * letter class
-	// one wave-chunk more that is walked twice (exact count, block-local); every 16th of them leaves a sample
+	// one wave-chunk more that is walked twice (exact count, block-local); every 64th of them leaves a sample
 	const unsigned long long lanes = __ballot(true);
 	uint32_t nth = 0;
 	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
 		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
-	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 15u) == 0;
+	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 63u) == 0;
+	// (a dword per trip, its four steps unrolled, the bytes as bit fields: see WideTrapChunk2)
 #pragma unroll 1
-	for (uint32_t i = 0; i < 16; ++i) {
-		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
-		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
-		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
-		v.w >>= 8;
-		const uint32_t c2n = HotLookup(v.x & 0xFFu);   // the next byte's (behind the 16th: of a zero, unused)
-		// the row's entry (a state without a row reads the escape row: "no row") ...
-		const uint32_t e = WideEntry(sid < p.wide ? sid : p.wide, K.pitch, c2);
-		uint32_t next = e;
-		if (e == p.wide) {   // ... and, for the lanes it sends outside the rows or that are there already, the table in memory
-			next = WideNext<N16>(p, sid, c2 >> 1);
-			asm volatile("" : "+v"(next));   // (the wait belongs in here: left to the join it is a vmcnt(0) every lane passes)
+	for (uint32_t w = 0; w < 4; ++w) {
+		const uint32_t x = v.x;
+		v.x = v.y;
+		v.y = v.z;
+		v.z = v.w;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			const uint32_t c2n = HotLookup(k < 3 ? (x >> (8 * k + 8)) & 0xFFu : v.x & 0xFFu);   // the next byte's (behind the 16th: unused)
+			// the row's entry (a state without a row reads the escape row: "no row") ...
+			const uint32_t e = WideEntry(sid < p.wide ? sid : p.wide, K.pitch, c2);
+			uint32_t next = e;
+			if (e == p.wide) {   // ... and, for the lanes it sends outside the rows or that are there already, the table in memory
+				next = WideNextC2<N16>(p, sid, c2);
+				asm volatile("" : "+v"(next));   // (the wait belongs in here: left to the join it is a vmcnt(0) every lane passes)
+			}
+			sid = next;
+			if (sampled && w * 4 + k == sampleStep) {
+				const bool out = sid >= p.wide;
+				const unsigned long long m = __ballot(out);
+				if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+					atomicAdd(&p.visitCold[sid], uint32_t(__popcll(m)));   // (see above: the step's lanes outside the rows)
+			}
+			c2 = c2n;
 		}
-		sid = next;
-		if (sampled && i == sampleStep) {
-			const bool out = sid >= p.wide;
-			const unsigned long long m = __ballot(out);
-			if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-				atomicAdd(&p.visitCold[sid], 1u);
-		}
-		c2 = c2n;
 	}
 	st = sid < p.wide ? sid : p.wide;
 	cold = sid;
@@ -121,64 +140,93 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 // A lane of either string sits in the escape row after the chunk: both strings' 16 bytes again, exactly (WideTrapChunk
 // for two chains; a chain that did not leave the rows is walked again as well -- it costs nothing in lock step and ends
 // where it ended).  One round trip to the table per step serves both chains.
+// `direct` (wave-uniform, != 0: the wave's count of such chunks): the wave did not try the rows alone first -- its last chunk
+// left them --, all lanes are here and this IS the walk of the chunk; the return value says whether a lane left the rows
+// in it (else: whether to come here directly next time, i.e. yes).
 template <bool N16>
-__device__ __forceinline__ void WideTrapChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 va,
-                                               u32x4 vb, uint32_t sa0, uint32_t sb0, uint32_t& sa, uint32_t& sb, uint32_t& colda,
-                                               uint32_t& coldb, uint32_t sampleStep)
+__device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 va,
+                                                   u32x4 vb, uint32_t sa0, uint32_t sb0, uint32_t& sa, uint32_t& sb, uint32_t& colda,
+                                                   uint32_t& coldb, uint32_t sampleStep, uint32_t direct)
 {
 	uint32_t ia = sa0 < p.wide ? sa0 : colda, ib = sb0 < p.wide ? sb0 : coldb;
 	uint32_t c2a = HotLookup(va.x & 0xFFu), c2b = HotLookup(vb.x & 0xFFu);
 	const unsigned long long lanes = __ballot(true);
-	uint32_t nth = 0;
-	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
-		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 2u);   // wave-chunks walked twice (exact): two here
-	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 30u) == 0;
+	uint32_t nth = direct << 1;
+	if (!direct) {
+		if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
+			nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 2u);   // wave-chunks walked twice (exact): two here
+		nth = uint32_t(__builtin_amdgcn_readfirstlane(int(nth)));
+	}
+	const bool sampled = (nth & 126u) == 0;
+	bool left = false;
+	// (a dword of each string per trip, its four steps unrolled: the bytes are bit fields of one register -- shifting the
+	// 16 bytes down by one in every step was 10 of the step's ~35 vector instructions, and four waves share a SIMD)
 #pragma unroll 1
-	for (uint32_t i = 0; i < 16; ++i) {
-		va.x = __builtin_amdgcn_alignbit(va.y, va.x, 8);
-		va.y = __builtin_amdgcn_alignbit(va.z, va.y, 8);
-		va.z = __builtin_amdgcn_alignbit(va.w, va.z, 8);
-		va.w >>= 8;
-		vb.x = __builtin_amdgcn_alignbit(vb.y, vb.x, 8);
-		vb.y = __builtin_amdgcn_alignbit(vb.z, vb.y, 8);
-		vb.z = __builtin_amdgcn_alignbit(vb.w, vb.z, 8);
-		vb.w >>= 8;
-		const uint32_t c2an = HotLookup(va.x & 0xFFu), c2bn = HotLookup(vb.x & 0xFFu);
-		const uint32_t ea = WideEntry(ia < p.wide ? ia : p.wide, K.pitch, c2a);
-		const uint32_t eb = WideEntry(ib < p.wide ? ib : p.wide, K.pitch, c2b);
-		uint32_t na = ea, nb = eb;
-		if (ea == p.wide || eb == p.wide) {
-			if (ea == p.wide)
-				na = WideNext<N16>(p, ia, c2a >> 1);
-			if (eb == p.wide)
-				nb = WideNext<N16>(p, ib, c2b >> 1);
-			asm volatile("" : "+v"(na), "+v"(nb));   // both loads on their way, ONE wait, inside this arm
+	for (uint32_t w = 0; w < 4; ++w) {
+		const uint32_t xa = va.x, xb = vb.x;
+		va.x = va.y;
+		va.y = va.z;
+		va.z = va.w;
+		vb.x = vb.y;
+		vb.y = vb.z;
+		vb.z = vb.w;
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k) {
+			// (behind the chunk's last byte: whatever the register holds -- any byte value is a valid address of cls8)
+			const uint32_t bna = k < 3 ? (xa >> (8 * k + 8)) & 0xFFu : va.x & 0xFFu;
+			const uint32_t bnb = k < 3 ? (xb >> (8 * k + 8)) & 0xFFu : vb.x & 0xFFu;
+			const uint32_t c2an = HotLookup(bna), c2bn = HotLookup(bnb);
+			const uint32_t ea = WideEntry(ia < p.wide ? ia : p.wide, K.pitch, c2a);
+			const uint32_t eb = WideEntry(ib < p.wide ? ib : p.wide, K.pitch, c2b);
+			uint32_t na = ea, nb = eb;
+			if (ea == p.wide || eb == p.wide) {
+				if (ea == p.wide)
+					na = WideNextC2<N16>(p, ia, c2a);
+				if (eb == p.wide)
+					nb = WideNextC2<N16>(p, ib, c2b);
+				asm volatile("" : "+v"(na), "+v"(nb));   // both loads on their way, ONE wait, inside this arm
+				left = true;
+			}
+			ia = na;
+			ib = nb;
+			if (sampled && w * 4 + k == sampleStep) {
+				const uint32_t out = ia >= p.wide ? ia : ib;
+				const bool is = ia >= p.wide || ib >= p.wide;
+				const unsigned long long m = __ballot(is);
+				const uint32_t weight = uint32_t(__popcll(__ballot(ia >= p.wide)) + __popcll(__ballot(ib >= p.wide)));
+				if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+					atomicAdd(&p.visitCold[out], weight);
+			}
+			c2a = c2an;
+			c2b = c2bn;
 		}
-		ia = na;
-		ib = nb;
-		if (sampled && i == sampleStep) {
-			const uint32_t out = ia >= p.wide ? ia : ib;
-			const bool is = ia >= p.wide || ib >= p.wide;
-			const unsigned long long m = __ballot(is);
-			if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-				atomicAdd(&p.visitCold[out], 1u);
-		}
-		c2a = c2an;
-		c2b = c2bn;
 	}
 	sa = ia < p.wide ? ia : p.wide;
 	colda = ia;
 	sb = ib < p.wide ? ib : p.wide;
 	coldb = ib;
+	if (!direct)
+		return 1u;
+	const unsigned long long out = __ballot(left);
+	if (out && (threadIdx.x & 63) == 0)
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 2u);   // (would have been walked twice)
+	return uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(out) | uint32_t(out >> 32)))) ? direct + 1u : 0u;
 }
 
 // 16 bytes of each of the lane's two strings through the rows, the two chains' lookups in turn.
+// `direct` (wave-uniform, kept by the caller from chunk to chunk): once a chunk left the rows the wave's next chunks skip
+// the attempt on the rows alone -- with 1.7 % of the steps outside them EVERY wave-chunk has such a lane, and the first
+// pass is a quarter of the time for nothing -- until a chunk stays inside them.
 template <bool N16>
 __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 va,
                                            const u32x4 vb, uint32_t& sa, uint32_t& sb, uint32_t& colda, uint32_t& coldb,
-                                           uint32_t sampleLane)
+                                           uint32_t sampleLane, uint32_t& direct)
 {
 	const uint32_t sa0 = sa, sb0 = sb;
+	if (direct) {
+		direct = WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, direct);
+		return;
+	}
 #pragma unroll
 	for (int w = 0; w < 4; ++w) {
 		const uint32_t xa = va[w], xb = vb[w];
@@ -195,8 +243,11 @@ __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, co
 		sa = WideEntry(sa, K.pitch, a3);
 		sb = WideEntry(sb, K.pitch, b3);
 	}
-	if (sa == p.wide || sb == p.wide)
-		WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u);
+	const bool trapped = sa == p.wide || sb == p.wide;
+	if (trapped)
+		WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, 0u);
+	const unsigned long long any = __ballot(trapped);
+	direct = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(any) | uint32_t(any >> 32)))) ? 1u : 0u;
 }
 
 // The first `count` (0..15) bytes of v through the rows: the whole chunk is walked, unrolled like WideChunk, and the
@@ -261,7 +312,7 @@ __device__ inline void FlushWide(const ScanParams& p, uint8_t* lds, const WideLa
 	__syncthreads();
 	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + W.histOff);
 	const uint32_t* prog = reinterpret_cast<const uint32_t*>(lds + W.progOff);
-	for (uint32_t i = threadIdx.x; i < p.wide; i += blockDim.x)
+	for (uint32_t i = threadIdx.x; i <= p.wide; i += blockDim.x)   // (slot `wide`: samples that found their lane outside the rows)
 		if (hist[i])
 			atomicAdd(&p.visitWide[i], hist[i]);
 	if (threadIdx.x == 0 && prog[1]) {
