@@ -135,7 +135,10 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 // transposes inside the quads, every line read from HBM twice -- was built and measured, profiles/
 // r05j_wide_curve_four_chains.jsonl: 1.42 against 1.29 TB/s on dict_1k / k512, 1.40 against 1.30 on dict_10k / k32, no
 // gain from 6 % of the steps outside the rows on, 3.55 against 4.28 where the working set fits.  With more chains in
-// lock step every re-walk step has a lane outside the rows and more of them per load; not kept.)
+// lock step every re-walk step has a lane outside the rows and more of them per load; not kept.  Once more with the re-walk
+// loop of today -- a third of the instructions, waves that skip the attempt on the rows --, r05l_wide_curve_four_chains_lean_loop.jsonl:
+// 1.86 against 1.82 on k512, 1.09 against 1.17 on k1000, 1.66 against 1.70 on dict_10k / k32: what bounds the walk beyond the
+// rows now is the rate of its scattered table loads, ~0.26 per clock and CU whatever the number of chains.)
 
 // A lane of either string sits in the escape row after the chunk: both strings' 16 bytes again, exactly (WideTrapChunk
 // for two chains; a chain that did not leave the rows is walked again as well -- it costs nothing in lock step and ends
