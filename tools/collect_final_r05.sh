@@ -16,6 +16,7 @@ for f in c1_nonreloc c2 c5a c5b set_d c4_shard cxx_records cxx_one_string 2ranks
 cp $S/wide_curve.jsonl $P/r05_wide_curve.jsonl
 cp $S/wide_pmc_fit.txt $P/r05_wide_pmc_dict_1k_k128.txt
 cp $S/wide_pmc_cold.txt $P/r05_wide_pmc_dict_10k_k10000.txt
+cp $S/wide_pmc_light.txt $P/r05_wide_pmc_dict_1k_k512.txt
 cp $S/stats_wide/stats_kernel_stats.csv $P/r05_wide_kernel_stats.csv
 cp $S/trace_timed_region_wide.txt $P/r05_wide_trace_timed_region.txt
 cp $S/micro_lds.log $P/r05_micro_lds.log

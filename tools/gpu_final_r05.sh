@@ -71,14 +71,16 @@ for f in sorted(glob.glob("gpurun_out/final_r05/bench_dict*.json")+glob.glob("gp
 PY
 timeout 900 python tools/wide_case.py --log2-strings 20 --out $OUT/wide_curve.jsonl > $OUT/wide_curve.log 2>&1; echo "wide_case rc=$?"
 i=0
-for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE"; do
+for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" "SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE" \
+           "TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/wpmc_fit/p$i -o pmc -- python bench.py --set dict_1k --corpus k128 --steps 5 --warmup 1 --settle 10 --no-cpu --cold-launches 0 > $OUT/wpmc_fit_$i.log 2>&1 || echo "wide pmc fit pass $i failed"
+  timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/wpmc_light/p$i -o pmc -- python bench.py --set dict_1k --corpus k512 --steps 5 --warmup 1 --settle 10 --no-cpu --cold-launches 0 > $OUT/wpmc_light_$i.log 2>&1 || echo "wide pmc light pass $i failed"
   timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/wpmc_cold/p$i -o pmc -- python bench.py --set dict_10k --corpus k10000 --steps 5 --warmup 1 --settle 10 --no-cpu --cold-launches 0 > $OUT/wpmc_cold_$i.log 2>&1 || echo "wide pmc cold pass $i failed"
 done
-for w in fit cold; do python tools/summarize_pmc.py $OUT/wpmc_$w --last 5 > $OUT/wide_pmc_$w.txt 2>&1; done; grep -A16 ScanWide $OUT/wide_pmc_fit.txt | head -18
+for w in fit light cold; do python tools/summarize_pmc.py $OUT/wpmc_$w --last 5 > $OUT/wide_pmc_$w.txt 2>&1; done; grep -A16 ScanWide $OUT/wide_pmc_fit.txt | head -18
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_wide -o stats -- python bench.py --set dict_1k --corpus k128 --steps 20 --warmup 5 --no-cpu --cold-launches 0 > $OUT/stats_wide.log 2>&1
-python tools/summarize_trace.py $OUT/stats_wide 20 ScanWideKernel | tee $OUT/trace_timed_region_wide.txt
+python tools/summarize_trace.py $OUT/stats_wide 20 ScanWide | tee $OUT/trace_timed_region_wide.txt
 for st in set_d set_a c2_single; do timeout 300 python tools/micro_lds.py $st --waves 16 --steps 1024 --reps 300 --out $OUT 2>&1 | grep -v amdgpu.ids; done > $OUT/micro_lds.log 2>&1; rm -f $OUT/micro_trace.bin $OUT/micro_rows.bin; grep "indep. u8\|chain u8\|^set" $OUT/micro_lds.log | cut -c1-150
 echo "== offset batches: ragged kernel (variant 1) against the default routing (stream kernel), same box"
 for c in urls loglines uniform2k uniform8k fixed4096 urls_x4 loglines_x4 uniform2k_x4; do
