@@ -138,7 +138,10 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 // lock step every re-walk step has a lane outside the rows and more of them per load; not kept.  Once more with the re-walk
 // loop of today -- a third of the instructions, waves that skip the attempt on the rows --, r05l_wide_curve_four_chains_lean_loop.jsonl:
 // 1.86 against 1.82 on k512, 1.09 against 1.17 on k1000, 1.66 against 1.70 on dict_10k / k32: what bounds the walk beyond the
-// rows now is the rate of its scattered table loads, ~0.26 per clock and CU whatever the number of chains.)
+// rows now is the rate of its scattered table loads, ~0.26 per clock and CU whatever the number of chains.  The address unit is
+// busy 81 % of the kernel there (r05_wide_pmc_dict_1k_k512.txt: 16.5 busy cycles per load instruction); ONE load instruction per step
+// for the lanes that need an entry of either chain, a second only for lanes that need both, halves the instructions and changes
+// nothing: 1.77 against 1.82 TB/s -- busy waiting for the L2, not issuing.)
 
 // A lane of either string sits in the escape row after the chunk: both strings' 16 bytes again, exactly (WideTrapChunk
 // for two chains; a chain that did not leave the rows is walked again as well -- it costs nothing in lock step and ends
