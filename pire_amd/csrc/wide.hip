@@ -282,7 +282,7 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	const bool heavy = p.massMeasured && p.outsideWide > 0.16f;   // (13 % of the steps outside the rows: 1.05 against 0.98 TB/s; 19 %: 0.71 against 0.80)
+	const bool heavy = p.massMeasured && p.outsideWide > 0.145f;   // (measured share 11.7 %: 1.16 against 1.00 TB/s; 16.9 %: 0.79 against 0.81; 30 %: 0.56 against 0.57)
 	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && !heavy && (p.wideTwiceShare > 0.3f || p.n >= uint64_t(cus) * 16 * 128));
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
