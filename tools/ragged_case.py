@@ -12,7 +12,8 @@ CASES = {  # name: (lo, hi, log2 strings, multiplier)
     "loglines": (64, 1024, 20, 1), "fixed4096": (32, 33, 18, 128), "uniform2k": (0, 2048, 20, 1),
     # the same shapes at four times the size (3.4 GiB of text): how much of the small batches' time is their tail
     # smaller batches of the same shapes: where the stream kernel's fixed part (search, table, first line) stops paying
-    "urls_16k": (20, 200, 14, 1), "urls_64k": (20, 200, 16, 1), "urls_256k": (20, 200, 18, 1), "loglines_64k": (64, 1024, 16, 1),
+    "urls_16k": (20, 200, 14, 1), "urls_64k": (20, 200, 16, 1), "urls_256k": (20, 200, 18, 1), "urls_1m": (20, 200, 20, 1),
+    "loglines_16k": (64, 1024, 14, 1), "loglines_64k": (64, 1024, 16, 1), "loglines_256k": (64, 1024, 18, 1),
     "urls_x4": (20, 200, 24, 1), "loglines_x4": (64, 1024, 22, 1), "uniform2k_x4": (0, 2048, 22, 1),
 }
 case = sys.argv[1]
