@@ -231,6 +231,32 @@ def test_wide_walk_is_chosen_once_the_scans_are_seen_leaving_the_dense_rows(pa, 
         ta.adapt()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [2, 3])
+def test_measured_share_outside_the_wide_rows_is_what_the_oracle_counts(pa, torch_cuda, cfg, variant):
+    """pire_hip_table_info.outside_wide_share after adapt(): of the wide walk's visit samples (one lane per wave and tile,
+    chosen by a hash of the wave's tile count) those that found their lane outside the rows.  Against the oracle's visit
+    counts of the same batch under the best possible ranking: the first sampler took lane l at tile l of its string and
+    nowhere else, and the share the library reported for a batch like this one was a twentieth of the truth."""
+    torch = torch_cuda
+    cfg.set(walk_variant=variant)
+    entry = W.wide_set("dict_10k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    n, length = 65536, 1024
+    data = records_of(entry, "k2048", 9, n, length)
+    d = torch.as_tensor(data, device="cuda")
+    for _ in range(4):                      # the ranking settles (the estimates are remembered from adapt() to adapt())
+        dev_run_strided(torch, t, d)
+        t.adapt()
+    info = t.refresh_info()
+    v = np.sort(o.visit_counts(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length))[::-1].astype(np.float64)
+    ideal = 1.0 - v[:info.wide_states].sum() / v.sum()
+    assert ideal > 0.1, ideal                # a third of the steps of this corpus have no row whatever the ranking
+    assert info.shares_measured
+    assert 0.8 * ideal <= info.outside_wide_share <= 1.4 * ideal, (ideal, info.outside_wide_share)
+
+
 # ---- offset batches of wide tables: the ragged kernel on the class-indexed walk ------------------------------------------
 
 
