@@ -213,14 +213,19 @@ typedef struct pire_hip_table_info {
 	uint32_t wide_states;     /* states with a class-indexed row in the wide walk's LDS image (0: table fits the dense rows) */
 	uint32_t wide_lds_bytes;  /* LDS bytes of that image per workgroup */
 	float outside_dense_share;   /* share of the ranking's mass (scans seen by adapt(), else the a-priori byte model) on   */
-	float outside_wide_share;    /* states without a dense row / without a wide row                                        */
+	                             /* states without a dense row                                                             */
+	float outside_wide_share;    /* ... without a row of the class-indexed walk.  Once that walk has run: the share of the */
+	                             /* steps of the scans between the two most recent adapt() calls that it SAW outside its    */
+	                             /* rows (of its visit samples, one lane per wave and 128-byte tile, those that found their */
+	                             /* lane there) -- not a share of the ranking's mass, which only knows states some sample   */
+	                             /* hit                                                                                     */
 	uint32_t shares_measured;    /* 1: those shares come from visit counters                                               */
 	uint32_t reserved2;
 	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
 	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
 	                                /* (exact, all devices)                                                                 */
-	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time: above 0.3 it     */
-	                                /* walks two strings per lane                                                           */
+	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time (a wave that skips */
+	                                /* the attempt on the rows alone counts the chunks in which a lane left them)           */
 	uint32_t reserved3;
 } pire_hip_table_info;
 
