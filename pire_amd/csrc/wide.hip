@@ -72,14 +72,15 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 	WideIssueTile(refill, voff, ahead, istride);
 	WideWaitTile<1>(cur);
 	TransposeTile(cur, lane);
-	// visit sample: one lane per wave per tile (the escape row counts into slot `wide`).  WHICH lane: a hash of the wave's
-	// tile count -- `t & 63` sampled lane l at tile l of its string and nowhere else, and a batch that repeats a base of a
-	// few thousand records (every benchmark here) was then seen at 2 048 places, over and over
-	if (lane == (myTiles * 0x9E3779B1u) >> 26)
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
 		WideChunk<N16>(p, lds, W, K, cur[k], st, cold, (t * 8 + k) & 63);
+	// visit sample: one lane per wave per tile (the escape row counts into slot `wide`), the state BEHIND the tile -- in
+	// front of a record's first tile every lane is in the start state, an eighth of the samples of 1 KiB records.  WHICH
+	// lane: a hash of the wave's tile count -- `t & 63` sampled lane l at tile l of its string and nowhere else, and a batch
+	// that repeats a base of a few thousand records (every benchmark here) was then seen at 2 048 places, over and over
+	if (lane == (myTiles * 0x9E3779B1u) >> 26)
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
 }
 
 // Fixed-length records, 16-byte aligned, at least two 128-byte tiles per record (+ a tail shorter than a tile), whole tasks
@@ -216,13 +217,13 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 			WideWaitTile<0>(b);
 			TransposeTile(a, lane);
 			TransposeTile(b, lane);
-			if (lane == (myTiles * 0x9E3779B1u) >> 26) {   // visit samples: one lane per wave per tile (WidePhase)
-				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sa, 1u);
-				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sb, 1u);
-			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				WideChunk2<N16>(p, lds, W, K, a[k], b[k], sa, sb, colda, coldb, (t * 8 + k) & 63, direct);
+			if (lane == (myTiles * 0x9E3779B1u) >> 26) {   // visit samples: one lane per wave per tile, behind it (WidePhase)
+				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sa, 1u);
+				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sb, 1u);
+			}
 			if (t & 1)   // wave-wide early out (multi.h:955-958), every other tile
 				done = __all(((WideEntry(sa, K.pitch, K.flagsOff) & WideEntry(sb, K.pitch, K.flagsOff)) & kAbsorbing) != 0);
 		}
