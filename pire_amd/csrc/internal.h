@@ -111,7 +111,7 @@ inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps
 // m_letters[ch], state = row[letter]).  A row is
 //     u16 next[letters]   device id of the target state; `wide` (the escape row's id) for targets without a row
 //     u16 flags           kFinal | kDead | kAbsorbing of the state
-// padded to an odd number of dwords; row `wide`, the escape row, leads to itself.  cls8 (2 * letter class of every byte
+// + 2 bytes where that makes a multiple of 8 (WidePitch); row `wide`, the escape row, leads to itself.  cls8 (2 * letter class of every byte
 // value) sits at LDS address 0, so that the byte IS the address of its class.  Behind the rows: one u32 visit counter
 // per row (what pire_hip_table_adapt() ranks from).
 struct WideLayout {
@@ -124,12 +124,15 @@ struct WideLayout {
 	uint32_t total;
 };
 
-// (an ODD number of dwords per row: rows then start in every LDS bank in turn -- with 18 dwords, 34 letters, the lanes of a
-// wave that read the same letter's entry of different rows would share 16 of the 32 banks)
+// (a number of HALFWORDS per row that is not a multiple of four -- an odd number of dwords, or of halfwords: rows then start
+// in every LDS bank in turn, in the second case at either half of its dword -- with 18
+// dwords, 34 letters, the lanes of a wave that read the same letter's entry of different rows would share 16 of the 32
+// banks.  Round 5 first padded to an odd number of DWORDS, 76 bytes for 34 letters; 70 do the same for the banks and
+// leave room for 8 % more rows.)
 __host__ __device__ inline uint32_t WidePitch(uint32_t letters)
 {
-	const uint32_t dwords = ((letters + 1) * 2 + 3) / 4;
-	return (dwords | 1u) * 4;
+	const uint32_t halfwords = letters + 1;   // the row's entries + its flags
+	return (halfwords % 4 ? halfwords : halfwords + 1) * 2;
 }
 
 __host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t letters, uint32_t regexps)

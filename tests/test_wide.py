@@ -75,7 +75,7 @@ def test_wide_image_walks_like_the_reference(name, corpus):
     info = t.info
     assert info.wide_states > info.hot_states and info.wide_lds_bytes <= 160 * 1024
     rows, wide, pitch, off = t.wide_layout()
-    assert wide == info.wide_states and rows.shape == (wide + 1, pitch // 2) and pitch % 4 == 0 and off == 256
+    assert wide == info.wide_states and rows.shape == (wide + 1, pitch // 2) and pitch % 8 != 0 and off == 256   # (rows start in every bank in turn)
     assert (rows[wide, :info.letters] == wide).all() and (rows[:, :info.letters] <= wide).all()   # the escape row is absorbing
     k = min(24, len(offs) - 1)
     strings = [bytes(text[int(offs[i]):int(offs[i + 1])])[:300] for i in range(k)]
