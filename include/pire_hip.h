@@ -160,10 +160,11 @@ typedef struct pire_hip_config {
 	                               /* reference's two-lookup step, multi.h:169-192) once the share of the scans' steps     */
 	                               /* outside the 255 dense rows passes 0.05 % (measured by adapt(); 5 % of the a-priori   */
 	                               /* estimate before), else the dense rows; 1 always the dense rows; 2 always the         */
-	                               /* class-indexed walk with one string per lane (working sets that fit its rows), 3      */
-	                               /* always with two strings per lane (working sets beyond them: twice the loads on their */
-	                               /* way; 0 picks between the two by the exact share of wave-chunks the walk had to walk  */
-	                               /* a second time).  Same results either way.                                            */
+	                               /* class-indexed walk with one string per lane, 3 always with two strings per lane      */
+	                               /* (twice the table loads on their way beyond the rows, half the waves); 0 takes two    */
+	                               /* for batches that give every wave slot of the chip a task of 128 strings (2^19 on    */
+	                               /* 256 CUs) unless more than 14.5 % of the steps were seen outside the rows.  Same      */
+	                               /* results either way.                                                                  */
 	uint32_t selftest;             /* the first time a table takes one of the kernels of pire_hip_run[_strided] (dense     */
 	                               /* rows, class-indexed walk, one string per lane, stream) that kernel first scans a     */
 	                               /* known-answer batch of 256 x 512 bytes -- text that walks this table's own states --  */

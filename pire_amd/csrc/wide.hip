@@ -273,18 +273,20 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
 	// Two forms (same results): one string per lane and a ring of two tiles, or two strings per lane (ScanWide2Kernel).
-	// The second is never slower where both were measured with a batch that fills the chip (profiles/
-	// r05k_wide_curve.jsonl: 4.24 against 4.22 TB/s where the working set fits the rows, 4.34 against 3.26 on set_b_mix,
-	// 1.70 against 1.05 with 5 % of the steps outside the rows) bar the heaviest corpora (0.71 against 0.80 with 19 %), so it takes
-	// every batch that gives all 16 waves of every CU a task of 128 strings -- and smaller ones once most wave-chunks leave
-	// the rows (the exact share since the last adapt()): the loads of the re-walk are then what the time goes into, and
-	// two chains per lane have two of them on their way.  walk_variant 2 / 3 force one.
+	// A wave of the second walks its two strings in the time a wave of the first walks one and one more (per wave the
+	// lookups of a step do not overlap much: 2.1 against 4.1 TB/s with 2^18 strings, half the waves), so it is for batches
+	// that give all 16 waves of every CU a task of 128 strings: there it is never slower where both were measured (profiles/
+	// r05_wide_curve.jsonl, r05m_wide_small_batches.txt: 4.25 against 4.23 TB/s where the working set fits the rows, 4.39
+	// against 3.56 on set_b_mix, 1.84 against 1.09 with 3 % of the steps outside the rows -- the loads of the walk beyond
+	// the rows are what the time goes into there, and two chains per lane have two of them on their way) bar the heaviest
+	// corpora (0.85 against 0.87 with 17 %).  Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside
+	// the rows: 1.09 against 0.92).  walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	const bool heavy = p.massMeasured && p.outsideWide > 0.145f;   // (measured share 11.7 %: 1.16 against 1.00 TB/s; 16.9 %: 0.79 against 0.81; 30 %: 0.56 against 0.57)
-	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && !heavy && (p.wideTwiceShare > 0.3f || p.n >= uint64_t(cus) * 16 * 128));
+	const bool heavy = p.massMeasured && p.outsideWide > 0.145f;
+	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && !heavy && p.n >= uint64_t(cus) * 16 * 128);
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
 	if (p.wideLaunched)
