@@ -111,8 +111,10 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	ZeroTile(b);
 	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
 	uint32_t myTiles = 0;
+	// tasks go round the blocks before they go round a block's waves: a batch with fewer tasks than wave slots then puts a few
+	// waves on every CU instead of sixteen on some (2^18 strings, two per lane: 2.1 TB/s on half the CUs)
 	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
-	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+	const uint64_t firstTask = uint64_t(wave) * gridDim.x + blockIdx.x;
 	bool primed = firstTask < ntasks;
 	if (primed)   // the first tile is on its way while the table is copied
 		WideIssueTile(a, voff, Uniform64(reinterpret_cast<uint64_t>(p.text) + firstTask * 64 * p.stride), istride);
@@ -186,8 +188,10 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 	uint32_t* prog = reinterpret_cast<uint32_t*>(lds + W.progOff);
 	uint32_t myTiles = 0;
 	uint32_t direct = 0;   // wave-uniform: the last chunk left the rows, the next ones skip the attempt on the rows alone (WideChunk2)
+	// tasks go round the blocks before they go round a block's waves: a batch with fewer tasks than wave slots then puts a few
+	// waves on every CU instead of sixteen on some (2^18 strings, two per lane: 2.1 TB/s on half the CUs)
 	const uint64_t taskStep = uint64_t(gridDim.x) * 16;
-	const uint64_t firstTask = uint64_t(blockIdx.x) * 16 + wave;
+	const uint64_t firstTask = uint64_t(wave) * gridDim.x + blockIdx.x;
 	LoadWideToLds(p, lds, W);
 	for (uint64_t task = firstTask; task < ntasks; task += taskStep) {
 		const uint64_t sA = task * 128 + lane, sB = sA + 64;
@@ -273,14 +277,14 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
 	int rc;
 	// Two forms (same results): one string per lane and a ring of two tiles, or two strings per lane (ScanWide2Kernel).
-	// A wave of the second walks its two strings in the time a wave of the first walks one and one more (per wave the
-	// lookups of a step do not overlap much: 2.1 against 4.1 TB/s with 2^18 strings, half the waves), so it is for batches
+	// A wave of the second walks its two strings in the time a wave of the first walks one and one more (3.6 against 4.0
+	// TB/s with 2^18 strings, half the waves), so it is for batches
 	// that give all 16 waves of every CU a task of 128 strings: there it is never slower where both were measured (profiles/
 	// r05_wide_curve.jsonl, r05m_wide_small_batches.txt: 4.25 against 4.23 TB/s where the working set fits the rows, 4.39
 	// against 3.56 on set_b_mix, 1.84 against 1.09 with 3 % of the steps outside the rows -- the loads of the walk beyond
 	// the rows are what the time goes into there, and two chains per lane have two of them on their way) bar the heaviest
 	// corpora (0.85 against 0.87 with 17 %).  Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside
-	// the rows: 1.09 against 0.92).  walk_variant 2 / 3 force one.
+	// the rows: 1.09 against 1.05).  walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
@@ -295,10 +299,10 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 		rc = PIRE_HIP_OK;
 	} else if (p.next16) {
 		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u16 table>" : "pirehip::ScanWideKernel<u16 table>");
-		rc = two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream);
+		rc = two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream, 1);
 	} else {
 		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u32 table>" : "pirehip::ScanWideKernel<u32 table>");
-		rc = two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream);
+		rc = two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream, 1);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;
