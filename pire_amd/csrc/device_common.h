@@ -48,11 +48,13 @@ constexpr uint32_t kDebugNoPartial = 1u << 26;
 constexpr uint32_t kDebugNoFinish = 1u << 25;
 constexpr uint32_t kDebugNoTrap = 1u << 24;
 constexpr uint32_t kDebugNoTranspose = 1u << 22;
-constexpr uint32_t kDebugTaskMap = 1u << 21;   // wave-major task numbering (a CU's waves on far-apart tasks)
 #else
 constexpr uint32_t kDebugNoRefill = 0, kDebugNoStep = 0, kDebugNoColdCount = 0, kDebugNoHist = 0, kDebugNoPartial = 0,
-                   kDebugNoFinish = 0, kDebugNoTrap = 0, kDebugNoTranspose = 0, kDebugTaskMap = 0;
+                   kDebugNoFinish = 0, kDebugNoTrap = 0, kDebugNoTranspose = 0;
 #endif
+// internal (tiled.hip): tasks go round the blocks before they go round a block's waves -- set by the launcher for batches with
+// fewer tasks than wave slots, which then put a few waves on every CU instead of sixteen on some
+constexpr uint32_t kSpreadTasks = 1u << 21;
 constexpr uint32_t kPermIds = 1u << 23;   // internal (segmented.hip): initIdx holds, outIdx receives, DEVICE state ids
 
 // Block-wide copy of `count16` 16-byte units from global memory to LDS with up to BATCH loads per thread in flight

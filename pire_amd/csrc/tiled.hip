@@ -216,8 +216,8 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void ScanTiledKernel(ScanParams p
 	// With an even tile count every task starts in slot a, so the ring can run straight through task boundaries.
 	const bool chain = rem == 0;
 	const uint64_t taskStep = uint64_t(gridDim.x) * WAVES;
-	const uint64_t firstTask = (p.flags & kDebugTaskMap) ? uint64_t(wave) * gridDim.x + blockIdx.x   // measurement knob
-	                                                      : uint64_t(blockIdx.x) * WAVES + wave;
+	const uint64_t firstTask = (p.flags & kSpreadTasks) ? uint64_t(wave) * gridDim.x + blockIdx.x   // (device_common.h)
+	                                                     : uint64_t(blockIdx.x) * WAVES + wave;
 	// The first tile of the wave's first task is requested BEFORE the table is copied into LDS: its HBM latency (a
 	// few microseconds when all 4 096 waves of a launch ask at once) then hides behind the copy.
 	bool primed = firstTask < ntasks;   // slot a already holds (or is receiving) tile 0 of the task about to start
@@ -467,6 +467,13 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	if (variant == 24)
 		variant = 0;
 	ScanParams q = p;
+	// a batch with fewer tasks than wave slots: a few waves on every CU instead of sixteen on some (kSpreadTasks)
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const int tpb = (p.n + 63) / 64 < uint64_t(cus) * 16 ? 1 : 0;
+	if (tpb)
+		q.flags |= kSpreadTasks;
 #ifdef PIRE_HIP_TUNING
 	q.stamps = nullptr;
 	if (getenv("PIRE_HIP_DEBUG_NOLOAD"))
@@ -482,7 +489,7 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	if (getenv("PIRE_HIP_DEBUG_NOTRAP"))
 		q.flags |= kDebugNoTrap;
 	if (getenv("PIRE_HIP_DEBUG_TASKMAP"))
-		q.flags |= kDebugTaskMap;
+		q.flags |= kSpreadTasks;
 	static unsigned long long* stampBuf = nullptr;
 	const bool stamping = getenv("PIRE_HIP_DEBUG_STAMPS") != nullptr;
 	if (stamping) {
@@ -504,28 +511,28 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 	switch (variant) {
 	case 1:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,rot>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 1>, q, 1024, L.total, stream);   // bank-rotated rows
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 1>, q, 1024, L.total, stream, tpb);   // bank-rotated rows
 		break;
 	case 2:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,plain,5>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream);   // no nt
+		rc = LaunchScan(ScanTiledKernel<16, 2, false, 5, 0>, q, 1024, L256.total, stream, tpb);   // no nt
 		break;
 	case 20:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,free-running>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream);   // waves not kept in step
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0>, q, 1024, L256.total, stream, tpb);   // waves not kept in step
 		break;
 	case 4:   // also chosen by PIRE_HIP_CHECKED=1
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,checked>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream);
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, true>, q, 1024, L256.total, stream, tpb);
 		break;
 	case 23:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5,rotated columns>");
 		q.hotRows = p.hotRowsRot ? p.hotRowsRot : p.hotRows;
 		if (!p.hotRowsRot) {
-			rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream);
+			rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream, tpb);
 			break;
 		}
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 2, false, true>, q, 1024, L256.total, stream);
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 2, false, true>, q, 1024, L256.total, stream, tpb);
 		break;
 	case 22:
 		// The transpose of tile t+1 in the shadows of the last 24 lookups of tile t (PhaseShadow).  Measured in round 3
@@ -533,11 +540,11 @@ int LaunchTiled(const ScanParams& p, hipStream_t stream)
 		// ~25 launches after an idle gap), -0.8 % at settled clocks, where the kernel sits 1.5 % above its load path
 		// and the earlier deadline for the refill (6.5 / 8 of a tile-time) costs more than the hidden VALU saves.
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,4,shadow>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 4, 0, false, true, true>, q, 1024, L256.total, stream);
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 4, 0, false, true, true>, q, 1024, L256.total, stream, tpb);
 		break;
 	default:
 		NoteKernel("tiled", "pirehip::ScanTiledKernel<16,2,nt,5>");
-		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream);
+		rc = LaunchScan(ScanTiledKernel<16, 2, true, 5, 0, false, true>, q, 1024, L256.total, stream, tpb);
 		break;
 	}
 #ifdef PIRE_HIP_TUNING
