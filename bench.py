@@ -416,13 +416,19 @@ def main():
     assert last - first == n
     base_text = None
     wide_base = None
+    wide_order = None
     if wide_entry:
         # `nbase` distinct records of the token corpus (built on the host, numpy), repeated over the batch on the device:
-        # record i of rank r = base[(first + i) % nbase]
+        # record i of rank r = base[(first + i + 1237 * (i // nbase)) % nbase]
         nbase = min(n, 16384)
         assert n % nbase == 0
         wide_base = W.wide_records(wide_entry, args.corpus, SEED, nbase, length)
-        text = torch.as_tensor(np.roll(wide_base, -(first % nbase), axis=0), device=dev).repeat(n // nbase, 1).contiguous()
+        # ... every repeat rotated by its own number of records (not a multiple of 64): a plain repeat has a period of
+        # nbase / 64 = 256 tasks -- the number of CUs --, and a kernel that hands task b + 256 w to wave w of block b then
+        # walks the SAME 64 records in all 16 waves of a CU, whose table loads hit each other's lines in the L1
+        # (dict_10k / k10000: 1.04 instead of 0.54 TB/s; found when the wide kernels' task order changed)
+        wide_order = ((np.arange(n, dtype=np.int64) % nbase) + (np.arange(n, dtype=np.int64) // nbase) * 1237 + first) % nbase
+        text = torch.as_tensor(wide_base, device=dev).index_select(0, torch.as_tensor(wide_order, device=dev)).contiguous()
     elif args.corpus == "cxx":
         # the reference's benchmark text repeated over the whole (global) batch; this rank's shard starts at byte first*length
         base_text = cxx_corpus_bytes()
@@ -708,8 +714,7 @@ def main():
                 host = wide_base[:sample]
                 # every string of the batch: the repeats of a base record must all have ended where the first one did
                 nb = wide_base.shape[0]
-                res["parity_of_repeats"] = bool((gpu_idx.reshape(-1, nb) == gpu_idx[:nb][None, :]).all() and
-                                                (gpu_fin.reshape(-1, nb) == gpu_fin[:nb][None, :]).all())
+                res["parity_of_repeats"] = bool((gpu_idx == gpu_idx[:nb][(wide_order - first) % nb]).all() and (gpu_fin == gpu_fin[:nb][(wide_order - first) % nb]).all())
             elif args.corpus == "cxx":
                 f = len(base_text)
                 host = np.resize(base_text, sample * length + f)[:sample * length].reshape(sample, length)

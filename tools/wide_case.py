@@ -57,7 +57,11 @@ def point_records(entry, corpus, n, length, reps):
     base = W.wide_records(entry, corpus, 0x5EED5EED, nbase, length)
     offs = np.arange(nbase + 1, dtype=np.uint64) * length
     oi, of = o.run(base.reshape(-1), offs, threads=8)
-    text = torch.as_tensor(base, device="cuda").repeat(n // nbase, 1).contiguous()
+    # (every repeat of the base rotated by its own number of records: a plain repeat has a period of 64 tasks, and a kernel
+    # whose block b hands task b + 256 w to its wave w then walks the same 64 records in all waves of a CU -- their table
+    # loads hit each other's lines in the L1)
+    order = ((np.arange(n, dtype=np.int64) % nbase) + (np.arange(n, dtype=np.int64) // nbase) * 1237) % nbase
+    text = torch.as_tensor(base, device="cuda").index_select(0, torch.as_tensor(order, device="cuda")).contiguous()
     idx = torch.empty(n, dtype=torch.int32, device="cuda")
     fin = torch.empty(n, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
@@ -72,9 +76,9 @@ def point_records(entry, corpus, n, length, reps):
         t.run_strided_device(text.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
 
     def parity():
-        gi = idx.cpu().numpy().astype(np.uint32).reshape(n // nbase, nbase)
-        gf = fin.cpu().numpy().reshape(n // nbase, nbase)
-        return bool((gi == oi[None, :]).all() and (gf == of[None, :]).all())
+        gi = idx.cpu().numpy().astype(np.uint32)
+        gf = fin.cpu().numpy()
+        return bool((gi == oi[order]).all() and (gf == of[order]).all())
 
     total = n * length
     for variant, label in ((1, "dense"), (2, "wide"), (3, "wide2"), (0, "auto")):
