@@ -103,6 +103,10 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 }
 
 // 16 bytes through the rows in LDS; lanes that leave them are re-walked exactly.
+// (WideChunk2's `direct` mode was tried here too, same box, same process: + 12 % where 3 % of the steps are outside the rows,
+// - 4 % where 30 % are -- which is where this form of the kernel runs when the batch fills the chip -- and the ranking the
+// next adapt() took from its samples cost the two-strings form 8 % on dict_10k / k512; with "two chunks in a row before a
+// wave stops trying the rows" on top: the same.  Not kept.)
 template <bool N16>
 __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
                                           uint32_t& st, uint32_t& cold, uint32_t sampleLane)
