@@ -103,6 +103,8 @@ struct CountingParams {
 	uint32_t* overflow;        // [0] = count, [1 ..] = strings too long for 16-bit counters: the 32-bit kernel takes them
 	const uint32_t* order;     // nullable: string k of the launch is order[k] (order.hip: by length class)
 	uint32_t serpentine;       // walk the order forwards and backwards in turn (the global order)
+	uint32_t spreadWaves;      // row kernels: a wave's 64 strings of the order go to the next BLOCK, not to the block's next wave (batches
+	                           // with fewer strings than the chip has lanes: a few waves on every CU instead of sixteen on some)
 	// CapturingScanner run
 	const uint8_t* tags;
 	uint8_t* outFinal;
@@ -460,7 +462,9 @@ __global__ __launch_bounds__(1024) void CountingRowKernel(CountingParams p)
 	const uint64_t maxLen = p.maxLen ? p.maxLen : 65000u;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
+		// (spreadWaves: four waves share a SIMD, and this kernel is bound by its issue -- 2^17 strings 788 instead of 514 GB/s)
+		const uint64_t k = OrderedIndex(pass, p.spreadWaves ? (uint64_t(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64 + lane : uint64_t(blockIdx.x) * blockDim.x + threadIdx.x,
+		                               uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		uint64_t b = 0, e = 0;
 		if (k < p.n) {
 			const uint64_t s = p.order ? p.order[k] : k;
@@ -970,7 +974,8 @@ __global__ __launch_bounds__(1024) void CaptureRowKernel(CountingParams p)
 	const uint32_t beginStep = (p.flags & PIRE_HIP_RUN_BEGIN) ? 1u : 0u;
 	for (uint64_t pass = 0; pass * gridDim.x * blockDim.x < p.n; ++pass) {
 		// (no lane leaves the pass early: the loads and the transpose below are the whole wave's)
-		const uint64_t k = OrderedIndex(pass, uint64_t(blockIdx.x) * blockDim.x + threadIdx.x, uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
+		const uint64_t k = OrderedIndex(pass, p.spreadWaves ? (uint64_t(threadIdx.x >> 6) * gridDim.x + blockIdx.x) * 64 + lane : uint64_t(blockIdx.x) * blockDim.x + threadIdx.x,   // (CountingRowKernel)
+		                                uint64_t(gridDim.x) * blockDim.x, p.serpentine != 0);
 		uint64_t b = 0, e = 0;
 		if (k < p.n) {
 			const uint64_t s = p.order ? p.order[k] : k;
@@ -1505,7 +1510,8 @@ int LaunchCounting(CountingParams p, int kind, hipStream_t stream, uint32_t nreg
 		const bool adv = kind == PIRE_HIP_COUNTING_ADVANCED;
 		// entries that are LDS addresses (CountingRowKernel) where the table leaves room for them and the batch fills the
 		// GPU; pire_hip_config.counting_variant: 1 = never, 2 = whenever the table fits
-		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((p.n + 1023) / 1024, uint64_t(cus))));
+		p.spreadWaves = p.n <= uint64_t(cus) * 1024 ? 1u : 0u;   // (one pass: the lengths of the order spread over the CUs as well)
+		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(p.spreadWaves ? (p.n + 63) / 64 : (p.n + 1023) / 1024, uint64_t(cus))));
 		if (byteRows) {
 			const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * kCountingRowPitch + 15) & ~size_t(15)) + 256 * 2 * nreg * 4);
 			switch (nreg) {
@@ -1781,7 +1787,8 @@ int LaunchHalfFinalRows(pire_hip_table* t, const uint8_t* text, const uint64_t* 
 	if (e == hipSuccess) {
 		p.overflow = static_cast<uint32_t*>(list);
 		const uint32_t rowLds = uint32_t(((size_t(p.states + 1) * (p.letters + 1) * 8 + 15) & ~size_t(15)) + size_t(lactCount) * 2 * nreg * 4 + 512);
-		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 1023) / 1024, uint64_t(cus))));
+		p.spreadWaves = n <= uint64_t(cus) * 1024 ? 1u : 0u;
+		const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(p.spreadWaves ? (n + 63) / 64 : (n + 1023) / 1024, uint64_t(cus))));
 		switch (nreg) {
 		case 1: LaunchRow<1, true>(p, 2, rblocks, rowLds, stream, &e); break;
 		case 2: LaunchRow<2, true>(p, 2, rblocks, rowLds, stream, &e); break;
@@ -2168,7 +2175,8 @@ try {
 			if (le != hipSuccess)
 				return HipFail(le, "hipFuncSetAttribute(LDS)");
 			NoteKernel("capture_rows");
-			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>((n + 1023) / 1024, uint64_t(cus))));
+			p.spreadWaves = n <= uint64_t(cus) * 1024 ? 1u : 0u;
+			const unsigned rblocks = unsigned(std::max<uint64_t>(1, std::min<uint64_t>(p.spreadWaves ? (n + 63) / 64 : (n + 1023) / 1024, uint64_t(cus))));
 			hipLaunchKernelGGL(CaptureRowKernel, dim3(rblocks), dim3(1024), rowLds, stream, p);
 		} else if (p.dense && !(flags & PIRE_HIP_RUN_GENERIC)) {
 			const uint32_t denseLds = p.states * 512;

@@ -9,7 +9,7 @@ from pire_amd import binding as pb
 from tests import helpers as H
 
 stream = torch.cuda.current_stream().cuda_stream
-m = 1 << 20
+m = 1 << int(__import__("os").environ.get("CAPTURE_LOG2_STRINGS", "20"))
 rng = np.random.RandomState(3)
 lens = rng.randint(64, 1024, size=m).astype(np.uint64)
 offs = np.zeros(m + 1, dtype=np.uint64)

@@ -17,7 +17,7 @@ case = [c for c in H.golden()["half_final"] if c["name"] == name][0]
 blob = H.load_blob(case["blob"])
 t = pire_amd.Table(blob)
 t.upload()
-m, lo, hi = 1 << 20, 64, 1024
+m, lo, hi = 1 << int(__import__("os").environ.get("HALF_FINAL_LOG2_STRINGS", "20")), 64, 1024
 rng = np.random.RandomState(3)
 lens = rng.randint(lo, hi, size=m).astype(np.uint64)
 offs = np.zeros(m + 1, dtype=np.uint64)
