@@ -279,12 +279,12 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	// Two forms (same results): one string per lane and a ring of two tiles, or two strings per lane (ScanWide2Kernel).
 	// A wave of the second walks its two strings in the time a wave of the first walks one and one more (3.6 against 4.0
 	// TB/s with 2^18 strings, half the waves), so it is for batches
-	// that give all 16 waves of every CU a task of 128 strings: there it is never slower where both were measured (profiles/
-	// r05_wide_curve.jsonl, r05m_wide_small_batches.txt: 4.25 against 4.23 TB/s where the working set fits the rows, 4.39
-	// against 3.56 on set_b_mix, 1.84 against 1.09 with 3 % of the steps outside the rows -- the loads of the walk beyond
-	// the rows are what the time goes into there, and two chains per lane have two of them on their way) bar the heaviest
-	// corpora (0.85 against 0.87 with 17 %).  Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside
-	// the rows: 1.09 against 1.05).  walk_variant 2 / 3 force one.
+	// that give all 16 waves of every CU a task of 128 strings: there it is as fast where the working set fits the rows
+	// (profiles/r05_wide_curve.jsonl: 4.29 against 4.27 TB/s) and faster beyond them -- 1.89 against 1.11 with 3 % of the
+	// steps outside the rows, 1.36 against 1.04 with 12 %: the loads of the walk beyond the rows are what the time goes into
+	// there, and two chains per lane have two of them on their way -- bar the heaviest corpora (0.63 against 0.65 with 29 %).
+	// Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside the rows: 1.09 against 1.05,
+	// r05m_wide_small_batches.txt).  walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
