@@ -427,7 +427,7 @@ def main():
         # nbase / 64 = 256 tasks -- the number of CUs --, and a kernel that hands task b + 256 w to wave w of block b then
         # walks the SAME 64 records in all 16 waves of a CU, whose table loads hit each other's lines in the L1
         # (dict_10k / k10000: 1.04 instead of 0.54 TB/s; found when the wide kernels' task order changed)
-        wide_order = ((np.arange(n, dtype=np.int64) % nbase) + (np.arange(n, dtype=np.int64) // nbase) * 1237 + first) % nbase
+        wide_order = W.rotated_repeat_order(n, nbase, first)
         text = torch.as_tensor(wide_base, device=dev).index_select(0, torch.as_tensor(wide_order, device=dev)).contiguous()
     elif args.corpus == "cxx":
         # the reference's benchmark text repeated over the whole (global) batch; this rank's shard starts at byte first*length

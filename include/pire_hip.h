@@ -163,8 +163,7 @@ typedef struct pire_hip_config {
 	                               /* class-indexed walk with one string per lane, 3 always with two strings per lane      */
 	                               /* (twice the table loads on their way beyond the rows, half the waves); 0 takes two    */
 	                               /* for batches that give every wave slot of the chip a task of 128 strings (2^19 on    */
-	                               /* 256 CUs) unless more than 14.5 % of the steps were seen outside the rows.  Same      */
-	                               /* results either way.                                                                  */
+	                               /* 256 CUs).  Same results either way.                                                  */
 	uint32_t selftest;             /* the first time a table takes one of the kernels of pire_hip_run[_strided] (dense     */
 	                               /* rows, class-indexed walk, one string per lane, stream) that kernel first scans a     */
 	                               /* known-answer batch of 256 x 512 bytes -- text that walks this table's own states --  */

@@ -282,15 +282,14 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	// that give all 16 waves of every CU a task of 128 strings: there it is as fast where the working set fits the rows
 	// (profiles/r05_wide_curve.jsonl: 4.29 against 4.27 TB/s) and faster beyond them -- 1.89 against 1.11 with 3 % of the
 	// steps outside the rows, 1.36 against 1.04 with 12 %: the loads of the walk beyond the rows are what the time goes into
-	// there, and two chains per lane have two of them on their way -- bar the heaviest corpora (0.63 against 0.65 with 29 %).
+	// there, and two chains per lane have two of them on their way; 1.09 against 0.97 with 17 %, the same (0.60-0.65) from 29 % on.
 	// Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside the rows: 1.09 against 1.05,
 	// r05m_wide_small_batches.txt).  walk_variant 2 / 3 force one.
 	const pire_hip_config cfg = GetConfig();
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	const bool heavy = p.massMeasured && p.outsideWide > 0.145f;
-	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && !heavy && p.n >= uint64_t(cus) * 16 * 128);
+	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.n >= uint64_t(cus) * 16 * 128);
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
 	if (p.wideLaunched)

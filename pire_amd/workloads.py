@@ -195,6 +195,21 @@ def wide_records(entry: dict, corpus: str, seed: int, n: int, length: int):
     return token_stream(seed, toks, wts, n * length).reshape(n, length)
 
 
+def rotated_repeat_order(n: int, nbase: int, first: int = 0):
+    """Record index (into a base of `nbase` distinct records) of every string of a batch of `n` that repeats the base --
+    every repeat rotated by its own number of records: string i = base[(first + i + 1237 * (i // nbase)) % nbase].
+
+    A plain repeat has a period of nbase / 64 tasks; with nbase = 16 384 that is 256 -- the number of CUs -- and a kernel that
+    hands task b + 256 w to wave w of block b then walks the SAME 64 records in all 16 waves of a CU, whose table loads hit
+    each other's lines in the L1: the corpora with 30 % of the steps outside the wide rows measured 1.04 instead of 0.54
+    TB/s that way (lesson 21).  1237 is odd (every alignment of a 64-record task occurs) and no
+    two waves of a block meet the same records (tests/test_workloads.py)."""
+    import numpy as np
+
+    i = np.arange(n, dtype=np.int64)
+    return (i % nbase + (i // nbase) * 1237 + first) % nbase
+
+
 def wide_urls(entry: dict, seed: int, n: int, listed_share: float = 0.25):
     """(text u8, offsets u64[n+1]): URLs for a blacklist scanner (samples/blacklist/blacklist.cpp:78-85 reads one per line):
     scheme, 0-2 subdomain labels, a host -- a word of the dictionary with probability `listed_share`, else a made-up domain

@@ -53,14 +53,14 @@ def working_set(o, text, offs, wide):
 def point_records(entry, corpus, n, length, reps):
     blob = W.load_blob(entry["blob"])
     o = ob.OracleScanner(blob)
-    nbase = min(n, 4096)
+    nbase = min(n, 16384)   # (as bench.py: with 4 096 two waves of a CU could meet part of the same records, tests/test_workloads.py)
     base = W.wide_records(entry, corpus, 0x5EED5EED, nbase, length)
     offs = np.arange(nbase + 1, dtype=np.uint64) * length
     oi, of = o.run(base.reshape(-1), offs, threads=8)
     # (every repeat of the base rotated by its own number of records: a plain repeat has a period of 64 tasks, and a kernel
     # whose block b hands task b + 256 w to its wave w then walks the same 64 records in all waves of a CU -- their table
     # loads hit each other's lines in the L1)
-    order = ((np.arange(n, dtype=np.int64) % nbase) + (np.arange(n, dtype=np.int64) // nbase) * 1237) % nbase
+    order = W.rotated_repeat_order(n, nbase)
     text = torch.as_tensor(base, device="cuda").index_select(0, torch.as_tensor(order, device="cuda")).contiguous()
     idx = torch.empty(n, dtype=torch.int32, device="cuda")
     fin = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -70,7 +70,7 @@ def point_records(entry, corpus, n, length, reps):
     info = t.info
     res = {"set": entry["name"], "corpus": corpus, "strings": n, "string_bytes": length, "states": info.states, "letters": info.letters,
            "dense_rows": info.hot_states, "wide_rows": info.wide_states, "wide_lds_bytes": info.wide_lds_bytes}
-    res.update(working_set(o, base[:256].reshape(-1), offs[:257], info.wide_states))
+    res.update(working_set(o, base[:1024].reshape(-1), offs[:1025], info.wide_states))
 
     def launch():
         t.run_strided_device(text.data_ptr(), n, length, length, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
