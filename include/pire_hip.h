@@ -171,7 +171,7 @@ typedef struct pire_hip_config {
 	                               /* a mismatch returns PIRE_HIP_ESELFTEST and nothing is written.  The kernels keep text */
 	                               /* on its way in registers with hand-counted waits; this catches a build or a device    */
 	                               /* on which that goes wrong where the build-time ISA audit (pire_hip_build_info) only   */
-	                               /* argues that it cannot.  ~1-2 ms once per table and kernel, on a stream of its own    */
+	                               /* argues that it cannot.  ~1 ms once per table and kernel, on a stream of its own      */
 	                               /* (an ON_DEVICE call blocks for that long, once); skipped while `stream` is being      */
 	                               /* captured.  0 default = on; 1 off; 2 on, with the expected answer of one string        */
 	                               /* altered (tests of the failure path)                                                  */
