@@ -175,6 +175,14 @@ typedef struct pire_hip_config {
 	                               /* (an ON_DEVICE call blocks for that long, once); skipped while `stream` is being      */
 	                               /* captured.  0 default = on; 1 off; 2 on, with the expected answer of one string        */
 	                               /* altered (tests of the failure path)                                                  */
+	uint32_t zip_variant;          /* the class-indexed walk's LDS image: 0 default = ZIPPED (a row of their own only for   */
+	                               /* <= 1 022 states; every other state of the tier 10 bytes: the row it is equal to       */
+	                               /* except in <= 3 letters, and where those lead -- 8-10 000 states of a dictionary        */
+	                               /* scanner in a CU's LDS instead of 2 200, two dependent LDS reads per byte instead of   */
+	                               /* one) once adapt() has measured more than 0.4 % of the steps outside the plain rows     */
+	                               /* and the zipped tier leaves less than 0.6 of that outside; 1 never; 2 whenever the     */
+	                               /* table has more states than plain rows.  Read when a table is ranked (created,          */
+	                               /* adapted).  Same results either way.                                                    */
 } pire_hip_config;
 #define PIRE_HIP_SEGMENT_WARMUP_NONE (~(uint64_t)0)
 #define PIRE_HIP_SEGMENT_BUDGET_NONE (~(uint64_t)0)
@@ -209,7 +217,8 @@ typedef struct pire_hip_table_info {
 	uint32_t compact_states;  /* states (hot ones included) that also have a class-indexed u16 row in LDS: the
 	                             exact re-walk of a chunk that left the dense rows stays in LDS for them */
 	uint32_t scanner_type;    /* ScannerIOTypes of the ingested blob (scanners/common.h:34-40): 1 Scanner, 2 SimpleScanner */
-	uint32_t reserved;
+	uint32_t zip_full_states; /* != 0: the wide walk's image is zipped (pire_hip_config.zip_variant) and this many of its   */
+	                          /* wide_states have a row of their own                                                     */
 	uint32_t wide_states;     /* states with a class-indexed row in the wide walk's LDS image (0: table fits the dense rows) */
 	uint32_t wide_lds_bytes;  /* LDS bytes of that image per workgroup */
 	float outside_dense_share;   /* share of the ranking's mass (scans seen by adapt(), else the a-priori byte model) on   */
@@ -220,13 +229,14 @@ typedef struct pire_hip_table_info {
 	                             /* lane there) -- not a share of the ranking's mass, which only knows states some sample   */
 	                             /* hit                                                                                     */
 	uint32_t shares_measured;    /* 1: those shares come from visit counters                                               */
-	uint32_t reserved2;
+	float zip_outside_share;     /* the plan that chose between the two images (last ranking): share of the ranking's mass  */
+	                             /* the zipped tier would leave outside (0: not planned) ...                               */
 	uint64_t last_wide_trap_chunks; /* 16-byte wave-chunks (64 strings x 16 bytes) the class-indexed walk had to walk a    */
 	                                /* second time because a lane left its rows, between the two most recent adapt() calls  */
 	                                /* (exact, all devices)                                                                 */
 	float wide_outside_chunk_share; /* ... as a share of the wave-chunks that walk was handed in that time (a wave that skips */
 	                                /* the attempt on the rows alone counts the chunks in which a lane left them)           */
-	uint32_t reserved3;
+	float zip_plain_outside_share; /* ... and the plain rows                                                               */
 } pire_hip_table_info;
 
 /* ---- table life cycle -------------------------------------------------------------------------- */
@@ -333,6 +343,18 @@ int pire_hip_table_layout(const pire_hip_table* t, uint32_t* orig_of_perm, uint8
  */
 int pire_hip_table_wide_layout(const pire_hip_table* t, uint16_t* rows, size_t cap, uint32_t* wide_states, uint32_t* pitch,
                                uint32_t* rows_offset);
+/*
+ * ... and of its ZIPPED form (pire_hip_config.zip_variant; pire_hip_table_wide_layout reports wide_states = 0 for such a table).
+ * geometry[8] = { tier, full, pitch, rows_offset, headers_offset, exceptions_offset, image_end, 3 }: device ids [0, full) have a
+ * row of their own (as above, `tier` = the escape state's id, row number `full` = the escape row), ids [full, tier) a header and
+ * three exception targets; all zeros: the table's image is not zipped.  image[(image_end - rows_offset) / 2] (cap = its capacity
+ * in u16 entries; NULL: only the geometry) = the bytes as they lie in LDS from rows_offset on:
+ *     rows              (full + 1) x pitch bytes
+ *     u32 header[tier + 1]  at headers_offset: bits 22..31 the row (device id < full, or `full`) this state's row is equal to except
+ *                       in the letters at bits 1..7, 8..14, 15..21 (127 = none)
+ *     u16 target[tier - full][3]  at exceptions_offset: where those letters lead (device id, `tier` = outside the tier)
+ */
+int pire_hip_table_zip_layout(const pire_hip_table* t, uint16_t* image, size_t cap, uint32_t geometry[8]);
 
 /* ---- the hot path -------------------------------------------------------------------------------- */
 

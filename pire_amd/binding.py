@@ -51,16 +51,16 @@ class TableInfo(C.Structure):
         ("adaptations", C.c_uint32),
         ("compact_states", C.c_uint32),
         ("scanner_type", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("zip_full_states", C.c_uint32),
         ("wide_states", C.c_uint32),
         ("wide_lds_bytes", C.c_uint32),
         ("outside_dense_share", C.c_float),
         ("outside_wide_share", C.c_float),
         ("shares_measured", C.c_uint32),
-        ("reserved2", C.c_uint32),
+        ("zip_outside_share", C.c_float),
         ("last_wide_trap_chunks", C.c_uint64),
         ("wide_outside_chunk_share", C.c_float),
-        ("reserved3", C.c_uint32),
+        ("zip_plain_outside_share", C.c_float),
     ]
 
 
@@ -125,6 +125,7 @@ class Config(C.Structure):
         ("slow_stats", C.c_uint32),
         ("walk_variant", C.c_uint32),
         ("selftest", C.c_uint32),
+        ("zip_variant", C.c_uint32),
     ]
 
 
@@ -153,6 +154,7 @@ ABI = [
     ("pire_hip_table_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_table_wide_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                              C.POINTER(C.c_uint32)]),
+    ("pire_hip_table_zip_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_run_strided", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32,
@@ -392,6 +394,23 @@ class Table:
         rows = np.empty((w.value + 1, pitch.value // 2), dtype=np.uint16)
         _check(lib().pire_hip_table_wide_layout(self._h, rows.ctypes.data, rows.size, C.byref(w), C.byref(pitch), C.byref(off)))
         return rows, w.value, pitch.value, off.value
+
+    def zip_layout(self):
+        """None, or the ZIPPED image of the class-indexed walk (pire_hip_table_zip_layout): a dict with tier, full, pitch,
+        rows_offset and the decoded pieces rows u16[full + 1, pitch / 2], headers u32[tier + 1], targets u16[tier - full, 3]."""
+        g = (C.c_uint32 * 8)()
+        _check(lib().pire_hip_table_zip_layout(self._h, None, 0, g))
+        tier, full, pitch, rows_off, h_off, x_off, end, k = list(g)
+        if not full:
+            return None
+        img = np.empty((end - rows_off) // 2, dtype=np.uint16)
+        _check(lib().pire_hip_table_zip_layout(self._h, img.ctypes.data, img.size, g))
+        raw = img.view(np.uint8)
+        rows = raw[:(full + 1) * pitch].view(np.uint16).reshape(full + 1, pitch // 2)
+        headers = raw[h_off - rows_off:h_off - rows_off + 4 * (tier + 1)].view(np.uint32)
+        targets = raw[x_off - rows_off:x_off - rows_off + 2 * k * (tier - full)].view(np.uint16).reshape(tier - full, k)
+        return {"tier": tier, "full": full, "pitch": pitch, "rows_offset": rows_off, "rows": rows, "headers": headers,
+                "targets": targets}
 
     def adapt(self) -> int:
         """Re-rank the LDS rows from the visit counters of earlier scans; returns the number of rows promoted."""

@@ -198,10 +198,10 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->next16 = d.next16;
 	p->visitWide = d.visitWide;
 	p->wide = d.wideRows ? h.wide : 0;
+	p->zipFull = d.wideRows ? h.zipFull : 0;
 	p->outsideDense = h.outsideDense;
 	p->outsideWide = h.outsideWide;
 	p->massMeasured = h.massMeasured;
-	p->wideTwiceShare = h.wideTwiceShare;
 	p->wideLaunched = &t->wideLaunched;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
@@ -284,6 +284,7 @@ pire_hip_config SeedFromEnvironment()
 	c.slow_stats = EnvU64("PIRE_HIP_SLOW_STATS") != 0;
 	c.walk_variant = uint32_t(EnvU64("PIRE_HIP_WALK_VARIANT"));
 	c.selftest = uint32_t(EnvU64("PIRE_HIP_SELFTEST"));
+	c.zip_variant = uint32_t(EnvU64("PIRE_HIP_ZIP_VARIANT"));
 	return c;
 }
 
@@ -402,7 +403,7 @@ int SelfTest(const ScanParams& p, int kind, const char* name, uint32_t mode)
 		q.visitCold = reinterpret_cast<uint32_t*>(base + offCold);
 		q.trapSignal = nullptr;
 		q.wideLaunched = &launched;
-		q.wideTwiceShare = pass ? 1.0f : 0.0f;
+		q.forceLanes = pass ? 2 : 1;   // (the batch is too small for LaunchWide to choose two strings per lane by itself)
 		unsigned long long* work = reinterpret_cast<unsigned long long*>(base + offWork);
 		rc = kind == kKindWide ? LaunchWide(q, own) : kind == kKindTiled ? LaunchTiled(q, own)
 		     : kind == kKindRaggedWide ? LaunchRaggedWide(q, work, own) : kind == kKindStream ? LaunchStream(q, own)
@@ -1169,9 +1170,11 @@ try {
 	out->lds_table_bytes = MakeLayout(h.hot, 0, 256u, h.compact ? (h.compact + 1) * CompactPitch(h.letters) : 0).total;
 	out->compact_states = h.compact;
 	out->scanner_type = h.scannerType;
-	out->reserved = 0;
+	out->zip_full_states = h.zipFull;
+	out->zip_outside_share = h.zipOutside;
+	out->zip_plain_outside_share = h.zipPlainOutside;
 	out->wide_states = h.wide;
-	out->wide_lds_bytes = h.wide ? MakeWideLayout(h.wide, h.letters, 0).total : 0;
+	out->wide_lds_bytes = h.wide ? MakeWideLayout(h.wide, h.letters, 0, h.zipFull).total : 0;
 	out->outside_dense_share = h.outsideDense;
 	out->outside_wide_share = h.outsideWide;
 	out->shares_measured = h.massMeasured ? 1 : 0;
@@ -1290,21 +1293,51 @@ try {
 	EnsureRanked(const_cast<pire_hip_table*>(t));
 	std::shared_lock<std::shared_mutex> stable(const_cast<pire_hip_table*>(t)->adaptMutex);
 	const HostTable& h = t->host;
-	const WideLayout wl = MakeWideLayout(h.wide, h.letters, 0);
+	const uint32_t wide = h.zipFull ? 0 : h.wide;   // a zipped image: pire_hip_table_zip_layout
+	const WideLayout wl = MakeWideLayout(wide, h.letters, 0);
 	if (wide_states)
-		*wide_states = h.wide;
+		*wide_states = wide;
 	if (pitch)
 		*pitch = wl.pitch;
 	if (rows_offset)
 		*rows_offset = wl.rowsOff;
-	if (rows && h.wide) {
+	if (rows && wide) {
 		const std::vector<uint16_t> img = BuildWideRows(h);
-		const size_t want = size_t(h.wide + 1) * wl.pitch / 2;
+		const size_t want = size_t(wide + 1) * wl.pitch / 2;
 		if (cap < want) {
 			SetError("wide layout: buffer too small");
 			return PIRE_HIP_EINVAL;
 		}
 		memcpy(rows, img.data(), want * sizeof(uint16_t));
+	}
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();   // an exception must not unwind through the C ABI
+}
+
+int pire_hip_table_zip_layout(const pire_hip_table* t, uint16_t* image, size_t cap, uint32_t geometry[8])
+try {
+	if (!t || !geometry) {
+		SetError("null table / geometry");
+		return PIRE_HIP_EINVAL;
+	}
+	EnsureRanked(const_cast<pire_hip_table*>(t));
+	std::shared_lock<std::shared_mutex> stable(const_cast<pire_hip_table*>(t)->adaptMutex);
+	const HostTable& h = t->host;
+	memset(geometry, 0, 8 * sizeof(uint32_t));
+	if (!h.zipFull)
+		return PIRE_HIP_OK;
+	const WideLayout wl = MakeWideLayout(h.wide, h.letters, 0, h.zipFull);
+	const uint32_t g[8] = {h.wide, h.zipFull, wl.pitch, wl.rowsOff, wl.hOff, wl.xOff, wl.imageEnd, kZipExceptions};
+	memcpy(geometry, g, sizeof(g));
+	if (image) {
+		const std::vector<uint16_t> img = BuildWideRows(h);
+		const size_t want = (wl.imageEnd - wl.rowsOff) / 2;
+		if (cap < want) {
+			SetError("zip layout: buffer too small");
+			return PIRE_HIP_EINVAL;
+		}
+		memcpy(image, img.data(), want * sizeof(uint16_t));
 	}
 	return PIRE_HIP_OK;
 } catch (...) {

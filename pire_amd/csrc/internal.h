@@ -117,7 +117,11 @@ inline uint32_t CompactCapacity(uint32_t hot, uint32_t letters, uint32_t regexps
 struct WideLayout {
 	uint32_t pitch;      // bytes per row
 	uint32_t rowsOff;    // 256
-	uint32_t rows;       // wide + 1 (the last one is the escape row)
+	uint32_t rows;       // states with a row + 1 (the last one is the escape row): wide + 1, zipped image: full + 1
+	uint32_t full;       // zipped image (below): states with a row of their own; else == wide
+	uint32_t hOff;       // zipped image: u32 header of every state of the tier and of the escape state (wide + 1 of them)
+	uint32_t xOff;       // zipped image: 3 x u16 exception targets of every state WITHOUT a row of its own (wide - full of them)
+	uint32_t imageEnd;   // end of what is copied from memory (rows [+ headers + exceptions]), 16-byte aligned
 	uint32_t histOff;    // u32[rows]
 	uint32_t countsOff;  // (regexps + 2) u32 block-local match counters
 	uint32_t progOff;    // u32 progress counter of the block's waves + u32 trap samples
@@ -135,13 +139,36 @@ __host__ __device__ inline uint32_t WidePitch(uint32_t letters)
 	return (halfwords % 4 ? halfwords : halfwords + 1) * 2;
 }
 
-__host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t letters, uint32_t regexps)
+// ---- the zipped image (round 6) ----------------------------------------------------------------------------------------
+// A dictionary automaton's rows are nearly all "the row of a shallower state, except for the one or two letters that
+// continue a word" (the failure-link structure of the reference's determinised `word1|word2|...`, samples/blacklist/
+// blacklist.cpp:65-76) -- a 70-byte row per state keeps 2 207 states of dict_10k's 30 202 in a CU's LDS, and from 3 % of the
+// steps outside them on the walk is bound by the L2's request rate.  The zipped image keeps a full row only
+// for `full` states (<= 1 023) and, for every other state of the tier, 10 bytes:
+//     u32 header    bits 22..31  index of the full row this state's row is equal to except in <= 3 letters
+//                   bits 1..7 / 8..14 / 15..21  those letter classes (127 = none)  [= 2 * class * 0x4081: ONE multiply of the
+//                   byte's doubled class compares all three]
+//     u16 target[3] where they lead
+// States with a row of their own have a header too (base = themselves, no letters): the step is the same code for every
+// lane --  h = header[st];  entry address = letter matches one of h's ? &target[st][k] : &row[h.base][letter];  st = u16 at it.
+// Two dependent LDS reads per byte instead of one, 3 LDS instructions instead of 2: slower while the working set fits
+// the plain rows, 4 x the states in LDS when it does not.  Device numbering: full states first, then the rest of the tier.
+constexpr uint32_t kZipMaxFull = 1022;      // + the escape row: 10 bits of base
+constexpr uint32_t kZipNoLetter = 127;
+constexpr uint32_t kZipExceptions = 3;
+constexpr uint32_t kZipMulC2 = 0x4081u;     // (2 * class) * 0x4081 = class at bits 1, 8, 15
+
+__host__ __device__ inline WideLayout MakeWideLayout(uint32_t wide, uint32_t letters, uint32_t regexps, uint32_t zipFull = 0)
 {
 	WideLayout w;
 	w.pitch = WidePitch(letters);
 	w.rowsOff = 256;
-	w.rows = wide + 1;
-	w.histOff = (w.rowsOff + w.rows * w.pitch + 15) / 16 * 16;
+	w.full = zipFull ? zipFull : wide;
+	w.rows = w.full + 1;
+	w.hOff = (w.rowsOff + w.rows * w.pitch + 3) / 4 * 4;
+	w.xOff = w.hOff + (zipFull ? (wide + 1) * 4 : 0);
+	w.imageEnd = (w.xOff + (zipFull ? (wide - zipFull) * 2 * kZipExceptions : 0) + 15) / 16 * 16;
+	w.histOff = w.imageEnd;
 	w.countsOff = (w.histOff + w.rows * 4 + 15) / 16 * 16;
 	w.progOff = w.countsOff + ((regexps + 2) * 4 + 15) / 16 * 16;
 	w.total = w.progOff + 16;
@@ -193,6 +220,11 @@ struct HostTable {
 	std::vector<uint64_t> inc64;      // [states] (orig numbering) byte r = how often regexp r is in the final list
 	uint32_t compact = 0;             // perm ids [0, compact) also have a class-indexed u16 row in LDS (tiled/ragged kernels)
 	uint32_t wide = 0;                // perm ids [0, wide) have a row in the wide walk's LDS image (wide.hip; 0 = no such image)
+	uint32_t zipFull = 0;             // != 0: the wide image is ZIPPED (MakeWideLayout): perm ids [0, zipFull) have a row of their own,
+	                                  // [zipFull, wide) a header + <= 3 exceptions against the row of zipBase[id - zipFull]
+	std::vector<uint16_t> zipBase;    // [wide - zipFull] perm id (< zipFull) of that row
+	float zipPlainOutside = 0;        // what the plan that chose between the two images estimated: share of the ranking's mass outside
+	float zipOutside = 0;             // the plain rows / outside the zipped tier (table.cpp ChooseZip)
 	float outsideDense = 0;           // share of the ranking's mass on states WITHOUT a dense row / ...
 	float outsideWide = 0;            // ... without a wide row (from the byte model until adapt() has seen scans, then measured)
 	bool massMeasured = false;        // those shares come from visit counters, not from the a-priori byte model
@@ -354,8 +386,9 @@ struct ScanParams {
 	const uint16_t* next16;     // nullable
 	uint32_t* visitWide;
 	uint32_t wide;              // states with a wide row; 0 = no image
+	uint32_t zipFull;           // != 0: the image is zipped (internal.h MakeWideLayout), this many states have a row of their own
 	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
-	float wideTwiceShare;              // host side only: share of the wide walk's wave-chunks walked twice (last adapt()): one or two strings per lane
+	uint32_t forceLanes;               // host side only: 1 / 2 = LaunchWide takes the kernel with that many strings per lane (the self-test)
 	std::atomic<uint64_t>* wideLaunched;   // host side only: wave-chunks handed to the wide walk since the last adapt()
 	bool massMeasured;                 // host side only
 	const uint64_t* incPerm; // nullable

@@ -713,7 +713,7 @@ struct RaggedClock {};
 // EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
 // state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
 // A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
-// WIDE (round 5; 1: the exact table behind the rows has u32 entries, 2: u16): the class-indexed walk of wide.hip instead of
+// WIDE (round 5; 1: the exact table behind the rows has u32 entries, 2: u16, 3: u16 and the LDS image is zipped, round 6): the class-indexed walk of wide.hip instead of
 // the dense rows -- S.hs is then a device id with a row or `wide` (the escape row), the state's end-of-string record comes
 // from memory (the LDS is the rows'), everything else of the kernel is what it was.  Plain scans only (NoAct).
 template <class Act, bool EXT, int WIDE = 0>
@@ -801,9 +801,9 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 						             S.pos + 16u * k);
 					else if constexpr (WIDE != 0) {
-						WideChunk<WIDE == 2>(p, lds, W, K, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
+						WideChunk<WIDE >= 2, WIDE == 3>(p, lds, W, K, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 						if (sampleLaneHere && uint32_t(k) == ((sampleHash >> 20) & 7u))
-							atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + S.hs, 1u);
+							WideSample<WIDE == 3>(p, lds, W, S.hs);
 					} else
 						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 				}
@@ -818,7 +818,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 					StepPartialAct(p, lds, L, v, tail, S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 					               S.pos + 16u * full);
 				else if constexpr (WIDE != 0)
-					WidePartial<WIDE == 2>(p, K, v, tail, S.hs, S.cold);
+					WidePartial<WIDE >= 2, WIDE == 3>(p, K, v, tail, S.hs, S.cold);
 				else
 					StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
 			}
@@ -830,7 +830,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			const uint8_t* q = reinterpret_cast<const uint8_t*>(S.pos);
 			for (uint32_t i = 0; i < nb; ++i) {
 				if constexpr (WIDE != 0)
-					st = WideNext<WIDE == 2>(p, st, uint32_t(lds[q[i]]) >> 1);
+					st = WideNext<WIDE >= 2>(p, st, uint32_t(lds[q[i]]) >> 1);
 				else
 					st = SlowStep(p, lds, L, st, q[i]);
 				if constexpr (Act::kActive)
@@ -904,10 +904,8 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 		clk.acc[k] = 0;
 	clk.t = clk.on ? __builtin_readcyclecounter() : 0;
 #endif
-	const WideLayout W = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0) : WideLayout();
-	WideConst K;
-	K.pitch = W.pitch;
-	K.flagsOff = p.letters * 2;
+	const WideLayout W = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, WIDE == 3 ? p.zipFull : 0) : WideLayout();
+	const WideConst K = WIDE ? MakeWideConst(p, W) : WideConst();
 	LdsLayout L = {};
 	if constexpr (WIDE != 0)
 		L.countsOff = W.countsOff;   // what FinishWith looks at
@@ -1009,7 +1007,7 @@ int LaunchRaggedT(const ScanParams& p, unsigned long long* workCounter, const Ac
 	// (the counter is zero: the last block of the launch that used the slot before put it back, internal.h WorkSlotOf)
 	hipError_t e;
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, CompactBytes(p));
-	const uint32_t ldsBytes = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0).total + uint32_t(sizeof(RaggedWork))
+	const uint32_t ldsBytes = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, WIDE == 3 ? p.zipFull : 0).total + uint32_t(sizeof(RaggedWork))
 	                               : L.total + kRaggedLdsExtra;
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
@@ -1094,6 +1092,10 @@ int LaunchRaggedWide(const ScanParams& p, unsigned long long* workCounter, hipSt
 	if (int rc = CheckCounts(p))
 		return rc;
 	const bool ext = p.ends || p.initIdx || (p.flags & kPermIds);
+	if (p.zipFull) {   // (a zipped image implies the u16 table: table.cpp ChooseZip)
+		NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u16 table, zipped rows>");
+		return ext ? LaunchRaggedT<NoAct, true, 3>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 3>(p, workCounter, NoAct(), stream);
+	}
 	if (p.next16) {
 		NoteKernel("ragged_wide", "pirehip::ScanRaggedKernel<NoAct, wide walk, u16 table>");
 		return ext ? LaunchRaggedT<NoAct, true, 2>(p, workCounter, NoAct(), stream) : LaunchRaggedT<NoAct, false, 2>(p, workCounter, NoAct(), stream);

@@ -18,7 +18,9 @@
 #include <cmath>
 #include <iterator>
 #include <cstring>
+#include <functional>
 #include <numeric>
+#include <stdexcept>
 
 #include "internal.h"
 
@@ -255,6 +257,143 @@ void MeasureShares(HostTable& t, const std::vector<double>& score)
 	t.outsideWide = total > 0 && t.wide ? float(std::max(0.0, 1.0 - wide / total)) : t.outsideDense;
 }
 
+// ---- the zipped image of the wide walk (internal.h MakeWideLayout; round 6) ---------------------------------------------
+// Which states of the ranking get a row of their own, which a header + <= 3 exceptions against one of those rows, in
+// rank order until the CU's LDS is full: a state whose row differs from the row of a state that already has one in at most
+// three letters costs 10 bytes, any other a row (pitch + 8 bytes) -- while `cap` rows are not used up; after that such a
+// state stays outside the tier (74 bytes buy seven zipped states).  `order`: the ranking, the first `hot` states keep
+// their places (they have rows: the dense-row kernels number them 0..hot-1).  Any outcome is correct: a state outside the
+// tier is walked through the exact table in memory.
+struct ZipPlan {
+	std::vector<uint32_t> full, zipped, rest;   // reference state indices, in rank order
+	std::vector<uint16_t> base;                 // per zipped state: position in `full` of the row it leans on
+	double inside = 0;                          // mass of the ranking on the tier
+};
+
+// number of letters two rows differ in, given up at more than `limit`
+inline uint32_t RowDistance(const uint32_t* a, const uint32_t* b, uint32_t letters, uint32_t limit)
+{
+	uint32_t d = 0, c = 0;
+	for (; c + 8 <= letters; c += 8) {
+		for (uint32_t k = 0; k < 8; ++k)
+			d += a[c + k] != b[c + k];
+		if (d > limit)
+			return d;
+	}
+	for (; c < letters; ++c)
+		d += a[c] != b[c];
+	return d;
+}
+
+ZipPlan PlanZip(const HostTable& t, const std::vector<uint32_t>& order, const std::vector<double>& score, uint32_t hot, uint32_t cap)
+{
+	const uint32_t N = t.states, C = t.letters;
+	ZipPlan z;
+	const uint32_t pitch = WidePitch(C);
+	const uint64_t fixed = MakeWideLayout(0, C, t.regexps <= kMaxLdsCountRegexps ? t.regexps : 0, 0).total + 64 + sizeof(uint32_t) * 8;
+	const uint64_t rowCost = pitch + 4 + 4, zipCost = 4 + 2 * kZipExceptions;   // row + header + visit counter / header + targets
+	uint64_t used = fixed + rowCost /* the escape row */ + 16;
+	cap = std::min(cap, kZipMaxFull);
+	auto mass = [&](uint32_t s) { return score[s] > 0 ? score[s] : 0.0; };
+	uint32_t lastBase = 0;
+	for (uint32_t i = 0; i < N; ++i) {
+		const uint32_t s = order[i];
+		if (used + std::max(rowCost, zipCost) > kLdsPerBlock || z.full.size() + z.zipped.size() >= 65000) {
+			z.rest.insert(z.rest.end(), order.begin() + i, order.end());
+			break;
+		}
+		const uint32_t* row = &t.next[size_t(s) * C];
+		int found = -1;
+		if (i >= hot && !(t.flags[s] & kAbsorbing)) {   // (an absorbing state keeps its row: the early-out reads the row's flags)
+			// the row the previous zipped state leans on first: states of one neighbourhood follow each other in the ranking
+			if (!z.full.empty() && RowDistance(row, &t.next[size_t(z.full[lastBase]) * C], C, kZipExceptions) <= kZipExceptions)
+				found = int(lastBase);
+			for (uint32_t f = 0; found < 0 && f < z.full.size(); ++f)
+				if (RowDistance(row, &t.next[size_t(z.full[f]) * C], C, kZipExceptions) <= kZipExceptions)
+					found = int(f);
+		}
+		if (found >= 0) {
+			z.zipped.push_back(s);
+			z.base.push_back(uint16_t(found));
+			lastBase = uint32_t(found);
+			used += zipCost;
+			z.inside += mass(s);
+		} else if (i < hot || z.full.size() < cap) {
+			z.full.push_back(s);
+			used += rowCost;
+			z.inside += mass(s);
+		} else {
+			z.rest.push_back(s);
+		}
+	}
+	return z;
+}
+
+// The choice between the plain rows and the zipped image (pire_hip_config.zip_variant: 0 by the ranking's masses once
+// adapt() has measured them, 1 never, 2 always), and the zipped numbering: full states, zipped states, the rest.
+void ChooseZip(HostTable& t, std::vector<uint32_t>& order, const std::vector<double>& score)
+{
+	const uint32_t N = t.states, C = t.letters;
+	const bool was = t.zipFull != 0;
+	t.zipFull = 0;
+	t.zipBase.clear();
+	t.zipPlainOutside = t.zipOutside = 0;
+	const uint32_t variant = GetConfig().zip_variant;
+	if (variant == 1 || !t.wide || t.wide >= N || N > 65000 || C > 126)
+		return;   // the plain rows hold every state / ids or letter classes the image's fields cannot hold
+	double total = 0, plainInside = 0;
+	for (uint32_t i = 0; i < N; ++i) {
+		const double v = score[order[i]] > 0 ? score[order[i]] : 0.0;
+		total += v;
+		if (i < t.wide)
+			plainInside += v;
+	}
+	if (total <= 0)
+		return;
+	t.zipPlainOutside = float(std::max(0.0, 1.0 - plainInside / total));
+	// Worth planning at all?  Without a measurement the byte model's masses say little about thousands of states; with one,
+	// the plain rows are the faster walk while the working set fits them (two LDS instructions per byte, not three).
+	const float enter = was ? 0.002f : 0.004f;   // (hysteresis: a zipped table stays zipped at a share that would not have made it one)
+	if (variant != 2 && (!t.massMeasured || t.zipPlainOutside < enter))
+		return;
+	ZipPlan best;
+	double bestInside = -1;
+	for (uint32_t cap : {kZipMaxFull, 767u, 511u}) {
+		if (cap < t.hot)
+			continue;
+		ZipPlan z = PlanZip(t, order, score, t.hot, cap);
+		// (caps in falling order: a smaller one has to put more of the ranking's mass into the tier to be taken -- where every
+		// visited state fits anyway, more rows mean more steps that need no exception and fewer distinct headers per wave)
+		if (z.inside > bestInside * 1.0005) {
+			bestInside = z.inside;
+			best = std::move(z);
+		}
+	}
+	if (bestInside < 0 || best.zipped.empty())
+		return;
+	const float zipOutside = float(std::max(0.0, 1.0 - bestInside / total));
+	t.zipOutside = zipOutside;
+	if (variant != 2 && !(zipOutside < 0.6f * t.zipPlainOutside))
+		return;
+	// (the plan counted bytes; what decides is the layout the kernels use, with the ragged kernel's work record behind it)
+	const uint32_t regexps = t.regexps <= kMaxLdsCountRegexps ? t.regexps : 0;
+	while (!best.zipped.empty() &&
+	       MakeWideLayout(uint32_t(best.full.size() + best.zipped.size()), C, regexps, uint32_t(best.full.size())).total + 128 > kLdsPerBlock) {
+		best.rest.insert(best.rest.begin(), best.zipped.back());
+		best.zipped.pop_back();
+		best.base.pop_back();
+	}
+	if (best.zipped.empty())
+		return;
+	order.clear();
+	order.insert(order.end(), best.full.begin(), best.full.end());
+	order.insert(order.end(), best.zipped.begin(), best.zipped.end());
+	order.insert(order.end(), best.rest.begin(), best.rest.end());
+	t.zipFull = uint32_t(best.full.size());
+	t.wide = uint32_t(best.full.size() + best.zipped.size());
+	t.zipBase = std::move(best.base);
+}
+
 // Renumber "hot first" by `score` (higher = hotter) and build the dense LDS rows.
 void PermuteByScore(HostTable& t, const std::vector<double>& score)
 {
@@ -303,6 +442,7 @@ void PermuteByScore(HostTable& t, const std::vector<double>& score)
 	// the wide walk's image (wide.hip): only for tables with more states than dense rows -- a table that fits the dense
 	// rows never leaves them
 	t.wide = N > t.hot ? WideCapacity(C, t.regexps, N) : 0;
+	ChooseZip(t, order, score);   // (may renumber everything behind the dense rows and raise t.wide)
 	t.origOfPerm = order;
 	MeasureShares(t, score);
 	t.permOfOrig.assign(N, 0);
@@ -703,20 +843,54 @@ void FreeAllDeviceTables(pire_hip_table* t)
 		(void)hipSetDevice(cur);
 }
 
-// The wide walk's LDS image (internal.h WideLayout) in the table's current numbering: entry = device id of the target,
-// `wide` (the escape row) for targets without a row; then the row's flags.
+// The wide walk's LDS image (internal.h WideLayout) in the table's current numbering, as it lies in LDS from rowsOff on:
+// rows -- entry = device id of the target, `wide` (the escape state) for targets outside the tier; then the row's flags --
+// and, zipped image (internal.h MakeWideLayout), the headers of all tier states + the escape state and the exception targets
+// of the zipped ones.
 std::vector<uint16_t> BuildWideRows(const HostTable& h)
 {
-	const uint32_t W = h.wide, C = h.letters, pitch2 = WidePitch(C) / 2;
-	std::vector<uint16_t> rows((size_t(W + 1) * pitch2 + 7) / 8 * 8, 0);
-	for (uint32_t pid = 0; pid <= W; ++pid) {
-		uint16_t* row = &rows[size_t(pid) * pitch2];
-		const uint32_t o = pid < W ? h.origOfPerm[pid] : 0;
+	const uint32_t W = h.wide, C = h.letters, F = h.zipFull ? h.zipFull : W;
+	const WideLayout wl = MakeWideLayout(W, C, 0, h.zipFull);
+	const uint32_t pitch2 = wl.pitch / 2;
+	std::vector<uint16_t> img((wl.imageEnd - wl.rowsOff) / 2 + 8, 0);
+	auto target = [&](uint32_t o, uint32_t c) { return uint16_t(std::min(h.permOfOrig[h.next[size_t(o) * C + c]], W)); };
+	for (uint32_t pid = 0; pid <= F; ++pid) {
+		uint16_t* row = &img[size_t(pid) * pitch2];
+		const uint32_t o = pid < F ? h.origOfPerm[pid] : 0;
 		for (uint32_t c = 0; c < C; ++c)
-			row[c] = uint16_t(pid < W ? std::min(h.permOfOrig[h.next[size_t(o) * C + c]], W) : W);
-		row[C] = pid < W ? h.flags[o] : 0;
+			row[c] = pid < F ? target(o, c) : uint16_t(W);
+		row[C] = pid < F ? h.flags[o] : 0;
 	}
-	return rows;
+	if (!h.zipFull)
+		return img;
+	uint16_t* hdr = &img[(wl.hOff - wl.rowsOff) / 2];
+	uint16_t* exc = &img[(wl.xOff - wl.rowsOff) / 2];
+	const uint32_t none = (kZipNoLetter << 1) | (kZipNoLetter << 8) | (kZipNoLetter << 15);
+	auto put = [&](uint32_t pid, uint32_t word) {
+		hdr[2 * pid] = uint16_t(word);
+		hdr[2 * pid + 1] = uint16_t(word >> 16);
+	};
+	for (uint32_t pid = 0; pid < F; ++pid)
+		put(pid, (pid << 22) | none);
+	put(W, (F << 22) | none);   // the escape state leans on the escape row
+	for (uint32_t pid = F; pid < W; ++pid) {
+		const uint32_t o = h.origOfPerm[pid], b = h.zipBase[pid - F], bo = h.origOfPerm[b];
+		uint32_t word = (b << 22), k = 0;
+		uint16_t* x = exc + size_t(pid - F) * kZipExceptions;
+		for (uint32_t c = 0; c < C; ++c)
+			if (h.next[size_t(o) * C + c] != h.next[size_t(bo) * C + c]) {
+				if (k == kZipExceptions)
+					throw std::logic_error("zipped image: a state with more exceptions than the plan allowed");
+				word |= c << (1 + 7 * k);
+				x[k++] = target(o, c);
+			}
+		for (; k < kZipExceptions; ++k) {
+			word |= kZipNoLetter << (1 + 7 * k);
+			x[k] = uint16_t(W);
+		}
+		put(pid, word);
+	}
+	return img;
 }
 
 int UploadTable(pire_hip_table* t, DeviceTable* image)
@@ -1272,7 +1446,22 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 	const float wideSeenOutside = wideSeen ? float(double(wideOutsideSamples) / wideSamples) : 0.0f;
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());
-	if (coldSamples == 0) {
+	// (a zipped table whose traffic no longer leaves the tier: would the plain rows hold it too?  They are the faster walk.)
+	bool unzip = false;
+	if (coldSamples == 0 && h.zipFull && GetConfig().zip_variant != 2) {
+		std::vector<double> sorted(score);
+		std::sort(sorted.begin(), sorted.end(), std::greater<double>());
+		const uint32_t plain = WideCapacity(h.letters, h.regexps, N);
+		double total = 0, inside = 0;
+		for (uint32_t i = 0; i < N; ++i) {
+			const double v = std::max(0.0, sorted[i]);
+			total += v;
+			if (i < plain)
+				inside += v;
+		}
+		unzip = total > 0 && 1.0 - inside / total < 0.002;
+	}
+	if (coldSamples == 0 && !unzip) {
 		MeasureShares(h, score);   // same numbering, measured masses
 		if (wideSeen)
 			h.outsideWide = wideSeenOutside;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void WideWaitTile(u32x4 (&r)[8])
 	             : "n"(TILES_BEHIND * 8));
 }
 
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, uint64_t rowBase,
                                           uint64_t chainBase, uint32_t voff, uint64_t istride, uint32_t lane, uint32_t t,
                                           uint32_t lastTile, u32x4 (&cur)[8], u32x4 (&refill)[8], uint32_t& st, uint32_t& cold,
@@ -74,25 +74,23 @@ __device__ __forceinline__ void WidePhase(const ScanParams& p, uint8_t* lds, con
 	TransposeTile(cur, lane);
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
-		WideChunk<N16>(p, lds, W, K, cur[k], st, cold, (t * 8 + k) & 63);
+		WideChunk<N16, ZIP>(p, lds, W, K, cur[k], st, cold, (t * 8 + k) & 63);
 	// visit sample: one lane per wave per tile (the escape row counts into slot `wide`), the state BEHIND the tile -- in
 	// front of a record's first tile every lane is in the start state, an eighth of the samples of 1 KiB records.  WHICH
 	// lane: a hash of the wave's tile count -- `t & 63` sampled lane l at tile l of its string and nowhere else, and a batch
 	// that repeats a base of a few thousand records (every benchmark here) was then seen at 2 048 places, over and over
 	if (lane == (myTiles * 0x9E3779B1u) >> 26)
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
+		WideSample<ZIP>(p, lds, W, st);
 }
 
 // Fixed-length records, 16-byte aligned, at least two 128-byte tiles per record (+ a tail shorter than a tile), whole tasks
 // of 64 strings: tiled.hip's ring of two register tiles, chained through task boundaries when the tile count is even.
-template <bool N16>
+template <bool N16, bool ZIP>
 __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
-	WideConst K;
-	K.pitch = W.pitch;
-	K.flagsOff = p.letters * 2;
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, ZIP ? p.zipFull : 0);
+	const WideConst K = MakeWideConst(p, W);
 	LdsLayout L = {};           // what Finish() looks at: the block-local counters
 	L.countsOff = W.countsOff;
 
@@ -132,10 +130,10 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 		if (!primed)
 			WideIssueTile(a, voff, rowBase, istride);
 		for (uint32_t t = 0; t < paired && !done; t += 2) {
-			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, st, cold, prog, myTiles);
-			WidePhase<N16>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, st, cold, prog, myTiles);
+			WidePhase<N16, ZIP>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t, lastTile, a, b, st, cold, prog, myTiles);
+			WidePhase<N16, ZIP>(p, lds, W, K, rowBase, chainBase, voff, istride, lane, t + 1, lastTile, b, a, st, cold, prog, myTiles);
 			// wave-wide early out (multi.h:955-958): every lane in a row whose every transition is a self loop
-			done = __all((WideEntry(st, K.pitch, K.flagsOff) & kAbsorbing) != 0);
+			done = __all((WideFlags<ZIP>(st, K) & kAbsorbing) != 0);
 		}
 		primed = hasNext && !done;   // an early-out leaves some other tile in slot a: re-prime then
 		if (done)
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 			TransposeTile(a, lane);
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				WideChunk<N16>(p, lds, W, K, a[k], st, cold, (lastTile * 8 + k) & 63);
+				WideChunk<N16, ZIP>(p, lds, W, K, a[k], st, cold, (lastTile * 8 + k) & 63);
 		}
 		uint32_t end = st < p.wide ? st : cold;
 		if (!done) {   // the tail shorter than a tile: exact steps straight from memory
@@ -166,14 +164,12 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 // A task = 128 strings, lane l walks strings l and l + 64 of it.  Both tiles live in the 64 tile registers the ring of
 // the kernel above uses for one string's two tiles, so there is no tile on its way during the walk: load, wait, walk
 // (the walk is 10 x the load here; and a load on its way would be waited for by the first vmcnt(0) of a re-walk anyway).
-template <bool N16>
+template <bool N16, bool ZIP>
 __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
-	WideConst K;
-	K.pitch = W.pitch;
-	K.flagsOff = p.letters * 2;
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, ZIP ? p.zipFull : 0);
+	const WideConst K = MakeWideConst(p, W);
 	LdsLayout L = {};
 	L.countsOff = W.countsOff;
 	const uint32_t lane = threadIdx.x & 63;
@@ -221,15 +217,21 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 			WideWaitTile<0>(b);
 			TransposeTile(a, lane);
 			TransposeTile(b, lane);
-#pragma unroll
-			for (int k = 0; k < 8; ++k)
-				WideChunk2<N16>(p, lds, W, K, a[k], b[k], sa, sb, colda, coldb, (t * 8 + k) & 63, direct);
+			// (written out: with the zipped step's larger body hipcc left the loop rolled and both tiles in scratch)
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[0], b[0], sa, sb, colda, coldb, (t * 8 + 0) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[1], b[1], sa, sb, colda, coldb, (t * 8 + 1) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[2], b[2], sa, sb, colda, coldb, (t * 8 + 2) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[3], b[3], sa, sb, colda, coldb, (t * 8 + 3) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[4], b[4], sa, sb, colda, coldb, (t * 8 + 4) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[5], b[5], sa, sb, colda, coldb, (t * 8 + 5) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[6], b[6], sa, sb, colda, coldb, (t * 8 + 6) & 63, direct);
+			WideChunk2<N16, ZIP>(p, lds, W, K, a[7], b[7], sa, sb, colda, coldb, (t * 8 + 7) & 63, direct);
 			if (lane == (myTiles * 0x9E3779B1u) >> 26) {   // visit samples: one lane per wave per tile, behind it (WidePhase)
-				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sa, 1u);
-				atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + sb, 1u);
+				WideSample<ZIP>(p, lds, W, sa);
+				WideSample<ZIP>(p, lds, W, sb);
 			}
 			if (t & 1)   // wave-wide early out (multi.h:955-958), every other tile
-				done = __all(((WideEntry(sa, K.pitch, K.flagsOff) & WideEntry(sb, K.pitch, K.flagsOff)) & kAbsorbing) != 0);
+				done = __all(((WideFlags<ZIP>(sa, K) & WideFlags<ZIP>(sb, K)) & kAbsorbing) != 0);
 		}
 		uint32_t enda = sa < p.wide ? sa : colda, endb = sb < p.wide ? sb : coldb;
 		if (!done) {   // the tail shorter than a tile: exact steps straight from memory
@@ -274,7 +276,7 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 		return rc;
 	ScanParams q = p;
 	q.n = p.n & ~uint64_t(63);   // whole 64-string tasks; the remainder goes to the generic kernel below
-	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0);
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, p.zipFull);
 	int rc;
 	// Two forms (same results): one string per lane and a ring of two tiles, or two strings per lane (ScanWide2Kernel).
 	// A wave of the second walks its two strings in the time a wave of the first walks one and one more (3.6 against 4.0
@@ -284,24 +286,27 @@ int LaunchWide(const ScanParams& p, hipStream_t stream)
 	// steps outside the rows, 1.36 against 1.04 with 12 %: the loads of the walk beyond the rows are what the time goes into
 	// there, and two chains per lane have two of them on their way; 1.09 against 0.97 with 17 %, the same (0.60-0.65) from 29 % on.
 	// Smaller batches: one string per lane, more waves (2^18 strings, 3 % outside the rows: 1.09 against 1.05,
-	// r05m_wide_small_batches.txt).  walk_variant 2 / 3 force one.
+	// r05m_wide_small_batches.txt).  walk_variant 2 / 3 force one; ScanParams::forceLanes (the first-use self-test) another.
 	const pire_hip_config cfg = GetConfig();
 	int cus = 0;
 	if (int rc = DeviceCUs(&cus))
 		return rc;
-	const bool two = cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.n >= uint64_t(cus) * 16 * 128);
+	const bool two = p.forceLanes ? p.forceLanes == 2 : cfg.walk_variant == 3 || (cfg.walk_variant != 2 && p.n >= uint64_t(cus) * 16 * 128);
 	if (two)
 		q.n = p.n & ~uint64_t(127);   // whole 128-string tasks
 	if (p.wideLaunched)
 		p.wideLaunched->fetch_add(q.n / 64 * (p.len / 16), std::memory_order_relaxed);
 	if (q.n == 0) {
 		rc = PIRE_HIP_OK;
+	} else if (p.zipFull) {   // (a zipped image implies the u16 table: table.cpp ChooseZip)
+		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u16 table, zipped rows>" : "pirehip::ScanWideKernel<u16 table, zipped rows>");
+		rc = two ? LaunchScan(ScanWide2Kernel<true, true>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<true, true>, q, 1024, W.total, stream, 1);
 	} else if (p.next16) {
 		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u16 table>" : "pirehip::ScanWideKernel<u16 table>");
-		rc = two ? LaunchScan(ScanWide2Kernel<true>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<true>, q, 1024, W.total, stream, 1);
+		rc = two ? LaunchScan(ScanWide2Kernel<true, false>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<true, false>, q, 1024, W.total, stream, 1);
 	} else {
 		NoteKernel("wide", two ? "pirehip::ScanWide2Kernel<u32 table>" : "pirehip::ScanWideKernel<u32 table>");
-		rc = two ? LaunchScan(ScanWide2Kernel<false>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<false>, q, 1024, W.total, stream, 1);
+		rc = two ? LaunchScan(ScanWide2Kernel<false, false>, q, 1024, W.total, stream, 1) : LaunchScan(ScanWideKernel<false, false>, q, 1024, W.total, stream, 1);
 	}
 	if (rc != PIRE_HIP_OK || q.n == p.n)
 		return rc;

@@ -10,13 +10,66 @@ namespace pirehip {
 struct WideConst {
 	uint32_t pitch;    // bytes per row
 	uint32_t flagsOff; // byte offset of a row's flags (2 * letters)
+	uint32_t full;     // states with a row of their own (== p.wide unless the image is zipped)
+	uint32_t hOff;     // zipped image: LDS byte address of the headers
+	uint32_t xRel;     // zipped image: xOff - 6 * full (state st's exception targets are at st * 6 + xRel)
 };
+
+__device__ __forceinline__ WideConst MakeWideConst(const ScanParams& p, const WideLayout& W)
+{
+	WideConst K;
+	K.pitch = W.pitch;
+	K.flagsOff = p.letters * 2;
+	K.full = W.full;
+	K.hOff = W.hOff;
+	K.xRel = W.xOff - 2 * kZipExceptions * W.full;
+	return K;
+}
+
+typedef const __attribute__((address_space(3))) uint32_t* LdsU32Ptr;
 
 // A row entry: the u16 at byte `c2` (2 * letter class) of state `st`'s row.  The rows start at LDS byte 256: the DS
 // instruction's immediate offset, so the address is ONE v_mad_u32_u24.
-__device__ __forceinline__ uint32_t WideEntry(uint32_t st, uint32_t pitch, uint32_t c2)
+// ZIP (internal.h MakeWideLayout): the state's header first -- the row it leans on and the <= 3 letters it differs in --,
+// then ONE u16 read: the exception's target if the letter is one of them, else that row's entry.  (c2 * 0x4081 puts the
+// class into the three letter fields at once; a field of the xor that is zero is a match, and a state's letters are distinct.)
+template <bool ZIP>
+__device__ __forceinline__ uint32_t WideEntry(uint32_t st, const WideConst& K, uint32_t c2)
 {
-	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(st, pitch) + c2 + 256u));
+	if constexpr (!ZIP) {
+		return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(st, K.pitch) + c2 + 256u));
+	} else {
+		const uint32_t h = *reinterpret_cast<LdsU32Ptr>(static_cast<uintptr_t>(K.hOff + (st << 2)));
+		const uint32_t x = h ^ __umul24(c2, kZipMulC2);
+		const uint32_t xa = __umul24(st, 2 * kZipExceptions) + K.xRel;
+		uint32_t a = __umul24(h >> 22, K.pitch) + c2 + 256u;
+		a = (x & 0x3F8000u) ? a : xa + 4;
+		a = (x & 0x007F00u) ? a : xa + 2;
+		a = (x & 0x0000FEu) ? a : xa;
+		return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(a));
+	}
+}
+
+// The flags of a state of the tier (the escape state's: 0).  Zipped image: only states with a row of their own have any
+// the walk looks at (an absorbing state keeps its row, table.cpp PlanZip).
+template <bool ZIP>
+__device__ __forceinline__ uint32_t WideFlags(uint32_t st, const WideConst& K)
+{
+	const uint32_t row = ZIP ? (st < K.full ? st : K.full) : st;
+	return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(row, K.pitch) + K.flagsOff + 256u));
+}
+
+// One visit sample of tier state `st` (or of the escape state: the lane is outside the tier).  The counters of the states
+// with a row are in LDS (the hot ones: same-address atomics); the zipped states' go straight to memory (each carries little).
+template <bool ZIP>
+__device__ __forceinline__ void WideSample(const ScanParams& p, uint8_t* lds, const WideLayout& W, uint32_t st)
+{
+	if (!ZIP || st < W.full)
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + st, 1u);
+	else if (st == p.wide)
+		atomicAdd(reinterpret_cast<uint32_t*>(lds + W.histOff) + W.full, 1u);
+	else
+		atomicAdd(&p.visitWide[st], 1u);
 }
 
 // The exact step for a state without a row (device ids in and out).
@@ -59,7 +112,7 @@ __device__ __forceinline__ uint32_t WideNextC2(const ScanParams& p, uint32_t st,
 // AdaptTable), so that the measured share of the steps outside the rows is a share.  (The first form sampled one fixed lane of 64 at the chunk's end,
 // like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
 // rows were there for 1 530 visited states 36 % of all wave-chunks were walked twice, profiles/r05_pmc_wide_first.txt.)
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
                                               uint32_t st0, uint32_t& st, uint32_t& cold, uint32_t sampleStep)
 {
@@ -82,7 +135,7 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 		for (uint32_t k = 0; k < 4; ++k) {
 			const uint32_t c2n = HotLookup(k < 3 ? (x >> (8 * k + 8)) & 0xFFu : v.x & 0xFFu);   // the next byte's (behind the 16th: unused)
 			// the row's entry (a state without a row reads the escape row: "no row") ...
-			const uint32_t e = WideEntry(sid < p.wide ? sid : p.wide, K.pitch, c2);
+			const uint32_t e = WideEntry<ZIP>(sid < p.wide ? sid : p.wide, K, c2);
 			uint32_t next = e;
 			if (e == p.wide) {   // ... and, for the lanes it sends outside the rows or that are there already, the table in memory
 				next = WideNextC2<N16>(p, sid, c2);
@@ -107,7 +160,7 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 // - 4 % where 30 % are -- which is where this form of the kernel runs when the batch fills the chip -- and the ranking the
 // next adapt() took from its samples cost the two-strings form 8 % on dict_10k / k512; with "two chunks in a row before a
 // wave stops trying the rows" on top: the same.  Not kept.)
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
                                           uint32_t& st, uint32_t& cold, uint32_t sampleLane)
 {
@@ -120,13 +173,13 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
 		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
 		const uint32_t c3 = HotLookup(x >> 24);
-		st = WideEntry(st, K.pitch, c0);
-		st = WideEntry(st, K.pitch, c1);
-		st = WideEntry(st, K.pitch, c2);
-		st = WideEntry(st, K.pitch, c3);
+		st = WideEntry<ZIP>(st, K, c0);
+		st = WideEntry<ZIP>(st, K, c1);
+		st = WideEntry<ZIP>(st, K, c2);
+		st = WideEntry<ZIP>(st, K, c3);
 	}
 	if (st == p.wide)
-		WideTrapChunk<N16>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
+		WideTrapChunk<N16, ZIP>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
 }
 
 
@@ -153,7 +206,7 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 // `direct` (wave-uniform, != 0: the wave's count of such chunks): the wave did not try the rows alone first -- its last chunk
 // left them --, all lanes are here and this IS the walk of the chunk; the return value says whether a lane left the rows
 // in it (else: whether to come here directly next time, i.e. yes).
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 va,
                                                    u32x4 vb, uint32_t sa0, uint32_t sb0, uint32_t& sa, uint32_t& sb, uint32_t& colda,
                                                    uint32_t& coldb, uint32_t sampleStep, uint32_t direct)
@@ -186,8 +239,8 @@ __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t*
 			const uint32_t bna = k < 3 ? (xa >> (8 * k + 8)) & 0xFFu : va.x & 0xFFu;
 			const uint32_t bnb = k < 3 ? (xb >> (8 * k + 8)) & 0xFFu : vb.x & 0xFFu;
 			const uint32_t c2an = HotLookup(bna), c2bn = HotLookup(bnb);
-			const uint32_t ea = WideEntry(ia < p.wide ? ia : p.wide, K.pitch, c2a);
-			const uint32_t eb = WideEntry(ib < p.wide ? ib : p.wide, K.pitch, c2b);
+			const uint32_t ea = WideEntry<ZIP>(ia < p.wide ? ia : p.wide, K, c2a);
+			const uint32_t eb = WideEntry<ZIP>(ib < p.wide ? ib : p.wide, K, c2b);
 			uint32_t na = ea, nb = eb;
 			if (ea == p.wide || eb == p.wide) {
 				if (ea == p.wide)
@@ -227,14 +280,14 @@ __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t*
 // `direct` (wave-uniform, kept by the caller from chunk to chunk): once a chunk left the rows the wave's next chunks skip
 // the attempt on the rows alone -- with 1.7 % of the steps outside them EVERY wave-chunk has such a lane, and the first
 // pass is a quarter of the time for nothing -- until a chunk stays inside them.
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 va,
                                            const u32x4 vb, uint32_t& sa, uint32_t& sb, uint32_t& colda, uint32_t& coldb,
                                            uint32_t sampleLane, uint32_t& direct)
 {
 	const uint32_t sa0 = sa, sb0 = sb;
 	if (direct) {
-		direct = WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, direct);
+		direct = WideTrapChunk2<N16, ZIP>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, direct);
 		return;
 	}
 #pragma unroll
@@ -244,18 +297,18 @@ __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, co
 		const uint32_t a1 = HotLookup((xa >> 8) & 0xFFu), b1 = HotLookup((xb >> 8) & 0xFFu);
 		const uint32_t a2 = HotLookup((xa >> 16) & 0xFFu), b2 = HotLookup((xb >> 16) & 0xFFu);
 		const uint32_t a3 = HotLookup(xa >> 24), b3 = HotLookup(xb >> 24);
-		sa = WideEntry(sa, K.pitch, a0);
-		sb = WideEntry(sb, K.pitch, b0);
-		sa = WideEntry(sa, K.pitch, a1);
-		sb = WideEntry(sb, K.pitch, b1);
-		sa = WideEntry(sa, K.pitch, a2);
-		sb = WideEntry(sb, K.pitch, b2);
-		sa = WideEntry(sa, K.pitch, a3);
-		sb = WideEntry(sb, K.pitch, b3);
+		sa = WideEntry<ZIP>(sa, K, a0);
+		sb = WideEntry<ZIP>(sb, K, b0);
+		sa = WideEntry<ZIP>(sa, K, a1);
+		sb = WideEntry<ZIP>(sb, K, b1);
+		sa = WideEntry<ZIP>(sa, K, a2);
+		sb = WideEntry<ZIP>(sb, K, b2);
+		sa = WideEntry<ZIP>(sa, K, a3);
+		sb = WideEntry<ZIP>(sb, K, b3);
 	}
 	const bool trapped = sa == p.wide || sb == p.wide;
 	if (trapped)
-		WideTrapChunk2<N16>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, 0u);
+		WideTrapChunk2<N16, ZIP>(p, lds, W, K, va, vb, sa0, sb0, sa, sb, colda, coldb, sampleLane & 15u, 0u);
 	const unsigned long long any = __ballot(trapped);
 	direct = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(any) | uint32_t(any >> 32)))) ? 1u : 0u;
 }
@@ -264,7 +317,7 @@ __device__ __forceinline__ void WideChunk2(const ScanParams& p, uint8_t* lds, co
 // state after byte `count` is kept; lanes with count == 0 keep their state (the ragged kernel's last, partial chunk of a
 // string: StepPartial of ragged.hip for this walk).  A lane that left the rows inside its bytes is re-walked exactly,
 // byte by byte through the table in memory (rolled; few lanes, few bytes).
-template <bool N16>
+template <bool N16, bool ZIP>
 __device__ __forceinline__ void WidePartial(const ScanParams& p, const WideConst& K, const u32x4 v, uint32_t count, uint32_t& st,
                                             uint32_t& cold)
 {
@@ -277,7 +330,7 @@ __device__ __forceinline__ void WidePartial(const ScanParams& p, const WideConst
 		for (int j = 0; j < 4; ++j) {
 			if (w == 3 && j == 3)
 				break;
-			h = WideEntry(h, K.pitch, HotLookup((x >> (8 * j)) & 0xFFu));
+			h = WideEntry<ZIP>(h, K, HotLookup((x >> (8 * j)) & 0xFFu));
 			snap = count == uint32_t(4 * w + j + 1) ? h : snap;
 		}
 	}
@@ -305,8 +358,8 @@ __device__ inline void LoadWideToLds(const ScanParams& p, uint8_t* lds, const Wi
 	uint32_t cls8 = 0;
 	if (threadIdx.x < 256)
 		cls8 = p.cls[threadIdx.x];
-	CopyToLds16<4>(lds + W.rowsOff, p.wideRows, (W.rows * W.pitch + 15) / 16);
-	__syncthreads();   // the copy's last unit may reach past the rows
+	CopyToLds16<4>(lds + W.rowsOff, p.wideRows, (W.imageEnd - W.rowsOff) / 16);
+	__syncthreads();   // the copy's last unit may reach past the image
 	if (threadIdx.x < 256)
 		lds[threadIdx.x] = uint8_t(2 * cls8);
 	for (uint32_t i = threadIdx.x; i < W.rows; i += blockDim.x)
@@ -322,9 +375,9 @@ __device__ inline void FlushWide(const ScanParams& p, uint8_t* lds, const WideLa
 	__syncthreads();
 	const uint32_t* hist = reinterpret_cast<const uint32_t*>(lds + W.histOff);
 	const uint32_t* prog = reinterpret_cast<const uint32_t*>(lds + W.progOff);
-	for (uint32_t i = threadIdx.x; i <= p.wide; i += blockDim.x)   // (slot `wide`: samples that found their lane outside the rows)
+	for (uint32_t i = threadIdx.x; i <= W.full; i += blockDim.x)   // (the last slot -> `wide`: samples that found their lane outside the tier)
 		if (hist[i])
-			atomicAdd(&p.visitWide[i], hist[i]);
+			atomicAdd(&p.visitWide[i < W.full ? i : p.wide], hist[i]);
 	if (threadIdx.x == 0 && prog[1]) {
 		atomicAdd(&p.visitHot[kWideTrapSlot], prog[1]);
 		const uint32_t total = atomicAdd(&p.visitHot[kTrapSlot], prog[1]) + prog[1];

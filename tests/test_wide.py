@@ -239,7 +239,7 @@ def test_measured_share_outside_the_wide_rows_is_what_the_oracle_counts(pa, torc
     counts of the same batch under the best possible ranking: the first sampler took lane l at tile l of its string and
     nowhere else, and the share the library reported for a batch like this one was a twentieth of the truth."""
     torch = torch_cuda
-    cfg.set(walk_variant=variant)
+    cfg.set(walk_variant=variant, zip_variant=1)   # (the plain rows: left to itself the library zips this table, tests/test_zip.py)
     entry = W.wide_set("dict_10k")
     blob = W.load_blob(entry["blob"])
     t, o = pa.Table(blob), ob.OracleScanner(blob)

@@ -81,8 +81,11 @@ def point_records(entry, corpus, n, length, reps):
         return bool((gi == oi[order]).all() and (gf == of[order]).all())
 
     total = n * length
-    for variant, label in ((1, "dense"), (2, "wide"), (3, "wide2"), (0, "auto")):
-        pb.set_config(walk_variant=variant, auto_adapt=1)
+    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide,wide2,zip,zip2,auto").split(","))
+    for variant, zipv, label in ((1, 1, "dense"), (2, 1, "wide"), (3, 1, "wide2"), (2, 2, "zip"), (3, 2, "zip2"), (0, 0, "auto")):
+        if label not in only:
+            continue
+        pb.set_config(walk_variant=variant, zip_variant=zipv, auto_adapt=1)
         for _ in range(4):   # the ranking learned from the batch itself, with the walk that is measured
             launch()
             torch.cuda.synchronize()
@@ -99,6 +102,9 @@ def point_records(entry, corpus, n, length, reps):
                       "wave_chunk_share_walked_twice_by_the_wide_walk": round(i2.last_wide_trap_chunks / max(1.0, launches * total / 1024.0), 6),
                       "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6),
                       "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6),
+                      "tier_states": int(i2.wide_states), "states_with_a_row": int(i2.zip_full_states) or int(i2.wide_states),
+                      "plan_share_outside_plain_rows": round(float(i2.zip_plain_outside_share), 6),
+                      "plan_share_outside_zipped_tier": round(float(i2.zip_outside_share), 6),
                       "symbol": pb.last_kernel_symbol()}
     return res
 
@@ -129,8 +135,11 @@ def point_urls(entry, n, reps):
     def launch():
         t.run_device(text.data_ptr(), doffs.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
 
-    for variant, label in ((1, "dense"), (2, "wide"), (0, "auto")):
-        pb.set_config(walk_variant=variant, auto_adapt=1)
+    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide,zip,auto").split(","))
+    for variant, zipv, label in ((1, 1, "dense"), (2, 1, "wide"), (2, 2, "zip"), (0, 0, "auto")):
+        if label not in only:
+            continue
+        pb.set_config(walk_variant=variant, zip_variant=zipv, auto_adapt=1)
         for _ in range(3):
             launch()
             torch.cuda.synchronize()
@@ -144,7 +153,9 @@ def point_urls(entry, n, reps):
         res[label] = {"kernel": kernel, "GBps": round(total / mean / 1e6, 1), "GBps_best": round(total / best / 1e6, 1),
                       "ms": round(mean, 4), "parity_all_strings": bool((gi == oi[None, :]).all() and (gf == of[None, :]).all()),
                       "measured_share_outside_dense_rows": round(float(i2.outside_dense_share), 6),
-                      "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6)}
+                      "measured_share_outside_wide_rows": round(float(i2.outside_wide_share), 6),
+                      "tier_states": int(i2.wide_states), "states_with_a_row": int(i2.zip_full_states) or int(i2.wide_states),
+                      "symbol": pb.last_kernel_symbol()}
     res["listed_share"] = round(float(of.mean()), 4)
     return res
 
