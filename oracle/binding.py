@@ -821,12 +821,15 @@ class RefScanner:
         return cls(L.pire_ref_compile(pats, opts, n, glue_max))
 
     @classmethod
-    def compile_dictionary(cls, words: Sequence[bytes], surround: bool = False):
+    def compile_dictionary(cls, words: Sequence[bytes], surround: bool = False, utf8: bool = False):
         """samples/blacklist/blacklist.cpp:65-76: the words as fixed strings joined with |=, wrapped as the sample wraps
         them (scheme, subdomains, path) or -- `surround` -- searched anywhere in the text (Fsm::Surround)."""
         L = ref_lib()
         arr = (C.c_char_p * len(words))(*[bytes(w) for w in words])
-        return cls(L.pire_ref_compile_dictionary(arr, len(words), 1 if surround else 0))
+        h = L.pire_ref_compile_dictionary(arr, len(words), 2 if utf8 else 1 if surround else 0)
+        if not h:
+            raise RuntimeError(L.pire_ref_last_error().decode())
+        return cls(h)
 
     @classmethod
     def load(cls, blob: bytes):

@@ -167,14 +167,20 @@ void* pire_ref_compile(const char* const* patterns, const char* const* options, 
  *   mode 0: wrapped as the sample does -- "^([a-z]+://)?([A-Za-z0-9\\-]+\\.)*" + words + "(/.*)?$" -- and compiled with
  *           Scanner(Fsm) (multi.h:123-131);
  *   mode 1: the same words Surround()ed (fsm.cpp:1198-1203) like every pattern of tools/bench (bench.cpp:101-102): the
- *           dictionary searched anywhere in a text. */
+ *           dictionary searched anywhere in a text;
+ *   mode 2: as mode 1, every word a PATTERN (letters only) parsed by the lexer with the UTF-8 encoding -- pire_ut.cpp:181-209's
+ *           way to a table of multi-byte letters. */
 void* pire_ref_compile_dictionary(const char* const* words, int n, int mode)
 {
 	try {
 		std::unique_ptr<RefScanner> h(new RefScanner);
 		Pire::Fsm re = Pire::Fsm::MakeFalse();
-		for (int i = 0; i < n; ++i)
-			re |= Pire::Fsm().Append(words[i]);
+		for (int i = 0; i < n; ++i) {
+			if (mode == 2)
+				re |= ParseOne(words[i], "un");   // through the lexer with Encodings::Utf8() (encoding.cpp:99-111, re_lexer.cpp), not Surround()ed yet
+			else
+				re |= Pire::Fsm().Append(words[i]);
+		}
 		if (mode == 0)
 			re = Pire::Lexer("^([a-z]+://)?([A-Za-z0-9\\-]+\\.)*").Parse() + re + Pire::Lexer("(/.*)?$").Parse();
 		else

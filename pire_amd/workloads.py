@@ -134,6 +134,47 @@ def synthetic_domains(n: int, seed: int = 1):
     return out
 
 
+# Mixed-script words for a LARGE-ALPHABET table (BASELINE config 5's wording): Cyrillic, Greek, accented and
+# capitalised Latin syllables, digits -- as UTF-8 some 110 distinct byte values occur, so the scanner the reference compiles
+# from them (lexer with Encodings::Utf8(), pire/encoding.cpp:99-111) has more than 100 letter classes.
+_SYL_CYR = ("ба бе би бо бу ва ве ви во га го да де ди до ду жа же жи за зе зо ка ке ки ко ку ла ле ли ло лу ма ме ми мо му на не ни но "
+            "ну па пе пи по ра ре ри ро ру са се си со су та те ти то ту фа фе хо ца че ша ше щи эк юр яр ый ов ев ин ск ст пр тр "
+            "град мир свет дом код сеть игра новь").split()
+_SYL_GRE = "αλ βα γε δι εκ ζω ηλ θε ικ κα λο μα νε ξυ ομ πα ρο σι τα υπ φι χο ψη ωρ ος ης ον πολ λογ".split()
+_SYL_ACC = ("ré né dé té lé mè prè für grü mü hö kö schö nä lä stra ße ça gar çon ñor se mañ ña pão ção île tô rê sû blå sø ær "
+            "ký ží čes řek ło ść").split()
+_SYL_CAP = ("Ba Be Co Da Fi Go Ha Jo Ka Le Mi No Pa Ra Sa Ti Vo Wa Net Web Shop News Mail Blog Soft Tech Data Cloud Game Play Qu Xe "
+            "Yo Ze Ul Ow Il El Ar Un").split()
+
+
+def synthetic_words_utf8(n: int, seed: int = 2):
+    """n distinct made-up words (bytes, UTF-8), letters and digits only (each is parsed as a PATTERN by the reference's lexer):
+    2-4 syllables of one script -- 45 % Cyrillic, 20 % lower-case Latin, 15 % Greek, 10 % accented Latin, 10 % capitalised
+    Latin with a number behind it; in the order drawn."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    lat = [x for x in _SYL if x.isalpha()]
+    out, seen = [], set()
+    while len(out) < n:
+        r = rng.rand()
+        k = rng.randint(2, 5)
+        if r < 0.45:
+            w = "".join(_SYL_CYR[rng.randint(len(_SYL_CYR))] for _ in range(k))
+        elif r < 0.65:
+            w = "".join(lat[rng.randint(len(lat))] for _ in range(k))
+        elif r < 0.80:
+            w = "".join(_SYL_GRE[rng.randint(len(_SYL_GRE))] for _ in range(k))
+        elif r < 0.90:
+            w = "".join(_SYL_ACC[rng.randint(len(_SYL_ACC))] for _ in range(k))
+        else:
+            w = "".join(_SYL_CAP[rng.randint(len(_SYL_CAP))] for _ in range(min(k, 3))) + str(rng.randint(0, 1000))
+        if w not in seen:
+            seen.add(w)
+            out.append(w.encode("utf-8"))
+    return out
+
+
 def token_stream(seed: int, tokens, weights, nbytes: int):
     """`nbytes` bytes of text: tokens drawn independently with the given weights, back to back (vectorised)."""
     import numpy as np
@@ -167,9 +208,27 @@ def wide_tokens(entry: dict, corpus: str):
     if entry["kind"] == "dictionary":
         k = int(corpus[1:])
         words = dictionary_words(entry)[:k]
-        labels = sorted({w.split(b".")[0] for w in words})
         rng = np.random.RandomState(77)
-        filler = sorted({"".join(_SYL[rng.randint(len(_SYL))] for _ in range(rng.randint(1, 4))).encode() for _ in range(4096)})
+        if entry.get("script") == "utf8":
+            # the words minus their last letter (never a whole dictionary word) and filler of the same scripts' syllables
+            labels = sorted({w.decode("utf-8")[:-1].encode("utf-8") for w in words})
+            syl = _SYL_CYR * 3 + [x for x in _SYL if x.isalpha()] + _SYL_GRE + _SYL_ACC + _SYL_CAP
+            filler = sorted({"".join(syl[rng.randint(len(syl))] for _ in range(rng.randint(1, 4))).encode("utf-8") for _ in range(4096)})
+            # ... none of which may CONTAIN a word of the whole dictionary (two-syllable words occur inside longer ones): the
+            # Surround()ed scanner would be absorbed in its accepting state and the rest of the record skipped
+            every = dictionary_words(entry)
+            first = {}
+            for w in every:
+                first.setdefault(w[:2], []).append(w)
+
+            def clean(tok):
+                return not any(tok.startswith(w, i) for i in range(len(tok) - 1) for w in first.get(tok[i:i + 2], ()))
+
+            labels = [t for t in labels if clean(t)]
+            filler = [t for t in filler if clean(t)]
+        else:
+            labels = sorted({w.split(b".")[0] for w in words})
+            filler = sorted({"".join(_SYL[rng.randint(len(_SYL))] for _ in range(rng.randint(1, 4))).encode() for _ in range(4096)})
         seps = [b" ", b"/", b"\n", b"=", b"_"]
         toks, wts = [], []
         for group, share in ((labels, 0.5), (filler, 0.5)):

@@ -54,7 +54,37 @@ def sample_records(entry, corpus, sc, blob):
             "share_of_steps_in_top_1700_states": round(float(cum[min(1699, len(cum) - 1)]), 6)}
 
 
+def utf8_entries():
+    """Large-alphabet dictionary scanners (round 6; BASELINE config 5's wording): mixed-script words (pire_amd/workloads.py
+    synthetic_words_utf8), every word parsed by the reference's lexer with Encodings::Utf8() (pire/encoding.cpp:99-111; as
+    tests/pire_ut.cpp:181-209 build their UTF-8 scanners), joined with Fsm::operator|= and Surround()ed: > 100 letter classes."""
+    words5k = W.synthetic_words_utf8(5000, seed=2)
+    words_file = write_gz("dict_words_utf8_5k.txt.gz", b"\n".join(words5k) + b"\n")
+    out = []
+    for n in (1000, 5000):
+        name = "dict_utf8_%dk" % (n // 1000)
+        sc = RefScanner.compile_dictionary(words5k[:n], True, utf8=True)
+        blob = sc.save()
+        entry = {"name": name, "kind": "dictionary", "mode": "surround", "script": "utf8", "words": n, "words_file": words_file,
+                 "source": "samples/blacklist/blacklist.cpp:65-76 with every word through Lexer + Encodings::Utf8() (encoding.cpp:99-111)",
+                 "geometry": {"states": sc.size, "letters": sc.letters, "regexps": sc.regexps, "initial": sc.initial, "bufsize": sc.bufsize},
+                 "blob": write_gz(name + ".blob.gz", blob), "blob_sha256": hashlib.sha256(blob).hexdigest(), "samples": {}}
+        for corpus in ("k32", "k512", "k%d" % n):
+            entry["samples"][corpus] = sample_records(entry, corpus, sc, blob)
+            print(name, corpus, {k: v for k, v in entry["samples"][corpus].items() if k.startswith(("distinct", "share"))}, flush=True)
+        out.append(entry)
+    return out
+
+
 def main():
+    if "--only-utf8" in sys.argv:   # keep the other entries of wide.json as they are (their determinisation takes minutes)
+        with open(os.path.join(HERE, "wide.json")) as f:
+            doc = json.load(f)
+        doc["wide"] = [w for w in doc["wide"] if w.get("script") != "utf8"] + utf8_entries()
+        with open(os.path.join(HERE, "wide.json"), "w") as f:
+            json.dump(doc, f, indent=1)
+        print("wrote", len(doc["wide"]), "wide sets")
+        return
     words10k = W.synthetic_domains(10000, seed=1)
     words_file = write_gz("dict_words_10k.txt.gz", b"\n".join(words10k) + b"\n")
     wide = []
@@ -91,6 +121,7 @@ def main():
     entry["samples"]["mix"] = sample_records(entry, "mix", sc, blob)
     print("set_b_mix", {k: v for k, v in entry["samples"]["mix"].items() if k.startswith(("distinct", "share"))}, flush=True)
     wide.append(entry)
+    wide += utf8_entries()
     with open(os.path.join(HERE, "wide.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden_wide.py", "reference": "yandex/pire v0.0.6 (oracle/_ref)", "wide": wide}, f, indent=1)
     print("wrote", len(wide), "wide sets")

@@ -105,7 +105,7 @@ def records_of(entry, corpus, seed, n, length):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,corpus", [("dict_1k", "k32"), ("dict_1k", "k1000"), ("dict_10k", "k2048"), ("dict_10k", "k10000"),
-                                         ("set_b_mix", "mix")])
+                                         ("set_b_mix", "mix"), ("dict_utf8_5k", "k5000")])
 @pytest.mark.parametrize("n,length", [(64, 256), (65, 4096), (1000, 1024), (333, 128 * 5 + 16), (4096 + 7, 512), (128, 4096 + 48)])
 def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     """pire_hip_run_strided with walk_variant = 2: partial waves, odd tile counts, tails shorter than a tile, counters."""
@@ -130,6 +130,46 @@ def test_wide_kernel_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     di, df, _ = dev_run_strided(torch, t, d)
     assert pb.last_kernel() in ("tiled", "generic")
     assert (di == oi).all() and (df == of).all()
+
+
+_EARLY = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walk,zipv", [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2)])
+def test_early_out_between_chained_tasks(pa, torch_cuda, cfg, walk, zipv):
+    """Several tasks per wave, an even number of tiles per record (the ring of two register tiles runs straight through task
+    boundaries), and two tasks out of three whose 64 records ALL reach the absorbing state in their first tile: the wave-wide
+    early-out (multi.h:955-958) ends such a task with a tile still on its way, and the next task must not see it.  Round 5's
+    ScanWideKernel waited for that tile behind the loop, where hipcc had already copied the slot: 557 of 2^20 strings of a
+    corpus like this one came out wrong (round 6).  Every fixed-length kernel, every string against the oracle."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    cfg.set(walk_variant=walk, zip_variant=zipv)
+    entry = W.wide_set("dict_1k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    n, length = 2 * cus * 16 * 64 + 64 * 37, 512          # two tasks (of 64 strings) for every wave slot of the chip, and a few more
+    key = (n, length)
+    if _EARLY.get("key") != key:
+        data = records_of(entry, "k128", 12345, n, length).copy()
+        word = np.frombuffer(W.dictionary_words(entry)[7], dtype=np.uint8)
+        planted = ((np.arange(n) // 64) % 3) != 0
+        data[planted, 3:3 + len(word)] = word
+        oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=8)
+        assert of[planted].all() and not of[~planted].any()
+        _EARLY.update(key=key, data=data, oi=oi, of=of)
+    data, oi, of = _EARLY["data"], _EARLY["oi"], _EARLY["of"]
+    d = torch.as_tensor(data, device="cuda")
+    for _ in range(2):
+        gi, gf, cnt = dev_run_strided(torch, t, d)
+        assert pb.last_kernel() in ("wide", "tiled") and ("zipped" in pb.last_kernel_symbol()) == (zipv == 2 and walk != 1)
+        bad = np.nonzero((gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (len(bad), bad[:10].tolist(), (bad[:10] // 64).tolist())
+        assert (cnt == expected_counts(o, oi, of)).all()
+        t.adapt()
 
 
 @pytest.mark.gpu

@@ -49,7 +49,7 @@ def walk_zip(t, z, strings):
 
 
 @pytest.mark.parametrize("name,corpus", [("dict_1k", "k1000"), ("dict_10k", "k2048"), ("dict_10k", "k10000"), ("blacklist_10k", "urls"),
-                                         ("set_b_mix", "mix")])
+                                         ("set_b_mix", "mix"), ("dict_utf8_1k", "k1000"), ("dict_utf8_5k", "k5000")])
 def test_zipped_image_walks_like_the_reference(cfg, name, corpus):
     import pire_amd
 
@@ -109,7 +109,8 @@ def test_zip_needs_a_measurement_or_an_order(cfg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,corpus", [("dict_1k", "k1000"), ("dict_10k", "k2048"), ("dict_10k", "k10000"), ("set_b_mix", "mix")])
+@pytest.mark.parametrize("name,corpus", [("dict_1k", "k1000"), ("dict_10k", "k2048"), ("dict_10k", "k10000"), ("set_b_mix", "mix"),
+                                         ("dict_utf8_1k", "k1000"), ("dict_utf8_5k", "k5000")])
 @pytest.mark.parametrize("n,length", [(64, 256), (65, 4096), (1000, 1024), (333, 128 * 5 + 16), (4096 + 7, 512), (128, 4096 + 48)])
 def test_zipped_kernels_vs_oracle(pa, torch_cuda, cfg, name, corpus, n, length):
     """pire_hip_run_strided on the zipped image, one and two strings per lane: partial waves, odd tile counts, tails, counters."""
