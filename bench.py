@@ -84,6 +84,9 @@ def parse():
     ap.add_argument("--walk", type=int, default=0, choices=[0, 1, 2],
                     help="pire_hip_config.walk_variant: 0 the library's choice between the dense rows and the class-indexed "
                          "walk, 1 always the dense rows, 2 always the class-indexed walk (same results)")
+    ap.add_argument("--zip", type=int, default=0, choices=[0, 1, 2],
+                    help="pire_hip_config.zip_variant: 0 the library's choice of the class-indexed walk's LDS image (zipped once adapt() "
+                         "has measured the scans leaving the plain rows), 1 never zipped, 2 always (same results)")
     ap.add_argument("--one-string", action="store_true", help="with --corpus cxx: the whole text as ONE string")
     ap.add_argument("--cpu-sample-log2", type=int, default=20, help="strings in the CPU baseline sample = 2^this")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -386,7 +389,7 @@ def main():
 
     # The library re-ranks a table's dense rows by itself when scans keep leaving them (pire_hip_config.auto_adapt).
     # Here the ranking is learned explicitly, on a held-out corpus (step 1 below), and must not move afterwards: off.
-    pb.set_config(auto_adapt=1, walk_variant=args.walk)
+    pb.set_config(auto_adapt=1, walk_variant=args.walk, zip_variant=args.zip)
     wide_entry = None
     try:
         wide_entry = W.wide_set(args.set)   # tests/golden/wide.json: dictionary scanners, token-mixture corpora
@@ -456,7 +459,7 @@ def main():
     settle = max(0, args.settle)
     cold_steps = max(1, min(args.steps, 10))
     cold_launches = max(0, args.cold_launches)
-    total_steps = 2 * (settle + args.warmup) + cold_steps + args.steps + cold_launches + 8
+    total_steps = 3 * (settle + args.warmup) + 2 * cold_steps + args.steps + cold_launches + 24
     counts_all = torch.zeros((total_steps + 16 if args.reduce_every_step else 16, table.RegexpsCount + 2), dtype=torch.int64,
                              device=dev)
     row_no = [0]
@@ -533,9 +536,14 @@ def main():
     if not args.no_adapt:
         n2 = max(64, min(n, 1 << 18))
         if wide_entry:
-            n2 = min(n2, 16384)
-            text2 = torch.as_tensor(W.wide_records(wide_entry, args.corpus, SEED_HELDOUT, n2, length), device=dev)
-            heldout = f"token corpus {args.corpus!r}, seed {SEED_HELDOUT:#x}, {n2} records"
+            # a held-out base of 16 384 records, repeated (rotated) like the timed text: a working set of 10 000 states whose deep
+            # ones carry 1e-5 of the steps each leaves a visit sample of every one of them only in a batch of this size (the
+            # samples are one lane per wave and 128-byte tile, and one re-walk in 64) -- round 5 ranked such tables from 64 MB
+            nb2 = min(n2, 16384)
+            base2 = torch.as_tensor(W.wide_records(wide_entry, args.corpus, SEED_HELDOUT, nb2, length), device=dev)
+            text2 = base2.index_select(0, torch.as_tensor(W.rotated_repeat_order(n2, nb2), device=dev)).contiguous()
+            del base2
+            heldout = f"token corpus {args.corpus!r}, seed {SEED_HELDOUT:#x}, {nb2} records repeated to {n2}"
         elif args.corpus == "cxx":
             # another cut of the same kind of text: the file reversed line by line would be another language; use the
             # text shifted by half a file and scanned as records of the same length
@@ -567,6 +575,32 @@ def main():
     cold_table.upload()
     cold_elapsed, cold_ms = timed(cold_table, cold_steps, settle + args.warmup)
     del cold_table
+    # --- 2b. (round 6) the same for a caller that only ENQUEUES and never calls adapt(): a third handle under the library's default
+    # policy (auto_adapt = 0: such calls start a re-ranking in the background and swap it in at a later launch boundary; the walk
+    # follows the trap signal meanwhile) -- a handful of passes on the timed corpus with nothing but the caller's own stream
+    # synchronisation between them, then a short timed leg.  Reported as value_enqueue_only_no_adapt.
+    enq = None
+    if not args.no_adapt and not args.one_string:
+        pb.set_config(auto_adapt=0)
+        enq_table = pire_amd.Table(blob)
+        enq_table.upload()
+        enq_row = next_row()
+        passes = 0
+        for passes in range(1, 13):
+            step(enq_table, enq_row)
+            torch.cuda.synchronize()
+            time.sleep(0.03)
+            if enq_table.refresh_info().adaptations >= 2:
+                break
+        enq_elapsed, enq_ms = timed(enq_table, cold_steps, settle + args.warmup)
+        ei = enq_table.refresh_info()
+        enq = {"value": round(float(n) * length * cold_steps * world / enq_elapsed / 1e9, 2), "kernel": pb.last_kernel_symbol(),
+               "kernel_avg_ms": round(float(np.mean(enq_ms)), 4), "passes_before_the_timed_leg": passes,
+               "adaptations_in_the_background": int(ei.adaptations), "explicit_adapt_calls": 0,
+               "what": "a fresh table, pire_hip_config defaults, PIRE_HIP_RUN_ON_DEVICE calls only; between the passes the caller "
+                       "synchronises its own stream and sleeps 30 ms"}
+        del enq_table
+        pb.set_config(auto_adapt=1)
     # --- 3. the timed region: settle + W warm-up passes, fence, exactly K passes, fence
     elapsed, kernel_ms = timed(table, args.steps, settle + args.warmup)
     per_rank_timed = list(per_rank)   # of THIS leg (the from-idle leg below overwrites per_rank)
@@ -648,11 +682,18 @@ def main():
             "dtype": "u8",
             "data": data,
             "value_before_adapt": round(float(n) * length * cold_steps * world / cold_elapsed / 1e9, 2),
+            "value_enqueue_only_no_adapt": enq["value"] if enq else None,
+            "enqueue_only_no_adapt": enq,
             "config": {
                 "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), {shape}, "
                             f"Begin().Run().End() per string, match-count reduce",
                 "patterns": big["patterns"],
-                "walk": {"variant_asked": args.walk, "wide_rows": info.wide_states, "wide_lds_bytes": info.wide_lds_bytes,
+                "walk": {"variant_asked": args.walk, "zip_variant_asked": args.zip, "wide_rows": info.wide_states,
+                         "states_with_a_row_of_their_own": info.zip_full_states or info.wide_states,
+                         "image": "zipped (header + <= 3 exceptions for the states without a row)" if info.zip_full_states else "plain rows",
+                         "plan_share_outside_plain_rows": round(float(info.zip_plain_outside_share), 6),
+                         "plan_share_outside_zipped_tier": round(float(info.zip_outside_share), 6),
+                         "wide_lds_bytes": info.wide_lds_bytes,
                          "measured_share_outside_dense_rows": round(float(info.outside_dense_share), 6),
                          "measured_share_outside_wide_rows": round(float(info.outside_wide_share), 6),
                          "shares_measured": bool(info.shares_measured)},

@@ -121,12 +121,15 @@ typedef struct pire_hip_config {
 	uint32_t slow_sets_in_memory;  /* 1: the wave-per-string form keeps its state sets in device memory                 */
 	uint32_t slow_no_list;         /* 1: never the 16-slot list kernel: bitset kernel (<= 256 states) / wave per string   */
 	/* adaptation of the dense-row ranking */
-	uint32_t auto_adapt;           /* re-rank the dense rows by itself when scans keep leaving them (see                 */
-	                               /* pire_hip_table_adapt()): 0 default = at the start of calls that synchronise anyway */
-	                               /* (host-pointer forms, HOST_OFFSETS) -- an adaptation drains the device              */
-	                               /* (hipDeviceSynchronize), so it never runs inside a call that only enqueues;         */
-	                               /* 1 never; 2 at every launch boundary, ON_DEVICE calls included (such a call may     */
-	                               /* then block and is not capturable)                                                  */
+	uint32_t auto_adapt;           /* re-rank the LDS rows by itself when scans keep leaving them (see                   */
+	                               /* pire_hip_table_adapt()): 0 default = in calls that synchronise anyway (host-pointer */
+	                               /* forms, HOST_OFFSETS) right there -- the device is drained (hipDeviceSynchronize) --, */
+	                               /* and in calls that only enqueue (ON_DEVICE) IN THE BACKGROUND: a worker thread copies */
+	                               /* the counters on a stream of its own, re-ranks a copy of the table, uploads the new   */
+	                               /* image, and a later launch boundary swaps it in -- such a call never waits for the    */
+	                               /* device and stays legal inside a stream capture; 1 never; 2 at every launch boundary, */
+	                               /* draining the device, ON_DEVICE calls included (such a call may then block and is not */
+	                               /* capturable); 3 round 5's default: never inside a call that only enqueues             */
 	uint32_t auto_adapt_min_traps; /* sampled trap count since the last ranking that triggers it (default 256)          */
 	/* offset batches (pire_hip_run) */
 	uint32_t ragged_variant;       /* 0 default: large offset batches (>= 160 MiB of text when the host knows the lengths, */

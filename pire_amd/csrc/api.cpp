@@ -202,6 +202,20 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->outsideDense = h.outsideDense;
 	p->outsideWide = h.outsideWide;
 	p->massMeasured = h.massMeasured;
+	if (!h.massMeasured && d.trapSignalHost) {
+		// A table nobody has adapted yet: what its scans so far left in the trap signal (mapped host memory: a read) says more
+		// about the share of the steps outside the dense rows than the a-priori byte model -- a sampled trap stands for 1 024
+		// lane-steps there.  The choice of the walk (WideWanted) follows it from the launch after the first ones have run.
+		const uint64_t bytes = t->bytesScanned.load(std::memory_order_relaxed);
+		const uint64_t traps = *d.trapSignalHost;
+		if (bytes >= (uint64_t(1) << 22) && traps >= 64) {
+			const float live = float(std::min(1.0, double(traps) * 1024.0 / double(bytes)));
+			if (live > p->outsideDense) {
+				p->outsideDense = live;
+				p->massMeasured = true;
+			}
+		}
+	}
 	p->wideLaunched = &t->wideLaunched;
 	p->incPerm = d.incPerm;
 	p->hotFinalLo = h.hotFinalLo;
@@ -461,6 +475,8 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 		}
 	}
 	NoteKernel(kNames[kind]);
+	if (p.owner && !(p.flags & (1u << 23)))   // (what the live estimate of FillParams divides the trap signal by)
+		p.owner->bytesScanned.fetch_add(p.offsets ? totalBytesHint : p.n * p.len, std::memory_order_relaxed);
 	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : raggedWide ? LaunchRaggedWide(p, workCounter, stream)
 	         : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
@@ -1141,6 +1157,7 @@ void pire_hip_table_destroy(pire_hip_table* t)
 {
 	if (!t)
 		return;
+	JoinBackgroundAdapt(t);
 	FreeAllDeviceTables(t);
 	FreeHalfRows(t);
 	if (t->segProduct)

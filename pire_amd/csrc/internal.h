@@ -12,6 +12,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -353,6 +354,19 @@ struct pire_hip_table {
 	std::shared_mutex adaptMutex;
 	std::atomic<uint32_t> autoAdapts{0};
 	std::atomic<uint64_t> wideLaunched{0};   // wave-chunks handed to the wide walk since the last adapt()
+	std::atomic<uint64_t> bytesScanned{0};   // text bytes handed to the kernels of pire_hip_run[_strided] since the last ranking (where the host knows)
+	// the adaptation a call that only enqueues starts in the background (table.cpp BackgroundAdaptStep): state 0 idle, 1 the
+	// worker is on its way, 2 `host` + `image` (device `device`) are ready to be swapped in at a launch boundary
+	struct Background {
+		std::mutex mutex;                 // start / join / swap, one at a time
+		std::thread thread;
+		std::atomic<int> state{0};
+		std::unique_ptr<pirehip::HostTable> host;
+		pirehip::DeviceTable image;
+		int device = -1;
+		uint64_t trapsAtLastLook = 0;     // the trap signal when a worker last found nothing to do
+		std::atomic<uint32_t> swaps{0};
+	} bg;
 	std::atomic<uint32_t> selfTested[pirehip::kMaxDevices] = {};   // per device, bit k: Dispatch's kernel kind k passed its known-answer
 	                                                               // batch on this table there (api.cpp SelfTest)
 };
@@ -654,6 +668,8 @@ struct Staging {
 // table.cpp
 int BuildHostTable(const void* blob, size_t len, HostTable* out);
 int UploadTable(pire_hip_table* t, DeviceTable* image);   // image of the CURRENT device (built on first use), copied out
+int BuildDeviceImage(const HostTable& h, int dev, DeviceTable* out);   // allocations + copies of a ranked table's image, current device
+void JoinBackgroundAdapt(pire_hip_table* t);   // waits for an adaptation in the background and drops what it prepared
 void EnsureRanked(pire_hip_table* t);
 std::vector<uint16_t> BuildWideRows(const HostTable& h);   // the wide walk's LDS image (WideLayout), current numbering
 // after UploadTable, current device: the per-state distance tables (built on first use)

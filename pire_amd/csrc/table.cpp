@@ -358,7 +358,7 @@ void ChooseZip(HostTable& t, std::vector<uint32_t>& order, const std::vector<dou
 		return;
 	ZipPlan best;
 	double bestInside = -1;
-	for (uint32_t cap : {kZipMaxFull, 767u, 511u}) {
+	for (uint32_t cap : {kZipMaxFull, 767u, 511u, 383u}) {   // (large alphabets: a row is 230 bytes, 23 zipped states)
 		if (cap < t.hot)
 			continue;
 		ZipPlan z = PlanZip(t, order, score, t.hot, cap);
@@ -791,6 +791,11 @@ int BuildHostTable(const void* blob, size_t len, HostTable* out)
 
 namespace {
 
+// The stream image uploads go through: null = plain hipMemcpy (the caller's thread waits for the device's legacy stream,
+// as every first run of a table always did); the background adaptation's worker sets a NON-BLOCKING stream of its own, so that
+// its copies neither wait for the caller's kernels nor hold them up (thread local: only that thread's uploads).
+thread_local hipStream_t g_putStream = nullptr;
+
 template <class T>
 int Put(T** dst, const std::vector<T>& src, uint64_t* total)
 {
@@ -800,7 +805,13 @@ int Put(T** dst, const std::vector<T>& src, uint64_t* total)
 	if (e != hipSuccess)
 		return HipFail(e, "hipMalloc(table)");
 	if (!src.empty()) {
-		e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+		if (g_putStream) {
+			e = hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, g_putStream);
+			if (e == hipSuccess)
+				e = hipStreamSynchronize(g_putStream);   // (`src` is often a temporary)
+		} else {
+			e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+		}
 		if (e != hipSuccess)
 			return HipFail(e, "hipMemcpy(table)");
 	}
@@ -909,8 +920,17 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 		*image = t->devs[dev];
 		return PIRE_HIP_OK;
 	}
+	DeviceTable d;
+	if (int rc = BuildDeviceImage(t->host, dev, &d))
+		return rc;
+	t->devs[dev] = d;
+	*image = d;
+	return PIRE_HIP_OK;
+}
 
-	const HostTable& h = t->host;
+// The device image of a ranked host table on the CURRENT device (`dev`): allocations + copies, nothing else.
+int BuildDeviceImage(const HostTable& h, int dev, DeviceTable* out)
+{
 	const uint32_t N = h.states, C = h.letters;
 	std::vector<uint32_t> nextPerm(size_t(N) * C);
 	std::vector<uint8_t> flagsPerm(N);
@@ -1054,8 +1074,7 @@ int UploadTable(pire_hip_table* t, DeviceTable* image)
 		return rc;
 	}
 	d.device = dev;
-	t->devs[dev] = d;
-	*image = d;
+	*out = d;
 	return PIRE_HIP_OK;
 }
 
@@ -1315,26 +1334,313 @@ int CheckFailures(pire_hip_table* t, uint64_t* out)
 	return PIRE_HIP_OK;
 }
 
+namespace {
+
+// What the scans on a table left in the visit counters of its device images, summed.
+struct SeenCounters {
+	std::vector<uint64_t> hot, cold, wide;
+	uint64_t wideTrapChunks = 0;       // wave-chunks the wide walk walked twice (exact)
+	uint64_t wideOutsideSamples = 0;   // of the wide walk's visit samples (one lane per wave and tile): lanes found outside the tier
+	bool any = false;
+};
+
+// Adds image `d`'s counters (current device) to `seen`.  stream == nullptr: plain copies behind a drained device (the caller
+// synchronised); else asynchronous copies on that (non-blocking) stream, waited for here -- the kernels of other streams go
+// on counting meanwhile: the counters are samples, a torn total is a sample too.
+int ReadCounters(const DeviceTable& d, uint32_t N, uint32_t wideStates, hipStream_t stream, SeenCounters* seen)
+{
+	std::vector<uint32_t> bufHot(kVisitHotSlots), bufCold(N), bufWide(wideStates + 1, 0);
+	hipError_t e;
+	if (stream) {
+		e = hipMemcpyAsync(bufHot.data(), d.visitHot, kVisitHotSlots * 4, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipMemcpyAsync(bufCold.data(), d.visitCold, size_t(N) * 4, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess && d.visitWide && wideStates)
+			e = hipMemcpyAsync(bufWide.data(), d.visitWide, size_t(wideStates + 1) * 4, hipMemcpyDeviceToHost, stream);
+		if (e == hipSuccess)
+			e = hipStreamSynchronize(stream);
+	} else {
+		e = hipMemcpy(bufHot.data(), d.visitHot, kVisitHotSlots * 4, hipMemcpyDeviceToHost);
+		if (e == hipSuccess)
+			e = hipMemcpy(bufCold.data(), d.visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
+		if (e == hipSuccess && d.visitWide && wideStates)
+			e = hipMemcpy(bufWide.data(), d.visitWide, size_t(wideStates + 1) * 4, hipMemcpyDeviceToHost);
+	}
+	if (e != hipSuccess)
+		return HipFail(e, "visit counters");
+	if (seen->hot.empty()) {
+		seen->hot.assign(256, 0);
+		seen->cold.assign(N, 0);
+		seen->wide.assign(wideStates + 1, 0);
+	}
+	seen->any = true;
+	for (uint32_t i = 0; i < 256; ++i)
+		seen->hot[i] += bufHot[i];
+	seen->wideTrapChunks += bufHot[kWideTrapSlot];
+	for (uint32_t i = 0; i < N; ++i)
+		seen->cold[i] += bufCold[i];
+	if (d.visitWide) {
+		for (uint32_t i = 0; i < wideStates; ++i)
+			seen->wide[i] += bufWide[i];
+		seen->wideOutsideSamples += bufWide[wideStates];
+	}
+	return PIRE_HIP_OK;
+}
+
+// The ranking's new scores from the counters (h keeps its numbering; h.seenMass and the statistics are updated).
+// Returns false when nothing left the rows and nothing else asks for a new numbering: the current one covers the traffic.
+struct Scored {
+	std::vector<double> score;
+	bool wideSeen = false;
+	float wideSeenOutside = 0;
+	bool rerank = false;
+};
+
+Scored ScoreFromCounters(HostTable& h, const SeenCounters& seen, uint64_t wideLaunched)
+{
+	const uint32_t N = h.states, H = h.hot;
+	// hot ids are sampled once per wave per 128-byte tile (1 of 64*128 lane-steps), cold ids once per trapped
+	// 16-byte chunk for one rotating lane of 64 (1 of 64*16 lane-steps): bring both to "lane-steps".
+	// The estimates are remembered from one adapt() to the next (halved each time): the counters are samples, a state
+	// that carries 1e-5 of the steps often has none in a given batch, and a ranking from the latest counters alone
+	// dropped such rows at every other call only to see them trap again (URL batches: 35-43 rows changed at EVERY
+	// adapt(), trap re-walks 19 % of the kernel time; profiles/r02_ragged_ablation.log).
+	Scored out;
+	out.score.resize(N);
+	uint64_t coldSamples = 0;
+	if (h.seenMass.size() != N)
+		h.seenMass.assign(N, 0.0);
+	for (uint32_t pid = 0; pid < N; ++pid) {
+		const uint32_t o = h.origOfPerm[pid];
+		double est = double(seen.cold[pid]) * 1024.0;
+		if (pid < H)
+			est += double(seen.hot[pid]) * 8192.0;
+		if (pid < h.wide && pid < seen.wide.size())
+			est += double(seen.wide[pid]) * 8192.0;   // the wide walk samples like the tiled kernel: one lane per wave per tile
+		if (pid >= H)
+			coldSamples += seen.cold[pid];
+		h.seenMass[o] = 0.5 * h.seenMass[o] + est;
+		out.score[o] = h.seenMass[o] + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
+	}
+	h.lastTrapSamples = coldSamples;
+	h.lastWideTrapChunks = seen.wideTrapChunks;
+	if (wideLaunched)   // (no wide launch since the last adapt(): the share stays what it was)
+		h.wideTwiceShare = float(std::min(1.0, double(seen.wideTrapChunks) / double(wideLaunched)));
+	h.massMeasured = true;
+	// The share of the steps outside the wide rows, as the scans since the last adapt() SAW it: of the wide walk's visit
+	// samples (one lane per wave and tile, whatever state it is in) those that found their lane outside the rows.  What
+	// the masses give instead is the share the new ranking would leave outside -- of the states that were sampled:
+	// on long-tailed tables most states outside the rows never are, and the figure is an order of magnitude too low.
+	double wideSamples = double(seen.wideOutsideSamples);
+	for (uint32_t i = 0; i < h.wide && i < seen.wide.size(); ++i)
+		wideSamples += double(seen.wide[i]);
+	out.wideSeen = wideSamples >= 4096.0;
+	out.wideSeenOutside = out.wideSeen ? float(double(seen.wideOutsideSamples) / wideSamples) : 0.0f;
+	// (a zipped table whose traffic no longer leaves the tier: would the plain rows hold it too?  They are the faster walk.)
+	bool unzip = false;
+	if (coldSamples == 0 && h.zipFull && GetConfig().zip_variant != 2) {
+		std::vector<double> sorted(out.score);
+		std::sort(sorted.begin(), sorted.end(), std::greater<double>());
+		const uint32_t plain = WideCapacity(h.letters, h.regexps, N);
+		double total = 0, inside = 0;
+		for (uint32_t i = 0; i < N; ++i) {
+			const double v = std::max(0.0, sorted[i]);
+			total += v;
+			if (i < plain)
+				inside += v;
+		}
+		unzip = total > 0 && 1.0 - inside / total < 0.002;
+	}
+	out.rerank = coldSamples != 0 || unzip;
+	return out;
+}
+
+}  // namespace
+
+// ---- adaptation in the background (round 6) -----------------------------------------------------------------------------
+// A caller that only enqueues (PIRE_HIP_RUN_ON_DEVICE) must never wait for the device inside a call -- and until round 6 its
+// table therefore never adapted unless it knew to call pire_hip_table_adapt() (0.3-0.7 TB/s for ever on tables the
+// a-priori ranking knows little about).  Now such a call, at its launch boundary, may START an adaptation: a worker thread
+// copies the visit counters on a non-blocking stream of its own (the caller's kernels go on), re-ranks a COPY of the host
+// table, uploads the new image on that stream and reports "ready"; a later launch boundary SWAPS table and image in (a few
+// pointer moves under the table's lock; the replaced images stay alive for launches still in flight and for captured graphs,
+// like those of every automatic adaptation).  No call waits for the device, none makes a call that is illegal during stream
+// capture.  pire_hip_table_adapt(), the synchronous automatic adaptation and pire_hip_table_destroy() first wait for a
+// worker that is on its way (and drop what it prepared).
+namespace {
+
+void BackgroundWorker(pire_hip_table* t, int dev)
+{
+	pire_hip_table::Background& bg = t->bg;
+	auto fail = [&]() { bg.state.store(0, std::memory_order_release); };
+	if (hipSetDevice(dev) != hipSuccess)
+		return fail();
+	hipStream_t side = nullptr;
+	if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess)
+		return fail();
+	std::unique_ptr<HostTable> h;
+	DeviceTable cur;
+	uint64_t launched = 0;
+	{
+		// the table as it is now (an adaptation of another kind would have waited for this thread before it took the lock)
+		std::shared_lock<std::shared_mutex> stable(t->adaptMutex);
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		cur = t->devs[dev];
+		if (cur.device == dev)
+			h.reset(new HostTable(t->host));
+		launched = t->wideLaunched.exchange(0, std::memory_order_relaxed);
+	}
+	bool ok = h != nullptr;
+	SeenCounters seen;
+	if (ok)
+		ok = ReadCounters(cur, h->states, h->wide, side, &seen) == PIRE_HIP_OK;
+	DeviceTable image;
+	if (ok) {
+		try {
+			Scored sc = ScoreFromCounters(*h, seen, launched);
+			if (sc.rerank) {
+				PermuteByScore(*h, sc.score);
+				if (sc.wideSeen)
+					h->outsideWide = sc.wideSeenOutside;
+				h->adaptations++;
+				g_putStream = side;
+				ok = BuildDeviceImage(*h, dev, &image) == PIRE_HIP_OK;
+				g_putStream = nullptr;
+			} else {
+				ok = false;   // nothing to do: the rows cover the traffic
+				std::lock_guard<std::mutex> lock(t->uploadMutex);
+				if (t->devs[dev].device == dev && t->devs[dev].trapSignalHost)
+					bg.trapsAtLastLook = *t->devs[dev].trapSignalHost;
+			}
+		} catch (...) {
+			g_putStream = nullptr;
+			ok = false;
+		}
+	}
+	(void)hipStreamDestroy(side);
+	(void)hipGetLastError();
+	if (!ok) {
+		if (image.device >= 0 || image.hotRows)
+			FreeDeviceTable(&image);
+		return fail();
+	}
+	bg.host = std::move(h);
+	bg.image = image;
+	bg.device = dev;
+	bg.state.store(2, std::memory_order_release);
+}
+
+}  // namespace
+
+// Waits for a background adaptation that is on its way and drops what it prepared (the caller is about to rank the table itself,
+// or to destroy it).
+void JoinBackgroundAdapt(pire_hip_table* t)
+{
+	pire_hip_table::Background& bg = t->bg;
+	std::lock_guard<std::mutex> one(bg.mutex);
+	if (bg.thread.joinable())
+		bg.thread.join();
+	if (bg.state.load(std::memory_order_acquire) == 2) {
+		int cur = -1;
+		(void)hipGetDevice(&cur);
+		if (bg.image.device >= 0 && hipSetDevice(bg.image.device) == hipSuccess)
+			FreeDeviceTable(&bg.image);
+		if (cur >= 0)
+			(void)hipSetDevice(cur);
+		bg.host.reset();
+		bg.image = DeviceTable();
+	}
+	bg.state.store(0, std::memory_order_release);
+}
+
+namespace {
+
+// A launch boundary of an enqueue-only call: swap in what a finished worker prepared; start a worker when the scans since the
+// last ranking left the rows often enough.  Never waits for the device.
+void BackgroundAdaptStep(pire_hip_table* t, uint64_t threshold)
+{
+	pire_hip_table::Background& bg = t->bg;
+	const int state = bg.state.load(std::memory_order_acquire);
+	if (state == 1)
+		return;   // on its way
+	if (state == 2) {
+		std::unique_lock<std::mutex> one(bg.mutex, std::try_to_lock);
+		if (!one.owns_lock() || bg.state.load(std::memory_order_acquire) != 2)
+			return;
+		if (bg.thread.joinable())
+			bg.thread.join();   // (it has stored "ready": it is past its last instruction that matters)
+		std::unique_lock<std::shared_mutex> exclusive(t->adaptMutex);   // entry points between "copied the pointers" and "enqueued" finish first
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		// every image holds the old numbering: they stay alive (launches in flight, captured graphs) until the table is destroyed
+		for (int k = 0; k < kMaxDevices; ++k)
+			if (t->devs[k].device >= 0) {
+				t->retired.push_back(t->devs[k]);
+				t->devs[k] = DeviceTable();
+			}
+		t->host = std::move(*bg.host);
+		bg.host.reset();
+		t->devs[bg.device] = bg.image;
+		bg.image = DeviceTable();
+		bg.trapsAtLastLook = 0;
+		t->bytesScanned.store(0, std::memory_order_relaxed);
+		t->autoAdapts.fetch_add(1, std::memory_order_relaxed);
+		bg.swaps.fetch_add(1, std::memory_order_relaxed);
+		bg.state.store(0, std::memory_order_release);
+		return;
+	}
+	if (t->autoAdapts.load(std::memory_order_relaxed) >= kMaxAutoAdapts)
+		return;
+	int dev = -1;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices)
+		return;
+	uint64_t traps = 0;
+	{
+		std::lock_guard<std::mutex> lock(t->uploadMutex);
+		if (t->devs[dev].device != dev || !t->devs[dev].trapSignalHost)
+			return;
+		traps = *t->devs[dev].trapSignalHost;
+	}
+	if (traps < threshold || traps < bg.trapsAtLastLook + threshold)
+		return;
+	std::unique_lock<std::mutex> one(bg.mutex, std::try_to_lock);
+	if (!one.owns_lock() || bg.state.load(std::memory_order_acquire) != 0)
+		return;
+	if (bg.thread.joinable())
+		bg.thread.join();
+	bg.state.store(1, std::memory_order_release);
+	try {
+		bg.thread = std::thread(BackgroundWorker, t, dev);
+	} catch (...) {
+		bg.state.store(0, std::memory_order_release);
+	}
+}
+
+}  // namespace
+
 // The policy behind pire_hip_config.auto_adapt.  Every launch boundary looks at the trap totals the images' blocks have
 // stored into mapped host memory (no synchronisation, no transfer: a read of a few host words); once the scans since the
 // last ranking left the dense rows more than `auto_adapt_min_traps` sampled times (default 256 samples ~ 256 Ki
-// lane-steps re-walked) the table is re-ranked right there -- the device is drained (hipDeviceSynchronize), the counters
-// read, the rows re-ranked, the images replaced -- and the launch that noticed goes on
-// with the new image.  Because of that drain the DEFAULT (auto_adapt = 0) re-ranks only inside calls that synchronise
-// anyway -- the host-pointer forms, and pire_hip_run with PIRE_HIP_RUN_HOST_OFFSETS -- and never inside a call that only
-// enqueues work (PIRE_HIP_RUN_ON_DEVICE: legal during stream capture, no stall of other streams; round 3 drained the
-// device there too, VERDICT r3 / ADVICE r3); a caller of the enqueue-only forms calls pire_hip_table_adapt() between
-// batches, or sets auto_adapt = 2 (every launch boundary).  A table adapts itself at most kMaxAutoAdapts times: the
-// remembered estimates make the ranking converge within two or three, and a workload whose traffic does
-// not fit 255 rows must not pay a re-ranking per call.
+// lane-steps re-walked) the table is re-ranked.  In a call that synchronises anyway -- the host-pointer forms, and
+// pire_hip_run with PIRE_HIP_RUN_HOST_OFFSETS -- right there: the device is drained (hipDeviceSynchronize), the counters
+// read, the rows re-ranked, the images replaced, and the launch that noticed goes on with the new image.  In a call that only
+// enqueues work (PIRE_HIP_RUN_ON_DEVICE: legal during stream capture, no stall of other streams) IN THE BACKGROUND (round 6,
+// above): such a call never waits; it finds the new image a few launch boundaries later.  auto_adapt = 1: never; 2: every
+// launch boundary drains and re-ranks (round 3's form); 3: round 5's default (never inside a call that only enqueues).
+// A table adapts itself at most kMaxAutoAdapts times: the remembered estimates make the ranking converge within two or three
+// (DESIGN.md 3.1), and a workload whose traffic does not fit the rows must not pay a re-ranking per call.
 void MaybeAutoAdapt(pire_hip_table* t, bool enqueueOnly)
 {
-	if (t->autoAdapts.load(std::memory_order_relaxed) >= kMaxAutoAdapts)
-		return;
 	const pire_hip_config cfg = GetConfig();
-	if (cfg.auto_adapt == 1 || (enqueueOnly && cfg.auto_adapt != 2))
+	if (cfg.auto_adapt == 1)
 		return;
 	const uint64_t threshold = cfg.auto_adapt_min_traps ? cfg.auto_adapt_min_traps : 256;
+	if (enqueueOnly && cfg.auto_adapt != 2) {
+		if (cfg.auto_adapt == 0)
+			BackgroundAdaptStep(t, threshold);
+		return;
+	}
+	if (t->autoAdapts.load(std::memory_order_relaxed) >= kMaxAutoAdapts)
+		return;
 	uint64_t traps = 0;
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
@@ -1351,6 +1657,7 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 {
 	if (changedRows)
 		*changedRows = 0;
+	JoinBackgroundAdapt(t);   // (before the lock: the worker takes it shared)
 	std::unique_lock<std::shared_mutex> exclusive(t->adaptMutex);
 	if (automatic) {
 		// re-check under the lock: another thread may just have done it
@@ -1364,107 +1671,40 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		t->autoAdapts.fetch_add(1, std::memory_order_relaxed);
 	}
 	HostTable& h = t->host;
-	const uint32_t N = h.states, H = h.hot;
+	const uint32_t H = h.hot;
 	// what every device that ever ran this table saw, summed
-	std::vector<uint64_t> hot(256, 0), cold(N, 0), wide(h.wide + 1, 0);
-	uint64_t wideTrapChunks = 0;   // wave-chunks the wide walk walked twice since the last adapt() (exact)
-	uint64_t wideOutsideSamples = 0;   // of the wide walk's visit samples (one lane per wave and tile): lanes found outside the rows
+	SeenCounters seen;
 	{
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
 		hipError_t e = hipGetDevice(&cur);
 		if (e != hipSuccess)
 			return HipFail(e, "hipGetDevice");
-		bool any = false;
-		std::vector<uint32_t> bufHot(kVisitHotSlots), bufCold(N), bufWide(h.wide + 1, 0);
 		for (int k = 0; k < kMaxDevices; ++k) {
 			if (t->devs[k].device < 0)
 				continue;
-			any = true;
-			if ((e = hipSetDevice(k)) == hipSuccess && (e = hipDeviceSynchronize()) == hipSuccess &&
-			    (e = hipMemcpy(bufHot.data(), t->devs[k].visitHot, kVisitHotSlots * 4, hipMemcpyDeviceToHost)) == hipSuccess)
-				e = hipMemcpy(bufCold.data(), t->devs[k].visitCold, size_t(N) * 4, hipMemcpyDeviceToHost);
-			if (e == hipSuccess && t->devs[k].visitWide && h.wide)
-				e = hipMemcpy(bufWide.data(), t->devs[k].visitWide, size_t(h.wide + 1) * 4, hipMemcpyDeviceToHost);
-			if (e != hipSuccess) {
+			int rc = PIRE_HIP_OK;
+			if ((e = hipSetDevice(k)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess)
+				rc = HipFail(e, "visit counters");
+			else
+				rc = ReadCounters(t->devs[k], h.states, h.wide, nullptr, &seen);
+			if (rc != PIRE_HIP_OK) {
 				(void)hipSetDevice(cur);
-				return HipFail(e, "visit counters");
+				return rc;
 			}
-			for (uint32_t i = 0; i < 256; ++i)
-				hot[i] += bufHot[i];
-			wideTrapChunks += bufHot[kWideTrapSlot];
-			for (uint32_t i = 0; i < N; ++i)
-				cold[i] += bufCold[i];
-			if (t->devs[k].visitWide)
-				for (uint32_t i = 0; i < h.wide; ++i)
-					wide[i] += bufWide[i];
-			if (t->devs[k].visitWide)
-				wideOutsideSamples += bufWide[h.wide];
 		}
 		(void)hipSetDevice(cur);
-		if (!any)
+		if (!seen.any)
 			return PIRE_HIP_OK;   // never ran: nothing observed
 	}
-	// hot ids are sampled once per wave per 128-byte tile (1 of 64*128 lane-steps), cold ids once per trapped
-	// 16-byte chunk for one rotating lane of 64 (1 of 64*16 lane-steps): bring both to "lane-steps".
-	// The estimates are remembered from one adapt() to the next (halved each time): the counters are samples, a state
-	// that carries 1e-5 of the steps often has none in a given batch, and a ranking from the latest counters alone
-	// dropped such rows at every other call only to see them trap again (URL batches: 35-43 rows changed at EVERY
-	// adapt(), trap re-walks 19 % of the kernel time; profiles/r02_ragged_ablation.log).
-	std::vector<double> score(N);
-	uint64_t coldSamples = 0;
-	if (h.seenMass.size() != N)
-		h.seenMass.assign(N, 0.0);
-	for (uint32_t pid = 0; pid < N; ++pid) {
-		const uint32_t o = h.origOfPerm[pid];
-		double est = double(cold[pid]) * 1024.0;
-		if (pid < H)
-			est += double(hot[pid]) * 8192.0;
-		if (pid < h.wide)
-			est += double(wide[pid]) * 8192.0;   // the wide walk samples like the tiled kernel: one lane per wave per tile
-		if (pid >= H)
-			coldSamples += cold[pid];
-		h.seenMass[o] = 0.5 * h.seenMass[o] + est;
-		score[o] = h.seenMass[o] + h.priorMass[o];   // prior (<= 1) only orders states nobody has visited yet
-	}
-	h.lastTrapSamples = coldSamples;
-	h.lastWideTrapChunks = wideTrapChunks;
-	{
-		const uint64_t launched = t->wideLaunched.exchange(0, std::memory_order_relaxed);
-		if (launched)   // (no wide launch since the last adapt(): the share stays what it was)
-			h.wideTwiceShare = float(std::min(1.0, double(wideTrapChunks) / double(launched)));
-	}
-	h.massMeasured = true;
-	// The share of the steps outside the wide rows, as the scans since the last adapt() SAW it: of the wide walk's visit
-	// samples (one lane per wave and tile, whatever state it is in) those that found their lane outside the rows.  What
-	// the masses below give instead is the share the new ranking would leave outside -- of the states that were sampled:
-	// on long-tailed tables most states outside the rows never are, and the figure is an order of magnitude too low.
-	double wideSamples = double(wideOutsideSamples);
-	for (uint32_t i = 0; i < h.wide && i < wide.size(); ++i)
-		wideSamples += double(wide[i]);
-	const bool wideSeen = wideSamples >= 4096.0;
-	const float wideSeenOutside = wideSeen ? float(double(wideOutsideSamples) / wideSamples) : 0.0f;
+	t->bytesScanned.store(0, std::memory_order_relaxed);
+	Scored sc = ScoreFromCounters(h, seen, t->wideLaunched.exchange(0, std::memory_order_relaxed));
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());
-	// (a zipped table whose traffic no longer leaves the tier: would the plain rows hold it too?  They are the faster walk.)
-	bool unzip = false;
-	if (coldSamples == 0 && h.zipFull && GetConfig().zip_variant != 2) {
-		std::vector<double> sorted(score);
-		std::sort(sorted.begin(), sorted.end(), std::greater<double>());
-		const uint32_t plain = WideCapacity(h.letters, h.regexps, N);
-		double total = 0, inside = 0;
-		for (uint32_t i = 0; i < N; ++i) {
-			const double v = std::max(0.0, sorted[i]);
-			total += v;
-			if (i < plain)
-				inside += v;
-		}
-		unzip = total > 0 && 1.0 - inside / total < 0.002;
-	}
-	if (coldSamples == 0 && !unzip) {
-		MeasureShares(h, score);   // same numbering, measured masses
-		if (wideSeen)
-			h.outsideWide = wideSeenOutside;
+	if (!sc.rerank) {
+		MeasureShares(h, sc.score);   // same numbering, measured masses
+		if (sc.wideSeen)
+			h.outsideWide = sc.wideSeenOutside;
 		std::lock_guard<std::mutex> lock(t->uploadMutex);
 		int cur = -1;
 		(void)hipGetDevice(&cur);
@@ -1481,9 +1721,9 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		(void)hipSetDevice(cur);
 		return PIRE_HIP_OK;   // nothing trapped: the current rows already cover the traffic
 	}
-	PermuteByScore(h, score);
-	if (wideSeen)
-		h.outsideWide = wideSeenOutside;
+	PermuteByScore(h, sc.score);
+	if (sc.wideSeen)
+		h.outsideWide = sc.wideSeenOutside;
 	std::vector<uint32_t> after(h.origOfPerm.begin(), h.origOfPerm.begin() + h.hot);
 	std::sort(after.begin(), after.end());
 	std::vector<uint32_t> diff;

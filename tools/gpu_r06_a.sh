@@ -4,8 +4,8 @@ set -u
 export PYTHONUNBUFFERED=1 TMPDIR=/tmp PYTHONPATH=.
 OUT=gpurun_out/r06a
 mkdir -p $OUT
-timeout 900 python -m pytest tests/test_zip.py tests/test_wide.py tests/test_selftest.py -m gpu -q 2>&1 | tail -5 | tee $OUT/pytest_zip.log
-WIDE_CASE_LEGS=wide2,zip,zip2,auto timeout 1500 python tools/wide_case.py --log2-strings 20 --points dict_utf8_1k:k32,dict_utf8_1k:k1000,dict_utf8_5k:k512,dict_utf8_5k:k5000,set_b_mix:mix --out $OUT/wide_curve.jsonl 2>&1 | tail -3 > $OUT/wide_curve.log
+true
+WIDE_CASE_LEGS=wide2,zip,zip2,auto timeout 1500 python tools/wide_case.py --log2-strings 20 --points dict_utf8_1k:k32,dict_utf8_1k:k1000,dict_utf8_5k:k512,dict_utf8_5k:k5000 --out $OUT/wide_curve.jsonl 2>&1 | tail -3 > $OUT/wide_curve.log
 python - <<'PY'
 import json
 for l in open("gpurun_out/r06a/wide_curve.jsonl"):
