@@ -386,6 +386,13 @@ def main():
     if world > 1 or args.force_dist:
         pd.init(args.backend, dev)   # "nccl" is RCCL on ROCm
         pd.FORCE_SINGLE_RANK_COLLECTIVES = bool(args.force_dist)
+    # who is here: every rank's host / device / PCI bus id, gathered through the process group itself.  Over RCCL two ranks on ONE
+    # GPU would report N x the throughput of a single device as "N GPUs": refused.
+    rank_devices = pd.describe_ranks(dev)
+    clashes = pd.ranks_sharing_a_device(rank_devices)
+    if args.backend == "nccl" and world > 1 and clashes:
+        raise SystemExit(f"ranks share a GPU {clashes}: {rank_devices} -- one process per GPU (torch.distributed.run --nproc-per-node N "
+                         "on a node with N GPUs); --backend gloo runs the launch path on fewer GPUs for control-flow tests")
 
     # The library re-ranks a table's dense rows by itself when scans keep leaving them (pire_hip_config.auto_adapt).
     # Here the ranking is learned explicitly, on a held-out corpus (step 1 below), and must not move afterwards: off.
@@ -703,6 +710,8 @@ def main():
                           "ranking_learned_on": heldout},
                 "strings_per_gpu": run_n, "string_bytes": run_len, "string_stride": run_stride, "corpus_seed": SEED,
                 "parallelism": f"shard-by-string x{world}",
+                "ranks_seen": len(rank_devices), "per_rank_device": rank_devices, "ranks_sharing_a_device": clashes,
+                "shard_ranges": [list(pd.shard_range(n * world, r, world)) for r in range(world)],
                 "reduce_backend": pd.backend_description(),
                 "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank_timed],
                 "per_rank_kernel_ms": [round(x, 4) for x in timed_stats["kernel_ms_of_ranks"]],

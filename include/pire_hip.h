@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define PIRE_HIP_ABI_VERSION 5
+#define PIRE_HIP_ABI_VERSION 6
 
 enum {
 	PIRE_HIP_OK        =  0,
@@ -312,6 +312,11 @@ int pire_hip_table_check_failures(pire_hip_table* t, uint64_t* out);
 void pire_hip_table_destroy(pire_hip_table* t);
 
 int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out);
+/* pire_hip_table_info has no size field and has grown at its end between ABI versions: a caller built against an older header
+ * passes ITS sizeof and gets the fields it knows (min(size, sizeof) bytes are written) -- or checks pire_hip_abi_version(), what
+ * the loaded library was built as, against its own PIRE_HIP_ABI_VERSION before calling pire_hip_table_get_info. */
+int pire_hip_table_get_info_sized(const pire_hip_table* t, void* out, size_t size);
+uint32_t pire_hip_abi_version(void);
 
 /* ---- per-state queries on the host (no GPU involved) ------------------------------------------- */
 

@@ -132,6 +132,8 @@ class Config(C.Structure):
 NONE = (1 << 64) - 1   # PIRE_HIP_SEGMENT_WARMUP_NONE / PIRE_HIP_SEGMENT_BUDGET_NONE: "really zero", 0 being "the default"
 
 
+ABI_VERSION = 6   # include/pire_hip.h PIRE_HIP_ABI_VERSION
+
 # every symbol include/pire_hip.h declares: (name, restype, argtypes)
 ABI = [
     ("pire_hip_build_info", C.c_char_p, []),
@@ -154,6 +156,8 @@ ABI = [
     ("pire_hip_table_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("pire_hip_table_wide_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                              C.POINTER(C.c_uint32)]),
+    ("pire_hip_table_get_info_sized", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("pire_hip_abi_version", C.c_uint32, []),
     ("pire_hip_table_zip_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -240,6 +244,10 @@ def lib():
                 raise
             fn.restype = res
             fn.argtypes = args
+        # the structs declared above are THIS header's (include/pire_hip.h PIRE_HIP_ABI_VERSION): a library of another version
+        # would write a pire_hip_table_info of another size into them
+        if not os.environ.get("PIRE_HIP_LIB") and hasattr(L, "pire_hip_abi_version") and L.pire_hip_abi_version() != ABI_VERSION:
+            raise ImportError(f"{_LIB_PATH} is ABI version {L.pire_hip_abi_version()}, this binding is {ABI_VERSION}: rebuild")
         _lib = L
     return _lib
 

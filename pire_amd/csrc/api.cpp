@@ -436,8 +436,11 @@ int SelfTest(const ScanParams& p, int kind, const char* name, uint32_t mode)
 				break;
 			}
 	}
-	if (own)
+	if (own) {
+		// (an error path may leave the kernel or a copy on its way: the block goes back to the cache only behind them -- ADVICE r5)
+		(void)hipStreamSynchronize(own);
 		(void)hipStreamDestroy(own);
+	}
 	StagingRelease(block, blockBytes);
 	if (rc == PIRE_HIP_OK && e != hipSuccess)
 		rc = HipFail(e, "self-test");
@@ -469,8 +472,13 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
 		if (mode != 1 && !(p.flags & (1u << 23)) &&   // (bit 23: device_common.h kPermIds, the segmented scan's internal passes)
 		     (hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing == hipStreamCaptureStatusNone)) {
-			if (int rc = SelfTest(p, kind, kNames[kind], mode))
+			if (int rc = SelfTest(p, kind, kNames[kind], mode)) {
+				if (ev0)
+					(void)hipEventDestroy(ev0);
+				if (ev1)
+					(void)hipEventDestroy(ev1);
 				return rc;
+			}
 			p.owner->selfTested[p.workDevice].fetch_or(1u << kind);
 		}
 	}
@@ -1163,6 +1171,23 @@ void pire_hip_table_destroy(pire_hip_table* t)
 	if (t->segProduct)
 		FreeAllDeviceTables(t->segProduct.get());   // the product automaton of the segmented scan's two modes
 	delete t;
+}
+
+uint32_t pire_hip_abi_version(void) { return PIRE_HIP_ABI_VERSION; }
+
+int pire_hip_table_get_info_sized(const pire_hip_table* t, void* out, size_t size)
+try {
+	if (!t || !out) {
+		SetError("null argument");
+		return PIRE_HIP_EINVAL;
+	}
+	pire_hip_table_info full;
+	if (int rc = pire_hip_table_get_info(t, &full))
+		return rc;
+	memcpy(out, &full, std::min(size, sizeof(full)));
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();
 }
 
 int pire_hip_table_get_info(const pire_hip_table* t, pire_hip_table_info* out)

@@ -36,6 +36,9 @@ struct Rccl {
 	int (*GroupEnd)() = nullptr;
 	const char* (*GetErrorString)(int) = nullptr;
 	int (*GetVersion)(int*) = nullptr;
+	int (*CommCount)(ncclComm_t, int*) = nullptr;
+	int (*CommCuDevice)(ncclComm_t, int*) = nullptr;
+	int (*CommUserRank)(ncclComm_t, int*) = nullptr;
 	bool ok = false;
 };
 
@@ -59,6 +62,9 @@ const Rccl& LoadRccl()
 		x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(dlsym(x.handle, "ncclGroupEnd"));
 		x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
 		x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(dlsym(x.handle, "ncclGetVersion"));
+		x.CommCount = reinterpret_cast<decltype(x.CommCount)>(dlsym(x.handle, "ncclCommCount"));
+		x.CommCuDevice = reinterpret_cast<decltype(x.CommCuDevice)>(dlsym(x.handle, "ncclCommCuDevice"));
+		x.CommUserRank = reinterpret_cast<decltype(x.CommUserRank)>(dlsym(x.handle, "ncclCommUserRank"));
 		x.ok = x.CommInitAll && x.CommDestroy && x.AllReduce && x.GroupStart && x.GroupEnd;
 		return x;
 	}();
@@ -320,6 +326,24 @@ try {
 			int version = 0;
 			if (r.GetVersion && r.GetVersion(&version) == kNcclSuccess)
 				m->backend += " " + std::to_string(version);
+			// what the communicator says it is (N > 1 has never run here -- whoever runs it first reads this): the
+			// size every rank's handle reports and the device each one sits on
+			if (r.CommCount && r.CommCuDevice && r.CommUserRank) {
+				std::string ranks;
+				int size0 = -1;
+				bool consistent = true;
+				for (int g = 0; g < ndev; ++g) {
+					int size = -1, dev = -1, rank = -1;
+					(void)r.CommCount(m->comms[g], &size);
+					(void)r.CommCuDevice(m->comms[g], &dev);
+					(void)r.CommUserRank(m->comms[g], &rank);
+					if (g == 0)
+						size0 = size;
+					consistent = consistent && size == size0 && dev == m->devices[g] && rank == g;
+					ranks += (g ? "," : "") + std::to_string(rank) + "@dev" + std::to_string(dev);
+				}
+				m->backend += ", communicator of " + std::to_string(size0) + " ranks [" + ranks + "]" + (consistent && size0 == ndev ? "" : " INCONSISTENT");
+			}
 		} else {
 			m->comms.clear();
 			m->backend = std::string("host (ncclCommInitAll: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error") + ")";

@@ -127,3 +127,40 @@ def backend_description() -> str:
             ver = "?"
         return f"rccl {ver} (torch.distributed backend nccl, HIP {torch.version.hip})"
     return name
+
+
+def describe_ranks(device=None):
+    """What every rank of the process group is and sits on, in rank order, on every rank: [{"rank", "host", "device", "pci_bus_id",
+    "name"}] (one all_gather_object; one entry without a process group).  bench.py prints it as `per_rank_device` next to
+    `ranks_seen`, so that whoever runs the 8-GPU line first can see that eight ranks were on eight GPUs."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    me = {"rank": int(os.environ.get("RANK", "0")), "host": socket.gethostname(), "device": None, "pci_bus_id": None, "name": None}
+    if device is not None and torch.cuda.is_available():
+        idx = device.index if hasattr(device, "index") and device.index is not None else torch.cuda.current_device()
+        props = torch.cuda.get_device_properties(idx)
+        me["device"] = int(idx)
+        me["name"] = props.name
+        bus = getattr(props, "pci_bus_id", None)
+        me["pci_bus_id"] = (f"{getattr(props, 'pci_domain_id', 0):04x}:{bus:02x}:{getattr(props, 'pci_device_id', 0):02x}"
+                            if bus is not None else (str(getattr(props, "uuid", "")) or None))
+    if not _collectives_on():
+        return [me]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, me)
+    return out
+
+
+def ranks_sharing_a_device(ranks):
+    """[(rank, rank)] pairs of `describe_ranks()` entries that sit on the same GPU of the same host."""
+    seen, clashes = {}, []
+    for r in ranks:
+        key = (r["host"], r["pci_bus_id"] if r["pci_bus_id"] is not None else r["device"])
+        if key in seen:
+            clashes.append((seen[key], r["rank"]))
+        else:
+            seen[key] = r["rank"]
+    return clashes

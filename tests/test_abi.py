@@ -211,3 +211,23 @@ def test_no_launch_path_reads_the_environment():
         text = re.sub(r"#ifdef PIRE_HIP_TUNING.*?#endif", "", text, flags=re.S)
         for m in re.finditer(r"getenv\(([^)]*)\)", text):
             assert name == "api.cpp" and ("name" in m.group(1) or "PIRE_HIP_SEGMENT_" in m.group(1)), (name, m.group(0))
+
+
+def test_info_for_a_caller_built_against_an_older_header():
+    """pire_hip_table_get_info_sized writes min(size, sizeof) bytes, pire_hip_abi_version() is the header's."""
+    import ctypes as C
+    import re
+
+    import pire_amd
+    from pire_amd import binding as pb
+
+    L = pb.lib()
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "pire_hip.h")) as f:
+        assert int(re.search(r"#define PIRE_HIP_ABI_VERSION (\d+)", f.read()).group(1)) == L.pire_hip_abi_version() == pb.ABI_VERSION
+    t = pire_amd.Table(H.load_blob("c2_single.blob"))
+    full = t.refresh_info()
+    old = (C.c_uint8 * 200)(*([0xAB] * 200))
+    assert L.pire_hip_table_get_info_sized(t._h, old, 48) == 0
+    assert bytes(old[:48]) == bytes(full)[:48] and all(b == 0xAB for b in old[48:])
+    big = (C.c_uint8 * 400)()
+    assert L.pire_hip_table_get_info_sized(t._h, big, 400) == 0 and bytes(big[:C.sizeof(full)]) == bytes(full)

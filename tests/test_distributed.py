@@ -60,6 +60,9 @@ def _worker(rank, world, port, n_total, length, q):
     work.wait()
     assert (t2 == t).all()
     slowest = pd.max_over_ranks(1.0 + rank)
+    who = pd.describe_ranks()                          # bench.py's `per_rank_device`: one entry per rank, in rank order
+    assert [w["rank"] for w in who] == list(range(world)) and pd.ranks_sharing_a_device(
+        [dict(w, device=w["rank"]) for w in who]) == []
     pd.barrier()
     if rank == 0:
         q.put((t.numpy().tolist(), slowest))
@@ -94,3 +97,14 @@ def test_two_rank_gloo_sharding_and_count_reduce():
             want[2 + r] += 1
     assert got == want.tolist()
     assert slowest == 2.0      # MAX over ranks of (1.0, 2.0)
+
+
+def test_ranks_on_one_device_are_noticed():
+    """bench.py refuses an RCCL line whose ranks share a GPU: the check behind it."""
+    from pire_amd import distributed as pd
+
+    ranks = [{"rank": r, "host": "h", "device": r % 2, "pci_bus_id": "0000:%02x:00" % (r % 2), "name": "x"} for r in range(4)]
+    assert pd.ranks_sharing_a_device(ranks) == [(0, 2), (1, 3)]
+    assert pd.ranks_sharing_a_device(ranks[:2]) == []
+    other_host = [dict(r, host="h%d" % r["rank"]) for r in ranks]
+    assert pd.ranks_sharing_a_device(other_host) == []

@@ -35,7 +35,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "pire_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip"]
+# The flags the audited ISA is compiled with ARE the build's: pire_amd/csrc/Makefile hands over its $(CFLAGS) (the
+# audit compiled with flags of its own, so an overridden ARCH or added flags were never looked at); without the Makefile -- the
+# tests, a call by hand -- the product's defaults.  The stamp records them, pire_hip_build_info() prints them.
+FLAGS = (os.environ["PIRE_AUDIT_CFLAGS"].split() if os.environ.get("PIRE_AUDIT_CFLAGS") else ["--offload-arch=gfx950", "-O3", "-std=c++17"]) + ["-x", "hip"]
 
 # unit -> (kernels whose loads are inline asm: substring of the mangled name, checked with the window-loop walker)
 WINDOW = {"tiled.hip": ["ScanTiledKernel", "ScanTiledSegKernel"], "wide.hip": ["ScanWideKernel", "ScanWide2Kernel"], "ragged.hip": ["ScanRaggedKernel"],
