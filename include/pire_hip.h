@@ -469,6 +469,10 @@ int pire_hip_suffix(pire_hip_table* t, const void* text, const uint64_t* offsets
 /* Name of the kernel the last run on this thread dispatched to ("tiled", "ragged", "generic", "ragged_prefix",
  * "prefix", "suffix", "pair_tiled", "ragged_half_final", "half_final", "segmented", "segmented+plain"); diagnostics. */
 const char* pire_hip_last_kernel(void);
+/* ",name,name,...": the kernels (names as pire_hip_last_kernel reports them) that have passed a first-use self-test in this
+ * process so far (pire_hip_config.selftest); thread-local copy.  Diagnostics: tests/test_selftest.py holds every name the
+ * library can emit against it. */
+const char* pire_hip_selftested_kernels(void);
 /* The instantiation behind it where there are several (e.g. "pirehip::ScanTiledKernel<16,2,nt,5>" for "tiled");
  * otherwise the same string as pire_hip_last_kernel(). */
 const char* pire_hip_last_kernel_symbol(void);

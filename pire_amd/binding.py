@@ -158,6 +158,7 @@ ABI = [
                                              C.POINTER(C.c_uint32)]),
     ("pire_hip_table_get_info_sized", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("pire_hip_abi_version", C.c_uint32, []),
+    ("pire_hip_selftested_kernels", C.c_char_p, []),
     ("pire_hip_table_zip_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -838,6 +839,11 @@ def build_info() -> str:
 
 def last_kernel() -> str:
     return lib().pire_hip_last_kernel().decode()
+
+
+def selftested_kernels():
+    """The kernel names that have passed a first-use self-test in this process."""
+    return [k for k in lib().pire_hip_selftested_kernels().decode().split(",") if k]
 
 
 def last_kernel_symbol() -> str:

@@ -20,6 +20,7 @@
 #include <stdexcept>
 
 #include "internal.h"
+#include "selftest.h"
 
 namespace pirehip {
 
@@ -309,10 +310,84 @@ pire_hip_config& ConfigStorage()
 }
 }  // namespace
 
+thread_local const pire_hip_config* g_cfgOverride = nullptr;
+thread_local bool g_inEntrySelfTest = false;
+
 pire_hip_config GetConfig()
 {
+	if (g_cfgOverride)
+		return *g_cfgOverride;   // a first-use self-test on this thread (selftest.h): its routing knobs
 	std::lock_guard<std::mutex> lock(g_cfgMutex);
 	return ConfigStorage();
+}
+
+int RunSelfTestVariants(const std::vector<std::function<void(pire_hip_config&)>>& edits, const std::function<int()>& body)
+{
+	const pire_hip_config base = GetConfig();
+	const pire_hip_config* const outer = g_cfgOverride;
+	const bool was = g_inEntrySelfTest;
+	int rc = PIRE_HIP_OK;
+	for (size_t k = 0; k < edits.size() && rc == PIRE_HIP_OK; ++k) {
+		pire_hip_config c = base;
+		c.auto_adapt = 1;      // the table is not re-ranked under a self-test
+		c.selftest = 1;        // ... and what the variant's call dispatches to is not tested again from inside
+		c.no_segments = 1;
+		edits[k](c);
+		g_cfgOverride = &c;
+		g_inEntrySelfTest = true;
+		try {
+			rc = body();
+		} catch (...) {
+			g_cfgOverride = outer;
+			g_inEntrySelfTest = was;
+			throw;
+		}
+		if (rc == PIRE_HIP_OK)
+			NoteSelfTested(pire_hip_last_kernel());
+		g_cfgOverride = outer;
+		g_inEntrySelfTest = was;
+	}
+	return rc;
+}
+
+int SelfTestMismatch(const char* what, uint32_t string, const std::string& got, const std::string& want)
+{
+	SetError(std::string("self-test of ") + what + " (kernel '" + pire_hip_last_kernel() + "') failed: string " + std::to_string(string) +
+	         " of the known-answer batch gave " + got + ", the table's transitions give " + want + " -- this build of libpire_hip.so (" +
+	         pire_hip_build_info() + ") must not be used on this device");
+	return PIRE_HIP_ESELFTEST;
+}
+
+bool EntrySelfTestDue(hipStream_t stream, uint32_t* mode)
+{
+	if (g_inEntrySelfTest)
+		return false;
+	*mode = GetConfig().selftest;
+	if (*mode == 1)
+		return false;
+	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+	return hipStreamIsCapturing(stream, &capturing) != hipSuccess || capturing == hipStreamCaptureStatusNone;
+}
+
+namespace {
+std::mutex g_testedMutex;
+std::string g_tested;   // ",name,name,"
+}  // namespace
+
+void NoteSelfTested(const char* kernel)
+{
+	std::lock_guard<std::mutex> lock(g_testedMutex);
+	const std::string key = std::string(",") + kernel + ",";
+	if (g_tested.empty())
+		g_tested = ",";
+	if (g_tested.find(key) == std::string::npos)
+		g_tested += std::string(kernel) + ",";
+}
+
+std::string SelfTestedKernels()
+{
+	std::lock_guard<std::mutex> lock(g_testedMutex);
+	return g_tested;
 }
 
 void NoteKernel(const char* name, const char* symbol)
@@ -480,6 +555,7 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 				return rc;
 			}
 			p.owner->selfTested[p.workDevice].fetch_or(1u << kind);
+			NoteSelfTested(kNames[kind]);
 		}
 	}
 	NoteKernel(kNames[kind]);
@@ -965,6 +1041,13 @@ int RunImpl(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64
 
 using namespace pirehip;
 
+const char* pire_hip_selftested_kernels(void)
+{
+	static thread_local std::string copy;
+	copy = SelfTestedKernels();
+	return copy.c_str();
+}
+
 extern "C" {
 
 int pire_hip_config_get(pire_hip_config* out)
@@ -1423,6 +1506,217 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+// ---- first-use self-tests of the entry points with actions (selftest.h) -------------------------------------------------
+namespace {
+
+enum : uint32_t { kEntryPrefix = 8, kEntrySuffix = 9, kEntryHalfFinal = 10, kEntryPair = 11 };   // bits of pire_hip_table::selfTested
+
+struct OwnStream {
+	hipStream_t s = nullptr;
+	OwnStream() { (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+	~OwnStream()
+	{
+		if (s) {
+			(void)hipStreamSynchronize(s);
+			(void)hipStreamDestroy(s);
+		}
+	}
+};
+
+// the table's transitions, flags and final lists in the reference's numbering: they never change (an adaptation renumbers
+// the DEVICE side only)
+struct HostWalk {
+	const HostTable& h;
+	uint32_t Next(uint32_t st, uint32_t ch) const { return h.next[size_t(st) * h.letters + h.cls[ch]]; }
+	bool Final(uint32_t st) const { return (h.flags[st] & kFinal) != 0; }
+	bool Dead(uint32_t st) const { return (h.flags[st] & kDead) != 0; }
+};
+
+bool EntryTested(pire_hip_table* t, uint32_t bit, int* dev)
+{
+	*dev = -1;
+	if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= kMaxDevices)
+		return true;   // (no device: the entry point says so itself)
+	return (t->selfTested[*dev].load(std::memory_order_relaxed) & (1u << bit)) != 0;
+}
+
+// LongestPrefix / ShortestPrefix as the reference walks them (run.h:69-100, 277-311), on the host table
+int64_t HostPrefix(const HostWalk& w, const uint8_t* b, const uint8_t* e, bool longest, bool throughBegin, bool throughEnd)
+{
+	uint32_t st = w.h.initial;
+	if (throughBegin)
+		st = w.Next(st, kBeginMark);
+	int64_t pos = -1;
+	if (longest) {
+		if (w.Final(st))
+			pos = 0;
+		for (const uint8_t* p = b; p != e; ++p) {
+			st = w.Next(st, *p);
+			if (w.Final(st))
+				pos = p + 1 - b;
+			if (w.Dead(st))
+				break;
+		}
+		if (throughEnd && w.Final(w.Next(st, kEndMark)))
+			pos = e - b;
+		return pos;
+	}
+	if (w.Final(st))
+		return 0;
+	for (const uint8_t* p = b; p != e; ++p) {
+		st = w.Next(st, *p);
+		if (w.Final(st))
+			return p + 1 - b;
+		if (w.Dead(st))
+			break;
+	}
+	if (throughEnd && w.Final(w.Next(st, kEndMark)))
+		return e - b;
+	return -1;
+}
+
+// LongestSuffix / ShortestSuffix (run.h:313-362): backwards from the last byte
+int64_t HostSuffix(const HostWalk& w, const uint8_t* first, const uint8_t* last1, bool longest, bool throughEnd, bool throughBegin)
+{
+	uint32_t st = w.h.initial;
+	if (throughEnd)
+		st = w.Next(st, kEndMark);
+	const uint8_t* r = last1;   // one past the byte the walk takes next (going down)
+	if (longest) {
+		int64_t pos = -1;
+		while (r != first && !w.Dead(st)) {
+			if (w.Final(st))
+				pos = last1 - r;
+			st = w.Next(st, r[-1]);
+			--r;
+		}
+		if (w.Final(st))
+			pos = last1 - r;
+		if (throughBegin && w.Final(w.Next(st, kBeginMark)))
+			pos = last1 - r;
+		return pos;
+	}
+	for (; r != first && !w.Final(st) && !w.Dead(st); --r)
+		st = w.Next(st, r[-1]);
+	if (throughBegin)
+		st = w.Next(st, kBeginMark);
+	return w.Final(st) ? int64_t(last1 - r) : -1;
+}
+
+KnownBatch TableBatch(const HostWalk& w, uint32_t n, uint32_t maxLen, uint32_t start, uint64_t seed)
+{
+	return MakeKnownBatch(n, maxLen, start, seed ^ (uint64_t(w.h.states) << 20) ^ w.h.letters,
+	                      [&](uint32_t st, uint32_t ch) { return w.Next(st, ch); }, [&](uint32_t st) { return w.Dead(st); });
+}
+
+int SelfTestPrefix(pire_hip_table* t, bool suffix, int a, int b, hipStream_t stream)
+{
+	uint32_t mode = 0;
+	int dev = -1;
+	const uint32_t bit = suffix ? kEntrySuffix : kEntryPrefix;
+	if (t->host.empty || EntryTested(t, bit, &dev) || !EntrySelfTestDue(stream, &mode))
+		return PIRE_HIP_OK;
+	const HostWalk w{t->host};
+	// (prefix: a = throughBegin, b = throughEnd; suffix: a = throughEnd, b = throughBegin -- the mark the walk starts with first)
+	const uint32_t start = a ? w.Next(t->host.initial, suffix ? kEndMark : kBeginMark) : t->host.initial;
+	const KnownBatch kb = TableBatch(w, 320, 200, start, suffix ? 2 : 1);
+	OwnStream own;
+	for (int longest = 0; longest < 2; ++longest) {
+		std::vector<int64_t> want(kb.n), got(kb.n);
+		for (uint32_t i = 0; i < kb.n; ++i) {
+			const uint8_t* s0 = kb.text.data() + kb.offsets[i];
+			const uint8_t* s1 = kb.text.data() + kb.offsets[i + 1];
+			want[i] = suffix ? HostSuffix(w, s0, s1, longest != 0, a != 0, b != 0) : HostPrefix(w, s0, s1, longest != 0, a != 0, b != 0);
+		}
+		if (mode == 2)
+			want[kb.n / 2] += 1;
+		std::vector<std::function<void(pire_hip_config&)>> variants;
+		variants.push_back([](pire_hip_config& c) { c.ragged_act_always = 1; c.no_ragged_act = 0; });   // the ragged kernel with actions
+		if (!suffix)
+			variants.push_back([](pire_hip_config& c) { c.no_ragged_act = 1; c.ragged_act_always = 0; });   // one string per lane
+		const int rc = RunSelfTestVariants(variants, [&]() -> int {
+			std::fill(got.begin(), got.end(), int64_t(-77));
+			const int r = suffix ? pire_hip_suffix(t, kb.text.data(), kb.offsets.data(), kb.n, longest, a, b, 0, got.data(), own.s)
+			                     : pire_hip_prefix(t, kb.text.data(), kb.offsets.data(), kb.n, longest, a, b, 0, got.data(), own.s);
+			if (r != PIRE_HIP_OK)
+				return r;
+			for (uint32_t i = 0; i < kb.n; ++i)
+				if (got[i] != want[i])
+					return SelfTestMismatch(suffix ? (longest ? "LongestSuffix" : "ShortestSuffix") : (longest ? "LongestPrefix" : "ShortestPrefix"),
+					                        i, std::to_string(got[i]), std::to_string(want[i]));
+			return PIRE_HIP_OK;
+		});
+		if (rc != PIRE_HIP_OK)
+			return rc;
+	}
+	t->selfTested[dev].fetch_or(1u << bit);
+	return PIRE_HIP_OK;
+}
+
+// HalfFinalScanner (half_final.h:137-164): Initialize and every Step end with TakeAction
+int SelfTestHalfFinal(pire_hip_table* t, uint32_t flags, hipStream_t stream)
+{
+	uint32_t mode = 0;
+	int dev = -1;
+	if (t->host.empty || EntryTested(t, kEntryHalfFinal, &dev) || !EntrySelfTestDue(stream, &mode))
+		return PIRE_HIP_OK;
+	const HostTable& h = t->host;
+	const HostWalk w{h};
+	const uint32_t R = h.regexps;
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END;
+	const uint32_t start = (flags & PIRE_HIP_RUN_BEGIN) ? w.Next(h.initial, kBeginMark) : h.initial;
+	const KnownBatch kb = TableBatch(w, 320, 200, start, 3);
+	std::vector<uint32_t> wantIdx(kb.n), wantRes(size_t(kb.n) * R, 0), gotIdx(kb.n), gotRes(size_t(kb.n) * R);
+	std::vector<uint8_t> wantFin(kb.n), gotFin(kb.n);
+	for (uint32_t i = 0; i < kb.n; ++i) {
+		uint32_t* m = wantRes.data() + size_t(i) * R;
+		auto take = [&](uint32_t st) {
+			if (w.Final(st))
+				for (uint64_t k = h.acceptOff[st]; k < h.acceptOff[st + 1]; ++k)
+					m[h.acceptIds[k]]++;
+		};
+		uint32_t st = h.initial;
+		take(st);
+		if (flags & PIRE_HIP_RUN_BEGIN)
+			take(st = w.Next(st, kBeginMark));
+		for (uint64_t k = kb.offsets[i]; k < kb.offsets[i + 1]; ++k)
+			take(st = w.Next(st, kb.text[k]));
+		if (flags & PIRE_HIP_RUN_END)
+			take(st = w.Next(st, kEndMark));
+		wantIdx[i] = st;
+		wantFin[i] = w.Final(st) ? 1 : 0;
+	}
+	if (mode == 2)
+		wantIdx[kb.n / 2] ^= 1;
+	std::vector<std::function<void(pire_hip_config&)>> variants;
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 2; });                        // the row kernel where the table has that image
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 0; });   // the ragged kernel with actions
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 1; });   // one string per lane
+	OwnStream own;
+	const int rc = RunSelfTestVariants(variants, [&]() -> int {
+		std::fill(gotIdx.begin(), gotIdx.end(), ~0u);
+		std::fill(gotRes.begin(), gotRes.end(), ~0u);
+		const int r = pire_hip_run_half_final(t, kb.text.data(), kb.offsets.data(), kb.n, flags, gotIdx.data(), gotFin.data(), gotRes.data(), own.s);
+		if (r != PIRE_HIP_OK)
+			return r;
+		for (uint32_t i = 0; i < kb.n; ++i) {
+			if (gotIdx[i] != wantIdx[i] || gotFin[i] != wantFin[i])
+				return SelfTestMismatch("HalfFinalScanner", i, "state " + std::to_string(gotIdx[i]), "state " + std::to_string(wantIdx[i]));
+			for (uint32_t r2 = 0; r2 < R; ++r2)
+				if (gotRes[size_t(i) * R + r2] != wantRes[size_t(i) * R + r2])
+					return SelfTestMismatch("HalfFinalScanner", i, "count " + std::to_string(gotRes[size_t(i) * R + r2]) + " for regexp " + std::to_string(r2),
+					                        std::to_string(wantRes[size_t(i) * R + r2]));
+		}
+		return PIRE_HIP_OK;
+	});
+	if (rc != PIRE_HIP_OK)
+		return rc;
+	t->selfTested[dev].fetch_or(1u << kEntryHalfFinal);
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
 int pire_hip_run_half_final(pire_hip_table* t, const void* text, const uint64_t* offsets, uint64_t n, uint32_t flags,
                             uint32_t* out_state_idx, uint8_t* out_final, uint32_t* out_results, void* streamPtr)
 try {
@@ -1431,6 +1725,9 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (n)
+		if (int rc = SelfTestHalfFinal(t, flags, stream))   // first use on this device: every kernel of this entry point, known answers
+			return rc;
 	ScanParams p;
 	const bool enqueueOnly = (flags & PIRE_HIP_RUN_ON_DEVICE) && !(flags & PIRE_HIP_RUN_HOST_OFFSETS);
 	TableUse use(t, enqueueOnly);
@@ -1582,6 +1879,9 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (n)
+		if (int rc = SelfTestPrefix(t, false, through_begin, through_end, stream))   // first use on this device (selftest.h)
+			return rc;
 	ScanParams p;
 	TableUse use(t, (flags & PIRE_HIP_RUN_ON_DEVICE) != 0);
 	if (int rc = FillParams(t, &p, through_begin ? PIRE_HIP_RUN_BEGIN : 0, /*wantDist=*/true))   // startPerm = Initialize [+ BeginMark]
@@ -1729,6 +2029,9 @@ try {
 		return PIRE_HIP_EINVAL;
 	}
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (n)
+		if (int rc = SelfTestPrefix(t, true, through_end, through_begin, stream))   // first use on this device (selftest.h)
+			return rc;
 	ScanParams p;
 	TableUse use(t, (flags & PIRE_HIP_RUN_ON_DEVICE) != 0);
 	if (int rc = FillParams(t, &p, 0))

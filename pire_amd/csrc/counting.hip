@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "internal.h"
+#include "selftest.h"
 #include "device_common.h"
 
 namespace pirehip {
@@ -75,6 +76,7 @@ struct pire_hip_counting_table {
 	std::vector<uint32_t> captureInfo;                    // [expanded states] original state << 8 | Final tag << 2 | action
 	uint32_t* captureInfoDev[pirehip::kMaxDevices] = {};
 	bool captureTried = false;
+	std::atomic<uint32_t> selfTested[pirehip::kMaxDevices] = {};   // per device: bit 0 counting, bit 1 capture passed their known-answer batches (selftest.h)
 };
 
 namespace pirehip {
@@ -1896,6 +1898,234 @@ try {
 	return pirehip::HandleException();
 }
 
+// ---- first-use self-tests (selftest.h): the counting scanners' and the capturing scanner's kernels -------------------------
+namespace {
+
+struct CountOwnStream {
+	hipStream_t s = nullptr;
+	CountOwnStream() { (void)hipStreamCreateWithFlags(&s, hipStreamNonBlocking); }
+	~CountOwnStream()
+	{
+		if (s) {
+			(void)hipStreamSynchronize(s);
+			(void)hipStreamDestroy(s);
+		}
+	}
+};
+
+bool CountingTested(pire_hip_counting_table* t, uint32_t bit, int* dev)
+{
+	*dev = -1;
+	if (hipGetDevice(dev) != hipSuccess || *dev < 0 || *dev >= pirehip::kMaxDevices)
+		return true;
+	return (t->selfTested[*dev].load(std::memory_order_relaxed) & (1u << bit)) != 0;
+}
+
+// the host's copy of the scanner: state | action << 32 per (state, letter) -- count.h / loaded.h as ingested
+struct CountWalk {
+	const pirehip::CountingHost& h;
+	uint64_t Trans(uint32_t st, uint32_t ch) const { return h.trans[size_t(st) * h.letters + h.letterOf[ch]]; }
+};
+
+pirehip::KnownBatch CountingBatch(const CountWalk& w, uint32_t n, uint32_t maxLen, uint32_t start, uint64_t seed)
+{
+	return pirehip::MakeKnownBatch(n, maxLen, start, seed ^ (uint64_t(w.h.states) << 24) ^ (uint64_t(w.h.letters) << 8),
+	                               [&](uint32_t st, uint32_t ch) { return uint32_t(w.Trans(st, ch)); }, [](uint32_t) { return false; });
+}
+
+// CountingScanner / AdvancedCountingScanner / NoGlueLimitCountingScanner on the host: count.h:175-192 (PerformIncrement,
+// PerformReset), 251-257 / 287-295 (the order of the two), 306-325 + 404-437 (NoGlueLimit), Result = max(current, total) 206
+void HostCount(const CountWalk& w, int kind, uint32_t flags, const uint8_t* b, const uint8_t* e, uint32_t* outIdx, uint32_t* results)
+{
+	using namespace pirehip;
+	const uint32_t R = w.h.regexps;
+	std::vector<uint32_t> cur(std::max<uint32_t>(R, 1), 0), tot(std::max<uint32_t>(R, 1), 0);
+	uint32_t updated = 0, st = w.h.initial;
+	constexpr uint32_t kInc = (1u << kMaxReCount) - 1u, kReset = kInc << kMaxReCount;
+	auto increment = [&](uint32_t a) {
+		for (uint32_t r = 0; r < R && r < kMaxReCount; ++r)
+			cur[r] += (a >> r) & 1u;
+		updated |= a << kMaxReCount;
+	};
+	auto reset = [&](uint32_t a) {
+		const uint32_t m = a & updated;
+		if (!m)
+			return;
+		for (uint32_t r = 0; r < R && r < kMaxReCount; ++r)
+			if (((m >> (kMaxReCount + r)) & 1u) && cur[r]) {
+				tot[r] = std::max(tot[r], cur[r]);
+				cur[r] = 0;
+			}
+		updated &= ~m;
+	};
+	auto take = [&](uint32_t a) {
+		if (kind == PIRE_HIP_COUNTING_NOGLUELIMIT) {
+			if (!w.h.actions.empty()) {
+				const uint32_t* act = w.h.actions.data() + a;
+				for (uint32_t k = *act++; k--;)
+					cur[*act++] = 0;
+				for (uint32_t k = *act++; k--;) {
+					const uint32_t id = *act++;
+					++cur[id];
+					tot[id] = std::max(tot[id], cur[id]);
+				}
+			} else {
+				if (a & 2u)
+					cur[0] = 0;
+				if (a & 1u) {
+					++cur[0];
+					tot[0] = std::max(tot[0], cur[0]);
+				}
+			}
+		} else if (kind == PIRE_HIP_COUNTING_ADVANCED) {
+			if (a & kReset)
+				reset(a);
+			if (a & kInc)
+				increment(a);
+		} else {
+			if (a & kInc)
+				increment(a);
+			if (a & kReset)
+				reset(a);
+		}
+	};
+	auto step = [&](uint32_t ch) {
+		const uint64_t x = w.Trans(st, ch);
+		st = uint32_t(x);
+		if (uint32_t(x >> 32))   // (0 = no action; a NoGlueLimit action is an offset into the lists, whose word 0 is their length)
+			take(uint32_t(x >> 32));
+	};
+	if (flags & PIRE_HIP_RUN_BEGIN)
+		step(kBeginMark);
+	for (const uint8_t* p = b; p != e; ++p)
+		step(*p);
+	if (flags & PIRE_HIP_RUN_END)
+		step(kEndMark);
+	*outIdx = st;
+	for (uint32_t r = 0; r < R; ++r)
+		results[r] = std::max(cur[r], tot[r]);
+}
+
+int SelfTestCounting(pire_hip_counting_table* t, int kind, uint32_t flags, hipStream_t stream)
+{
+	using namespace pirehip;
+	uint32_t mode = 0;
+	int dev = -1;
+	if (CountingTested(t, 0, &dev) || !EntrySelfTestDue(stream, &mode) || !t->host.states)
+		return PIRE_HIP_OK;
+	const CountWalk w{t->host};
+	const uint32_t R = std::max<uint32_t>(t->host.regexps, 1);
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END;
+	const uint32_t start = (flags & PIRE_HIP_RUN_BEGIN) ? uint32_t(w.Trans(t->host.initial, kBeginMark)) : t->host.initial;
+	const KnownBatch kb = CountingBatch(w, 320, 200, start, 11);
+	std::vector<uint32_t> wantIdx(kb.n), gotIdx(kb.n), wantRes(size_t(kb.n) * R, 0), gotRes(size_t(kb.n) * R);
+	for (uint32_t i = 0; i < kb.n; ++i)
+		HostCount(w, kind, flags, kb.text.data() + kb.offsets[i], kb.text.data() + kb.offsets[i + 1], &wantIdx[i], &wantRes[size_t(i) * R]);
+	if (mode == 2)
+		wantIdx[kb.n / 2] ^= 1;
+	std::vector<std::function<void(pire_hip_config&)>> variants;
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 2; });   // whole lines per lane: rows by byte / by letter where the table has them
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; });   // 16 bytes at a time: packed 16-bit counters / the 32-bit kernel
+	CountOwnStream own;
+	uint32_t extra = 0;   // the third pass: PIRE_HIP_RUN_GENERIC = the 32-bit kernel alone
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; });
+	size_t pass = 0;
+	const int rc = RunSelfTestVariants(variants, [&]() -> int {
+		extra = pass++ == 2 ? PIRE_HIP_RUN_GENERIC : 0u;
+		std::fill(gotIdx.begin(), gotIdx.end(), ~0u);
+		std::fill(gotRes.begin(), gotRes.end(), ~0u);
+		const int r = pire_hip_counting_run(t, kind, kb.text.data(), kb.offsets.data(), kb.n, flags | extra, gotIdx.data(), gotRes.data(), own.s);
+		if (r != PIRE_HIP_OK)
+			return r;
+		for (uint32_t i = 0; i < kb.n; ++i) {
+			if (gotIdx[i] != wantIdx[i])
+				return SelfTestMismatch("the counting scanner", i, "state " + std::to_string(gotIdx[i]), "state " + std::to_string(wantIdx[i]));
+			for (uint32_t r2 = 0; r2 < t->host.regexps; ++r2)
+				if (gotRes[size_t(i) * R + r2] != wantRes[size_t(i) * R + r2])
+					return SelfTestMismatch("the counting scanner", i, "count " + std::to_string(gotRes[size_t(i) * R + r2]) + " for regexp " + std::to_string(r2),
+					                        std::to_string(wantRes[size_t(i) * R + r2]));
+		}
+		return PIRE_HIP_OK;
+	});
+	if (rc != PIRE_HIP_OK)
+		return rc;
+	t->selfTested[dev].fetch_or(1u);
+	return PIRE_HIP_OK;
+}
+
+// CapturingScanner on the host: capture.h:89-116 (the step counter, BeginCapture = 1 / EndCapture = 2 taken while nothing is
+// captured yet), Final from the tags (capture.h:134)
+int SelfTestCapture(pire_hip_counting_table* t, uint32_t flags, hipStream_t stream)
+{
+	using namespace pirehip;
+	uint32_t mode = 0;
+	int dev = -1;
+	if (CountingTested(t, 1, &dev) || !EntrySelfTestDue(stream, &mode) || !t->host.states || t->host.type != 4)
+		return PIRE_HIP_OK;
+	const CountWalk w{t->host};
+	flags &= PIRE_HIP_RUN_BEGIN | PIRE_HIP_RUN_END;
+	const uint32_t start = (flags & PIRE_HIP_RUN_BEGIN) ? uint32_t(w.Trans(t->host.initial, kBeginMark)) : t->host.initial;
+	const KnownBatch kb = CountingBatch(w, 320, 200, start, 12);
+	std::vector<uint32_t> wantIdx(kb.n), gotIdx(kb.n);
+	std::vector<uint8_t> wantFin(kb.n), gotFin(kb.n);
+	std::vector<int64_t> wantB(kb.n), wantE(kb.n), gotB(kb.n), gotE(kb.n);
+	for (uint32_t i = 0; i < kb.n; ++i) {
+		uint32_t st = t->host.initial;
+		int64_t begin = -1, end = -1, counter = 0;
+		auto step = [&](uint32_t ch) {
+			const uint64_t x = w.Trans(st, ch);
+			const bool captured = begin >= 0 && end >= 0;
+			st = uint32_t(x);
+			++counter;
+			const uint32_t a = uint32_t(x >> 32);
+			if ((a & 1u) && !captured)
+				begin = counter - 1;
+			else if ((a & 2u) && !captured)
+				end = counter - 1;
+		};
+		if (flags & PIRE_HIP_RUN_BEGIN)
+			step(kBeginMark);
+		for (uint64_t k = kb.offsets[i]; k < kb.offsets[i + 1]; ++k)
+			step(kb.text[k]);
+		if (flags & PIRE_HIP_RUN_END)
+			step(kEndMark);
+		wantIdx[i] = st;
+		wantFin[i] = !t->host.tags.empty() && (t->host.tags[st] & 1u) ? 1 : 0;
+		wantB[i] = begin;
+		wantE[i] = end;
+	}
+	if (mode == 2)
+		wantIdx[kb.n / 2] ^= 1;
+	std::vector<std::function<void(pire_hip_config&)>> variants;
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 2; c.ragged_act_always = 1; c.no_ragged_act = 0; });   // the ragged kernel with actions (>= 256 strings) ...
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 2; c.no_ragged_act = 1; });   // ... whole lines per lane (CaptureRowKernel) ...
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 1; });   // ... dense rows, 16 bytes at a time ...
+	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 1; });   // ... and (PIRE_HIP_RUN_GENERIC) letter + transition
+	CountOwnStream own;
+	size_t pass = 0;
+	const int rc = RunSelfTestVariants(variants, [&]() -> int {
+		const uint32_t extra = pass++ == 3 ? PIRE_HIP_RUN_GENERIC : 0u;
+		std::fill(gotIdx.begin(), gotIdx.end(), ~0u);
+		std::fill(gotB.begin(), gotB.end(), int64_t(-77));
+		const int r = pire_hip_capture_run(t, kb.text.data(), kb.offsets.data(), kb.n, flags | extra, gotIdx.data(), gotFin.data(), gotB.data(),
+		                                   gotE.data(), own.s);
+		if (r != PIRE_HIP_OK)
+			return r;
+		for (uint32_t i = 0; i < kb.n; ++i)
+			if (gotIdx[i] != wantIdx[i] || gotFin[i] != wantFin[i] || gotB[i] != wantB[i] || gotE[i] != wantE[i])
+				return SelfTestMismatch("the capturing scanner", i,
+				                        "state " + std::to_string(gotIdx[i]) + " captured [" + std::to_string(gotB[i]) + ", " + std::to_string(gotE[i]) + ")",
+				                        "state " + std::to_string(wantIdx[i]) + " captured [" + std::to_string(wantB[i]) + ", " + std::to_string(wantE[i]) + ")");
+		return PIRE_HIP_OK;
+	});
+	if (rc != PIRE_HIP_OK)
+		return rc;
+	t->selfTested[dev].fetch_or(2u);
+	return PIRE_HIP_OK;
+}
+
+}  // namespace
+
 int pire_hip_counting_run(pire_hip_counting_table* t, int kind, const void* text, const uint64_t* offsets, uint64_t n,
                           uint32_t flags, uint32_t* out_state_idx, uint32_t* out_results, void* streamPtr)
 try {
@@ -1917,6 +2147,8 @@ try {
 	if (n == 0)
 		return PIRE_HIP_OK;
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (int rc = SelfTestCounting(t, kind, flags, stream))   // first use on this device: every kernel of this entry point, known answers (selftest.h)
+		return rc;
 	CountingDevice image;
 	if (int rc = UploadCounting(t, &image))
 		return rc;
@@ -2110,6 +2342,8 @@ try {
 	if (n == 0)
 		return PIRE_HIP_OK;
 	hipStream_t stream = static_cast<hipStream_t>(streamPtr);
+	if (int rc = SelfTestCapture(t, flags, stream))   // first use on this device (selftest.h)
+		return rc;
 	CountingDevice image;
 	if (int rc = UploadCounting(t, &image))
 		return rc;

@@ -1555,6 +1555,20 @@ void JoinBackgroundAdapt(pire_hip_table* t)
 
 namespace {
 
+// Whether the scans since the last ranking ask for a new one: `threshold` sampled traps -- or, for a table nobody has ranked from
+// measurements yet, a first look after 32 MB of text once a few dozen traps say the a-priori ranking is off: such a table may have
+// taken the class-indexed walk on the strength of those few traps (api.cpp FillParams), traps no more, and would otherwise keep
+// the a-priori rows -- and the slower walk -- for ever.
+bool AdaptationDue(pire_hip_table* t, uint64_t traps, uint64_t threshold)
+{
+	if (traps >= threshold)
+		return true;
+	if (traps < 64 || t->bytesScanned.load(std::memory_order_relaxed) < (uint64_t(32) << 20))
+		return false;
+	std::shared_lock<std::shared_mutex> stable(t->adaptMutex);
+	return !t->host.massMeasured;
+}
+
 // A launch boundary of an enqueue-only call: swap in what a finished worker prepared; start a worker when the scans since the
 // last ranking left the rows often enough.  Never waits for the device.
 void BackgroundAdaptStep(pire_hip_table* t, uint64_t threshold)
@@ -1600,7 +1614,7 @@ void BackgroundAdaptStep(pire_hip_table* t, uint64_t threshold)
 			return;
 		traps = *t->devs[dev].trapSignalHost;
 	}
-	if (traps < threshold || traps < bg.trapsAtLastLook + threshold)
+	if (!AdaptationDue(t, traps, threshold) || (bg.trapsAtLastLook && traps < bg.trapsAtLastLook + threshold))
 		return;
 	std::unique_lock<std::mutex> one(bg.mutex, std::try_to_lock);
 	if (!one.owns_lock() || bg.state.load(std::memory_order_acquire) != 0)
@@ -1648,7 +1662,7 @@ void MaybeAutoAdapt(pire_hip_table* t, bool enqueueOnly)
 			if (t->devs[k].device >= 0 && t->devs[k].trapSignalHost)
 				traps += *t->devs[k].trapSignalHost;
 	}
-	if (traps < threshold)
+	if (!AdaptationDue(t, traps, threshold))
 		return;
 	(void)AdaptTable(t, nullptr, true);   // a performance measure: a failure here surfaces in the launch that follows
 }

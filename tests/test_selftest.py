@@ -105,3 +105,88 @@ def test_self_test_leaves_the_visit_counters_alone(pa, torch_cuda, cfg):
     # the scan above is 64 x 256 steps in one state's row, too few for a sample; the self-test's 131 072 steps through
     # the whole table would have left dozens, in the dense rows' counters and in the trap counters
     assert info.adaptations == 0 and info.last_trap_samples == 0    # "never ran: nothing observed"
+
+
+# ---- the entry points with actions (round 6, csrc/selftest.h): prefix / suffix / half-final searches, counting and capturing ----
+
+def _golden_blob(name):
+    from tests import helpers as H
+
+    return H.load_blob([c for c in H.all_cases() if c["name"] == name][0]["blob"])
+
+
+def _strings(seed, n=300):
+    from tests import helpers as H
+
+    return H.random_strings(np.random.RandomState(seed), n, 150, b"abc def,hello w0123456789()-XYZ@\n")
+
+
+def _entry_calls(pa):
+    """(label in the failure message, a callable making a FRESH table and one call of the entry point, kernels the self-test must reach)"""
+    from tests import helpers as H
+
+    set_a = _blob("set_a")
+    strings = _strings(5)
+    text, offs = H.pack(strings)
+    counting = [c for c in H.golden()["counting"] if c["kind"] == 1 and c["regexps"] >= 2][0]
+    capturing = H.golden()["capturing"][0]
+    return [
+        ("Prefix (kernel", lambda: pa.Table(set_a).prefix(text, offs, True), {"ragged_prefix", "prefix"}),
+        ("Suffix (kernel", lambda: pa.Table(set_a).suffix(text, offs, True), {"suffix"}),
+        ("HalfFinalScanner", lambda: pa.Table(set_a).run_half_final(text, offs), {"ragged_half_final", "half_final"}),
+        ("the counting scanner", lambda: pa.CountingTable(H.load_blob(counting["blob"]), counting["kind"]).run_strings(strings),
+         {"counting", "counting_packed", "counting_rows"}),
+        ("the capturing scanner", lambda: pa.CountingTable(H.load_blob(capturing["blob"]), 0).capture(text, offs),
+         {"capture", "capture_dense", "capture_rows"}),
+    ]
+
+
+@pytest.mark.gpu
+def test_entry_points_with_actions_test_every_kernel_they_can_take_on_first_use(pa, torch_cuda, cfg):
+    """selftest = 2 (one expected answer altered): the first call of each entry point on a fresh table is refused with
+    PIRE_HIP_ESELFTEST and the entry point's name; selftest = 0: it passes, and the kernels the library reports as self-tested
+    include every kernel the entry point can route to."""
+    from pire_amd import binding as pb
+
+    for label, call, kernels in _entry_calls(pa):
+        cfg.set(selftest=2)
+        with pytest.raises(pb.PireHipError) as err:
+            call()
+        assert err.value.code == ESELFTEST and "self-test of " in str(err.value) and label in str(err.value), (label, str(err.value))
+        cfg.set(selftest=0)
+        call()
+        tested = set(pb.selftested_kernels())
+        assert kernels <= tested, (label, kernels - tested, tested)
+        cfg.set(selftest=1)
+        call()   # switched off: nothing tested, nothing refused
+
+
+def test_every_kernel_name_the_library_can_emit_has_a_self_test():
+    """Every NoteKernel("...") name in the sources is either reached by a first-use self-test (the names the GPU test above and the
+    KINDS table check) or listed here with the reason it is not."""
+    import os
+    import re
+
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pire_amd", "csrc")
+    names = set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp")):
+            with open(os.path.join(csrc, f)) as fh:
+                src = fh.read()
+            for m in re.finditer(r"NoteKernel\(([^;]*?)\);", src, re.S):
+                names.update(re.findall(r'"([a-z_+0-9]+)"', m.group(1).split(",")[0] if "?" not in m.group(1) else m.group(1).split(', "pirehip')[0]))
+    covered = {k[0] for k in KINDS} | {"ragged_prefix", "prefix", "suffix", "ragged_half_final", "half_final", "half_final_rows", "counting",
+                                       "counting_packed", "counting_rows", "counting_letter_rows", "capture", "capture_dense", "capture_rows",
+                                       "ragged_capture"}
+    not_covered = {
+        "pair_tiled": "ScannerPair on fixed-length records: the fused pass is held against two plain passes by tests/test_pair.py; no first-use test yet",
+        "segmented": "the segmented scan verifies itself: every segment's guessed start state is checked against the true one on the device",
+        "segmented+plain": "as 'segmented'",
+        "tiled_seg": "a pass of the segmented scan (kPermIds): see 'segmented'",
+        "slow": "SlowScanner: no first-use test yet (plain HIP, no hand-counted waits)",
+        "slow_list": "as 'slow'",
+        "slow_wide": "as 'slow'",
+    }
+    assert names, "no NoteKernel calls found"
+    missing = names - covered - set(not_covered)
+    assert not missing, f"kernels without a first-use self-test and without a stated reason: {sorted(missing)}"
