@@ -362,9 +362,13 @@ void ChooseZip(HostTable& t, std::vector<uint32_t>& order, const std::vector<dou
 		if (cap < t.hot)
 			continue;
 		ZipPlan z = PlanZip(t, order, score, t.hot, cap);
-		// (caps in falling order: a smaller one has to put more of the ranking's mass into the tier to be taken -- where every
-		// visited state fits anyway, more rows mean more steps that need no exception and fewer distinct headers per wave)
-		if (z.inside > bestInside * 1.0005) {
+		// (caps in falling order, strictly more of the ranking's mass inside the tier to be taken: where every sampled state fits
+		// anyway the first, with the most rows, stays.  The masses are samples of a long tail: the share they leave outside the tier
+		// is several times too low -- the states no sample has hit are visited too -- and which cap wins is only roughly right; a
+		// Good-Turing estimate for the unseen mass and a tie-break on the number of states were tried and changed no choice.  A BYTE
+		// form of the header -- a letter compared by one v_cmp_eq_u32_sdwa, 13 vector instructions per step instead of 19, at most 255
+		// rows to lean on -- was built too: + 3 %; the zipped walk is bound by its three LDS instructions per byte.  Not kept.)
+		if (z.inside > bestInside) {
 			bestInside = z.inside;
 			best = std::move(z);
 		}
