@@ -640,7 +640,7 @@ def main():
         # HBM traffic per launch from the committed PMC passes (collected separately, as rocprofv3 requires)
         traffic = traffic_src = lds = traffic_note = None
         sources = kernel_sources_sha16()
-        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)

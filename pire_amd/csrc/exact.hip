@@ -294,6 +294,32 @@ __global__ __launch_bounds__(1024) void SuffixKernel(SuffixParams q)
 			u32x4 v = *reinterpret_cast<const u32x4*>(block);
 			uint32_t k = uint32_t(cur - 1 - block);                          // index of the next byte inside the block
 			const uint32_t kLow = block >= lo ? 0u : uint32_t(lo - block);   // first index that belongs to the string
+			// A whole block of the string from a state with a dense row: its sixteen bytes top down through the dense rows alone
+			// (round 6; the prefix kernel's DenseChunk, backwards).  Neither a Dead nor a Final state among the sixteen reached
+			// (the rows are ordered plain, Dead, Final) -> nothing to record but what the state in front of them says, take the
+			// state; otherwise the block byte by byte below.  The suffix searches were never measured before round 6: 0.52 TB/s of
+			// log lines with the byte-wise walk alone (a SlowStep, a flag lookup and three funnel shifts per byte).
+			if (k == 15 && kLow == 0 && st < p.hot) {
+				uint32_t h = st, mx = 0;
+#pragma unroll
+				for (int w = 3; w >= 0; --w) {
+					const uint32_t x = v[w];
+#pragma unroll
+					for (int b2 = 3; b2 >= 0; --b2) {
+						h = lds[h * L.pitch + ((x >> (8 * b2)) & 0xFFu)];
+						mx = mx > h ? mx : h;
+					}
+				}
+				if (mx < p.hotDeadLo) {
+					if (q.longest && (f & kFinal))
+						pos = (long long)(top - cur);
+					st = h;
+					f = 0;   // a plain dense state: neither Final nor Dead
+					cur -= 16;
+					go = cur > lo;
+					continue;
+				}
+			}
 			// bring byte k to the top of the 128-bit value, then peel bytes off the top
 			for (uint32_t sh = 15 - k; sh; --sh) {
 				v.w = __builtin_amdgcn_alignbit(v.w, v.z, 24);

@@ -128,3 +128,60 @@ def test_explicit_adapt_and_destroy_wait_for_the_worker(pa, torch_cuda, cfg):
             gi, gf, _ = dev_run_strided(torch, t, d)
             assert (gi == oi).all() and (gf == of).all()
         del t                                          # destroy right behind the last launch boundary
+
+
+def test_background_adaptation_through_the_c_abi_alone_from_several_threads(cfg):
+    """No torch: device buffers from pire_hip_device_alloc, four host threads making enqueue-only calls on ONE table (each on the
+    default stream, each waiting for its own results) while the table adapts in the background underneath them -- every answer the
+    oracle's.  This is the test the ThreadSanitizer build of the library runs (tools/gpu_final_r06.sh: torch's own HIP
+    initialisation does not survive the preloaded sanitizer runtime, the library's does)."""
+    import ctypes as C
+    import threading
+
+    import pire_amd
+    from pire_amd import binding as pb
+
+    if pire_amd.device_count() == 0:
+        pytest.skip("needs a HIP device")
+    cfg.set(auto_adapt=0, walk_variant=0, zip_variant=0, auto_adapt_min_traps=64)
+    entry = W.wide_set("dict_1k")
+    blob = W.load_blob(entry["blob"])
+    n, length = 16384, 1024
+    data = W.wide_records(entry, "k512", 21, n, length)
+    o = ob.OracleScanner(blob)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    L = pb.lib()
+    t = pire_amd.Table(blob)
+    t.upload()
+    dtext = C.c_void_p()
+    assert L.pire_hip_device_alloc(data.size, C.byref(dtext)) == 0
+    assert L.pire_hip_copy_to_device(dtext, data.ctypes.data, data.size, None) == 0 and L.pire_hip_stream_synchronize(None) == 0
+    errors = []
+
+    def worker(k):
+        didx, dfin = C.c_void_p(), C.c_void_p()
+        try:
+            assert L.pire_hip_device_alloc(n * 4, C.byref(didx)) == 0 and L.pire_hip_device_alloc(n, C.byref(dfin)) == 0
+            gi, gf = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint8)
+            for i in range(10):
+                t.run_strided_device(dtext.value, n, length, length, pb.FLAG_BEGIN | pb.FLAG_END, didx.value, dfin.value, 0, 0, 0)
+                assert L.pire_hip_copy_to_host(gi.ctypes.data, didx, n * 4, None) == 0
+                assert L.pire_hip_copy_to_host(gf.ctypes.data, dfin, n, None) == 0
+                assert L.pire_hip_stream_synchronize(None) == 0
+                if not ((gi == oi).all() and (gf == of).all()):
+                    errors.append((k, i, int((gi != oi).sum())))
+                time.sleep(0.01)
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+        finally:
+            L.pire_hip_device_free(didx)
+            L.pire_hip_device_free(dfin)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    L.pire_hip_device_free(dtext)
+    assert not errors, errors
+    assert t.refresh_info().adaptations >= 1, "forty passes over a corpus that leaves the a-priori rows: the table never adapted"
