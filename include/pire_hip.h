@@ -287,6 +287,18 @@ int pire_hip_table_glue(const pire_hip_table* lhs, const pire_hip_table* rhs, si
  */
 int pire_hip_table_glue_gpu(const pire_hip_table* lhs, const pire_hip_table* rhs, size_t max_size, pire_hip_table** out);
 
+/*
+ * This table's own configuration: from now on every entry point that takes `t` runs under *cfg instead of the process-wide
+ * configuration (pire_hip_config_set) -- kernel routing, walk / zip variants at its next ranking, the adaptation policy, the
+ * first-use self-test --, on whatever thread it is called.  Two users of the library in one process need not agree on the
+ * process-wide knobs (or touch them at all).  cfg == NULL: back to the process-wide configuration.  Fields beyond cfg->size take
+ * the process-wide values of the moment of the call.  Waits for calls in flight on `t` (not for the device).
+ * pire_hip_run_pair on two tables with configurations of their own: the first table's.
+ */
+int pire_hip_table_config_set(pire_hip_table* t, const pire_hip_config* cfg);
+/* The configuration calls on `t` run under (its own, else the process-wide one); out->size as pire_hip_config_get. */
+int pire_hip_table_config_get(const pire_hip_table* t, pire_hip_config* out);
+
 /* Upload the device image to the CURRENT HIP device now (otherwise done lazily by the first run). */
 int pire_hip_table_upload(pire_hip_table* t);
 

@@ -159,6 +159,8 @@ ABI = [
     ("pire_hip_table_get_info_sized", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     ("pire_hip_abi_version", C.c_uint32, []),
     ("pire_hip_selftested_kernels", C.c_char_p, []),
+    ("pire_hip_table_config_set", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("pire_hip_table_config_get", C.c_int, [C.c_void_p, C.c_void_p]),
     ("pire_hip_table_zip_layout", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]),
     ("pire_hip_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -420,6 +422,25 @@ class Table:
         targets = raw[x_off - rows_off:x_off - rows_off + 2 * k * (tier - full)].view(np.uint16).reshape(tier - full, k)
         return {"tier": tier, "full": full, "pitch": pitch, "rows_offset": rows_off, "rows": rows, "headers": headers,
                 "targets": targets}
+
+    def set_config(self, **fields):
+        """pire_hip_table_config_set: this table's own configuration = the current one with `fields` changed; no fields: back to the
+        process-wide configuration."""
+        if not fields:
+            _check(lib().pire_hip_table_config_set(self._h, None))
+            return None
+        c = self.get_config()
+        for k, v in fields.items():
+            setattr(c, k, v)
+        c.size = C.sizeof(Config)
+        _check(lib().pire_hip_table_config_set(self._h, C.byref(c)))
+        return c
+
+    def get_config(self) -> "Config":
+        c = Config()
+        c.size = C.sizeof(Config)
+        _check(lib().pire_hip_table_config_get(self._h, C.byref(c)))
+        return c
 
     def adapt(self) -> int:
         """Re-rank the LDS rows from the visit counters of earlier scans; returns the number of rows promoted."""

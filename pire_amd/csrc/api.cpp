@@ -1222,6 +1222,47 @@ try {
 	return pirehip::HandleException();   // an exception must not unwind through the C ABI
 }
 
+int pire_hip_table_config_set(pire_hip_table* t, const pire_hip_config* in)
+try {
+	if (!t || (in && in->size < sizeof(uint32_t))) {
+		SetError("pire_hip_table_config_set: null table, or in->size does not hold the caller's sizeof(pire_hip_config)");
+		return PIRE_HIP_EINVAL;
+	}
+	const pire_hip_config now = GetConfig();
+	std::unique_lock<std::shared_mutex> exclusive(t->adaptMutex);   // no entry point is looking at it
+	if (!in) {
+		t->hasConfig = false;
+		return PIRE_HIP_OK;
+	}
+	t->config = now;   // fields beyond in->size: the process-wide values of this moment
+	memcpy(&t->config, in, std::min<size_t>(in->size, sizeof(t->config)));
+	t->config.size = sizeof(t->config);
+	t->hasConfig = true;
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();
+}
+
+int pire_hip_table_config_get(const pire_hip_table* t, pire_hip_config* out)
+try {
+	if (!t || !out || out->size < sizeof(uint32_t)) {
+		SetError("pire_hip_table_config_get: null argument, or out->size does not hold the caller's sizeof(pire_hip_config)");
+		return PIRE_HIP_EINVAL;
+	}
+	pire_hip_config c = GetConfig();
+	{
+		std::shared_lock<std::shared_mutex> stable(const_cast<pire_hip_table*>(t)->adaptMutex);
+		if (t->hasConfig)
+			c = t->config;
+	}
+	const uint32_t n = std::min<uint32_t>(out->size, uint32_t(sizeof(c)));
+	memcpy(out, &c, n);
+	out->size = n;
+	return PIRE_HIP_OK;
+} catch (...) {
+	return pirehip::HandleException();
+}
+
 int pire_hip_table_adapt(pire_hip_table* t, uint32_t* changed_rows)
 try {
 	if (!t) {

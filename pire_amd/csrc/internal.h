@@ -367,6 +367,11 @@ struct pire_hip_table {
 		uint64_t trapsAtLastLook = 0;     // the trap signal when a worker last found nothing to do
 		std::atomic<uint32_t> swaps{0};
 	} bg;
+	// pire_hip_table_config_set(): this table's own configuration (a second user of the library in the same process -- another
+	// component, another thread pool -- sets the process-wide one for itself).  Written under adaptMutex held
+	// exclusively, read by the entry points under TableUse.
+	bool hasConfig = false;
+	pire_hip_config config = {};
 	std::atomic<uint32_t> selfTested[pirehip::kMaxDevices] = {};   // per device, bit k: Dispatch's kernel kind k passed its known-answer
 	                                                               // batch on this table there (api.cpp SelfTest)
 };
@@ -785,16 +790,33 @@ int LaunchRaggedCapture(const ScanParams& p, unsigned long long* workCounter, co
 // then replace numbering and images -- so whatever an entry point derives from t->host after FillParams belongs to the
 // image its ScanParams point at, and an adaptation may run concurrently with scans on other host threads (ADVICE r3:
 // round 3 dropped the lock when FillParams returned).  Two tables (pire_hip_run_pair): acquire in address order.
+extern thread_local const pire_hip_config* g_cfgOverride;   // api.cpp: what GetConfig() returns on this thread when set
 struct TableUse {
 	std::shared_lock<std::shared_mutex> lock;
+	const pire_hip_config* outer = nullptr;
+	bool pushed = false;
 	TableUse() {}
 	TableUse(pire_hip_table* t, bool enqueueOnly) { Acquire(t, enqueueOnly); }
+	TableUse(const TableUse&) = delete;
+	TableUse& operator=(const TableUse&) = delete;
+	~TableUse()
+	{
+		if (pushed)
+			g_cfgOverride = outer;
+	}
 	void Acquire(pire_hip_table* t, bool enqueueOnly)
 	{
 		if (lock.owns_lock())
 			return;   // a second look at the same table inside one entry point (an adaptation would wait for this very lock)
 		MaybeAutoAdapt(t, enqueueOnly);
 		lock = std::shared_lock<std::shared_mutex>(t->adaptMutex);
+		// the table's own configuration, if it has one, for everything this entry point does on this thread (a first-use
+		// self-test in progress keeps its own: it already started from the table's)
+		if (t->hasConfig && !g_cfgOverride) {
+			outer = g_cfgOverride;
+			g_cfgOverride = &t->config;
+			pushed = true;
+		}
 	}
 };
 // for the other translation units: TableUse::Acquire(t) + FillParams

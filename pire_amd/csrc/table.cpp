@@ -1648,7 +1648,12 @@ void BackgroundAdaptStep(pire_hip_table* t, uint64_t threshold)
 // (DESIGN.md 3.1), and a workload whose traffic does not fit the rows must not pay a re-ranking per call.
 void MaybeAutoAdapt(pire_hip_table* t, bool enqueueOnly)
 {
-	const pire_hip_config cfg = GetConfig();
+	pire_hip_config cfg = GetConfig();
+	{
+		std::shared_lock<std::shared_mutex> stable(t->adaptMutex);
+		if (t->hasConfig && !g_cfgOverride)
+			cfg = t->config;   // (pire_hip_table_config_set: the policy is the table's own)
+	}
 	if (cfg.auto_adapt == 1)
 		return;
 	const uint64_t threshold = cfg.auto_adapt_min_traps ? cfg.auto_adapt_min_traps : 256;

@@ -231,3 +231,18 @@ def test_info_for_a_caller_built_against_an_older_header():
     assert bytes(old[:48]) == bytes(full)[:48] and all(b == 0xAB for b in old[48:])
     big = (C.c_uint8 * 400)()
     assert L.pire_hip_table_get_info_sized(t._h, big, 400) == 0 and bytes(big[:C.sizeof(full)]) == bytes(full)
+
+
+def test_a_table_keeps_a_configuration_of_its_own():
+    """pire_hip_table_config_set: the configuration calls on ONE table run under, next to the process-wide one."""
+    t = pire_amd.Table(H.load_blob("c2_single.blob"))
+    before = pb.get_config()
+    assert t.get_config().walk_variant == before.walk_variant
+    t.set_config(walk_variant=2, selftest=1)
+    mine = t.get_config()
+    assert (mine.walk_variant, mine.selftest) == (2, 1) and mine.ragged_variant == before.ragged_variant
+    assert pb.get_config().walk_variant == before.walk_variant          # the process-wide configuration has not moved
+    other = pire_amd.Table(H.load_blob("c2_single.blob"))
+    assert other.get_config().walk_variant == before.walk_variant       # nor has another table's
+    t.set_config()
+    assert t.get_config().walk_variant == before.walk_variant

@@ -48,6 +48,7 @@ def test_gpu_prefix_matches_oracle(case):
 
     blob = H.load_blob(case["blob"])
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    ref = ob.RefScanner.load(blob) if ob.ref_available() else None
     rng = np.random.RandomState(21)
     strings = (H.random_strings(rng, 1500, 120, b"abcdefhelo wrdxHTailnI0123 \t/.:fb") + [b""] * 3 +
                H.random_strings(rng, 300, 80) + [b"hello  world", b"say hello   wod and more", b"aaab", b"xxabc"])
@@ -57,6 +58,8 @@ def test_gpu_prefix_matches_oracle(case):
             want = o.prefix(text, offs, longest, tb, te)
             got = t.prefix(text, offs, longest, tb, te)
             assert (got == want).all(), (longest, tb, te, np.nonzero(got != want)[0][:5])
+            if ref is not None:   # ... and the unmodified reference itself (the GPU searches were held against the restatement only)
+                assert (got == ref.prefix(text, offs, longest, tb, te)).all(), (longest, tb, te)
 
 
 @pytest.mark.gpu

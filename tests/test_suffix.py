@@ -60,6 +60,7 @@ def test_gpu_suffix_matches_oracle(case):
 
     blob = H.load_blob(case["blob"])
     t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+    ref = ob.RefScanner.load(blob) if ob.ref_available() else None
     rng = np.random.RandomState(22)
     strings = (H.random_strings(rng, 1500, 120, b"abcdefhelo wrdxHTailnI0123 \t/.:fb") + [b""] * 3 +
                H.random_strings(rng, 300, 80) + [b"dlrow  olleh", b"x" * 300 + b"cba", b"baaa", b"a"])
@@ -69,6 +70,8 @@ def test_gpu_suffix_matches_oracle(case):
             want = o.suffix(text, offs, longest, te, tb)
             got = t.suffix(text, offs, longest, te, tb)
             assert (got == want).all(), (longest, te, tb, np.nonzero(got != want)[0][:5])
+            if ref is not None:   # ... and the unmodified reference itself
+                assert (got == ref.suffix(text, offs, longest, te, tb)).all(), (longest, te, tb)
 
 
 @pytest.mark.gpu
@@ -91,3 +94,32 @@ def test_gpu_suffix_known_answers():
     strings = [b"b" * k + b"baaa" + b"b" * (k % 3) for k in range(40)]
     tx, offs = H.pack(strings)
     assert (t.suffix(tx, offs, True) == o.suffix(tx, offs, True)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_suffix_whole_blocks_through_the_dense_rows():
+    """Round 6: a whole 16-byte block of the string from a state with a dense row is walked top down through the dense rows
+    alone (exact.hip SuffixKernel).  Strings of 0..700 bytes cut out of the benchmark corpus at every alignment -- blocks that
+    reach a Final or a Dead state, blocks that leave the dense rows, first and last blocks that are not whole -- against the
+    oracle and, where it is built, the unmodified reference; set_a's patterns are $-anchored, a table that dies early, one that
+    never does."""
+    import pire_amd
+
+    big = [b for b in H.big_sets() if b["name"] == "set_a"][0]
+    data = ob.corpus_fill(9, 0, 1024, 1024, H.plants_for(big), threads=4).reshape(-1)
+    rng = np.random.RandomState(6)
+    lens = rng.randint(0, 700, size=1400).astype(np.uint64)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    text = data[:int(offs[-1])]
+    for name in ("set_a", "set_d", "survey_known_answer"):
+        case = [x for x in H.all_cases() + H.big_sets() if x["name"] == name][0]
+        blob = H.load_blob(case["blob"])
+        t, o = pire_amd.Table(blob), ob.OracleScanner(blob)
+        ref = ob.RefScanner.load(blob) if ob.ref_available() else None
+        for longest in (True, False):
+            for te, tb in ((False, False), (True, True)):
+                got = t.suffix(text, offs, longest, te, tb)
+                assert (got == o.suffix(text, offs, longest, te, tb)).all(), (name, longest, te, tb)
+                if ref is not None:
+                    assert (got == ref.suffix(text, offs, longest, te, tb)).all(), (name, longest, te, tb)

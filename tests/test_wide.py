@@ -381,3 +381,27 @@ def test_ragged_kernel_on_the_wide_walk_records_cut_anywhere(pa, torch_cuda, cfg
         assert pb.last_kernel() == "ragged_wide"
         assert (gi == oi).all() and (gf == of).all(), name
         assert (cnt == expected_counts(o, oi, of)).all()
+
+
+@pytest.mark.gpu
+def test_two_tables_with_configurations_of_their_own(pa, torch_cuda, cfg):
+    """pire_hip_table_config_set (round 6): two users of the library in one process, each with its own routing -- one table
+    pinned to the dense rows, one to the class-indexed walk, the process-wide configuration untouched; same answers."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    entry = W.wide_set("dict_1k")
+    blob = W.load_blob(entry["blob"])
+    o = ob.OracleScanner(blob)
+    n, length = 2048, 1024
+    data = records_of(entry, "k128", 3, n, length)
+    oi, of = o.run(data.reshape(-1), np.arange(n + 1, dtype=np.uint64) * length, threads=4)
+    d = torch.as_tensor(data, device="cuda")
+    dense, wide = pa.Table(blob), pa.Table(blob)
+    dense.set_config(walk_variant=1)
+    wide.set_config(walk_variant=2)
+    for _ in range(2):
+        for t, kernel in ((dense, "tiled"), (wide, "wide"), (dense, "tiled")):
+            gi, gf, _c = dev_run_strided(torch, t, d)
+            assert pb.last_kernel() == kernel and (gi == oi).all() and (gf == of).all()
+    assert pb.get_config().walk_variant == 0
