@@ -575,8 +575,8 @@ def main():
             torch.cuda.synchronize()
             adapted_rows += table.adapt()
         del text2
-    # --- 2. the table as pire_hip_table_create ranks it (a-priori byte model, never adapted): a second handle, a short
-    # timed leg on the timed corpus, reported as value_before_adapt.
+    # --- 2. the table as pire_hip_table_create ranks it (a-priori byte model, adaptation switched OFF: auto_adapt = 1): a second
+    # handle, a short timed leg on the timed corpus, reported as value_ranking_frozen (rounds 1-5 called it value_before_adapt).
     # `settle`: an MI355X that has been idle for more than ~1 ms restarts its power management transient -- two or three
     # launches at boost clocks, a dip to 0.8-0.9 ms per launch, recovery after 20-30 launches (~25 ms); profiles/
     # r03_warmup_curve.log.  Every timed leg is therefore preceded by `settle` untimed passes (default 60, 40 ms of
@@ -635,6 +635,7 @@ def main():
 
     if rank == 0:
         scanned = float(n) * length * args.steps * world
+        frozen_value = round(float(n) * length * cold_steps * world / cold_elapsed / 1e9, 2)
         value = scanned / elapsed / 1e9
         algo_bytes = n * length + 5 * run_n                # input read once + u32 state idx + u8 final per string
         avg_ms = float(np.mean(kernel_ms))
@@ -691,8 +692,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": data,
-            "value_before_adapt": round(float(n) * length * cold_steps * world / cold_elapsed / 1e9, 2),
+            # (round 6) "before adapt()" = what a caller gets who never calls pire_hip_table_adapt(): the library's default policy,
+            # calls that only enqueue (leg 2b).  The table whose ranking is FROZEN as created (auto_adapt = 1, leg 2) beside it.
+            "value_before_adapt": enq["value"] if enq else frozen_value,
+            "value_before_adapt_is": ("value_enqueue_only_no_adapt: a fresh table, library defaults, no adapt() call, no device-wide "
+                                      "synchronisation" if enq else "value_ranking_frozen (this run made no enqueue-only leg)"),
             "value_enqueue_only_no_adapt": enq["value"] if enq else None,
+            "value_ranking_frozen": frozen_value,
             "enqueue_only_no_adapt": enq,
             "config": {
                 "workload": f"{WORKLOADS.get(args.set, args.set)} ({args.set}), {shape}, "
@@ -731,7 +737,7 @@ def main():
                 "lds_gather": lds,
                 "kernel": kernel_name, "kernel_avg_ms": round(avg_ms, 4),
                 "kernel_min_ms": round(float(np.min(kernel_ms)), 4),
-                "kernel_avg_ms_before_adapt": round(float(np.mean(cold_ms)), 4),
+                "kernel_avg_ms_ranking_frozen": round(float(np.mean(cold_ms)), 4),
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
             },

@@ -69,6 +69,8 @@ public:
 	{
 		// the PUBLIC hand-off: Scanner::Save (multi.h:307, 557-573); NonrelocScanner saves as Relocatable (604-608);
 		// SimpleScanner::Save (scanner_io.cpp:35-49)
+		if (pire_hip_abi_version() != PIRE_HIP_ABI_VERSION)   // structs of this header vs. the loaded library's: refuse, do not guess
+			throw Pire::Error("pire_hip: libpire_hip.so was built with another ABI version than this header");
 		std::ostringstream out;
 		sc.Save(&out);
 		const std::string blob = out.str();
@@ -84,11 +86,11 @@ public:
 
 	pire_hip_table* Handle() const { return m_table; }
 
-	/* Which states have dense LDS rows is a performance choice the table makes from a byte model of text and then
-	 * corrects from what the scans really visit -- by itself (pire_hip_config.auto_adapt, on by default: a table whose
-	 * scans keep leaving the dense rows re-ranks them at the next launch), or here, explicitly, after a representative
-	 * batch.  Results never depend on it.  Returns the number of rows that entered the dense set.  Must not run
-	 * concurrently with scans on this table (the automatic form may). */
+	/* Which states have rows in LDS is a performance choice the table makes from a byte model of text and then corrects
+	 * from what the scans really visit -- by itself (pire_hip_config.auto_adapt = 0, the default: a worker thread re-ranks a
+	 * copy of the table and a later launch swaps it in; no call is made to wait), or here, explicitly, after a representative
+	 * batch.  Results never depend on it.  Returns the number of rows that entered the dense set.  May run while other
+	 * threads scan with this table (it joins a running worker first). */
 	unsigned Adapt()
 	{
 		uint32_t changed = 0;

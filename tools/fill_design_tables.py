@@ -24,7 +24,7 @@ def headline():
     alg = rf["algorithmic_bytes_per_launch"]
     return f"""| | value | source |
 |---|---|---|
-| `python bench.py --steps 20 --warmup 5` (the driver's command) | **{h['value']:.0f} GB/s**, {h['ms_per_step']:.3f} ms per step; before any adaptation {h['value_before_adapt']:.0f} | `profiles/r06_bench_n1.json` |
+| `python bench.py --steps 20 --warmup 5` (the driver's command) | **{h['value']:.0f} GB/s**, {h['ms_per_step']:.3f} ms per step; no `adapt()` call, enqueue-only {h['value_before_adapt']:.0f}, ranking frozen as created {h.get('value_ranking_frozen', h['value_before_adapt']):.0f} | `profiles/r06_bench_n1.json` |
 | `python bench.py` (defaults: 50 steps) | {hd['value']:.0f} GB/s | `r06_bench_n1_defaults.json` |
 | kernel `ScanTiledKernel<16,2,nt,5>`, HIP events in `bench.py` | avg {rf['kernel_avg_ms']:.4f} ms (min {rf['kernel_min_ms']:.4f}) → {rf['achieved']:.0f} GB/s algorithmic = **{rf['frac']:.3f} of 8 TB/s** ({rf['frac_of_measured_copy_ceiling_6290']:.3f} × the measured copy ceiling of the part) | same |
 | the same 20 launches in `rocprofv3 --kernel-trace --stats` | avg {m.group(1)} ms (min {m.group(2)}, max {m.group(3)}) → {alg / float(m.group(1)) / 1e6:.0f} GB/s = {alg / float(m.group(1)) / 1e6 / 8000:.3f} | `r06_bench_kernel_stats.csv`, `r06_bench_trace_timed_region.txt` |
@@ -102,7 +102,7 @@ def wide():
                 f"{a['kernel']} {a['GBps']:.0f} ({a.get('symbol', '').split('::')[-1]}) |\n")
     out += ("\nEvery string of every batch equal to the oracle's answer (`parity_all_strings` in `profiles/r06_wide_curve.jsonl`).  `bench.py` lines (ranking learned on a held-out "
             "corpus of the batch's size, CPU baseline = the reference on all cores, parity of the whole batch; `enqueue only` = a fresh table, no `adapt()` call, calls that only enqueue):\n\n")
-    out += "| `bench.py --set … --corpus …` | value | kernel | roofline frac (HBM) | tier: states (rows), share outside | before any adaptation | enqueue only, no `adapt()` | reference on the host cores | file |\n|---|---|---|---|---|---|---|---|---|\n"
+    out += "| `bench.py --set … --corpus …` | value | kernel | roofline frac (HBM) | tier: states (rows), share outside | ranking frozen as created (`auto_adapt = 1`) | `value_before_adapt`: enqueue only, no `adapt()` | reference on the host cores | file |\n|---|---|---|---|---|---|---|---|---|\n"
     for f, what in (("set_b_mix_mix", "set_b_mix mix"), ("dict_1k_k32", "dict_1k k32"), ("dict_1k_k128", "dict_1k k128"), ("dict_1k_k512", "dict_1k k512"),
                     ("dict_1k_k1000", "dict_1k k1000"), ("dict_10k_k32", "dict_10k k32"), ("dict_10k_k512", "dict_10k k512"), ("dict_10k_k2048", "dict_10k k2048"),
                     ("dict_10k_k10000", "dict_10k k10000"), ("c5_dict_10k_16k", "dict_10k k10000 --len 16384 (C5's shape: 2^20 × 16 KiB)"),
@@ -116,7 +116,7 @@ def wide():
         w = d["config"]["walk"]
         e = d.get("enqueue_only_no_adapt") or {}
         out += (f"| {what} | **{d['value']:.0f} GB/s** | `{d['roofline']['kernel'].split('::')[-1]}` | {d['roofline']['frac']:.3f} | "
-                f"{w['wide_rows']} ({w['states_with_a_row_of_their_own']}), {w['measured_share_outside_wide_rows'] * 100:.2f} % | {d['value_before_adapt']:.0f} | "
+                f"{w['wide_rows']} ({w['states_with_a_row_of_their_own']}), {w['measured_share_outside_wide_rows'] * 100:.2f} % | {d.get('value_ranking_frozen', d['value_before_adapt']):.0f} | "
                 f"{('%.0f after %d passes' % (e['value'], e['passes_before_the_timed_leg'])) if e else '—'} | "
                 f"{('%.1f GB/s on %d cores, parity %s' % (c['value'], c['cores'], c['parity_vs_gpu'])) if c else '—'} | `r06_bench_{f}.json` |\n")
     return out
