@@ -200,6 +200,9 @@ int FillParams(pire_hip_table* t, ScanParams* p, uint32_t flags, bool wantDist =
 	p->visitWide = d.visitWide;
 	p->wide = d.wideRows ? h.wide : 0;
 	p->zipFull = d.wideRows ? h.zipFull : 0;
+	p->wideOutSlot = p->wide;
+	p->wideRowsStream = d.wideRows ? d.wideRowsStream : nullptr;
+	p->wideStream = d.wideRows ? d.wideStream : 0;
 	p->outsideDense = h.outsideDense;
 	p->outsideWide = h.outsideWide;
 	p->massMeasured = h.massMeasured;
@@ -418,7 +421,7 @@ namespace {
 // kernel scans a batch whose answer the host image's transitions give (the accessor walk of pire_hip_table_next, 131 072
 // steps), on a stream and with visit counters of its own.  The text is a walk through the table's own states that
 // stays out of the dead ones where it can, so that the end state depends on every byte of the string.
-enum KernelKind : int { kKindGeneric, kKindTiled, kKindWide, kKindRagged, kKindRaggedWide, kKindStream };
+enum KernelKind : int { kKindGeneric, kKindTiled, kKindWide, kKindRagged, kKindRaggedWide, kKindStream, kKindStreamWide };
 
 int SelfTest(const ScanParams& p, int kind, const char* name, uint32_t mode)
 {
@@ -496,7 +499,7 @@ int SelfTest(const ScanParams& p, int kind, const char* name, uint32_t mode)
 		unsigned long long* work = reinterpret_cast<unsigned long long*>(base + offWork);
 		rc = kind == kKindWide ? LaunchWide(q, own) : kind == kKindTiled ? LaunchTiled(q, own)
 		     : kind == kKindRaggedWide ? LaunchRaggedWide(q, work, own) : kind == kKindStream ? LaunchStream(q, own)
-		     : kind == kKindRagged ? LaunchRagged(q, work, own) : LaunchGeneric(q, own);
+		     : kind == kKindStreamWide ? LaunchStreamWide(q, own) : kind == kKindRagged ? LaunchRagged(q, work, own) : LaunchGeneric(q, own);
 		if (rc != PIRE_HIP_OK)
 			break;
 		if ((e = hipMemcpyAsync(got.data(), base + offOut, kStrings * 4, hipMemcpyDeviceToHost, own)) != hipSuccess ||
@@ -538,10 +541,12 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 	// a table whose scans keep leaving the dense rows: the class-indexed walk (wide.hip; offset batches: the ragged kernel on it)
 	const bool wideTable = (tiled || ragged) && WideWanted(p, GetConfig());
 	const bool wide = tiled && p.len >= 256 && wideTable;
-	const bool raggedWide = ragged && wideTable;
-	const bool streamed = ragged && !raggedWide && StreamEligible(p, totalBytesHint);
-	const int kind = wide ? kKindWide : tiled ? kKindTiled : raggedWide ? kKindRaggedWide : streamed ? kKindStream : ragged ? kKindRagged : kKindGeneric;
-	static const char* const kNames[] = {"generic", "tiled", "wide", "ragged", "ragged_wide", "stream"};
+	const bool streamWide = ragged && wideTable && StreamWideEligible(p, totalBytesHint);
+	const bool raggedWide = ragged && wideTable && !streamWide;
+	const bool streamed = ragged && !wideTable && StreamEligible(p, totalBytesHint);
+	const int kind = wide ? kKindWide : tiled ? kKindTiled : streamWide ? kKindStreamWide : raggedWide ? kKindRaggedWide : streamed ? kKindStream
+	                 : ragged ? kKindRagged : kKindGeneric;
+	static const char* const kNames[] = {"generic", "tiled", "wide", "ragged", "ragged_wide", "stream", "stream_wide"};
 	if (p.owner && !(p.owner->selfTested[p.workDevice].load(std::memory_order_relaxed) & (1u << kind))) {
 		const uint32_t mode = GetConfig().selftest;
 		hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
@@ -561,8 +566,9 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 	NoteKernel(kNames[kind]);
 	if (p.owner && !(p.flags & (1u << 23)))   // (what the live estimate of FillParams divides the trap signal by)
 		p.owner->bytesScanned.fetch_add(p.offsets ? totalBytesHint : p.n * p.len, std::memory_order_relaxed);
-	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : raggedWide ? LaunchRaggedWide(p, workCounter, stream)
-	         : streamed ? LaunchStream(p, stream) : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
+	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : streamWide ? LaunchStreamWide(p, stream)
+	         : raggedWide ? LaunchRaggedWide(p, workCounter, stream) : streamed ? LaunchStream(p, stream)
+	         : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);
 	if (g_timing) {
 		(void)hipEventRecord(ev1, stream);
 		if (rc == PIRE_HIP_OK) {

@@ -190,6 +190,31 @@ inline uint32_t WideCapacity(uint32_t letters, uint32_t regexps, uint32_t states
 	return rows - 1 < states ? rows - 1 : states;
 }
 
+// ---- the stream kernel on the wide walk (stream.hip, round 6) ------------------------------------------------------------
+// The stream kernel keeps the positions of a sub-task's strings in LDS, per wave -- with the wide walk's image beside them:
+// sub-tasks of 640 strings (42 KB for 16 waves) and an image of its own with a SMALLER TIER, the first `StreamWideTier` states
+// of the same numbering (entries that lead beyond it are the escape state's; a zipped image keeps its rows and drops headers).
+constexpr uint32_t kStreamWideStrings = 640;   // at least (a zipped image that leaves more room gets larger sub-tasks, stream.hip)
+constexpr uint32_t kStreamWideStageBytes = 16 * (kStreamWideStrings + 16) * 4;   // kStreamWaves waves
+inline uint32_t StreamWideTier(uint32_t letters, uint32_t regexps, uint32_t wide, uint32_t zipFull)
+{
+	if (!wide)
+		return 0;
+	const uint32_t r = regexps <= kMaxLdsCountRegexps ? regexps : 0;
+	const uint32_t budget = kLdsPerBlock - kStreamWideStageBytes - 64;
+	if (MakeWideLayout(zipFull ? zipFull : 1, letters, r, zipFull).total > budget)
+		return 0;   // (a zipped image whose rows alone do not leave the room)
+	uint32_t lo = zipFull ? zipFull : 1, hi = wide;   // the largest tier whose layout fits (the layout grows with the tier)
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi + 1) / 2;
+		if (MakeWideLayout(mid, letters, r, zipFull).total <= budget)
+			lo = mid;
+		else
+			hi = mid - 1;
+	}
+	return lo;
+}
+
 // Host-side, fully decoded scanner.  States are in the REFERENCE's numbering ("orig") unless a name says perm.
 struct HostTable {
 	// geometry (mirrors Scanner::Locals, multi.h:315-323)
@@ -269,6 +294,8 @@ struct DeviceTable {
 	uint16_t* compactRows = nullptr;  // [(compact+1) rows] LDS address / 4 of the next state's row (last row = escape), padded
 	uint16_t* wideRows = nullptr;     // [(wide+1) rows] the wide walk's LDS image (WideLayout), or null
 	uint16_t* next16 = nullptr;       // [states*letters] nextPerm as u16 when states <= 65536 (half the L2 footprint), or null
+	uint16_t* wideRowsStream = nullptr;   // the wide image once more with the stream kernel's smaller tier (StreamWideTier), or null
+	uint32_t wideStream = 0;          // ... its tier
 	uint32_t* visitWide = nullptr;    // [wide+1] sampled visits of the wide rows (one lane per wave per 128-byte tile)
 	uint32_t* visitHot = nullptr;     // [256]    sampled visits of hot perm ids (one lane per wave per tile)
 	uint32_t* visitCold = nullptr;    // [states] trapped chunks that ended in this (cold) perm id
@@ -406,6 +433,10 @@ struct ScanParams {
 	uint32_t* visitWide;
 	uint32_t wide;              // states with a wide row; 0 = no image
 	uint32_t zipFull;           // != 0: the image is zipped (internal.h MakeWideLayout), this many states have a row of their own
+	uint32_t wideOutSlot;       // visitWide[wideOutSlot] counts the visit samples that found their lane outside the tier (== wide,
+	                            // except under the stream kernel's image, whose tier is a prefix of the table's)
+	const uint16_t* wideRowsStream;   // host side only: the stream kernel's image (LaunchStreamWide swaps it in) and its tier
+	uint32_t wideStream;
 	float outsideDense, outsideWide;   // host side only: LaunchTiled's choice between the dense and the wide walk
 	uint32_t forceLanes;               // host side only: 1 / 2 = LaunchWide takes the kernel with that many strings per lane (the self-test)
 	std::atomic<uint64_t>* wideLaunched;   // host side only: wave-chunks handed to the wide walk since the last adapt()
@@ -676,7 +707,7 @@ int UploadTable(pire_hip_table* t, DeviceTable* image);   // image of the CURREN
 int BuildDeviceImage(const HostTable& h, int dev, DeviceTable* out);   // allocations + copies of a ranked table's image, current device
 void JoinBackgroundAdapt(pire_hip_table* t);   // waits for an adaptation in the background and drops what it prepared
 void EnsureRanked(pire_hip_table* t);
-std::vector<uint16_t> BuildWideRows(const HostTable& h);   // the wide walk's LDS image (WideLayout), current numbering
+std::vector<uint16_t> BuildWideRows(const HostTable& h, uint32_t tier = 0);   // the wide walk's LDS image (WideLayout), current numbering; tier != 0: of the first `tier` states only
 // after UploadTable, current device: the per-state distance tables (built on first use)
 int EnsureActDist(pire_hip_table* t, const uint8_t** distFinalPerm, const uint8_t** distFlaggedPerm);
 void FreeAllDeviceTables(pire_hip_table* t);
@@ -709,6 +740,8 @@ int LaunchRaggedWide(const ScanParams& p, unsigned long long* workCounter, hipSt
 // stream.hip: offset batches of many short strings, every lane a run of consecutive strings
 bool StreamEligible(const ScanParams& p, uint64_t totalBytesHint);
 int LaunchStream(const ScanParams& p, hipStream_t stream);
+bool StreamWideEligible(const ScanParams& p, uint64_t totalBytesHint);   // ... on the class-indexed walk (offset batches of a wide table)
+int LaunchStreamWide(const ScanParams& p, hipStream_t stream);
 // segmented.hip: few long strings, cut into segments that are scanned in parallel (speculatively; the chain of
 // segments is then followed on the host, so the call synchronises its stream)
 bool SegmentedEligible(uint64_t n, uint64_t totalBytes);

@@ -33,6 +33,7 @@
 //     (ExactRest).  Results never depend on which rows are dense, on lambda or on how the batch was cut.
 
 #include "stream_common.h"
+#include "wide_common.h"
 
 namespace pirehip {
 
@@ -108,11 +109,57 @@ __device__ __forceinline__ void StepChunkB(const u32x4 v, uint32_t c, uint32_t s
 	snap = sn;
 }
 
+// ---- the same on the class-indexed walk (WIDE: 2 = rows of u16 entries in LDS, 3 = the zipped image; wide_common.h) -----------
+// The state is a device id with a place in the tier or `p.wide` (the escape state: sticky, S.cold holds the id).  The classes
+// of the sixteen bytes do not depend on the walk; the restart at a boundary is a select in front of the row's address.
+template <bool ZIP>
+__device__ __forceinline__ void WideChunkPlain(const WideConst& K, const u32x4 v, uint32_t& st)
+{
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		const uint32_t c0 = HotLookup(x & 0xFFu);
+		const uint32_t c1 = HotLookup((x >> 8) & 0xFFu);
+		const uint32_t c2 = HotLookup((x >> 16) & 0xFFu);
+		const uint32_t c3 = HotLookup(x >> 24);
+		st = WideEntry<ZIP>(st, K, c0);
+		st = WideEntry<ZIP>(st, K, c1);
+		st = WideEntry<ZIP>(st, K, c2);
+		st = WideEntry<ZIP>(st, K, c3);
+	}
+}
+
+template <bool ZIP>
+__device__ __forceinline__ void WideChunkB(const WideConst& K, const u32x4 v, uint32_t c, uint32_t start, uint32_t& st, uint32_t& snap)
+{
+	const unsigned long long any = __ballot(c < 16u), b0 = __ballot((c & 1u) != 0), b1 = __ballot((c & 2u) != 0),
+	                         b2 = __ballot((c & 4u) != 0), b3 = __ballot((c & 8u) != 0);
+	uint32_t h = st, sn = st;
+#pragma unroll
+	for (int w = 0; w < 4; ++w) {
+		const uint32_t x = v[w];
+		const uint32_t cl[4] = {HotLookup(x & 0xFFu), HotLookup((x >> 8) & 0xFFu), HotLookup((x >> 16) & 0xFFu), HotLookup(x >> 24)};
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int j = 4 * w + b;
+			const unsigned long long m = any & ((j & 1) ? b0 : ~b0) & ((j & 2) ? b1 : ~b1) & ((j & 4) ? b2 : ~b2) & ((j & 8) ? b3 : ~b3);
+			const bool at = __builtin_amdgcn_inverse_ballot_w64(m);
+			const uint32_t next = WideEntry<ZIP>(at ? start : h, K, cl[b]);
+			sn = at ? h : sn;
+			h = next;
+		}
+	}
+	st = h;
+	snap = sn;
+}
+
 // Bytes from .. 15 of chunk k of the window, exactly, for one lane: boundaries as they come (any number, empty strings
 // included), the exact step for the bytes of live strings.  `st` = the state in front of byte `from`.  Rolled: the cold path.
-__device__ __forceinline__ void ExactRest(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, LdsWordPtr eo,
+template <int WIDE>
+__device__ __forceinline__ void ExactRest(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const WideLayout& W, const WideConst& K, LdsWordPtr eo,
                                           const u32x4& v, uint32_t k, uint32_t from, uint32_t st, StreamLane& S, uint32_t sampleLane)
 {
+	const uint32_t lim = WIDE ? p.wide : p.hot;
 #pragma unroll 1
 	for (uint32_t i = from; i < 16; ++i) {
 		while (S.E - S.wpos == 16u * k + i) {
@@ -121,26 +168,42 @@ __device__ __forceinline__ void ExactRest(const ScanParams& p, const uint8_t* ld
 		}
 		if (S.live) {
 			const uint32_t word = i < 8 ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w);
-			st = SlowStep(p, lds, L, st, (word >> (8u * (i & 3u))) & 0xFFu);
+			const uint32_t byte = (word >> (8u * (i & 3u))) & 0xFFu;
+			if constexpr (WIDE != 0) {
+				// the row's entry in LDS; the table in memory only where that says "no row" (the state has none, or the target)
+				const uint32_t c2 = HotLookup(byte);
+				uint32_t next = WideEntry<WIDE == 3>(st < lim ? st : lim, K, c2);
+				if (next == lim) {
+					next = WideNextC2<true>(p, st, c2);
+					asm volatile("" : "+v"(next));   // (the wait belongs in here)
+				}
+				st = next;
+			} else {
+				st = SlowStep(p, lds, L, st, byte);
+			}
 		}
 	}
-	S.hs = st < p.hot ? st : p.hot;
+	S.hs = st < lim ? st : lim;
 	S.cold = st;
 	// tell pire_hip_table_adapt() which rows deserve LDS, sampled like TrapChunk's
-	if (S.live && st >= p.hot && (threadIdx.x & 63) == sampleLane) {
+	if (S.live && st >= lim && (threadIdx.x & 63) == sampleLane) {
 		atomicAdd(&p.visitCold[st], 1u);
-		atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + kLdsTrapSlot, 1u);
+		if constexpr (WIDE != 0)
+			atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+		else
+			atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + kLdsTrapSlot, 1u);
 	}
 }
 
 // One window: start fetching the next line into `nxt`, walk the line held in `cur`.  Returns whether any lane of the wave
 // has a further line.
-template <bool START0>
-__device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, LdsWordPtr eo,
-                                            uint64_t lineBase, StreamLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8], uint32_t iter,
-                                            bool walk)
+template <bool START0, int WIDE>
+__device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const WideLayout& W, const WideConst& K,
+                                            LdsWordPtr eo, uint64_t lineBase, StreamLane& S, u32x4 (&cur)[8], u32x4 (&nxt)[8],
+                                            uint32_t iter, bool walk)
 {
 	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t lim = WIDE ? p.wide : p.hot;   // S.hs == lim: the state has no row, S.cold is its id
 	const bool more = S.laneEnd > S.wpos + 128u;   // boundaries of this lane lie behind this window
 	// The NEXT line is requested before this one is waited for (its address depends on nothing but the window counter),
 	// as the tiled kernel does: its latency then runs behind the wait, the transpose and the walk of this line.  With the
@@ -154,8 +217,12 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 	asm volatile("s_waitcnt vmcnt(8)"
 	             : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
 	TransposeTile(cur, lane);
-	if (lane == (iter & 63) && S.live)   // visit sample, as in the tiled kernel
-		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
+	if (lane == (iter & 63) && S.live) {   // visit sample, as in the tiled kernel
+		if constexpr (WIDE != 0)
+			WideSample<WIDE == 3>(p, lds, W, S.hs);
+		else
+			atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
+	}
 	// (`walk` is false in a sub-task's first phase only: its window is the line in FRONT of the lanes' first lines, there
 	// to get the first lines requested from inside the loop -- asynchronous asm loads issued in front of the loop end up
 	// in registers the loop does not use, and the compiler copies them over while they are in flight)
@@ -174,37 +241,48 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 		if (!__any(c < 16u)) {
 #endif
 			// no string of the wave ends in this chunk: the tiled kernel's step
-			uint32_t h = S.hs;
+			if constexpr (WIDE != 0) {
+				uint32_t h = S.hs;
+				WideChunkPlain<WIDE == 3>(K, cur[k], h);
+				S.hs = h;
+				if (h == lim && S.live)   // (lanes between their strings walk bytes that are not theirs: wherever that leads)
+					WideTrapChunk<true, WIDE == 3>(p, lds, W, K, cur[k], hs0, S.hs, S.cold, (iter * 8 + k) & 15u);
+			} else {
+				uint32_t h = S.hs;
 #pragma unroll
-			for (int w = 0; w < 4; ++w) {
-				const uint32_t x = cur[k][w];
-				h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
-				h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
-				h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
-				h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
-			}
-			S.hs = h;
-			if (h == p.hot && S.live) {
-				// TrapChunk without the compact tier (its LDS holds the string positions here): the chunk again through the
-				// full table, the cold end state sampled for pire_hip_table_adapt()
-				const uint32_t f = SlowChunk(p, lds, L, cur[k], hs0 != p.hot ? hs0 : S.cold);
-				S.hs = f < p.hot ? f : p.hot;
-				S.cold = f;
-				if (f >= p.hot && lane == ((iter * 8 + k) & 63)) {
-					atomicAdd(&p.visitCold[f], 1u);
-					atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + kLdsTrapSlot, 1u);
+				for (int w = 0; w < 4; ++w) {
+					const uint32_t x = cur[k][w];
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0400u));
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0401u));
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0402u));
+					h = HotLookup(__builtin_amdgcn_perm(h, x, 0x0c0c0403u));
+				}
+				S.hs = h;
+				if (h == p.hot && S.live) {
+					// TrapChunk without the compact tier (its LDS holds the string positions here): the chunk again through the
+					// full table, the cold end state sampled for pire_hip_table_adapt()
+					const uint32_t f = SlowChunk(p, lds, L, cur[k], hs0 != p.hot ? hs0 : S.cold);
+					S.hs = f < p.hot ? f : p.hot;
+					S.cold = f;
+					if (f >= p.hot && lane == ((iter * 8 + k) & 63)) {
+						atomicAdd(&p.visitCold[f], 1u);
+						atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + kLdsTrapSlot, 1u);
+					}
 				}
 			}
 		} else {
 			uint32_t snap;
-			StepChunkB<START0>(cur[k], c, p.startPerm, S.hs, snap);
+			if constexpr (WIDE != 0)
+				WideChunkB<WIDE == 3>(K, cur[k], c, p.startPerm, S.hs, snap);
+			else
+				StepChunkB<START0>(cur[k], c, p.startPerm, S.hs, snap);
 			const bool isB = c < 16u;
-			// the part of the chunk that belongs to the current string left the dense rows (or was outside them all along),
+			// the part of the chunk that belongs to the current string left the rows (or was outside them all along),
 			// or the part that belongs to the string starting here did: this lane's chunk again, exactly
-			const bool trapBefore = S.live && (isB ? snap == p.hot : S.hs == p.hot);
-			const bool trapAfter = isB && S.hs == p.hot && S.nxt < S.sEnd;
+			const bool trapBefore = S.live && (isB ? snap == lim : S.hs == lim);
+			const bool trapAfter = isB && S.hs == lim && S.nxt < S.sEnd;
 			bool exact = trapBefore || trapAfter;
-			uint32_t from = 0, st = hs0 != p.hot ? hs0 : S.cold;
+			uint32_t from = 0, st = hs0 != lim ? hs0 : S.cold;
 #if defined(PIRE_EXP) && PIRE_EXP == 4   // timing experiment: boundary chunks walked, boundaries not processed
 			if (false) {
 #else
@@ -218,12 +296,12 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 				}
 			}
 			if (exact)
-				ExactRest(p, lds, L, eo, cur[k], uint32_t(k), from, st, S, (iter * 8 + k) & 63);
+				ExactRest<WIDE>(p, lds, L, W, K, eo, cur[k], uint32_t(k), from, st, S, (iter * 8 + k) & 63);
 		}
 	}
 	// strings that end with the line: their boundary is here, not in a window of its own (which may not exist)
 	while (S.E - S.wpos == 128u) {
-		StreamBoundary(eo, S, S.hs != p.hot ? S.hs : S.cold);
+		StreamBoundary(eo, S, S.hs != lim ? S.hs : S.cold);
 		S.hs = p.startPerm;
 		S.cold = p.startPerm;
 	}
@@ -253,7 +331,9 @@ __device__ __forceinline__ bool StreamPhase(const ScanParams& p, uint8_t* lds, c
 #define PIRE_SCLK(k) do { } while (0)
 #endif
 
-template <bool START0>
+// WIDE (round 6): 0 = the dense rows; 2 / 3 = the class-indexed walk on the stream image of the table (internal.h
+// StreamWideTier: plain rows / zipped), sub-tasks of kStreamWideStrings strings, end-of-string records from memory.
+template <bool START0, int WIDE>
 __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeom g)
 {
 #ifdef PIRE_HIP_TUNING
@@ -261,11 +341,18 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 	const unsigned long long sclkStart = sclkT;
 #endif
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
+	const WideLayout W = WIDE ? MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, WIDE == 3 ? p.zipFull : 0) : WideLayout();
+	const WideConst K = WIDE ? MakeWideConst(p, W) : WideConst();
+	LdsLayout L = {};
+	if constexpr (WIDE != 0)
+		L.countsOff = W.countsOff;   // what FinishWith looks at
+	else
+		L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
 	FinRec* finHot = reinterpret_cast<FinRec*>(lds + L.total);
 	const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
-	LdsWordPtr eo = reinterpret_cast<LdsWordPtr>(
-		static_cast<uintptr_t>(L.total + kRaggedFinBytes + wave * kStreamStageWords * 4u));
+	LdsWordPtr eo = reinterpret_cast<LdsWordPtr>(static_cast<uintptr_t>(
+		WIDE ? W.total + wave * (g.maxStrings + 16u) * 4u : L.total + kRaggedFinBytes + wave * kStreamStageWords * 4u));
+	const uint32_t kMaxStrings = WIDE ? g.maxStrings : kStreamMaxStrings;   // (wide walk: what the image leaves room for)
 
 	// ---- this wave's task: strings [i0, i1), found before the table is copied (the searches' round trips overlap the
 	// other waves' part of the copy)
@@ -273,17 +360,19 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 	const bool hasTask = StreamTaskOfWave(p.offsets, p.n, g, i0, i1);
 	(void)hasTask;
 	PIRE_SCLK(0);
-	{
-		const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+	const FinRec* recs = (p.flags & PIRE_HIP_RUN_END) ? p.finEnd : p.finSelf;
+	if constexpr (WIDE != 0) {
+		LoadWideToLds(p, lds, W);   // ends with a barrier
+	} else {
 		for (uint32_t i = threadIdx.x; i < p.hot; i += blockDim.x)
 			finHot[i] = recs[i];
+		LoadTableToLds(p, lds, L);   // ends with a barrier
 	}
-	LoadTableToLds(p, lds, L);   // ends with a barrier
 	PIRE_SCLK(1);
 
 	const uint64_t textBase = reinterpret_cast<uint64_t>(p.text);
 	uint32_t iter = 0;
-	const uint32_t subStrings = StreamSubStrings(i1 - i0);
+	const uint32_t subStrings = StreamSubStrings(i1 - i0, kMaxStrings);
 	for (uint64_t sub = i0; sub < i1; sub += subStrings) {
 		// (what the set-up derives from the lane number -- a dozen addresses and positions -- is cheap to compute and was
 		// hoisted out of this loop and carried across the window loop through scratch: opaque here, so it stays inside)
@@ -301,9 +390,20 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 				const uint32_t q = base + lane;
 				uint32_t st = p.startPerm;
 				if (q < m)
-					for (uint64_t at = p.offsets[sub + q], end = p.offsets[sub + q + 1]; at < end; ++at)
-						st = SlowStep(p, lds, L, st, p.text[at]);
-				FinishRagged<false>(p, lds, L, finHot, uint32_t(sub + q), q < m, st);
+					for (uint64_t at = p.offsets[sub + q], end = p.offsets[sub + q + 1]; at < end; ++at) {
+						if constexpr (WIDE != 0)
+							st = WideNext<true>(p, st, uint32_t(lds[p.text[at]]) >> 1);
+						else
+							st = SlowStep(p, lds, L, st, p.text[at]);
+					}
+				if constexpr (WIDE != 0) {
+					u32x4 raw = {0, 0, 0, 0};
+					if (q < m)
+						raw = *reinterpret_cast<const u32x4*>(&recs[st]);
+					FinishWith<false>(p, lds, L, uint32_t(sub + q), q < m, raw);
+				} else {
+					FinishRagged<false>(p, lds, L, finHot, uint32_t(sub + q), q < m, st);
+				}
 			}
 			continue;
 		}
@@ -332,10 +432,10 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		bool walk = false;
 		PIRE_SCLK(2);
 		for (;; iter += 2) {
-			if (!StreamPhase<START0>(p, lds, L, eo, lineBase, S, a, b, iter, walk))
+			if (!StreamPhase<START0, WIDE>(p, lds, L, W, K, eo, lineBase, S, a, b, iter, walk))
 				break;
 			walk = true;
-			if (!StreamPhase<START0>(p, lds, L, eo, lineBase, S, b, a, iter + 1, true))
+			if (!StreamPhase<START0, WIDE>(p, lds, L, W, K, eo, lineBase, S, b, a, iter + 1, true))
 				break;
 		}
 		PIRE_SCLK(3);
@@ -344,10 +444,6 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		// cost a microsecond per 64 strings one after the other)
 #if defined(PIRE_EXP) && PIRE_EXP == 1   // timing experiment: no flush
 		for (uint32_t base = m; base < m; base += 256) {
-#elif defined(PIRE_EXP) && PIRE_EXP == 2   // timing experiment: the flush 64 strings at a time
-		for (uint32_t base = 0; base < m; base += 64)
-			FinishRagged<false>(p, lds, L, finHot, uint32_t(sub + base + lane), base + lane < m, base + lane < m ? eo[base + lane + 1] : 0u);
-		for (uint32_t base = m; base < m; base += 256) {
 #else
 		for (uint32_t base = 0; base < m; base += 256) {
 #endif
@@ -355,7 +451,13 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				const uint32_t q = base + uint32_t(j) * 64 + lane;
-				rec[j] = FinRecordOf(p, finHot, q < m, q < m ? eo[q + 1] : 0u);
+				if constexpr (WIDE != 0) {   // every record from memory (the LDS is the rows'); the four loads on their way together
+					rec[j] = u32x4{0, 0, 0, 0};
+					if (q < m)
+						rec[j] = *reinterpret_cast<const u32x4*>(&recs[eo[q + 1]]);
+				} else {
+					rec[j] = FinRecordOf(p, finHot, q < m, q < m ? eo[q + 1] : 0u);
+				}
 			}
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
@@ -379,7 +481,10 @@ __global__ __launch_bounds__(1024) void ScanStreamKernel(ScanParams p, StreamGeo
 		}
 	}
 #endif
-	FlushCounts(p, lds, L);
+	if constexpr (WIDE != 0)
+		FlushWide(p, lds, W);
+	else
+		FlushCounts(p, lds, L);
 }
 
 // ------------------------------------------------------------------------------------------ launcher
@@ -408,6 +513,21 @@ bool StreamEligible(const ScanParams& p, uint64_t totalBytesHint)
 
 #ifdef PIRE_HIP_TUNING
 static unsigned long long* g_streamClockBuf = nullptr;
+// stage clocks: accumulated over launches (no synchronisation here: a drained GPU drops its clocks and the stamps
+// would describe another machine); pire_hip_debug_stream_clocks() reads and clears them
+static void StreamTuning(ScanParams& p, StreamGeom& g)
+{
+	p.stamps = nullptr;
+	if (getenv("PIRE_HIP_DEBUG_STREAM_CLOCKS")) {
+		if (!g_streamClockBuf) {
+			(void)hipMalloc(reinterpret_cast<void**>(&g_streamClockBuf), 16 * 8);
+			(void)hipMemset(g_streamClockBuf, 0, 16 * 8);
+		}
+		p.stamps = g_streamClockBuf;
+	}
+	if (const char* lam = getenv("PIRE_HIP_STREAM_LAMBDA"))
+		g.lambda = uint32_t(std::max(1, atoi(lam)));
+}
 #endif
 
 int LaunchStream(const ScanParams& p0, hipStream_t stream)
@@ -422,11 +542,12 @@ int LaunchStream(const ScanParams& p0, hipStream_t stream)
 	const LdsLayout L = MakeLayout(p.hot, p.outCounts ? p.regexps : 0, 256u, 0);
 	const uint32_t ldsBytes = L.total + kRaggedFinBytes + kStreamWaves * kStreamStageWords * 4;
 	const bool start0 = p.startPerm == 0;
-	hipError_t e = SetDynamicLds(start0 ? reinterpret_cast<const void*>(ScanStreamKernel<true>) : reinterpret_cast<const void*>(ScanStreamKernel<false>),
+	hipError_t e = SetDynamicLds(start0 ? reinterpret_cast<const void*>(ScanStreamKernel<true, 0>) : reinterpret_cast<const void*>(ScanStreamKernel<false, 0>),
 	                             ldsBytes);
 	if (e != hipSuccess)
 		return HipFail(e, "hipFuncSetAttribute(LDS)");
 	StreamGeom g;
+	g.maxStrings = kStreamMaxStrings;
 	g.lambda = 16;   // a boundary costs the wave a few lane-steps' worth of instructions (1 / 16 / 64 measured: 16 by a hair); what matters is that keys stay distinct among empty strings
 	g.minTaskUnits = 64 * 256;
 	// every CU (the kernel starts as many of a block's waves as the batch has work for, see perBlock there); the host
@@ -434,23 +555,77 @@ int LaunchStream(const ScanParams& p0, hipStream_t stream)
 	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), p.n / 64));
 	NoteKernel("stream", start0 ? "pirehip::ScanStreamKernel<start0>" : "pirehip::ScanStreamKernel<any start>");
 #ifdef PIRE_HIP_TUNING
-	// stage clocks: accumulated over launches (no synchronisation here: a drained GPU drops its clocks and the stamps
-	// would describe another machine); pire_hip_debug_stream_clocks() reads and clears them
-	p.stamps = nullptr;
-	if (getenv("PIRE_HIP_DEBUG_STREAM_CLOCKS")) {
-		if (!g_streamClockBuf) {
-			(void)hipMalloc(reinterpret_cast<void**>(&g_streamClockBuf), 16 * 8);
-			(void)hipMemset(g_streamClockBuf, 0, 16 * 8);
-		}
-		p.stamps = g_streamClockBuf;
-	}
-	if (const char* lam = getenv("PIRE_HIP_STREAM_LAMBDA"))
-		g.lambda = uint32_t(std::max(1, atoi(lam)));
+	StreamTuning(p, g);
 #endif
 	if (start0)
-		hipLaunchKernelGGL(ScanStreamKernel<true>, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+		hipLaunchKernelGGL((ScanStreamKernel<true, 0>), dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
 	else
-		hipLaunchKernelGGL(ScanStreamKernel<false>, dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+		hipLaunchKernelGGL((ScanStreamKernel<false, 0>), dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+	e = hipGetLastError();
+	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "stream kernel launch");
+}
+
+// ---- the class-indexed walk (round 6) -------------------------------------------------------------------------------------
+// Offset batches of a table whose scans keep leaving the dense rows took the ragged kernel on the wide walk: one string per
+// lane, windows 44 % full on URL-sized strings and every chunk of the longest lane paid by the whole wave -- 0.83-1.03 TB/s
+// on a blacklist scanner's URL batches whose working set FITS the rows (profiles/r06_wide_curve.jsonl), a quarter of what
+// the same walk does on fixed-length records.  The stream kernel's cut (runs of consecutive strings, whole lines, boundaries
+// inside the chunk walk) on the same step; the price is LDS: the strings' positions sit beside the image, so the image is the
+// table's first StreamWideTier states (a zipped image: the same rows, fewer headers).
+bool StreamWideEligible(const ScanParams& p, uint64_t totalBytesHint)
+{
+	const uint32_t variant = GetConfig().ragged_variant;
+	if (variant == 1 || !p.wideRowsStream || !p.next16 || !p.wideStream)
+		return false;
+	if (!p.offsets || p.ends || p.initIdx || (p.flags & kPermIds) || p.startPerm >= p.wideStream)
+		return false;
+	if (p.n >= (1ull << 32) - (1ull << 16) || p.n < 64)
+		return false;
+	// Opt-in only (ragged_variant = 2).  Measured on URL batches of the blacklist scanners, 8 M strings (profiles/
+	// r06_stream_wide_urls.jsonl): where every state of the table has a place in the zipped tier 923 against the ragged
+	// kernel's 949 GB/s; wherever lanes leave the tier -- and this image's tier is the smaller one -- 0.33-0.52 against
+	// 0.59-1.03 TB/s: in a URL batch every 16-byte chunk of a wave holds a string boundary, a chunk with a boundary AND a lane
+	// outside the rows is walked again byte by byte, and with 0.6 % of the steps outside the rows that is every chunk.
+	(void)totalBytesHint;
+	return variant == 2;
+}
+
+int LaunchStreamWide(const ScanParams& p0, hipStream_t stream)
+{
+	if (int rc = CheckCounts(p0))
+		return rc;
+	ScanParams p = p0;
+	p.wideOutSlot = p0.wide;   // (the table's counters: the slot behind ITS tier counts the samples outside)
+	p.wide = p0.wideStream;
+	p.wideRows = p0.wideRowsStream;
+	const bool zip = p.zipFull != 0;
+	int cus = 0;
+	if (int rc = DeviceCUs(&cus))
+		return rc;
+	const WideLayout W = MakeWideLayout(p.wide, p.letters, p.outCounts ? p.regexps : 0, p.zipFull);
+	// sub-tasks as large as the image leaves room for (a zipped image of a few thousand states: most of the dense kernel's 1 280)
+	StreamGeom g;
+	g.maxStrings = W.total + 64 < kLdsPerBlock ? std::min<uint32_t>(kStreamMaxStrings, ((kLdsPerBlock - W.total - 64) / (kStreamWaves * 4) - 16) / 64 * 64) : 0;
+	const uint32_t ldsBytes = W.total + kStreamWaves * (g.maxStrings + 16) * 4;
+	if (g.maxStrings < kStreamWideStrings || ldsBytes > kLdsPerBlock) {
+		SetError("stream kernel on the wide walk: the image does not leave room for the strings' positions");
+		return PIRE_HIP_EINVAL;
+	}
+	hipError_t e = SetDynamicLds(zip ? reinterpret_cast<const void*>(ScanStreamKernel<false, 3>) : reinterpret_cast<const void*>(ScanStreamKernel<false, 2>),
+	                             ldsBytes);
+	if (e != hipSuccess)
+		return HipFail(e, "hipFuncSetAttribute(LDS)");
+	g.lambda = 16;
+	g.minTaskUnits = 64 * 256;
+	const uint64_t blocks = std::max<uint64_t>(1, std::min<uint64_t>(uint64_t(cus), p.n / 64));
+#ifdef PIRE_HIP_TUNING
+	StreamTuning(p, g);
+#endif
+	NoteKernel("stream_wide", zip ? "pirehip::ScanStreamKernel<wide walk, zipped rows>" : "pirehip::ScanStreamKernel<wide walk>");
+	if (zip)
+		hipLaunchKernelGGL((ScanStreamKernel<false, 3>), dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
+	else
+		hipLaunchKernelGGL((ScanStreamKernel<false, 2>), dim3(unsigned(blocks)), dim3(kStreamWaves * 64), ldsBytes, stream, p, g);
 	e = hipGetLastError();
 	return e == hipSuccess ? PIRE_HIP_OK : HipFail(e, "stream kernel launch");
 }

@@ -15,6 +15,7 @@ constexpr uint32_t kStreamWaves = 16;
 struct StreamGeom {
 	uint32_t lambda;         // cost of a string boundary in bytes of walk
 	uint32_t minTaskUnits;   // a wave is not started for less than this much key
+	uint32_t maxStrings;     // strings of one sub-task (the dense rows: kStreamMaxStrings; the wide walk: what its image leaves room for)
 };
 
 typedef __attribute__((address_space(3))) uint32_t* LdsWordPtr;
@@ -88,9 +89,9 @@ __device__ __forceinline__ bool StreamTaskOfWave(const uint64_t* offsets, uint64
 
 // Sub-tasks of equal size (a task of 1 030 strings is not one of 1 024 and one of 6: the second would pay a whole pipeline
 // start for six strings, and the launch ends with its slowest wave): strings per sub-task of a task of `taskStrings`.
-__device__ __forceinline__ uint32_t StreamSubStrings(uint64_t taskStrings)
+__device__ __forceinline__ uint32_t StreamSubStrings(uint64_t taskStrings, uint32_t maxStrings = kStreamMaxStrings)
 {
-	const uint64_t subTasks = (taskStrings + kStreamMaxStrings - 1) / kStreamMaxStrings;
+	const uint64_t subTasks = (taskStrings + maxStrings - 1) / maxStrings;
 	return subTasks ? uint32_t((taskStrings + subTasks - 1) / subTasks) : 0;
 }
 

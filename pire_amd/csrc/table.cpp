@@ -832,7 +832,7 @@ void FreeDeviceTable(DeviceTable* d)
 	void* ptrs[] = {d->hotRows, d->hotRowsRot, d->hotFlags, d->cls, d->nextPerm, d->flagsPerm, d->origOfPerm,
 	                d->permOfOrig, d->acceptMaskPerm, d->acceptOffPerm, d->acceptIds, d->visitHot, d->visitCold,
 	                d->finSelf,    d->finEnd,  d->workCounter, d->compactRows, d->incPerm,
-	                d->distFinalPerm, d->distFlaggedPerm, d->wideRows, d->next16, d->visitWide};
+	                d->distFinalPerm, d->distFlaggedPerm, d->wideRows, d->next16, d->visitWide, d->wideRowsStream};
 	for (void* q : ptrs)
 		if (q)
 			(void)hipFree(q);
@@ -862,9 +862,9 @@ void FreeAllDeviceTables(pire_hip_table* t)
 // rows -- entry = device id of the target, `wide` (the escape state) for targets outside the tier; then the row's flags --
 // and, zipped image (internal.h MakeWideLayout), the headers of all tier states + the escape state and the exception targets
 // of the zipped ones.
-std::vector<uint16_t> BuildWideRows(const HostTable& h)
+std::vector<uint16_t> BuildWideRows(const HostTable& h, uint32_t tier)
 {
-	const uint32_t W = h.wide, C = h.letters, F = h.zipFull ? h.zipFull : W;
+	const uint32_t W = tier ? tier : h.wide, C = h.letters, F = h.zipFull ? h.zipFull : W;
 	const WideLayout wl = MakeWideLayout(W, C, 0, h.zipFull);
 	const uint32_t pitch2 = wl.pitch / 2;
 	std::vector<uint16_t> img((wl.imageEnd - wl.rowsOff) / 2 + 8, 0);
@@ -1049,6 +1049,13 @@ int BuildDeviceImage(const HostTable& h, int dev, DeviceTable* out)
 		for (size_t i = 0; i < nextPerm.size(); ++i)
 			n16[i] = uint16_t(nextPerm[i]);
 		rc = Put(&d.next16, n16, &d.bytes);
+		// ... and the image for the stream kernel (a smaller tier: the strings' positions share the LDS with it) -- for images made
+		// while that kernel is asked for: it is opt-in (stream.hip StreamWideEligible), nobody else pays for the second image
+		const uint32_t tier = GetConfig().ragged_variant == 2 ? StreamWideTier(C, h.regexps, h.wide, h.zipFull) : 0;
+		if (!rc && tier > h.hot && tier > h.zipFull) {
+			rc = Put(&d.wideRowsStream, BuildWideRows(h, tier), &d.bytes);
+			d.wideStream = tier;
+		}
 	}
 	if (!rc)
 		rc = Put(&d.visitHot, std::vector<uint32_t>(kVisitHotSlots, 0), &d.bytes);

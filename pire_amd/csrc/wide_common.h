@@ -377,7 +377,7 @@ __device__ inline void FlushWide(const ScanParams& p, uint8_t* lds, const WideLa
 	const uint32_t* prog = reinterpret_cast<const uint32_t*>(lds + W.progOff);
 	for (uint32_t i = threadIdx.x; i <= W.full; i += blockDim.x)   // (the last slot -> `wide`: samples that found their lane outside the tier)
 		if (hist[i])
-			atomicAdd(&p.visitWide[i < W.full ? i : p.wide], hist[i]);
+			atomicAdd(&p.visitWide[i < W.full ? i : p.wideOutSlot], hist[i]);
 	if (threadIdx.x == 0 && prog[1]) {
 		atomicAdd(&p.visitHot[kWideTrapSlot], prog[1]);
 		const uint32_t total = atomicAdd(&p.visitHot[kTrapSlot], prog[1]) + prog[1];

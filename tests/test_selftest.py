@@ -32,6 +32,7 @@ KINDS = [
     ("ragged", dict(ragged_variant=1), "set_a", ("offsets", 3000)),
     ("stream", dict(ragged_variant=2), "set_a", ("offsets", 3000)),
     ("ragged_wide", dict(walk_variant=2), "dict_1k", ("offsets", 3000)),
+    ("stream_wide", dict(walk_variant=2, ragged_variant=2), "dict_1k", ("offsets", 3000)),
     ("generic", dict(), "set_a", ("strided", 8, 100)),
 ]
 

@@ -383,6 +383,93 @@ def test_ragged_kernel_on_the_wide_walk_records_cut_anywhere(pa, torch_cuda, cfg
         assert (cnt == expected_counts(o, oi, of)).all()
 
 
+STREAM_WIDE_CASES = [
+    # scanner, corpus, zip_variant (1 plain rows, 2 zipped), lengths, strings, lead
+    ("dict_1k", "k128", 1, "urls", 70001, 0),
+    ("dict_1k", "k1000", 2, "urls", 70001, 77),
+    ("dict_1k", "k512", 1, "tiny", 30000, 5),
+    ("dict_1k", "k512", 2, "tiny", 30000, 3),
+    ("dict_10k", "k10000", 1, "mixed", 20000, 1),
+    ("dict_10k", "k10000", 2, "mixed", 20000, 127),
+    ("dict_10k", "k2048", 2, "lines", 9000, 128),
+    ("dict_10k", "k512", 1, "aligned", 6000, 112),
+    ("dict_10k", "k512", 2, "aligned", 6000, 0),
+    ("dict_utf8_5k", "k5000", 2, "edges", 70001, 3),
+    ("dict_utf8_1k", "k1000", 1, "empty", 5000, 9),
+    ("dict_1k", "k1000", 2, "uniform", 64, 0),
+    ("dict_10k", "k10000", 2, "urls", 300000, 64),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,corpus,zipv,kind,n,lead", STREAM_WIDE_CASES, ids=lambda v: str(v))
+def test_stream_kernel_on_the_wide_walk_vs_oracle(pa, torch_cuda, cfg, name, corpus, zipv, kind, n, lead):
+    """the stream kernel (runs of consecutive strings per lane, boundaries inside the chunk walk) on the
+    class-indexed walk -- the image with the smaller tier (internal.h StreamWideTier), plain rows and zipped -- against the
+    oracle: text that visits thousands of states and leaves the tier (dict_10k / k10000), boundaries of every kind (inside a
+    chunk, on a chunk, on a line, several per chunk, runs of empty strings), a text that starts anywhere in a line, both flag
+    combinations, match counters; before and after the table has ranked its rows from these very scans."""
+    from pire_amd import binding as pb
+    from tests.test_gpu_parity import stream_lengths
+
+    torch = torch_cuda
+    cfg.set(no_offsets_peek=1, ragged_variant=2, walk_variant=2, zip_variant=zipv, auto_adapt=1)
+    entry = W.wide_set(name)
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(n + len(kind) + lead)
+    ln = stream_lengths(rng, kind, n).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[0] = lead
+    offs[1:] = lead + np.cumsum(ln)
+    total = int(offs[-1])
+    records = (total + 1023) // 1024 + 1
+    text = W.wide_records(entry, corpus, 41 + lead, records, 1024).reshape(-1)[:total].copy()
+    for round_ in range(2):
+        for flags in (BE, 0):
+            oi, of = o.run(text, offs, flags=flags, threads=4)
+            gi, gf, cnt = dev_run_offsets(torch, t, text, offs, flags=flags)
+            # (a zipped image whose rows leave no room for the strings' positions -- 113 letter classes, 230-byte rows -- keeps the
+            # ragged kernel: internal.h StreamWideTier)
+            either = name == "dict_utf8_5k" and zipv == 2   # (fits as created, not once the ranking has given it more rows)
+            assert pb.last_kernel() in (("generic",) if n < 256 else ("stream_wide", "ragged_wide") if either else ("stream_wide",)), pb.last_kernel()
+            assert ("zipped" in pb.last_kernel_symbol()) == (zipv == 2 and n >= 256), pb.last_kernel_symbol()
+            bad = np.nonzero((gi != oi) | (gf != of))[0]
+            assert len(bad) == 0, (round_, flags, len(bad), bad[:10], ln[bad[:10]], offs[bad[:10]])
+            assert (cnt == expected_counts(o, oi, of)).all()
+        t.adapt()   # the second round: rows ranked from what the stream kernel's samples said
+    # resume states keep the ragged kernel (the stream kernel starts every string in the same state)
+    init = rng.randint(0, t.Size, size=n).astype(np.uint32)
+    oi, of = o.run(text, offs, flags=ob.FLAG_END, init_idx=init, threads=4)
+    gi, gf, _ = dev_run_offsets(torch, t, text, offs, flags=ob.FLAG_END, init=init)
+    assert pb.last_kernel() in ("ragged_wide", "generic")
+    assert (gi == oi).all() and (gf == of).all()
+
+
+@pytest.mark.gpu
+def test_stream_kernel_on_the_wide_walk_is_opt_in(pa, torch_cuda, cfg):
+    """Routing: measured slower than the ragged kernel on the same walk wherever lanes leave the tier, so a
+    blacklist scanner's URL batch of a million strings keeps ragged_wide by default; ragged_variant = 2 asks for stream_wide;
+    same answers."""
+    from pire_amd import binding as pb
+
+    torch = torch_cuda
+    entry = W.wide_set("blacklist_1k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    cfg.set(no_offsets_peek=1, walk_variant=2, ragged_variant=2)
+    t.upload()                                   # (the stream kernel's image is made for tables uploaded while it is asked for)
+    for n in ((1 << 20) + 5, 3000):
+        text, offs = W.wide_urls(entry, 5, n)
+        oi, of = o.run(text, offs, threads=4)
+        for variant, want in ((0, "ragged_wide"), (2, "stream_wide"), (1, "ragged_wide")):
+            cfg.set(ragged_variant=variant)
+            gi, gf, cnt = dev_run_offsets(torch, t, text, offs)
+            assert pb.last_kernel() == want, (n, variant, pb.last_kernel())
+            assert (gi == oi).all() and (gf == of).all()
+            assert (cnt == expected_counts(o, oi, of)).all()
+
+
 @pytest.mark.gpu
 def test_two_tables_with_configurations_of_their_own(pa, torch_cuda, cfg):
     """pire_hip_table_config_set (round 6): two users of the library in one process, each with its own routing -- one table

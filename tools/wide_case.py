@@ -135,16 +135,27 @@ def point_urls(entry, n, reps):
     def launch():
         t.run_device(text.data_ptr(), doffs.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
 
-    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide,zip,auto").split(","))
-    for variant, zipv, label in ((1, 1, "dense"), (2, 1, "wide"), (2, 2, "zip"), (0, 0, "auto")):
+    # (*_ragged: ragged_variant = 1, the one-string-per-lane kernel on the same walk -- what offset batches of a wide table took
+    # before the stream kernel had the class-indexed walk)
+    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide_ragged,wide,zip_ragged,zip,auto").split(","))
+    for variant, zipv, raggedv, label in ((1, 1, 0, "dense"), (2, 1, 1, "wide_ragged"), (2, 1, 0, "wide"), (2, 2, 1, "zip_ragged"),
+                                          (2, 2, 0, "zip"), (0, 0, 0, "auto")):
         if label not in only:
             continue
-        pb.set_config(walk_variant=variant, zip_variant=zipv, auto_adapt=1)
+        pb.set_config(walk_variant=variant, zip_variant=zipv, ragged_variant=raggedv, auto_adapt=1)
         for _ in range(3):
             launch()
             torch.cuda.synchronize()
             t.adapt()
         mean, best = timed(launch, total, reps)
+        try:   # tuning build (PIRE_HIP_LIB=tools/ab/libpire_hip_tuning.so PIRE_HIP_DEBUG_STREAM_CLOCKS=1): the stream kernel's stage clocks
+            import ctypes as C
+            out = (C.c_double * 8)()
+            if pb.lib().pire_hip_debug_stream_clocks(out) == 0:
+                print("%s stream clocks, us per wave: search %.2f | table copy %.2f | positions + lane search %.2f | window loop %.2f | "
+                      "flush %.2f | whole wave %.2f ; %.1f phases per wave, %d wave-launches" % (label, *out[:7], int(out[7])), flush=True)
+        except AttributeError:
+            pass
         gi = idx.cpu().numpy().astype(np.uint32).reshape(rep, nbase)
         gf = fin.cpu().numpy().reshape(rep, nbase)
         kernel = pb.last_kernel()
