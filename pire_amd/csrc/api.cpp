@@ -1681,6 +1681,8 @@ int SelfTestPrefix(pire_hip_table* t, bool suffix, int a, int b, hipStream_t str
 		variants.push_back([](pire_hip_config& c) { c.ragged_act_always = 1; c.no_ragged_act = 0; });   // the ragged kernel with actions
 		if (!suffix)
 			variants.push_back([](pire_hip_config& c) { c.no_ragged_act = 1; c.ragged_act_always = 0; });   // one string per lane
+		if (!suffix && t->host.wide && t->host.states <= 65536)   // ... and the ragged kernel with actions on the class-indexed walk
+			variants.push_back([](pire_hip_config& c) { c.ragged_act_always = 1; c.no_ragged_act = 0; c.walk_variant = 2; c.tiled_variant = 0; c.checked = 0; });
 		const int rc = RunSelfTestVariants(variants, [&]() -> int {
 			std::fill(got.begin(), got.end(), int64_t(-77));
 			const int r = suffix ? pire_hip_suffix(t, kb.text.data(), kb.offsets.data(), kb.n, longest, a, b, 0, got.data(), own.s)
@@ -1739,6 +1741,8 @@ int SelfTestHalfFinal(pire_hip_table* t, uint32_t flags, hipStream_t stream)
 	variants.push_back([](pire_hip_config& c) { c.counting_variant = 2; });                        // the row kernel where the table has that image
 	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 0; });   // the ragged kernel with actions
 	variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 1; });   // one string per lane
+	if (h.wide && h.states <= 65536)   // the ragged kernel with actions on the class-indexed walk
+		variants.push_back([](pire_hip_config& c) { c.counting_variant = 1; c.no_ragged_act = 0; c.walk_variant = 2; c.tiled_variant = 0; c.checked = 0; });
 	OwnStream own;
 	const int rc = RunSelfTestVariants(variants, [&]() -> int {
 		std::fill(gotIdx.begin(), gotIdx.end(), ~0u);

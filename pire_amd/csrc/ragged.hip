@@ -132,6 +132,7 @@ struct NoAct {
 struct HalfFinalAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
+	static constexpr uint32_t kWideMask = kFinal;   // what a chunk of the wide walk is walked again for (WideChunkAct)
 	uint32_t* results;
 	struct Lane {
 		uint32_t c[8];
@@ -238,6 +239,7 @@ struct HalfFinalAct {
 struct HalfFinalWideAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
+	static constexpr uint32_t kWideMask = kFinal;
 	uint32_t* results;
 	struct Lane {
 		uint32_t* row;
@@ -294,8 +296,10 @@ struct PrefixAct {
 	// address temporaries this instantiation needed 12 bytes of scratch and kept per-lane loads, which made the
 	// wait for the window twice the walk: profiles/r02_ragged_clocks.log)
 	static constexpr bool kGroupLoads = true;
+	static constexpr uint32_t kWideMask = kFinal | kDead;   // (a Dead state ends the search: the rest of the string is skipped)
 	long long* outLen;
 	uint32_t longest, throughEnd;
+	uint32_t startFlags;   // flags of the state every string starts in: the host knows them (a load per string otherwise)
 	struct Lane {
 		uint64_t begin;
 		long long pos;
@@ -338,7 +342,8 @@ struct PrefixAct {
 		al.pos = -1;
 		al.stop = 0;
 		const uint32_t st = p.startPerm;                   // Initialize (+ BeginMark), run.h:280-283
-		if (StateFlags(p, lds, L, st) & kFinal) {
+		// (the wide walk's launch has p.hot = 0 and the flags from the host; the dense one reads them where it always did)
+		if ((p.hot ? StateFlags(p, lds, L, st) : startFlags) & kFinal) {
 			al.pos = 0;                                    // run.h:284 / 301-302
 			if (!longest)
 				al.stop = 3u;
@@ -375,6 +380,7 @@ struct PrefixAct {
 struct CaptureAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
+	static constexpr uint32_t kWideMask = kFinal;
 	const uint32_t* info;
 	long long* outBegin;
 	long long* outEnd;
@@ -713,6 +719,129 @@ struct RaggedClock {};
 // EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
 // state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
 // A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
+// ---- the walks with actions on the class-indexed walk (round 6) -----------------------------------------
+// A dictionary scanner under LongestPrefix or as a HalfFinalScanner visits thousands of states: on the dense rows nearly every
+// chunk leaves them and is walked again from memory (0.3 TB/s on log lines, profiles/r06_actions_wide.jsonl).  The same walk
+// through the wide rows: the fast path asks of every state it enters whether it is Final or Dead -- plain rows: the flags
+// halfword at the end of the state's row (a third LDS read per step, off the dependent chain); zipped image: bit 0 of the
+// state's header, which the next step reads anyway -- and only a chunk that met such a state, or left the tier, is walked
+// again with the action (WideActBytes: the rows in LDS, the table in memory for states without one, the action's own look at
+// the state only where the image says "Final or Dead").  The host hands the kernel p.hot = 0: to the actions every state is one
+// "without a dense row" (flags, increments and end-of-string records from memory, under wave-uniform branches of their own).
+// What the image says about a state of the tier (or the escape state): plain rows -- the flags halfword at the end of its row;
+// zipped -- its header, bit 0 = Final (Dead is not in there: a Dead state stays Dead, so the walks that care look at the
+// flags of the state a chunk ENDS in, which a Dead state has -- absorbing states keep a row of their own, table.cpp PlanZip --
+// and a Dead state they miss only costs them the walk to the end of the string, never the answer).
+template <bool ZIP>
+__device__ __forceinline__ uint32_t WideFlaggedBits(uint32_t st, const WideConst& K)
+{
+	if constexpr (ZIP)
+		return *reinterpret_cast<LdsU32Ptr>(static_cast<uintptr_t>(K.hOff + (st << 2)));
+	else
+		return *reinterpret_cast<LdsU16Ptr>(static_cast<uintptr_t>(__umul24(st, K.pitch) + K.flagsOff + 256u));
+}
+template <bool ZIP, uint32_t MASK>
+__device__ __forceinline__ bool WideIsFlagged(uint32_t bits, uint32_t endState, const WideConst& K)
+{
+	if constexpr (!ZIP)
+		return (bits & MASK) != 0;
+	bool f = (bits & 1u) != 0;
+	if constexpr ((MASK & kDead) != 0)
+		f = f || (WideFlags<true>(endState, K) & kDead) != 0;
+	return f;
+}
+
+// The first `count` (<= 16) bytes of v exactly, device ids all the way, the action after every step that enters a state the
+// image calls Final or Dead -- or a state outside the tier, of which the image says nothing.  Rolled: the cold path.
+template <class Act, bool ZIP>
+__device__ __forceinline__ uint32_t WideActBytes(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const WideConst& K,
+                                                 u32x4 v, uint32_t sid, uint32_t count, const Act& act, typename Act::Lane& al,
+                                                 uint64_t addr)
+{
+#pragma unroll 1
+	for (uint32_t i = 0; i < count; ++i) {
+		const uint32_t c2 = HotLookup(v.x & 0xFFu);
+		uint32_t next = WideEntry<ZIP>(sid < p.wide ? sid : p.wide, K, c2);
+		bool look = true;
+		if (next == p.wide) {
+			next = WideNextC2<true>(p, sid, c2);
+			asm volatile("" : "+v"(next));   // (the wait belongs in here)
+		} else {
+			look = WideIsFlagged<ZIP, Act::kWideMask>(WideFlaggedBits<ZIP>(next, K), next, K);
+		}
+		sid = next;
+		if (look)
+			act.Step(p, lds, L, al, sid, addr + i + 1);
+		v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+		v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+		v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+		v.w >>= 8;
+	}
+	return sid;
+}
+
+// 16 bytes (count == 16) or the first `count` (0..15) of a string's last chunk through the wide rows with the visit test.
+template <class Act, bool ZIP, bool PARTIAL>
+__device__ __forceinline__ void WideChunkAct(const ScanParams& p, uint8_t* lds, const LdsLayout& L, const WideLayout& W, const WideConst& K,
+                                             const u32x4 v, uint32_t count, uint32_t& st, uint32_t& cold, const Act& act,
+                                             typename Act::Lane& al, uint64_t addr)
+{
+	const uint32_t st0 = st;
+	uint32_t h = st, snap = st, acc = 0;
+	if constexpr (ZIP) {
+		// (a dword per trip, rolled: the zipped step's temporaries times sixteen did not fit beside the two line tiles and the
+		// action's own registers -- 8 VGPR spills in the half-final instantiation, and a spill in this loop is a wrong result)
+		u32x4 t = v;
+#pragma unroll 1
+		for (uint32_t w = 0; w < 4; ++w) {
+			const uint32_t x = t.x;
+			t.x = t.y;
+			t.y = t.z;
+			t.z = t.w;
+#pragma unroll
+			for (uint32_t j = 0; j < 4; ++j) {
+				const uint32_t nh = WideEntry<ZIP>(h, K, HotLookup((x >> (8 * j)) & 0xFFu));
+				const uint32_t bits = WideFlaggedBits<ZIP>(nh, K);
+				const bool in = !PARTIAL || count >= 4 * w + j + 1;
+				acc |= in ? bits : 0u;
+				h = nh;
+				snap = count == 4 * w + j + 1 ? h : snap;
+			}
+		}
+	} else {
+#pragma unroll
+		for (int w = 0; w < 4; ++w) {
+			const uint32_t x = v[w];
+			const uint32_t cl[4] = {HotLookup(x & 0xFFu), HotLookup((x >> 8) & 0xFFu), HotLookup((x >> 16) & 0xFFu), HotLookup(x >> 24)};
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				if (PARTIAL && w == 3 && j == 3)
+					break;
+				h = WideEntry<ZIP>(h, K, cl[j]);
+				const uint32_t bits = WideFlaggedBits<ZIP>(h, K);
+				if constexpr (PARTIAL) {
+					const bool in = count >= uint32_t(4 * w + j + 1);
+					acc |= in ? bits : 0u;
+					snap = count == uint32_t(4 * w + j + 1) ? h : snap;
+				} else {
+					acc |= bits;
+				}
+			}
+		}
+	}
+	st = PARTIAL ? snap : h;
+	if ((!PARTIAL || count != 0) && (WideIsFlagged<ZIP, Act::kWideMask>(acc, st, K) || st == p.wide) && act.Wants(al)) {
+		const uint32_t sid = WideActBytes<Act, ZIP>(p, lds, L, K, v, st0 < p.wide ? st0 : cold, count, act, al, addr);
+		st = sid < p.wide ? sid : p.wide;
+		cold = sid;
+		// tell pire_hip_table_adapt() which states deserve a place in the tier, sampled like the plain walk's re-walks
+		if (sid >= p.wide && (threadIdx.x & 63) == ((uint32_t(addr) >> 4) & 63u)) {
+			atomicAdd(&p.visitCold[sid], 1u);
+			atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
+		}
+	}
+}
+
 // WIDE (round 5; 1: the exact table behind the rows has u32 entries, 2: u16, 3: u16 and the LDS image is zipped, round 6): the class-indexed walk of wide.hip instead of
 // the dense rows -- S.hs is then a device id with a row or `wide` (the escape row), the state's end-of-string record comes
 // from memory (the LDS is the rows'), everything else of the kernel is what it was.  Plain scans only (NoAct).
@@ -724,7 +853,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
                                             const Act& act, typename Act::Lane& al, RaggedClock& clk,
                                             const WideLayout& W = WideLayout(), const WideConst& K = WideConst())
 {
-	static_assert(!WIDE || !Act::kActive, "the wide walk has no actions");
+	static_assert(!(WIDE == 1 && Act::kActive), "the walks with actions take the wide walk with the u16 table only");
 	WaitAllLoads(cur);
 	PIRE_RCLK(clk, 0);
 	if constexpr (Act::kGroupLoads)
@@ -797,7 +926,11 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) < full) {
-					if constexpr (Act::kActive)
+					if constexpr (Act::kActive && WIDE != 0) {
+						WideChunkAct<Act, WIDE == 3, false>(p, lds, L, W, K, cur[k], 16u, S.hs, S.cold, act, al, S.pos + 16u * k);
+						if (sampleLaneHere && uint32_t(k) == ((sampleHash >> 20) & 7u))
+							WideSample<WIDE == 3>(p, lds, W, S.hs);
+					} else if constexpr (Act::kActive)
 						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 						             S.pos + 16u * k);
 					else if constexpr (WIDE != 0) {
@@ -814,7 +947,9 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 				for (int k = 1; k < 8; ++k)
 					if (full == uint32_t(k))
 						v = cur[k];
-				if constexpr (Act::kActive)
+				if constexpr (Act::kActive && WIDE != 0)
+					WideChunkAct<Act, WIDE == 3, true>(p, lds, L, W, K, v, tail, S.hs, S.cold, act, al, S.pos + 16u * full);
+				else if constexpr (Act::kActive)
 					StepPartialAct(p, lds, L, v, tail, S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 					               S.pos + 16u * full);
 				else if constexpr (WIDE != 0)
@@ -843,7 +978,7 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	PIRE_RCLK(clk, 3);
 	if constexpr (Act::kActive) {
 		if (ends)
-			act.Finish(p, lds, L, reinterpret_cast<const uint8_t*>(finHot), al, S.sIdx, S.hs != p.hot ? S.hs : S.cold, S.end);
+			act.Finish(p, lds, L, reinterpret_cast<const uint8_t*>(finHot), al, S.sIdx, S.hs != (WIDE ? p.wide : p.hot) ? S.hs : S.cold, S.end);
 	} else if (__any(ends) && !(p.flags & kDebugNoFinish)) {
 		if constexpr (WIDE != 0) {
 			// the end-of-string record from memory, under a wave-uniform branch of its own and waited for inside it (FinRecordOf)
@@ -1111,6 +1246,21 @@ bool RaggedActEligible(const ScanParams& p)
 	return p.offsets != nullptr && p.n >= 256 && p.n < (1ull << 32) - (1ull << 16) && !GetConfig().no_ragged_act;
 }
 
+// The walks with actions on the class-indexed walk (WideChunkAct above): for tables WideWanted() sends there, with the u16 table
+// behind the rows.  To the actions every state is then one without a dense row (p.hot = 0: flags, increments, records from memory).
+static bool WideActWanted(const ScanParams& p)
+{
+	return p.next16 && p.wide && p.wideRows && !p.ends && !p.initIdx && !(p.flags & kPermIds) && WideWanted(p, GetConfig());
+}
+static void ForWideAct(ScanParams* p)
+{
+	p->hot = 0;
+	p->hotFinalLo = 0;
+	p->hotDeadLo = 0;
+	p->compact = 0;
+	p->actDist = nullptr;
+}
+
 int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter, uint32_t* outResults, hipStream_t stream)
 {
 	ScanParams p = p0;    // with the compact rows: trapped chunks that cannot reach a Final state use them (actDist)
@@ -1124,6 +1274,11 @@ int LaunchRaggedHalfFinal(const ScanParams& p0, unsigned long long* workCounter,
 	}
 	HalfFinalAct act;
 	act.results = outResults;
+	if (WideActWanted(p)) {   // a table whose scans keep leaving the dense rows: the same walk through the wide rows
+		ForWideAct(&p);
+		NoteKernel("ragged_half_final_wide", p.zipFull ? "pirehip::ScanRaggedKernel<HalfFinalAct, wide walk, zipped rows>" : "pirehip::ScanRaggedKernel<HalfFinalAct, wide walk>");
+		return p.zipFull ? LaunchRaggedT<decltype(act), false, 3>(p, workCounter, act, stream) : LaunchRaggedT<decltype(act), false, 2>(p, workCounter, act, stream);
+	}
 	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);
 }
 
@@ -1154,6 +1309,12 @@ int LaunchRaggedPrefix(const ScanParams& p0, unsigned long long* workCounter, bo
 	act.outLen = outLen;
 	act.longest = longest ? 1 : 0;
 	act.throughEnd = throughEnd ? 1 : 0;
+	act.startFlags = p.owner ? p.owner->host.flags[p.hostOrigOfPerm[p.startPerm]] : 0;
+	if (WideActWanted(p)) {
+		ForWideAct(&p);
+		NoteKernel("ragged_prefix_wide", p.zipFull ? "pirehip::ScanRaggedKernel<PrefixAct, wide walk, zipped rows>" : "pirehip::ScanRaggedKernel<PrefixAct, wide walk>");
+		return p.zipFull ? LaunchRaggedT<decltype(act), false, 3>(p, workCounter, act, stream) : LaunchRaggedT<decltype(act), false, 2>(p, workCounter, act, stream);
+	}
 	return LaunchRaggedT<decltype(act), false>(p, workCounter, act, stream);
 }
 

@@ -885,8 +885,11 @@ std::vector<uint16_t> BuildWideRows(const HostTable& h, uint32_t tier)
 		hdr[2 * pid] = uint16_t(word);
 		hdr[2 * pid + 1] = uint16_t(word >> 16);
 	};
+	// bit 0 of a header (no part of the letter fields: 2 * class * 0x4081 has it clear): the state is Final -- what the walks
+	// with actions look for in a chunk (ragged.hip WideChunkAct); the plain walks never look at it
+	auto flagged = [&](uint32_t pid) { return (h.flags[h.origOfPerm[pid]] & kFinal) ? 1u : 0u; };
 	for (uint32_t pid = 0; pid < F; ++pid)
-		put(pid, (pid << 22) | none);
+		put(pid, (pid << 22) | none | flagged(pid));
 	put(W, (F << 22) | none);   // the escape state leans on the escape row
 	for (uint32_t pid = F; pid < W; ++pid) {
 		const uint32_t o = h.origOfPerm[pid], b = h.zipBase[pid - F], bo = h.origOfPerm[b];
@@ -903,7 +906,7 @@ std::vector<uint16_t> BuildWideRows(const HostTable& h, uint32_t tier)
 			word |= kZipNoLetter << (1 + 7 * k);
 			x[k] = uint16_t(W);
 		}
-		put(pid, word);
+		put(pid, word | flagged(pid));
 	}
 	return img;
 }

@@ -132,9 +132,9 @@ def _entry_calls(pa):
     counting = [c for c in H.golden()["counting"] if c["kind"] == 1 and c["regexps"] >= 2][0]
     capturing = H.golden()["capturing"][0]
     return [
-        ("Prefix (kernel", lambda: pa.Table(set_a).prefix(text, offs, True), {"ragged_prefix", "prefix"}),
+        ("Prefix (kernel", lambda: pa.Table(set_a).prefix(text, offs, True), {"ragged_prefix", "prefix", "ragged_prefix_wide"}),
         ("Suffix (kernel", lambda: pa.Table(set_a).suffix(text, offs, True), {"suffix"}),
-        ("HalfFinalScanner", lambda: pa.Table(set_a).run_half_final(text, offs), {"ragged_half_final", "half_final"}),
+        ("HalfFinalScanner", lambda: pa.Table(set_a).run_half_final(text, offs), {"ragged_half_final", "half_final", "ragged_half_final_wide"}),
         ("the counting scanner", lambda: pa.CountingTable(H.load_blob(counting["blob"]), counting["kind"]).run_strings(strings),
          {"counting", "counting_packed", "counting_rows"}),
         ("the capturing scanner", lambda: pa.CountingTable(H.load_blob(capturing["blob"]), 0).capture(text, offs),
@@ -176,7 +176,8 @@ def test_every_kernel_name_the_library_can_emit_has_a_self_test():
                 src = fh.read()
             for m in re.finditer(r"NoteKernel\(([^;]*?)\);", src, re.S):
                 names.update(re.findall(r'"([a-z_+0-9]+)"', m.group(1).split(",")[0] if "?" not in m.group(1) else m.group(1).split(', "pirehip')[0]))
-    covered = {k[0] for k in KINDS} | {"ragged_prefix", "prefix", "suffix", "ragged_half_final", "half_final", "half_final_rows", "counting",
+    covered = {k[0] for k in KINDS} | {"ragged_prefix", "ragged_prefix_wide", "prefix", "suffix", "ragged_half_final", "ragged_half_final_wide",
+                                       "half_final", "half_final_rows", "counting",
                                        "counting_packed", "counting_rows", "counting_letter_rows", "capture", "capture_dense", "capture_rows",
                                        "ragged_capture"}
     not_covered = {

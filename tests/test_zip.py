@@ -73,6 +73,9 @@ def test_zipped_image_walks_like_the_reference(cfg, name, corpus):
     orig_of_perm, _ = t.layout()
     perm_of_orig = np.empty_like(orig_of_perm)
     perm_of_orig[orig_of_perm] = np.arange(len(orig_of_perm), dtype=np.uint32)
+    # bit 0 of a header: "Final" -- what the walks with actions look for in a chunk (ragged.hip WideChunkAct)
+    flagged = np.array([t.Final(int(x)) for x in orig_of_perm[:z["tier"]]])
+    assert ((hdr[:z["tier"]] & 1).astype(bool) == flagged).all() and not (int(hdr[z["tier"]]) & 1)
     o = ob.OracleScanner(blob)
     byte_of_class = {}
     for ch in list(range(256)) + [258, 259]:
