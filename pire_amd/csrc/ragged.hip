@@ -303,7 +303,7 @@ struct PrefixAct {
 	struct Lane {
 		uint64_t begin;
 		long long pos;
-		uint32_t stop;   // 1 search over, 2 Final before the first byte (shortest: answered at once), 4 ended Dead
+		uint32_t stop;   // 1 search over, 2 Final before the first byte (shortest: answered at once), 4 ended Dead, 8 Final for good
 	};
 	__device__ __forceinline__ bool Wants(const Lane& al) const { return !(al.stop & 1u); }
 	__device__ __forceinline__ uint32_t Threshold(const ScanParams& p) const { return p.hotDeadLo; }
@@ -331,6 +331,10 @@ struct PrefixAct {
 			al.pos = (long long)(after - al.begin);
 			if (!longest)
 				al.stop |= 1u;                             // ShortestPrefixPred stops on the first Final
+			else if (f & kAbsorbing)
+				al.stop |= 9u;                             // Final for good (every transition a self loop, marks included: what a
+				                                           // Surround()ed dictionary is behind a match): the longest prefix is the
+				                                           // whole string -- Finish() says so, the rest of the string is not walked
 		}
 		if (f & kDead)
 			al.stop |= 5u;                                 // both predicates stop on a dead state
@@ -355,7 +359,7 @@ struct PrefixAct {
 	{
 		// a search that ended Dead stays not-Final through EndMark; one that was answered before the first byte
 		// does not look at EndMark at all; a shortest prefix already found is kept (run.h:286-290 / 305-309)
-		const bool asks = throughEnd && !(al.stop & 6u) && (longest || al.pos < 0);
+		const bool asks = throughEnd && !(al.stop & 14u) && (longest || al.pos < 0);
 		const bool cold = asks && st >= p.hot;
 		uint32_t fl = asks && !cold ? area[st] : 0u;   // flags of the state End() leads to: LDS for a dense-row state
 		if (__any(cold)) {
@@ -364,7 +368,7 @@ struct PrefixAct {
 				asm volatile("" : "+v"(fl));   // the wait belongs in here
 			}
 		}
-		if (asks && (fl & kFinal))
+		if ((asks && (fl & kFinal)) || (al.stop & 8u))
 			al.pos = (long long)(end - al.begin);
 		outLen[s] = al.pos;
 	}

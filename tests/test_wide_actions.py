@@ -21,6 +21,14 @@ def _lines(entry, corpus, seed, n):
     offs[1:] = np.cumsum(lens)
     total = int(offs[-1])
     text = W.wide_records(entry, corpus, seed, (total + 1023) // 1024 + 1, 1024).reshape(-1)[:total].copy()
+    # the corpora hold no whole word of the dictionary: one written into every 7th line that has room (behind it a Surround()ed
+    # scanner is in ONE Final state for good -- PrefixAct's short cut -- and every chunk is one "with a Final state")
+    words = W.dictionary_words(entry)
+    for i in range(0, n, 7):
+        w = words[rng.randint(0, len(words))]
+        if int(lens[i]) > len(w):
+            at = int(offs[i]) + rng.randint(0, int(lens[i]) - len(w))
+            text[at:at + len(w)] = np.frombuffer(w, dtype=np.uint8)
     return text, offs
 
 
@@ -100,3 +108,4 @@ def test_the_walks_with_actions_follow_the_table_to_the_wide_walk(pa, torch_cuda
     cfg.set(walk_variant=1)
     assert (t.prefix(text, offs, True, True, True) == want).all()
     assert pb.last_kernel() == "ragged_prefix"
+    assert (want >= 0).mean() > 0.05 and (want == np.diff(offs).astype(np.int64))[want >= 0].all()   # behind a match: Final for good
