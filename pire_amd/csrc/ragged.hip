@@ -133,6 +133,7 @@ struct HalfFinalAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	static constexpr uint32_t kWideMask = kFinal;   // what a chunk of the wide walk is walked again for (WideChunkAct)
+	static constexpr bool kBulk = true;             // ... and Bulk() below is there for chunks that start in a Final state for good
 	uint32_t* results;
 	struct Lane {
 		uint32_t c[8];
@@ -156,6 +157,15 @@ struct HalfFinalAct {
 #pragma unroll
 		for (int r = 0; r < 8; ++r)
 			al.c[r] += uint32_t(inc >> (8 * r)) & 0xFFu;
+	}
+	// `steps` steps that all end in `st` again, a Final state whose every transition is a self loop (what a Surround()ed
+	// dictionary is behind a match): the action of each of them at once (the wide walk, WideChunkAct)
+	__device__ __forceinline__ void Bulk(const ScanParams& p, Lane& al, uint32_t st, uint32_t steps) const
+	{
+		const uint64_t inc = p.incPerm[st];
+#pragma unroll
+		for (int r = 0; r < 8; ++r)
+			al.c[r] += steps * (uint32_t(inc >> (8 * r)) & 0xFFu);
 	}
 	// after a step inside the dense rows that ended in h >= Threshold()
 	__device__ __forceinline__ void HotStep(const ScanParams&, const uint8_t*, const LdsLayout&, const uint8_t* area,
@@ -240,6 +250,7 @@ struct HalfFinalWideAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	static constexpr uint32_t kWideMask = kFinal;
+	static constexpr bool kBulk = false;
 	uint32_t* results;
 	struct Lane {
 		uint32_t* row;
@@ -297,6 +308,7 @@ struct PrefixAct {
 	// wait for the window twice the walk: profiles/r02_ragged_clocks.log)
 	static constexpr bool kGroupLoads = true;
 	static constexpr uint32_t kWideMask = kFinal | kDead;   // (a Dead state ends the search: the rest of the string is skipped)
+	static constexpr bool kBulk = false;                    // (Step() stops the search at a Final state that is one for good)
 	long long* outLen;
 	uint32_t longest, throughEnd;
 	uint32_t startFlags;   // flags of the state every string starts in: the host knows them (a load per string otherwise)
@@ -385,6 +397,7 @@ struct CaptureAct {
 	static constexpr bool kActive = true;
 	static constexpr bool kGroupLoads = kRaggedGroupLoads;
 	static constexpr uint32_t kWideMask = kFinal;
+	static constexpr bool kBulk = false;
 	const uint32_t* info;
 	long long* outBegin;
 	long long* outEnd;
@@ -792,6 +805,16 @@ __device__ __forceinline__ void WideChunkAct(const ScanParams& p, uint8_t* lds, 
 {
 	const uint32_t st0 = st;
 	uint32_t h = st, snap = st, acc = 0;
+	// A chunk that STARTS in a Final state that is one for good (every transition a self loop: its row says so, an absorbing state
+	// keeps a row of its own in either image) ends there, and every step of it takes that state's action: once for all of them.
+	bool absorbed = false;
+	if constexpr (Act::kBulk) {
+		absorbed = (WideFlags<ZIP>(st0, K) & (kFinal | kAbsorbing)) == (kFinal | kAbsorbing) && (!PARTIAL || count != 0);
+		if (__any(absorbed)) {
+			if (absorbed)
+				act.Bulk(p, al, st0, PARTIAL ? count : 16u);
+		}
+	}
 	if constexpr (ZIP) {
 		// (a dword per trip, rolled: the zipped step's temporaries times sixteen did not fit beside the two line tiles and the
 		// action's own registers -- 8 VGPR spills in the half-final instantiation, and a spill in this loop is a wrong result)
@@ -834,7 +857,7 @@ __device__ __forceinline__ void WideChunkAct(const ScanParams& p, uint8_t* lds, 
 		}
 	}
 	st = PARTIAL ? snap : h;
-	if ((!PARTIAL || count != 0) && (WideIsFlagged<ZIP, Act::kWideMask>(acc, st, K) || st == p.wide) && act.Wants(al)) {
+	if ((!PARTIAL || count != 0) && !absorbed && (WideIsFlagged<ZIP, Act::kWideMask>(acc, st, K) || st == p.wide) && act.Wants(al)) {
 		const uint32_t sid = WideActBytes<Act, ZIP>(p, lds, L, K, v, st0 < p.wide ? st0 : cold, count, act, al, addr);
 		st = sid < p.wide ? sid : p.wide;
 		cold = sid;

@@ -108,6 +108,7 @@ timeout 200 python tools/half_final_case.py half_5 2>&1 | grep "half_final\|refe
 timeout 300 python tools/counting_case.py count_glued3_advanced 2>&1 | grep "counting\|reference" | tee $OUT/counting.log | cut -c1-220
 timeout 300 python tools/capture_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/capture.log | cut -c1-220
 timeout 200 python tools/actions_case.py 2>&1 | grep -v amdgpu.ids > $OUT/actions.log; tail -4 $OUT/actions.log | cut -c1-200
+timeout 600 python tools/actions_wide_case.py 2>&1 | grep "^{" > $OUT/actions_wide.jsonl; wc -l $OUT/actions_wide.jsonl
 { LONG_TOTAL_LOG2=30 timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm"; timeout 120 python tools/long_grep_case.py 2>&1 | grep "^grep"; } | tee $OUT/long_strings.log | cut -c1-200
 timeout 200 python tools/pair_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pair.log | cut -c1-200
 for st in slow_x300 slow_x400_utf8; do timeout 400 python bench.py --set $st --log2-strings 16 --len 4096 --steps 5 --warmup 2 --cpu-sample-log2 10 2>&1 | tail -1 | cut -c1-1500; done > $OUT/bench_slow_wide.jsonl; cut -c1-200 $OUT/bench_slow_wide.jsonl

@@ -135,11 +135,10 @@ def point_urls(entry, n, reps):
     def launch():
         t.run_device(text.data_ptr(), doffs.data_ptr(), n, 3, idx.data_ptr(), fin.data_ptr(), 0, 0, stream)
 
-    # (*_ragged: ragged_variant = 1, the one-string-per-lane kernel on the same walk -- what offset batches of a wide table took
-    # before the stream kernel had the class-indexed walk)
-    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide_ragged,wide,zip_ragged,zip,auto").split(","))
-    for variant, zipv, raggedv, label in ((1, 1, 0, "dense"), (2, 1, 1, "wide_ragged"), (2, 1, 0, "wide"), (2, 2, 1, "zip_ragged"),
-                                          (2, 2, 0, "zip"), (0, 0, 0, "auto")):
+    # (*_stream: ragged_variant = 2, the stream kernel on the same walk -- opt-in; the others: the library's routing)
+    only = set(os.environ.get("WIDE_CASE_LEGS", "dense,wide,wide_stream,zip,zip_stream,auto").split(","))
+    for variant, zipv, raggedv, label in ((1, 1, 0, "dense"), (2, 1, 0, "wide"), (2, 1, 2, "wide_stream"), (2, 2, 0, "zip"),
+                                          (2, 2, 2, "zip_stream"), (0, 0, 0, "auto")):
         if label not in only:
             continue
         pb.set_config(walk_variant=variant, zip_variant=zipv, ragged_variant=raggedv, auto_adapt=1)
