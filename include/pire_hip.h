@@ -136,7 +136,9 @@ typedef struct pire_hip_config {
 	                               /* >= 2^20 strings when the offsets are on the device) take the stream kernel (every    */
 	                               /* lane walks a run of consecutive strings), smaller ones the ragged kernel (one string */
 	                               /* per lane at a time); 1 always the ragged kernel; 2 the stream kernel from 256        */
-	                               /* strings (tests).  Same results either way.                                            */
+	                               /* strings (tests) -- and, for tables on the class-indexed walk, the stream kernel on   */
+	                               /* that walk, which 0 never takes (measured slower there; its image is  */
+	                               /* built for tables uploaded while 2 is set).  Same results either way.                 */
 	uint32_t host_staging;         /* device staging of the host-pointer forms of the prefix / suffix / half-final /   */
 	                               /* counting / capture / slow entry points: 0 blocks cached per device between calls */
 	                               /* (no allocation in steady state), 1 hipMalloc + hipFree per call (round 2),       */

@@ -27,6 +27,7 @@ for f in prefix suffix half_final counting actions long_strings capture pair hos
 for f in counting_variants capture_variants half_final_variants counting_many_regexps slow_ragged slow_ragged_nostats; do cp $S/$f.log $P/r06_final_$f.log; done
 cp $S/counting_kernel_stats.txt $P/r06_counting_kernel_stats.txt
 [ -s $S/actions_wide.jsonl ] && cp $S/actions_wide.jsonl $P/r06_actions_wide.jsonl
+[ -s $S/selftest_cost.txt ] && cp $S/selftest_cost.txt $P/r06_selftest_cost.txt
 [ -f $S/tsan_summary.txt ] && cat $S/tsan_pytest.log $S/tsan_summary.txt > $P/r06_tsan_gpu_summary.txt
 cp gpurun_out/final_r06.log $P/r06_final_run.log
 python tools/fill_design_tables.py

@@ -112,6 +112,7 @@ timeout 600 python tools/actions_wide_case.py 2>&1 | grep "^{" > $OUT/actions_wi
 { LONG_TOTAL_LOG2=30 timeout 120 python tools/long_case.py 2>&1 | grep -v "amdgpu.ids\|pire_hip segm"; timeout 120 python tools/long_grep_case.py 2>&1 | grep "^grep"; } | tee $OUT/long_strings.log | cut -c1-200
 timeout 200 python tools/pair_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pair.log | cut -c1-200
 for st in slow_x300 slow_x400_utf8; do timeout 400 python bench.py --set $st --log2-strings 16 --len 4096 --steps 5 --warmup 2 --cpu-sample-log2 10 2>&1 | tail -1 | cut -c1-1500; done > $OUT/bench_slow_wide.jsonl; cut -c1-200 $OUT/bench_slow_wide.jsonl
+timeout 300 python tools/selftest_cost.py 2>&1 | grep "self-test" | tee $OUT/selftest_cost.txt | cut -c1-200
 echo "== host-pointer mode"
 timeout 300 python tools/host_call_latency.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_call_latency.log | tail -8
 echo "== C++ shim and the pigrep example"
