@@ -731,11 +731,6 @@ struct RaggedClock {};
 #define PIRE_RCLK(c, k) do { } while (0)
 #endif
 
-// One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
-// Returns false when the wave has nothing left to do.
-// EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
-// state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
-// A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
 // ---- the walks with actions on the class-indexed walk (round 6) -----------------------------------------
 // A dictionary scanner under LongestPrefix or as a HalfFinalScanner visits thousands of states: on the dense rows nearly every
 // chunk leaves them and is walked again from memory (0.3 TB/s on log lines, profiles/r06_actions_wide.jsonl).  The same walk
@@ -869,6 +864,11 @@ __device__ __forceinline__ void WideChunkAct(const ScanParams& p, uint8_t* lds, 
 	}
 }
 
+// One iteration: start fetching the next window into `nxt`, walk the current window held in `cur`.
+// Returns false when the wave has nothing left to do.
+// EXT: the extensions segmented.hip needs (separate end offsets, resume states fetched with the offsets, device
+// state ids in and out).  A separate instantiation: compiled into the plain kernel they cost it 2-8 % (measured
+// A/B on one box: fixed 4 KiB strings 3 267 -> 3 026 GB/s), although none of it runs there.
 // WIDE (round 5; 1: the exact table behind the rows has u32 entries, 2: u16, 3: u16 and the LDS image is zipped, round 6): the class-indexed walk of wide.hip instead of
 // the dense rows -- S.hs is then a device id with a row or `wide` (the escape row), the state's end-of-string record comes
 // from memory (the LDS is the rows'), everything else of the kernel is what it was.  Plain scans only (NoAct).
