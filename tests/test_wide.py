@@ -383,6 +383,38 @@ def test_ragged_kernel_on_the_wide_walk_records_cut_anywhere(pa, torch_cuda, cfg
         assert (cnt == expected_counts(o, oi, of)).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("zipv", [1, 2], ids=["plain rows", "zipped"])
+@pytest.mark.parametrize("kind,n", [("urls", 70001), ("tiny", 30000), ("mixed", 20000), ("uniform", 1025), ("empty", 5000),
+                                    ("aligned", 6000), ("edges", 70001), ("lines", 9000), ("skewed", 2500), ("urls", 300)])
+def test_ragged_kernel_on_the_wide_walk_string_lengths_of_every_kind(pa, torch_cuda, cfg, kind, n, zipv):
+    """The ragged kernel on the class-indexed walk, plain rows and zipped: URL-sized strings, runs of empty and tiny ones, ranges
+    that end in the middle of a wave's grab, strings that all fill their window, a few very long ones.  (Written for round 6's
+    experiment of handing a wave's strings out in the order of their lengths -- parity-green, 6 % slower, not kept: DESIGN.md 7 --
+    and kept as the parity test it is.)"""
+    from pire_amd import binding as pb
+    from tests.test_gpu_parity import stream_lengths
+
+    torch = torch_cuda
+    cfg.set(no_offsets_peek=1, ragged_variant=1, walk_variant=2, zip_variant=zipv, auto_adapt=1)
+    entry = W.wide_set("dict_1k")
+    blob = W.load_blob(entry["blob"])
+    t, o = pa.Table(blob), ob.OracleScanner(blob)
+    rng = np.random.RandomState(n + len(kind))
+    ln = stream_lengths(rng, kind, n).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(ln)
+    total = int(offs[-1])
+    text = W.wide_records(entry, "k512", 23, (total + 1023) // 1024 + 1, 1024).reshape(-1)[:total].copy()
+    for flags in (BE, 0):
+        oi, of = o.run(text, offs, flags=flags, threads=4)
+        gi, gf, cnt = dev_run_offsets(torch, t, text, offs, flags=flags)
+        assert pb.last_kernel() == "ragged_wide", pb.last_kernel()
+        bad = np.nonzero((gi != oi) | (gf != of))[0]
+        assert len(bad) == 0, (flags, len(bad), bad[:10], ln[bad[:10]])
+        assert (cnt == expected_counts(o, oi, of)).all()
+
+
 STREAM_WIDE_CASES = [
     # scanner, corpus, zip_variant (1 plain rows, 2 zipped), lengths, strings, lead
     ("dict_1k", "k128", 1, "urls", 70001, 0),
