@@ -1051,7 +1051,17 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	S.busy = nBusy;
 	S.loaded = nLoad;
 	PIRE_RCLK(clk, 5);
-	return __any(nBusy || S.pend);
+	if (__any(nBusy || S.pend))
+		return true;
+	// The wave's last window: the (dummy) loads into `nxt` are still on their way, and behind the loop the registers are the
+	// epilogue's -- the flush of the visit counters starts with a barrier that waits for LDS only, and a line that landed late
+	// overwrote the zero high word of its counter index: a memory fault once in a few hundred launches of a kernel whose
+	// strings all die at their first byte, i.e. whose last iteration has nothing to walk (found by tools/stress_dict.py, round
+	// 6; every instantiation of this kernel since round 2 had the window).  Waited for HERE, on the way out -- and without
+	// naming the registers: named, the instantiations at the register limit carried them to this point through scratch,
+	// stored while the loads were in flight (the build's audit refused three of them).
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	return false;
 }
 
 template <class Act, bool EXT, int WIDE = 0>

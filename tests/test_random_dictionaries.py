@@ -47,8 +47,12 @@ def draw_text(rng, words, symbols, total):
     return np.frombuffer(bytes(out[:total]), dtype=np.uint8).copy()
 
 
-def run_seed(pa, torch, cfg, seed):
+def run_seed(pa, torch, cfg, seed, verbose=False):
     from pire_amd import binding as pb
+
+    def say(*a):
+        if verbose:
+            print(*a, flush=True)
 
     rng = np.random.RandomState(7000 + seed)
     words, symbols, mode = draw_dictionary(rng)
@@ -58,6 +62,7 @@ def run_seed(pa, torch, cfg, seed):
     if o.size <= 300 or o.letters > 127:
         return "skipped"
     what = (seed, len(words), mode, o.size, o.letters)
+    say(what)
     # ---- fixed-length records: both wide kernels, both images
     n, length = 2048, int(rng.choice([384, 1024, 1152]))
     data = draw_text(rng, words, symbols, n * length).reshape(n, length)
@@ -80,6 +85,7 @@ def run_seed(pa, torch, cfg, seed):
         for round_ in range(2):
             for walk in (2, 3):
                 cfg.set(walk_variant=walk)
+                say("zip", zipv, "round", round_, "strided walk", walk, n, length)
                 gi, gf, cnt = dev_run_strided(torch, t, d)
                 assert pb.last_kernel() == "wide", (what, pb.last_kernel())
                 assert (gi == oi).all() and (gf == of).all(), (what, zipv, round_, walk, "strided")
@@ -89,15 +95,18 @@ def run_seed(pa, torch, cfg, seed):
                 cfg.set(ragged_variant=raggedv)
                 if round_ == 0 and raggedv == 2:
                     t.upload()   # (the stream kernel's image is built for tables uploaded while it is asked for)
+                say("offsets, ragged_variant", raggedv, kind, m)
                 gi, gf, cnt = dev_run_offsets(torch, t, text, offs)
                 assert pb.last_kernel() in ("ragged_wide", "stream_wide", "generic"), (what, pb.last_kernel())
                 assert (gi == roi).all() and (gf == rof).all(), (what, zipv, round_, raggedv, kind, m, pb.last_kernel())
                 assert (cnt == expected_counts(o, roi, rof)).all()
             cfg.set(ragged_variant=0)
             for (lg, tb), want in want_prefix.items():
+                say("prefix", lg, tb)
                 got = t.prefix(text, offs, lg, tb, tb)
                 assert (got == want).all(), (what, zipv, round_, "prefix", lg, tb, pb.last_kernel())
             if t.RegexpsCount <= 8:
+                say("half-final")
                 gi, gf, gr = t.run_half_final(text, offs)
                 assert (gi == hi).all() and (gf == hf).all() and (gr == hr).all(), (what, zipv, round_, "half-final", pb.last_kernel())
             t.adapt()   # the second round: rows ranked from what these scans saw
@@ -110,3 +119,40 @@ def test_random_dictionary_through_every_kernel_of_the_wide_walk(pa, torch_cuda,
         pytest.skip("oracle/_ref not built")
     if run_seed(pa, torch_cuda, cfg, seed) == "skipped":
         pytest.skip("the dictionary drawn compiles to a table the wide walk is not for")
+
+
+def test_the_ragged_kernel_waits_for_its_last_window_before_it_leaves(pa, torch_cuda, cfg):
+    """Found by tools/stress_dict.py (round 6, seed 206): ScanRaggedKernel left its window loop with the (dummy) loads of the
+    next window still on their way; the epilogue's barrier waits for LDS only, and a line that landed late overwrote a register
+    of the counter flush -- a memory fault (or an atomic add somewhere) once in a few hundred launches, whenever a wave's LAST
+    iteration has nothing to walk: prefix searches whose strings all die at their first byte (a blacklist scanner walked
+    without BeginMark), batches that end in empty strings.  Every instantiation since round 2 had the window; the kernel now
+    waits on its way out (ragged.hip RaggedPhase).  Hundreds of such launches, every answer the oracle's, no fault."""
+    from pire_amd import binding as pb
+
+    if not ob.ref_available():
+        pytest.skip("oracle/_ref not built")
+    torch = torch_cuda
+    rng = np.random.RandomState(7000 + 206)
+    words, symbols, mode = draw_dictionary(rng)
+    assert mode == 0
+    blob = ob.RefScanner.compile_dictionary(words, surround=False, utf8=False).save()
+    o = ob.OracleScanner(blob)
+    ln = stream_lengths(np.random.RandomState(3), "edges", 20000).astype(np.uint64)
+    offs = np.zeros(len(ln) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(ln)
+    text = draw_text(rng, words, symbols, int(offs[-1]))
+    want = o.prefix(text, offs, False, False, False)
+    assert (want < 0).all()                      # dead at the first byte, every one of them
+    empty = np.zeros(5001, dtype=np.uint64)      # 5 000 empty strings
+    eoi, eof = o.run(text[:0], empty, threads=1)
+    for walk in (2, 1):
+        cfg.set(walk_variant=walk, zip_variant=1, auto_adapt=1, ragged_act_always=1, no_offsets_peek=1, ragged_variant=1)
+        t = pa.Table(blob)
+        for _ in range(150):
+            assert (t.prefix(text, offs, False, False, False) == want).all()
+        assert pb.last_kernel() == ("ragged_prefix_wide" if walk == 2 else "ragged_prefix")
+        for _ in range(150):
+            gi, gf, _ = dev_run_offsets(torch, t, np.zeros(16, dtype=np.uint8), empty)
+            assert (gi == eoi).all() and (gf == eof).all()
+        assert pb.last_kernel() in ("ragged_wide", "ragged")

@@ -8,8 +8,9 @@ first, last = int(sys.argv[1]) if len(sys.argv) > 1 else 10, int(sys.argv[2]) if
 ok = skipped = 0
 for seed in range(first, last):
     mp = _Cfg()
+    print('seed', seed, flush=True)
     try:
-        r = T.run_seed(pire_amd, torch, mp, seed)
+        r = T.run_seed(pire_amd, torch, mp, seed, verbose=bool(os.environ.get('STRESS_VERBOSE')))
         ok += r == "ok"
         skipped += r == "skipped"
     except BaseException as e:
