@@ -121,6 +121,46 @@ def test_inflight_register_check_sees_a_copied_tile():
     assert mod.check(two + ["\ts_waitcnt vmcnt(8)", "\tv_mov_b32_e32 v60, v70"] + tail)
 
 
+def test_inflight_register_check_follows_the_ways_out_of_the_window_loop():
+    """Round 6 (lessons 24 and 29): a load issued in the loop's last trip is still on its way when the loop is
+    left.  The checker follows every exit edge -- both arms of every branch -- until all loads are waited for: an epilogue that
+    names a tile register first is reported (the ragged kernel's counter flush did: a memory fault once in a few hundred
+    launches), one that waits first is not, and eight younger loads with vmcnt(8) retire the loop's (loads return in order)."""
+    loop = [".LBB0_1:"] + ["\tglobal_load_dwordx4 v[%d:%d], v[40:41], off" % (4 * j, 4 * j + 3) for j in range(8)]
+    loop += ["\ts_waitcnt vmcnt(8)", "\tv_add_u32_e32 v50, v50, v51", "\ts_cbranch_vccz .LBB0_3", "\ts_cbranch_scc1 .LBB0_1"]
+    mod = _inflight()
+    bad = loop + ["\ts_barrier", "\tv_mov_b32_e32 v3, 0", ".LBB0_3:", "\ts_waitcnt vmcnt(0)", "\ts_endpgm"]
+    rep = mod.check_exits(bad)
+    assert rep and "v_mov_b32_e32 v3, 0" in rep[0][1]
+    good = loop + ["\ts_waitcnt vmcnt(0)", "\ts_barrier", "\tv_mov_b32_e32 v3, 0", ".LBB0_3:", "\ts_waitcnt vmcnt(0)", "\tv_mov_b32_e32 v4, 0", "\ts_endpgm"]
+    assert mod.check_exits(good) == []
+    # the branch out of the loop leads to code that names a tile register before it waits
+    assert mod.check_exits(loop + ["\ts_waitcnt vmcnt(0)", "\ts_endpgm", ".LBB0_3:", "\tv_mov_b32_e32 v60, v28", "\ts_endpgm"])
+    # the next task's request behind the loop: eight younger loads, vmcnt(8) -- the loop's own have landed
+    nxt = ["\tglobal_load_dwordx4 v[%d:%d], v[40:41], off" % (64 + 4 * j, 64 + 4 * j + 3) for j in range(8)]
+    assert mod.check_exits(loop + nxt + ["\ts_waitcnt vmcnt(8)", "\tv_mov_b32_e32 v60, v28", "\ts_endpgm", ".LBB0_3:", "\ts_endpgm"]) == []
+    assert mod.check_exits(loop + nxt[:4] + ["\ts_waitcnt vmcnt(8)", "\tv_mov_b32_e32 v60, v28", "\ts_endpgm", ".LBB0_3:", "\ts_endpgm"])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_the_exit_check_sees_round_5s_wide_kernel_and_is_quiet_on_the_product():
+    """check_exits on real ISA: the form of ScanWideKernel that round 5 shipped (kept behind PIRE_EXP == 2 for this test and for
+    test_early_out_between_chained_tasks) waited for a tile behind the loop, where hipcc had copied the slot -- reported; the
+    product's kernels are clean (the build demands it: build_audit.py)."""
+    import subprocess
+
+    mod = _inflight()
+    asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DPIRE_EXP=2", "-x", "hip", "--offload-device-only", "-S",
+                          os.path.join(ROOT, "pire_amd", "csrc", "wide.hip"), "-o", "-"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         text=True, check=True).stdout
+    seen = 0
+    for name, body in mod.kernels(asm):
+        if "ScanWideKernel" in name:
+            seen += 1
+            assert mod.check_exits(body), name
+    assert seen >= 3
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_sanitizer_builds_carry_the_products_device_code():
     """The sanitizer libraries instrument the HOST side (-O1 -g); their kernels must be the product's, instruction for

@@ -16,8 +16,10 @@ link fails when an audit fails, and the result -- hipcc's version, the kernels l
 
 What is checked, per unit (the product's flags: -O3 --offload-arch=gfx950):
   tiled / wide / ragged / stream / pair   no scratch, no VGPR spills, <= 128 VGPRs (16 waves per CU); in the window loop no
-                                          instruction names a tile register between its load and the wait that covers it
-                                          (inflight_registers.py)
+                                          instruction names a tile register between its load and the wait that covers it,
+                                          and on every way OUT of that loop none does before the loop's last loads are
+                                          waited for (inflight_registers.py check / check_exits; round 6: both bugs of this
+                                          round were loads still on their way when a loop was left)
   counting                                the row kernels: a0..a31 named by the loads and v_accvgpr_read only, loads of the
                                           form `global_load_dwordx4 a[..], v[..], off`, no scratch inside the window loop,
                                           VGPRs + AGPRs <= 128; every other kernel of the unit: no scratch
@@ -120,6 +122,10 @@ def audit_window_unit(unit, extra=()):
                     fails.append("%s: no window loop found" % name)
                 elif rep:
                     fails.append("%s: %d instructions name a tile register between its load and its wait, first: %s" % (name, len(rep), rep[0][1]))
+                ex = mod.check_exits(body)   # (round 6: the ways OUT of the window loop, DESIGN.md 6 lessons 24 and 29)
+                if ex:
+                    fails.append("%s: behind the window loop %d instructions name a tile register before the loop's last loads are waited for, first: %s"
+                                 % (name, len(ex), ex[0][1]))
         if found < len(WALKED[unit]):
             fails.append("%s: %d kernel bodies in the ISA, at least %d expected (%s)" % (unit, found, len(WALKED[unit]), ", ".join(WALKED[unit])))
     return fails, seen

@@ -122,6 +122,102 @@ def check(body):
     return sorted(set(reports))
 
 
+def check_exits(body):
+    """Round 6 (lessons 24 and 29): what happens to the tile registers on the ways OUT of the window loop.  A load
+    issued from inline asm in the loop's last trip is still on its way when the loop is left; behind the loop the registers are
+    somebody else's, and whatever names one of them before an `s_waitcnt vmcnt(0)` reads data that has not arrived or is
+    overwritten when it does.  For every exit edge of the window loop (a branch out of it, the fall-through behind its back
+    edge) the code is followed -- both arms of every branch, up to 4 000 instructions -- until it waits for all loads
+    (s_waitcnt vmcnt(0)) or ends; an instruction that names a register any asm load of the loop writes, met before that, is
+    reported.  [(line number, text)], or None when the kernel has no window loop."""
+    code, labels, from_asm = [], {}, []
+    in_asm = False
+    has_markers = any("#ASMSTART" in line for line in body)
+    for line in body:
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
+        text = line.split(";")[0].strip()
+        code.append(text)
+        from_asm.append(in_asm or not has_markers)
+        m = re.match(r"^(\.LBB\S+):", text)
+        if m:
+            labels[m.group(1)] = len(code) - 1
+    best = None
+    for i, text in enumerate(code):
+        m = re.match(r"^s_cbranch_\w+\s+(\.LBB\S+)|^s_branch\s+(\.LBB\S+)", text)
+        if not m:
+            continue
+        target = labels.get(m.group(1) or m.group(2))
+        if target is None or target > i:
+            continue
+        n = sum(1 for t in code[target:i] if t.startswith("global_load_dwordx4"))
+        if n >= 8 and (best is None or i - target < best[1] - best[0]):
+            best = (target, i)
+    if best is None:
+        return None
+    lo, hi = best
+    tiles = set()
+    for i in range(lo, hi + 1):
+        if code[i].startswith("global_load_dwordx4") and from_asm[i]:
+            tiles |= regs(code[i].split()[1].rstrip(","))
+    # exit edges
+    starts = set()
+    if not code[hi].startswith("s_branch"):
+        starts.add(hi + 1)
+    for i in range(lo, hi + 1):
+        m = re.match(r"^s_cbranch_\w+\s+(\.LBB\S+)|^s_branch\s+(\.LBB\S+)", code[i])
+        if m:
+            t = labels.get(m.group(1) or m.group(2))
+            if t is not None and (t > hi or t < lo):
+                starts.add(t)
+    reports, seen = [], set()
+    stack = [(s0, 0, 0) for s0 in sorted(starts)]   # (instruction, depth, loads issued since the loop was left)
+    while stack:
+        i, depth, younger = stack.pop()
+        while i < len(code) and depth < 4000:
+            if (i, min(younger, 64)) in seen:
+                break
+            seen.add((i, min(younger, 64)))
+            text = code[i]
+            depth += 1
+            if not text or text.endswith(":") or text.startswith("."):
+                i += 1
+                continue
+            op = text.split()[0]
+            if op == "s_endpgm":
+                break
+            if op == "s_waitcnt":
+                m = re.search(r"vmcnt\((\d+)\)", text)
+                if m and int(m.group(1)) <= younger:
+                    break   # loads return in order: all but the `younger` loads issued since have landed, the loop's among them
+                i += 1
+                continue
+            if lo <= i <= hi:
+                break   # back inside the window loop (an outer loop's next trip): the loop's own waits take over
+            if op.startswith("global_load") or op.startswith("scratch_load") or op.startswith("buffer_load") or \
+               op.startswith("global_store") or op.startswith("scratch_store") or op.startswith("global_atomic"):
+                if regs(" ".join(text.split()[2:])) & tiles and not (op.startswith("global_load_dwordx4") and from_asm[i]):
+                    reports.append((i, text))
+                    break
+                younger += 1   # (an asm load that lands in a tile register again is the next task's request: queued behind the loop's)
+                i += 1
+                continue
+            if regs(text) & tiles:
+                reports.append((i, text))
+                break
+            m = re.match(r"^s_cbranch_\w+\s+(\.LBB\S+)|^s_branch\s+(\.LBB\S+)", text)
+            if m:
+                t = labels.get(m.group(1) or m.group(2))
+                if t is not None:
+                    stack.append((t, depth, younger))
+                if op == "s_branch":
+                    break
+            i += 1
+    return sorted(set(reports))
+
+
 def main():
     unit, names = sys.argv[1], sys.argv[2:]
     asm = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "--offload-device-only", "-S", unit, "-o", "-"],
@@ -139,6 +235,11 @@ def main():
         for i, text in rep[:12]:
             print("    line %5d: %s" % (i, text))
         bad += len(rep)
+        ex = check_exits(body) or []
+        print("%-110s on the ways out of the window loop: %d reports" % ("", len(ex)))
+        for i, text in ex[:12]:
+            print("    line %5d: %s" % (i, text))
+        bad += len(ex)
     return 1 if bad else 0
 
 
