@@ -722,7 +722,7 @@ def main():
                 "parallelism": f"shard-by-string x{world}",
                 "ranks_seen": len(rank_devices), "per_rank_device": rank_devices, "ranks_sharing_a_device": clashes,
                 "shard_ranges": [list(pd.shard_range(n * world, r, world)) for r in range(world)],
-                "reduce_backend": pd.backend_description(),
+                "reduce_backend": pd.backend_description(), "rccl_version": pd.rccl_version(),
                 "per_rank_GBps": [round(float(n) * length * args.steps / t / 1e9, 1) for t in per_rank_timed],
                 "per_rank_kernel_ms": [round(x, 4) for x in timed_stats["kernel_ms_of_ranks"]],
                 "counter_reduce": ("after every pass, asynchronously (round 4's form)" if args.reduce_every_step else

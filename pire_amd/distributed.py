@@ -129,6 +129,16 @@ def backend_description() -> str:
     return name
 
 
+def rccl_version():
+    """The RCCL this torch was built with ("2.26.6"), whether or not a process group is up; None without one."""
+    try:
+        import torch
+
+        return ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def describe_ranks(device=None):
     """What every rank of the process group is and sits on, in rank order, on every rank: [{"rank", "host", "device", "pci_bus_id",
     "name"}] (one all_gather_object; one entry without a process group).  bench.py prints it as `per_rank_device` next to
