@@ -565,7 +565,18 @@ int Dispatch(const ScanParams& p, hipStream_t stream, unsigned long long* workCo
 	}
 	NoteKernel(kNames[kind]);
 	if (p.owner && !(p.flags & (1u << 23)))   // (what the live estimate of FillParams divides the trap signal by)
-		p.owner->bytesScanned.fetch_add(p.offsets ? totalBytesHint : p.n * p.len, std::memory_order_relaxed);
+	{
+		// (offsets on the device: the host does not know the bytes -- the hint is ~0, which round 6's first form ADDED to the count:
+		// it wrapped.  What the live estimate of FillParams divides by takes nothing for such a batch -- a guess there would turn
+		// tables to the other walk on a guess --; the share of offset batches takes 48 bytes a string.)
+		const bool known = !p.offsets || totalBytesHint != ~0ull;
+		const uint64_t bytes = !p.offsets ? p.n * p.len : known ? totalBytesHint : p.n * 48;
+		if (known)
+			p.owner->bytesScanned.fetch_add(bytes, std::memory_order_relaxed);
+		p.owner->bytesNominal.fetch_add(bytes, std::memory_order_relaxed);
+		if (p.offsets)
+			p.owner->bytesOffsetBatches.fetch_add(bytes, std::memory_order_relaxed);
+	}
 	int rc = wide ? LaunchWide(p, stream) : tiled ? LaunchTiled(p, stream) : streamWide ? LaunchStreamWide(p, stream)
 	         : raggedWide ? LaunchRaggedWide(p, workCounter, stream) : streamed ? LaunchStream(p, stream)
 	         : ragged ? LaunchRagged(p, workCounter, stream) : LaunchGeneric(p, stream);

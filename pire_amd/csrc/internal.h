@@ -249,6 +249,8 @@ struct HostTable {
 	uint32_t zipFull = 0;             // != 0: the wide image is ZIPPED (MakeWideLayout): perm ids [0, zipFull) have a row of their own,
 	                                  // [zipFull, wide) a header + <= 3 exceptions against the row of zipBase[id - zipFull]
 	std::vector<uint16_t> zipBase;    // [wide - zipFull] perm id (< zipFull) of that row
+	float offsetBatchShare = 0;       // share of the bytes scanned since the last ranking that came as offset batches (one string per
+	                                  // lane: the zipped step's 20 vector instructions bound that kernel, table.cpp ChooseZip)
 	float zipPlainOutside = 0;        // what the plan that chose between the two images estimated: share of the ranking's mass outside
 	float zipOutside = 0;             // the plain rows / outside the zipped tier (table.cpp ChooseZip)
 	float outsideDense = 0;           // share of the ranking's mass on states WITHOUT a dense row / ...
@@ -382,6 +384,9 @@ struct pire_hip_table {
 	std::atomic<uint32_t> autoAdapts{0};
 	std::atomic<uint64_t> wideLaunched{0};   // wave-chunks handed to the wide walk since the last adapt()
 	std::atomic<uint64_t> bytesScanned{0};   // text bytes handed to the kernels of pire_hip_run[_strided] since the last ranking (where the host knows)
+	std::atomic<uint64_t> bytesNominal{0};   // ... the same with 48 bytes a string where it does not (offsets on the device), and
+	std::atomic<uint64_t> bytesOffsetBatches{0};   // those of them that came as offset batches (the ragged / stream kernels): what
+	                                               // ChooseZip weighs the zipped image by (HostTable::offsetBatchShare)
 	// the adaptation a call that only enqueues starts in the background (table.cpp BackgroundAdaptStep): state 0 idle, 1 the
 	// worker is on its way, 2 `host` + `image` (device `device`) are ready to be swapped in at a launch boundary
 	struct Background {

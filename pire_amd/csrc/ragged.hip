@@ -768,10 +768,13 @@ __device__ __forceinline__ bool WideIsFlagged(uint32_t bits, uint32_t endState, 
 template <class Act, bool ZIP>
 __device__ __forceinline__ uint32_t WideActBytes(const ScanParams& p, const uint8_t* lds, const LdsLayout& L, const WideConst& K,
                                                  u32x4 v, uint32_t sid, uint32_t count, const Act& act, typename Act::Lane& al,
-                                                 uint64_t addr)
+                                                 uint64_t addr, uint32_t sampleStep, uint32_t& sampleSid)
 {
+	sampleSid = 0;
 #pragma unroll 1
 	for (uint32_t i = 0; i < count; ++i) {
+		if (i == sampleStep)
+			sampleSid = sid;   // the state whose row (or table line) this step looks up: what the ranking counts
 		const uint32_t c2 = HotLookup(v.x & 0xFFu);
 		uint32_t next = WideEntry<ZIP>(sid < p.wide ? sid : p.wide, K, c2);
 		bool look = true;
@@ -853,12 +856,16 @@ __device__ __forceinline__ void WideChunkAct(const ScanParams& p, uint8_t* lds, 
 	}
 	st = PARTIAL ? snap : h;
 	if ((!PARTIAL || count != 0) && !absorbed && (WideIsFlagged<ZIP, Act::kWideMask>(acc, st, K) || st == p.wide) && act.Wants(al)) {
-		const uint32_t sid = WideActBytes<Act, ZIP>(p, lds, L, K, v, st0 < p.wide ? st0 : cold, count, act, al, addr);
+		// tell pire_hip_table_adapt() which states deserve a place in the tier: one lane of 64 (by the chunk's address), the state
+		// in front of ONE of the chunk's steps (by the address too: not the state the chunk ends in -- an offset batch's strings
+		// start with their windows, and a state they are in at their 6th byte and nowhere else would never be seen)
+		const uint32_t h = ((uint32_t(addr) >> 4) + blockIdx.x * 0x632BE5ABu) * 0x9E3779B1u;
+		uint32_t seen;
+		const uint32_t sid = WideActBytes<Act, ZIP>(p, lds, L, K, v, st0 < p.wide ? st0 : cold, count, act, al, addr, (h >> 22) & 15u, seen);
 		st = sid < p.wide ? sid : p.wide;
 		cold = sid;
-		// tell pire_hip_table_adapt() which states deserve a place in the tier, sampled like the plain walk's re-walks
-		if (sid >= p.wide && (threadIdx.x & 63) == ((uint32_t(addr) >> 4) & 63u)) {
-			atomicAdd(&p.visitCold[sid], 1u);
+		if (seen >= p.wide && (threadIdx.x & 63) == (h >> 26) && ((h >> 22) & 15u) < count) {
+			atomicAdd(&p.visitCold[seen], 1u);
 			atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
 		}
 	}
@@ -945,28 +952,42 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 		if (__any(nb != 0 && S.loaded)) {
 			const uint32_t nbl = S.loaded ? nb : 0u;
 			const uint32_t full = nbl >> 4, tail = nbl & 15u;
-			// (the wide walk samples INSIDE the window, behind one of its chunks: a URL is one window, in front of it every lane
-			// is in the start state and behind it mostly in the dead one -- the samples said "nothing outside the rows" of
-			// batches that had 1.5 % of their steps there)
+			// The wide walk's visit sample: the state behind ONE byte of the window of ONE lane, both drawn per iteration -- every
+			// lane-step of a wave's 64 x 128 with the same chance, whatever the strings' lengths.  (Round 5 took the state behind
+			// one of the window's CHUNKS: a URL is one window that starts with the string, so only the states a URL is in behind
+			// its 16th, 32nd, ... byte were ever seen, and the seven states of "http://", 1.4 % of all steps each, never -- in the
+			// tier they went without samples, their mass halved with every adapt() until they dropped out, trapped, came back:
+			// after eight rounds the 6th, 9th, 13th, 16th and 18th most visited states of a blacklist scanner had no row and
+			// 4.1 % of the steps were outside the tier where 0.5 % need be; tools/ranking_quality.py.)  The walk does not keep
+			// the states inside a chunk: the drawn lane walks the drawn chunk again from the state in front of it, up to 15 bytes,
+			// exactly (the table in memory where the rows say "no row").  What is counted is the state IN FRONT of the drawn byte
+			// -- the state whose row that step looks up: the state every string starts in is in front of a byte, never behind one.
+			// (drawn per iteration AND wave: if every wave counted its iterations from 0 -- a launch of a URL batch has 32 -- then drawn
+			// from the count alone the same 32 pairs of lane and byte are looked at by every wave of every launch; round 5's did, and the
+			// state every string starts in, in front of byte 0, happened not to be among them: it sank through the ranking launch
+			// by launch although every string looks it up, tools/sampler_probe.py)
+			// -- so every wave starts its count somewhere else: ScanRaggedKernel)
 			const uint32_t sampleHash = iter * 0x9E3779B1u;
 			const bool sampleLaneHere = WIDE && (threadIdx.x & 63) == (sampleHash >> 26) && !(p.flags & kDebugNoHist);
+			const uint32_t sampleAt = (sampleHash >> 19) & 127u, sampleChunk = sampleAt >> 4;   // wave-uniform
+			uint32_t sampleFrom = 0;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) < full) {
-					if constexpr (Act::kActive && WIDE != 0) {
+					if (WIDE != 0 && uint32_t(k) == sampleChunk)
+						sampleFrom = S.hs != p.wide ? S.hs : S.cold;
+					if constexpr (Act::kActive && WIDE != 0)
 						WideChunkAct<Act, WIDE == 3, false>(p, lds, L, W, K, cur[k], 16u, S.hs, S.cold, act, al, S.pos + 16u * k);
-						if (sampleLaneHere && uint32_t(k) == ((sampleHash >> 20) & 7u))
-							WideSample<WIDE == 3>(p, lds, W, S.hs);
-					} else if constexpr (Act::kActive)
+					else if constexpr (Act::kActive)
 						StepChunkAct(p, lds, L, cur[k], S.hs, S.cold, reinterpret_cast<const uint8_t*>(finHot), act, al,
 						             S.pos + 16u * k);
-					else if constexpr (WIDE != 0) {
+					else if constexpr (WIDE != 0)
 						WideChunk<WIDE >= 2, WIDE == 3>(p, lds, W, K, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
-						if (sampleLaneHere && uint32_t(k) == ((sampleHash >> 20) & 7u))
-							WideSample<WIDE == 3>(p, lds, W, S.hs);
-					} else
+					else
 						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 				}
+			if (WIDE != 0 && full == sampleChunk)
+				sampleFrom = S.hs != p.wide ? S.hs : S.cold;   // (the drawn byte lies in the lane's partial last chunk)
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
 				// all the partial last chunks of the wave in ONE pass: pick each lane's chunk, walk it with a snapshot
 				u32x4 v = cur[0];
@@ -983,6 +1004,33 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 					WidePartial<WIDE >= 2, WIDE == 3>(p, K, v, tail, S.hs, S.cold);
 				else
 					StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
+			}
+			if constexpr (WIDE != 0) {
+				if (sampleLaneHere && sampleAt < nbl) {
+					u32x4 v = cur[0];
+#pragma unroll
+					for (int k = 1; k < 8; ++k)
+						if (sampleChunk == uint32_t(k))
+							v = cur[k];
+					uint32_t sid = sampleFrom;   // device id of the state in front of the chunk
+#pragma unroll 1
+					for (uint32_t i = 0; i < (sampleAt & 15u); ++i) {
+						const uint32_t c2 = HotLookup(v.x & 0xFFu);
+						uint32_t next = WideEntry<WIDE == 3>(sid < p.wide ? sid : p.wide, K, c2);
+						if (next == p.wide) {
+							next = WideNextC2<WIDE >= 2>(p, sid, c2);
+							asm volatile("" : "+v"(next));   // (the wait belongs in here)
+						}
+						sid = next;
+						v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+						v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+						v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+						v.w >>= 8;
+					}
+					// (a state outside the tier is counted as "outside" here; WHICH state it is the re-walks say -- WideTrapChunk, one
+					// sample per 1 024 lane-steps outside the tier where this one stands for 8 192 --, and the walks with actions below)
+					WideSample<WIDE == 3>(p, lds, W, sid < p.wide ? sid : p.wide);
+				}
 			}
 		}
 		if (nb != 0 && !S.loaded) {
@@ -1132,7 +1180,9 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 			S.pendInit = p.initIdx[S.sIdxN];
 	}
 	PIRE_RCLK(clk, 6);
-	uint32_t iter = 0;
+	// (the iteration count seeds the visit samples -- which lane, which byte -- and every wave starts it somewhere else: RaggedPhase)
+	const uint32_t iter0 = uint32_t(__builtin_amdgcn_readfirstlane(int((blockIdx.x * 16u + (threadIdx.x >> 6)) * 0x632BE5ABu)));
+	uint32_t iter = iter0;
 	for (;; iter += 2) {
 		if (!RaggedPhase<Act, EXT, WIDE>(p, lds, L, finHot, work, workCounter, grab, textBase, safeEnd, R, S, a, b, iter, act, al, clk, W, K))
 			break;
@@ -1145,7 +1195,7 @@ __global__ __launch_bounds__(1024) void ScanRaggedKernel(ScanParams p, unsigned 
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef PIRE_HIP_TUNING
 	if (clk.on && (threadIdx.x & 63) == 0) {
-		clk.acc[7] = iter;
+		clk.acc[7] = iter - iter0;
 		for (int k = 0; k < 8; ++k)
 			atomicAdd(&p.stamps[k], clk.acc[k]);
 		atomicAdd(&p.stamps[8], 1ull);

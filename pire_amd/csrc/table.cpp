@@ -353,7 +353,12 @@ void ChooseZip(HostTable& t, std::vector<uint32_t>& order, const std::vector<dou
 	t.zipPlainOutside = float(std::max(0.0, 1.0 - plainInside / total));
 	// Worth planning at all?  Without a measurement the byte model's masses say little about thousands of states; with one,
 	// the plain rows are the faster walk while the working set fits them (two LDS instructions per byte, not three).
-	const float enter = was ? 0.002f : 0.004f;   // (hysteresis: a zipped table stays zipped at a share that would not have made it one)
+	// Offset batches (one string per lane) are another matter: that kernel is bound by its vector instructions, of which the zipped
+	// step has 20 where the plain one has 5 -- URL batches of a blacklist scanner with 26 000 states, 2.6 % of the steps outside
+	// the plain rows: 784 GB/s on them, 570 on the zipped image that leaves 0.5 % outside (profiles/r06_wide_curve.jsonl).  A table
+	// whose bytes came mostly that way is zipped only from a share the plain rows really cannot live with.
+	const bool offsetBatches = t.offsetBatchShare > 0.5f;
+	const float enter = offsetBatches ? (was ? 0.05f : 0.08f) : (was ? 0.002f : 0.004f);   // (hysteresis: a zipped table stays zipped at a share that would not have made it one)
 	if (variant != 2 && (!t.massMeasured || t.zipPlainOutside < enter))
 		return;
 	ZipPlan best;
@@ -1463,7 +1468,7 @@ Scored ScoreFromCounters(HostTable& h, const SeenCounters& seen, uint64_t wideLa
 			if (i < plain)
 				inside += v;
 		}
-		unzip = total > 0 && 1.0 - inside / total < 0.002;
+		unzip = total > 0 && 1.0 - inside / total < (h.offsetBatchShare > 0.5f ? 0.05 : 0.002);   // (ChooseZip's own thresholds)
 	}
 	out.rerank = coldSamples != 0 || unzip;
 	return out;
@@ -1503,6 +1508,9 @@ void BackgroundWorker(pire_hip_table* t, int dev)
 		if (cur.device == dev)
 			h.reset(new HostTable(t->host));
 		launched = t->wideLaunched.exchange(0, std::memory_order_relaxed);
+		const uint64_t all = t->bytesNominal.load(std::memory_order_relaxed), off = t->bytesOffsetBatches.load(std::memory_order_relaxed);
+		if (h && all)
+			h->offsetBatchShare = float(std::min(1.0, double(off) / double(all)));
 	}
 	bool ok = h != nullptr;
 	SeenCounters seen;
@@ -1577,7 +1585,7 @@ bool AdaptationDue(pire_hip_table* t, uint64_t traps, uint64_t threshold)
 {
 	if (traps >= threshold)
 		return true;
-	if (traps < 64 || t->bytesScanned.load(std::memory_order_relaxed) < (uint64_t(32) << 20))
+	if (traps < 64 || t->bytesNominal.load(std::memory_order_relaxed) < (uint64_t(32) << 20))
 		return false;
 	std::shared_lock<std::shared_mutex> stable(t->adaptMutex);
 	return !t->host.massMeasured;
@@ -1611,6 +1619,8 @@ void BackgroundAdaptStep(pire_hip_table* t, uint64_t threshold)
 		bg.image = DeviceTable();
 		bg.trapsAtLastLook = 0;
 		t->bytesScanned.store(0, std::memory_order_relaxed);
+		t->bytesNominal.store(0, std::memory_order_relaxed);
+		t->bytesOffsetBatches.store(0, std::memory_order_relaxed);
 		t->autoAdapts.fetch_add(1, std::memory_order_relaxed);
 		bg.swaps.fetch_add(1, std::memory_order_relaxed);
 		bg.state.store(0, std::memory_order_release);
@@ -1730,7 +1740,12 @@ int AdaptTable(pire_hip_table* t, uint32_t* changedRows, bool automatic)
 		if (!seen.any)
 			return PIRE_HIP_OK;   // never ran: nothing observed
 	}
-	t->bytesScanned.store(0, std::memory_order_relaxed);
+	{
+		t->bytesScanned.store(0, std::memory_order_relaxed);
+		const uint64_t all = t->bytesNominal.exchange(0, std::memory_order_relaxed), off = t->bytesOffsetBatches.exchange(0, std::memory_order_relaxed);
+		if (all)
+			h.offsetBatchShare = float(std::min(1.0, double(off) / double(all)));
+	}
 	Scored sc = ScoreFromCounters(h, seen, t->wideLaunched.exchange(0, std::memory_order_relaxed));
 	std::vector<uint32_t> before(h.origOfPerm.begin(), h.origOfPerm.begin() + H);
 	std::sort(before.begin(), before.end());

@@ -112,7 +112,8 @@ __device__ __forceinline__ uint32_t WideNextC2(const ScanParams& p, uint32_t st,
 // AdaptTable), so that the measured share of the steps outside the rows is a share.  (The first form sampled one fixed lane of 64 at the chunk's end,
 // like TrapChunk: a state that carries 1e-6 of the steps was never seen and stayed without a row, and although 2 148
 // rows were there for 1 530 visited states 36 % of all wave-chunks were walked twice, profiles/r05_pmc_wide_first.txt.)
-template <bool N16, bool ZIP>
+// CREDIT = false: no samples from here (an A/B switch of round 6; every kernel takes them).
+template <bool N16, bool ZIP, bool CREDIT = true>
 __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, u32x4 v,
                                               uint32_t st0, uint32_t& st, uint32_t& cold, uint32_t sampleStep)
 {
@@ -123,7 +124,16 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 	uint32_t nth = 0;
 	if ((threadIdx.x & 63) == uint32_t(__ffsll(lanes)) - 1u)
 		nth = atomicAdd(reinterpret_cast<uint32_t*>(lds + W.progOff) + 1, 1u);
-	const bool sampled = (uint32_t(__builtin_amdgcn_readfirstlane(int(nth))) & 63u) == 0;
+	const uint32_t nthU = uint32_t(__builtin_amdgcn_readfirstlane(int(nth)));
+	const bool sampled = (nthU & 63u) == 0;
+	// WHICH step of the sampled re-walk leaves the sample: drawn from the re-walk's number, not taken from the chunk's place in
+	// its window (round 6: `sampleStep` was (8 * iteration + chunk) % 16 -- for chunk k of a window only step k or k + 8 -- and an
+	// offset batch's strings start with their windows: a state a URL is in at its 6th byte and nowhere else -- "scheme:/",
+	// 1.4 % of all steps -- was never seen once it was outside the tier, and every URL left the rows there for good;
+	// tools/ranking_quality.py)
+	// (... and from the block's number too: the count of re-walks restarts with every launch, a block of a URL batch makes a few
+	// hundred -- from the count alone only the first handful of draws ever happened, steps 0, 9, 3, 13, 7, and nothing else)
+	sampleStep = (((nthU >> 6) + blockIdx.x * 0x632BE5ABu) * 0x9E3779B1u) >> 28;
 	// (a dword per trip, its four steps unrolled, the bytes as bit fields: see WideTrapChunk2)
 #pragma unroll 1
 	for (uint32_t w = 0; w < 4; ++w) {
@@ -134,6 +144,16 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 #pragma unroll
 		for (uint32_t k = 0; k < 4; ++k) {
 			const uint32_t c2n = HotLookup(k < 3 ? (x >> (8 * k + 8)) & 0xFFu : v.x & 0xFFu);   // the next byte's (behind the 16th: unused)
+			// the sample: the state IN FRONT of the drawn step -- the state whose row (or table line) the step looks up.  (Round 5
+			// took the state behind it: the state every string starts in is in front of a step and never behind one, so once it
+			// was outside the tier it stayed there -- 1.8 % of a URL batch's steps, every string leaving the rows with its first
+			// byte, and nothing to tell adapt() about it; tools/ranking_quality.py.)
+			if (CREDIT && sampled && w * 4 + k == sampleStep) {
+				const bool out = sid >= p.wide;
+				const unsigned long long m = __ballot(out);
+				if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+					atomicAdd(&p.visitCold[sid], uint32_t(__popcll(m)));   // (see above: the step's lanes outside the rows)
+			}
 			// the row's entry (a state without a row reads the escape row: "no row") ...
 			const uint32_t e = WideEntry<ZIP>(sid < p.wide ? sid : p.wide, K, c2);
 			uint32_t next = e;
@@ -142,12 +162,6 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 				asm volatile("" : "+v"(next));   // (the wait belongs in here: left to the join it is a vmcnt(0) every lane passes)
 			}
 			sid = next;
-			if (sampled && w * 4 + k == sampleStep) {
-				const bool out = sid >= p.wide;
-				const unsigned long long m = __ballot(out);
-				if (out && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-					atomicAdd(&p.visitCold[sid], uint32_t(__popcll(m)));   // (see above: the step's lanes outside the rows)
-			}
 			c2 = c2n;
 		}
 	}
@@ -160,7 +174,7 @@ __device__ __forceinline__ void WideTrapChunk(const ScanParams& p, uint8_t* lds,
 // - 4 % where 30 % are -- which is where this form of the kernel runs when the batch fills the chip -- and the ranking the
 // next adapt() took from its samples cost the two-strings form 8 % on dict_10k / k512; with "two chunks in a row before a
 // wave stops trying the rows" on top: the same.  Not kept.)
-template <bool N16, bool ZIP>
+template <bool N16, bool ZIP, bool CREDIT = true>
 __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, const WideLayout& W, const WideConst& K, const u32x4 v,
                                           uint32_t& st, uint32_t& cold, uint32_t sampleLane)
 {
@@ -179,7 +193,7 @@ __device__ __forceinline__ void WideChunk(const ScanParams& p, uint8_t* lds, con
 		st = WideEntry<ZIP>(st, K, c3);
 	}
 	if (st == p.wide)
-		WideTrapChunk<N16, ZIP>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
+		WideTrapChunk<N16, ZIP, CREDIT>(p, lds, W, K, v, st0, st, cold, sampleLane & 15u);
 }
 
 
@@ -221,6 +235,7 @@ __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t*
 		nth = uint32_t(__builtin_amdgcn_readfirstlane(int(nth)));
 	}
 	const bool sampled = (nth & 126u) == 0;
+	sampleStep = (((nth >> 7) + blockIdx.x * 0x632BE5ABu) * 0x9E3779B1u) >> 28;   // (drawn from the re-walk's and the block's number: see WideTrapChunk)
 	bool left = false;
 	// (a dword of each string per trip, its four steps unrolled: the bytes are bit fields of one register -- shifting the
 	// 16 bytes down by one in every step was 10 of the step's ~35 vector instructions, and four waves share a SIMD)
@@ -239,6 +254,14 @@ __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t*
 			const uint32_t bna = k < 3 ? (xa >> (8 * k + 8)) & 0xFFu : va.x & 0xFFu;
 			const uint32_t bnb = k < 3 ? (xb >> (8 * k + 8)) & 0xFFu : vb.x & 0xFFu;
 			const uint32_t c2an = HotLookup(bna), c2bn = HotLookup(bnb);
+			if (sampled && w * 4 + k == sampleStep) {   // (the states IN FRONT of the drawn step: see WideTrapChunk)
+				const uint32_t out = ia >= p.wide ? ia : ib;
+				const bool is = ia >= p.wide || ib >= p.wide;
+				const unsigned long long m = __ballot(is);
+				const uint32_t weight = uint32_t(__popcll(__ballot(ia >= p.wide)) + __popcll(__ballot(ib >= p.wide)));
+				if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
+					atomicAdd(&p.visitCold[out], weight);
+			}
 			const uint32_t ea = WideEntry<ZIP>(ia < p.wide ? ia : p.wide, K, c2a);
 			const uint32_t eb = WideEntry<ZIP>(ib < p.wide ? ib : p.wide, K, c2b);
 			uint32_t na = ea, nb = eb;
@@ -252,14 +275,6 @@ __device__ __forceinline__ uint32_t WideTrapChunk2(const ScanParams& p, uint8_t*
 			}
 			ia = na;
 			ib = nb;
-			if (sampled && w * 4 + k == sampleStep) {
-				const uint32_t out = ia >= p.wide ? ia : ib;
-				const bool is = ia >= p.wide || ib >= p.wide;
-				const unsigned long long m = __ballot(is);
-				const uint32_t weight = uint32_t(__popcll(__ballot(ia >= p.wide)) + __popcll(__ballot(ib >= p.wide)));
-				if (is && (threadIdx.x & 63) == uint32_t(__ffsll(m)) - 1u)
-					atomicAdd(&p.visitCold[out], weight);
-			}
 			c2a = c2an;
 			c2b = c2bn;
 		}
