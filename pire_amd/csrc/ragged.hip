@@ -944,7 +944,10 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 
 	PIRE_RCLK(clk, 2);
 	// ---- walk the current window
-	if (!WIDE && (threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))   // visit sample, as in the tiled kernel
+	// (the walks with actions on the dense rows keep round 2's visit sample -- the state a window STARTS in, one lane per
+	// iteration -- and the re-walks' own: their instantiations have no register left for the drawn byte's, below)
+	constexpr bool kDrawn = WIDE != 0 || !Act::kActive;
+	if (!kDrawn && (threadIdx.x & 63) == (iter & 63) && nb != 0 && !(p.flags & kDebugNoHist))
 		atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + S.hs, 1u);
 	if (p.flags & kDebugNoStep) {
 		// timing experiments: no walk at all
@@ -968,14 +971,15 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			// by launch although every string looks it up, tools/sampler_probe.py)
 			// -- so every wave starts its count somewhere else: ScanRaggedKernel)
 			const uint32_t sampleHash = iter * 0x9E3779B1u;
-			const bool sampleLaneHere = WIDE && (threadIdx.x & 63) == (sampleHash >> 26) && !(p.flags & kDebugNoHist);
+			const bool sampleLaneHere = kDrawn && (threadIdx.x & 63) == (sampleHash >> 26) && !(p.flags & kDebugNoHist);
+			const uint32_t lim = WIDE ? p.wide : p.hot;   // (S.hs == lim: the state has no row, S.cold is its id)
 			const uint32_t sampleAt = (sampleHash >> 19) & 127u, sampleChunk = sampleAt >> 4;   // wave-uniform
 			uint32_t sampleFrom = 0;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 				if (uint32_t(k) < full) {
-					if (WIDE != 0 && uint32_t(k) == sampleChunk)
-						sampleFrom = S.hs != p.wide ? S.hs : S.cold;
+					if (kDrawn && uint32_t(k) == sampleChunk)
+						sampleFrom = S.hs != lim ? S.hs : S.cold;
 					if constexpr (Act::kActive && WIDE != 0)
 						WideChunkAct<Act, WIDE == 3, false>(p, lds, L, W, K, cur[k], 16u, S.hs, S.cold, act, al, S.pos + 16u * k);
 					else if constexpr (Act::kActive)
@@ -986,8 +990,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 					else
 						StepChunk<0>(p, lds, L, cur[k], S.hs, S.cold, (iter * 8 + k) & 63);
 				}
-			if (WIDE != 0 && full == sampleChunk)
-				sampleFrom = S.hs != p.wide ? S.hs : S.cold;   // (the drawn byte lies in the lane's partial last chunk)
+			if (kDrawn && full == sampleChunk)
+				sampleFrom = S.hs != lim ? S.hs : S.cold;   // (the drawn byte lies in the lane's partial last chunk)
 			if (__any(tail != 0) && !(p.flags & kDebugNoPartial)) {
 				// all the partial last chunks of the wave in ONE pass: pick each lane's chunk, walk it with a snapshot
 				u32x4 v = cur[0];
@@ -1004,6 +1008,39 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 					WidePartial<WIDE >= 2, WIDE == 3>(p, K, v, tail, S.hs, S.cold);
 				else
 					StepPartial(p, lds, L, v, tail, S.hs, S.cold, (iter + 32) & 63);
+			}
+			if constexpr (WIDE == 0 && kDrawn) {
+				// The dense rows' sample, drawn like the wide walk's (above): the state in front of one byte of one lane's window,
+				// walked to exactly.  A state with a dense row counts there; any other is told to adapt() in the re-walks' units (a
+				// sample here stands for 8 192 lane-steps, one of theirs for 1 024; the re-walks keep their own sample of the state
+				// a chunk ends in -- it finds the heavy states outside the rows eight times sooner, and what it adds on top for
+				// some of them costs nothing but a row given a little early).  (Rounds 2-5: the state a window STARTS
+				// in, and of a chunk that left the rows the state it ENDS in if that has no row -- on a URL batch the first is the
+				// start state every time and the second misses every state the walk passes through on its way back into the rows:
+				// a state with 4.6 % of all lookups stood outside the 255 rows for good, 17 % of the steps there where 2 % need be;
+				// tools/ranking_quality.py ... dense.)
+				// (every fourth iteration, four times the weight: the dense walk's iteration is short, and a lane walking up to 15
+				// steps alone at its end was 6-8 % of it -- 2 140 -> 2 013 GB/s on set_a's URL batch when every iteration drew)
+				if (sampleLaneHere && sampleAt < nbl && (iter & 3u) == 0) {
+					u32x4 v = cur[0];
+#pragma unroll
+					for (int k = 1; k < 8; ++k)
+						if (sampleChunk == uint32_t(k))
+							v = cur[k];
+					uint32_t st = sampleFrom;
+#pragma unroll 1
+					for (uint32_t i = 0; i < (sampleAt & 15u); ++i) {
+						st = SlowStep(p, lds, L, st, v.x & 0xFFu);
+						v.x = __builtin_amdgcn_alignbit(v.y, v.x, 8);
+						v.y = __builtin_amdgcn_alignbit(v.z, v.y, 8);
+						v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
+						v.w >>= 8;
+					}
+					if (st < p.hot)
+						atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + st, 4u);
+					else
+						atomicAdd(&p.visitCold[st], 32u);   // (the trap signal stays the re-walks': one of 64 of them, TrapChunk)
+				}
 			}
 			if constexpr (WIDE != 0) {
 				if (sampleLaneHere && sampleAt < nbl) {

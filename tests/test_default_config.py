@@ -50,8 +50,10 @@ def test_host_entry_points_under_the_default_policy(pa, cfg, name):
     rng = np.random.RandomState(5)
     alphabet = b"abcdeaxHedInrTailhello w0123456789()- ABCXYZ@Qnet"
     strings = H.random_strings(rng, 3000, 300, alphabet)
+    # (every fifth string gets a witness: the walk leaves the know-nothing prior's rows often enough for a trigger of 8 sampled traps
+    # whatever lanes the samples fall on -- with 40 strings per witness it was a matter of which lane was looked at when)
     for w in [bytes.fromhex(h) for h in big["witnesses_hex"]]:
-        for k in rng.randint(0, len(strings), size=40):
+        for k in rng.randint(0, len(strings), size=600 // max(1, len(big["witnesses_hex"])) * 2):
             strings[k] = strings[k][: len(strings[k]) // 2] + w
     text, offs = H.pack(strings)
     want = o.run(text, offs, threads=4)

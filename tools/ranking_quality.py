@@ -10,6 +10,7 @@ from pire_amd import binding as pb
 from pire_amd import workloads as W
 
 name = sys.argv[1] if len(sys.argv) > 1 else "blacklist_1k"
+dense = len(sys.argv) > 2 and sys.argv[2] == "dense"   # the 255 dense rows under the ragged kernel instead of the wide tier
 entry = W.wide_set(name)
 blob = W.load_blob(entry["blob"])
 o = ob.OracleScanner(blob)
@@ -37,9 +38,9 @@ text = torch.as_tensor(np.ascontiguousarray(t1), device="cuda").repeat(rep).cont
 doffs = torch.as_tensor(offs.astype(np.int64), device="cuda")
 n = len(lens)
 idx = torch.empty(n, dtype=torch.int32, device="cuda"); fin = torch.empty(n, dtype=torch.uint8, device="cuda")
-pb.set_config(walk_variant=2, zip_variant=1, auto_adapt=1)
+pb.set_config(walk_variant=1 if dense else 2, zip_variant=1, auto_adapt=1, ragged_variant=1)
 t = pire_amd.Table(blob); t.upload()
-tier = t.info.wide_states
+tier = t.info.hot_states if dense else t.info.wide_states
 ideal = np.argsort(-v1)
 print(name, "tier", tier, "ideal ranking (other sample): outside %.4f" % (1 - v2[ideal[:tier]].sum() / v2.sum()))
 for k in range(8):
@@ -49,7 +50,7 @@ for k in range(8):
     orig_of_perm, _ = t.layout()
     inside = v2[orig_of_perm[:tier]].sum() / v2.sum()
     i2 = t.refresh_info()
-    print("after %d x (scan of %d URLs + adapt()): outside %.4f ; the library's own measure %.4f" % (k + 1, n, 1 - inside, i2.outside_wide_share))
+    print("after %d x (scan of %d URLs + adapt()): outside %.4f ; the library's own measure %.4f" % (k + 1, n, 1 - inside, i2.outside_dense_share if dense else i2.outside_wide_share))
     perm_of_orig = np.empty_like(orig_of_perm); perm_of_orig[orig_of_perm] = np.arange(len(orig_of_perm), dtype=orig_of_perm.dtype)
     out = [(v2[s0] / v2.sum(), int(s0), int(perm_of_orig[s0]), int(np.nonzero(ideal == s0)[0][0])) for s0 in np.argsort(-v2)[:3000] if perm_of_orig[s0] >= tier][:6]
     print("   heaviest states outside the tier (share of steps, state, its place in the library's ranking, in the ideal one):",
