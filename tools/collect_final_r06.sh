@@ -28,6 +28,9 @@ for f in counting_variants capture_variants half_final_variants counting_many_re
 cp $S/counting_kernel_stats.txt $P/r06_counting_kernel_stats.txt
 [ -s $S/actions_wide.jsonl ] && cp $S/actions_wide.jsonl $P/r06_actions_wide.jsonl
 [ -s $S/selftest_cost.txt ] && cp $S/selftest_cost.txt $P/r06_selftest_cost.txt
+[ -s $S/ranking_quality.txt ] && cp $S/ranking_quality.txt $P/r06_ranking_quality.txt
+[ -s $S/sampler_probe.txt ] && cp $S/sampler_probe.txt $P/r06_sampler_probe.txt
+[ -s $S/stress_dict_60.log ] && cp $S/stress_dict_60.log $P/r06_stress_dict_60.log
 [ -f $S/tsan_summary.txt ] && cat $S/tsan_pytest.log $S/tsan_summary.txt > $P/r06_tsan_gpu_summary.txt
 cp gpurun_out/final_r06.log $P/r06_final_run.log
 python tools/fill_design_tables.py

@@ -113,6 +113,11 @@ timeout 600 python tools/actions_wide_case.py 2>&1 | grep "^{" > $OUT/actions_wi
 timeout 200 python tools/pair_case.py 2>&1 | grep -v amdgpu.ids | tee $OUT/pair.log | cut -c1-200
 for st in slow_x300 slow_x400_utf8; do timeout 400 python bench.py --set $st --log2-strings 16 --len 4096 --steps 5 --warmup 2 --cpu-sample-log2 10 2>&1 | tail -1 | cut -c1-1500; done > $OUT/bench_slow_wide.jsonl; cut -c1-200 $OUT/bench_slow_wide.jsonl
 timeout 300 python tools/selftest_cost.py 2>&1 | grep "self-test" | tee $OUT/selftest_cost.txt | cut -c1-200
+echo "== what adapt() learns: the ranking against the best one (oracle's lookup counts), rounds of scan + adapt()"
+{ for a in "blacklist_1k" "blacklist_10k" "blacklist_1k dense"; do timeout 300 python tools/ranking_quality.py $a 2>&1 | grep "^after\|ideal"; done; } | cut -c1-200 | tee $OUT/ranking_quality.txt | grep "ideal\|after [18] x"
+timeout 300 python tools/sampler_probe.py 2>&1 | grep "^states\|round" | cut -c1-260 > $OUT/sampler_probe.txt; tail -2 $OUT/sampler_probe.txt
+echo "== random dictionaries through every kernel of the wide walk (tools/stress_dict.py, 60 seeds here; profiles/r06_stress_dict.log: 300)"
+timeout 900 python tools/stress_dict.py 400 460 2>&1 | grep -v amdgpu.ids | tail -2 | tee $OUT/stress_dict_60.log
 echo "== host-pointer mode"
 timeout 300 python tools/host_call_latency.py 2>&1 | grep -v amdgpu.ids | tee $OUT/host_call_latency.log | tail -8
 echo "== C++ shim and the pigrep example"
