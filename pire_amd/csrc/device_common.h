@@ -396,13 +396,30 @@ __device__ __forceinline__ void TrapChunk(const ScanParams& p, const uint8_t* ld
 	} else {
 		hs = p.hot;
 		cold = f;
-		// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64):
-		// un-sampled, the device-scope atomics of every trapped lane serialised on a few dozen addresses and
-		// cost 4x the whole kernel (measured: 0.80 -> 3.45 ms on set_a).
-		if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount)) {
-			atomicAdd(&p.visitCold[f], 1u);
-			atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + kLdsTrapSlot, 1u);
+	}
+	// Rare path: tell pire_hip_table_adapt() which rows deserve LDS.  SAMPLED (one rotating lane of 64): un-sampled, the
+	// device-scope atomics of every trapped lane serialised on a few dozen addresses and cost 4x the whole kernel (measured:
+	// 0.80 -> 3.45 ms on set_a).  WHAT is told (round 6): the state IN FRONT of one step of the chunk, the step
+	// drawn from the chunk's place and the block's number, walked to exactly -- if it has no dense row.  (Rounds 1-5 told the
+	// state the chunk ENDS in, if that has none: a state the walk passes through on its way back into the rows was never
+	// seen, nor one that lives at a fixed offset of every record -- 4.0 % of the lookups of URL records outside the 255 rows
+	// where 0.5 % need be, tools/ranking_quality_records.py.)  The trap signal counts chunks that end outside the rows, as before.
+	if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount)) {
+		const uint32_t step = ((sampleLane + blockIdx.x * 0x632BE5ABu) * 0x9E3779B1u) >> 28;
+		uint32_t s = st0;
+		u32x4 w = v;
+#pragma unroll 1
+		for (uint32_t i = 0; i < step; ++i) {
+			s = SlowStep(p, lds, L, s, w.x & 0xFF);
+			w.x = __builtin_amdgcn_alignbit(w.y, w.x, 8);
+			w.y = __builtin_amdgcn_alignbit(w.z, w.y, 8);
+			w.z = __builtin_amdgcn_alignbit(w.w, w.z, 8);
+			w.w >>= 8;
 		}
+		if (s >= p.hot)
+			atomicAdd(&p.visitCold[s], 1u);
+		if (f >= p.hot)
+			atomicAdd(reinterpret_cast<uint32_t*>(const_cast<uint8_t*>(lds) + L.histOff) + kLdsTrapSlot, 1u);
 	}
 }
 

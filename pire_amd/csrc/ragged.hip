@@ -100,8 +100,23 @@ __device__ __forceinline__ void StepPartial(const ScanParams& p, const uint8_t* 
 		} else {
 			hs = p.hot;
 			cold = f;
-			if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount))
-				atomicAdd(&p.visitCold[f], 1u);
+		}
+		// (the sample: the state in front of a drawn one of the chunk's `count` steps, as TrapChunk's -- not the state behind
+		// the last one: that is the state the STRING ends in, which nothing looks up; rounds 2-5 gave rows to those)
+		if ((threadIdx.x & 63) == sampleLane && !(p.flags & kDebugNoColdCount)) {
+			const uint32_t step = (((sampleLane + blockIdx.x * 0x632BE5ABu) * 0x9E3779B1u) >> 28) % count;
+			uint32_t s = st0;
+			u32x4 w = v;
+#pragma unroll 1
+			for (uint32_t i = 0; i < step; ++i) {
+				s = SlowStep(p, lds, L, s, w.x & 0xFF);
+				w.x = __builtin_amdgcn_alignbit(w.y, w.x, 8);
+				w.y = __builtin_amdgcn_alignbit(w.z, w.y, 8);
+				w.z = __builtin_amdgcn_alignbit(w.w, w.z, 8);
+				w.w >>= 8;
+			}
+			if (s >= p.hot)
+				atomicAdd(&p.visitCold[s], 1u);
 		}
 	}
 }
@@ -913,9 +928,13 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 	const uint32_t nIdx = cont ? S.sIdx : S.sIdxN;
 	const bool nBusy = cont || takeNew;
 	const bool nLoad = nBusy && nEnd > nPos && nPos + 128 <= safeEnd;
-	// unconditional (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
-	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives
-	if (!(p.flags & kDebugNoRefill)) {
+	// unconditional PER LANE (idle lanes fetch a harmless valid line): a load under a per-lane condition could be turned into
+	// load-to-a-copy + select by the compiler, and the select would read the register before the data arrives.  But not when
+	// NO lane has a window to fetch (round 6): that is the wave's last iteration -- nothing busy, nothing pending --, and what it
+	// requested was still on its way when the kernel's epilogue took the registers (lesson 29; the waits on the way out stay,
+	// but hipcc moved the epilogue's first vector instruction, `tid << 2`, in front of one of them in the dense prefix
+	// instantiation: a fault in two runs of five of tests/test_random_scanners.py).  Nothing requested, nothing on its way.
+	if (!(p.flags & kDebugNoRefill) && __any(nLoad)) {
 		if constexpr (Act::kGroupLoads)
 			IssueTileGroup(nxt, nLoad ? nPos : reinterpret_cast<uint64_t>(p.hotRows), threadIdx.x & 63);
 		else
@@ -1011,10 +1030,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 			}
 			if constexpr (WIDE == 0 && kDrawn) {
 				// The dense rows' sample, drawn like the wide walk's (above): the state in front of one byte of one lane's window,
-				// walked to exactly.  A state with a dense row counts there; any other is told to adapt() in the re-walks' units (a
-				// sample here stands for 8 192 lane-steps, one of theirs for 1 024; the re-walks keep their own sample of the state
-				// a chunk ends in -- it finds the heavy states outside the rows eight times sooner, and what it adds on top for
-				// some of them costs nothing but a row given a little early).  (Rounds 2-5: the state a window STARTS
+				// walked to exactly, if it has a dense row; which states are looked up WITHOUT one the re-walks say, fairly too since
+				// round 6 (device_common.h TrapChunk), one sample per 1 024 lane-steps of theirs.  (Rounds 2-5: the state a window STARTS
 				// in, and of a chunk that left the rows the state it ENDS in if that has no row -- on a URL batch the first is the
 				// start state every time and the second misses every state the walk passes through on its way back into the rows:
 				// a state with 4.6 % of all lookups stood outside the 255 rows for good, 17 % of the steps there where 2 % need be;
@@ -1036,10 +1053,8 @@ __device__ __forceinline__ bool RaggedPhase(const ScanParams& p, uint8_t* lds, c
 						v.z = __builtin_amdgcn_alignbit(v.w, v.z, 8);
 						v.w >>= 8;
 					}
-					if (st < p.hot)
+					if (st < p.hot)   // (a state without a row: the re-walks say which, device_common.h TrapChunk)
 						atomicAdd(reinterpret_cast<uint32_t*>(lds + L.histOff) + st, 4u);
-					else
-						atomicAdd(&p.visitCold[st], 32u);   // (the trap signal stays the re-walks': one of 64 of them, TrapChunk)
 				}
 			}
 			if constexpr (WIDE != 0) {

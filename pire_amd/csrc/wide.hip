@@ -168,6 +168,9 @@ __global__ __launch_bounds__(1024, 4) void ScanWideKernel(ScanParams p)
 	}
 	WideWaitTile<0>(a);
 	WideWaitTile<0>(b);
+	// (for the build's audit, which follows every way out of the task loop until all loads are waited for: nothing is on its way
+	// here -- the loops above wait for what they request before they are left -- and this says so where the walker can see it)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	FlushWide(p, lds, W);
 }
 
@@ -256,6 +259,9 @@ __global__ __launch_bounds__(1024, 4) void ScanWide2Kernel(ScanParams p)
 		Finish(p, lds, L, sA, true, enda);
 		Finish(p, lds, L, sB, true, endb);
 	}
+	// (for the build's audit, which follows every way out of the task loop until all loads are waited for: nothing is on its way
+	// here -- the loops above wait for what they request before they are left -- and this says so where the walker can see it)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	FlushWide(p, lds, W);
 }
 

@@ -146,7 +146,9 @@ def test_inflight_register_check_follows_the_ways_out_of_the_window_loop():
 def test_the_exit_check_sees_round_5s_wide_kernel_and_is_quiet_on_the_product():
     """check_exits on real ISA: the form of ScanWideKernel that round 5 shipped (kept behind PIRE_EXP == 2 for this test and for
     test_early_out_between_chained_tasks) waited for a tile behind the loop, where hipcc had copied the slot -- reported; the
-    product's kernels are clean (the build demands it: build_audit.py)."""
+    product's kernels are clean (the build demands it: build_audit.py).  And the walker must look at the WINDOW loop: the
+    block-wide table copy in front of it is a loop of eight dwordx4 loads too (the compiler's own), and until round 6 that was
+    the loop it took in the kernels where it is the shorter one -- a fault of the dense prefix instantiation went unseen."""
     import subprocess
 
     mod = _inflight()
@@ -157,7 +159,7 @@ def test_the_exit_check_sees_round_5s_wide_kernel_and_is_quiet_on_the_product():
     for name, body in mod.kernels(asm):
         if "ScanWideKernel" in name:
             seen += 1
-            assert mod.check_exits(body), name
+            assert mod.check_exits(body, outermost=False), name   # (the ways out of the INNER tile loop: build_audit.py INNER_EXITS)
     assert seen >= 3
 
 

@@ -601,7 +601,9 @@ def test_auto_adapt_reranks_at_a_launch_boundary(pa, torch_cuda, name, cfg):
             assert 1 <= info.adaptations <= 3, info.adaptations
             assert rows_after != rows_before
             t.adapt()                                # reads the counters of the launches since the last re-ranking
-            assert t.info.last_trap_samples * 20 < info.last_trap_samples + 20   # the traps have collapsed
+            # the traps have collapsed (counts of a few dozen since round 6: a sample is the state in front of ONE drawn step of a
+            # re-walked chunk, if that has no row -- not every re-walked chunk that ends outside the rows)
+            assert t.info.last_trap_samples * 8 < info.last_trap_samples + 20
         else:
             assert info.adaptations == 0 and rows_after == rows_before, (policy, host_calls)
         gi, gf, cnt = dev_run_strided(torch, t, d)

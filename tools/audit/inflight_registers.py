@@ -111,7 +111,9 @@ def check(body):
         target = labels.get(m.group(1) or m.group(2))
         if target is None or target > i:
             continue
-        n = sum(1 for t in code[target:i] if t.startswith("global_load_dwordx4"))
+        # (the loads issued from INLINE ASM: the block-wide table copy in front of the window loop is a loop of eight dwordx4 loads
+        # too -- the compiler's own --, and round 6 found the walker looking at that one in the kernels where it is the shorter)
+        n = sum(1 for j in range(target, i) if code[j].startswith("global_load_dwordx4") and from_asm[j])
         if n >= 8 and (best is None or i - target < best[1] - best[0]):
             best = (target, i)
     if best is None:
@@ -122,14 +124,20 @@ def check(body):
     return sorted(set(reports))
 
 
-def check_exits(body):
+def check_exits(body, outermost=True):
     """Round 6 (lessons 24 and 29): what happens to the tile registers on the ways OUT of the window loop.  A load
     issued from inline asm in the loop's last trip is still on its way when the loop is left; behind the loop the registers are
     somebody else's, and whatever names one of them before an `s_waitcnt vmcnt(0)` reads data that has not arrived or is
     overwritten when it does.  For every exit edge of the window loop (a branch out of it, the fall-through behind its back
     edge) the code is followed -- both arms of every branch, up to 4 000 instructions -- until it waits for all loads
     (s_waitcnt vmcnt(0)) or ends; an instruction that names a register any asm load of the loop writes, met before that, is
-    reported.  [(line number, text)], or None when the kernel has no window loop."""
+    reported.  [(line number, text)], or None when the kernel has no window loop.
+    WHICH loop: by default the OUTERMOST back edge around the asm loads -- behind it lies the kernel's epilogue, where the two
+    faults of round 6 were (the ragged kernel's counter flush; hipcc had moved its first instruction in front of a wait that was
+    there).  outermost=False: the innermost one -- the ways out of a tile loop INSIDE a task loop, where round 5's ScanWideKernel
+    waited behind the loop; in layout order that also follows blocks of the outer loop that the compiler laid out behind the
+    inner back edge and that name tiles waited for long ago, so the build asks for it only where it is known to be quiet
+    (build_audit.py INNER_EXITS)."""
     code, labels, from_asm = [], {}, []
     in_asm = False
     has_markers = any("#ASMSTART" in line for line in body)
@@ -152,8 +160,10 @@ def check_exits(body):
         target = labels.get(m.group(1) or m.group(2))
         if target is None or target > i:
             continue
-        n = sum(1 for t in code[target:i] if t.startswith("global_load_dwordx4"))
-        if n >= 8 and (best is None or i - target < best[1] - best[0]):
+        # (the loads issued from INLINE ASM: the block-wide table copy in front of the window loop is a loop of eight dwordx4 loads
+        # too -- the compiler's own --, and round 6 found the walker looking at that one in the kernels where it is the shorter)
+        n = sum(1 for j in range(target, i) if code[j].startswith("global_load_dwordx4") and from_asm[j])
+        if n >= 8 and (best is None or ((i - target > best[1] - best[0]) if outermost else (i - target < best[1] - best[0]))):
             best = (target, i)
     if best is None:
         return None
@@ -236,7 +246,7 @@ def main():
             print("    line %5d: %s" % (i, text))
         bad += len(rep)
         ex = check_exits(body) or []
-        print("%-110s on the ways out of the window loop: %d reports" % ("", len(ex)))
+        print("%-110s on the ways out of the (outermost) window loop: %d reports" % ("", len(ex)))
         for i, text in ex[:12]:
             print("    line %5d: %s" % (i, text))
         bad += len(ex)
