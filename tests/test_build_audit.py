@@ -142,6 +142,26 @@ def test_inflight_register_check_follows_the_ways_out_of_the_window_loop():
     assert mod.check_exits(loop + nxt[:4] + ["\ts_waitcnt vmcnt(8)", "\tv_mov_b32_e32 v60, v28", "\ts_endpgm", ".LBB0_3:", "\ts_endpgm"])
 
 
+def test_the_walker_takes_the_loop_with_the_asm_loads_not_the_table_copy():
+    """Round 6: "the innermost loop with eight dwordx4 loads" was the block-wide table copy (the compiler's own loads) in the
+    kernels where that is shorter than the window loop -- the walker looked at the wrong loop and a fault of the dense prefix
+    instantiation went unseen.  A listing with both: the copy loop first, then a window loop whose loads stand between the asm
+    markers and whose way out names a tile register before any wait."""
+    copy = [".LBB0_1:"] + ["\tglobal_load_dwordx4 v[%d:%d], v[90:91], off" % (100 + 4 * j, 103 + 4 * j) for j in range(8)]
+    copy += ["\ts_waitcnt vmcnt(0)", "\tds_write_b128 v99, v[100:103]", "\ts_cbranch_scc1 .LBB0_1"]
+    window = [".LBB0_2:", "\t;;#ASMSTART"] + ["\tglobal_load_dwordx4 v[%d:%d], v[40:41], off" % (4 * j, 4 * j + 3) for j in range(8)] + ["\t;;#ASMEND"]
+    window += ["\tv_add_u32_e32 v50, v50, v51", "\tv_add_u32_e32 v52, v50, v51", "\tv_add_u32_e32 v53, v50, v51", "\tv_add_u32_e32 v54, v50, v51",
+               "\ts_cbranch_scc1 .LBB0_2"]
+    tail = ["\tv_mov_b32_e32 v3, 0", "\ts_waitcnt vmcnt(0)", "\ts_endpgm"]
+    mod = _inflight()
+    rep = mod.check_exits(copy + window + tail)
+    assert rep and "v_mov_b32_e32 v3, 0" in rep[0][1]
+    assert mod.check_exits(copy + window + ["\ts_waitcnt vmcnt(0)"] + tail) == []
+    # (and the in-loop check: a tile register named between its load and a wait, in the WINDOW loop)
+    bad = window[:-1] + ["\tv_mov_b32_e32 v60, v28", "\ts_waitcnt vmcnt(0)", "\ts_cbranch_scc1 .LBB0_2"]
+    assert mod.check(copy + bad + tail)
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_the_exit_check_sees_round_5s_wide_kernel_and_is_quiet_on_the_product():
     """check_exits on real ISA: the form of ScanWideKernel that round 5 shipped (kept behind PIRE_EXP == 2 for this test and for
